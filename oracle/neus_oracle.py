@@ -1,0 +1,373 @@
+"""CPU ORACLE for the NRHints volumetric-rendering hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain PyTorch-CPU tensor arithmetic, what the reference's
+``NeuSHintRenderer.forward`` computes.  It is the checker the HIP
+path is compared against and the timed leg of ``bench.py``'s ``cpu_baseline``.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg
+may import it; nothing under ``nrhints_amd/`` does.  It is not a fallback.
+
+Parity pin: every function below is checked in ``tests/test_oracle_golden.py``
+against fixtures produced by importing the reference itself in the build
+container (``tests/golden/make_golden.py``); the reference ships no tests or
+golden vectors of its own.
+
+Two evaluation strategies, same mathematics:
+
+* ``mode="as_written"`` - the reference's call pattern: 13 full SDF-net forwards
+  per render (feature head always evaluated), d(sdf)/dx by autograd.  This is
+  what the CPU baseline times.
+* ``mode="minimal"``   - one SDF evaluation per point, analytic reverse chain for
+  the gradient (what the HIP kernels do).  Used to show the restructuring is
+  value-preserving.
+
+All citations are ``path:line`` under /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SPEC_ROUGHNESS = (0.02, 0.05, 0.13, 0.34)  # models/neus_hint_model.py:161
+
+
+# --------------------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------------------
+def fold_weight_norm(g: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """W = g * v / ||v||_2 per output row (nn.utils.weight_norm, dim=0; fields/sdf_field.py:81-82)."""
+    return v * (g / v.norm(dim=1, keepdim=True))
+
+
+@dataclass
+class OracleParams:
+    sdf_w: List[torch.Tensor]      # 8 trunk layers [out,in]
+    sdf_b: List[torch.Tensor]
+    sdf_head_w: torch.Tensor       # [1,256]
+    sdf_head_b: torch.Tensor
+    feat_w: torch.Tensor           # [256,256]
+    feat_b: torch.Tensor
+    col_w: List[torch.Tensor]      # 5 layers
+    col_b: List[torch.Tensor]
+    variance: torch.Tensor         # scalar
+
+
+def params_from_state(state: Dict[str, np.ndarray], dtype=torch.float32) -> OracleParams:
+    """Dense (weight-norm folded) parameters from a reference-layout state dict (SURVEY.md §5 key contract)."""
+    t = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in state.items()}
+
+    def lin(prefix):
+        return fold_weight_norm(t[prefix + ".weight_g"], t[prefix + ".weight_v"]), t[prefix + ".bias"]
+
+    sw, sb = zip(*[lin(f"sdf_network.lin{i}") for i in range(8)])
+    hw, hb = lin("sdf_network.out_sdf")
+    fw, fb = lin("sdf_network.out_feat")
+    cw, cb = zip(*[lin(f"color_network.lin{i}") for i in range(5)])
+    return OracleParams(list(sw), list(sb), hw, hb, fw, fb, list(cw), list(cb), t["deviation_network.variance"])
+
+
+# --------------------------------------------------------------------------------------
+# fields
+# --------------------------------------------------------------------------------------
+def nerf_encode(x: torch.Tensor, n_freq: int) -> torch.Tensor:
+    """[x, sin(x_d 2^k) (d-major, k-minor), sin(x_d 2^k + pi/2)]   (fields/encodings.py:155-176)."""
+    freqs = 2.0 ** torch.linspace(0.0, n_freq - 1, n_freq, dtype=x.dtype)
+    s = (x[..., None] * freqs).reshape(*x.shape[:-1], -1)
+    return torch.cat([x, torch.sin(torch.cat([s, s + math.pi / 2.0], dim=-1))], dim=-1)
+
+
+def softplus100(x: torch.Tensor) -> torch.Tensor:
+    """nn.Softplus(beta=100), threshold 20 (fields/sdf_field.py:104)."""
+    return F.softplus(x, beta=100)
+
+
+def sdf_forward(p: OracleParams, pts: torch.Tensor, want_feat: bool = True):
+    """SDF trunk + heads (fields/sdf_field.py:106-123).  Returns (sdf [P,1], feat [P,256] or None)."""
+    e = nerf_encode(pts * 3.0, 6)
+    h = e
+    for l in range(8):
+        if l == 4:
+            h = torch.cat([h, e], dim=1) / math.sqrt(2.0)
+        h = softplus100(F.linear(h, p.sdf_w[l], p.sdf_b[l]))
+    sdf = F.linear(h, p.sdf_head_w, p.sdf_head_b) / 3.0
+    feat = F.linear(h, p.feat_w, p.feat_b) if want_feat else None
+    return sdf, feat
+
+
+def sdf_gradient_autograd(p: OracleParams, pts: torch.Tensor) -> torch.Tensor:
+    """d(sdf)/d(pts) the way the reference gets it: a full forward under enable_grad and one
+    reverse sweep (fields/sdf_field.py:136-148)."""
+    x = pts.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        y, _ = sdf_forward(p, x, want_feat=True)  # .sdf() runs the whole forward incl. out_feat (:125-126)
+        (g,) = torch.autograd.grad(y, x, torch.ones_like(y))
+    return g.detach()
+
+
+def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: bool = True):
+    """One forward that keeps sigma'(z_l) = sigmoid(100 z_l), then the reverse chain by hand.
+    Mathematically identical to ``sdf_gradient_autograd``; this is the structure of the HIP kernel."""
+    x3 = pts * 3.0
+    e = nerf_encode(x3, 6)
+    h = e
+    dact = []
+    for l in range(8):
+        if l == 4:
+            h = torch.cat([h, e], dim=1) / math.sqrt(2.0)
+        z = F.linear(h, p.sdf_w[l], p.sdf_b[l])
+        t = z * 100.0
+        ez = torch.exp(t)
+        dact.append(torch.where(t > 20.0, torch.ones_like(t), ez / (ez + 1.0)))  # softplus_backward
+        h = softplus100(z)
+    sdf = F.linear(h, p.sdf_head_w, p.sdf_head_b) / 3.0
+    feat = F.linear(h, p.feat_w, p.feat_b) if want_feat else None
+    g = (p.sdf_head_w / 3.0).expand(pts.shape[0], -1)
+    ge_skip = None
+    for l in range(7, -1, -1):
+        g = (g * dact[l]) @ p.sdf_w[l]
+        if l == 4:
+            g = g / math.sqrt(2.0)
+            ge_skip = g[:, 217:]
+            g = g[:, :217]
+    ge = g + ge_skip  # gradient w.r.t. the 39-d embedding
+    freqs = 2.0 ** torch.linspace(0.0, 5.0, 6, dtype=pts.dtype)
+    s = (x3[..., None] * freqs)                       # [P,3,6]
+    gs = ge[:, 3:21].reshape(-1, 3, 6)
+    gc = ge[:, 21:39].reshape(-1, 3, 6)
+    dx3 = ge[:, 0:3] + ((gs * torch.cos(s) + gc * torch.cos(s + math.pi / 2.0)) * freqs).sum(-1)
+    return sdf, feat, dx3 * 3.0
+
+
+def color_forward(p: OracleParams, pts, normals, view, feat, pls, vis, cue) -> torch.Tensor:
+    """Reflectance MLP, input order [pts, enc4(view), normals, enc4(pl), feat, enc4(vis), enc4(cue)]
+    (fields/reflectance_network.py:68-96)."""
+    x = torch.cat([pts, nerf_encode(view, 4), normals, nerf_encode(pls, 4), feat,
+                   nerf_encode(vis, 4), nerf_encode(cue, 4)], dim=-1)
+    for l in range(5):
+        x = F.linear(x, p.col_w[l], p.col_b[l])
+        if l < 4:
+            x = torch.relu(x)
+    return torch.sigmoid(x)
+
+
+# --------------------------------------------------------------------------------------
+# sampler
+# --------------------------------------------------------------------------------------
+def excl_cumprod_one_minus(alpha: torch.Tensor) -> torch.Tensor:
+    """prod_{k<j}(1 - alpha_k + 1e-7)  (models/neus_hint_model.py:311-312, 429-430, 521-523)."""
+    ones = torch.ones_like(alpha[:, :1])
+    return torch.cumprod(torch.cat([ones, 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
+
+
+def sample_pdf_det(bins: torch.Tensor, weights: torch.Tensor, n: int) -> torch.Tensor:
+    """Deterministic inverse-CDF sampling (models/neus_hint_model.py:21-65 with det=True)."""
+    w = weights + 1e-5
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], dim=-1)
+    u = torch.linspace(0.0, 1.0, n).to(bins.dtype).expand(bins.shape[0], n).contiguous()  # fp32 linspace as in :31
+    ind = torch.searchsorted(cdf, u, right=True)
+    lo = (ind - 1).clamp(min=0)
+    hi = ind.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    b_lo, b_hi = torch.gather(bins, 1, lo), torch.gather(bins, 1, hi)
+    den = c_hi - c_lo
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    return b_lo + (u - c_lo) / den * (b_hi - b_lo)
+
+
+def up_sample(o, d, z, sdf, n_new: int, inv_s: float) -> torch.Tensor:
+    """One importance step at fixed sharpness (models/neus_hint_model.py:270-315)."""
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    r = torch.linalg.norm(pts, dim=-1)
+    inside = (r[:, :-1] < 1.0) | (r[:, 1:] < 1.0)
+    s0, s1 = sdf[:, :-1], sdf[:, 1:]
+    z0, z1 = z[:, :-1], z[:, 1:]
+    mid = (s0 + s1) * 0.5
+    cos = (s1 - s0) / (z1 - z0 + 1e-5)
+    prev = torch.cat([torch.zeros_like(cos[:, :1]), cos[:, :-1]], dim=-1)
+    cos = torch.minimum(prev, cos).clip(-1e3, 0.0) * inside
+    dist = z1 - z0
+    c_prev = torch.sigmoid((mid - cos * dist * 0.5) * inv_s)
+    c_next = torch.sigmoid((mid + cos * dist * 0.5) * inv_s)
+    alpha = (c_prev - c_next + 1e-5) / (c_prev + 1e-5)
+    w = alpha * excl_cumprod_one_minus(alpha)
+    return sample_pdf_det(z, w, n_new)
+
+
+def merge_sorted(z, z_new, sdf=None, sdf_new=None):
+    """Concatenate + sort z, carrying the SDF values along (models/neus_hint_model.py:317-331)."""
+    zc, idx = torch.sort(torch.cat([z, z_new], dim=-1), dim=-1)
+    if sdf is None:
+        return zc, None
+    return zc, torch.gather(torch.cat([sdf, sdf_new], dim=-1), 1, idx)
+
+
+def hierarchical_z(p: OracleParams, o, d, z, n_steps: int = 4, n_new: int = 16, full_forward: bool = True):
+    """Coarse SDF + 4 x (up_sample, merge) (models/neus_hint_model.py:696-713 and :397-412)."""
+    n = o.shape[0]
+    # the reference's .sdf() always pays for the feature head too (fields/sdf_field.py:125-126);
+    # full_forward=False skips it (value-identical, what the HIP sampler does)
+    sdf = sdf_forward(p, (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3), full_forward)[0].reshape(n, -1)
+    for i in range(n_steps):
+        zn = up_sample(o, d, z, sdf, n_new, 64.0 * 2 ** i)
+        if i + 1 < n_steps:
+            sn = sdf_forward(p, (o[:, None, :] + d[:, None, :] * zn[..., None]).reshape(-1, 3), full_forward)[0]
+            z, sdf = merge_sorted(z, zn, sdf, sn.reshape(n, -1))
+        else:
+            z, _ = merge_sorted(z, zn)
+    return z
+
+
+# --------------------------------------------------------------------------------------
+# alpha / hints
+# --------------------------------------------------------------------------------------
+def inv_s_of(p: OracleParams) -> torch.Tensor:
+    """exp(10 variance) clipped to [1e-6, 1e6] (models/neus_hint_model.py:110, 337)."""
+    # the reference multiplies a float32 ones([P,1]) by the 0-dim exp(10 v): the product is float32 even
+    # when the module was cast to float64 - kept so the fp64 goldens match to rounding.
+    return torch.exp(p.variance * 10.0).float().to(p.variance.dtype).clip(1e-6, 1e6)
+
+
+def alpha_from(sdf, grad, dirs, dists, inv_s, cos_anneal: float):
+    """SDF -> alpha (models/neus_hint_model.py:339-356). sdf [P,1], grad/dirs [P,3], dists [P,1]."""
+    true_cos = (dirs * grad).sum(-1, keepdim=True)
+    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + F.relu(-true_cos) * cos_anneal)
+    nxt = sdf + iter_cos * dists * 0.5
+    prv = sdf - iter_cos * dists * 0.5
+    c_prev, c_next = torch.sigmoid(prv * inv_s), torch.sigmoid(nxt * inv_s)
+    return ((c_prev - c_next + 1e-5) / (c_prev + 1e-5)).clip(0.0, 1.0)
+
+
+def _sdf_and_grad(p, pts, mode, want_feat):
+    if mode == "as_written":
+        sdf, feat = sdf_forward(p, pts, True)               # render_core :504 / get_alpha :335
+        sdf2, _ = sdf_forward(p, pts, True)                 # get_alpha's own forward (:335)
+        grad = sdf_gradient_autograd(p, pts)                # :336 -> third forward + reverse
+        return sdf2, feat, grad
+    sdf, feat, grad = sdf_forward_grad_analytic(p, pts, want_feat)
+    return sdf, feat, grad
+
+
+def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=None, mode="minimal"):
+    """Shadow ray light -> hit point, transmittance before the last sample
+    (models/neus_hint_model.py:373-432)."""
+    n = pls.shape[0]
+    dvec = hit - pls
+    L = torch.linalg.norm(dvec, dim=-1, keepdim=True)
+    ds = dvec / L
+    z = torch.linspace(0.0, 1.0, 64).to(pls.dtype)[None, :] * L * (1.0 - offset)
+    if t_rand is not None:  # stratified jitter in training (:388-395)
+        mids = 0.5 * (z[:, 1:] + z[:, :-1])
+        upper = torch.cat([mids, z[:, -1:]], -1)
+        lower = torch.cat([z[:, :1], mids], -1)
+        z = lower + (upper - lower) * t_rand
+    z = hierarchical_z(p, pls, ds, z, full_forward=(mode == "as_written"))
+    dists = torch.cat([z[:, 1:] - z[:, :-1], (L / 64.0).expand(n, 1)], dim=-1)
+    mid = z + dists * 0.5
+    pts = (pls[:, None, :] + ds[:, None, :] * mid[..., None]).reshape(-1, 3)
+    dirs = ds[:, None, :].expand(n, 128, 3).reshape(-1, 3)
+    if mode == "as_written":
+        sdf, _ = sdf_forward(p, pts, True)
+        grad = sdf_gradient_autograd(p, pts)
+    else:
+        sdf, _, grad = sdf_forward_grad_analytic(p, pts, False)
+    alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s_of(p), cos_anneal).reshape(n, 128)
+    return excl_cumprod_one_minus(alpha)[:, -1:]
+
+
+def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
+    """Cook-Torrance cue for the 4 roughness values (models/neus_hint_model.py:590-615)."""
+    l = F.normalize(pls - hit, dim=-1)
+    v = F.normalize(-d, dim=-1)
+    h = F.normalize(l + v, dim=-1)
+    ndl = (hit_normal * l).sum(-1).clip(0.0, 1.0)
+    ndv = (hit_normal * v).sum(-1).clip(0.0, 1.0)
+    ndh = (hit_normal * h).sum(-1).clip(0.0, 1.0)
+    hdv = (h * v).sum(-1).clip(0.0, 1.0)
+    ndh2 = torch.pow(ndh, 2)
+    out = []
+    for rough in SPEC_ROUGHNESS:
+        k = (rough + 1.0) * (rough + 1.0) / 8.0
+        g = ndv / (ndv * (1.0 - k) + k) * (ndl / (ndl * (1.0 - k) + k))
+        a2 = rough * rough
+        ndf = a2 / (math.pi * torch.pow(ndh2 * (a2 - 1.0) + 1.0, 2))
+        f = 0.04 + 0.96 * torch.pow(1.0 - hdv, 5)
+        out.append(ndf * g * f / (4.0 * ndv + 1e-3))
+    return torch.stack(out, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# the renderer
+# --------------------------------------------------------------------------------------
+def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is_training=False,
+                   global_step=0, anneal_end=50_000, t_rand_primary=None, t_rand_shadow=None,
+                   mode="minimal", keep_intermediates=False) -> Dict[str, torch.Tensor]:
+    """``NeuSHintRenderer.forward`` with the default nr-hints config
+    (models/neus_hint_model.py:653-751 -> render_core :475-651)."""
+    n = o.shape[0]
+    dt = o.dtype
+    cos_anneal = 1.0
+    if is_training and anneal_end > 0:
+        cos_anneal = min(1.0, global_step / anneal_end)       # :669-671
+    sample_dist = 2.0 / 64                                     # :673
+    z = near + (far - near) * torch.linspace(0.0, 1.0, 64).to(dt)[None, :]
+    if is_training:
+        z = z + (t_rand_primary - 0.5) * 2.0 / 64              # :681-683
+    with torch.no_grad():
+        z = hierarchical_z(p, o, d, z, full_forward=(mode == "as_written"))  # :696-713
+    # ---- render_core ----
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=dt)], dim=-1)
+    mid = z + dists * 0.5
+    pts = (o[:, None, :] + d[:, None, :] * mid[..., None]).reshape(-1, 3)
+    dirs = d[:, None, :].expand(n, 128, 3).reshape(-1, 3)
+    pls = pl[:, None, :].expand(n, 128, 3).reshape(-1, 3)
+    sdf, feat, grad = _sdf_and_grad(p, pts, mode, True)
+    inv_s = inv_s_of(p)
+    alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, 128)
+    radius = torch.linalg.norm(pts, dim=-1).reshape(n, 128)
+    inside = (radius < 1.0).to(dt)
+    weights = alpha * excl_cumprod_one_minus(alpha)            # :521-523
+    wsum = weights.sum(-1, keepdim=True)
+    depth = (mid * weights).sum(-1, keepdim=True)              # :532
+    hit = o + d * depth                                        # :533
+    vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode)  # :546-551
+    n_hat = F.normalize(grad, dim=-1)                          # :584
+    hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
+    cue = specular_cue(hit_n, pl, hit, d)                      # :590-615
+    vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
+    cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
+    col = color_forward(p, pts, n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :626
+    rgb = (col * weights[..., None]).sum(1)
+    if background_rgb is not None:
+        rgb = rgb + background_rgb * (1.0 - wsum)              # :635-637
+    out = dict(rgb=rgb, depth=depth, weights=weights, s_val=(1.0 / inv_s).expand(n, 128),
+               inside_sphere=inside, relax_inside_sphere=inside,            # :745 (quirk kept)
+               analytic_normals=grad.reshape(n, 128, 3),
+               normalized_analytic_normals=n_hat.reshape(n, 128, 3),
+               visibilities=vis, specular_cue=cue_s.reshape(n, 128, 4))
+    if keep_intermediates:
+        out.update(z_vals=z, mid_z=mid, sdf=sdf.reshape(n, 128), alpha=alpha, hit=hit, hit_normal=hit_n,
+                   sampled_color=col, feat=feat)
+    return out
+
+
+def render_chunked(p, o, d, pl, near, far, chunk=512, **kw):
+    """The reference's eval loop shape: 512-ray chunks (models/neus_hint_model.py:212,
+    pipelines/base_pipeline.py:110-120)."""
+    outs = [render_forward(p, o[i:i + chunk], d[i:i + chunk], pl[i:i + chunk], near[i:i + chunk],
+                           far[i:i + chunk], **kw) for i in range(0, o.shape[0], chunk)]
+    return {k: torch.cat([x[k] for x in outs], dim=0) for k in outs[0]}
+
+
+def train_loss(out, rgb_gt, igr_weight=0.1):
+    """L1 colour + eikonal (pipelines/base_pipeline.py:57-62)."""
+    nrays = out["rgb"].shape[0]
+    rgb_loss = (out["rgb"] - rgb_gt).abs().sum() / (nrays + 1e-5)
+    ge = (torch.linalg.norm(out["analytic_normals"], dim=-1) - 1.0) ** 2
+    m = out["relax_inside_sphere"]
+    eik = (m * ge).sum() / (m.sum() + 1e-5)
+    return rgb_loss + igr_weight * eik, rgb_loss, eik
