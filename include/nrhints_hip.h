@@ -1,0 +1,121 @@
+/* nrhints_hip.h - C ABI of the MI355X (gfx950) NRHints volumetric-rendering hot path.
+ *
+ * libnrhints_hip.so replaces, for the default `nr-hints` model configuration, the arithmetic inside the
+ * reference's  NeuSHintRenderer.forward  (models/neus_hint_model.py:653-751) and the field networks it calls
+ * (fields/sdf_field.py:106-148, fields/reflectance_network.py:68-96, fields/encodings.py:155-176).
+ * The reference has no FFI layer of its own (it is pure PyTorch); the seam a maintainer binds is the Python
+ * class  nrhints_amd.NeuSHintRenderer  which loads this library through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-owned, contiguous float32 memory unless marked (host)
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises the host
+ *   - return value: 0 = NRH_OK, negative = NRH_E_*; nrh_last_error_string() describes the last failure of the
+ *     calling thread; no C++ exception, no ownership, crosses this boundary
+ *   - weights arrive PACKED (nrhints_amd/packing.py documents the layout): weight-norm already folded
+ *     (W = g * v / ||v||_row, fields/sdf_field.py:81-82), transposed copies for the reverse chain included
+ */
+#ifndef NRHINTS_HIP_H
+#define NRHINTS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRH_OK 0
+#define NRH_E_INVALID (-1)     /* null pointer / bad size / bad mode */
+#define NRH_E_LAUNCH (-2)      /* HIP reported an error at launch */
+#define NRH_E_WORKSPACE (-3)   /* workspace too small */
+#define NRH_E_UNSUPPORTED (-4) /* configuration outside the compiled network shape */
+
+/* ABI version (major * 100 + minor) and a human-readable build string. */
+int nrh_version(void);
+const char* nrh_build_info(void);
+const char* nrh_last_error_string(void);
+
+/* Sizes (in floats) of the packed parameter buffers and of the per-wave scratch the gradient kernels need.
+ * out[0] sdf packed weights, out[1] sdf biases, out[2] sdf head, out[3] colour packed weights,
+ * out[4] colour biases, out[5] per-ray colour-input table stride, out[6] scratch floats per resident wave.
+ * `out` is a HOST pointer to 8 ints. */
+int nrh_param_sizes(int* out);
+
+/* Number of persistent workgroups the MLP kernels will launch on the current device (scratch sizing). */
+int nrh_mlp_grid(void);
+
+/* ---- live kernel timing (measurement only; used by bench.py's roofline leg) --------------------------------
+ * nrh_kernel_timing_select(kind): from now on bracket every launch of one kernel family with HIP events recorded
+ * on the launching stream; kind 0/1/2 = SDF kernel in that mode, 3 = reflectance kernel, -1 = off (default).
+ * nrh_kernel_timing_read: synchronises those events, returns their summed duration (ms) and count, and clears.
+ * total_ms / launches are HOST pointers.  Not thread-safe; leave it off outside benchmarks. */
+int nrh_kernel_timing_select(int kind);
+int nrh_kernel_timing_read(double* total_ms, long long* launches);
+
+/* ---- SDF network -------------------------------------------------------------------------------------------
+ * Evaluates the SDF MLP at points  p = ro[ray] + rd[ray] * t[ray * t_stride + j],  j < n_per_ray.
+ *   mode 0: sdf only              (SDFNetwork.sdf,      fields/sdf_field.py:125-126; sampler call sites
+ *                                  models/neus_hint_model.py:699, :325, :399)
+ *   mode 1: sdf + d(sdf)/dp       (SDFNetwork.gradient, fields/sdf_field.py:136-148; shadow-ray get_alpha :335-336)
+ *   mode 2: sdf + feature + grad  (SDFNetwork.forward,  fields/sdf_field.py:106-123 + .gradient; render_core :504-508)
+ * sdf  is written at sdf[ray * sdf_stride + j];  grad [nrays*n_per_ray,3];  feat in 16-point D-layout tiles
+ * [ceil(npts/16)][16][64][4] (nrhints_amd/packing.py: feat_tiles_to_rows converts to [npts,256]).
+ * scratch: nrh_mlp_grid() * 4 * out[6] floats (modes 1, 2), may be null for mode 0. */
+int nrh_sdf_eval(int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                 const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                 int sdf_stride, float* grad, float* feat, float* scratch, void* stream);
+
+/* ---- hierarchical sampler (one launch = merge the previous 16 samples and/or draw 16 new ones) ------------
+ * NeuSHintRenderer.up_sample (models/neus_hint_model.py:270-315) + sample_pdf (:21-65, det=True) +
+ * cat_z_vals (:317-331) + section mid-points (:491-496, :416-418).
+ *   z, s          [nrays,128] sorted ray parameters / sdf values, `n` valid on entry
+ *   do_merge      merge znew_in (and snew_in if merge_sdf) into z (and s); n grows by 16
+ *   do_upsample   write 16 new samples per ray to znew_out using fixed sharpness inv_s (= 64 * 2^step)
+ *   do_finalize   (n == 128 after the merge) write section lengths `dists` and mid-points `tmid`; the last
+ *                 section length is last_dist_ray[ray] if non-null, else last_dist
+ *   lin16         torch.linspace(0,1,16) as float32 */
+int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const float* znew_in,
+                     const float* snew_in, float* znew_out, const float* lin16, const float* last_dist_ray,
+                     float* tmid, float* dists, float inv_s, float last_dist, int nrays, int n, int do_merge,
+                     int merge_sdf, int do_upsample, int do_finalize, void* stream);
+
+/* ---- reflectance network ------------------------------------------------------------------------------------
+ * ReflectanceNetwork.forward (fields/reflectance_network.py:68-96) for 128 samples per ray.
+ *   feat     D-layout tiles from nrh_sdf_eval(mode 2);  nhat [nrays*128,3] unit normals;
+ *   raymisc  [nrays, out[5]] per-ray part of the input: enc4(view) | enc4(pl) | enc4(vis) | enc4(cue)
+ *   color    [nrays*128,3] */
+int nrh_color_eval(const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
+                   const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
+                   void* stream);
+
+/* ---- the renderer -------------------------------------------------------------------------------------------
+ * NeuSHintRenderer.forward, default nr-hints configuration, no autograd (models/neus_hint_model.py:653-751):
+ * 64 coarse + 4x16 importance samples, shadow hint through the alpha-blended hit point, 4-roughness specular cue.
+ * Inputs  (RayBundle fields, camera/ray_utils.py:214-235): origins, directions, pl_positions [n,3]; nears, fars [n].
+ * Outputs (RenderOutput fields, models/neus_hint_model.py:216-233), any of the optional ones may be null:
+ *   rgb [n,3], depth [n], weights [n,128], inside_sphere [n,128], analytic_normals [n,128,3],
+ *   normalized_normals [n,128,3], visibilities [n], specular_cue [n,128,4].
+ * Scalars: inv_s = clip(exp(10 * variance), 1e-6, 1e6) (:110, :337); cos_anneal (:669-671).
+ * background (device, [3]) may be null.  t_rand_primary [n] / t_rand_shadow [n,64]: training jitter (:682, :394),
+ * null at evaluation.  lin64 / lin16: torch.linspace(0,1,64|16) as float32.  zero_hints: geometry warm-up (:577, :617).
+ * workspace: nrh_render_workspace_floats(n) floats. */
+typedef struct NrhNet {
+  const float* sdf_w;
+  const float* sdf_b;
+  const float* sdf_head;
+  const float* col_w;
+  const float* col_b;
+  float inv_s;
+} NrhNet;
+
+long long nrh_render_workspace_floats(long long nrays);
+
+int nrh_render_forward(const NrhNet* net /* host */, const float* origins, const float* directions,
+                       const float* pl_positions, const float* nears, const float* fars, long long nrays,
+                       const float* background, float cos_anneal, const float* t_rand_primary,
+                       const float* t_rand_shadow, int zero_hints, const float* lin64, const float* lin16,
+                       float* rgb, float* depth, float* weights, float* inside_sphere, float* analytic_normals,
+                       float* normalized_normals, float* visibilities, float* specular_cue, float* workspace,
+                       long long workspace_floats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRHINTS_HIP_H */

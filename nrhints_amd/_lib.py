@@ -1,0 +1,97 @@
+"""ctypes binding of libnrhints_hip.so (C ABI: include/nrhints_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, the product path raises.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C nrhints_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnrhints_hip.so")
+
+NRH_OK = 0
+_ERRNAMES = {-1: "NRH_E_INVALID", -2: "NRH_E_LAUNCH", -3: "NRH_E_WORKSPACE", -4: "NRH_E_UNSUPPORTED"}
+
+# every symbol include/nrhints_hip.h declares (tests check the .so exports exactly these)
+EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param_sizes", "nrh_mlp_grid",
+            "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
+            "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read")
+
+
+class NrhNet(Structure):
+    _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
+                ("col_b", c_void_p), ("inv_s", c_float)]
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class NrhError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises HipExtensionMissing if the .so is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: the HIP hot path is not built (run __graft_entry__.build()). "
+            "nrhints_amd has no CPU/PyTorch fallback for rendering.")
+    lib = ctypes.CDLL(LIB_PATH)
+    P = c_void_p
+    lib.nrh_version.restype = c_int
+    lib.nrh_build_info.restype = c_char_p
+    lib.nrh_last_error_string.restype = c_char_p
+    lib.nrh_param_sizes.argtypes = [POINTER(c_int)]
+    lib.nrh_mlp_grid.restype = c_int
+    lib.nrh_sdf_eval.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
+    lib.nrh_sampler_step.argtypes = [P, P, P, P, P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, P]
+    lib.nrh_color_eval.argtypes = [P, P, P, P, P, P, P, P, c_longlong, P, P]
+    lib.nrh_render_workspace_floats.argtypes = [c_longlong]
+    lib.nrh_render_workspace_floats.restype = c_longlong
+    lib.nrh_render_forward.argtypes = [POINTER(NrhNet), P, P, P, P, P, c_longlong, P, c_float, P, P, c_int, P, P,
+                                       P, P, P, P, P, P, P, P, P, c_longlong, P]
+    lib.nrh_kernel_timing_select.argtypes = [c_int]
+    lib.nrh_kernel_timing_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_longlong)]
+    for name in EXPORTED:
+        getattr(lib, name)  # AttributeError if the build is stale
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != NRH_OK:
+        msg = load().nrh_last_error_string().decode(errors="replace")
+        raise NrhError(f"{what} failed: {_ERRNAMES.get(rc, rc)}: {msg}")
+
+
+def param_sizes():
+    out = (c_int * 8)()
+    check(load().nrh_param_sizes(out), "nrh_param_sizes")
+    return list(out)
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"expected a contiguous float32 tensor on the GPU, got {type(t)} "
+                         f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)} contiguous={getattr(t, 'is_contiguous', lambda: None)()}")
+    return c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

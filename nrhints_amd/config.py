@@ -1,0 +1,124 @@
+"""Configuration dataclasses of the hot path - the shape/behaviour contract of the reference's defaults.
+
+Mirrors the field names and default values of ``SDFNetConfig`` (fields/sdf_field.py:11-36),
+``ReflectanceNetConfig`` (fields/reflectance_network.py:9-22), ``SingleVarianceNetConfig`` /
+``NeuSRendererConfig`` / ``NeuSModelConfig`` (models/neus_hint_model.py:96-213) so that a reference config tree
+can be passed field for field.  Branches the HIP path does not implement are rejected loudly by
+``NeuSHintRenderer`` (see ``unsupported_reason``), never silently mis-computed.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import List, Optional
+
+
+class DepthComputationType(Enum):
+    AlphaBlend = "alpha_blending"
+    MaximalWeightPoint = "maximum_point"
+    SphereTracing = "sphere_tracing"
+
+
+class NormalComputationType(Enum):
+    Analytic = "analytic"
+    NormalizedAnalytic = "normalized_analytic"
+
+
+@dataclass(frozen=True)
+class SDFNetConfig:
+    d_in: int = 3
+    d_out_feat: int = 256
+    d_hidden: int = 256
+    n_layers: int = 8
+    skip_in: List[int] = field(default_factory=lambda: [4])
+    multi_res: int = 6
+    init_bias: float = 0.5
+    scale: float = 3.0
+    geometric_init: bool = True
+    weight_norm: bool = True
+    inside_outside: bool = False
+
+
+@dataclass(frozen=True)
+class ReflectanceNetConfig:
+    d_hidden: int = 256
+    n_layers: int = 4
+    weight_norm: bool = True
+    multi_res: int = 4
+    squeeze_out: bool = True
+
+
+@dataclass(frozen=True)
+class SingleVarianceNetConfig:
+    init_val: float = 0.3
+
+
+@dataclass(frozen=True)
+class NeuSRendererConfig:
+    use_outside_nerf: bool = False
+    n_samples: int = 64
+    n_importance_samples: int = 64
+    n_outside_samples: int = 32
+    normal_type: NormalComputationType = NormalComputationType.NormalizedAnalytic
+    up_sample_steps: int = 4
+    depth_type: DepthComputationType = DepthComputationType.AlphaBlend
+    shadow_hint: bool = True
+    force_shadow_map: bool = False
+    specular_hint: bool = True
+    force_specular_cue: bool = False
+    shadow_ray_offset: float = 1e-2
+    specular_roughness: List[float] = field(default_factory=lambda: [0.02, 0.05, 0.13, 0.34])
+    shadow_hint_gradient: bool = False
+    specular_hint_gradient: bool = False
+    n_shadow_importance_clip: int = -1
+    n_shadow_samples: int = 64
+    n_shadow_importance_samples: int = 64
+    override_near_far_to_sphere: bool = True
+
+
+@dataclass(frozen=True)
+class NeuSModelConfig:
+    sdf_network: SDFNetConfig = field(default_factory=SDFNetConfig)
+    deviation_network: SingleVarianceNetConfig = field(default_factory=SingleVarianceNetConfig)
+    reflectance_network: ReflectanceNetConfig = field(default_factory=ReflectanceNetConfig)
+    renderer: NeuSRendererConfig = field(default_factory=NeuSRendererConfig)
+    igr_weight: float = 0.1
+    lr: float = 5e-4
+    lr_alpha: float = 0.05
+    warm_up_end: int = 5_000
+    end_iter: int = 1_000_000
+    anneal_end: int = 50_000
+    geometry_warmup_end: int = 0
+    batch_size: int = 512
+    shadow_mini_chunk_size: int = 2048
+    training_chunk_size: int = 512
+    inference_chunk_size: int = 512
+
+
+def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
+    """None if ``cfg`` is the network/renderer shape the gfx950 kernels are compiled for, else why not."""
+    s, c, r = cfg.sdf_network, cfg.reflectance_network, cfg.renderer
+    checks = [
+        (s.d_in == 3 and s.d_out_feat == 256 and s.d_hidden == 256 and s.n_layers == 8 and list(s.skip_in) == [4]
+         and s.multi_res == 6 and s.weight_norm and not s.inside_outside and float(s.scale) == 3.0,
+         "sdf_network must be the default 8x256 / skip_in=[4] / multi_res=6 / scale=3 MLP"),
+        (c.d_hidden == 256 and c.n_layers == 4 and c.multi_res == 4 and c.weight_norm and c.squeeze_out,
+         "reflectance_network must be the default 4x256 / multi_res=4 / sigmoid MLP"),
+        (not r.use_outside_nerf, "use_outside_nerf=True (outside NeRF background) is not implemented"),
+        (r.n_samples == 64 and r.n_importance_samples == 64 and r.up_sample_steps == 4,
+         "n_samples/n_importance_samples/up_sample_steps must be 64/64/4"),
+        (r.n_shadow_samples == 64 and r.n_shadow_importance_samples == 64,
+         "n_shadow_samples/n_shadow_importance_samples must be 64/64"),
+        (r.n_shadow_importance_clip == -1, "only the hit-point shadow mode (n_shadow_importance_clip=-1) is implemented"),
+        (r.shadow_hint and r.specular_hint, "shadow_hint and specular_hint must both be on (PLNaive is not implemented)"),
+        (list(r.specular_roughness) == [0.02, 0.05, 0.13, 0.34], "specular_roughness must be the default 4 values"),
+        (r.depth_type == DepthComputationType.AlphaBlend, "only DepthComputationType.AlphaBlend is implemented"),
+        (r.normal_type == NormalComputationType.NormalizedAnalytic,
+         "only NormalComputationType.NormalizedAnalytic is implemented"),
+        (not r.shadow_hint_gradient and not r.specular_hint_gradient, "hint gradients are not implemented"),
+        (abs(r.shadow_ray_offset - 1e-2) < 1e-12, "shadow_ray_offset must be 1e-2"),
+    ]
+    for ok, why in checks:
+        if not ok:
+            return why
+    return None

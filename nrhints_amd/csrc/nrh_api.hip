@@ -1,0 +1,368 @@
+// C ABI of libnrhints_hip.so (declared in include/nrhints_hip.h).  Single translation unit: the kernel sources
+// are included here so one hipcc invocation builds the whole library for gfx950.
+#include "nrh_sdf.hip"
+#include "nrh_color.hip"
+#include "nrh_rays.hip"
+
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nrhints_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "", long long b = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", what, hipGetErrorString(e));
+    return NRH_E_LAUNCH;
+  }
+  return NRH_OK;
+}
+
+int g_cus = 0;
+bool g_attr_done = false;
+
+int device_cus() {
+  if (g_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    g_cus = prop.multiProcessorCount;
+  }
+  return g_cus;
+}
+
+int mlp_grid() {
+  const int cus = device_cus();
+  return cus > 0 ? cus * 2 : 0;  // 2 workgroups (8 waves, 2 x 64 KiB LDS) resident per CU
+}
+
+int ensure_attrs() {
+  if (g_attr_done) return NRH_OK;
+  hipError_t e;
+  e = hipFuncSetAttribute((const void*)nrh::sdf_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
+  if (e != hipSuccess) return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+  g_attr_done = true;
+  return NRH_OK;
+}
+
+inline long long round64(long long x) { return (x + 63) / 64 * 64; }
+
+// ---- optional live kernel timing (bench.py's roofline leg): HIP events around one kernel family ----
+struct TimedLaunch { hipEvent_t a, b; };
+int g_time_kind = -1;  // -1 off; 0/1/2 = sdf_kernel<mode>; 3 = color_kernel
+std::vector<TimedLaunch> g_timed;
+void timing_begin(int kind, hipStream_t st, TimedLaunch& t, bool& on) {
+  on = (kind == g_time_kind);
+  if (!on) return;
+  hipEventCreate(&t.a);
+  hipEventCreate(&t.b);
+  hipEventRecord(t.a, st);
+}
+void timing_end(hipStream_t st, TimedLaunch& t, bool on) {
+  if (!on) return;
+  hipEventRecord(t.b, st);
+  g_timed.push_back(t);
+}
+
+int sdf_eval_impl(int mode, const float* w, const float* b, const float* head, const float* ro, const float* rd,
+                  const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad,
+                  float* feat, float* scratch, hipStream_t st) {
+  if (mode < 0 || mode > 2) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode must be 0, 1 or 2%s", "");
+  if (!w || !b || !head || !ro || !rd || !t || !sdf) return fail(NRH_E_INVALID, "nrh_sdf_eval: null pointer%s", "");
+  if (mode >= 1 && (!grad || !scratch)) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode %s needs grad and scratch", mode == 1 ? "1" : "2");
+  if (mode == 2 && !feat) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode 2 needs feat%s", "");
+  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray || sdf_stride < n_per_ray)
+    return fail(NRH_E_INVALID, "nrh_sdf_eval: bad n_per_ray/stride%s", "");
+  if (nrays == 0) return NRH_OK;
+  int rc = ensure_attrs();
+  if (rc) return rc;
+  nrh::SdfArgs a;
+  a.w = w; a.b = b; a.head = head; a.ro = ro; a.rd = rd; a.t = t; a.sdf = sdf; a.grad = grad; a.feat = feat;
+  a.scratch = scratch;
+  a.npts = nrays * n_per_ray;
+  a.n_per_ray = n_per_ray; a.t_stride = t_stride; a.sdf_stride = sdf_stride;
+  const long long groups = (a.npts + 63) / 64;
+  if (groups > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_sdf_eval: too many points%s", "");
+  a.ntile_groups = (int)groups;
+  const int grid = (int)(groups < mlp_grid() ? groups : mlp_grid());
+  if (grid <= 0) return fail(NRH_E_LAUNCH, "no HIP device%s", "");
+  TimedLaunch tl;
+  bool timed;
+  timing_begin(mode, st, tl, timed);
+  if (mode == 0) hipLaunchKernelGGL(nrh::sdf_kernel<0>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  else if (mode == 1) hipLaunchKernelGGL(nrh::sdf_kernel<1>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(nrh::sdf_kernel<2>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  timing_end(st, tl, timed);
+  return check_launch("sdf_kernel");
+}
+
+int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
+  const int blocks = (a.nrays + nrh::RAYS_PER_BLOCK - 1) / nrh::RAYS_PER_BLOCK;
+  hipLaunchKernelGGL(nrh::sampler_step_kernel, dim3(blocks), dim3(256), 0, st, a);
+  return check_launch("sampler_step_kernel");
+}
+
+int color_eval_impl(const float* w, const float* b, const float* feat, const float* ro, const float* rd,
+                    const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
+                    hipStream_t st) {
+  if (!w || !b || !feat || !ro || !rd || !tmid || !nhat || !raymisc || !color)
+    return fail(NRH_E_INVALID, "nrh_color_eval: null pointer%s", "");
+  if (nrays == 0) return NRH_OK;
+  int rc = ensure_attrs();
+  if (rc) return rc;
+  nrh::ColorArgs a;
+  a.w = w; a.b = b; a.feat = feat; a.ro = ro; a.rd = rd; a.tmid = tmid; a.nhat = nhat; a.raymisc = raymisc;
+  a.color = color;
+  a.npts = nrays * 128;
+  const long long groups = (a.npts + 63) / 64;
+  if (groups > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_color_eval: too many points%s", "");
+  a.ntile_groups = (int)groups;
+  const int grid = (int)(groups < mlp_grid() ? groups : mlp_grid());
+  if (grid <= 0) return fail(NRH_E_LAUNCH, "no HIP device%s", "");
+  TimedLaunch tl;
+  bool timed;
+  timing_begin(3, st, tl, timed);
+  hipLaunchKernelGGL(nrh::color_kernel, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  timing_end(st, tl, timed);
+  return check_launch("color_kernel");
+}
+
+// hierarchical sampling of one family of rays: coarse sdf, 4 x (up-sample 16, evaluate, merge), finalise sections
+int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, float* s, float* znew, float* snew,
+                const float* lin16, const float* last_dist_ray, float last_dist, float* tmid, float* dists,
+                long long n, hipStream_t st) {
+  int rc = sdf_eval_impl(0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, z, 128, 64, n, s, 128, nullptr, nullptr,
+                         nullptr, st);
+  if (rc) return rc;
+  for (int i = 0; i < 4; ++i) {
+    nrh::StepArgs a;
+    a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew; a.snew_in = snew; a.znew_out = znew; a.lin16 = lin16;
+    a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.last_dist = last_dist;
+    a.nrays = (int)n;
+    // launch A: up-sample step i from the current (merged) state
+    a.inv_s = 64.0f * (float)(1 << i);
+    a.n = 64 + 16 * i; a.do_merge = 0; a.merge_sdf = 0; a.do_upsample = 1; a.do_finalize = 0;
+    rc = sampler_step_impl(a, st);
+    if (rc) return rc;
+    const bool last = (i == 3);
+    if (!last) {
+      rc = sdf_eval_impl(0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, znew, 16, 16, n, snew, 16, nullptr, nullptr,
+                         nullptr, st);
+      if (rc) return rc;
+    }
+    // launch B: merge (with sdf unless last); finalise after the last merge
+    a.do_merge = 1; a.merge_sdf = last ? 0 : 1; a.do_upsample = 0; a.do_finalize = last ? 1 : 0;
+    rc = sampler_step_impl(a, st);
+    if (rc) return rc;
+  }
+  return NRH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrh_version(void) { return 100; }
+const char* nrh_build_info(void) { return "nrhints_hip gfx950 fp32-mfma16x16x4 " __DATE__ " " __TIME__; }
+const char* nrh_last_error_string(void) { return g_err; }
+
+int nrh_param_sizes(int* out) {
+  if (!out) return fail(NRH_E_INVALID, "nrh_param_sizes: null%s", "");
+  out[0] = nrh::SDF_PACKED_FLOATS;
+  out[1] = nrh::SDF_BIAS_FLOATS;
+  out[2] = nrh::SDF_HEAD_FLOATS;
+  out[3] = nrh::COL_PACKED_FLOATS;
+  out[4] = nrh::COL_BIAS_FLOATS;
+  out[5] = nrh::RAYMISC_STRIDE;
+  out[6] = nrh::SDF_SCRATCH_FLOATS_PER_WAVE;
+  out[7] = 0;
+  return NRH_OK;
+}
+
+int nrh_mlp_grid(void) { return mlp_grid(); }
+
+int nrh_kernel_timing_select(int kind) {
+  if (kind < -1 || kind > 3) return fail(NRH_E_INVALID, "nrh_kernel_timing_select: kind must be -1..3%s", "");
+  for (auto& t : g_timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  g_timed.clear();
+  g_time_kind = kind;
+  return NRH_OK;
+}
+
+int nrh_kernel_timing_read(double* total_ms, long long* launches) {
+  if (!total_ms || !launches) return fail(NRH_E_INVALID, "nrh_kernel_timing_read: null%s", "");
+  double tot = 0.0;
+  for (auto& t : g_timed) {
+    float ms = 0.f;
+    if (hipEventSynchronize(t.b) != hipSuccess || hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess)
+      return fail(NRH_E_LAUNCH, "nrh_kernel_timing_read: event query failed%s", "");
+    tot += ms;
+    hipEventDestroy(t.a);
+    hipEventDestroy(t.b);
+  }
+  *total_ms = tot;
+  *launches = (long long)g_timed.size();
+  g_timed.clear();
+  return NRH_OK;
+}
+
+int nrh_sdf_eval(int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                 const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                 int sdf_stride, float* grad, float* feat, float* scratch, void* stream) {
+  return sdf_eval_impl(mode, sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat,
+                       scratch, (hipStream_t)stream);
+}
+
+int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const float* znew_in,
+                     const float* snew_in, float* znew_out, const float* lin16, const float* last_dist_ray,
+                     float* tmid, float* dists, float inv_s, float last_dist, int nrays, int n, int do_merge,
+                     int merge_sdf, int do_upsample, int do_finalize, void* stream) {
+  if (!ro || !rd || !z || !s) return fail(NRH_E_INVALID, "nrh_sampler_step: null pointer%s", "");
+  if (do_merge && (!znew_in || (merge_sdf && !snew_in))) return fail(NRH_E_INVALID, "nrh_sampler_step: merge needs znew_in/snew_in%s", "");
+  if (do_upsample && (!znew_out || !lin16)) return fail(NRH_E_INVALID, "nrh_sampler_step: upsample needs znew_out/lin16%s", "");
+  if (do_finalize && (!tmid || !dists)) return fail(NRH_E_INVALID, "nrh_sampler_step: finalize needs tmid/dists%s", "");
+  const int n_after = n + (do_merge ? 16 : 0);
+  if (n < 2 || n_after > 128 || (do_finalize && n_after != 128))
+    return fail(NRH_E_INVALID, "nrh_sampler_step: bad sample count%s", "");
+  if (nrays <= 0) return nrays == 0 ? NRH_OK : fail(NRH_E_INVALID, "nrh_sampler_step: nrays < 0%s", "");
+  nrh::StepArgs a;
+  a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew_in; a.snew_in = snew_in; a.znew_out = znew_out;
+  a.lin16 = lin16; a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.inv_s = inv_s;
+  a.last_dist = last_dist; a.nrays = nrays; a.n = n; a.do_merge = do_merge; a.merge_sdf = merge_sdf;
+  a.do_upsample = do_upsample; a.do_finalize = do_finalize;
+  return sampler_step_impl(a, (hipStream_t)stream);
+}
+
+int nrh_color_eval(const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
+                   const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
+                   void* stream) {
+  return color_eval_impl(col_w, col_b, feat, ro, rd, tmid, nhat, raymisc, nrays, color, (hipStream_t)stream);
+}
+
+// workspace carve-up (floats per ray, each array rounded up to a multiple of 64 floats)
+#define NRH_WS_FIELDS(X)                                                                                             \
+  X(zbuf, 128) X(sbuf, 128) X(znew, 16) X(snew, 16) X(tmid, 128) X(dists, 128) X(sdf_c, 128) X(grad_c, 384)          \
+  X(feat, 32768) X(weights, 128) X(inside, 128) X(nhat, 384) X(depth, 1) X(wsum, 1) X(cue, 4) X(srd, 3) X(slast, 1)  \
+  X(tmid_s, 128) X(dists_s, 128) X(sdf_s, 128) X(grad_s, 384) X(vis, 1) X(raymisc, nrh::RAYMISC_STRIDE)              \
+  X(color, 384) X(cue_b, 512)
+
+long long nrh_render_workspace_floats(long long nrays) {
+  if (nrays < 0) return -1;
+  long long tot = 0;
+#define X(name, per) tot += round64(nrays * (long long)(per));
+  NRH_WS_FIELDS(X)
+#undef X
+  tot += (long long)mlp_grid() * 4 * nrh::SDF_SCRATCH_FLOATS_PER_WAVE;
+  return tot;
+}
+
+int nrh_render_forward(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
+                       const float* nears, const float* fars, long long nrays, const float* background,
+                       float cos_anneal, const float* t_rand_primary, const float* t_rand_shadow, int zero_hints,
+                       const float* lin64, const float* lin16, float* rgb, float* depth, float* weights,
+                       float* inside_sphere, float* analytic_normals, float* normalized_normals, float* visibilities,
+                       float* specular_cue, float* workspace, long long workspace_floats, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !net->col_w || !net->col_b)
+    return fail(NRH_E_INVALID, "nrh_render_forward: null network pointer%s", "");
+  if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || !rgb || !workspace)
+    return fail(NRH_E_INVALID, "nrh_render_forward: null pointer%s", "");
+  if (nrays < 0 || nrays > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_render_forward: nrays out of range (chunk the call)%s", "");
+  if (nrays == 0) return NRH_OK;
+  if (workspace_floats < nrh_render_workspace_floats(nrays))
+    return fail(NRH_E_WORKSPACE, "nrh_render_forward: workspace too small%s (need %lld floats)", "", nrh_render_workspace_floats(nrays));
+  if (((uintptr_t)workspace & 15) != 0) return fail(NRH_E_INVALID, "nrh_render_forward: workspace must be 16-byte aligned%s", "");
+  const long long n = nrays;
+  float* p = workspace;
+#define X(name, per) float* ws_##name = p; p += round64(n * (long long)(per));
+  NRH_WS_FIELDS(X)
+#undef X
+  float* scratch = p;
+  // outputs the caller asked for are written in place, the rest live in the workspace
+  float* o_weights = weights ? weights : ws_weights;
+  float* o_inside = inside_sphere ? inside_sphere : ws_inside;
+  float* o_grad = analytic_normals ? analytic_normals : ws_grad_c;
+  float* o_nhat = normalized_normals ? normalized_normals : ws_nhat;
+  float* o_depth = depth ? depth : ws_depth;
+  float* o_vis = visibilities ? visibilities : ws_vis;
+  float* o_cue_b = specular_cue;  // optional broadcast copy
+
+  // ---- primary rays: coarse z, hierarchical sampling ----
+  {
+    nrh::CoarseArgs c;
+    c.near_ = nears; c.far_ = fars; c.lin64 = lin64; c.t_rand = t_rand_primary; c.z = ws_zbuf; c.nrays = (int)n;
+    const long long tot = n * 64;
+    hipLaunchKernelGGL(nrh::coarse_z_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c);
+    int rc = check_launch("coarse_z_kernel");
+    if (rc) return rc;
+  }
+  int rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f,
+                       ws_tmid, ws_dists, n, st);
+  if (rc) return rc;
+  // ---- render_core: sdf + feature + gradient at the 128 section mid-points ----
+  rc = sdf_eval_impl(2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, ws_tmid, 128, 128, n, ws_sdf_c, 128,
+                     o_grad, ws_feat, scratch, st);
+  if (rc) return rc;
+  {
+    nrh::CoreArgs c;
+    c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = ws_sdf_c; c.grad = o_grad; c.dists = ws_dists;
+    c.tmid = ws_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
+    c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
+    c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal; c.shadow_offset = 1e-2f;
+    const double rough[4] = {0.02, 0.05, 0.13, 0.34};  // models/neus_hint_model.py:161
+    for (int i = 0; i < 4; ++i) {
+      const double k = (rough[i] + 1.0) * (rough[i] + 1.0) / 8.0, a2 = rough[i] * rough[i];
+      c.kk[i] = (float)k; c.omk[i] = (float)(1.0 - k); c.a2[i] = (float)a2; c.a2m1[i] = (float)(a2 - 1.0);
+    }
+    c.zero_hints = zero_hints;
+    c.nrays = (int)n;
+    hipLaunchKernelGGL(nrh::core_alpha_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
+    rc = check_launch("core_alpha_kernel");
+    if (rc) return rc;
+  }
+  // ---- shadow rays light -> hit point ----
+  if (!zero_hints) {
+    rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s,
+                     ws_dists_s, n, st);
+    if (rc) return rc;
+    rc = sdf_eval_impl(1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
+                       128, ws_grad_s, nullptr, scratch, st);
+    if (rc) return rc;
+  }
+  {
+    nrh::ShadowArgs c;
+    c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = ws_dists_s;
+    c.cue = ws_cue; c.vis = o_vis; c.raymisc = ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
+    c.nrays = (int)n; c.zero_hints = zero_hints;
+    hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
+    rc = check_launch("shadow_finish_kernel");
+    if (rc) return rc;
+  }
+  // ---- reflectance + composite ----
+  rc = color_eval_impl(net->col_w, net->col_b, ws_feat, origins, directions, ws_tmid, o_nhat, ws_raymisc, n, ws_color, st);
+  if (rc) return rc;
+  {
+    nrh::CompositeArgs c;
+    c.color = ws_color; c.weights = o_weights; c.wsum = ws_wsum; c.bg = background; c.rgb = rgb; c.nrays = (int)n;
+    hipLaunchKernelGGL(nrh::composite_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
+    rc = check_launch("composite_kernel");
+    if (rc) return rc;
+  }
+  return NRH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+// Per-ray stages of the NeuS-with-hints renderer on gfx950: one 64-lane wavefront per ray, every 128-sample
+// sequence held two elements per lane (j0 = lane, j1 = lane + 64), scans and reductions by wave shuffles.
+//
+// Restates (reference, models/neus_hint_model.py): coarse z (:673-683), up_sample (:270-315), sample_pdf (:21-65),
+// cat_z_vals (:317-331), section mid-points (:491-496 / :416-418), get_alpha's alpha formula (:339-356), weights /
+// depth / hit point (:512-533), shadow-ray set-up and transmittance (:380-395, :429-432), hit normal and the
+// Cook-Torrance cue (:583-616), composite (:635-637).
+#include "nrh_mlp.h"
+
+namespace nrh {
+
+constexpr int RAYS_PER_BLOCK = 4;
+
+// -------------------------------------------------------------------------------------------------
+// coarse z:  z_j = near + (far - near) * lin64[j]   (+ one jitter per ray in training)
+// -------------------------------------------------------------------------------------------------
+struct CoarseArgs {
+  const float* near_;
+  const float* far_;
+  const float* lin64;   // torch.linspace(0,1,64) as float32 (bit-exact table from the host)
+  const float* t_rand;  // [N] or null
+  float* z;             // [N,128], first 64 written
+  int nrays;
+};
+__global__ void coarse_z_kernel(const CoarseArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)a.nrays * 64) return;
+  const int ray = (int)(i >> 6), j = (int)(i & 63);
+  const float nr = a.near_[ray], fr = a.far_[ray];
+  float z = nr + (fr - nr) * a.lin64[j];
+  if (a.t_rand) z = z + (a.t_rand[ray] - 0.5f) * 2.0f / 64.0f;
+  a.z[(long long)ray * 128 + j] = z;
+}
+
+// -------------------------------------------------------------------------------------------------
+// one launch = [merge the 16 samples of the previous step] + [up-sample 16 new ones | finalise sections]
+// -------------------------------------------------------------------------------------------------
+struct StepArgs {
+  const float* ro;        // [N,3]
+  const float* rd;        // [N,3]
+  float* z;               // [N,128] sorted ray parameters (n valid)
+  float* s;               // [N,128] sdf at those parameters
+  const float* znew_in;   // [N,16] samples to merge
+  const float* snew_in;   // [N,16] their sdf (merge_sdf)
+  float* znew_out;        // [N,16] new samples
+  const float* lin16;     // torch.linspace(0,1,16)
+  const float* last_dist_ray;  // [N] per-ray last section length, or null -> last_dist
+  float* tmid;            // [N,128] section mid-points (finalize)
+  float* dists;           // [N,128] section lengths (finalize)
+  float inv_s;
+  float last_dist;
+  int nrays;
+  int n;                  // valid entries before the merge
+  int do_merge, merge_sdf, do_upsample, do_finalize;
+};
+
+__global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
+  __shared__ float sz[RAYS_PER_BLOCK][144];
+  __shared__ float ss[RAYS_PER_BLOCK][144];
+  __shared__ float sx[RAYS_PER_BLOCK][144];  // radius, then cdf
+  __shared__ float sc[RAYS_PER_BLOCK][144];  // section cos
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * RAYS_PER_BLOCK + wave;
+  const bool active = ray_raw < a.nrays;
+  const long long ray = active ? ray_raw : a.nrays - 1;
+  float* Z = sz[wave];
+  float* S = ss[wave];
+  float* X = sx[wave];
+  float* C = sc[wave];
+  int n = a.n;
+  const int j0 = lane, j1 = lane + 64;
+  float z0 = (j0 < n) ? a.z[ray * 128 + j0] : 0.0f;
+  float z1 = (j1 < n) ? a.z[ray * 128 + j1] : 0.0f;
+  float s0 = (j0 < n) ? a.s[ray * 128 + j0] : 0.0f;
+  float s1 = (j1 < n) ? a.s[ray * 128 + j1] : 0.0f;
+
+  if (a.do_merge) {
+    // stable merge of two sorted lists by rank counting (old entries win ties, as a stable sort of cat[z, z_new])
+    const float zn = (lane < 16) ? a.znew_in[ray * 16 + lane] : 0.0f;
+    const float sn = (lane < 16 && a.merge_sdf) ? a.snew_in[ray * 16 + lane] : 0.0f;
+    int c0 = 0, c1 = 0, cn = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float zk = __shfl(zn, k, 64);
+      c0 += (zk < z0) ? 1 : 0;
+      c1 += (zk < z1) ? 1 : 0;
+      const unsigned long long b0 = __ballot(j0 < n && z0 <= zk);
+      const unsigned long long b1 = __ballot(j1 < n && z1 <= zk);
+      const int cnt = __popcll(b0) + __popcll(b1);
+      cn = (lane == k) ? cnt : cn;
+    }
+    if (j0 < n) { Z[j0 + c0] = z0; S[j0 + c0] = s0; }
+    if (j1 < n) { Z[j1 + c1] = z1; S[j1 + c1] = s1; }
+    if (lane < 16) { Z[lane + cn] = zn; S[lane + cn] = sn; }
+    __syncthreads();
+    n += 16;
+    z0 = (j0 < n) ? Z[j0] : 0.0f;
+    z1 = (j1 < n) ? Z[j1] : 0.0f;
+    s0 = (j0 < n) ? S[j0] : 0.0f;
+    s1 = (j1 < n) ? S[j1] : 0.0f;
+    if (active) {
+      if (j0 < n) { a.z[ray * 128 + j0] = z0; if (a.merge_sdf) a.s[ray * 128 + j0] = s0; }
+      if (j1 < n) { a.z[ray * 128 + j1] = z1; if (a.merge_sdf) a.s[ray * 128 + j1] = s1; }
+    }
+  } else {
+    if (j0 < n) { Z[j0] = z0; S[j0] = s0; }
+    if (j1 < n) { Z[j1] = z1; S[j1] = s1; }
+    __syncthreads();
+  }
+
+  if (a.do_upsample) {
+    const float ox = a.ro[ray * 3 + 0], oy = a.ro[ray * 3 + 1], oz = a.ro[ray * 3 + 2];
+    const float dx = a.rd[ray * 3 + 0], dy = a.rd[ray * 3 + 1], dz = a.rd[ray * 3 + 2];
+    auto radius = [&](float z) {
+      const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
+      return sqrtf(px * px + py * py + pz * pz);
+    };
+    const float r0 = radius(z0), r1 = radius(z1);
+    if (j0 < n) X[j0] = r0;
+    if (j1 < n) X[j1] = r1;
+    __syncthreads();
+    const bool v0 = j0 < n - 1, v1 = j1 < n - 1;  // section j = [z_j, z_{j+1}]
+    const float zn0 = v0 ? Z[j0 + 1] : z0, zn1 = v1 ? Z[j1 + 1] : z1;
+    const float sn0 = v0 ? S[j0 + 1] : s0, sn1 = v1 ? S[j1 + 1] : s1;
+    const float rn0 = v0 ? X[j0 + 1] : r0, rn1 = v1 ? X[j1 + 1] : r1;
+    const float cos0 = (sn0 - s0) / (zn0 - z0 + 1e-5f);
+    const float cos1 = (sn1 - s1) / (zn1 - z1 + 1e-5f);
+    C[j0] = cos0;
+    C[j1] = cos1;
+    __syncthreads();
+    const float pc0 = (j0 == 0) ? 0.0f : C[j0 - 1];
+    const float pc1 = C[j1 - 1];
+    auto section_alpha = [&](float s_a, float s_b, float dist, float cosv, float pcos, float ra, float rb) {
+      const float inside = ((ra < 1.0f) || (rb < 1.0f)) ? 1.0f : 0.0f;
+      float c = fminf(pcos, cosv);
+      c = fminf(fmaxf(c, -1e3f), 0.0f) * inside;
+      const float mid = (s_a + s_b) * 0.5f;
+      const float pe = mid - c * dist * 0.5f;
+      const float ne = mid + c * dist * 0.5f;
+      const float pcdf = sigmoidf_(pe * a.inv_s);
+      const float ncdf = sigmoidf_(ne * a.inv_s);
+      return (pcdf - ncdf + 1e-5f) / (pcdf + 1e-5f);
+    };
+    const float al0 = section_alpha(s0, sn0, zn0 - z0, cos0, pc0, r0, rn0);
+    const float al1 = section_alpha(s1, sn1, zn1 - z1, cos1, pc1, r1, rn1);
+    float T0, T1;
+    excl_prod_128(v0 ? (1.0f - al0 + 1e-7f) : 1.0f, v1 ? (1.0f - al1 + 1e-7f) : 1.0f, T0, T1);
+    const float w0 = v0 ? (al0 * T0 + 1e-5f) : 0.0f;  // weights + 1e-5 (sample_pdf)
+    const float w1 = v1 ? (al1 * T1 + 1e-5f) : 0.0f;
+    const float tot = wave_sum(w0 + w1);
+    float cs0, cs1;
+    incl_sum_128(w0 / tot, w1 / tot, cs0, cs1);
+    __syncthreads();  // everyone done with X (radius) before it becomes the cdf
+    if (lane == 0) X[0] = 0.0f;
+    if (v0) X[j0 + 1] = cs0;
+    if (v1) X[j1 + 1] = cs1;
+    __syncthreads();
+    const float cd0 = (j0 < n) ? X[j0] : 2.0f;
+    const float cd1 = (j1 < n) ? X[j1] : 2.0f;
+    int ind = 0;
+    float u = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float uk = a.lin16[k];
+      const unsigned long long b0 = __ballot(j0 < n && cd0 <= uk);  // searchsorted(right=True)
+      const unsigned long long b1 = __ballot(j1 < n && cd1 <= uk);
+      const int cnt = __popcll(b0) + __popcll(b1);
+      if (lane == k) { ind = cnt; u = uk; }
+    }
+    if (lane < 16) {
+      const int below = max(ind - 1, 0), above = min(ind, n - 1);
+      const float cb = X[below], ca = X[above];
+      const float bb = Z[below], ba = Z[above];
+      float den = ca - cb;
+      den = (den < 1e-5f) ? 1.0f : den;
+      const float t = (u - cb) / den;
+      if (active) a.znew_out[ray * 16 + lane] = bb + t * (ba - bb);
+    }
+  }
+
+  if (a.do_finalize) {
+    // section lengths and mid-points of the final 128 samples
+    const float last = a.last_dist_ray ? a.last_dist_ray[ray] : a.last_dist;
+    const float d0 = Z[j0 + 1] - z0;
+    const float d1 = (j1 < 127) ? (Z[j1 + 1] - z1) : last;
+    if (active) {
+      a.dists[ray * 128 + j0] = d0;
+      a.dists[ray * 128 + j1] = d1;
+      a.tmid[ray * 128 + j0] = z0 + d0 * 0.5f;
+      a.tmid[ray * 128 + j1] = z1 + d1 * 0.5f;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// SDF -> alpha -> weights on the primary ray; depth, hit point, hit normal, specular cue; shadow-ray set-up
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float neus_alpha(float sdf, float gx, float gy, float gz, float dx, float dy, float dz,
+                                            float dist, float inv_s, float ca) {
+  const float true_cos = dx * gx + dy * gy + dz * gz;
+  const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.0f) * (1.0f - ca) + fmaxf(-true_cos, 0.0f) * ca);
+  const float en = sdf + iter_cos * dist * 0.5f;
+  const float ep = sdf - iter_cos * dist * 0.5f;
+  const float pc = sigmoidf_(ep * inv_s);
+  const float nc = sigmoidf_(en * inv_s);
+  return fminf(fmaxf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.0f), 1.0f);
+}
+
+struct CoreArgs {
+  const float* ro;
+  const float* rd;
+  const float* pl;
+  const float* sdf;     // [N,128]
+  const float* grad;    // [N*128,3]
+  const float* dists;   // [N,128]
+  const float* tmid;    // [N,128]
+  const float* lin64;
+  const float* t_rand_shadow;  // [N,64] or null
+  float* weights;       // [N,128]
+  float* inside;        // [N,128]
+  float* nhat;          // [N*128,3]
+  float* depth;         // [N]
+  float* wsum;          // [N]
+  float* cue;           // [N,4]
+  float* cue_b;         // [N,128,4] broadcast copy (RenderOutput.specular_cue) or null
+  float* srd;           // [N,3] shadow ray direction
+  float* slast;         // [N] light distance / 64
+  float* zs;            // [N,128] coarse shadow z (first 64)
+  float inv_s, cos_anneal, shadow_offset;
+  // per-roughness constants evaluated in double on the host, as Python does for the reference's scalars
+  // (models/neus_hint_model.py:604, 609): k, 1 - k, a^2, a^2 - 1
+  float kk[4], omk[4], a2[4], a2m1[4];
+  int zero_hints;  // geometry warm-up: cue = 0 (:617-619)
+  int nrays;
+};
+
+__global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * RAYS_PER_BLOCK + wave;
+  const bool active = ray_raw < a.nrays;
+  const long long ray = active ? ray_raw : a.nrays - 1;
+  const float ox = a.ro[ray * 3 + 0], oy = a.ro[ray * 3 + 1], oz = a.ro[ray * 3 + 2];
+  const float dx = a.rd[ray * 3 + 0], dy = a.rd[ray * 3 + 1], dz = a.rd[ray * 3 + 2];
+  float al[2], mid[2], nh[2][3], ins[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const long long P = ray * 128 + lane + 64 * e;
+    const float gx = a.grad[P * 3 + 0], gy = a.grad[P * 3 + 1], gz = a.grad[P * 3 + 2];
+    mid[e] = a.tmid[P];
+    al[e] = neus_alpha(a.sdf[P], gx, gy, gz, dx, dy, dz, a.dists[P], a.inv_s, a.cos_anneal);
+    const float px = ox + dx * mid[e], py = oy + dy * mid[e], pz = oz + dz * mid[e];
+    ins[e] = (sqrtf(px * px + py * py + pz * pz) < 1.0f) ? 1.0f : 0.0f;
+    const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
+    nh[e][0] = gx / gn;
+    nh[e][1] = gy / gn;
+    nh[e][2] = gz / gn;
+  }
+  float T0, T1;
+  excl_prod_128(1.0f - al[0] + 1e-7f, 1.0f - al[1] + 1e-7f, T0, T1);
+  const float w0 = al[0] * T0, w1 = al[1] * T1;
+  const float wsum = wave_sum(w0 + w1);
+  const float depth = wave_sum(mid[0] * w0 + mid[1] * w1);
+  const float hnx = wave_sum(nh[0][0] * w0 + nh[1][0] * w1);
+  const float hny = wave_sum(nh[0][1] * w0 + nh[1][1] * w1);
+  const float hnz = wave_sum(nh[0][2] * w0 + nh[1][2] * w1);
+
+  // ---- per-ray quantities (computed redundantly on all lanes; cheap) ----
+  const float hx = ox + dx * depth, hy = oy + dy * depth, hz = oz + dz * depth;  // hit point
+  const float plx = a.pl[ray * 3 + 0], ply = a.pl[ray * 3 + 1], plz = a.pl[ray * 3 + 2];
+  const float hnn = fmaxf(sqrtf(hnx * hnx + hny * hny + hnz * hnz), 1e-12f);
+  const float nx = hnx / hnn, ny = hny / hnn, nz = hnz / hnn;
+  // l, v, h
+  float lx = plx - hx, ly = ply - hy, lz = plz - hz;
+  const float ln = fmaxf(sqrtf(lx * lx + ly * ly + lz * lz), 1e-12f);
+  lx /= ln; ly /= ln; lz /= ln;
+  float vx = -dx, vy = -dy, vz = -dz;
+  const float vn = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+  vx /= vn; vy /= vn; vz /= vn;
+  float hvx = lx + vx, hvy = ly + vy, hvz = lz + vz;
+  const float hvn = fmaxf(sqrtf(hvx * hvx + hvy * hvy + hvz * hvz), 1e-12f);
+  hvx /= hvn; hvy /= hvn; hvz /= hvn;
+  auto clip01 = [](float x) { return fminf(fmaxf(x, 0.0f), 1.0f); };
+  const float ndl = clip01(nx * lx + ny * ly + nz * lz);
+  const float ndv = clip01(nx * vx + ny * vy + nz * vz);
+  const float ndh = clip01(nx * hvx + ny * hvy + nz * hvz);
+  const float hdv = clip01(hvx * vx + hvy * vy + hvz * vz);
+  const float ndh2 = ndh * ndh;
+  float cue[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float g1 = ndv / (ndv * a.omk[i] + a.kk[i]);
+    const float g2 = ndl / (ndl * a.omk[i] + a.kk[i]);
+    const float dn = ndh2 * a.a2m1[i] + 1.0f;
+    const float ndf = a.a2[i] / (3.14159265358979323846f * (dn * dn));
+    const float om = 1.0f - hdv;
+    const float f = 0.04f + 0.96f * (om * om * om * om * om);
+    cue[i] = a.zero_hints ? 0.0f : ndf * (g1 * g2) * f / (4.0f * ndv + 1e-3f);
+  }
+  // shadow ray: light -> hit point (get_visibility :380-386)
+  const float svx = hx - plx, svy = hy - ply, svz = hz - plz;
+  const float L = sqrtf(svx * svx + svy * svy + svz * svz);
+
+  if (active) {
+    a.weights[ray * 128 + lane] = w0;
+    a.weights[ray * 128 + lane + 64] = w1;
+    a.inside[ray * 128 + lane] = ins[0];
+    a.inside[ray * 128 + lane + 64] = ins[1];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.nhat[(ray * 128 + lane + 64 * e) * 3 + c] = nh[e][c];
+    if (a.cue_b) {
+      const f32x4 cv = {cue[0], cue[1], cue[2], cue[3]};
+      reinterpret_cast<f32x4*>(a.cue_b)[ray * 128 + lane] = cv;
+      reinterpret_cast<f32x4*>(a.cue_b)[ray * 128 + lane + 64] = cv;
+    }
+    // coarse shadow samples z_j = lin[j] * L * (1 - offset)  (+ stratified jitter in training, :388-395)
+    const float om = 1.0f - a.shadow_offset;
+    float zj = a.lin64[lane] * L * om;
+    if (a.t_rand_shadow) {
+      const float zp = (lane > 0) ? a.lin64[lane - 1] * L * om : zj;
+      const float zn = (lane < 63) ? a.lin64[lane + 1] * L * om : zj;
+      const float lower = (lane > 0) ? 0.5f * (zj + zp) : zj;
+      const float upper = (lane < 63) ? 0.5f * (zn + zj) : zj;
+      zj = lower + (upper - lower) * a.t_rand_shadow[ray * 64 + lane];
+    }
+    a.zs[ray * 128 + lane] = zj;
+    if (lane == 0) {
+      a.depth[ray] = depth;
+      a.wsum[ray] = wsum;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a.cue[ray * 4 + i] = cue[i];
+      a.srd[ray * 3 + 0] = svx / L;
+      a.srd[ray * 3 + 1] = svy / L;
+      a.srd[ray * 3 + 2] = svz / L;
+      a.slast[ray] = L / 64.0f;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// shadow ray: alpha -> transmittance in front of the last sample; then the per-ray encodings for the colour net
+// -------------------------------------------------------------------------------------------------
+struct ShadowArgs {
+  const float* rd;      // primary ray direction (view)
+  const float* pl;      // light position
+  const float* srd;     // shadow ray direction
+  const float* sdf;     // [N,128] along the shadow ray
+  const float* grad;    // [N*128,3]
+  const float* dists;   // [N,128]
+  const float* cue;     // [N,4]
+  float* vis;           // [N]
+  float* raymisc;       // [N,RAYMISC_STRIDE]
+  float inv_s, cos_anneal;
+  int nrays;
+  int zero_hints;       // geometry warm-up: hints are zero (models/neus_hint_model.py:577-579, 617-619)
+};
+
+__device__ __forceinline__ float enc4_entry_dyn(const float* x, int D, int e) {
+  if (e < D) return x[e];
+  int idx = e - D;
+  float ph = 0.0f;
+  if (idx >= D * 4) { idx -= D * 4; ph = NRH_HALF_PI; }
+  const int d = idx >> 2, k = idx & 3;
+  return sin_cw(x[d] * (float)(1 << k) + ph);
+}
+
+__global__ __launch_bounds__(256) void shadow_finish_kernel(const ShadowArgs a) {
+  __shared__ float sv[RAYS_PER_BLOCK][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * RAYS_PER_BLOCK + wave;
+  const bool active = ray_raw < a.nrays;
+  const long long ray = active ? ray_raw : a.nrays - 1;
+  float vis = 0.0f;
+  if (!a.zero_hints) {
+    const float dx = a.srd[ray * 3 + 0], dy = a.srd[ray * 3 + 1], dz = a.srd[ray * 3 + 2];
+    float al[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const long long P = ray * 128 + lane + 64 * e;
+      al[e] = neus_alpha(a.sdf[P], a.grad[P * 3 + 0], a.grad[P * 3 + 1], a.grad[P * 3 + 2], dx, dy, dz, a.dists[P],
+                         a.inv_s, a.cos_anneal);
+    }
+    float T0, T1;
+    excl_prod_128(1.0f - al[0] + 1e-7f, 1.0f - al[1] + 1e-7f, T0, T1);
+    vis = __shfl(T1, 63, 64);  // exclusive product at j = 127 (models/neus_hint_model.py:429-432)
+  }
+  float* V = sv[wave];
+  if (lane < 3) V[lane] = a.rd[ray * 3 + lane];
+  if (lane >= 3 && lane < 6) V[lane] = a.pl[ray * 3 + lane - 3];
+  if (lane == 6) V[6] = vis;
+  if (lane >= 7 && lane < 11) V[lane] = a.zero_hints ? 0.0f : a.cue[ray * 4 + lane - 7];
+  __syncthreads();
+  if (active) {
+    if (lane == 0) a.vis[ray] = vis;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = lane + 64 * e;
+      if (i < 99) {
+        float v;
+        if (i < 27) v = enc4_entry_dyn(V + 0, 3, i);        // enc4(view dir)
+        else if (i < 54) v = enc4_entry_dyn(V + 3, 3, i - 27);  // enc4(light position, un-normalised)
+        else if (i < 63) v = enc4_entry_dyn(V + 6, 1, i - 54);  // enc4(visibility)
+        else v = enc4_entry_dyn(V + 7, 4, i - 63);              // enc4(specular cue)
+        a.raymisc[ray * RAYMISC_STRIDE + i] = v;
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// rgb = sum_j c_j w_j + background * (1 - sum_j w_j)
+// -------------------------------------------------------------------------------------------------
+struct CompositeArgs {
+  const float* color;    // [N*128,3]
+  const float* weights;  // [N,128]
+  const float* wsum;     // [N]
+  const float* bg;       // [3] or null
+  float* rgb;            // [N,3]
+  int nrays;
+};
+__global__ __launch_bounds__(256) void composite_kernel(const CompositeArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * RAYS_PER_BLOCK + wave;
+  const bool active = ray_raw < a.nrays;
+  const long long ray = active ? ray_raw : a.nrays - 1;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const long long P = ray * 128 + lane + 64 * e;
+    const float w = a.weights[P];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += a.color[P * 3 + c] * w;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
+  if (active && lane == 0) {
+    const float ws = a.wsum[ray];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rgb[ray * 3 + c] = acc[c] + (a.bg ? a.bg[c] * (1.0f - ws) : 0.0f);
+  }
+}
+
+}  // namespace nrh

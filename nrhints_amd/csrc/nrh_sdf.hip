@@ -1,0 +1,267 @@
+// SDF network on gfx950: value, appearance feature and analytic d(sdf)/dx in ONE pass per point.
+//
+// Replaces, per point, the reference's  SDFNetwork.forward  (fields/sdf_field.py:106-123),  .sdf  (:125-126)
+// and  .gradient  (:136-148, autograd)  - i.e. up to three full forwards plus an autograd sweep
+// (models/neus_hint_model.py:504, :335, :336) - by one forward that keeps sigma'(z) = sigmoid(100 z) of
+// every activation and one hand-written reverse chain through W^T.  Exact fp32 (v_mfma_f32_16x16x4_f32).
+//
+// Layer plan (all GEMMs are 256x256 except the first/last):
+//   L0   39(->48) -> 256   softplus100        in = NeRF encoding of 3x, computed in registers
+//   L1,L2          256 -> 256
+//   L3             256 -> 217(->256, zero rows); outputs 217..255 are REPLACED by the 39 embedding values, which
+//                  reproduces cat([h, embed]) of the skip connection with no data movement (fields/sdf_field.py:114)
+//   L4..L7         256 -> 256   (W4 pre-scaled by 1/sqrt(2))
+//   head           sdf = (w_s . h + b_s) / 3              (VALU dot + 2 shuffles)
+//   FEAT           256 -> 256, no activation              (MODE 2 only)
+//   R7..R1         g <- W_l^T (sigma'_l * g)              (MODE >= 1)
+//   R0             39(->64) <- 256, then d/dx of the encoding
+#include "nrh_mlp.h"
+
+namespace nrh {
+
+struct SdfArgs {
+  const float* w;      // packed stages (SDF_PACKED_FLOATS)
+  const float* b;      // [9][256]
+  const float* head;   // [257]
+  const float* ro;     // [nrays,3]
+  const float* rd;     // [nrays,3]
+  const float* t;      // ray parameter of point (ray, j): t[ray * t_stride + j]
+  float* sdf;          // sdf[ray * sdf_stride + j]
+  float* grad;         // [npts,3] (MODE >= 1)
+  float* feat;         // [ntiles][16][64][4] D-layout tiles (MODE 2)
+  float* scratch;      // gridDim.x * 4 * SDF_SCRATCH_FLOATS_PER_WAVE (MODE >= 1)
+  long long npts;
+  int n_per_ray;
+  int t_stride;
+  int sdf_stride;
+  int ntile_groups;    // ceil(npts / 64)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  int par = 0;
+  float* const scr = (MODE >= 1) ? a.scratch + (size_t)(blockIdx.x * 4 + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
+
+  dma_chunk(a.w + SDF_OFF_L0, smem, 6, wave, lane);
+  __syncthreads();
+
+  for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
+    const long long tile = (long long)tg * 4 + wave;
+    const long long P = tile * TILE_PTS + j;
+    const bool valid = P < a.npts;
+    const long long Pc = valid ? P : a.npts - 1;
+    const long long ray = Pc / a.n_per_ray;
+    const int jj = (int)(Pc - ray * a.n_per_ray);
+    const float tt = a.t[ray * a.t_stride + jj];
+    float x3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt) * 3.0f;  // inputs * scale
+
+    // ---- L0: embedding -> 256 ----
+    float emb[12];
+    {
+      float all[39];
+      nerf_enc_all<3, 6>(x3, all);
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) emb[b * 4 + r] = sel_q<39>(all, b * 16 + r, q);  // entry 16b + 4q + r
+    }
+    float h[64];
+    {
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch) * 16 + 4 * q);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch + 1) * 16 + 4 * q);
+        f32x4 d0, d1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t0, t1;
+          softplus100(acc0[r] + b0[r], h[ch * 8 + r], t0);
+          softplus100(acc1[r] + b1[r], h[ch * 8 + 4 + r], t1);
+          d0[r] = t0;
+          d1[r] = t1;
+        }
+        if (MODE >= 1) {
+          *reinterpret_cast<f32x4*>(scr + ((0 * 16 + 2 * ch) * 64 + lane) * 4) = d0;
+          *reinterpret_cast<f32x4*>(scr + ((0 * 16 + 2 * ch + 1) * 64 + lane) * 4) = d1;
+        }
+      };
+      run_stage<3, 8, false>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, epi, wave, lane);
+    }
+
+    // ---- steps 1..15: L1..L7, FEAT, R7..R1 share one 256x256 body ----
+    float skip[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) skip[i] = 0.0f;
+    const int last_step = (MODE == 0) ? 7 : 15;
+    float head_part = 0.0f;
+    for (int s = 1; s <= last_step; ++s) {
+      if (MODE == 1 && s == 8) continue;  // no feature head
+      if (MODE == 0 && s > 7) break;
+      const float* wcur;
+      const float* wnxt;
+      int npc = 32;
+      if (s <= 7) wcur = a.w + sdf_off_L(s);
+      else if (s == 8) wcur = a.w + SDF_OFF_FEAT;
+      else wcur = a.w + sdf_off_R(16 - s);
+      if (s < 7) wnxt = a.w + sdf_off_L(s + 1);
+      else if (s == 7) {
+        if (MODE == 0) { wnxt = a.w + SDF_OFF_L0; npc = 6; }
+        else if (MODE == 1) wnxt = a.w + sdf_off_R(7);
+        else wnxt = a.w + SDF_OFF_FEAT;
+      } else if (s == 8) wnxt = a.w + sdf_off_R(7);
+      else if (s < 15) wnxt = a.w + sdf_off_R(16 - s - 1);
+      else wnxt = a.w + SDF_OFF_R0;
+
+      if (MODE >= 1 && s == 9) {
+        // start of the reverse chain: t_7 = sigma'_7 * (w_s / 3), written by L7's epilogue
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          const f32x4 dv = *reinterpret_cast<const f32x4*>(scr + ((7 * 16 + b) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[b * 4 + r] = dv[r];
+        }
+      }
+
+      float ho[64];
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
+        if (s <= 7) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch) * 16 + 4 * q);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch + 1) * 16 + 4 * q);
+          f32x4 d0, d1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t0, t1;
+            softplus100(acc0[r] + b0[r], ho[ch * 8 + r], t0);
+            softplus100(acc1[r] + b1[r], ho[ch * 8 + 4 + r], t1);
+            d0[r] = t0;
+            d1[r] = t1;
+          }
+          if (ch >= 6 && s == 3) {
+            // skip connection: features 217..255 of L4's input are the embedding (fields/sdf_field.py:113-114)
+            float all[39];
+            nerf_enc_all<3, 6>(x3, all);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e1 = (2 * ch + 1) * 16 + 4 * q + r - 217;
+              if (ch == 7) {  // block 14: always >= 217
+                ho[ch * 8 + r] = sel_q<39>(all, (2 * ch) * 16 + r - 217, q);
+                d0[r] = 0.0f;
+              }
+              if (e1 >= 0) {  // block 13 (partly) or 15
+                ho[ch * 8 + 4 + r] = sel_q<39>(all, (2 * ch + 1) * 16 + r - 217, q);
+                d1[r] = 0.0f;
+              }
+            }
+          }
+          if (s == 7) {
+            // sdf head folded into L7's epilogue: partial w_s . h8, and t_7 = sigma'_7 * w_s / 3 for the reverse chain
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              head_part += w0[r] * ho[ch * 8 + r];
+              head_part += w1[r] * ho[ch * 8 + 4 + r];
+              d0[r] = d0[r] * (w0[r] / 3.0f);
+              d1[r] = d1[r] * (w1[r] / 3.0f);
+            }
+          }
+          if (MODE >= 1) {
+            *reinterpret_cast<f32x4*>(scr + ((s * 16 + 2 * ch) * 64 + lane) * 4) = d0;
+            *reinterpret_cast<f32x4*>(scr + ((s * 16 + 2 * ch + 1) * 64 + lane) * 4) = d1;
+          }
+        } else if (s == 8) {
+          if (MODE == 2) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + 8 * 256 + (2 * ch) * 16 + 4 * q);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + 8 * 256 + (2 * ch + 1) * 16 + 4 * q);
+            if (tile * TILE_PTS < a.npts) {
+              float* ft = a.feat + (size_t)tile * (16 * 256);
+              *reinterpret_cast<f32x4*>(ft + ((2 * ch) * 64 + lane) * 4) = acc0 + b0;
+              *reinterpret_cast<f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4) = acc1 + b1;
+            }
+          }
+        } else {
+          if (MODE >= 1) {
+            const int l = 16 - s;  // this stage multiplied by W_l^T; its output feeds layer l-1's sigma'
+            if (l == 4 && ch >= 6) {
+              // gradient w.r.t. the embedding through the skip connection (inputs 217..255 of L4)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (2 * ch >= 13) skip[(2 * ch - 13) * 4 + r] = acc0[r];
+                skip[(2 * ch + 1 - 13) * 4 + r] = acc1[r];
+              }
+            }
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(scr + (((l - 1) * 16 + 2 * ch) * 64 + lane) * 4);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(scr + (((l - 1) * 16 + 2 * ch + 1) * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              ho[ch * 8 + r] = acc0[r] * d0[r];
+              ho[ch * 8 + 4 + r] = acc1[r] * d1[r];
+            }
+          }
+        }
+      };
+      run_stage<16, 8, false>(wcur, wnxt, npc, smem, par, h, nullptr, epi, wave, lane);
+
+      if (s == 7) {
+        // sdf head: (w_s . h8 + b_s) / scale   (fields/sdf_field.py:121)
+        float part = head_part;
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (valid && q == 0) a.sdf[ray * a.sdf_stride + jj] = (part + a.head[256]) / 3.0f;
+      }
+      if (s != 8) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) h[i] = ho[i];
+      }
+    }
+
+    if (MODE >= 1) {
+      // ---- R0: gradient w.r.t. the 39 embedding entries, then chain through the encoding ----
+      float ge[16];
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ge[ch * 8 + r] = acc0[r]; ge[ch * 8 + 4 + r] = acc1[r]; }
+      };
+      run_stage<16, 2, false>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 6, smem, par, h, nullptr, epi, wave, lane);
+
+      float dx[3] = {0.f, 0.f, 0.f};
+      {
+        float dc[39];
+        nerf_enc_dall<3, 6>(x3, dc);
+        // entry e = 16b + 4q + r of the R0 output, entry e = 16(b+13) + 4q + r - 217 of the skip part;
+        // every candidate q is enumerated statically so nothing is indexed at run time
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const int e = b * 16 + 4 * qq + r;
+              if (e < 39) dx[nerf_enc_dim<3, 6>(e)] += (q == qq) ? ge[b * 4 + r] * dc[e] : 0.0f;
+              const int es = (b + 13) * 16 + 4 * qq + r - 217;
+              if (es >= 0 && es < 39) dx[nerf_enc_dim<3, 6>(es)] += (q == qq) ? skip[b * 4 + r] * dc[es] : 0.0f;
+            }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dx[c] += __shfl_xor(dx[c], 16, 64);
+        dx[c] += __shfl_xor(dx[c], 32, 64);
+      }
+      if (valid && q == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.grad[P * 3 + c] = dx[c] * 3.0f;  // d(3x)/dx
+      }
+    }
+  }
+}
+
+template __global__ void sdf_kernel<0>(const SdfArgs);
+template __global__ void sdf_kernel<1>(const SdfArgs);
+template __global__ void sdf_kernel<2>(const SdfArgs);
+
+}  // namespace nrh

@@ -1,0 +1,81 @@
+"""Thin tensor-level wrappers over the fine-grained C entry points (include/nrhints_hip.h).
+
+``NeuSHintRenderer.forward`` does not use these (it makes one fused C call per chunk); they exist so that each
+kernel can be parity-tested in isolation and so that callers such as mesh extraction can query the SDF alone.
+All tensors are float32, contiguous, on the GPU.  No fallback: errors raise.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib, packing
+
+
+def _scratch(device) -> torch.Tensor:
+    lib = _lib.load()
+    n = lib.nrh_mlp_grid() * 4 * packing.SDF_SCRATCH_FLOATS_PER_WAVE
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def sdf_eval(mode: int, sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_stride: Optional[int] = None,
+             scratch: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """SDF (mode 0), + gradient (mode 1), + feature (mode 2) at points ro[ray] + rd[ray] * t[ray, j].
+
+    Returns (sdf [nrays, n_per_ray], grad [nrays*n_per_ray, 3] | None, feat tiles | None)."""
+    lib = _lib.load()
+    nrays = ro.shape[0]
+    t_stride = n_per_ray if t_stride is None else t_stride
+    dev = ro.device
+    sdf = torch.empty(nrays, n_per_ray, dtype=torch.float32, device=dev)
+    npts = nrays * n_per_ray
+    grad = torch.empty(npts, 3, dtype=torch.float32, device=dev) if mode >= 1 else None
+    feat = torch.empty(((npts + 15) // 16) * 4096, dtype=torch.float32, device=dev) if mode == 2 else None
+    if mode >= 1 and scratch is None:
+        scratch = _scratch(dev)
+    P = _lib.ptr
+    rc = lib.nrh_sdf_eval(mode, P(sdf_w), P(sdf_b), P(sdf_head), P(ro), P(rd), P(t), t_stride, n_per_ray, nrays,
+                          P(sdf), n_per_ray, P(grad), P(feat), P(scratch) if mode >= 1 else None, _lib.stream_handle())
+    _lib.check(rc, "nrh_sdf_eval")
+    return sdf, grad, feat
+
+
+def sdf_at_points(mode: int, sdf_w, sdf_b, sdf_head, pts):
+    """Convenience: free points [P,3] (one 'ray' per point, t = 0)."""
+    zeros = torch.zeros_like(pts)
+    t = torch.zeros(pts.shape[0], dtype=torch.float32, device=pts.device)
+    return sdf_eval(mode, sdf_w, sdf_b, sdf_head, pts.contiguous(), zeros, t, 1)
+
+
+def sampler_step(ro, rd, z, s, n: int, *, znew_in=None, snew_in=None, upsample_inv_s: Optional[float] = None,
+                 lin16=None, finalize: bool = False, last_dist: float = 2.0 / 64, last_dist_ray=None):
+    """One launch of the hierarchical sampler.  ``z``/``s`` ([nrays,128]) are updated in place by a merge.
+    Returns (znew_out [nrays,16] | None, tmid | None, dists | None)."""
+    lib = _lib.load()
+    nrays = ro.shape[0]
+    dev = ro.device
+    do_merge = znew_in is not None
+    merge_sdf = snew_in is not None
+    do_up = upsample_inv_s is not None
+    znew_out = torch.empty(nrays, 16, dtype=torch.float32, device=dev) if do_up else None
+    tmid = torch.empty(nrays, 128, dtype=torch.float32, device=dev) if finalize else None
+    dists = torch.empty(nrays, 128, dtype=torch.float32, device=dev) if finalize else None
+    P = _lib.ptr
+    rc = lib.nrh_sampler_step(P(ro), P(rd), P(z), P(s), P(znew_in), P(snew_in), P(znew_out), P(lin16),
+                              P(last_dist_ray), P(tmid), P(dists), float(upsample_inv_s or 0.0), float(last_dist),
+                              nrays, n, int(do_merge), int(merge_sdf), int(do_up), int(finalize), _lib.stream_handle())
+    _lib.check(rc, "nrh_sampler_step")
+    return znew_out, tmid, dists
+
+
+def color_eval(col_w, col_b, feat_tiles, ro, rd, tmid, nhat, raymisc) -> torch.Tensor:
+    """Reflectance MLP for nrays x 128 samples -> [nrays*128, 3]."""
+    lib = _lib.load()
+    nrays = ro.shape[0]
+    color = torch.empty(nrays * 128, 3, dtype=torch.float32, device=ro.device)
+    P = _lib.ptr
+    rc = lib.nrh_color_eval(P(col_w), P(col_b), P(feat_tiles), P(ro), P(rd), P(tmid), P(nhat), P(raymisc), nrays,
+                            P(color), _lib.stream_handle())
+    _lib.check(rc, "nrh_color_eval")
+    return color

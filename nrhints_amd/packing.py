@@ -1,0 +1,139 @@
+"""Host-side parameter packing for the gfx950 MLP kernels (torch ops only, differentiable).
+
+The kernels (csrc/nrh_mlp.h) consume every GEMM stage as chunks of two 16-row output blocks; inside a chunk the
+A operands of ``v_mfma_f32_16x16x4_f32`` for (output block ob, K block kb) are one 1 KiB line, lane-linear:
+
+    packed[chunk][obi][kb][lane][c] = W[(2*chunk + obi)*16 + (lane & 15)][kb*16 + 4*(lane >> 4) + c]
+
+so that one ``ds_read_b128`` per lane fetches the four A values of four consecutive MFMAs and the copy
+global -> LDS is a straight ``global_load_lds_dwordx4`` stream.
+
+Weight-norm is folded here (W = g * v / ||v||_row, reference fields/sdf_field.py:81-82 /
+fields/reflectance_network.py:61-62), the 1/sqrt(2) of the skip connection (fields/sdf_field.py:114) is folded
+into W4, and the reflectance net's first-layer columns are permuted to the order the colour kernel produces
+its inputs in (csrc/nrh_color.hip).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import torch
+
+# geometry shared with csrc/nrh_mlp.h
+SDF_L0_FLOATS = 8 * 2 * 3 * 256
+SDF_REG_FLOATS = 8 * 2 * 16 * 256
+SDF_R0_FLOATS = 2 * 2 * 16 * 256
+SDF_PACKED_FLOATS = SDF_L0_FLOATS + 15 * SDF_REG_FLOATS + SDF_R0_FLOATS
+SDF_BIAS_FLOATS = 9 * 256
+SDF_HEAD_FLOATS = 257
+COL_C0B_FLOATS = 8 * 2 * 7 * 256
+COL_PACKED_FLOATS = SDF_REG_FLOATS + COL_C0B_FLOATS + 3 * SDF_REG_FLOATS + 2 * 16 * 256
+COL_BIAS_FLOATS = 4 * 256 + 16
+RAYMISC_STRIDE = 100
+SDF_SCRATCH_FLOATS_PER_WAVE = 8 * 16 * 256
+
+
+def fold_weight_norm(g: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """Dense weight of an old-style ``nn.utils.weight_norm`` Linear (dim=0): W = v * (g / ||v||_row)."""
+    return v * (g / v.norm(dim=1, keepdim=True))
+
+
+def pack_stage(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """Pack a dense [out,in] matrix, zero-padded to [rows, cols] (rows % 32 == 0, cols % 16 == 0)."""
+    assert rows % 32 == 0 and cols % 16 == 0 and w.shape[0] <= rows and w.shape[1] <= cols
+    wp = torch.nn.functional.pad(w, (0, cols - w.shape[1], 0, rows - w.shape[0]))
+    nch, kb = rows // 32, cols // 16
+    # [chunk, obi, i, kb, q, c] -> [chunk, obi, kb, q, i, c];  lane = q*16 + i
+    return wp.reshape(nch, 2, 16, kb, 4, 4).permute(0, 1, 3, 4, 2, 5).reshape(-1)
+
+
+def _pad_vec(b: torch.Tensor, n: int) -> torch.Tensor:
+    return b if b.shape[0] == n else torch.cat([b, b.new_zeros(n - b.shape[0])])
+
+
+def dense_params(state: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, torch.Tensor]:
+    """Weight-norm-folded dense matrices from a reference-layout state dict / parameter dict."""
+    def lin(name):
+        return (fold_weight_norm(state[f"{prefix}{name}.weight_g"], state[f"{prefix}{name}.weight_v"]),
+                state[f"{prefix}{name}.bias"])
+    out = {}
+    for i in range(8):
+        out[f"sdf_w{i}"], out[f"sdf_b{i}"] = lin(f"sdf_network.lin{i}")
+    out["sdf_head_w"], out["sdf_head_b"] = lin("sdf_network.out_sdf")
+    out["feat_w"], out["feat_b"] = lin("sdf_network.out_feat")
+    for i in range(5):
+        out[f"col_w{i}"], out[f"col_b{i}"] = lin(f"color_network.lin{i}")
+    return out
+
+
+def check_default_shapes(d: Dict[str, torch.Tensor]) -> None:
+    """The kernels are compiled for the default nr-hints network shape."""
+    want = {"sdf_w0": (256, 39), "sdf_w1": (256, 256), "sdf_w2": (256, 256), "sdf_w3": (217, 256),
+            "sdf_w4": (256, 256), "sdf_w5": (256, 256), "sdf_w6": (256, 256), "sdf_w7": (256, 256),
+            "sdf_head_w": (1, 256), "feat_w": (256, 256), "col_w0": (256, 361), "col_w1": (256, 256),
+            "col_w2": (256, 256), "col_w3": (256, 256), "col_w4": (3, 256)}
+    for k, shp in want.items():
+        if tuple(d[k].shape) != shp:
+            raise ValueError(f"unsupported network shape: {k} is {tuple(d[k].shape)}, the HIP kernels are built for {shp} "
+                             "(default nr-hints config: d_hidden=256, 8/4 layers, skip_in=[4], multires 6/4, "
+                             "shadow + 4-roughness specular hints)")
+
+
+def pack_sdf(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (packed stages [SDF_PACKED_FLOATS], biases [9*256], head [257]) in kernel execution order
+    L0 | L1..L7 | FEAT | R7..R1 | R0  (R_l = W_l^T for the analytic reverse chain)."""
+    w = [d[f"sdf_w{i}"] for i in range(8)]
+    w4 = w[4] / math.sqrt(2.0)           # cat([h, embed]) / sqrt(2) folded into the weights
+    fwd = [w[0], w[1], w[2], w[3], w4, w[5], w[6], w[7]]
+    parts = [pack_stage(fwd[0], 256, 48)]
+    parts += [pack_stage(fwd[l], 256, 256) for l in range(1, 8)]
+    parts.append(pack_stage(d["feat_w"], 256, 256))
+    parts += [pack_stage(fwd[l].t(), 256, 256) for l in range(7, 0, -1)]
+    parts.append(pack_stage(fwd[0].t(), 64, 256))
+    packed = torch.cat(parts)
+    assert packed.numel() == SDF_PACKED_FLOATS
+    bias = torch.cat([_pad_vec(d[f"sdf_b{i}"], 256) for i in range(8)] + [d["feat_b"]])
+    head = torch.cat([d["sdf_head_w"].reshape(-1), d["sdf_head_b"].reshape(-1)])
+    return packed.contiguous(), bias.contiguous(), head.contiguous()
+
+
+def color_input_permutation() -> Tuple[torch.Tensor, torch.Tensor]:
+    """Column indices of the reference's 361-wide reflectance input
+    [pts 0:3 | enc4(view) 3:30 | normal 30:33 | enc4(pl) 33:60 | feat 60:316 | enc4(vis) 316:325 | enc4(cue) 325:361]
+    (fields/reflectance_network.py:77-82) in kernel order: (feature part [256], other part [105] =
+    [pts, normal, enc4(view), enc4(pl), enc4(vis), enc4(cue)])."""
+    feat = torch.arange(60, 316)
+    misc = torch.cat([torch.arange(0, 3), torch.arange(30, 33), torch.arange(3, 30), torch.arange(33, 60),
+                      torch.arange(316, 325), torch.arange(325, 361)])
+    return feat, misc
+
+
+def pack_color(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (packed stages [COL_PACKED_FLOATS], biases [4*256+16]) in order C0a | C0b | C1 | C2 | C3 | C4."""
+    fi, mi = color_input_permutation()
+    w0 = d["col_w0"]
+    parts = [pack_stage(w0[:, fi.to(w0.device)], 256, 256), pack_stage(w0[:, mi.to(w0.device)], 256, 112)]
+    parts += [pack_stage(d[f"col_w{l}"], 256, 256) for l in (1, 2, 3)]
+    parts.append(pack_stage(d["col_w4"], 32, 256))
+    packed = torch.cat(parts)
+    assert packed.numel() == COL_PACKED_FLOATS
+    bias = torch.cat([d["col_b0"], d["col_b1"], d["col_b2"], d["col_b3"], _pad_vec(d["col_b4"], 16)])
+    return packed.contiguous(), bias.contiguous()
+
+
+def feat_tiles_to_rows(tiles: torch.Tensor, npts: int) -> torch.Tensor:
+    """D-layout feature tiles [ntiles,16(block),64(lane),4(r)] -> [npts,256]
+    (lane = q*16 + j; feature = 16*block + 4*q + r; point = 16*tile + j)."""
+    nt = tiles.numel() // 4096
+    t = tiles.reshape(nt, 16, 4, 16, 4)            # tile, block, q, j, r
+    return t.permute(0, 3, 1, 2, 4).reshape(nt * 16, 256)[:npts]
+
+
+def rows_to_feat_tiles(rows: torch.Tensor) -> torch.Tensor:
+    """[npts,256] -> D-layout tiles (npts padded up to a multiple of 16 with zeros)."""
+    npts = rows.shape[0]
+    nt = (npts + 15) // 16
+    if nt * 16 != npts:
+        rows = torch.cat([rows, rows.new_zeros(nt * 16 - npts, 256)], 0)
+    return rows.reshape(nt, 16, 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)

@@ -1,0 +1,264 @@
+"""``NeuSHintRenderer`` - drop-in for the reference class of the same name (models/neus_hint_model.py:236).
+
+Same constructor argument (a ``NeuSModelConfig`` tree), same ``forward(ray_bundle, is_training, background_rgb,
+global_step) -> RenderOutput`` signature, same parameter / state-dict key names
+(``sdf_network.lin{0..7}.{bias,weight_g,weight_v}``, ``sdf_network.out_sdf.*``, ``sdf_network.out_feat.*``,
+``deviation_network.variance``, ``color_network.lin{0..4}.*`` - SURVEY.md §5), so released reference checkpoints
+load with ``load_state_dict`` and ``pipelines/base_pipeline.py:30`` can construct it unchanged.
+
+All arithmetic of the forward runs in libnrhints_hip.so (hand-written gfx950 kernels) through the C ABI; this
+module only owns the parameters, packs them, sizes the workspace and enqueues ONE C call per ray chunk on the
+current torch stream.  There is no PyTorch/CPU fallback: without the extension or without a GPU it raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, packing
+from .config import NeuSModelConfig, unsupported_reason
+from .containers import RayBundle, RenderOutput
+
+N_SAMPLES_TOTAL = 128
+
+
+def _apply_wn(lin: nn.Module) -> nn.Module:
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return nn.utils.weight_norm(lin)  # old-style hook: parameters weight_g / weight_v, as in the reference
+
+
+class SDFNetwork(nn.Module):
+    """Parameter container + SAL geometric initialisation of the SDF MLP (fields/sdf_field.py:40-104).
+
+    The initial zero level set is a sphere of radius ``init_bias``.  Layer/in/out dims: 39->256, 256->256 x2,
+    256->217, 256->256 x4, heads 256->1 and 256->256.
+    """
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        emb = config.d_in * (2 * config.multi_res + 1)
+        dims = [emb] + [config.d_hidden] * config.n_layers + [config.d_out_feat + 1]
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 2):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in config.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l], out_dim)
+            if config.geometric_init:
+                std = math.sqrt(2.0) / math.sqrt(out_dim)
+                nn.init.constant_(lin.bias, 0.0)
+                if l == 0:
+                    # only the raw xyz columns start non-zero: the net initially ignores the sinusoids
+                    nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    nn.init.normal_(lin.weight[:, :3], 0.0, std)
+                else:
+                    nn.init.normal_(lin.weight, 0.0, std)
+                    if l in config.skip_in:
+                        nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+            if config.weight_norm:
+                lin = _apply_wn(lin)
+            setattr(self, f"lin{l}", lin)
+        bias = config.init_bias * config.scale
+        for name, out_dim in (("sdf", 1), ("feat", dims[-1] - 1)):
+            lin = nn.Linear(dims[-2], out_dim)
+            if config.geometric_init:
+                sign = -1.0 if config.inside_outside else 1.0
+                nn.init.normal_(lin.weight, mean=sign * math.sqrt(math.pi) / math.sqrt(dims[-1]), std=0.0001)
+                nn.init.constant_(lin.bias, -sign * bias)
+            if config.weight_norm:
+                lin = _apply_wn(lin)
+            setattr(self, f"out_{name}", lin)
+
+
+class ReflectanceNetwork(nn.Module):
+    """Parameter container of the reflectance MLP (fields/reflectance_network.py:26-66): 361 -> 4x256 -> 3."""
+
+    def __init__(self, d_feature: int, d_in: int, d_out: int, config, n_cue: int):
+        super().__init__()
+        pe3 = 3 * 2 * config.multi_res          # extra dims of enc(view) / enc(pl) beyond the raw vector
+        d0 = d_in + d_feature + 2 * pe3 + 1 * 2 * config.multi_res + n_cue * 2 * config.multi_res
+        dims = [d0] + [config.d_hidden] * config.n_layers + [d_out]
+        for l in range(len(dims) - 1):
+            lin = nn.Linear(dims[l], dims[l + 1])
+            if config.weight_norm:
+                lin = _apply_wn(lin)
+            setattr(self, f"lin{l}", lin)
+
+
+class SingleVarianceNetwork(nn.Module):
+    """NeuS sharpness: inv_s = exp(10 * variance) (models/neus_hint_model.py:104-110)."""
+
+    def __init__(self, init_val: float):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(init_val)))
+
+
+class NeuSHintRenderer(nn.Module):
+    #: rays per C call; bounds the workspace (about 145 KB per ray + 268 MB of gradient scratch)
+    max_chunk_rays = 32768
+
+    def __init__(self, config: NeuSModelConfig = None):
+        super().__init__()
+        config = NeuSModelConfig() if config is None else config
+        why = unsupported_reason(config)
+        if why is not None:
+            raise ValueError(f"NeuSHintRenderer (MI355X): unsupported configuration: {why}")
+        self.config = config
+        self.has_shadow_hint = True
+        self.has_specular_hint = True
+        self.sdf_network = SDFNetwork(config.sdf_network)
+        self.deviation_network = SingleVarianceNetwork(config.deviation_network.init_val)
+        n_cue = len(config.renderer.specular_roughness)
+        self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + 1 + n_cue, 3,
+                                                config.reflectance_network, n_cue)
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+        self._consts = {}
+
+    # ---------------------------------------------------------------------------------------------
+    def _param_key(self, device):
+        return (str(device),) + tuple((id(p), p._version) for p in self.parameters())
+
+    def packed_params(self, device):
+        """Fold weight-norm and pack for the kernels; cached until a parameter changes."""
+        key = self._param_key(device)
+        if self._packed_key != key:
+            with torch.no_grad():
+                state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
+                d = packing.dense_params(state)
+                packing.check_default_shapes(d)
+                sw, sb, sh = packing.pack_sdf(d)
+                cw, cb = packing.pack_color(d)
+                inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6).item())
+            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s)
+            self._packed_key = key
+        return self._packed
+
+    def _const(self, device):
+        k = str(device)
+        if k not in self._consts:
+            # linspace evaluated on the CPU so the tables are bit-identical to the reference's CPU/GPU values
+            self._consts[k] = (torch.linspace(0.0, 1.0, 64).to(device), torch.linspace(0.0, 1.0, 16).to(device))
+        return self._consts[k]
+
+    def _workspace(self, device, nrays):
+        lib = _lib.load()
+        need = int(lib.nrh_render_workspace_floats(nrays))
+        k = str(device)
+        ws = self._ws.get(k)
+        if ws is None or ws.numel() < need:
+            self._ws[k] = ws = torch.empty(need, dtype=torch.float32, device=device)
+        return ws
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(self, ray_bundle: RayBundle, is_training: bool = False, background_rgb: Optional[torch.Tensor] = None,
+                global_step: int = 0, _t_rand_primary: Optional[torch.Tensor] = None,
+                _t_rand_shadow: Optional[torch.Tensor] = None) -> RenderOutput:
+        lib = _lib.load()
+        o, d, pl = ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions
+        near, far = ray_bundle.nears, ray_bundle.fars
+        if near is None or far is None:
+            raise ValueError("ray_bundle.nears / fars are required")
+        if o.dim() != 2 or o.shape[-1] != 3 or d.shape != o.shape or pl.shape != o.shape:
+            raise ValueError(f"origins/directions/pl_positions must all be [N,3], got {tuple(o.shape)}, "
+                             f"{tuple(d.shape)}, {tuple(pl.shape)}")
+        n = o.shape[0]
+        if near.numel() != n or far.numel() != n:
+            raise ValueError("nears / fars must be [N,1]")
+        if not o.is_cuda:
+            raise RuntimeError("NeuSHintRenderer (MI355X) runs on the GPU only: move the RayBundle to cuda "
+                               "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
+        needs_grad = torch.is_grad_enabled() and (
+            any(t.requires_grad for t in (o, d, pl, near, far)) or
+            (is_training and any(p.requires_grad for p in self.parameters())))
+        if needs_grad:
+            raise NotImplementedError(
+                "the backward kernels of the hot path are not built yet: call forward under torch.no_grad() "
+                "(DESIGN.md 'what comes next'); values for is_training=True are available without a graph")
+        device = o.device
+        f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
+        o, d, pl = f32(o), f32(d), f32(pl)
+        near, far = f32(near).reshape(-1), f32(far).reshape(-1)
+        cfg = self.config
+        cos_anneal = 1.0
+        if is_training and cfg.anneal_end > 0:
+            cos_anneal = min(1.0, global_step / cfg.anneal_end)
+        zero_hints = 1 if (is_training and global_step < cfg.geometry_warmup_end) else 0
+        t_rand_p = t_rand_s = None
+        if is_training:
+            # same draw order as the reference: primary jitter [N,1] (:682), then shadow jitter [N,64] (:394)
+            t_rand_p = f32(_t_rand_primary).reshape(-1) if _t_rand_primary is not None else torch.rand(n, device=device)
+            if not zero_hints:
+                t_rand_s = f32(_t_rand_shadow) if _t_rand_shadow is not None else torch.rand(n, 64, device=device)
+        bg = None
+        if background_rgb is not None:
+            bg = f32(background_rgb.to(device)).reshape(-1)
+            if bg.numel() != 3:
+                raise ValueError("background_rgb must be [1,3]")
+
+        pk = self.packed_params(device)
+        lin64, lin16 = self._const(device)
+        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"]), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
+                          _lib.ptr(pk["col_w"]), _lib.ptr(pk["col_b"]), pk["inv_s"])
+        T = N_SAMPLES_TOTAL
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
+        rgb, depth, vis = new(n, 3), new(n, 1), new(n, 1)
+        weights, inside = new(n, T), new(n, T)
+        normals, nhat, cue = new(n, T, 3), new(n, T, 3), new(n, T, 4)
+        chunk = max(1, min(self.max_chunk_rays, n))
+        ws = self._workspace(device, chunk)
+        stream = _lib.stream_handle()
+        P = _lib.ptr
+        for i in range(0, n, chunk):
+            m = min(chunk, n - i)
+            sl = slice(i, i + m)
+            rc = lib.nrh_render_forward(
+                net, P(o[sl]), P(d[sl]), P(pl[sl]), P(near[sl]), P(far[sl]), m, P(bg), cos_anneal,
+                P(t_rand_p[sl]) if t_rand_p is not None else None,
+                P(t_rand_s[sl]) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16),
+                P(rgb[sl]), P(depth[sl]), P(weights[sl]), P(inside[sl]), P(normals[sl]), P(nhat[sl]), P(vis[sl]),
+                P(cue[sl]), P(ws), ws.numel(), stream)
+            _lib.check(rc, "nrh_render_forward")
+        s_val = torch.full((1, 1), 1.0 / pk["inv_s"], dtype=torch.float32, device=device).expand(n, T)
+        return RenderOutput(rgb=rgb, depth=depth, weights=weights, s_val=s_val, inside_sphere=inside,
+                            relax_inside_sphere=inside, analytic_normals=normals,
+                            normalized_analytic_normals=nhat, visibilities=vis, specular_cue=cue)
+
+    # ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sdf(self, pts: torch.Tensor) -> torch.Tensor:
+        """SDF values at free points [P,3] -> [P,1] (SDFNetwork.sdf; used by extract_fields,
+        models/neus_hint_model.py:68-83, 753-758)."""
+        lib = _lib.load()
+        if not pts.is_cuda:
+            raise RuntimeError("NeuSHintRenderer.sdf runs on the GPU only")
+        pts = pts.detach().to(torch.float32).contiguous()
+        n = pts.shape[0]
+        pk = self.packed_params(pts.device)
+        zeros3 = torch.zeros_like(pts)
+        t = torch.zeros(n, dtype=torch.float32, device=pts.device)
+        out = torch.empty(n, 1, dtype=torch.float32, device=pts.device)
+        P = _lib.ptr
+        rc = lib.nrh_sdf_eval(0, P(pk["sdf_w"]), P(pk["sdf_b"]), P(pk["sdf_head"]), P(pts), P(zeros3), P(t), 1, 1, n,
+                              P(out), 1, None, None, None, _lib.stream_handle())
+        _lib.check(rc, "nrh_sdf_eval")
+        return out
+
+    @torch.no_grad()
+    def extract_fields(self, bound_min, bound_max, resolution: int) -> np.ndarray:
+        """Dense -sdf grid for marching cubes (models/neus_hint_model.py:68-83); one kernel launch per z-slab."""
+        dev = next(self.parameters()).device
+        xs = [torch.linspace(float(bound_min[i]), float(bound_max[i]), resolution, device=dev) for i in range(3)]
+        u = np.zeros([resolution] * 3, dtype=np.float32)
+        slab = max(1, (1 << 22) // (resolution * resolution))
+        for x0 in range(0, resolution, slab):
+            xx, yy, zz = torch.meshgrid(xs[0][x0:x0 + slab], xs[1], xs[2], indexing="ij")
+            pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+            u[x0:x0 + slab] = (-self.sdf(pts)).reshape(xx.shape).cpu().numpy()
+        return u

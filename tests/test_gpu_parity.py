@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed golden fixtures.
+
+Tolerances are float32 ones and are written next to each assertion.  The reference's own fp32-vs-fp64 noise
+floor on this path: rgb <= 1e-5, depth 6e-5, visibilities 2.5e-4, per-sample weights up to
+3.7e-3 at isolated samples with mean 1e-6 - hence mean + outlier budgets for per-sample fields.
+"""
+import numpy as np
+import pytest
+import torch
+
+import nrhints_amd as na
+from nrhints_amd import ops, packing as pk
+from nrhints_amd.synthetic import make_rays, psnr
+from oracle import neus_oracle as orc
+from tests.conftest import load_npz
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def cu(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).float().contiguous().cuda()
+
+
+@pytest.fixture(scope="module", params=["a", "b"])
+def scene(request, scene_states):
+    tag = request.param
+    st = scene_states[tag]
+    model = na.NeuSHintRenderer(na.NeuSModelConfig())
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+    model = model.cuda().eval()
+    packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()))
+    return tag, model, packed, orc.params_from_state(st), orc.params_from_state(st, torch.float64)
+
+
+def test_native_library_loaded():
+    from nrhints_amd import _lib
+    lib = _lib.load()
+    assert lib.nrh_version() >= 100
+    assert lib.nrh_mlp_grid() > 0
+    assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
+                                      pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
+
+
+@pytest.mark.parametrize("npts", [1, 37, 64, 1000, 4096 + 5])
+def test_sdf_modes_vs_oracle(scene, npts):
+    tag, model, packed, p32, p64 = scene
+    g = torch.Generator().manual_seed(npts)
+    pts = (torch.rand(npts, 3, generator=g) * 2 - 1) * 0.95
+    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, pts.double())
+    for mode in (0, 1, 2):
+        sdf, grad, feat = ops.sdf_at_points(mode, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], pts.cuda())
+        # fp32 MFMA chain vs fp64 oracle: |sdf| ~ 1, 8 layers of K=256 fp32 accumulation
+        np.testing.assert_allclose(sdf.cpu().numpy()[:, 0], o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
+        if mode >= 1:
+            # gradient magnitude ~1 (scene b up to ~3); fp32 reverse chain
+            np.testing.assert_allclose(grad.cpu().numpy(), o_grad.numpy(), rtol=0, atol=1e-4 if tag == "a" else 5e-4)
+        if mode == 2:
+            f = pk.feat_tiles_to_rows(feat.cpu(), npts).numpy()
+            np.testing.assert_allclose(f, o_feat.numpy(), rtol=0, atol=3e-5)
+
+
+def test_sdf_golden_fixture(scene):
+    """Directly against what the imported reference produced (tests/golden/unit_*.npz)."""
+    tag, model, packed, _, _ = scene
+    u = load_npz(f"unit_{tag}.npz")
+    sdf, grad, feat = ops.sdf_at_points(2, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], cu(u["sdf_pts"]))
+    P = u["sdf_pts"].shape[0]
+    out = np.concatenate([sdf.cpu().numpy(), pk.feat_tiles_to_rows(feat.cpu(), P).numpy()], axis=1)
+    np.testing.assert_allclose(out, u["sdf_out_f64"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(out, u["sdf_out"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), u["sdf_grad_f64"], rtol=0, atol=1e-4 if tag == "a" else 5e-4)
+
+
+def test_sdf_along_rays_strided(scene):
+    """Ray-parametrised points with a row stride (the sampler's calling convention)."""
+    tag, model, packed, p32, p64 = scene
+    o, d, pl, near, far = make_rays(50, seed=5, spread=0.1)
+    z = np.zeros((50, 128), np.float32)
+    z[:, :24] = near + (far - near) * np.linspace(0, 1, 24, dtype=np.float32)[None]
+    sdf, _, _ = ops.sdf_eval(0, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], cu(o), cu(d), cu(z), 24, t_stride=128)
+    pts = (T(o)[:, None] + T(d)[:, None] * T(z[:, :24])[..., None]).reshape(-1, 3)
+    ref = orc.sdf_forward(p64, pts.double(), False)[0].reshape(50, 24)
+    np.testing.assert_allclose(sdf.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-6)
+
+
+def test_sampler_steps_vs_golden(scene):
+    tag, model, packed, p32, _ = scene
+    u = load_npz(f"unit_{tag}.npz")
+    o, d = cu(u["us_o"]), cu(u["us_d"])
+    N = o.shape[0]
+    lin16 = torch.linspace(0, 1, 16).cuda()
+    z = torch.zeros(N, 128, device="cuda")
+    s = torch.zeros(N, 128, device="cuda")
+    z[:, :64], s[:, :64] = cu(u["us_z0"]), cu(u["us_sdf0"])
+    n = 64
+    for i in range(4):
+        znew, _, _ = ops.sampler_step(o, d, z, s, n, upsample_inv_s=64.0 * 2 ** i, lin16=lin16)
+        got, want = znew.cpu().numpy(), u[f"us_znew{i}"]
+        # inverse-CDF samples: continuous in the inputs except at the denom<1e-5 switch; allow a few bin flips
+        bad = np.abs(got - want) > 2e-5
+        assert bad.mean() < 2e-3, (i, bad.sum(), np.abs(got - want).max())
+        # continue from the recorded samples so one flipped bin cannot cascade
+        znew_ref = cu(want)
+        if i < 3:
+            pts = (o[:, None] + d[:, None] * znew_ref[..., None]).reshape(-1, 3)
+            snew = orc.sdf_forward(p32, pts.cpu(), False)[0].reshape(N, 16).cuda().contiguous()
+            ops.sampler_step(o, d, z, s, n, znew_in=znew_ref, snew_in=snew)
+            n += 16
+            np.testing.assert_array_equal(z[:, :n].cpu().numpy(), u[f"us_zcat{i}"])
+            np.testing.assert_allclose(s[:, :n].cpu().numpy(), u[f"us_sdfcat{i}"], rtol=0, atol=3e-6)
+            s[:, :n] = cu(u[f"us_sdfcat{i}"])
+        else:
+            _, tmid, dists = ops.sampler_step(o, d, z, s, n, znew_in=znew_ref, finalize=True)
+            n += 16
+            zc = u[f"us_zcat{i}"]
+            np.testing.assert_array_equal(z.cpu().numpy(), zc)
+            dd = np.concatenate([zc[:, 1:] - zc[:, :-1], np.full((N, 1), 2.0 / 64, np.float32)], axis=1)
+            np.testing.assert_array_equal(dists.cpu().numpy(), dd)
+            np.testing.assert_array_equal(tmid.cpu().numpy(), zc + dd * np.float32(0.5))
+
+
+def test_color_vs_golden(scene):
+    tag, model, packed, p32, _ = scene
+    u = load_npz(f"unit_{tag}.npz")
+    # the fixture has 160 free points; lay them out as 2 "rays" of 128 samples (pad by repetition) with
+    # ro = 0, rd = 0 and the point carried by ... -> instead rebuild per-ray inputs: use points on real rays
+    N = 3
+    o, d, pl, near, far = make_rays(N, seed=21, spread=0.1)
+    g = torch.Generator().manual_seed(3)
+    tmid = torch.rand(N, 128, generator=g) * 2 + 2
+    nhat = torch.nn.functional.normalize(torch.randn(N * 128, 3, generator=g), dim=-1)
+    feat = torch.randn(N * 128, 256, generator=g) * 0.3
+    vis = torch.rand(N, 1, generator=g)
+    cue = torch.rand(N, 4, generator=g) * 2
+    raymisc = torch.zeros(N, pk.RAYMISC_STRIDE)
+    raymisc[:, 0:27] = orc.nerf_encode(T(d), 4)
+    raymisc[:, 27:54] = orc.nerf_encode(T(pl), 4)
+    raymisc[:, 54:63] = orc.nerf_encode(vis, 4)
+    raymisc[:, 63:99] = orc.nerf_encode(cue, 4)
+    col = ops.color_eval(packed["col_w"], packed["col_b"], pk.rows_to_feat_tiles(feat).cuda(), cu(o), cu(d),
+                         tmid.cuda(), nhat.cuda().contiguous(), raymisc.cuda())
+    pts = (T(o)[:, None] + T(d)[:, None] * tmid[..., None]).reshape(-1, 3)
+    rep = lambda x: x[:, None, :].expand(N, 128, x.shape[-1]).reshape(N * 128, -1)
+    ref = orc.color_forward(p32, pts, nhat, rep(T(d)), feat, rep(T(pl)), rep(vis), rep(cue))
+    np.testing.assert_allclose(col.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-6)  # sigmoid output in [0,1]
+
+
+FIELDS_PER_SAMPLE = (("weights", 3e-5, 3e-2), ("analytic_normals", 3e-4, 0.3),
+                     ("normalized_analytic_normals", 3e-4, 0.6), ("specular_cue", 2e-3, 0.1))
+
+
+def _bundle(o, d, pl, near, far):
+    return na.RayBundle(origins=cu(o), directions=cu(d), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+
+
+def _check_against(out, g, sfx=""):
+    rgb = out.rgb.cpu().numpy()
+    # headline tolerance of the fp32 path: rgb within 1e-4 absolute and PSNR(ours, reference) >= 80 dB
+    np.testing.assert_allclose(rgb, g["rgb" + sfx], rtol=0, atol=1e-4)
+    assert psnr(rgb, g["rgb" + sfx]) > 80.0
+    np.testing.assert_allclose(out.depth.cpu().numpy(), g["depth" + sfx], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(out.visibilities.cpu().numpy(), g["visibilities" + sfx], rtol=0, atol=3e-3)
+    assert np.mean(out.inside_sphere.cpu().numpy() != g["inside_sphere" + sfx]) < 2e-3
+    for k, mean_tol, max_tol in FIELDS_PER_SAMPLE:
+        diff = np.abs(getattr(out, k).cpu().numpy() - g[k + sfx])
+        assert diff.mean() < mean_tol, (k, diff.mean())
+        assert diff.max() < max_tol, (k, diff.max())
+
+
+def test_render_eval_vs_golden(scene):
+    tag, model, packed, p32, _ = scene
+    g = load_npz(f"render_{tag}.npz")
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    with torch.no_grad():
+        out = model(rb, is_training=False, background_rgb=torch.ones(1, 3).cuda())
+        out0 = model(rb, is_training=False, background_rgb=torch.zeros(1, 3).cuda())
+    assert out.rgb.shape == (96, 3) and out.weights.shape == (96, 128) and out.specular_cue.shape == (96, 128, 4)
+    assert out.relax_inside_sphere.data_ptr() == out.inside_sphere.data_ptr()  # upstream quirk kept (:745)
+    _check_against(out, g)            # vs reference fp32
+    _check_against(out, g, "_f64")    # vs reference fp64
+    np.testing.assert_allclose(out0.rgb.cpu().numpy(), g["rgb_bg0"], rtol=0, atol=1e-4)
+    inv_s = float(np.exp(10.0 * (0.3 if tag == "a" else 0.7)))
+    np.testing.assert_allclose(out.s_val.cpu().numpy(), g["s_val"], rtol=1e-5)
+    assert abs(1.0 / out.s_val[0, 0].item() - inv_s) / inv_s < 1e-5
+
+
+def test_render_training_values_vs_golden(scene):
+    tag, model, packed, p32, _ = scene
+    g = load_npz(f"train_{tag}.npz")
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    with torch.no_grad():
+        out = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["global_step"]),
+                    _t_rand_primary=cu(g["t_rand_primary"]), _t_rand_shadow=cu(g["t_rand_shadow"]))
+    np.testing.assert_allclose(out.rgb.cpu().numpy(), g["rgb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out.visibilities.cpu().numpy(), g["visibilities"], rtol=0, atol=3e-3)
+    np.testing.assert_allclose(out.depth.cpu().numpy(), g["depth"], rtol=0, atol=3e-4)
+    o = {k: getattr(out, k).cpu() for k in ("rgb", "analytic_normals", "relax_inside_sphere")}
+    loss, rgb_loss, eik = orc.train_loss(o, T(g["rgb_gt"]))
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-4)
+
+
+def test_render_vs_oracle_many_rays(scene):
+    """1 000 rays incl. misses; oracle in 'minimal' mode on the CPU (a few seconds)."""
+    tag, model, packed, p32, _ = scene
+    rays = make_rays(1000, seed=17, spread=0.15)
+    with torch.no_grad():
+        out = model(_bundle(*rays), background_rgb=torch.ones(1, 3).cuda())
+    ref = orc.render_chunked(p32, *(T(a) for a in rays), chunk=500, background_rgb=torch.ones(1, 3), mode="minimal")
+    rgb = out.rgb.cpu().numpy()
+    assert psnr(rgb, ref["rgb"].numpy()) > 80.0
+    d = np.abs(rgb - ref["rgb"].numpy())
+    assert d.max() < 5e-4 and d.mean() < 5e-6, (d.max(), d.mean())
+    dv = np.abs(out.visibilities.cpu().numpy() - ref["visibilities"].numpy())
+    assert dv.mean() < 1e-4 and dv.max() < 2e-2
+
+
+def test_render_properties_full_size(scene):
+    """Size-independent invariants at a BASELINE-sized batch (config 1: 4096 rays, then 40 000)."""
+    tag, model, packed, _, _ = scene
+    for n in (4096, 40000):
+        rays = make_rays(n, seed=n, spread=0.12)
+        rb = _bundle(*rays)
+        with torch.no_grad():
+            a = model(rb, background_rgb=torch.ones(1, 3).cuda())
+            b = model(rb, background_rgb=torch.zeros(1, 3).cuda())
+        assert torch.isfinite(a.rgb).all() and torch.isfinite(a.weights).all()
+        wsum = a.weights.sum(-1, keepdim=True)
+        assert (a.weights >= 0).all() and (wsum <= 1.0 + 1e-4).all()
+        assert (a.rgb >= -1e-6).all() and (a.rgb <= 1.0 + 1e-5).all()
+        assert (a.visibilities >= 0).all() and (a.visibilities <= 1.0 + 1e-6).all()
+        # composite is affine in the background: rgb(bg=1) - rgb(bg=0) = 1 - sum(w)
+        torch.testing.assert_close(a.rgb - b.rgb, (1.0 - wsum).expand(-1, 3), rtol=0, atol=2e-6)
+        # everything except rgb is background independent, and the render is deterministic
+        assert torch.equal(a.weights, b.weights) and torch.equal(a.depth, b.depth)
+        # unit normals where the gradient is non-degenerate
+        nn_ = a.normalized_analytic_normals.norm(dim=-1)
+        assert ((nn_ - 1).abs() < 1e-4).all()
+        # rays that miss the unit sphere by a margin see (almost) nothing
+        o, d = T(rays[0]), T(rays[1])
+        closest = torch.linalg.norm(o - (o * d).sum(-1, keepdim=True) * d, dim=-1)
+        miss = (closest > 1.05).cuda()
+        if miss.any():
+            assert wsum[miss].max() < 0.05
+        # chunk independence: the same rays in differently sized C calls give bit-identical pixels
+        model.max_chunk_rays = 1536
+        with torch.no_grad():
+            c = model(rb, background_rgb=torch.ones(1, 3).cuda())
+        model.max_chunk_rays = type(model).max_chunk_rays
+        assert torch.equal(a.rgb, c.rgb) and torch.equal(a.visibilities, c.visibilities)
+
+
+def test_edge_cases(scene):
+    tag, model, packed, _, _ = scene
+    rays = make_rays(1, seed=1)
+    with torch.no_grad():
+        one = model(_bundle(*rays), background_rgb=torch.ones(1, 3).cuda())
+    assert one.rgb.shape == (1, 3) and torch.isfinite(one.rgb).all()
+    empty = [np.zeros((0, 3), np.float32)] * 3 + [np.zeros((0, 1), np.float32)] * 2
+    with torch.no_grad():
+        e = model(_bundle(*empty), background_rgb=torch.ones(1, 3).cuda())
+    assert e.rgb.shape == (0, 3) and e.weights.shape == (0, 128)
+    # CPU tensors are refused (no silent fallback), grads are refused (backward not built yet)
+    with pytest.raises(RuntimeError):
+        model(na.RayBundle(*(T(a) for a in rays[:3]), nears=T(rays[3]), fars=T(rays[4])))
+    rb = _bundle(*rays)
+    rb.origins.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        model(rb)
+
+
+def test_sdf_query_and_grid(scene):
+    tag, model, packed, p32, _ = scene
+    pts = (torch.rand(300, 3) * 2 - 1)
+    got = model.sdf(pts.cuda()).cpu()
+    ref = orc.sdf_forward(p32, pts, False)[0]
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=5e-6)
+    u = model.extract_fields([-1, -1, -1], [1, 1, 1], 24)
+    assert u.shape == (24, 24, 24) and np.isfinite(u).all()
+    assert u[12, 12, 12] > 0 > u[0, 0, 0]  # -sdf: positive inside, negative outside

@@ -1,0 +1,126 @@
+"""CPU-side tests: host logic of the drop-in module, containers, config guards, and that the C-ABI library loads
+and exports every symbol include/nrhints_hip.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import nrhints_amd as na
+from nrhints_amd import _lib, packing as pk
+from tests.conftest import ROOT, load_npz
+
+
+def test_library_loads_and_exports_header_symbols():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "nrhints_hip.h")).read()
+    declared = set(re.findall(r"\b(nrh_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTED), declared ^ set(_lib.EXPORTED)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    lib.nrh_version.restype = ctypes.c_int
+    assert lib.nrh_version() == 100
+    sizes = (ctypes.c_int * 8)()
+    assert lib.nrh_param_sizes(sizes) == 0
+    assert list(sizes)[:7] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS, pk.COL_PACKED_FLOATS,
+                               pk.COL_BIAS_FLOATS, pk.RAYMISC_STRIDE, pk.SDF_SCRATCH_FLOATS_PER_WAVE]
+    # argument validation works without a device
+    lib.nrh_last_error_string.restype = ctypes.c_char_p
+    assert lib.nrh_param_sizes(None) == -1 and b"null" in lib.nrh_last_error_string()
+    lib.nrh_render_workspace_floats.restype = ctypes.c_longlong
+    lib.nrh_render_workspace_floats.argtypes = [ctypes.c_longlong]
+    assert lib.nrh_render_workspace_floats(-5) == -1
+
+
+def test_module_init_and_state_dict_match_reference_fixture():
+    """Same constructor RNG consumption and the same 46 state-dict keys as the reference module
+    (fixture recorded from the imported reference under torch.manual_seed(0))."""
+    torch.manual_seed(0)
+    m = na.NeuSHintRenderer(na.NeuSModelConfig())
+    sd = m.state_dict()
+    ref = load_npz("scene_a_state.npz")
+    assert sorted(sd.keys()) == sorted(ref.keys()) and len(sd) == 46
+    for k, v in ref.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    assert sum(p.numel() for p in m.parameters()) == 820_923
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()})  # reference checkpoints load as-is
+
+
+def test_unsupported_configs_are_rejected():
+    bad = [
+        na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=64)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=8)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.SphereTracing)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(normal_type=na.NormalComputationType.Analytic)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_importance_samples=32)),
+    ]
+    for cfg in bad:
+        assert na.unsupported_reason(cfg)
+        with pytest.raises(ValueError):
+            na.NeuSHintRenderer(cfg)
+    assert na.unsupported_reason(na.NeuSModelConfig()) is None
+
+
+def test_no_cpu_fallback():
+    m = na.NeuSHintRenderer()
+    rb = na.RayBundle(origins=torch.zeros(4, 3), directions=torch.zeros(4, 3), pl_positions=torch.zeros(4, 3),
+                      nears=torch.zeros(4, 1), fars=torch.ones(4, 1))
+    with pytest.raises(RuntimeError):
+        m(rb)
+    with pytest.raises(RuntimeError):
+        m.sdf(torch.zeros(3, 3))
+    with pytest.raises(ValueError):
+        m(na.RayBundle(origins=torch.zeros(4, 3), directions=torch.zeros(4, 3), pl_positions=torch.zeros(4, 3)))
+
+
+def test_containers_batch_semantics():
+    n, T = 6, 128
+    ro = na.RenderOutput(rgb=torch.rand(n, 3), depth=torch.rand(n, 1), weights=torch.rand(n, T),
+                         s_val=torch.rand(1, 1).expand(n, T), inside_sphere=torch.ones(n, T),
+                         relax_inside_sphere=torch.ones(n, T), analytic_normals=torch.rand(n, T, 3),
+                         normalized_analytic_normals=torch.rand(n, T, 3), visibilities=torch.rand(n, 1),
+                         specular_cue=torch.rand(n, T, 4))
+    assert ro.shape == (n,) and len(ro) == n
+    r2 = ro.reshape((2, 3))
+    assert r2.shape == (2, 3) and r2.analytic_normals.shape == (2, 3, T, 3) and r2.specular_cue.shape == (2, 3, T, 4)
+    assert r2[1].shape == (3,) and r2[1, 2].rgb.shape == (3,)
+    cat = na.td_concat([ro[:2], ro[2:]])
+    assert torch.equal(cat.weights, ro.weights) and cat.shape == (n,)
+    assert ro.to("cpu").rgb.device.type == "cpu" and r2.flatten().shape == (n,)
+    # eval-side reduction of the reference's pipeline works on it (pipelines/base_pipeline.py:125)
+    nm = torch.einsum("...ij,...i,...i->...j", r2.analytic_normals, r2.weights, r2.inside_sphere)
+    assert nm.shape == (2, 3, 3)
+    rb = na.RayBundle(origins=torch.zeros(5, 3), directions=torch.zeros(5, 3), pl_positions=torch.zeros(1, 3),
+                      nears=torch.zeros(5, 1), fars=torch.ones(5, 1))
+    assert rb.pl_positions.shape == (5, 3) and rb[1:3].shape == (2,)
+
+
+def test_packing_is_differentiable_and_cached():
+    m = na.NeuSHintRenderer()
+    st = dict(m.named_parameters())
+    d = pk.dense_params({k: v for k, v in st.items()})
+    w, b, h = pk.pack_sdf(d)
+    (w.sum() + b.sum() + h.sum()).backward()
+    assert m.sdf_network.lin3.weight_v.grad is not None and m.sdf_network.out_sdf.weight_g.grad is not None
+    p1 = m.packed_params(torch.device("cpu"))
+    assert m.packed_params(torch.device("cpu")) is p1
+    with torch.no_grad():
+        m.deviation_network.variance.add_(0.1)
+    p2 = m.packed_params(torch.device("cpu"))
+    assert p2 is not p1 and abs(p2["inv_s"] - float(np.exp(4.0))) / np.exp(4.0) < 1e-5
+
+
+def test_synthetic_rays_match_reference_near_far():
+    from nrhints_amd.synthetic import make_image_rays, make_rays
+    o, d, pl, near, far = make_rays(100, seed=1)
+    np.testing.assert_allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-6)
+    np.testing.assert_allclose(far - near, 2.0, atol=1e-5)
+    mid = 0.5 * (near + far)
+    np.testing.assert_allclose(mid[:, 0], -(o * d).sum(-1), atol=1e-4)
+    o, d, pl, near, far = make_image_rays(8, 8, row0=2, row1=5)
+    assert o.shape == (24, 3) and np.allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-6)
