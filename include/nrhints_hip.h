@@ -13,6 +13,9 @@
  *     calling thread; no C++ exception, no ownership, crosses this boundary
  *   - weights arrive PACKED (nrhints_amd/packing.py documents the layout): weight-norm already folded
  *     (W = g * v / ||v||_row, fields/sdf_field.py:81-82), transposed copies for the reverse chain included
+ *   - `precision` selects the matrix arithmetic: 0 = v_mfma_f32_16x16x4_f32 on float32 weights; 1 = "f16x3",
+ *     three v_mfma_f32_16x16x32_f16 per product on weights pre-split into fp16 (hi, lo*2^11) pairs - the packed
+ *     weight buffer then holds fp16 pairs in the same number of bytes; biases, heads and all I/O stay float32
  */
 #ifndef NRHINTS_HIP_H
 #define NRHINTS_HIP_H
@@ -58,7 +61,7 @@ int nrh_kernel_timing_read(double* total_ms, long long* launches);
  * sdf  is written at sdf[ray * sdf_stride + j];  grad [nrays*n_per_ray,3];  feat in 16-point D-layout tiles
  * [ceil(npts/16)][16][64][4] (nrhints_amd/packing.py: feat_tiles_to_rows converts to [npts,256]).
  * scratch: nrh_mlp_grid() * 4 * out[6] floats (modes 1, 2), may be null for mode 0. */
-int nrh_sdf_eval(int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                  const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                  int sdf_stride, float* grad, float* feat, float* scratch, void* stream);
 
@@ -81,7 +84,7 @@ int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const
  *   feat     D-layout tiles from nrh_sdf_eval(mode 2);  nhat [nrays*128,3] unit normals;
  *   raymisc  [nrays, out[5]] per-ray part of the input: enc4(view) | enc4(pl) | enc4(vis) | enc4(cue)
  *   color    [nrays*128,3] */
-int nrh_color_eval(const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
+int nrh_color_eval(int precision, const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
                    const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
                    void* stream);
 
@@ -103,6 +106,7 @@ typedef struct NrhNet {
   const float* col_w;
   const float* col_b;
   float inv_s;
+  int precision; /* 0 = f32 MFMA (exact fp32), 1 = f16x3 split MFMA (fp32-equivalent accuracy, 16/3 the rate) */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

@@ -23,7 +23,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
 
 class NrhNet(Structure):
     _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
-                ("col_b", c_void_p), ("inv_s", c_float)]
+                ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int)]
 
 
 class HipExtensionMissing(RuntimeError):
@@ -53,10 +53,10 @@ def load():
     lib.nrh_last_error_string.restype = c_char_p
     lib.nrh_param_sizes.argtypes = [POINTER(c_int)]
     lib.nrh_mlp_grid.restype = c_int
-    lib.nrh_sdf_eval.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
+    lib.nrh_sdf_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
     lib.nrh_sampler_step.argtypes = [P, P, P, P, P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, c_int,
                                      c_int, c_int, P]
-    lib.nrh_color_eval.argtypes = [P, P, P, P, P, P, P, P, c_longlong, P, P]
+    lib.nrh_color_eval.argtypes = [c_int, P, P, P, P, P, P, P, P, c_longlong, P, P]
     lib.nrh_render_workspace_floats.argtypes = [c_longlong]
     lib.nrh_render_workspace_floats.restype = c_longlong
     lib.nrh_render_forward.argtypes = [POINTER(NrhNet), P, P, P, P, P, c_longlong, P, c_float, P, P, c_int, P, P,
@@ -81,13 +81,17 @@ def param_sizes():
     return list(out)
 
 
-def ptr(t):
-    """Device pointer of a contiguous float32 CUDA(HIP) tensor, or None."""
+PRECISIONS = {"f32": 0, "f16x3": 1}
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous float32 (or ``dtype``) CUDA(HIP) tensor, or None."""
     if t is None:
         return None
     import torch
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-        raise ValueError(f"expected a contiguous float32 tensor on the GPU, got {type(t)} "
+    dtype = torch.float32 if dtype is None else dtype
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"expected a contiguous {dtype} tensor on the GPU, got {type(t)} "
                          f"{getattr(t, 'dtype', None)} {getattr(t, 'device', None)} contiguous={getattr(t, 'is_contiguous', lambda: None)()}")
     return c_void_p(t.data_ptr())
 

@@ -50,10 +50,12 @@ int mlp_grid() {
 int ensure_attrs() {
   if (g_attr_done) return NRH_OK;
   hipError_t e;
-  e = hipFuncSetAttribute((const void*)nrh::sdf_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
+  const void* fns[] = {(const void*)nrh::sdf_kernel<0, 0>, (const void*)nrh::sdf_kernel<1, 0>, (const void*)nrh::sdf_kernel<2, 0>,
+                       (const void*)nrh::sdf_kernel<0, 1>, (const void*)nrh::sdf_kernel<1, 1>, (const void*)nrh::sdf_kernel<2, 1>,
+                       (const void*)nrh::color_kernel<0>, (const void*)nrh::color_kernel<1>};
+  e = hipSuccess;
+  for (const void* f : fns)
+    if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
   if (e != hipSuccess) return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   g_attr_done = true;
   return NRH_OK;
@@ -78,10 +80,11 @@ void timing_end(hipStream_t st, TimedLaunch& t, bool on) {
   g_timed.push_back(t);
 }
 
-int sdf_eval_impl(int mode, const float* w, const float* b, const float* head, const float* ro, const float* rd,
+int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const float* head, const float* ro, const float* rd,
                   const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad,
                   float* feat, float* scratch, hipStream_t st) {
   if (mode < 0 || mode > 2) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode must be 0, 1 or 2%s", "");
+  if (prec < 0 || prec > 1) return fail(NRH_E_INVALID, "nrh_sdf_eval: precision must be 0 (f32) or 1 (f16x3)%s", "");
   if (!w || !b || !head || !ro || !rd || !t || !sdf) return fail(NRH_E_INVALID, "nrh_sdf_eval: null pointer%s", "");
   if (mode >= 1 && (!grad || !scratch)) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode %s needs grad and scratch", mode == 1 ? "1" : "2");
   if (mode == 2 && !feat) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode 2 needs feat%s", "");
@@ -103,9 +106,17 @@ int sdf_eval_impl(int mode, const float* w, const float* b, const float* head, c
   TimedLaunch tl;
   bool timed;
   timing_begin(mode, st, tl, timed);
-  if (mode == 0) hipLaunchKernelGGL(nrh::sdf_kernel<0>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
-  else if (mode == 1) hipLaunchKernelGGL(nrh::sdf_kernel<1>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(nrh::sdf_kernel<2>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  const dim3 g(grid), blk(nrh::MLP_THREADS);
+  const int lds = nrh::MLP_LDS_BYTES;
+  if (prec == 0) {
+    if (mode == 0) hipLaunchKernelGGL((nrh::sdf_kernel<0, 0>), g, blk, lds, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((nrh::sdf_kernel<1, 0>), g, blk, lds, st, a);
+    else hipLaunchKernelGGL((nrh::sdf_kernel<2, 0>), g, blk, lds, st, a);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((nrh::sdf_kernel<0, 1>), g, blk, lds, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((nrh::sdf_kernel<1, 1>), g, blk, lds, st, a);
+    else hipLaunchKernelGGL((nrh::sdf_kernel<2, 1>), g, blk, lds, st, a);
+  }
   timing_end(st, tl, timed);
   return check_launch("sdf_kernel");
 }
@@ -116,7 +127,7 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
   return check_launch("sampler_step_kernel");
 }
 
-int color_eval_impl(const float* w, const float* b, const float* feat, const float* ro, const float* rd,
+int color_eval_impl(int prec, const float* w, const float* b, const float* feat, const float* ro, const float* rd,
                     const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
                     hipStream_t st) {
   if (!w || !b || !feat || !ro || !rd || !tmid || !nhat || !raymisc || !color)
@@ -136,7 +147,9 @@ int color_eval_impl(const float* w, const float* b, const float* feat, const flo
   TimedLaunch tl;
   bool timed;
   timing_begin(3, st, tl, timed);
-  hipLaunchKernelGGL(nrh::color_kernel, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  if (prec == 0) hipLaunchKernelGGL(nrh::color_kernel<0>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  else if (prec == 1) hipLaunchKernelGGL(nrh::color_kernel<1>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  else return fail(NRH_E_INVALID, "nrh_color_eval: precision must be 0 (f32) or 1 (f16x3)%s", "");
   timing_end(st, tl, timed);
   return check_launch("color_kernel");
 }
@@ -145,7 +158,7 @@ int color_eval_impl(const float* w, const float* b, const float* feat, const flo
 int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, float* s, float* znew, float* snew,
                 const float* lin16, const float* last_dist_ray, float last_dist, float* tmid, float* dists,
                 long long n, hipStream_t st) {
-  int rc = sdf_eval_impl(0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, z, 128, 64, n, s, 128, nullptr, nullptr,
+  int rc = sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, z, 128, 64, n, s, 128, nullptr, nullptr,
                          nullptr, st);
   if (rc) return rc;
   for (int i = 0; i < 4; ++i) {
@@ -160,7 +173,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
     if (rc) return rc;
     const bool last = (i == 3);
     if (!last) {
-      rc = sdf_eval_impl(0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, znew, 16, 16, n, snew, 16, nullptr, nullptr,
+      rc = sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, znew, 16, 16, n, snew, 16, nullptr, nullptr,
                          nullptr, st);
       if (rc) return rc;
     }
@@ -176,8 +189,8 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 100; }
-const char* nrh_build_info(void) { return "nrhints_hip gfx950 fp32-mfma16x16x4 " __DATE__ " " __TIME__; }
+int nrh_version(void) { return 101; }
+const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
 int nrh_param_sizes(int* out) {
@@ -220,10 +233,10 @@ int nrh_kernel_timing_read(double* total_ms, long long* launches) {
   return NRH_OK;
 }
 
-int nrh_sdf_eval(int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                  const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                  int sdf_stride, float* grad, float* feat, float* scratch, void* stream) {
-  return sdf_eval_impl(mode, sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat,
+  return sdf_eval_impl(precision, mode, sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat,
                        scratch, (hipStream_t)stream);
 }
 
@@ -247,10 +260,10 @@ int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const
   return sampler_step_impl(a, (hipStream_t)stream);
 }
 
-int nrh_color_eval(const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
+int nrh_color_eval(int precision, const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
                    const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
                    void* stream) {
-  return color_eval_impl(col_w, col_b, feat, ro, rd, tmid, nhat, raymisc, nrays, color, (hipStream_t)stream);
+  return color_eval_impl(precision, col_w, col_b, feat, ro, rd, tmid, nhat, raymisc, nrays, color, (hipStream_t)stream);
 }
 
 // workspace carve-up (floats per ray, each array rounded up to a multiple of 64 floats)
@@ -279,6 +292,8 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
   hipStream_t st = (hipStream_t)stream;
   if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !net->col_w || !net->col_b)
     return fail(NRH_E_INVALID, "nrh_render_forward: null network pointer%s", "");
+  if (net->precision < 0 || net->precision > 1)
+    return fail(NRH_E_INVALID, "nrh_render_forward: net->precision must be 0 (f32) or 1 (f16x3)%s", "");
   if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || !rgb || !workspace)
     return fail(NRH_E_INVALID, "nrh_render_forward: null pointer%s", "");
   if (nrays < 0 || nrays > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_render_forward: nrays out of range (chunk the call)%s", "");
@@ -314,7 +329,7 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
                        ws_tmid, ws_dists, n, st);
   if (rc) return rc;
   // ---- render_core: sdf + feature + gradient at the 128 section mid-points ----
-  rc = sdf_eval_impl(2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, ws_tmid, 128, 128, n, ws_sdf_c, 128,
+  rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, ws_tmid, 128, 128, n, ws_sdf_c, 128,
                      o_grad, ws_feat, scratch, st);
   if (rc) return rc;
   {
@@ -339,7 +354,7 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s,
                      ws_dists_s, n, st);
     if (rc) return rc;
-    rc = sdf_eval_impl(1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
+    rc = sdf_eval_impl(net->precision, 1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
                        128, ws_grad_s, nullptr, scratch, st);
     if (rc) return rc;
   }
@@ -353,7 +368,7 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     if (rc) return rc;
   }
   // ---- reflectance + composite ----
-  rc = color_eval_impl(net->col_w, net->col_b, ws_feat, origins, directions, ws_tmid, o_nhat, ws_raymisc, n, ws_color, st);
+  rc = color_eval_impl(net->precision, net->col_w, net->col_b, ws_feat, origins, directions, ws_tmid, o_nhat, ws_raymisc, n, ws_color, st);
   if (rc) return rc;
   {
     nrh::CompositeArgs c;

@@ -35,25 +35,67 @@ __device__ __forceinline__ void dma_chunk(const float* __restrict__ src, char* d
   }
 }
 
-#define NRH_MFMA4(ACC, AV, B0, B1, B2, B3)                                   \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).x, (B0), ACC, 0, 0, 0);    \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).y, (B1), ACC, 0, 0, 0);    \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).z, (B2), ACC, 0, 0, 0);    \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).w, (B3), ACC, 0, 0, 0);
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- precision modes -------------------------------------------------------------------------------------------
+// PREC 0  "f32"    v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation (157 TFLOP/s peak).
+// PREC 1  "f16x3"  every fp32 value x is carried as two fp16 numbers, hi = fp16(x) and lo = fp16((x - hi) * 2^11)
+//                  (the 2^11 keeps lo out of the fp16 subnormal range); a product x*w is evaluated as
+//                  hi_x*hi_w + 2^-11 (hi_x*lo_w + lo_x*hi_w) with three v_mfma_f32_16x16x32_f16 into two fp32
+//                  accumulators.  The dropped lo*lo term and the fp16 rounding of lo are both ~2^-22 relative, i.e.
+//                  fp32 round-off class (measured on the SDF net: same error against fp64 as the fp32 chain,
+//                  DESIGN.md §5), at 16/3 of the fp32 matrix rate.
+constexpr float LO_SCALE = 2048.0f;
+constexpr float LO_UNSCALE = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f16x2 h = {(_Float16)a, (_Float16)b};
+  const f16x2 l = {(_Float16)((a - (float)h.x) * LO_SCALE), (_Float16)((b - (float)h.y) * LO_SCALE)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// Activations of one layer for this wave's 16 points, in the form the MFMA B operand wants them.
+//   PREC 0: KB*4 floats in D-layout.   PREC 1: per 32-wide K step, 8 fp16 hi + 8 fp16 lo (4 + 4 packed VGPRs):
+//   elements 0..3 = features 16*(2s)+4q+0..3, elements 4..7 = features 16*(2s+1)+4q+0..3.
+template <int PREC, int KB>
+struct Act;
+template <int KB>
+struct Act<0, KB> {
+  float v[KB * 4];
+  // the 8 outputs of chunk ch (blocks 2ch and 2ch+1, registers 0..3 each)
+  __device__ __forceinline__ void set_chunk(int ch, const float (&o)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[ch * 8 + r] = o[r];
+  }
+};
+template <int KB>
+struct Act<1, KB> {
+  static_assert(KB % 2 == 0, "f16x3 K steps are 32 wide");
+  uint32_t h[KB * 2], l[KB * 2];
+  __device__ __forceinline__ void set_chunk(int ch, const float (&o)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) split_pack2(o[2 * r], o[2 * r + 1], h[ch * 4 + r], l[ch * 4 + r]);
+  }
+};
 
 // One GEMM stage: out[NCH*32 features] = A[NCH*32 x KB*16] * in[KB*16 features], all for this wave's 16 points.
 //   wsrc   packed weights of this stage: NCH chunks of 2*KB KiB, chunk ch resident in LDS buffer `par` on entry
 //   wnext  first chunk of whatever runs next (prefetched during the last chunk), next_pieces its size in KiB
 //   init   optional accumulator start values (D-layout, NCH*8 floats) - used to split one layer's K in two
 //   epi    epi(ch, acc0, acc1): consumes the two finished 16-feature blocks 2*ch and 2*ch+1
-template <int KB, int NCH, bool HAS_INIT, typename Epi>
+// LDS image of a chunk (both precisions 2*KB KiB):
+//   PREC 0: [obi 2][kb KB][lane 64] float4           - A of 4 consecutive 16x16x4 MFMAs
+//   PREC 1: [obi 2][s KB/2][hi|lo][lane 64] 8 x fp16 - A of one 16x16x32 MFMA (hi) / its low part
+template <int PREC, int KB, int NCH, bool HAS_INIT, typename Epi>
 __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const float* __restrict__ wnext,
-                                          int next_pieces, char* smem, int& par, const float (&in)[KB * 4],
+                                          int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
                                           const float* init, Epi&& epi, int wave, int lane) {
   constexpr int PIECES = 2 * KB;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    const f32x4* A = reinterpret_cast<const f32x4*>(smem + par * WBUF_BYTES);
     char* nxt = smem + (par ^ 1) * WBUF_BYTES;
     if (ch + 1 < NCH) {
       dma_chunk(wsrc + (ch + 1) * PIECES * 256, nxt, PIECES, wave, lane);
@@ -65,29 +107,61 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
       acc0 = f32x4{init[ch * 8 + 0], init[ch * 8 + 1], init[ch * 8 + 2], init[ch * 8 + 3]};
       acc1 = f32x4{init[ch * 8 + 4], init[ch * 8 + 5], init[ch * 8 + 6], init[ch * 8 + 7]};
     }
-    // software-pipelined by one K block: the A operands of block kb+1 are in flight while block kb's
-    // 8 MFMAs (2 independent accumulators, 256 cycles) run; sched_barrier keeps hipcc from hoisting all
-    // 2*KB ds_read_b128 to the top of the chunk (128 live VGPRs -> spills at 2 waves/SIMD).
-    f32x4 a0 = A[(0 * KB + 0) * 64 + lane];
-    f32x4 a1 = A[(1 * KB + 0) * 64 + lane];
+    if constexpr (PREC == 0) {
+      const f32x4* A = reinterpret_cast<const f32x4*>(smem + par * WBUF_BYTES);
+      // software-pipelined by one K block: the A operands of block kb+1 are in flight while block kb's
+      // 8 MFMAs (2 independent accumulators, 256 cycles) run; sched_barrier keeps hipcc from hoisting all
+      // 2*KB ds_read_b128 to the top of the chunk (128 live VGPRs -> spills at 2 waves/SIMD).
+      f32x4 a0 = A[(0 * KB + 0) * 64 + lane];
+      f32x4 a1 = A[(1 * KB + 0) * 64 + lane];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      f32x4 n0 = a0, n1 = a1;
-      if (kb + 1 < KB) {
-        n0 = A[(0 * KB + kb + 1) * 64 + lane];
-        n1 = A[(1 * KB + kb + 1) * 64 + lane];
+      for (int kb = 0; kb < KB; ++kb) {
+        f32x4 n0 = a0, n1 = a1;
+        if (kb + 1 < KB) {
+          n0 = A[(0 * KB + kb + 1) * 64 + lane];
+          n1 = A[(1 * KB + kb + 1) * 64 + lane];
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, in.v[kb * 4 + 0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, in.v[kb * 4 + 0], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, in.v[kb * 4 + 1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, in.v[kb * 4 + 1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, in.v[kb * 4 + 2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, in.v[kb * 4 + 2], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, in.v[kb * 4 + 3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, in.v[kb * 4 + 3], acc1, 0, 0, 0);
+        a0 = n0;
+        a1 = n1;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, in[kb * 4 + 0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, in[kb * 4 + 0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, in[kb * 4 + 1], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, in[kb * 4 + 1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, in[kb * 4 + 2], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, in[kb * 4 + 2], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, in[kb * 4 + 3], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, in[kb * 4 + 3], acc1, 0, 0, 0);
-      a0 = n0;
-      a1 = n1;
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      constexpr int KS = KB / 2;
+      const u32x4* A = reinterpret_cast<const u32x4*>(smem + par * WBUF_BYTES);
+      auto ld = [&](int obi, int s, int part) { return A[((obi * KS + s) * 2 + part) * 64 + lane]; };
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};  // cross terms, scaled by 2^11
+      u32x4 ah0 = ld(0, 0, 0), al0 = ld(0, 0, 1), ah1 = ld(1, 0, 0), al1 = ld(1, 0, 1);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        u32x4 nh0 = ah0, nl0 = al0, nh1 = ah1, nl1 = al1;
+        if (s + 1 < KS) {
+          nh0 = ld(0, s + 1, 0);
+          nl0 = ld(0, s + 1, 1);
+          nh1 = ld(1, s + 1, 0);
+          nl1 = ld(1, s + 1, 1);
+        }
+        const u32x4 bhu = {in.h[s * 4 + 0], in.h[s * 4 + 1], in.h[s * 4 + 2], in.h[s * 4 + 3]};
+        const u32x4 blu = {in.l[s * 4 + 0], in.l[s * 4 + 1], in.l[s * 4 + 2], in.l[s * 4 + 3]};
+        const f16x8 bh = __builtin_bit_cast(f16x8, bhu), bl = __builtin_bit_cast(f16x8, blu);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah0), bh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah1), bh, acc1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah0), bl, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah1), bl, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al0), bh, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al1), bh, c1, 0, 0, 0);
+        ah0 = nh0; al0 = nl0; ah1 = nh1; al1 = nl1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc0 += c0 * LO_UNSCALE;
+      acc1 += c1 * LO_UNSCALE;
     }
     epi(ch, acc0, acc1);
     __syncthreads();  // waits this wave's LDS-DMA (vmcnt(0)) and orders the buffer swap
@@ -97,7 +171,7 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
 
 // ---------------- packed-buffer geometry of the SDF net (floats) ----------------
 // execution order: L0 | L1..L7 | FEAT | R7..R1 | R0        (R_l = W_l^T, the reverse chain)
-constexpr int SDF_L0_FLOATS = 8 * 2 * 3 * 256;     // 8 chunks x (2 ob x 3 kb) KiB
+constexpr int SDF_L0_FLOATS = 8 * 2 * 4 * 256;     // 8 chunks x (2 ob x 4 kb) KiB (39 inputs -> 64)
 constexpr int SDF_REG_FLOATS = 8 * 2 * 16 * 256;   // a 256x256 stage
 constexpr int SDF_R0_FLOATS = 2 * 2 * 16 * 256;    // 64 (39 used) x 256
 constexpr int SDF_OFF_L0 = 0;
@@ -111,9 +185,9 @@ constexpr int SDF_HEAD_FLOATS = 257;                // w_s[256], b_s
 constexpr int SDF_SCRATCH_FLOATS_PER_WAVE = 8 * 16 * 256;  // sigma' of 8 layers x 256 features x 16 points
 
 // ---------------- packed-buffer geometry of the reflectance net ----------------
-// C0a (feature part of the input, K=256) | C0b (105 per-sample/per-ray inputs, K=112) | C1..C3 | C4 (3 rows in a 32-row chunk)
+// C0a (feature part of the input, K=256) | C0b (105 per-sample/per-ray inputs, K=128) | C1..C3 | C4 (3 rows in a 32-row chunk)
 constexpr int COL_OFF_C0A = 0;
-constexpr int COL_C0B_FLOATS = 8 * 2 * 7 * 256;
+constexpr int COL_C0B_FLOATS = 8 * 2 * 8 * 256;   // 105 inputs -> 128
 constexpr int COL_OFF_C0B = SDF_REG_FLOATS;
 __host__ __device__ constexpr int col_off_C(int l) { return SDF_REG_FLOATS + COL_C0B_FLOATS + (l - 1) * SDF_REG_FLOATS; }  // l=1..3
 constexpr int COL_OFF_C4 = SDF_REG_FLOATS + COL_C0B_FLOATS + 3 * SDF_REG_FLOATS;

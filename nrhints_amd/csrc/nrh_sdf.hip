@@ -3,24 +3,27 @@
 // Replaces, per point, the reference's  SDFNetwork.forward  (fields/sdf_field.py:106-123),  .sdf  (:125-126)
 // and  .gradient  (:136-148, autograd)  - i.e. up to three full forwards plus an autograd sweep
 // (models/neus_hint_model.py:504, :335, :336) - by one forward that keeps sigma'(z) = sigmoid(100 z) of
-// every activation and one hand-written reverse chain through W^T.  Exact fp32 (v_mfma_f32_16x16x4_f32).
+// every activation and one hand-written reverse chain through W^T.
 //
 // Layer plan (all GEMMs are 256x256 except the first/last):
-//   L0   39(->48) -> 256   softplus100        in = NeRF encoding of 3x, computed in registers
+//   L0   39(->64) -> 256   softplus100        in = NeRF encoding of 3x, computed in registers
 //   L1,L2          256 -> 256
 //   L3             256 -> 217(->256, zero rows); outputs 217..255 are REPLACED by the 39 embedding values, which
 //                  reproduces cat([h, embed]) of the skip connection with no data movement (fields/sdf_field.py:114)
 //   L4..L7         256 -> 256   (W4 pre-scaled by 1/sqrt(2))
-//   head           sdf = (w_s . h + b_s) / 3              (VALU dot + 2 shuffles)
+//   head           sdf = (w_s . h + b_s) / 3              (VALU dot + 2 shuffles, folded into L7's epilogue)
 //   FEAT           256 -> 256, no activation              (MODE 2 only)
 //   R7..R1         g <- W_l^T (sigma'_l * g)              (MODE >= 1)
 //   R0             39(->64) <- 256, then d/dx of the encoding
+// sigma' lives in a per-wave global scratch between the forward and the reverse sweep (2 048 values per point do not
+// fit on chip): fp32 in PREC 0, unorm16 in PREC 1 (absolute error <= 7.6e-6 on a factor in [0,1]; halves the only
+// non-trivial memory traffic of this kernel so that it stays in the 256 MiB Infinity Cache).
 #include "nrh_mlp.h"
 
 namespace nrh {
 
 struct SdfArgs {
-  const float* w;      // packed stages (SDF_PACKED_FLOATS)
+  const float* w;      // packed stages (SDF_PACKED_FLOATS floats, or the same number of fp16 hi/lo pairs)
   const float* b;      // [9][256]
   const float* head;   // [257]
   const float* ro;     // [nrays,3]
@@ -37,7 +40,45 @@ struct SdfArgs {
   int ntile_groups;    // ceil(npts / 64)
 };
 
-template <int MODE>
+__device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
+  const uint32_t ua = (uint32_t)(a * 65535.0f + 0.5f), ub = (uint32_t)(b * 65535.0f + 0.5f);
+  return ua | (ub << 16);
+}
+
+// store / load the 8 sigma' values of chunk ch of layer l (l < 7)
+template <int PREC>
+__device__ __forceinline__ void dsig_store(float* scr, int l, int ch, int lane, const float (&d)[8]) {
+  if constexpr (PREC == 0) {
+    *reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4) = f32x4{d[0], d[1], d[2], d[3]};
+    *reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4) = f32x4{d[4], d[5], d[6], d[7]};
+  } else {
+    const u32x4 v = {unorm16x2(d[0], d[1]), unorm16x2(d[2], d[3]), unorm16x2(d[4], d[5]), unorm16x2(d[6], d[7])};
+    *reinterpret_cast<u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4) = v;
+  }
+}
+template <int PREC>
+__device__ __forceinline__ void dsig_load(const float* scr, int l, int ch, int lane, float (&d)[8]) {
+  if constexpr (PREC == 0) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { d[r] = a[r]; d[4 + r] = b[r]; }
+  } else {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d[2 * r] = (float)(v[r] & 0xffffu) * (1.0f / 65535.0f);
+      d[2 * r + 1] = (float)(v[r] >> 16) * (1.0f / 65535.0f);
+    }
+  }
+}
+// t_7 = sigma'_7 * w_s / 3 is not confined to [0,1]: always fp32
+template <int PREC>
+__device__ __forceinline__ float* t7_ptr(float* scr, int blk, int lane) {
+  return scr + ((PREC == 0) ? 7 * 16 * 256 : 7 * 2048) + (blk * 64 + lane) * 4;
+}
+
+template <int MODE, int PREC>
 __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -46,7 +87,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   int par = 0;
   float* const scr = (MODE >= 1) ? a.scratch + (size_t)(blockIdx.x * 4 + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
 
-  dma_chunk(a.w + SDF_OFF_L0, smem, 6, wave, lane);
+  dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
   __syncthreads();
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
@@ -62,35 +103,34 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt) * 3.0f;  // inputs * scale
 
     // ---- L0: embedding -> 256 ----
-    float emb[12];
+    Act<PREC, 4> emb;
     {
       float all[39];
       nerf_enc_all<3, 6>(x3, all);
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
+      for (int c2 = 0; c2 < 2; ++c2) {
+        float o[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) emb[b * 4 + r] = sel_q<39>(all, b * 16 + r, q);  // entry 16b + 4q + r
+        for (int r = 0; r < 8; ++r) o[r] = sel_q<39>(all, (2 * c2 + (r >> 2)) * 16 + (r & 3), q);  // entry 16b + 4q + r
+        emb.set_chunk(c2, o);
+      }
     }
-    float h[64];
+
+    Act<PREC, 16> h;
     {
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch) * 16 + 4 * q);
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch + 1) * 16 + 4 * q);
-        f32x4 d0, d1;
+        float o[8], d[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float t0, t1;
-          softplus100(acc0[r] + b0[r], h[ch * 8 + r], t0);
-          softplus100(acc1[r] + b1[r], h[ch * 8 + 4 + r], t1);
-          d0[r] = t0;
-          d1[r] = t1;
+          softplus100(acc0[r] + b0[r], o[r], d[r]);
+          softplus100(acc1[r] + b1[r], o[4 + r], d[4 + r]);
         }
-        if (MODE >= 1) {
-          *reinterpret_cast<f32x4*>(scr + ((0 * 16 + 2 * ch) * 64 + lane) * 4) = d0;
-          *reinterpret_cast<f32x4*>(scr + ((0 * 16 + 2 * ch + 1) * 64 + lane) * 4) = d1;
-        }
+        h.set_chunk(ch, o);
+        if (MODE >= 1) dsig_store<PREC>(scr, 0, ch, lane, d);
       };
-      run_stage<3, 8, false>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, epi, wave, lane);
+      run_stage<PREC, 4, 8, false>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, epi, wave, lane);
     }
 
     // ---- steps 1..15: L1..L7, FEAT, R7..R1 share one 256x256 body ----
@@ -110,7 +150,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
       else wcur = a.w + sdf_off_R(16 - s);
       if (s < 7) wnxt = a.w + sdf_off_L(s + 1);
       else if (s == 7) {
-        if (MODE == 0) { wnxt = a.w + SDF_OFF_L0; npc = 6; }
+        if (MODE == 0) { wnxt = a.w + SDF_OFF_L0; npc = 8; }
         else if (MODE == 1) wnxt = a.w + sdf_off_R(7);
         else wnxt = a.w + SDF_OFF_FEAT;
       } else if (s == 8) wnxt = a.w + sdf_off_R(7);
@@ -120,26 +160,24 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
       if (MODE >= 1 && s == 9) {
         // start of the reverse chain: t_7 = sigma'_7 * (w_s / 3), written by L7's epilogue
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-          const f32x4 dv = *reinterpret_cast<const f32x4*>(scr + ((7 * 16 + b) * 64 + lane) * 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[b * 4 + r] = dv[r];
+        for (int ch = 0; ch < 8; ++ch) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane));
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane));
+          const float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          h.set_chunk(ch, o);
         }
       }
 
-      float ho[64];
+      Act<PREC, 16> ho;
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
         if (s <= 7) {
           const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch) * 16 + 4 * q);
           const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch + 1) * 16 + 4 * q);
-          f32x4 d0, d1;
+          float o[8], d[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float t0, t1;
-            softplus100(acc0[r] + b0[r], ho[ch * 8 + r], t0);
-            softplus100(acc1[r] + b1[r], ho[ch * 8 + 4 + r], t1);
-            d0[r] = t0;
-            d1[r] = t1;
+            softplus100(acc0[r] + b0[r], o[r], d[r]);
+            softplus100(acc1[r] + b1[r], o[4 + r], d[4 + r]);
           }
           if (ch >= 6 && s == 3) {
             // skip connection: features 217..255 of L4's input are the embedding (fields/sdf_field.py:113-114)
@@ -149,12 +187,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             for (int r = 0; r < 4; ++r) {
               const int e1 = (2 * ch + 1) * 16 + 4 * q + r - 217;
               if (ch == 7) {  // block 14: always >= 217
-                ho[ch * 8 + r] = sel_q<39>(all, (2 * ch) * 16 + r - 217, q);
-                d0[r] = 0.0f;
+                o[r] = sel_q<39>(all, (2 * ch) * 16 + r - 217, q);
+                d[r] = 0.0f;
               }
               if (e1 >= 0) {  // block 13 (partly) or 15
-                ho[ch * 8 + 4 + r] = sel_q<39>(all, (2 * ch + 1) * 16 + r - 217, q);
-                d1[r] = 0.0f;
+                o[4 + r] = sel_q<39>(all, (2 * ch + 1) * 16 + r - 217, q);
+                d[4 + r] = 0.0f;
               }
             }
           }
@@ -164,16 +202,19 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              head_part += w0[r] * ho[ch * 8 + r];
-              head_part += w1[r] * ho[ch * 8 + 4 + r];
-              d0[r] = d0[r] * (w0[r] / 3.0f);
-              d1[r] = d1[r] * (w1[r] / 3.0f);
+              head_part += w0[r] * o[r];
+              head_part += w1[r] * o[4 + r];
+              d[r] = d[r] * (w0[r] / 3.0f);
+              d[4 + r] = d[4 + r] * (w1[r] / 3.0f);
             }
+            if (MODE >= 1) {
+              *reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)) = f32x4{d[0], d[1], d[2], d[3]};
+              *reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)) = f32x4{d[4], d[5], d[6], d[7]};
+            }
+          } else if (MODE >= 1) {
+            dsig_store<PREC>(scr, s, ch, lane, d);
           }
-          if (MODE >= 1) {
-            *reinterpret_cast<f32x4*>(scr + ((s * 16 + 2 * ch) * 64 + lane) * 4) = d0;
-            *reinterpret_cast<f32x4*>(scr + ((s * 16 + 2 * ch + 1) * 64 + lane) * 4) = d1;
-          }
+          ho.set_chunk(ch, o);
         } else if (s == 8) {
           if (MODE == 2) {
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + 8 * 256 + (2 * ch) * 16 + 4 * q);
@@ -195,17 +236,18 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
                 skip[(2 * ch + 1 - 13) * 4 + r] = acc1[r];
               }
             }
-            const f32x4 d0 = *reinterpret_cast<const f32x4*>(scr + (((l - 1) * 16 + 2 * ch) * 64 + lane) * 4);
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(scr + (((l - 1) * 16 + 2 * ch + 1) * 64 + lane) * 4);
+            float d[8], o[8];
+            dsig_load<PREC>(scr, l - 1, ch, lane, d);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              ho[ch * 8 + r] = acc0[r] * d0[r];
-              ho[ch * 8 + 4 + r] = acc1[r] * d1[r];
+              o[r] = acc0[r] * d[r];
+              o[4 + r] = acc1[r] * d[4 + r];
             }
+            ho.set_chunk(ch, o);
           }
         }
       };
-      run_stage<16, 8, false>(wcur, wnxt, npc, smem, par, h, nullptr, epi, wave, lane);
+      run_stage<PREC, 16, 8, false>(wcur, wnxt, npc, smem, par, h, nullptr, epi, wave, lane);
 
       if (s == 7) {
         // sdf head: (w_s . h8 + b_s) / scale   (fields/sdf_field.py:121)
@@ -214,10 +256,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         part += __shfl_xor(part, 32, 64);
         if (valid && q == 0) a.sdf[ray * a.sdf_stride + jj] = (part + a.head[256]) / 3.0f;
       }
-      if (s != 8) {
-#pragma unroll
-        for (int i = 0; i < 64; ++i) h[i] = ho[i];
-      }
+      if (s != 8) h = ho;
     }
 
     if (MODE >= 1) {
@@ -227,7 +266,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ge[ch * 8 + r] = acc0[r]; ge[ch * 8 + 4 + r] = acc1[r]; }
       };
-      run_stage<16, 2, false>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 6, smem, par, h, nullptr, epi, wave, lane);
+      run_stage<PREC, 16, 2, false>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 8, smem, par, h, nullptr, epi, wave, lane);
 
       float dx[3] = {0.f, 0.f, 0.f};
       {
@@ -259,9 +298,5 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     }
   }
 }
-
-template __global__ void sdf_kernel<0>(const SdfArgs);
-template __global__ void sdf_kernel<1>(const SdfArgs);
-template __global__ void sdf_kernel<2>(const SdfArgs);
 
 }  // namespace nrh

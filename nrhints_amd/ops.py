@@ -19,6 +19,11 @@ def _scratch(device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+def _wptr(w):
+    """Packed weights: float32 (precision 0) or float16 pairs (precision 1, f16x3)."""
+    return _lib.ptr(w, w.dtype), (0 if w.dtype == torch.float32 else 1)
+
+
 def sdf_eval(mode: int, sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_stride: Optional[int] = None,
              scratch: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
     """SDF (mode 0), + gradient (mode 1), + feature (mode 2) at points ro[ray] + rd[ray] * t[ray, j].
@@ -35,7 +40,8 @@ def sdf_eval(mode: int, sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_str
     if mode >= 1 and scratch is None:
         scratch = _scratch(dev)
     P = _lib.ptr
-    rc = lib.nrh_sdf_eval(mode, P(sdf_w), P(sdf_b), P(sdf_head), P(ro), P(rd), P(t), t_stride, n_per_ray, nrays,
+    wp, prec = _wptr(sdf_w)
+    rc = lib.nrh_sdf_eval(prec, mode, wp, P(sdf_b), P(sdf_head), P(ro), P(rd), P(t), t_stride, n_per_ray, nrays,
                           P(sdf), n_per_ray, P(grad), P(feat), P(scratch) if mode >= 1 else None, _lib.stream_handle())
     _lib.check(rc, "nrh_sdf_eval")
     return sdf, grad, feat
@@ -75,7 +81,8 @@ def color_eval(col_w, col_b, feat_tiles, ro, rd, tmid, nhat, raymisc) -> torch.T
     nrays = ro.shape[0]
     color = torch.empty(nrays * 128, 3, dtype=torch.float32, device=ro.device)
     P = _lib.ptr
-    rc = lib.nrh_color_eval(P(col_w), P(col_b), P(feat_tiles), P(ro), P(rd), P(tmid), P(nhat), P(raymisc), nrays,
+    wp, prec = _wptr(col_w)
+    rc = lib.nrh_color_eval(prec, wp, P(col_b), P(feat_tiles), P(ro), P(rd), P(tmid), P(nhat), P(raymisc), nrays,
                             P(color), _lib.stream_handle())
     _lib.check(rc, "nrh_color_eval")
     return color

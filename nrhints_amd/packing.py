@@ -21,13 +21,13 @@ from typing import Dict, Tuple
 import torch
 
 # geometry shared with csrc/nrh_mlp.h
-SDF_L0_FLOATS = 8 * 2 * 3 * 256
+SDF_L0_FLOATS = 8 * 2 * 4 * 256
 SDF_REG_FLOATS = 8 * 2 * 16 * 256
 SDF_R0_FLOATS = 2 * 2 * 16 * 256
 SDF_PACKED_FLOATS = SDF_L0_FLOATS + 15 * SDF_REG_FLOATS + SDF_R0_FLOATS
 SDF_BIAS_FLOATS = 9 * 256
 SDF_HEAD_FLOATS = 257
-COL_C0B_FLOATS = 8 * 2 * 7 * 256
+COL_C0B_FLOATS = 8 * 2 * 8 * 256
 COL_PACKED_FLOATS = SDF_REG_FLOATS + COL_C0B_FLOATS + 3 * SDF_REG_FLOATS + 2 * 16 * 256
 COL_BIAS_FLOATS = 4 * 256 + 16
 RAYMISC_STRIDE = 100
@@ -46,6 +46,34 @@ def pack_stage(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     nch, kb = rows // 32, cols // 16
     # [chunk, obi, i, kb, q, c] -> [chunk, obi, kb, q, i, c];  lane = q*16 + i
     return wp.reshape(nch, 2, 16, kb, 4, 4).permute(0, 1, 3, 4, 2, 5).reshape(-1)
+
+
+LO_SCALE = 2048.0
+
+
+def split_f16(x: torch.Tensor):
+    """fp32 -> (hi, lo) fp16 with x ~= hi + lo / 2^11  (csrc/nrh_mlp.h, precision mode "f16x3")."""
+    hi = x.to(torch.float16)
+    lo = ((x - hi.to(x.dtype)) * LO_SCALE).to(torch.float16)
+    return hi, lo
+
+
+def pack_stage_h3(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """f16x3 packing of a dense [out,in] matrix (rows % 32 == 0, cols % 32 == 0) -> fp16 tensor of 2*rows*cols
+    elements (same byte count as the fp32 packing):
+
+        packed[chunk][obi][s][part][lane][e]   part 0 = hi, 1 = lo;   e < 4: W[row][32s + 4q + e]
+                                                                      e >= 4: W[row][32s + 16 + 4q + (e-4)]
+    with row = (2*chunk + obi)*16 + (lane & 15), q = lane >> 4 - the 8 fp16 A elements of one
+    v_mfma_f32_16x16x32_f16, K slot (q, e) matching the B operand built from two D-layout blocks."""
+    assert rows % 32 == 0 and cols % 32 == 0 and w.shape[0] <= rows and w.shape[1] <= cols
+    wp = torch.nn.functional.pad(w.detach().float(), (0, cols - w.shape[1], 0, rows - w.shape[0]))
+    nch, ks = rows // 32, cols // 32
+    hi, lo = split_f16(wp)
+    both = torch.stack([hi, lo], 0)                                 # [part, rows, cols]
+    # [part, chunk, obi, i, s, half(2 blocks), q, e4] -> [chunk, obi, s, part, q, i, half, e4]; lane = q*16+i, e = half*4+e4
+    t = both.reshape(2, nch, 2, 16, ks, 2, 4, 4).permute(1, 2, 4, 0, 6, 3, 5, 7)
+    return t.reshape(-1).contiguous()
 
 
 def _pad_vec(b: torch.Tensor, n: int) -> torch.Tensor:
@@ -80,19 +108,21 @@ def check_default_shapes(d: Dict[str, torch.Tensor]) -> None:
                              "shadow + 4-roughness specular hints)")
 
 
-def pack_sdf(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """-> (packed stages [SDF_PACKED_FLOATS], biases [9*256], head [257]) in kernel execution order
-    L0 | L1..L7 | FEAT | R7..R1 | R0  (R_l = W_l^T for the analytic reverse chain)."""
+def pack_sdf(d: Dict[str, torch.Tensor], precision: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (packed stages, biases [9*256], head [257]) in kernel execution order
+    L0 | L1..L7 | FEAT | R7..R1 | R0  (R_l = W_l^T for the analytic reverse chain).
+    precision 0: float32 [SDF_PACKED_FLOATS]; precision 1 (f16x3): float16 [2 * SDF_PACKED_FLOATS]."""
+    ps = pack_stage if precision == 0 else pack_stage_h3
     w = [d[f"sdf_w{i}"] for i in range(8)]
     w4 = w[4] / math.sqrt(2.0)           # cat([h, embed]) / sqrt(2) folded into the weights
     fwd = [w[0], w[1], w[2], w[3], w4, w[5], w[6], w[7]]
-    parts = [pack_stage(fwd[0], 256, 48)]
-    parts += [pack_stage(fwd[l], 256, 256) for l in range(1, 8)]
-    parts.append(pack_stage(d["feat_w"], 256, 256))
-    parts += [pack_stage(fwd[l].t(), 256, 256) for l in range(7, 0, -1)]
-    parts.append(pack_stage(fwd[0].t(), 64, 256))
+    parts = [ps(fwd[0], 256, 64)]
+    parts += [ps(fwd[l], 256, 256) for l in range(1, 8)]
+    parts.append(ps(d["feat_w"], 256, 256))
+    parts += [ps(fwd[l].t(), 256, 256) for l in range(7, 0, -1)]
+    parts.append(ps(fwd[0].t(), 64, 256))
     packed = torch.cat(parts)
-    assert packed.numel() == SDF_PACKED_FLOATS
+    assert packed.numel() == SDF_PACKED_FLOATS * (1 if precision == 0 else 2)
     bias = torch.cat([_pad_vec(d[f"sdf_b{i}"], 256) for i in range(8)] + [d["feat_b"]])
     head = torch.cat([d["sdf_head_w"].reshape(-1), d["sdf_head_b"].reshape(-1)])
     return packed.contiguous(), bias.contiguous(), head.contiguous()
@@ -109,15 +139,16 @@ def color_input_permutation() -> Tuple[torch.Tensor, torch.Tensor]:
     return feat, misc
 
 
-def pack_color(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (packed stages [COL_PACKED_FLOATS], biases [4*256+16]) in order C0a | C0b | C1 | C2 | C3 | C4."""
+def pack_color(d: Dict[str, torch.Tensor], precision: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (packed stages, biases [4*256+16]) in order C0a | C0b | C1 | C2 | C3 | C4 (fp32 or fp16 pairs, see pack_sdf)."""
+    ps = pack_stage if precision == 0 else pack_stage_h3
     fi, mi = color_input_permutation()
     w0 = d["col_w0"]
-    parts = [pack_stage(w0[:, fi.to(w0.device)], 256, 256), pack_stage(w0[:, mi.to(w0.device)], 256, 112)]
-    parts += [pack_stage(d[f"col_w{l}"], 256, 256) for l in (1, 2, 3)]
-    parts.append(pack_stage(d["col_w4"], 32, 256))
+    parts = [ps(w0[:, fi.to(w0.device)], 256, 256), ps(w0[:, mi.to(w0.device)], 256, 128)]
+    parts += [ps(d[f"col_w{l}"], 256, 256) for l in (1, 2, 3)]
+    parts.append(ps(d["col_w4"], 32, 256))
     packed = torch.cat(parts)
-    assert packed.numel() == COL_PACKED_FLOATS
+    assert packed.numel() == COL_PACKED_FLOATS * (1 if precision == 0 else 2)
     bias = torch.cat([d["col_b0"], d["col_b1"], d["col_b2"], d["col_b3"], _pad_vec(d["col_b4"], 16)])
     return packed.contiguous(), bias.contiguous()
 

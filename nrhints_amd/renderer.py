@@ -101,9 +101,16 @@ class SingleVarianceNetwork(nn.Module):
 class NeuSHintRenderer(nn.Module):
     #: rays per C call; bounds the workspace (about 145 KB per ray + 268 MB of gradient scratch)
     max_chunk_rays = 32768
+    #: matrix arithmetic of the MLP kernels: "f32" (v_mfma_f32_16x16x4_f32, exact fp32) or "f16x3" (three
+    #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
+    precision = "f32"
 
-    def __init__(self, config: NeuSModelConfig = None):
+    def __init__(self, config: NeuSModelConfig = None, precision: Optional[str] = None):
         super().__init__()
+        if precision is not None:
+            if precision not in _lib.PRECISIONS:
+                raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+            self.precision = precision
         config = NeuSModelConfig() if config is None else config
         why = unsupported_reason(config)
         if why is not None:
@@ -123,7 +130,7 @@ class NeuSHintRenderer(nn.Module):
 
     # ---------------------------------------------------------------------------------------------
     def _param_key(self, device):
-        return (str(device),) + tuple((id(p), p._version) for p in self.parameters())
+        return (str(device), self.precision) + tuple((id(p), p._version) for p in self.parameters())
 
     def packed_params(self, device):
         """Fold weight-norm and pack for the kernels; cached until a parameter changes."""
@@ -133,10 +140,11 @@ class NeuSHintRenderer(nn.Module):
                 state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
                 d = packing.dense_params(state)
                 packing.check_default_shapes(d)
-                sw, sb, sh = packing.pack_sdf(d)
-                cw, cb = packing.pack_color(d)
+                prec = _lib.PRECISIONS[self.precision]
+                sw, sb, sh = packing.pack_sdf(d, prec)
+                cw, cb = packing.pack_color(d, prec)
                 inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6).item())
-            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s)
+            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s, precision=prec)
             self._packed_key = key
         return self._packed
 
@@ -204,8 +212,8 @@ class NeuSHintRenderer(nn.Module):
 
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
-        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"]), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
-                          _lib.ptr(pk["col_w"]), _lib.ptr(pk["col_b"]), pk["inv_s"])
+        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
+                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"])
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         rgb, depth, vis = new(n, 3), new(n, 1), new(n, 1)
@@ -245,7 +253,7 @@ class NeuSHintRenderer(nn.Module):
         t = torch.zeros(n, dtype=torch.float32, device=pts.device)
         out = torch.empty(n, 1, dtype=torch.float32, device=pts.device)
         P = _lib.ptr
-        rc = lib.nrh_sdf_eval(0, P(pk["sdf_w"]), P(pk["sdf_b"]), P(pk["sdf_head"]), P(pts), P(zeros3), P(t), 1, 1, n,
+        rc = lib.nrh_sdf_eval(pk["precision"], 0, P(pk["sdf_w"], pk["sdf_w"].dtype), P(pk["sdf_b"]), P(pk["sdf_head"]), P(pts), P(zeros3), P(t), 1, 1, n,
                               P(out), 1, None, None, None, _lib.stream_handle())
         _lib.check(rc, "nrh_sdf_eval")
         return out

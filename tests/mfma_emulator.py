@@ -29,8 +29,50 @@ def mfma_16x16x4(a, b, c):
     return out
 
 
+def mfma_16x16x32(a, b, c):
+    """a, b: [64, 8] per-lane fp16 operands (as float64 values); K slot (q, e) of lane q*16 + i/j.
+    Any consistent slot -> k map gives the same result, which is all the kernels rely on."""
+    A = a.reshape(4, 16, 8).transpose(1, 0, 2).reshape(16, 32)     # [i, (q,e)]
+    B = b.reshape(4, 16, 8).transpose(0, 2, 1).reshape(32, 16)     # [(q,e), j]
+    D = A @ B
+    out = c.copy()
+    for r in range(4):
+        out[r] += D[4 * Q + r, J]
+    return out
+
+
+def split16(x):
+    hi = x.astype(np.float16)
+    lo = ((x - hi.astype(np.float64)) * 2048.0).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def run_stage_h3(packed16, KB, NCH, inp, init=None):
+    """f16x3 stage: packed16 = fp16 buffer from packing.pack_stage_h3; inp [KB*4, 64] float values (split here
+    exactly as Act<1>::set_chunk does)."""
+    KS = KB // 2
+    w = np.asarray(packed16, dtype=np.float64).reshape(NCH, 2, KS, 2, 64, 8)
+    out = np.zeros((NCH * 8, 64))
+    for ch in range(NCH):
+        for obi in range(2):
+            acc = np.zeros((4, 64)) if init is None else init[ch * 8 + obi * 4: ch * 8 + obi * 4 + 4].copy()
+            cross = np.zeros((4, 64))
+            for s in range(KS):
+                vals = inp[s * 8: s * 8 + 8].T                      # [lane, 8]: blocks 2s (regs 0..3), 2s+1 (0..3)
+                bh, bl = split16(vals)
+                ah, al = w[ch, obi, s, 0], w[ch, obi, s, 1]
+                acc = mfma_16x16x32(ah, bh, acc)
+                cross = mfma_16x16x32(ah, bl, cross)
+                cross = mfma_16x16x32(al, bh, cross)
+            out[ch * 8 + obi * 4: ch * 8 + obi * 4 + 4] = acc + cross / 2048.0
+    return out
+
+
 def run_stage(packed, KB, NCH, inp, init=None):
-    """packed: flat stage buffer; inp: [KB*4, 64]; returns out [NCH*8, 64] (D-layout)."""
+    """packed: flat stage buffer; inp: [KB*4, 64]; returns out [NCH*8, 64] (D-layout).
+    A float16 buffer selects the f16x3 emulation."""
+    if packed.dtype == np.float16:
+        return run_stage_h3(packed, KB, NCH, inp, init)
     w = packed.reshape(NCH, 2, KB, 64, 4)
     out = np.zeros((NCH * 8, 64))
     for ch in range(NCH):
@@ -91,19 +133,29 @@ def softplus100(z):
 
 def sdf_tile(packed, bias, head, pts16, mode):
     """One wave's work: pts16 [16,3] -> (sdf [16], grad [16,3] or None, feat [16,256] or None)."""
-    packed = np.asarray(packed, dtype=np.float64)
+    packed = np.asarray(packed)
+    sc = 2 if packed.dtype == np.float16 else 1      # fp16 pairs: two elements per fp32-equivalent slot
+    if sc == 1:
+        packed = packed.astype(np.float64)
+
+    packed_ = packed
+
+    class _Buf:
+        def __getitem__(self, sl):
+            return packed_[sl.start * sc: sl.stop * sc]
+    packed = _Buf()
     bias = np.asarray(bias, dtype=np.float64)
     head = np.asarray(head, dtype=np.float64)
     x3 = pts16[J] * 3.0                     # per lane [64,3]
     allv = enc_all(x3)                      # [64,39]
-    emb = np.zeros((12, 64))
-    for b in range(3):
+    emb = np.zeros((16, 64))
+    for b in range(4):
         for r in range(4):
             e = 16 * b + 4 * Q + r
             emb[b * 4 + r] = np.where(e < 39, allv[LANES, np.minimum(e, 38)], 0.0)
     sig = {}
     off = 0
-    out = run_stage(packed[off: off + pk.SDF_L0_FLOATS], 3, 8, emb)
+    out = run_stage(packed[off: off + pk.SDF_L0_FLOATS], 4, 8, emb)
     off += pk.SDF_L0_FLOATS
     h, sig[0] = softplus100(out + bias_regs(bias, 0))
     head_part = None
@@ -162,7 +214,16 @@ def sdf_tile(packed, bias, head, pts16, mode):
 
 def color_tile(packed, bias, feat16, misc16):
     """feat16 [16,256], misc16 [16,105] (kernel order) -> rgb [16,3]."""
-    packed = np.asarray(packed, dtype=np.float64)
+    packed = np.asarray(packed)
+    sc = 2 if packed.dtype == np.float16 else 1
+    if sc == 1:
+        packed = packed.astype(np.float64)
+    packed_ = packed
+
+    class _Buf:
+        def __getitem__(self, sl):
+            return packed_[sl.start * sc: sl.stop * sc]
+    packed = _Buf()
     bias = np.asarray(bias, dtype=np.float64)
     h = np.zeros((64, 64))
     for b in range(16):
@@ -171,12 +232,12 @@ def color_tile(packed, bias, feat16, misc16):
     off = 0
     part = run_stage(packed[off: off + pk.SDF_REG_FLOATS], 16, 8, h)
     off += pk.SDF_REG_FLOATS
-    misc = np.zeros((28, 64))
-    for b in range(7):
+    misc = np.zeros((32, 64))
+    for b in range(8):
         for r in range(4):
             m = 16 * b + 4 * Q + r
             misc[b * 4 + r] = np.where(m < 105, misc16[J, np.minimum(m, 104)], 0.0)
-    out = run_stage(packed[off: off + pk.COL_C0B_FLOATS], 7, 8, misc, init=part)
+    out = run_stage(packed[off: off + pk.COL_C0B_FLOATS], 8, 8, misc, init=part)
     off += pk.COL_C0B_FLOATS
     h = np.maximum(out + bias_regs(bias, 0), 0.0)
     for l in (1, 2, 3):

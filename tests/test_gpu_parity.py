@@ -22,11 +22,12 @@ def cu(a):
     return (T(a) if isinstance(a, np.ndarray) else a).float().contiguous().cuda()
 
 
-@pytest.fixture(scope="module", params=["a", "b"])
+@pytest.fixture(scope="module", params=["a-f32", "b-f32", "a-f16x3", "b-f16x3"])
 def scene(request, scene_states):
-    tag = request.param
+    """scene (a: reference init, b: perturbed, sharp) x matrix arithmetic (exact fp32 MFMA | fp16 3-term split)."""
+    tag, prec = request.param.split("-")
     st = scene_states[tag]
-    model = na.NeuSHintRenderer(na.NeuSModelConfig())
+    model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision=prec)
     model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
     model = model.cuda().eval()
     packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()))
@@ -36,7 +37,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 100
+    assert lib.nrh_version() >= 101
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 100
+    assert lib.nrh_version() == 101
     sizes = (ctypes.c_int * 8)()
     assert lib.nrh_param_sizes(sizes) == 0
     assert list(sizes)[:7] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS, pk.COL_PACKED_FLOATS,

@@ -45,6 +45,33 @@ def test_color_chain_emulated(packed):
     np.testing.assert_allclose(rgb, ref, rtol=0, atol=1e-10)
 
 
+def test_f16x3_chain_emulated(scene_states):
+    """The f16x3 packing + split arithmetic (hi, lo*2^11; three products, two accumulators) through the whole SDF
+    chain and the colour net: fp32-class accuracy against the fp64 oracle."""
+    st = {k: torch.from_numpy(np.asarray(v)) for k, v in scene_states["b"].items()}
+    d = pk.dense_params(st)
+    p64 = orc.params_from_state(scene_states["b"], torch.float64)
+    w, b, head = pk.pack_sdf(d, precision=1)
+    assert w.dtype == torch.float16 and w.numel() == 2 * pk.SDF_PACKED_FLOATS
+    rs = np.random.RandomState(3)
+    pts = (rs.rand(16, 3) * 2 - 1) * 0.8
+    sdf, grad, feat = emu.sdf_tile(w.numpy(), b.numpy(), head.numpy(), pts, mode=2)
+    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, torch.from_numpy(pts))
+    np.testing.assert_allclose(sdf, o_sdf.numpy()[:, 0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(feat, o_feat.numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(grad, o_grad.numpy(), rtol=0, atol=1e-4)
+    cw, cb = pk.pack_color(d, precision=1)
+    P = 16
+    T = torch.from_numpy
+    ptsc, nrm, view = rs.randn(P, 3), rs.randn(P, 3), rs.randn(P, 3)
+    featc, pl, vis, cue = rs.randn(P, 256) * 0.3, rs.randn(P, 3) * 3, rs.rand(P, 1), rs.rand(P, 4)
+    ref = orc.color_forward(p64, T(ptsc), T(nrm), T(view), T(featc), T(pl), T(vis), T(cue)).numpy()
+    misc = np.concatenate([ptsc, nrm, orc.nerf_encode(T(view), 4).numpy(), orc.nerf_encode(T(pl), 4).numpy(),
+                           orc.nerf_encode(T(vis), 4).numpy(), orc.nerf_encode(T(cue), 4).numpy()], axis=1)
+    rgb = emu.color_tile(cw.numpy(), cb.numpy(), featc, misc)
+    np.testing.assert_allclose(rgb, ref, rtol=0, atol=2e-6)
+
+
 def test_feat_tile_roundtrip():
     rows = torch.randn(37, 256)
     tiles = pk.rows_to_feat_tiles(rows)
