@@ -37,7 +37,8 @@ const char* nrh_last_error_string(void);
 
 /* Sizes (in floats) of the packed parameter buffers and of the per-wave scratch the gradient kernels need.
  * out[0] sdf packed weights, out[1] sdf biases, out[2] sdf head, out[3] colour packed weights,
- * out[4] colour biases, out[5] per-ray colour-input table stride, out[6] scratch floats per resident wave.
+ * out[4] colour biases, out[5] per-ray colour-input table stride, out[6] scratch floats per resident wave,
+ * out[7] waves per MLP workgroup (scratch = nrh_mlp_grid() * out[7] * out[6] floats).
  * `out` is a HOST pointer to 8 ints. */
 int nrh_param_sizes(int* out);
 
@@ -60,7 +61,7 @@ int nrh_kernel_timing_read(double* total_ms, long long* launches);
  *   mode 2: sdf + feature + grad  (SDFNetwork.forward,  fields/sdf_field.py:106-123 + .gradient; render_core :504-508)
  * sdf  is written at sdf[ray * sdf_stride + j];  grad [nrays*n_per_ray,3];  feat in 16-point D-layout tiles
  * [ceil(npts/16)][16][64][4] (nrhints_amd/packing.py: feat_tiles_to_rows converts to [npts,256]).
- * scratch: nrh_mlp_grid() * 4 * out[6] floats (modes 1, 2), may be null for mode 0. */
+ * scratch: nrh_mlp_grid() * out[7] * out[6] floats (modes 1, 2), may be null for mode 0. */
 int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                  const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                  int sdf_stride, float* grad, float* feat, float* scratch, void* stream);

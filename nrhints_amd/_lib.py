@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnrhints_hip.so")
+LIB_PATH = os.environ.get("NRHINTS_HIP_LIB") or os.path.join(_HERE, "lib", "libnrhints_hip.so")
 
 NRH_OK = 0
 _ERRNAMES = {-1: "NRH_E_INVALID", -2: "NRH_E_LAUNCH", -3: "NRH_E_WORKSPACE", -4: "NRH_E_UNSUPPORTED"}

@@ -44,7 +44,7 @@ int device_cus() {
 
 int mlp_grid() {
   const int cus = device_cus();
-  return cus > 0 ? cus * 2 : 0;  // 2 workgroups (8 waves, 2 x 64 KiB LDS) resident per CU
+  return cus > 0 ? cus * (8 / nrh::WG_WAVES) : 0;  // 8 resident waves per CU (2 per SIMD at 256 VGPRs)
 }
 
 int ensure_attrs() {
@@ -98,7 +98,7 @@ int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const floa
   a.scratch = scratch;
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride; a.sdf_stride = sdf_stride;
-  const long long groups = (a.npts + 63) / 64;
+  const long long groups = (a.npts + 16 * nrh::WG_WAVES - 1) / (16 * nrh::WG_WAVES);
   if (groups > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_sdf_eval: too many points%s", "");
   a.ntile_groups = (int)groups;
   const int grid = (int)(groups < mlp_grid() ? groups : mlp_grid());
@@ -139,7 +139,7 @@ int color_eval_impl(int prec, const float* w, const float* b, const float* feat,
   a.w = w; a.b = b; a.feat = feat; a.ro = ro; a.rd = rd; a.tmid = tmid; a.nhat = nhat; a.raymisc = raymisc;
   a.color = color;
   a.npts = nrays * 128;
-  const long long groups = (a.npts + 63) / 64;
+  const long long groups = (a.npts + 16 * nrh::WG_WAVES - 1) / (16 * nrh::WG_WAVES);
   if (groups > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_color_eval: too many points%s", "");
   a.ntile_groups = (int)groups;
   const int grid = (int)(groups < mlp_grid() ? groups : mlp_grid());
@@ -202,7 +202,7 @@ int nrh_param_sizes(int* out) {
   out[4] = nrh::COL_BIAS_FLOATS;
   out[5] = nrh::RAYMISC_STRIDE;
   out[6] = nrh::SDF_SCRATCH_FLOATS_PER_WAVE;
-  out[7] = 0;
+  out[7] = nrh::WG_WAVES;
   return NRH_OK;
 }
 
@@ -279,7 +279,7 @@ long long nrh_render_workspace_floats(long long nrays) {
 #define X(name, per) tot += round64(nrays * (long long)(per));
   NRH_WS_FIELDS(X)
 #undef X
-  tot += (long long)mlp_grid() * 4 * nrh::SDF_SCRATCH_FLOATS_PER_WAVE;
+  tot += (long long)mlp_grid() * nrh::WG_WAVES * nrh::SDF_SCRATCH_FLOATS_PER_WAVE;
   return tot;
 }
 

@@ -35,9 +35,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
   int par = 0;
   dma_chunk(a.w + COL_OFF_C0A, smem, 32, wave, lane);
   __syncthreads();
+  stagger_enter(wave);
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
-    const long long tile = (long long)tg * 4 + wave;
+    const long long tile = (long long)tg * WG_WAVES + wave;
     const long long P = tile * TILE_PTS + j;
     const bool valid = P < a.npts;
     const long long Pc = valid ? P : a.npts - 1;
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       const float* ft = a.feat + (size_t)tilec * (16 * 256);
 #pragma unroll
       for (int ch = 0; ch < 8; ++ch) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ft + ((2 * ch) * 64 + lane) * 4);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4);
+        const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(ft + ((2 * ch) * 64 + lane) * 4));
+        const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4));
         const float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         h.set_chunk(ch, o);
       }
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       run_stage<PREC, 16, 1, false>(a.w + COL_OFF_C4, a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, epi, wave, lane);
     }
   }
+  stagger_exit(wave);
 }
 
 }  // namespace nrh

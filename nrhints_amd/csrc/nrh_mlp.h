@@ -21,16 +21,47 @@ namespace nrh {
 
 constexpr int WBUF_BYTES = 32768;          // one LDS weight buffer (2 ob x 16 kb x 1 KiB)
 constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
-constexpr int MLP_THREADS = 256;           // 4 waves, one 16-point tile each
+// ---- tuning knobs (compile-time; profiles/README.md records what each was measured to do) ----
+#ifndef NRH_WG_WAVES
+#define NRH_WG_WAVES 4        // waves per workgroup = 16-point tiles sharing one weight stream
+#endif
+#ifndef NRH_KPREFETCH
+#define NRH_KPREFETCH 1       // K steps of A operands in flight ahead of the MFMAs (f16x3 path)
+#endif
+#ifndef NRH_SCHED_BARRIER
+#define NRH_SCHED_BARRIER 1   // pin the ds_read / MFMA interleave with sched_barrier per K step
+#endif
+#ifndef NRH_NT_SCRATCH
+#define NRH_NT_SCRATCH 0      // non-temporal loads/stores for the stream-once sigma' scratch and feature tiles
+#endif
+#ifndef NRH_PKRTZ
+#define NRH_PKRTZ 0           // v_cvt_pkrtz_f16_f32 for the hi/lo split (round-toward-zero hi, still exact hi+lo)
+#endif
+#ifndef NRH_PIPE_EPI
+#define NRH_PIPE_EPI 0        // run the epilogue of chunk c after the MFMAs of chunk c+1 are issued (same wave overlap)
+#endif
+#ifndef NRH_SGB_VALU
+#define NRH_SGB_VALU 0        // >0: sched_group_barrier pattern "1 MFMA, N VALU" inside the f16x3 K loop
+#endif
+// ablation switches (WRONG RESULTS - timing experiments only, see profiles/README.md)
+#ifndef NRH_ABL
+#define NRH_ABL 0             // bit 0: no LDS-DMA, 1: no barrier, 2: no MFMA, 3: no ds_read of A (f16x3), 4: trivial epilogue
+#endif
+#ifndef NRH_STAGGER
+#define NRH_STAGGER 0         // 8-wave workgroups: waves 4..7 run one phase behind waves 0..3 (MFMA phase | epilogue
+#endif                        // phase, a barrier after each) so the two waves of every SIMD are always in opposite phases
+constexpr int WG_WAVES = NRH_WG_WAVES;
+constexpr int MLP_THREADS = 64 * WG_WAVES;  // one 16-point tile per wave
 constexpr int TILE_PTS = 16;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Asynchronously copy `npieces` KiB (global, contiguous) into an LDS buffer; the 4 waves interleave.
+// Asynchronously copy `npieces` KiB (global, contiguous) into an LDS buffer; the waves of the workgroup interleave.
 __device__ __forceinline__ void dma_chunk(const float* __restrict__ src, char* dst_lds, int npieces, int wave,
                                           int lane) {
-  for (int k = wave; k < npieces; k += 4) {
+  if (NRH_ABL & 1) return;
+  for (int k = wave; k < npieces; k += WG_WAVES) {
     __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 256 + lane * 4), (lptr_t)(dst_lds + k * 1024), 16, 0, 0);
   }
 }
@@ -51,10 +82,47 @@ constexpr float LO_SCALE = 2048.0f;
 constexpr float LO_UNSCALE = 1.0f / 2048.0f;
 
 __device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
+#if NRH_PKRTZ
+  typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+  const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h.x) * LO_SCALE, (b - (float)h.y) * LO_SCALE);
+#else
   const f16x2 h = {(_Float16)a, (_Float16)b};
   const f16x2 l = {(_Float16)((a - (float)h.x) * LO_SCALE), (_Float16)((b - (float)h.y) * LO_SCALE)};
+#endif
   hi = __builtin_bit_cast(uint32_t, h);
   lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// stream-once global traffic (sigma' scratch, feature tiles)
+template <typename V>
+__device__ __forceinline__ void st_stream(V* p, V v) {
+#if NRH_NT_SCRATCH
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+template <typename V>
+__device__ __forceinline__ V ld_stream(const V* p) {
+#if NRH_NT_SCRATCH
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
+// Phase offset of the two halves of an 8-wave workgroup (NRH_STAGGER): call once at kernel entry / exit.
+__device__ __forceinline__ void stagger_enter(int wave) {
+#if NRH_STAGGER
+  static_assert(NRH_WG_WAVES == 8, "NRH_STAGGER needs 8-wave workgroups");
+  if (wave >= 4) __syncthreads();
+#endif
+}
+__device__ __forceinline__ void stagger_exit(int wave) {
+#if NRH_STAGGER
+  if (wave < 4) __syncthreads();
+#endif
 }
 
 // Activations of one layer for this wave's 16 points, in the form the MFMA B operand wants them.
@@ -94,6 +162,7 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
                                           const float* init, Epi&& epi, int wave, int lane) {
   constexpr int PIECES = 2 * KB;
+  f32x4 pend0 = {0.f, 0.f, 0.f, 0.f}, pend1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     char* nxt = smem + (par ^ 1) * WBUF_BYTES;
@@ -136,37 +205,74 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     } else {
       constexpr int KS = KB / 2;
       const u32x4* A = reinterpret_cast<const u32x4*>(smem + par * WBUF_BYTES);
-      auto ld = [&](int obi, int s, int part) { return A[((obi * KS + s) * 2 + part) * 64 + lane]; };
+      auto ld = [&](int obi, int s, int part) {
+        if (NRH_ABL & 8) { u32x4 z = {(uint32_t)(obi + s), (uint32_t)part, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(z)); return z; }
+        return A[((obi * KS + s) * 2 + part) * 64 + lane];
+      };
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};  // cross terms, scaled by 2^11
-      u32x4 ah0 = ld(0, 0, 0), al0 = ld(0, 0, 1), ah1 = ld(1, 0, 0), al1 = ld(1, 0, 1);
+      constexpr int PF = NRH_KPREFETCH;          // K steps in flight ahead of the one being multiplied
+      u32x4 ra[PF + 1][4];                       // ring of A operand sets {hi0, lo0, hi1, lo1}
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        if (p < KS) { ra[p][0] = ld(0, p, 0); ra[p][1] = ld(0, p, 1); ra[p][2] = ld(1, p, 0); ra[p][3] = ld(1, p, 1); }
+      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        u32x4 nh0 = ah0, nl0 = al0, nh1 = ah1, nl1 = al1;
-        if (s + 1 < KS) {
-          nh0 = ld(0, s + 1, 0);
-          nl0 = ld(0, s + 1, 1);
-          nh1 = ld(1, s + 1, 0);
-          nl1 = ld(1, s + 1, 1);
+        if (s + PF < KS) {
+          const int w = (s + PF) % (PF + 1);
+          ra[w][0] = ld(0, s + PF, 0);
+          ra[w][1] = ld(0, s + PF, 1);
+          ra[w][2] = ld(1, s + PF, 0);
+          ra[w][3] = ld(1, s + PF, 1);
         }
+        const int c = s % (PF + 1);
         const u32x4 bhu = {in.h[s * 4 + 0], in.h[s * 4 + 1], in.h[s * 4 + 2], in.h[s * 4 + 3]};
         const u32x4 blu = {in.l[s * 4 + 0], in.l[s * 4 + 1], in.l[s * 4 + 2], in.l[s * 4 + 3]};
         const f16x8 bh = __builtin_bit_cast(f16x8, bhu), bl = __builtin_bit_cast(f16x8, blu);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah0), bh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah1), bh, acc1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah0), bl, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah1), bl, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al0), bh, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al1), bh, c1, 0, 0, 0);
-        ah0 = nh0; al0 = nl0; ah1 = nh1; al1 = nl1;
+        const f16x8 ah0 = __builtin_bit_cast(f16x8, ra[c][0]), al0 = __builtin_bit_cast(f16x8, ra[c][1]);
+        const f16x8 ah1 = __builtin_bit_cast(f16x8, ra[c][2]), al1 = __builtin_bit_cast(f16x8, ra[c][3]);
+        if (NRH_ABL & 4) {
+          asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(ah0), "v"(ah1), "v"(al0), "v"(al1), "v"(bh), "v"(bl));
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, c1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c1, 0, 0, 0);
+        }
+#if NRH_SGB_VALU > 0
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, NRH_SGB_VALU, 0);  // N VALU / TRANS
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                     // next K step's 4 ds_read_b128
+#elif NRH_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       acc0 += c0 * LO_UNSCALE;
       acc1 += c1 * LO_UNSCALE;
     }
+#if NRH_PIPE_EPI
+    // the previous chunk's epilogue is independent of this chunk's MFMAs: placed here, the scheduler may slot its
+    // VALU work into the 16-cycle issue gaps of the matrix pipe
+    if (ch > 0) epi(ch - 1, pend0, pend1);
+    pend0 = acc0;
+    pend1 = acc1;
+#else
+#if NRH_STAGGER
+    __syncthreads();  // phase boundary: the other half of the workgroup swaps between its MFMA and epilogue phases
+#endif
     epi(ch, acc0, acc1);
-    __syncthreads();  // waits this wave's LDS-DMA (vmcnt(0)) and orders the buffer swap
+#endif
+    if (!(NRH_ABL & 2)) __syncthreads();  // waits this wave's LDS-DMA (vmcnt(0)) and orders the buffer swap
     par ^= 1;
   }
+#if NRH_PIPE_EPI
+  epi(NCH - 1, pend0, pend1);
+#endif
 }
 
 // ---------------- packed-buffer geometry of the SDF net (floats) ----------------

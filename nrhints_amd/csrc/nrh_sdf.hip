@@ -32,12 +32,12 @@ struct SdfArgs {
   float* sdf;          // sdf[ray * sdf_stride + j]
   float* grad;         // [npts,3] (MODE >= 1)
   float* feat;         // [ntiles][16][64][4] D-layout tiles (MODE 2)
-  float* scratch;      // gridDim.x * 4 * SDF_SCRATCH_FLOATS_PER_WAVE (MODE >= 1)
+  float* scratch;      // gridDim.x * WG_WAVES * SDF_SCRATCH_FLOATS_PER_WAVE (MODE >= 1)
   long long npts;
   int n_per_ray;
   int t_stride;
   int sdf_stride;
-  int ntile_groups;    // ceil(npts / 64)
+  int ntile_groups;    // ceil(npts / (16 * WG_WAVES))
 };
 
 __device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
@@ -49,22 +49,22 @@ __device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
 template <int PREC>
 __device__ __forceinline__ void dsig_store(float* scr, int l, int ch, int lane, const float (&d)[8]) {
   if constexpr (PREC == 0) {
-    *reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4) = f32x4{d[0], d[1], d[2], d[3]};
-    *reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4) = f32x4{d[4], d[5], d[6], d[7]};
+    st_stream(reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4), f32x4{d[0], d[1], d[2], d[3]});
+    st_stream(reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4), f32x4{d[4], d[5], d[6], d[7]});
   } else {
     const u32x4 v = {unorm16x2(d[0], d[1]), unorm16x2(d[2], d[3]), unorm16x2(d[4], d[5]), unorm16x2(d[6], d[7])};
-    *reinterpret_cast<u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4) = v;
+    st_stream(reinterpret_cast<u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4), v);
   }
 }
 template <int PREC>
 __device__ __forceinline__ void dsig_load(const float* scr, int l, int ch, int lane, float (&d)[8]) {
   if constexpr (PREC == 0) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4);
+    const f32x4 a = ld_stream(reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4));
+    const f32x4 b = ld_stream(reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4));
 #pragma unroll
     for (int r = 0; r < 4; ++r) { d[r] = a[r]; d[4 + r] = b[r]; }
   } else {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4);
+    const u32x4 v = ld_stream(reinterpret_cast<const u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       d[2 * r] = (float)(v[r] & 0xffffu) * (1.0f / 65535.0f);
@@ -85,13 +85,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   int par = 0;
-  float* const scr = (MODE >= 1) ? a.scratch + (size_t)(blockIdx.x * 4 + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
+  float* const scr = (MODE >= 1) ? a.scratch + (size_t)(blockIdx.x * WG_WAVES + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
 
   dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
   __syncthreads();
+  stagger_enter(wave);
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
-    const long long tile = (long long)tg * 4 + wave;
+    const long long tile = (long long)tg * WG_WAVES + wave;
     const long long P = tile * TILE_PTS + j;
     const bool valid = P < a.npts;
     const long long Pc = valid ? P : a.npts - 1;
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         // start of the reverse chain: t_7 = sigma'_7 * (w_s / 3), written by L7's epilogue
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane));
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane));
+          const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)));
+          const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)));
           const float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           h.set_chunk(ch, o);
         }
@@ -176,8 +177,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
           float o[8], d[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            softplus100(acc0[r] + b0[r], o[r], d[r]);
-            softplus100(acc1[r] + b1[r], o[4 + r], d[4 + r]);
+            if (NRH_ABL & 16) {
+              o[r] = acc0[r]; o[4 + r] = acc1[r]; d[r] = b0[r]; d[4 + r] = b1[r];
+            } else {
+              softplus100(acc0[r] + b0[r], o[r], d[r]);
+              softplus100(acc1[r] + b1[r], o[4 + r], d[4 + r]);
+            }
           }
           if (ch >= 6 && s == 3) {
             // skip connection: features 217..255 of L4's input are the embedding (fields/sdf_field.py:113-114)
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
               d[4 + r] = d[4 + r] * (w1[r] / 3.0f);
             }
             if (MODE >= 1) {
-              *reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)) = f32x4{d[0], d[1], d[2], d[3]};
-              *reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)) = f32x4{d[4], d[5], d[6], d[7]};
+              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)), f32x4{d[0], d[1], d[2], d[3]});
+              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)), f32x4{d[4], d[5], d[6], d[7]});
             }
           } else if (MODE >= 1) {
             dsig_store<PREC>(scr, s, ch, lane, d);
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + 8 * 256 + (2 * ch + 1) * 16 + 4 * q);
             if (tile * TILE_PTS < a.npts) {
               float* ft = a.feat + (size_t)tile * (16 * 256);
-              *reinterpret_cast<f32x4*>(ft + ((2 * ch) * 64 + lane) * 4) = acc0 + b0;
-              *reinterpret_cast<f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4) = acc1 + b1;
+              st_stream(reinterpret_cast<f32x4*>(ft + ((2 * ch) * 64 + lane) * 4), acc0 + b0);
+              st_stream(reinterpret_cast<f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4), acc1 + b1);
             }
           }
         } else {
@@ -297,6 +302,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
       }
     }
   }
+  stagger_exit(wave);
 }
 
 }  // namespace nrh

@@ -15,7 +15,7 @@ from . import _lib, packing
 
 def _scratch(device) -> torch.Tensor:
     lib = _lib.load()
-    n = lib.nrh_mlp_grid() * 4 * packing.SDF_SCRATCH_FLOATS_PER_WAVE
+    n = lib.nrh_mlp_grid() * _lib.param_sizes()[7] * packing.SDF_SCRATCH_FLOATS_PER_WAVE
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
