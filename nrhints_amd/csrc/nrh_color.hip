@@ -26,6 +26,13 @@ struct ColorArgs {
   int ntile_groups;
 };
 
+struct BiasV {
+  f32x4 b0, b1;
+};
+__device__ __forceinline__ f32x4 relu4(const f32x4 x) {
+  return f32x4{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f), fmaxf(x[2], 0.0f), fmaxf(x[3], 0.0f)};
+}
+
 template <int PREC>
 __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -35,7 +42,6 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
   int par = 0;
   dma_chunk(a.w + COL_OFF_C0A, smem, 32, wave, lane);
   __syncthreads();
-  stagger_enter(wave);
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -59,11 +65,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
     }
     float part[64];
     {
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
+      auto pre = [&](int) { return 0; };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { part[ch * 8 + r] = acc0[r]; part[ch * 8 + 4 + r] = acc1[r]; }
       };
-      run_stage<PREC, 16, 8, false>(a.w + COL_OFF_C0A, a.w + COL_OFF_C0B, 16, smem, par, h, nullptr, epi, wave, lane);
+      run_stage<PREC, 16, 8, false>(a.w + COL_OFF_C0A, a.w + COL_OFF_C0B, 16, smem, par, h, nullptr, pre, epi, wave, lane);
     }
     // ---- C0b: per-sample + per-ray part; entry m = 16b + 4q + r of [p, n, raymisc[0..98]] ----
     Act<PREC, 8> misc;
@@ -98,51 +105,51 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       }
     }
     {
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch) * 16 + 4 * q);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch + 1) * 16 + 4 * q);
-        float o[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = fmaxf(acc0[r] + b0[r], 0.0f);
-          o[4 + r] = fmaxf(acc1[r] + b1[r], 0.0f);
-        }
-        h.set_chunk(ch, o);
+      auto pre = [&](int ch) {
+        BiasV p;
+        p.b0 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch) * 16 + 4 * q);
+        p.b1 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch + 1) * 16 + 4 * q);
+        return p;
       };
-      run_stage<PREC, 8, 8, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1), 32, smem, par, misc, part, epi, wave, lane);
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
+        h.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
+      };
+      run_stage<PREC, 8, 8, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1), 32, smem, par, misc, part, pre, epi, wave, lane);
     }
     // ---- C1..C3 ----
     for (int l = 1; l <= 3; ++l) {
       Act<PREC, 16> ho;
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + l * 256 + (2 * ch) * 16 + 4 * q);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + l * 256 + (2 * ch + 1) * 16 + 4 * q);
-        float o[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = fmaxf(acc0[r] + b0[r], 0.0f);
-          o[4 + r] = fmaxf(acc1[r] + b1[r], 0.0f);
-        }
-        ho.set_chunk(ch, o);
+      auto pre = [&](int ch) {
+        BiasV p;
+        p.b0 = *reinterpret_cast<const f32x4*>(a.b + l * 256 + (2 * ch) * 16 + 4 * q);
+        p.b1 = *reinterpret_cast<const f32x4*>(a.b + l * 256 + (2 * ch + 1) * 16 + 4 * q);
+        return p;
+      };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
+        ho.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
       };
       const float* wn = (l < 3) ? a.w + col_off_C(l + 1) : a.w + COL_OFF_C4;
-      run_stage<PREC, 16, 8, false>(a.w + col_off_C(l), wn, 32, smem, par, h, nullptr, epi, wave, lane);
+      run_stage<PREC, 16, 8, false>(a.w + col_off_C(l), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
       h = ho;
     }
     // ---- C4: 3 output rows (block 0, lanes q == 0 hold r = 0..2) + sigmoid ----
     {
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
+      auto pre = [&](int) {
+        BiasV p;
+        p.b0 = *reinterpret_cast<const f32x4*>(a.b + 4 * 256 + 4 * q);
+        p.b1 = p.b0;
+        return p;
+      };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
         (void)acc1;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + 4 * 256 + 4 * q);
         if (valid && q == 0) {
 #pragma unroll
-          for (int r = 0; r < 3; ++r) a.color[P * 3 + r] = sigmoidf_(acc0[r] + b0[r]);
+          for (int r = 0; r < 3; ++r) a.color[P * 3 + r] = sigmoidf_(acc0[r] + p.b0[r]);
         }
       };
-      run_stage<PREC, 16, 1, false>(a.w + COL_OFF_C4, a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, epi, wave, lane);
+      run_stage<PREC, 16, 1, false>(a.w + COL_OFF_C4, a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, pre, epi, wave, lane);
     }
   }
-  stagger_exit(wave);
 }
 
 }  // namespace nrh

@@ -69,23 +69,28 @@ __device__ __forceinline__ void incl_sum_128(float f0, float f1, float& s0, floa
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // nn.Softplus(beta=100, threshold=20) and its derivative sigmoid(100 z)
-// (reference: fields/sdf_field.py:104; aten softplus / softplus_backward).
+// (reference: fields/sdf_field.py:104; aten softplus / softplus_backward), four adjacent registers at a time so
+// that the mul/add parts compile to v_pk_*_f32 without register shuffles.
 // Built on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, <= 1 ulp each): the libm
-// expf/log1pf pair costs ~300 VALU instructions per activation, which at 2 009 activations per point is
-// as long as the MFMA work itself.  log2(1+e) instead of log1p(e) costs at most 6e-8 * ln2/100 = 4e-10
-// ABSOLUTE error in h - below half an ulp of the O(1e-2..1) activations it is added to downstream.
-__device__ __forceinline__ void softplus100(float z, float& h, float& dh) {
-  const float t = z * 100.0f;
-  const float e = __builtin_amdgcn_exp2f(t * 1.44269504088896340736f);
-  const float ope = 1.0f + e;
-  const bool lin = t > 20.0f;
-  h = lin ? z : __builtin_amdgcn_logf(ope) * 6.9314718055994530942e-3f;  // log2(1+e) * ln2 / 100
-  dh = lin ? 1.0f : e * __builtin_amdgcn_rcpf(ope);
-}
-__device__ __forceinline__ float softplus100_val(float z) {
-  float h, d;
-  softplus100(z, h, d);
-  return h;
+// expf/log1pf pair costs ~300 VALU instructions per activation.  log2(1+e) instead of log1p(e) costs at most
+// 6e-8 * ln2/100 = 4e-10 ABSOLUTE error in h - below half an ulp of the O(1e-2..1) activations it feeds.
+// The "linear above 20" switch is taken on t*log2(e) > 20*log2(e); at the switch both branches agree to 2e-11.
+template <bool WANT_D>
+__device__ __forceinline__ void softplus100_4(const f32x4 z, f32x4& h, f32x4& d) {
+  const f32x4 t = z * 144.26950408889634074f;  // 100 * log2(e)
+  f32x4 e, l;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+  const f32x4 ope = e + 1.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) l[r] = __builtin_amdgcn_logf(ope[r]);
+  l = l * 6.9314718055994530942e-3f;  // ln2 / 100
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool lin = t[r] > 28.853900817779268147f;
+    h[r] = lin ? z[r] : l[r];
+    if (WANT_D) d[r] = lin ? 1.0f : e[r] * __builtin_amdgcn_rcpf(ope[r]);
+  }
 }
 
 // sin for |x| up to a few 1e3: 3-term Cody-Waite reduction by pi/2 (fma) + cephes minimax kernels on
@@ -157,6 +162,36 @@ template <int D, int F>
 __host__ __device__ constexpr int nerf_enc_dim(int e) {
   return e < D ? e : ((e - D) % (D * F)) / F;
 }
+// Entry e = base + 4*q of enc_F(x) for THIS lane's q (0 outside [0, D(2F+1))): the four candidates are enumerated at
+// compile time, the sine argument is selected, and ONE sin is evaluated - 36 sines per point would otherwise be
+// computed three times per tile to use 28 of them.
+template <int D, int F>
+__device__ __forceinline__ float nerf_enc_entry_q(const float (&x)[D], int base, int q) {
+  constexpr int N = D * (2 * F + 1);
+  float arg = 0.0f, raw = 0.0f;
+  int kind = 0;  // 0 -> zero, 1 -> raw input, 2 -> sine
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int e = base + 4 * qq;
+    if (e < 0 || e >= N) continue;
+    const bool mine = (q == qq);
+    if (e < D) {
+      raw = mine ? x[e] : raw;
+      kind = mine ? 1 : kind;
+    } else {
+      int idx = e - D;
+      const float ph = (idx >= D * F) ? NRH_HALF_PI : 0.0f;
+      idx = idx % (D * F);
+      const int d = idx / F, k = idx % F;
+      const float cand = x[d] * (float)(1 << k) + ph;
+      arg = mine ? cand : arg;
+      kind = mine ? 2 : kind;
+    }
+  }
+  const float s = sin_cw(arg);
+  return (kind == 2) ? s : ((kind == 1) ? raw : 0.0f);
+}
+
 // select v[base + 4*q] for the lane's q = lane>>4 with compile-time candidates (entries >= N read as 0)
 template <int N>
 __device__ __forceinline__ float sel_q(const float (&v)[N], int base, int q) {

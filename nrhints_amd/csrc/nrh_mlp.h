@@ -23,7 +23,7 @@ constexpr int WBUF_BYTES = 32768;          // one LDS weight buffer (2 ob x 16 k
 constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
 // ---- tuning knobs (compile-time; profiles/README.md records what each was measured to do) ----
 #ifndef NRH_WG_WAVES
-#define NRH_WG_WAVES 4        // waves per workgroup = 16-point tiles sharing one weight stream
+#define NRH_WG_WAVES 8        // waves per workgroup = 16-point tiles sharing one weight stream (8: +6..24 % vs 4)
 #endif
 #ifndef NRH_KPREFETCH
 #define NRH_KPREFETCH 1       // K steps of A operands in flight ahead of the MFMAs (f16x3 path)
@@ -32,24 +32,15 @@ constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
 #define NRH_SCHED_BARRIER 1   // pin the ds_read / MFMA interleave with sched_barrier per K step
 #endif
 #ifndef NRH_NT_SCRATCH
-#define NRH_NT_SCRATCH 0      // non-temporal loads/stores for the stream-once sigma' scratch and feature tiles
+#define NRH_NT_SCRATCH 1      // non-temporal loads/stores for the stream-once sigma' scratch and feature tiles
 #endif
 #ifndef NRH_PKRTZ
-#define NRH_PKRTZ 0           // v_cvt_pkrtz_f16_f32 for the hi/lo split (round-toward-zero hi, still exact hi+lo)
-#endif
-#ifndef NRH_PIPE_EPI
-#define NRH_PIPE_EPI 0        // run the epilogue of chunk c after the MFMAs of chunk c+1 are issued (same wave overlap)
-#endif
-#ifndef NRH_SGB_VALU
-#define NRH_SGB_VALU 0        // >0: sched_group_barrier pattern "1 MFMA, N VALU" inside the f16x3 K loop
+#define NRH_PKRTZ 1           // v_cvt_pkrtz_f16_f32 for the hi/lo split (round-toward-zero hi, still exact hi+lo)
 #endif
 // ablation switches (WRONG RESULTS - timing experiments only, see profiles/README.md)
 #ifndef NRH_ABL
 #define NRH_ABL 0             // bit 0: no LDS-DMA, 1: no barrier, 2: no MFMA, 3: no ds_read of A (f16x3), 4: trivial epilogue
 #endif
-#ifndef NRH_STAGGER
-#define NRH_STAGGER 0         // 8-wave workgroups: waves 4..7 run one phase behind waves 0..3 (MFMA phase | epilogue
-#endif                        // phase, a barrier after each) so the two waves of every SIMD are always in opposite phases
 constexpr int WG_WAVES = NRH_WG_WAVES;
 constexpr int MLP_THREADS = 64 * WG_WAVES;  // one 16-point tile per wave
 constexpr int TILE_PTS = 16;
@@ -112,19 +103,6 @@ __device__ __forceinline__ V ld_stream(const V* p) {
 #endif
 }
 
-// Phase offset of the two halves of an 8-wave workgroup (NRH_STAGGER): call once at kernel entry / exit.
-__device__ __forceinline__ void stagger_enter(int wave) {
-#if NRH_STAGGER
-  static_assert(NRH_WG_WAVES == 8, "NRH_STAGGER needs 8-wave workgroups");
-  if (wave >= 4) __syncthreads();
-#endif
-}
-__device__ __forceinline__ void stagger_exit(int wave) {
-#if NRH_STAGGER
-  if (wave < 4) __syncthreads();
-#endif
-}
-
 // Activations of one layer for this wave's 16 points, in the form the MFMA B operand wants them.
 //   PREC 0: KB*4 floats in D-layout.   PREC 1: per 32-wide K step, 8 fp16 hi + 8 fp16 lo (4 + 4 packed VGPRs):
 //   elements 0..3 = features 16*(2s)+4q+0..3, elements 4..7 = features 16*(2s+1)+4q+0..3.
@@ -138,6 +116,10 @@ struct Act<0, KB> {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[ch * 8 + r] = o[r];
   }
+  __device__ __forceinline__ void set_chunk(int ch, const f32x4 o0, const f32x4 o1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[ch * 8 + r] = o0[r]; v[ch * 8 + 4 + r] = o1[r]; }
+  }
 };
 template <int KB>
 struct Act<1, KB> {
@@ -147,22 +129,30 @@ struct Act<1, KB> {
 #pragma unroll
     for (int r = 0; r < 4; ++r) split_pack2(o[2 * r], o[2 * r + 1], h[ch * 4 + r], l[ch * 4 + r]);
   }
+  __device__ __forceinline__ void set_chunk(int ch, const f32x4 o0, const f32x4 o1) {
+    split_pack2(o0[0], o0[1], h[ch * 4 + 0], l[ch * 4 + 0]);
+    split_pack2(o0[2], o0[3], h[ch * 4 + 1], l[ch * 4 + 1]);
+    split_pack2(o1[0], o1[1], h[ch * 4 + 2], l[ch * 4 + 2]);
+    split_pack2(o1[2], o1[3], h[ch * 4 + 3], l[ch * 4 + 3]);
+  }
 };
 
 // One GEMM stage: out[NCH*32 features] = A[NCH*32 x KB*16] * in[KB*16 features], all for this wave's 16 points.
 //   wsrc   packed weights of this stage: NCH chunks of 2*KB KiB, chunk ch resident in LDS buffer `par` on entry
 //   wnext  first chunk of whatever runs next (prefetched during the last chunk), next_pieces its size in KiB
 //   init   optional accumulator start values (D-layout, NCH*8 floats) - used to split one layer's K in two
-//   epi    epi(ch, acc0, acc1): consumes the two finished 16-feature blocks 2*ch and 2*ch+1
+//   pre    pre(ch) -> P: issues the epilogue's global loads (bias, sigma', head weights) BEFORE the K loop so that
+//          their L2 latency hides under the chunk's MFMAs (left inside the epilogue they cost ~700 exposed cycles
+//          per chunk: the K loop is fenced by sched_barrier, nothing can be hoisted across it)
+//   epi    epi(ch, acc0, acc1, P): consumes the two finished 16-feature blocks 2*ch and 2*ch+1
 // LDS image of a chunk (both precisions 2*KB KiB):
 //   PREC 0: [obi 2][kb KB][lane 64] float4           - A of 4 consecutive 16x16x4 MFMAs
 //   PREC 1: [obi 2][s KB/2][hi|lo][lane 64] 8 x fp16 - A of one 16x16x32 MFMA (hi) / its low part
-template <int PREC, int KB, int NCH, bool HAS_INIT, typename Epi>
+template <int PREC, int KB, int NCH, bool HAS_INIT, typename Pre, typename Epi>
 __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const float* __restrict__ wnext,
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
-                                          const float* init, Epi&& epi, int wave, int lane) {
+                                          const float* init, Pre&& pre, Epi&& epi, int wave, int lane) {
   constexpr int PIECES = 2 * KB;
-  f32x4 pend0 = {0.f, 0.f, 0.f, 0.f}, pend1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     char* nxt = smem + (par ^ 1) * WBUF_BYTES;
@@ -171,6 +161,7 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     } else if (wnext != nullptr) {
       dma_chunk(wnext, nxt, next_pieces, wave, lane);
     }
+    const auto pv = pre(ch);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (HAS_INIT) {
       acc0 = f32x4{init[ch * 8 + 0], init[ch * 8 + 1], init[ch * 8 + 2], init[ch * 8 + 3]};
@@ -241,38 +232,17 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
           c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c1, 0, 0, 0);
         }
-#if NRH_SGB_VALU > 0
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, NRH_SGB_VALU, 0);  // N VALU / TRANS
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                     // next K step's 4 ds_read_b128
-#elif NRH_SCHED_BARRIER
+#if NRH_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
 #endif
       }
       acc0 += c0 * LO_UNSCALE;
       acc1 += c1 * LO_UNSCALE;
     }
-#if NRH_PIPE_EPI
-    // the previous chunk's epilogue is independent of this chunk's MFMAs: placed here, the scheduler may slot its
-    // VALU work into the 16-cycle issue gaps of the matrix pipe
-    if (ch > 0) epi(ch - 1, pend0, pend1);
-    pend0 = acc0;
-    pend1 = acc1;
-#else
-#if NRH_STAGGER
-    __syncthreads();  // phase boundary: the other half of the workgroup swaps between its MFMA and epilogue phases
-#endif
-    epi(ch, acc0, acc1);
-#endif
+    epi(ch, acc0, acc1, pv);
     if (!(NRH_ABL & 2)) __syncthreads();  // waits this wave's LDS-DMA (vmcnt(0)) and orders the buffer swap
     par ^= 1;
   }
-#if NRH_PIPE_EPI
-  epi(NCH - 1, pend0, pend1);
-#endif
 }
 
 // ---------------- packed-buffer geometry of the SDF net (floats) ----------------

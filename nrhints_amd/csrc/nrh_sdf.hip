@@ -45,31 +45,40 @@ __device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
   return ua | (ub << 16);
 }
 
-// store / load the 8 sigma' values of chunk ch of layer l (l < 7)
+// the 8 sigma' values of chunk ch of layer l (l < 7): two float4 (PREC 0) or one uint4 of unorm16 pairs (PREC 1)
+struct PreV {
+  f32x4 a0, a1;  // forward: bias of blocks 2ch, 2ch+1;  reverse: sigma' (PREC 0) / a0 = packed unorm16 (PREC 1)
+  f32x4 b0, b1;  // layer 7 only: sdf-head weights of the two blocks
+};
+
 template <int PREC>
-__device__ __forceinline__ void dsig_store(float* scr, int l, int ch, int lane, const float (&d)[8]) {
+__device__ __forceinline__ void dsig_store(float* scr, int l, int ch, int lane, const f32x4 d0, const f32x4 d1) {
   if constexpr (PREC == 0) {
-    st_stream(reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4), f32x4{d[0], d[1], d[2], d[3]});
-    st_stream(reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4), f32x4{d[4], d[5], d[6], d[7]});
+    st_stream(reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4), d0);
+    st_stream(reinterpret_cast<f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4), d1);
   } else {
-    const u32x4 v = {unorm16x2(d[0], d[1]), unorm16x2(d[2], d[3]), unorm16x2(d[4], d[5]), unorm16x2(d[6], d[7])};
+    const u32x4 v = {unorm16x2(d0[0], d0[1]), unorm16x2(d0[2], d0[3]), unorm16x2(d1[0], d1[1]), unorm16x2(d1[2], d1[3])};
     st_stream(reinterpret_cast<u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4), v);
   }
 }
 template <int PREC>
-__device__ __forceinline__ void dsig_load(const float* scr, int l, int ch, int lane, float (&d)[8]) {
+__device__ __forceinline__ void dsig_issue(const float* scr, int l, int ch, int lane, PreV& p) {
   if constexpr (PREC == 0) {
-    const f32x4 a = ld_stream(reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4));
-    const f32x4 b = ld_stream(reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { d[r] = a[r]; d[4 + r] = b[r]; }
+    p.a0 = ld_stream(reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch) * 64 + lane) * 4));
+    p.a1 = ld_stream(reinterpret_cast<const f32x4*>(scr + ((l * 16 + 2 * ch + 1) * 64 + lane) * 4));
   } else {
-    const u32x4 v = ld_stream(reinterpret_cast<const u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      d[2 * r] = (float)(v[r] & 0xffffu) * (1.0f / 65535.0f);
-      d[2 * r + 1] = (float)(v[r] >> 16) * (1.0f / 65535.0f);
-    }
+    p.a0 = __builtin_bit_cast(f32x4, ld_stream(reinterpret_cast<const u32x4*>(scr + l * 2048 + (ch * 64 + lane) * 4)));
+  }
+}
+template <int PREC>
+__device__ __forceinline__ void dsig_decode(const PreV& p, f32x4& d0, f32x4& d1) {
+  if constexpr (PREC == 0) {
+    d0 = p.a0;
+    d1 = p.a1;
+  } else {
+    const u32x4 v = __builtin_bit_cast(u32x4, p.a0);
+    d0 = f32x4{(float)(v[0] & 0xffffu), (float)(v[0] >> 16), (float)(v[1] & 0xffffu), (float)(v[1] >> 16)} * (1.0f / 65535.0f);
+    d1 = f32x4{(float)(v[2] & 0xffffu), (float)(v[2] >> 16), (float)(v[3] & 0xffffu), (float)(v[3] >> 16)} * (1.0f / 65535.0f);
   }
 }
 // t_7 = sigma'_7 * w_s / 3 is not confined to [0,1]: always fp32
@@ -86,10 +95,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   const int j = lane & 15, q = lane >> 4;
   int par = 0;
   float* const scr = (MODE >= 1) ? a.scratch + (size_t)(blockIdx.x * WG_WAVES + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
+  constexpr bool WANT_D = MODE >= 1;
 
   dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
   __syncthreads();
-  stagger_enter(wave);
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -103,35 +112,35 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt) * 3.0f;  // inputs * scale
 
-    // ---- L0: embedding -> 256 ----
+    // ---- L0: embedding (entry 16b + 4q + r in register b*4 + r; blocks 0..2 hold the 39 entries) -> 256 ----
     Act<PREC, 4> emb;
-    {
-      float all[39];
-      nerf_enc_all<3, 6>(x3, all);
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
-        float o[8];
+    for (int c2 = 0; c2 < 2; ++c2) {
+      float o[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = sel_q<39>(all, (2 * c2 + (r >> 2)) * 16 + (r & 3), q);  // entry 16b + 4q + r
-        emb.set_chunk(c2, o);
+      for (int r = 0; r < 8; ++r) {
+        const int b = 2 * c2 + (r >> 2);
+        o[r] = (b < 3) ? nerf_enc_entry_q<3, 6>(x3, b * 16 + (r & 3), q) : 0.0f;
       }
+      emb.set_chunk(c2, o);
     }
 
     Act<PREC, 16> h;
     {
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch) * 16 + 4 * q);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch + 1) * 16 + 4 * q);
-        float o[8], d[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          softplus100(acc0[r] + b0[r], o[r], d[r]);
-          softplus100(acc1[r] + b1[r], o[4 + r], d[4 + r]);
-        }
-        h.set_chunk(ch, o);
-        if (MODE >= 1) dsig_store<PREC>(scr, 0, ch, lane, d);
+      auto pre = [&](int ch) {
+        PreV p;
+        p.a0 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch) * 16 + 4 * q);
+        p.a1 = *reinterpret_cast<const f32x4*>(a.b + (2 * ch + 1) * 16 + 4 * q);
+        return p;
       };
-      run_stage<PREC, 4, 8, false>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, epi, wave, lane);
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const PreV& p) {
+        f32x4 h0, h1, d0, d1;
+        softplus100_4<WANT_D>(acc0 + p.a0, h0, d0);
+        softplus100_4<WANT_D>(acc1 + p.a1, h1, d1);
+        h.set_chunk(ch, h0, h1);
+        if (MODE >= 1) dsig_store<PREC>(scr, 0, ch, lane, d0, d1);
+      };
+      run_stage<PREC, 4, 8, false>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, pre, epi, wave, lane);
     }
 
     // ---- steps 1..15: L1..L7, FEAT, R7..R1 share one 256x256 body ----
@@ -164,70 +173,65 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         for (int ch = 0; ch < 8; ++ch) {
           const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)));
           const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)));
-          const float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          h.set_chunk(ch, o);
+          h.set_chunk(ch, v0, v1);
         }
       }
 
       Act<PREC, 16> ho;
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
-        if (s <= 7) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch) * 16 + 4 * q);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch + 1) * 16 + 4 * q);
-          float o[8], d[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (NRH_ABL & 16) {
-              o[r] = acc0[r]; o[4 + r] = acc1[r]; d[r] = b0[r]; d[4 + r] = b1[r];
-            } else {
-              softplus100(acc0[r] + b0[r], o[r], d[r]);
-              softplus100(acc1[r] + b1[r], o[4 + r], d[4 + r]);
-            }
+      auto pre = [&](int ch) {
+        PreV p;
+        if (s <= 8) {
+          p.a0 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch) * 16 + 4 * q);
+          p.a1 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch + 1) * 16 + 4 * q);
+          if (s == 7) {
+            p.b0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
+            p.b1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
           }
+        } else if (MODE >= 1) {
+          dsig_issue<PREC>(scr, 16 - s - 1, ch, lane, p);  // sigma' of the layer this stage's output feeds
+        }
+        return p;
+      };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const PreV& p) {
+        if (s <= 7) {
+          f32x4 h0, h1, d0, d1;
+          softplus100_4<WANT_D>(acc0 + p.a0, h0, d0);
+          softplus100_4<WANT_D>(acc1 + p.a1, h1, d1);
           if (ch >= 6 && s == 3) {
             // skip connection: features 217..255 of L4's input are the embedding (fields/sdf_field.py:113-114)
-            float all[39];
-            nerf_enc_all<3, 6>(x3, all);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int e1 = (2 * ch + 1) * 16 + 4 * q + r - 217;
               if (ch == 7) {  // block 14: always >= 217
-                o[r] = sel_q<39>(all, (2 * ch) * 16 + r - 217, q);
-                d[r] = 0.0f;
+                h0[r] = nerf_enc_entry_q<3, 6>(x3, (2 * ch) * 16 + r - 217, q);
+                d0[r] = 0.0f;
               }
-              if (e1 >= 0) {  // block 13 (partly) or 15
-                o[4 + r] = sel_q<39>(all, (2 * ch + 1) * 16 + r - 217, q);
-                d[4 + r] = 0.0f;
+              if ((2 * ch + 1) * 16 + 4 * q + r - 217 >= 0) {  // block 13 (partly) or 15
+                h1[r] = nerf_enc_entry_q<3, 6>(x3, (2 * ch + 1) * 16 + r - 217, q);
+                d1[r] = 0.0f;
               }
             }
           }
           if (s == 7) {
             // sdf head folded into L7's epilogue: partial w_s . h8, and t_7 = sigma'_7 * w_s / 3 for the reverse chain
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              head_part += w0[r] * o[r];
-              head_part += w1[r] * o[4 + r];
-              d[r] = d[r] * (w0[r] / 3.0f);
-              d[4 + r] = d[4 + r] * (w1[r] / 3.0f);
+              head_part += p.b0[r] * h0[r];
+              head_part += p.b1[r] * h1[r];
             }
             if (MODE >= 1) {
-              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)), f32x4{d[0], d[1], d[2], d[3]});
-              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)), f32x4{d[4], d[5], d[6], d[7]});
+              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)), d0 * (p.b0 / 3.0f));
+              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)), d1 * (p.b1 / 3.0f));
             }
           } else if (MODE >= 1) {
-            dsig_store<PREC>(scr, s, ch, lane, d);
+            dsig_store<PREC>(scr, s, ch, lane, d0, d1);
           }
-          ho.set_chunk(ch, o);
+          ho.set_chunk(ch, h0, h1);
         } else if (s == 8) {
           if (MODE == 2) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b + 8 * 256 + (2 * ch) * 16 + 4 * q);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.b + 8 * 256 + (2 * ch + 1) * 16 + 4 * q);
             if (tile * TILE_PTS < a.npts) {
               float* ft = a.feat + (size_t)tile * (16 * 256);
-              st_stream(reinterpret_cast<f32x4*>(ft + ((2 * ch) * 64 + lane) * 4), acc0 + b0);
-              st_stream(reinterpret_cast<f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4), acc1 + b1);
+              st_stream(reinterpret_cast<f32x4*>(ft + ((2 * ch) * 64 + lane) * 4), acc0 + p.a0);
+              st_stream(reinterpret_cast<f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4), acc1 + p.a1);
             }
           }
         } else {
@@ -241,18 +245,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
                 skip[(2 * ch + 1 - 13) * 4 + r] = acc1[r];
               }
             }
-            float d[8], o[8];
-            dsig_load<PREC>(scr, l - 1, ch, lane, d);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              o[r] = acc0[r] * d[r];
-              o[4 + r] = acc1[r] * d[4 + r];
-            }
-            ho.set_chunk(ch, o);
+            f32x4 d0, d1;
+            dsig_decode<PREC>(p, d0, d1);
+            ho.set_chunk(ch, acc0 * d0, acc1 * d1);
           }
         }
       };
-      run_stage<PREC, 16, 8, false>(wcur, wnxt, npc, smem, par, h, nullptr, epi, wave, lane);
+      run_stage<PREC, 16, 8, false>(wcur, wnxt, npc, smem, par, h, nullptr, pre, epi, wave, lane);
 
       if (s == 7) {
         // sdf head: (w_s . h8 + b_s) / scale   (fields/sdf_field.py:121)
@@ -267,11 +266,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     if (MODE >= 1) {
       // ---- R0: gradient w.r.t. the 39 embedding entries, then chain through the encoding ----
       float ge[16];
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1) {
+      auto pre = [&](int) { return 0; };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ge[ch * 8 + r] = acc0[r]; ge[ch * 8 + 4 + r] = acc1[r]; }
       };
-      run_stage<PREC, 16, 2, false>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 8, smem, par, h, nullptr, epi, wave, lane);
+      run_stage<PREC, 16, 2, false>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 8, smem, par, h, nullptr, pre, epi, wave, lane);
 
       float dx[3] = {0.f, 0.f, 0.f};
       {
@@ -302,7 +302,6 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
       }
     }
   }
-  stagger_exit(wave);
 }
 
 }  // namespace nrh

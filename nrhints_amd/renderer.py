@@ -103,7 +103,7 @@ class NeuSHintRenderer(nn.Module):
     max_chunk_rays = 32768
     #: matrix arithmetic of the MLP kernels: "f32" (v_mfma_f32_16x16x4_f32, exact fp32) or "f16x3" (three
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
-    precision = "f32"
+    precision = "f16x3"
 
     def __init__(self, config: NeuSModelConfig = None, precision: Optional[str] = None):
         super().__init__()

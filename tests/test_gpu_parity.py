@@ -168,11 +168,13 @@ def _check_against(out, g, sfx=""):
     assert np.mean(out.inside_sphere.cpu().numpy() != g["inside_sphere" + sfx]) < 2e-3
     for k, mean_tol, max_tol in FIELDS_PER_SAMPLE:
         diff = np.abs(getattr(out, k).cpu().numpy() - g[k + sfx])
-        # against the fp64 run the yardstick is the reference's own fp32-vs-fp64 distance on this fixture (scene b:
-        # normals differ by 1e-3 on average and 1.1 at isolated samples, because the sample positions move)
-        noise = np.abs(g[k].astype(np.float64) - g[k + "_f64"]) if sfx else np.zeros(1)
+        # the yardstick for per-sample fields is the reference's own fp32-vs-fp64 distance on this fixture (scene b:
+        # normals differ by 1e-3 on average and 1.1 at isolated samples, because individual sample positions move)
+        noise = np.abs(g[k].astype(np.float64) - g[k + "_f64"])
         assert diff.mean() < max(mean_tol, 2.0 * noise.mean()), (k, diff.mean(), noise.mean())
         assert diff.max() < max(max_tol, 1.5 * noise.max()), (k, diff.max(), noise.max())
+        # isolated samples only: no more outliers than a small multiple of what the reference shows against itself
+        assert (diff > max_tol).mean() < max(1e-3, 3.0 * (noise > max_tol).mean()), (k, (diff > max_tol).sum())
 
 
 def test_render_eval_vs_golden(scene):
