@@ -56,6 +56,26 @@ def build_scene(precision):
     return model, state_b
 
 
+def pmc_traffic(precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/pmc_run.sh): FETCH_SIZE [KiB] x 2 (gfx950 counts wide coalesced reads at half their size) + WRITE_SIZE
+    [KiB].  None if no counter summary for this precision is committed."""
+    import glob
+    import re
+    tag = {"f16x3": "1", "f32": "0"}[precision]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{precision}_v*", "summary.txt")))
+    if not files:
+        return None, None
+    txt = open(files[-1]).read()
+    m = re.search(r"sdf_kernel<2, %s>\n((?:   .*\n)+)" % tag, txt)
+    if not m:
+        return None, None
+    vals = dict(re.findall(r"(\w+)\s+n=\s*\d+ mean=([0-9.e+]+)", m.group(1)))
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, None
+    return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(state, rays_np, n_sample, gpu_rgb):
     """Time the oracle ("as written": 13 SDF forwards + autograd gradient per render, 512-ray chunks) on the host.
 
@@ -156,6 +176,7 @@ def main():
         pts_per_launch = nrays * 128 * args.steps / launches
         avg_ms = k_ms.value / launches
         achieved = FLOP_PER_POINT_CORE * pts_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(args.precision)
         line = {
             "metric": "rendered rays/sec (128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,7 +191,8 @@ def main():
                        "whole_path_frac_of_mfma_peak": round(value * FLOP_PER_RAY / 1e12 / world / peak, 4)},
             "roofline": {"bound": "mfma", "kernel": "sdf_kernel<2> (sdf + feature + d sdf/dx, 128 pts/ray)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(pts_per_launch * 1044),
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
                          "algorithmic_flop_per_point": FLOP_PER_POINT_CORE},
         }

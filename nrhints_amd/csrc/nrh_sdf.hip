@@ -41,8 +41,10 @@ struct SdfArgs {
 };
 
 __device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
-  const uint32_t ua = (uint32_t)(a * 65535.0f + 0.5f), ub = (uint32_t)(b * 65535.0f + 0.5f);
-  return ua | (ub << 16);
+  // v_cvt_pknorm_u16_f32: both values clamped to [0,1], scaled by 65535, rounded to nearest, packed - one VALU op
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 p = __builtin_amdgcn_cvt_pknorm_u16(a, b);
+  return __builtin_bit_cast(uint32_t, p);
 }
 
 // the 8 sigma' values of chunk ch of layer l (l < 7): two float4 (PREC 0) or one uint4 of unorm16 pairs (PREC 1)
