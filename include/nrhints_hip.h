@@ -95,7 +95,9 @@ int nrh_color_eval(int precision, const float* col_w, const float* col_b, const 
  * Inputs  (RayBundle fields, camera/ray_utils.py:214-235): origins, directions, pl_positions [n,3]; nears, fars [n].
  * Outputs (RenderOutput fields, models/neus_hint_model.py:216-233), any of the optional ones may be null:
  *   rgb [n,3], depth [n], weights [n,128], inside_sphere [n,128], analytic_normals [n,128,3],
- *   normalized_normals [n,128,3], visibilities [n], specular_cue [n,128,4].
+ *   normalized_normals [n,128,3], visibilities [n], specular_cue [n,128,4]; and, for callers that continue the
+ *   computation themselves (the autograd training path), the section mid-points mid_z [n,128] and lengths dists [n,128]
+ *   (models/neus_hint_model.py:491-493).
  * Scalars: inv_s = clip(exp(10 * variance), 1e-6, 1e6) (:110, :337); cos_anneal (:669-671).
  * background (device, [3]) may be null.  t_rand_primary [n] / t_rand_shadow [n,64]: training jitter (:682, :394),
  * null at evaluation.  lin64 / lin16: torch.linspace(0,1,64|16) as float32.  zero_hints: geometry warm-up (:577, :617).
@@ -117,8 +119,8 @@ int nrh_render_forward(const NrhNet* net /* host */, const float* origins, const
                        const float* background, float cos_anneal, const float* t_rand_primary,
                        const float* t_rand_shadow, int zero_hints, const float* lin64, const float* lin16,
                        float* rgb, float* depth, float* weights, float* inside_sphere, float* analytic_normals,
-                       float* normalized_normals, float* visibilities, float* specular_cue, float* workspace,
-                       long long workspace_floats, void* stream);
+                       float* normalized_normals, float* visibilities, float* specular_cue, float* mid_z, float* dists,
+                       float* workspace, long long workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,7 +60,7 @@ def load():
     lib.nrh_render_workspace_floats.argtypes = [c_longlong]
     lib.nrh_render_workspace_floats.restype = c_longlong
     lib.nrh_render_forward.argtypes = [POINTER(NrhNet), P, P, P, P, P, c_longlong, P, c_float, P, P, c_int, P, P,
-                                       P, P, P, P, P, P, P, P, P, c_longlong, P]
+                                       P, P, P, P, P, P, P, P, P, P, P, c_longlong, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]
     lib.nrh_kernel_timing_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_longlong)]
     for name in EXPORTED:

@@ -189,7 +189,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 101; }
+int nrh_version(void) { return 102; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -288,7 +288,8 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
                        float cos_anneal, const float* t_rand_primary, const float* t_rand_shadow, int zero_hints,
                        const float* lin64, const float* lin16, float* rgb, float* depth, float* weights,
                        float* inside_sphere, float* analytic_normals, float* normalized_normals, float* visibilities,
-                       float* specular_cue, float* workspace, long long workspace_floats, void* stream) {
+                       float* specular_cue, float* mid_z, float* dists, float* workspace, long long workspace_floats,
+                       void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !net->col_w || !net->col_b)
     return fail(NRH_E_INVALID, "nrh_render_forward: null network pointer%s", "");
@@ -315,6 +316,8 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
   float* o_depth = depth ? depth : ws_depth;
   float* o_vis = visibilities ? visibilities : ws_vis;
   float* o_cue_b = specular_cue;  // optional broadcast copy
+  float* o_tmid = mid_z ? mid_z : ws_tmid;
+  float* o_dists = dists ? dists : ws_dists;
 
   // ---- primary rays: coarse z, hierarchical sampling ----
   {
@@ -326,16 +329,16 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     if (rc) return rc;
   }
   int rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f,
-                       ws_tmid, ws_dists, n, st);
+                       o_tmid, o_dists, n, st);
   if (rc) return rc;
   // ---- render_core: sdf + feature + gradient at the 128 section mid-points ----
-  rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, ws_tmid, 128, 128, n, ws_sdf_c, 128,
+  rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n, ws_sdf_c, 128,
                      o_grad, ws_feat, scratch, st);
   if (rc) return rc;
   {
     nrh::CoreArgs c;
-    c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = ws_sdf_c; c.grad = o_grad; c.dists = ws_dists;
-    c.tmid = ws_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
+    c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = ws_sdf_c; c.grad = o_grad; c.dists = o_dists;
+    c.tmid = o_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
     c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
     c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal; c.shadow_offset = 1e-2f;
     const double rough[4] = {0.02, 0.05, 0.13, 0.34};  // models/neus_hint_model.py:161
@@ -368,7 +371,7 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     if (rc) return rc;
   }
   // ---- reflectance + composite ----
-  rc = color_eval_impl(net->precision, net->col_w, net->col_b, ws_feat, origins, directions, ws_tmid, o_nhat, ws_raymisc, n, ws_color, st);
+  rc = color_eval_impl(net->precision, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid, o_nhat, ws_raymisc, n, ws_color, st);
   if (rc) return rc;
   {
     nrh::CompositeArgs c;

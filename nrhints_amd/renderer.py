@@ -19,7 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib, packing
+from . import _lib, autograd_core, packing
 from .config import NeuSModelConfig, unsupported_reason
 from .containers import RayBundle, RenderOutput
 
@@ -182,13 +182,11 @@ class NeuSHintRenderer(nn.Module):
         if not o.is_cuda:
             raise RuntimeError("NeuSHintRenderer (MI355X) runs on the GPU only: move the RayBundle to cuda "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
+        # A graph is needed exactly when the reference would build one: grad mode on and something upstream of the
+        # output requires grad (parameters in training / checkpoint fine-tuning, ray tensors in register_view).
         needs_grad = torch.is_grad_enabled() and (
-            any(t.requires_grad for t in (o, d, pl, near, far)) or
-            (is_training and any(p.requires_grad for p in self.parameters())))
-        if needs_grad:
-            raise NotImplementedError(
-                "the backward kernels of the hot path are not built yet: call forward under torch.no_grad() "
-                "(DESIGN.md 'what comes next'); values for is_training=True are available without a graph")
+            any(t.requires_grad for t in (o, d, pl)) or any(p.requires_grad for p in self.parameters()))
+        o_g, d_g, pl_g = o, d, pl
         device = o.device
         f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
         o, d, pl = f32(o), f32(d), f32(pl)
@@ -219,6 +217,8 @@ class NeuSHintRenderer(nn.Module):
         rgb, depth, vis = new(n, 3), new(n, 1), new(n, 1)
         weights, inside = new(n, T), new(n, T)
         normals, nhat, cue = new(n, T, 3), new(n, T, 3), new(n, T, 4)
+        mid_z = new(n, T) if needs_grad else None
+        dists = new(n, T) if needs_grad else None
         chunk = max(1, min(self.max_chunk_rays, n))
         ws = self._workspace(device, chunk)
         stream = _lib.stream_handle()
@@ -231,8 +231,21 @@ class NeuSHintRenderer(nn.Module):
                 P(t_rand_p[sl]) if t_rand_p is not None else None,
                 P(t_rand_s[sl]) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16),
                 P(rgb[sl]), P(depth[sl]), P(weights[sl]), P(inside[sl]), P(normals[sl]), P(nhat[sl]), P(vis[sl]),
-                P(cue[sl]), P(ws), ws.numel(), stream)
+                P(cue[sl]), P(mid_z[sl]) if needs_grad else None, P(dists[sl]) if needs_grad else None,
+                P(ws), ws.numel(), stream)
             _lib.check(rc, "nrh_render_forward")
+        if needs_grad:
+            # differentiable part (render_core) over the HIP results; see autograd_core.py
+            dense = packing.dense_params(dict(self.named_parameters()))
+            core = autograd_core.render_core(
+                dense, self.deviation_network.variance, o_g.to(torch.float32), d_g.to(torch.float32),
+                pl_g.to(torch.float32), mid_z, dists, vis, cue[:, 0, :].contiguous(), cos_anneal,
+                background_rgb.to(device) if background_rgb is not None else None)
+            return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
+                                inside_sphere=inside, relax_inside_sphere=inside,
+                                analytic_normals=core["analytic_normals"],
+                                normalized_analytic_normals=core["normalized_analytic_normals"], visibilities=vis,
+                                specular_cue=cue)
         s_val = torch.full((1, 1), 1.0 / pk["inv_s"], dtype=torch.float32, device=device).expand(n, T)
         return RenderOutput(rgb=rgb, depth=depth, weights=weights, s_val=s_val, inside_sphere=inside,
                             relax_inside_sphere=inside, analytic_normals=normals,

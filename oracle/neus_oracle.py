@@ -56,9 +56,12 @@ class OracleParams:
     variance: torch.Tensor         # scalar
 
 
-def params_from_state(state: Dict[str, np.ndarray], dtype=torch.float32) -> OracleParams:
-    """Dense (weight-norm folded) parameters from a reference-layout state dict (SURVEY.md §5 key contract)."""
-    t = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in state.items()}
+def params_from_state(state, dtype=torch.float32) -> OracleParams:
+    """Dense (weight-norm folded) parameters from a reference-layout state dict (SURVEY.md §5 key contract).
+    Values may be numpy arrays or torch tensors; tensors that require grad keep their autograd history, so
+    gradients w.r.t. the raw weight_g / weight_v / bias / variance parameters can be taken through the fold."""
+    t = {k: (v.to(dtype) if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v)).to(dtype))
+         for k, v in state.items()}
 
     def lin(prefix):
         return fold_weight_norm(t[prefix + ".weight_g"], t[prefix + ".weight_v"]), t[prefix + ".bias"]
@@ -98,14 +101,18 @@ def sdf_forward(p: OracleParams, pts: torch.Tensor, want_feat: bool = True):
     return sdf, feat
 
 
-def sdf_gradient_autograd(p: OracleParams, pts: torch.Tensor) -> torch.Tensor:
+def sdf_gradient_autograd(p: OracleParams, pts: torch.Tensor, create_graph: bool = False) -> torch.Tensor:
     """d(sdf)/d(pts) the way the reference gets it: a full forward under enable_grad and one
-    reverse sweep (fields/sdf_field.py:136-148)."""
-    x = pts.detach().clone().requires_grad_(True)
+    reverse sweep (fields/sdf_field.py:136-148).  ``create_graph`` keeps the result differentiable, as the
+    reference's training step needs for the eikonal term and the normal-dependent colour (create_graph=True, :145)."""
+    if create_graph:
+        x = pts if pts.requires_grad else pts.requires_grad_(True)
+    else:
+        x = pts.detach().clone().requires_grad_(True)
     with torch.enable_grad():
         y, _ = sdf_forward(p, x, want_feat=True)  # .sdf() runs the whole forward incl. out_feat (:125-126)
-        (g,) = torch.autograd.grad(y, x, torch.ones_like(y))
-    return g.detach()
+        (g,) = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=create_graph, retain_graph=create_graph)
+    return g if create_graph else g.detach()
 
 
 def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: bool = True):
@@ -242,11 +249,11 @@ def alpha_from(sdf, grad, dirs, dists, inv_s, cos_anneal: float):
     return ((c_prev - c_next + 1e-5) / (c_prev + 1e-5)).clip(0.0, 1.0)
 
 
-def _sdf_and_grad(p, pts, mode, want_feat):
+def _sdf_and_grad(p, pts, mode, want_feat, differentiable=False):
     if mode == "as_written":
         sdf, feat = sdf_forward(p, pts, True)               # render_core :504 / get_alpha :335
         sdf2, _ = sdf_forward(p, pts, True)                 # get_alpha's own forward (:335)
-        grad = sdf_gradient_autograd(p, pts)                # :336 -> third forward + reverse
+        grad = sdf_gradient_autograd(p, pts, create_graph=differentiable)  # :336 -> third forward + reverse
         return sdf2, feat, grad
     sdf, feat, grad = sdf_forward_grad_analytic(p, pts, want_feat)
     return sdf, feat, grad
@@ -305,7 +312,7 @@ def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is_training=False,
                    global_step=0, anneal_end=50_000, t_rand_primary=None, t_rand_shadow=None,
-                   mode="minimal", keep_intermediates=False) -> Dict[str, torch.Tensor]:
+                   mode="minimal", keep_intermediates=False, differentiable=False) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651)."""
     n = o.shape[0]
@@ -325,19 +332,24 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     pts = (o[:, None, :] + d[:, None, :] * mid[..., None]).reshape(-1, 3)
     dirs = d[:, None, :].expand(n, 128, 3).reshape(-1, 3)
     pls = pl[:, None, :].expand(n, 128, 3).reshape(-1, 3)
-    sdf, feat, grad = _sdf_and_grad(p, pts, mode, True)
+    # ``differentiable`` (training): the render_core graph is kept, incl. the double-backward path through d sdf/dx
+    # (mode "as_written" only); sampling, depth / hit point, shadow hint and specular cue stay outside the graph as
+    # in the reference (:697, :531, :379, :589).
+    sdf, feat, grad = _sdf_and_grad(p, pts, mode, True, differentiable)
     inv_s = inv_s_of(p)
     alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, 128)
     radius = torch.linalg.norm(pts, dim=-1).reshape(n, 128)
     inside = (radius < 1.0).to(dt)
     weights = alpha * excl_cumprod_one_minus(alpha)            # :521-523
     wsum = weights.sum(-1, keepdim=True)
-    depth = (mid * weights).sum(-1, keepdim=True)              # :532
-    hit = o + d * depth                                        # :533
-    vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode)  # :546-551
+    with torch.no_grad():
+        depth = (mid * weights).sum(-1, keepdim=True)          # :531-533 (no_grad)
+        hit = o + d * depth
+        vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode)  # :546-551, :379
     n_hat = F.normalize(grad, dim=-1)                          # :584
     hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
-    cue = specular_cue(hit_n, pl, hit, d)                      # :590-615
+    with torch.no_grad():
+        cue = specular_cue(hit_n, pl, hit, d)                  # :589-615 (no_grad)
     vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
     cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
     col = color_forward(p, pts, n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :626

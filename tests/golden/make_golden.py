@@ -177,9 +177,9 @@ def main():
         torch.manual_seed(5)
         torch.rand = rec_rand
         try:
-            rb = RayBundle(origins=torch.from_numpy(o), directions=torch.from_numpy(d),
-                           pl_positions=torch.from_numpy(pl), nears=torch.from_numpy(near),
-                           fars=torch.from_numpy(far))
+            rays_t = [torch.from_numpy(a).clone().requires_grad_(i < 3) for i, a in enumerate((o, d, pl, near, far))]
+            rb = RayBundle(origins=rays_t[0], directions=rays_t[1], pl_positions=rays_t[2], nears=rays_t[3],
+                           fars=rays_t[4])
             r = m32(rb, is_training=True, background_rgb=torch.ones(1, 3), global_step=20000)
         finally:
             torch.rand = real_rand
@@ -196,6 +196,13 @@ def main():
         loss = rgb_loss + 0.1 * eik
         trec["rgb_gt"] = gt.numpy()
         trec["loss"], trec["rgb_loss"], trec["eikonal_loss"] = (x.detach().numpy() for x in (loss, rgb_loss, eik))
+        # parameter / ray gradients of that loss (trainer/trainer.py:278-279), for the backward parity tests
+        m32.zero_grad()
+        loss.backward()
+        for name, prm in m32.named_parameters():
+            trec["grad." + name] = prm.grad.detach().numpy().copy() if prm.grad is not None else np.zeros(0, np.float32)
+        for nm, t in zip(("origins", "directions", "pl_positions"), rays_t):
+            trec["grad.rays." + nm] = t.grad.detach().numpy().copy()
         np.savez_compressed(os.path.join(HERE, f"train_{tag}.npz"), **trec)
         print("scene", tag, "done; rgb mean", float(rec["rgb"].mean()), "vis mean", float(rec["visibilities"].mean()))
 

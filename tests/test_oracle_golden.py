@@ -131,3 +131,30 @@ def test_render_training_forward_and_loss(scene):
     loss, rgb_loss, eik = orc.train_loss(out, T(g["rgb_gt"]))
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
     np.testing.assert_allclose(eik.item(), g["eikonal_loss"], rtol=2e-3)
+
+
+def test_training_gradients(scene_states):
+    """Loss gradients w.r.t. every raw parameter and the rays, against what the reference's backward produced."""
+    for tag in ("a", "b"):
+        g = load_npz(f"train_{tag}.npz")
+        st = {k: T(np.asarray(v)).clone().requires_grad_(True) for k, v in scene_states[tag].items()}
+        p = orc.params_from_state(st)
+        rays = [T(g[k]).clone() for k in ("o", "d", "pl", "near", "far")]
+        for r in rays[:3]:
+            r.requires_grad_(True)
+        out = orc.render_forward(p, *rays, background_rgb=torch.ones(1, 3), is_training=True,
+                                 global_step=int(g["global_step"]), t_rand_primary=T(g["t_rand_primary"]),
+                                 t_rand_shadow=T(g["t_rand_shadow"]), mode="as_written", differentiable=True)
+        loss, _, _ = orc.train_loss(out, T(g["rgb_gt"]))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+        for k, v in st.items():
+            want = g["grad." + k]
+            got = v.grad.numpy()
+            scale = max(np.abs(want).max(), 1e-8)
+            # fp32 sums with cancellation (e.g. the scalar d loss / d variance): 1 % of the largest entry
+            assert np.abs(got - want).max() / scale < 1e-2, (tag, k, np.abs(got - want).max(), scale)
+        for nm, r in zip(("origins", "directions", "pl_positions"), rays[:3]):
+            want = g["grad.rays." + nm]
+            scale = max(np.abs(want).max(), 1e-8)
+            assert np.abs(r.grad.numpy() - want).max() / scale < 2e-3, (tag, nm)
