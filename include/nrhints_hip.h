@@ -97,7 +97,9 @@ int nrh_color_eval(int precision, const float* col_w, const float* col_b, const 
  *   rgb [n,3], depth [n], weights [n,128], inside_sphere [n,128], analytic_normals [n,128,3],
  *   normalized_normals [n,128,3], visibilities [n], specular_cue [n,128,4]; and, for callers that continue the
  *   computation themselves (the autograd training path), the section mid-points mid_z [n,128] and lengths dists [n,128]
- *   (models/neus_hint_model.py:491-493).
+ *   (models/neus_hint_model.py:491-493); and the per-pixel normal maps of the evaluation loop,
+ *   normal_map / normalized_normal_map [n,3] = sum_j normal_j * weight_j * inside_j in world space
+ *   (pipelines/base_pipeline.py:125-131 computes them on the CPU from the per-sample arrays).
  * Scalars: inv_s = clip(exp(10 * variance), 1e-6, 1e6) (:110, :337); cos_anneal (:669-671).
  * background (device, [3]) may be null.  t_rand_primary [n] / t_rand_shadow [n,64]: training jitter (:682, :394),
  * null at evaluation.  lin64 / lin16: torch.linspace(0,1,64|16) as float32.  zero_hints: geometry warm-up (:577, :617).
@@ -120,7 +122,16 @@ int nrh_render_forward(const NrhNet* net /* host */, const float* origins, const
                        const float* t_rand_shadow, int zero_hints, const float* lin64, const float* lin16,
                        float* rgb, float* depth, float* weights, float* inside_sphere, float* analytic_normals,
                        float* normalized_normals, float* visibilities, float* specular_cue, float* mid_z, float* dists,
-                       float* workspace, long long workspace_floats, void* stream);
+                       float* normal_map, float* normalized_normal_map, float* workspace, long long workspace_floats,
+                       void* stream);
+
+/* ---- pixel -> ray for one pinhole view ------------------------------------------------------------------------
+ * RayGenerator.forward without pose / light deltas (camera/ray_generator.py:79-139): rows [row0, row0+nrows) of a
+ * `width`-wide image, pose = row-major [3,4] camera-to-world (HOST pointer, 12 floats), pl = light position (HOST, 3).
+ * Writes origins/directions/pl_positions [nrows*width,3] and nears/fars [nrows*width] (unit-sphere near/far, :135-139). */
+int nrh_generate_rays(const float* pose, const float* pl, float cx, float cy, float fx, float fy, int width, int row0,
+                      int nrows, float* origins, float* directions, float* pl_positions, float* nears, float* fars,
+                      void* stream);
 
 #ifdef __cplusplus
 }

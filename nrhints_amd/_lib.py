@@ -18,7 +18,7 @@ _ERRNAMES = {-1: "NRH_E_INVALID", -2: "NRH_E_LAUNCH", -3: "NRH_E_WORKSPACE", -4:
 # every symbol include/nrhints_hip.h declares (tests check the .so exports exactly these)
 EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param_sizes", "nrh_mlp_grid",
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
-            "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read")
+            "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays")
 
 
 class NrhNet(Structure):
@@ -60,7 +60,9 @@ def load():
     lib.nrh_render_workspace_floats.argtypes = [c_longlong]
     lib.nrh_render_workspace_floats.restype = c_longlong
     lib.nrh_render_forward.argtypes = [POINTER(NrhNet), P, P, P, P, P, c_longlong, P, c_float, P, P, c_int, P, P,
-                                       P, P, P, P, P, P, P, P, P, P, P, c_longlong, P]
+                                       P, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, P]
+    lib.nrh_generate_rays.argtypes = [POINTER(c_float), POINTER(c_float), c_float, c_float, c_float, c_float, c_int,
+                                      c_int, c_int, P, P, P, P, P, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]
     lib.nrh_kernel_timing_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_longlong)]
     for name in EXPORTED:

@@ -189,7 +189,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 102; }
+int nrh_version(void) { return 103; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -273,6 +273,23 @@ int nrh_color_eval(int precision, const float* col_w, const float* col_b, const 
   X(tmid_s, 128) X(dists_s, 128) X(sdf_s, 128) X(grad_s, 384) X(vis, 1) X(raymisc, nrh::RAYMISC_STRIDE)              \
   X(color, 384) X(cue_b, 512)
 
+int nrh_generate_rays(const float* pose /* host, 12 */, const float* pl /* host, 3 */, float cx, float cy, float fx, float fy,
+                      int width, int row0, int nrows, float* origins, float* directions, float* pl_positions,
+                      float* nears, float* fars, void* stream) {
+  if (!pose || !pl || !origins || !directions || !pl_positions || !nears || !fars)
+    return fail(NRH_E_INVALID, "nrh_generate_rays: null pointer%s", "");
+  if (width <= 0 || nrows < 0 || row0 < 0 || fx == 0.0f || fy == 0.0f) return fail(NRH_E_INVALID, "nrh_generate_rays: bad geometry%s", "");
+  if (nrows == 0) return NRH_OK;
+  nrh::RayGenArgs a;
+  for (int i = 0; i < 12; ++i) a.pose[i] = pose[i];
+  for (int i = 0; i < 3; ++i) a.pl[i] = pl[i];
+  a.cx = cx; a.cy = cy; a.fx = fx; a.fy = fy; a.width = width; a.row0 = row0; a.nrows = nrows;
+  a.origins = origins; a.dirs = directions; a.pls = pl_positions; a.nears = nears; a.fars = fars;
+  const long long tot = (long long)nrows * width;
+  hipLaunchKernelGGL(nrh::raygen_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("raygen_kernel");
+}
+
 long long nrh_render_workspace_floats(long long nrays) {
   if (nrays < 0) return -1;
   long long tot = 0;
@@ -288,8 +305,8 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
                        float cos_anneal, const float* t_rand_primary, const float* t_rand_shadow, int zero_hints,
                        const float* lin64, const float* lin16, float* rgb, float* depth, float* weights,
                        float* inside_sphere, float* analytic_normals, float* normalized_normals, float* visibilities,
-                       float* specular_cue, float* mid_z, float* dists, float* workspace, long long workspace_floats,
-                       void* stream) {
+                       float* specular_cue, float* mid_z, float* dists, float* normal_map, float* normalized_normal_map,
+                       float* workspace, long long workspace_floats, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !net->col_w || !net->col_b)
     return fail(NRH_E_INVALID, "nrh_render_forward: null network pointer%s", "");
@@ -376,6 +393,7 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
   {
     nrh::CompositeArgs c;
     c.color = ws_color; c.weights = o_weights; c.wsum = ws_wsum; c.bg = background; c.rgb = rgb; c.nrays = (int)n;
+    c.inside = o_inside; c.grad = o_grad; c.nhat = o_nhat; c.nmap = normal_map; c.nnmap = normalized_normal_map;
     hipLaunchKernelGGL(nrh::composite_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
     rc = check_launch("composite_kernel");
     if (rc) return rc;

@@ -417,6 +417,12 @@ struct CompositeArgs {
   const float* wsum;     // [N]
   const float* bg;       // [3] or null
   float* rgb;            // [N,3]
+  // optional per-pixel normal maps  sum_j n_j w_j inside_j  (pipelines/base_pipeline.py:125-131, einsum on the CPU there)
+  const float* inside;   // [N,128]
+  const float* grad;     // [N*128,3] analytic normals
+  const float* nhat;     // [N*128,3] normalised
+  float* nmap;           // [N,3] or null
+  float* nnmap;          // [N,3] or null
   int nrays;
 };
 __global__ __launch_bounds__(256) void composite_kernel(const CompositeArgs a) {
@@ -439,6 +445,72 @@ __global__ __launch_bounds__(256) void composite_kernel(const CompositeArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) a.rgb[ray * 3 + c] = acc[c] + (a.bg ? a.bg[c] * (1.0f - ws) : 0.0f);
   }
+  if (a.nmap || a.nnmap) {
+    float m0[3] = {0.f, 0.f, 0.f}, m1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const long long P = ray * 128 + lane + 64 * e;
+      const float w = a.weights[P] * a.inside[P];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        m0[c] += a.grad[P * 3 + c] * w;
+        m1[c] += a.nhat[P * 3 + c] * w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { m0[c] = wave_sum(m0[c]); m1[c] = wave_sum(m1[c]); }
+    if (active && lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (a.nmap) a.nmap[ray * 3 + c] = m0[c];
+        if (a.nnmap) a.nnmap[ray * 3 + c] = m1[c];
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// pixel -> ray for one pinhole view (camera/ray_generator.py:79-139, no pose/light deltas):
+//   dir_cam = ((x + .5 - cx)/fx, -(y + .5 - cy)/fy, -1);  d = normalize(R dir_cam);  o = t;  near/far = mid -+ 1
+// -------------------------------------------------------------------------------------------------
+struct RayGenArgs {
+  float pose[12];   // row-major [3,4] camera-to-world
+  float pl[3];      // point light position of the view
+  float cx, cy, fx, fy;
+  int width, row0, nrows;
+  float* origins;   // [nrows*width,3]
+  float* dirs;
+  float* pls;
+  float* nears;     // [nrows*width]
+  float* fars;
+};
+__global__ void raygen_kernel(const RayGenArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)a.nrows * a.width) return;
+  const int y = a.row0 + (int)(i / a.width), x = (int)(i % a.width);
+  const float dcx = ((float)x + 0.5f - a.cx) / a.fx;
+  const float dcy = -((float)y + 0.5f - a.cy) / a.fy;
+  const float dcz = -1.0f;
+  float d[3], o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    d[r] = dcx * a.pose[r * 4 + 0] + dcy * a.pose[r * 4 + 1] + dcz * a.pose[r * 4 + 2];  // sum(dirs[None,:] * R, -1)
+    o[r] = a.pose[r * 4 + 3];
+  }
+  const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] /= nrm;
+  const float aa = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const float bb = 2.0f * (o[0] * d[0] + o[1] * d[1] + o[2] * d[2]);
+  const float mid = 0.5f * (-bb) / aa;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    a.origins[i * 3 + r] = o[r];
+    a.dirs[i * 3 + r] = d[r];
+    a.pls[i * 3 + r] = a.pl[r];
+  }
+  a.nears[i] = mid - 1.0f;
+  a.fars[i] = mid + 1.0f;
 }
 
 }  // namespace nrh

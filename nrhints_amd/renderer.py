@@ -208,32 +208,13 @@ class NeuSHintRenderer(nn.Module):
             if bg.numel() != 3:
                 raise ValueError("background_rgb must be [1,3]")
 
+        res = self._render_chunks(o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints,
+                                  want_samples=True, want_maps=False, want_mid=needs_grad)
+        rgb, depth, vis = res["rgb"], res["depth"], res["visibilities"]
+        weights, inside, normals, nhat, cue = (res[k] for k in ("weights", "inside", "normals", "nhat", "cue"))
+        mid_z, dists = res.get("mid_z"), res.get("dists")
         pk = self.packed_params(device)
-        lin64, lin16 = self._const(device)
-        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
-                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"])
         T = N_SAMPLES_TOTAL
-        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
-        rgb, depth, vis = new(n, 3), new(n, 1), new(n, 1)
-        weights, inside = new(n, T), new(n, T)
-        normals, nhat, cue = new(n, T, 3), new(n, T, 3), new(n, T, 4)
-        mid_z = new(n, T) if needs_grad else None
-        dists = new(n, T) if needs_grad else None
-        chunk = max(1, min(self.max_chunk_rays, n))
-        ws = self._workspace(device, chunk)
-        stream = _lib.stream_handle()
-        P = _lib.ptr
-        for i in range(0, n, chunk):
-            m = min(chunk, n - i)
-            sl = slice(i, i + m)
-            rc = lib.nrh_render_forward(
-                net, P(o[sl]), P(d[sl]), P(pl[sl]), P(near[sl]), P(far[sl]), m, P(bg), cos_anneal,
-                P(t_rand_p[sl]) if t_rand_p is not None else None,
-                P(t_rand_s[sl]) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16),
-                P(rgb[sl]), P(depth[sl]), P(weights[sl]), P(inside[sl]), P(normals[sl]), P(nhat[sl]), P(vis[sl]),
-                P(cue[sl]), P(mid_z[sl]) if needs_grad else None, P(dists[sl]) if needs_grad else None,
-                P(ws), ws.numel(), stream)
-            _lib.check(rc, "nrh_render_forward")
         if needs_grad:
             # differentiable part (render_core) over the HIP results; see autograd_core.py
             dense = packing.dense_params(dict(self.named_parameters()))
@@ -250,6 +231,60 @@ class NeuSHintRenderer(nn.Module):
         return RenderOutput(rgb=rgb, depth=depth, weights=weights, s_val=s_val, inside_sphere=inside,
                             relax_inside_sphere=inside, analytic_normals=normals,
                             normalized_analytic_normals=nhat, visibilities=vis, specular_cue=cue)
+
+    # ---------------------------------------------------------------------------------------------
+    def _render_chunks(self, o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints, want_samples: bool,
+                       want_maps: bool, want_mid: bool):
+        """Enqueue nrh_render_forward per chunk of rays; returns a dict of freshly allocated output tensors.
+        want_samples: materialise the per-sample RenderOutput fields; want_maps: the per-pixel normal maps of the
+        evaluation loop; want_mid: section mid-points / lengths (for the autograd training path)."""
+        lib = _lib.load()
+        device = o.device
+        n = o.shape[0]
+        pk = self.packed_params(device)
+        lin64, lin16 = self._const(device)
+        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
+                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"])
+        T = N_SAMPLES_TOTAL
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
+        out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))
+        if want_samples:
+            out.update(weights=new(n, T), inside=new(n, T), normals=new(n, T, 3), nhat=new(n, T, 3), cue=new(n, T, 4))
+        if want_maps:
+            out.update(normal_map=new(n, 3), normalized_normal_map=new(n, 3))
+        if want_mid:
+            out.update(mid_z=new(n, T), dists=new(n, T))
+        chunk = max(1, min(self.max_chunk_rays, n))
+        ws = self._workspace(device, chunk)
+        stream = _lib.stream_handle()
+        P = _lib.ptr
+        opt = lambda key, sl: P(out[key][sl]) if key in out else None
+        for i in range(0, n, chunk):
+            m = min(chunk, n - i)
+            sl = slice(i, i + m)
+            rc = lib.nrh_render_forward(
+                net, P(o[sl]), P(d[sl]), P(pl[sl]), P(near[sl]), P(far[sl]), m, P(bg), cos_anneal,
+                P(t_rand_p[sl]) if t_rand_p is not None else None,
+                P(t_rand_s[sl]) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16),
+                P(out["rgb"][sl]), P(out["depth"][sl]), opt("weights", sl), opt("inside", sl), opt("normals", sl),
+                opt("nhat", sl), P(out["visibilities"][sl]), opt("cue", sl), opt("mid_z", sl), opt("dists", sl),
+                opt("normal_map", sl), opt("normalized_normal_map", sl), P(ws), ws.numel(), stream)
+            _lib.check(rc, "nrh_render_forward")
+        return out
+
+    @torch.no_grad()
+    def render_products(self, ray_bundle: RayBundle, background_rgb: Optional[torch.Tensor] = None):
+        """Evaluation fast path: per-PIXEL products only - rgb, depth, shadow map (visibilities) and the two weighted
+        normal maps in world space - 15 floats per ray instead of the 1 669 of a full RenderOutput
+        (what pipelines/base_pipeline.py:110-133 copies to the host per 512-ray chunk and reduces on the CPU)."""
+        o, d, pl = ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions
+        if not o.is_cuda:
+            raise RuntimeError("NeuSHintRenderer (MI355X) runs on the GPU only")
+        f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
+        bg = f32(background_rgb.to(o.device)).reshape(-1) if background_rgb is not None else None
+        return self._render_chunks(f32(o), f32(d), f32(pl), f32(ray_bundle.nears).reshape(-1),
+                                   f32(ray_bundle.fars).reshape(-1), bg, 1.0, None, None, 0,
+                                   want_samples=False, want_maps=True, want_mid=False)
 
     # ---------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -37,7 +37,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 102
+    assert lib.nrh_version() >= 103
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
@@ -316,3 +316,41 @@ def test_training_step_gradients(scene):
         scale = max(np.abs(want).max(), 1e-8)
         assert np.abs(t_.grad.cpu().numpy() - want).max() / scale < 2e-2, nm
     model.zero_grad()
+
+
+def test_eval_image_products_and_raygen(scene):
+    """Fused ray generation + on-device image reductions against the reference's formulas."""
+    from nrhints_amd.pipeline import CameraModel, generate_rays, render_image
+    from nrhints_amd.synthetic import make_image_rays
+    tag, model, packed, p32, _ = scene
+    cam = CameraModel(H=24, W=32, cx=16.0, cy=12.0, fx=40.0, fy=40.0)
+    # pose / light of the synthetic orbit camera
+    o_np, d_np, pl_np, near_np, far_np = make_image_rays(24, 32, focal=40.0)
+    # rebuild the pose make_image_rays used: origin + the three direction vectors of pixel rays are enough to check
+    # generate_rays against it through an explicit pose
+    import numpy as _np
+    ce, se, ca, sa = _np.cos(0.5), _np.sin(0.5), _np.cos(0.6), _np.sin(0.6)
+    pos = 4.0 * _np.array([ce * ca, ce * sa, se])
+    fwd = -pos / _np.linalg.norm(pos)
+    right = _np.cross(fwd, _np.array([0.0, 0.0, 1.0])); right /= _np.linalg.norm(right)
+    up = _np.cross(right, fwd)
+    pose = torch.tensor(_np.concatenate([_np.stack([right, up, -fwd], axis=1), pos[:, None]], axis=1), dtype=torch.float32)
+    rb = generate_rays(cam, pose, T(pl_np[0]), "cuda")
+    np.testing.assert_allclose(rb.directions.cpu().numpy(), d_np, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(rb.origins.cpu().numpy(), o_np, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rb.nears.cpu().numpy(), near_np, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(rb.fars.cpu().numpy(), far_np, rtol=0, atol=2e-5)
+    # image products == reductions of the full RenderOutput (pipelines/base_pipeline.py:125-131)
+    img = render_image(model, cam, pose, T(pl_np[0]), white_background=True)
+    with torch.no_grad():
+        full = model(rb, background_rgb=torch.ones(1, 3).cuda())
+    assert torch.equal(img["rgb"].reshape(-1, 3), full.rgb)
+    rot = torch.linalg.inv(pose[:3, :3]).cuda()
+    for key, field in (("analytic_normals", full.analytic_normals), ("normalized_analytic_normals", full.normalized_analytic_normals)):
+        ref = torch.einsum("...ij,...i,...i->...j", field, full.weights, full.inside_sphere)
+        ref = (rot[None] @ ref[:, :, None])[:, :, 0]
+        torch.testing.assert_close(img[key].reshape(-1, 3), ref, rtol=0, atol=2e-5)
+    gt = img["rgb"].clone() + 0.01
+    out = render_image(model, cam, pose, T(pl_np[0]), rgb_gt=gt[4:12], row0=4, row1=12)
+    assert out["rgb"].shape == (8, 32, 3) and torch.equal(out["rgb"], img["rgb"][4:12])
+    assert abs(render_image(model, cam, pose, T(pl_np[0]), rgb_gt=gt)["psnr"] - 40.0) < 1e-2
