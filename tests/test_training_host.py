@@ -1,0 +1,84 @@
+"""Host-side training logic on CPU: loss formula vs the recorded reference loss, LR schedule, and the flat-gradient
+all-reduce over gloo with world size 2 (the renderer itself needs a GPU; a small stand-in module carries the grads)."""
+import math
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+import nrhints_amd as na
+from nrhints_amd.training import FlatGradAllReduce, lr_factor, make_optimizer, train_loss_dict
+from tests.conftest import load_npz
+
+
+def test_loss_matches_reference_record():
+    g = load_npz("train_b.npz")
+    T = torch.from_numpy
+    n = g["rgb"].shape[0]
+    out = na.RenderOutput(rgb=T(g["rgb"]), depth=T(g["depth"]), weights=T(g["weights"]), s_val=torch.ones(n, 128),
+                          inside_sphere=T(g["inside_sphere"]), relax_inside_sphere=T(g["inside_sphere"]),
+                          analytic_normals=T(g["analytic_normals"]), normalized_analytic_normals=T(g["analytic_normals"]))
+    d = train_loss_dict(out, T(g["rgb_gt"]))
+    np.testing.assert_allclose(d["loss"].item(), g["loss"], rtol=1e-6)
+    np.testing.assert_allclose(d["rgb_loss"].item(), g["rgb_loss"], rtol=1e-6)
+    np.testing.assert_allclose(d["eikonal_loss"].item(), g["eikonal_loss"], rtol=1e-6)
+
+
+def test_lr_schedule():
+    assert lr_factor(0) == 0.0 and abs(lr_factor(2500) - 0.5) < 1e-12 and abs(lr_factor(5000) - 1.0) < 1e-12
+    assert abs(lr_factor(1_000_000) - 0.05) < 1e-12
+    mid = (5000 + 1_000_000) // 2
+    assert abs(lr_factor(mid) - (0.5 * 0.95 + 0.05)) < 1e-5
+    m = na.NeuSHintRenderer()
+    extra = [nn.Parameter(torch.zeros(10, 6))]
+    opt, sched = make_optimizer(m, extra)
+    assert len(opt.param_groups) == 2 and len(opt.param_groups[0]["params"]) == 46
+    assert opt.param_groups[0]["initial_lr"] == 5e-4 and opt.param_groups[1]["initial_lr"] == 1e-4
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)           # ranks start with DIFFERENT weights ...
+        net = nn.Sequential(nn.Linear(5, 7), nn.Softplus(beta=100), nn.Linear(7, 3))
+        sync = FlatGradAllReduce(net.parameters())
+        sync.broadcast_parameters(0)            # ... and are made identical, as DDP does at wrap time
+        torch.manual_seed(7 + rank)             # per-rank batch
+        x, y = torch.randn(16, 5), torch.randn(16, 3)
+        loss = ((net(x) - y) ** 2).mean()
+        loss.backward()
+        sync()
+        flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        np.save(os.path.join(out_dir, f"g{rank}.npy"), flat.numpy())
+        np.save(os.path.join(out_dir, f"w{rank}.npy"), w.numpy())
+        np.save(os.path.join(out_dir, f"x{rank}.npy"), torch.cat([x.reshape(-1), y.reshape(-1)]).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    w0, w1 = np.load(tmp_path / "w0.npy"), np.load(tmp_path / "w1.npy")
+    np.testing.assert_array_equal(g0, g1)       # every rank holds the mean gradient
+    np.testing.assert_array_equal(w0, w1)       # parameters were broadcast
+    # the mean gradient equals the gradient of the mean loss over both batches, computed in one process
+    torch.manual_seed(100)
+    net = nn.Sequential(nn.Linear(5, 7), nn.Softplus(beta=100), nn.Linear(7, 3))
+    total = 0.0
+    for r in range(2):
+        xy = torch.from_numpy(np.load(tmp_path / f"x{r}.npy"))
+        x, y = xy[:80].reshape(16, 5), xy[80:].reshape(16, 3)
+        total = total + ((net(x) - y) ** 2).mean() / 2
+    total.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    np.testing.assert_allclose(g0, ref, rtol=1e-5, atol=1e-7)
