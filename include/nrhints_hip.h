@@ -85,7 +85,7 @@ int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const
  *   feat     D-layout tiles from nrh_sdf_eval(mode 2);  nhat [nrays*128,3] unit normals;
  *   raymisc  [nrays, out[5]] per-ray part of the input: enc4(view) | enc4(pl) | enc4(vis) | enc4(cue)
  *   color    [nrays*128,3] */
-int nrh_color_eval(int precision, const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
+int nrh_color_eval(int precision, int hints, const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
                    const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
                    void* stream);
 
@@ -112,6 +112,10 @@ typedef struct NrhNet {
   const float* col_b;
   float inv_s;
   int precision; /* 0 = f32 MFMA (exact fp32), 1 = f16x3 split MFMA (fp32-equivalent accuracy, 16/3 the rate) */
+  int hints;       /* 1 = shadow + specular hints (nr-hints presets); 0 = none (pl-naive preset, configs/main_config.py:67-76):
+                      no shadow march, reflectance input 316 wide, col_w packed accordingly */
+  int normal_type; /* 0 = NormalizedAnalytic, 1 = Analytic normal fed to the reflectance net (models/neus_hint_model.py:621-625) */
+  int depth_type;  /* 0 = AlphaBlend, 1 = MaximalWeightPoint (:528-538) */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

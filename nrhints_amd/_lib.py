@@ -23,7 +23,8 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
 
 class NrhNet(Structure):
     _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
-                ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int)]
+                ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
+                ("normal_type", c_int), ("depth_type", c_int)]
 
 
 class HipExtensionMissing(RuntimeError):
@@ -56,7 +57,7 @@ def load():
     lib.nrh_sdf_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
     lib.nrh_sampler_step.argtypes = [P, P, P, P, P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, c_int,
                                      c_int, c_int, P]
-    lib.nrh_color_eval.argtypes = [c_int, P, P, P, P, P, P, P, P, c_longlong, P, P]
+    lib.nrh_color_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, P, P, c_longlong, P, P]
     lib.nrh_render_workspace_floats.argtypes = [c_longlong]
     lib.nrh_render_workspace_floats.restype = c_longlong
     lib.nrh_render_forward.argtypes = [POINTER(NrhNet), P, P, P, P, P, c_longlong, P, c_float, P, P, c_int, P, P,

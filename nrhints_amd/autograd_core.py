@@ -36,7 +36,7 @@ def _sdf_net(d: Dict[str, torch.Tensor], pts: torch.Tensor):
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
-                background_rgb) -> Dict[str, torch.Tensor]:
+                background_rgb, analytic_normal: bool = False) -> Dict[str, torch.Tensor]:
     """``d``: weight-norm-folded dense parameters WITH autograd history (packing.dense_params on the live
     nn.Parameters); mid_z / dists [N,128], vis [N,1], cue [N,4]: graph-less results of the HIP forward."""
     n, T = mid_z.shape
@@ -57,7 +57,10 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     weights = alpha * trans
     n_hat = F.normalize(grad, dim=-1)
     rep = lambda x: x[:, None, :].expand(n, T, x.shape[-1]).reshape(n * T, -1)
-    x = torch.cat([pts, _enc(view, 4), n_hat, _enc(rep(pl), 4), feat, _enc(rep(vis), 4), _enc(rep(cue), 4)], dim=-1)
+    parts = [pts, _enc(view, 4), grad if analytic_normal else n_hat, _enc(rep(pl), 4), feat]
+    if vis is not None:  # vis / cue are None for the pl-naive model (no hints)
+        parts += [_enc(rep(vis), 4), _enc(rep(cue), 4)]
+    x = torch.cat(parts, dim=-1)
     for l in range(5):
         x = F.linear(x, d[f"col_w{l}"], d[f"col_b{l}"])
         if l < 4:

@@ -110,11 +110,11 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
         (r.n_shadow_samples == 64 and r.n_shadow_importance_samples == 64,
          "n_shadow_samples/n_shadow_importance_samples must be 64/64"),
         (r.n_shadow_importance_clip == -1, "only the hit-point shadow mode (n_shadow_importance_clip=-1) is implemented"),
-        (r.shadow_hint and r.specular_hint, "shadow_hint and specular_hint must both be on (PLNaive is not implemented)"),
+        (r.shadow_hint == r.specular_hint and not r.force_shadow_map and not r.force_specular_cue,
+         "shadow_hint and specular_hint must be both on (nr-hints) or both off (pl-naive); force_* dumps are not implemented"),
         (list(r.specular_roughness) == [0.02, 0.05, 0.13, 0.34], "specular_roughness must be the default 4 values"),
-        (r.depth_type == DepthComputationType.AlphaBlend, "only DepthComputationType.AlphaBlend is implemented"),
-        (r.normal_type == NormalComputationType.NormalizedAnalytic,
-         "only NormalComputationType.NormalizedAnalytic is implemented"),
+        (r.depth_type in (DepthComputationType.AlphaBlend, DepthComputationType.MaximalWeightPoint),
+         "DepthComputationType.SphereTracing is not implemented"),
         (not r.shadow_hint_gradient and not r.specular_hint_gradient, "hint gradients are not implemented"),
         (abs(r.shadow_ray_offset - 1e-2) < 1e-12, "shadow_ray_offset must be 1e-2"),
     ]

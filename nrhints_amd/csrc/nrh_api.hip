@@ -52,7 +52,8 @@ int ensure_attrs() {
   hipError_t e;
   const void* fns[] = {(const void*)nrh::sdf_kernel<0, 0>, (const void*)nrh::sdf_kernel<1, 0>, (const void*)nrh::sdf_kernel<2, 0>,
                        (const void*)nrh::sdf_kernel<0, 1>, (const void*)nrh::sdf_kernel<1, 1>, (const void*)nrh::sdf_kernel<2, 1>,
-                       (const void*)nrh::color_kernel<0>, (const void*)nrh::color_kernel<1>};
+                       (const void*)nrh::color_kernel<0, 8>, (const void*)nrh::color_kernel<1, 8>,
+                       (const void*)nrh::color_kernel<0, 4>, (const void*)nrh::color_kernel<1, 4>};
   e = hipSuccess;
   for (const void* f : fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
@@ -127,7 +128,7 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
   return check_launch("sampler_step_kernel");
 }
 
-int color_eval_impl(int prec, const float* w, const float* b, const float* feat, const float* ro, const float* rd,
+int color_eval_impl(int prec, int hints, const float* w, const float* b, const float* feat, const float* ro, const float* rd,
                     const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
                     hipStream_t st) {
   if (!w || !b || !feat || !ro || !rd || !tmid || !nhat || !raymisc || !color)
@@ -147,8 +148,12 @@ int color_eval_impl(int prec, const float* w, const float* b, const float* feat,
   TimedLaunch tl;
   bool timed;
   timing_begin(3, st, tl, timed);
-  if (prec == 0) hipLaunchKernelGGL(nrh::color_kernel<0>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
-  else if (prec == 1) hipLaunchKernelGGL(nrh::color_kernel<1>, dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  const dim3 g(grid), blk(nrh::MLP_THREADS);
+  const int lds = nrh::MLP_LDS_BYTES;
+  if (prec == 0 && hints) hipLaunchKernelGGL((nrh::color_kernel<0, 8>), g, blk, lds, st, a);
+  else if (prec == 1 && hints) hipLaunchKernelGGL((nrh::color_kernel<1, 8>), g, blk, lds, st, a);
+  else if (prec == 0) hipLaunchKernelGGL((nrh::color_kernel<0, 4>), g, blk, lds, st, a);
+  else if (prec == 1) hipLaunchKernelGGL((nrh::color_kernel<1, 4>), g, blk, lds, st, a);
   else return fail(NRH_E_INVALID, "nrh_color_eval: precision must be 0 (f32) or 1 (f16x3)%s", "");
   timing_end(st, tl, timed);
   return check_launch("color_kernel");
@@ -189,7 +194,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 103; }
+int nrh_version(void) { return 104; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -260,10 +265,10 @@ int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const
   return sampler_step_impl(a, (hipStream_t)stream);
 }
 
-int nrh_color_eval(int precision, const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
+int nrh_color_eval(int precision, int hints, const float* col_w, const float* col_b, const float* feat, const float* ro, const float* rd,
                    const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
                    void* stream) {
-  return color_eval_impl(precision, col_w, col_b, feat, ro, rd, tmid, nhat, raymisc, nrays, color, (hipStream_t)stream);
+  return color_eval_impl(precision, hints, col_w, col_b, feat, ro, rd, tmid, nhat, raymisc, nrays, color, (hipStream_t)stream);
 }
 
 // workspace carve-up (floats per ray, each array rounded up to a multiple of 64 floats)
@@ -312,6 +317,10 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     return fail(NRH_E_INVALID, "nrh_render_forward: null network pointer%s", "");
   if (net->precision < 0 || net->precision > 1)
     return fail(NRH_E_INVALID, "nrh_render_forward: net->precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if ((net->hints != 0 && net->hints != 1) || (net->normal_type != 0 && net->normal_type != 1) ||
+      (net->depth_type != 0 && net->depth_type != 1))
+    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type / depth_type must be 0 or 1%s", "");
+  const int no_hints = zero_hints || !net->hints;  // no shadow march: geometry warm-up, or the pl-naive model
   if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || !rgb || !workspace)
     return fail(NRH_E_INVALID, "nrh_render_forward: null pointer%s", "");
   if (nrays < 0 || nrays > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_render_forward: nrays out of range (chunk the call)%s", "");
@@ -363,14 +372,15 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
       const double k = (rough[i] + 1.0) * (rough[i] + 1.0) / 8.0, a2 = rough[i] * rough[i];
       c.kk[i] = (float)k; c.omk[i] = (float)(1.0 - k); c.a2[i] = (float)a2; c.a2m1[i] = (float)(a2 - 1.0);
     }
-    c.zero_hints = zero_hints;
+    c.zero_hints = no_hints;
+    c.depth_max_weight = net->depth_type;
     c.nrays = (int)n;
     hipLaunchKernelGGL(nrh::core_alpha_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
     rc = check_launch("core_alpha_kernel");
     if (rc) return rc;
   }
   // ---- shadow rays light -> hit point ----
-  if (!zero_hints) {
+  if (!no_hints) {
     rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s,
                      ws_dists_s, n, st);
     if (rc) return rc;
@@ -382,13 +392,14 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     nrh::ShadowArgs c;
     c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = ws_dists_s;
     c.cue = ws_cue; c.vis = o_vis; c.raymisc = ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
-    c.nrays = (int)n; c.zero_hints = zero_hints;
+    c.nrays = (int)n; c.zero_hints = no_hints;
     hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
     rc = check_launch("shadow_finish_kernel");
     if (rc) return rc;
   }
   // ---- reflectance + composite ----
-  rc = color_eval_impl(net->precision, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid, o_nhat, ws_raymisc, n, ws_color, st);
+  rc = color_eval_impl(net->precision, net->hints, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid,
+                       net->normal_type ? o_grad : o_nhat, ws_raymisc, n, ws_color, st);
   if (rc) return rc;
   {
     nrh::CompositeArgs c;

@@ -19,7 +19,7 @@ struct ColorArgs {
   const float* ro;       // [nrays,3]
   const float* rd;       // [nrays,3]
   const float* tmid;     // [nrays,128]
-  const float* nhat;     // [npts,3] unit normals
+  const float* nhat;     // [npts,3] normal fed to the net: unit normals (NormalizedAnalytic) or raw gradients (Analytic)
   const float* raymisc;  // [nrays,RAYMISC_STRIDE]
   float* color;          // [npts,3]
   long long npts;
@@ -33,7 +33,7 @@ __device__ __forceinline__ f32x4 relu4(const f32x4 x) {
   return f32x4{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f), fmaxf(x[2], 0.0f), fmaxf(x[3], 0.0f)};
 }
 
-template <int PREC>
+template <int PREC, int MKB>
 __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -70,10 +70,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) { part[ch * 8 + r] = acc0[r]; part[ch * 8 + 4 + r] = acc1[r]; }
       };
-      run_stage<PREC, 16, 8, false>(a.w + COL_OFF_C0A, a.w + COL_OFF_C0B, 16, smem, par, h, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 16, 8, false>(a.w + COL_OFF_C0A, a.w + COL_OFF_C0B, 2 * MKB, smem, par, h, nullptr, pre, epi, wave, lane);
     }
     // ---- C0b: per-sample + per-ray part; entry m = 16b + 4q + r of [p, n, raymisc[0..98]] ----
-    Act<PREC, 8> misc;
+    Act<PREC, MKB> misc;
     {
       const float tt = a.tmid[Pc];
       float pn[6];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       }
       const float* rm = a.raymisc + ray * RAYMISC_STRIDE;
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
+      for (int ch = 0; ch < MKB / 2; ++ch) {
         float o[8];
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
             const float ld = rm[(m >= 6) ? m - 6 : 0];
             v = (m < 6) ? per : ld;
           } else {
-            v = (m < COL_MISC) ? rm[(m < COL_MISC) ? m - 6 : 0] : 0.0f;
+            v = (m < col_misc(MKB)) ? rm[(m < col_misc(MKB)) ? m - 6 : 0] : 0.0f;
           }
           o[r8] = v;
         }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
         h.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
       };
-      run_stage<PREC, 8, 8, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1), 32, smem, par, misc, part, pre, epi, wave, lane);
+      run_stage<PREC, MKB, 8, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1, MKB), 32, smem, par, misc, part, pre, epi, wave, lane);
     }
     // ---- C1..C3 ----
     for (int l = 1; l <= 3; ++l) {
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
         ho.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
       };
-      const float* wn = (l < 3) ? a.w + col_off_C(l + 1) : a.w + COL_OFF_C4;
-      run_stage<PREC, 16, 8, false>(a.w + col_off_C(l), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
+      const float* wn = (l < 3) ? a.w + col_off_C(l + 1, MKB) : a.w + col_off_C4(MKB);
+      run_stage<PREC, 16, 8, false>(a.w + col_off_C(l, MKB), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
       h = ho;
     }
     // ---- C4: 3 output rows (block 0, lanes q == 0 hold r = 0..2) + sigmoid ----
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
           for (int r = 0; r < 3; ++r) a.color[P * 3 + r] = sigmoidf_(acc0[r] + p.b0[r]);
         }
       };
-      run_stage<PREC, 16, 1, false>(a.w + COL_OFF_C4, a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 16, 1, false>(a.w + col_off_C4(MKB), a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, pre, epi, wave, lane);
     }
   }
 }

@@ -262,14 +262,17 @@ constexpr int SDF_SCRATCH_FLOATS_PER_WAVE = 8 * 16 * 256;  // sigma' of 8 layers
 
 // ---------------- packed-buffer geometry of the reflectance net ----------------
 // C0a (feature part of the input, K=256) | C0b (105 per-sample/per-ray inputs, K=128) | C1..C3 | C4 (3 rows in a 32-row chunk)
+// MKB = K blocks of the non-feature part of layer 0: 8 with the shadow/specular hints (105 inputs -> 128), 4 without
+// (the reference's `pl-naive` preset, configs/main_config.py:67-76: 60 inputs -> 64)
 constexpr int COL_OFF_C0A = 0;
-constexpr int COL_C0B_FLOATS = 8 * 2 * 8 * 256;   // 105 inputs -> 128
 constexpr int COL_OFF_C0B = SDF_REG_FLOATS;
-__host__ __device__ constexpr int col_off_C(int l) { return SDF_REG_FLOATS + COL_C0B_FLOATS + (l - 1) * SDF_REG_FLOATS; }  // l=1..3
-constexpr int COL_OFF_C4 = SDF_REG_FLOATS + COL_C0B_FLOATS + 3 * SDF_REG_FLOATS;
-constexpr int COL_PACKED_FLOATS = COL_OFF_C4 + 2 * 16 * 256;
+__host__ __device__ constexpr int col_c0b_floats(int mkb) { return 8 * 2 * mkb * 256; }
+__host__ __device__ constexpr int col_off_C(int l, int mkb) { return SDF_REG_FLOATS + col_c0b_floats(mkb) + (l - 1) * SDF_REG_FLOATS; }  // l=1..3
+__host__ __device__ constexpr int col_off_C4(int mkb) { return SDF_REG_FLOATS + col_c0b_floats(mkb) + 3 * SDF_REG_FLOATS; }
+__host__ __device__ constexpr int col_packed_floats(int mkb) { return col_off_C4(mkb) + 2 * 16 * 256; }
+constexpr int COL_PACKED_FLOATS = col_packed_floats(8);
 constexpr int COL_BIAS_FLOATS = 4 * 256 + 16;
-constexpr int COL_MISC = 105;        // [p 3, n 3, enc4(view) 27, enc4(pl) 27, enc4(vis) 9, enc4(cue) 36]
+__host__ __device__ constexpr int col_misc(int mkb) { return mkb == 8 ? 105 : 60; }  // [p 3, n 3, enc4(view) 27, enc4(pl) 27 (, enc4(vis) 9, enc4(cue) 36)]
 constexpr int RAYMISC_STRIDE = 100;  // per-ray part of the above: 27 + 27 + 9 + 36 = 99 (+1 pad)
 
 }  // namespace nrh

@@ -231,6 +231,7 @@ struct CoreArgs {
   // (models/neus_hint_model.py:604, 609): k, 1 - k, a^2, a^2 - 1
   float kk[4], omk[4], a2[4], a2m1[4];
   int zero_hints;  // geometry warm-up: cue = 0 (:617-619)
+  int depth_max_weight;  // DepthComputationType.MaximalWeightPoint (:534-538) instead of alpha blending
   int nrays;
 };
 
@@ -259,7 +260,18 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
   excl_prod_128(1.0f - al[0] + 1e-7f, 1.0f - al[1] + 1e-7f, T0, T1);
   const float w0 = al[0] * T0, w1 = al[1] * T1;
   const float wsum = wave_sum(w0 + w1);
-  const float depth = wave_sum(mid[0] * w0 + mid[1] * w1);
+  float depth = wave_sum(mid[0] * w0 + mid[1] * w1);
+  if (a.depth_max_weight) {
+    // depth = mid_z at argmax_j w_j, first index on ties (torch.argmax)
+    float wmax = fmaxf(w0, w1);
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o2, 64));
+    int idx = (w0 == wmax) ? lane : ((w1 == wmax) ? lane + 64 : 1 << 20);
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) idx = min(idx, __shfl_xor(idx, o2, 64));
+    const float cand = (idx & 64) ? mid[1] : mid[0];
+    depth = __shfl(cand, idx & 63, 64);
+  }
   const float hnx = wave_sum(nh[0][0] * w0 + nh[1][0] * w1);
   const float hny = wave_sum(nh[0][1] * w0 + nh[1][1] * w1);
   const float hnz = wave_sum(nh[0][2] * w0 + nh[1][2] * w1);

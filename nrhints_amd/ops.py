@@ -75,14 +75,14 @@ def sampler_step(ro, rd, z, s, n: int, *, znew_in=None, snew_in=None, upsample_i
     return znew_out, tmid, dists
 
 
-def color_eval(col_w, col_b, feat_tiles, ro, rd, tmid, nhat, raymisc) -> torch.Tensor:
-    """Reflectance MLP for nrays x 128 samples -> [nrays*128, 3]."""
+def color_eval(col_w, col_b, feat_tiles, ro, rd, tmid, nhat, raymisc, hints: bool = True) -> torch.Tensor:
+    """Reflectance MLP for nrays x 128 samples -> [nrays*128, 3] (``hints=False``: the 316-input pl-naive net)."""
     lib = _lib.load()
     nrays = ro.shape[0]
     color = torch.empty(nrays * 128, 3, dtype=torch.float32, device=ro.device)
     P = _lib.ptr
     wp, prec = _wptr(col_w)
-    rc = lib.nrh_color_eval(prec, wp, P(col_b), P(feat_tiles), P(ro), P(rd), P(tmid), P(nhat), P(raymisc), nrays,
+    rc = lib.nrh_color_eval(prec, int(hints), wp, P(col_b), P(feat_tiles), P(ro), P(rd), P(tmid), P(nhat), P(raymisc), nrays,
                             P(color), _lib.stream_handle())
     _lib.check(rc, "nrh_color_eval")
     return color

@@ -29,6 +29,10 @@ SDF_BIAS_FLOATS = 9 * 256
 SDF_HEAD_FLOATS = 257
 COL_C0B_FLOATS = 8 * 2 * 8 * 256
 COL_PACKED_FLOATS = SDF_REG_FLOATS + COL_C0B_FLOATS + 3 * SDF_REG_FLOATS + 2 * 16 * 256
+
+
+def col_packed_floats(hints: bool = True) -> int:
+    return SDF_REG_FLOATS + 8 * 2 * (8 if hints else 4) * 256 + 3 * SDF_REG_FLOATS + 2 * 16 * 256
 COL_BIAS_FLOATS = 4 * 256 + 16
 RAYMISC_STRIDE = 100
 SDF_SCRATCH_FLOATS_PER_WAVE = 8 * 16 * 256
@@ -95,11 +99,11 @@ def dense_params(state: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, 
     return out
 
 
-def check_default_shapes(d: Dict[str, torch.Tensor]) -> None:
+def check_default_shapes(d: Dict[str, torch.Tensor], hints: bool = True) -> None:
     """The kernels are compiled for the default nr-hints network shape."""
     want = {"sdf_w0": (256, 39), "sdf_w1": (256, 256), "sdf_w2": (256, 256), "sdf_w3": (217, 256),
             "sdf_w4": (256, 256), "sdf_w5": (256, 256), "sdf_w6": (256, 256), "sdf_w7": (256, 256),
-            "sdf_head_w": (1, 256), "feat_w": (256, 256), "col_w0": (256, 361), "col_w1": (256, 256),
+            "sdf_head_w": (1, 256), "feat_w": (256, 256), "col_w0": (256, 361 if hints else 316), "col_w1": (256, 256),
             "col_w2": (256, 256), "col_w3": (256, 256), "col_w4": (3, 256)}
     for k, shp in want.items():
         if tuple(d[k].shape) != shp:
@@ -128,27 +132,28 @@ def pack_sdf(d: Dict[str, torch.Tensor], precision: int = 0) -> Tuple[torch.Tens
     return packed.contiguous(), bias.contiguous(), head.contiguous()
 
 
-def color_input_permutation() -> Tuple[torch.Tensor, torch.Tensor]:
+def color_input_permutation(hints: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Column indices of the reference's 361-wide reflectance input
     [pts 0:3 | enc4(view) 3:30 | normal 30:33 | enc4(pl) 33:60 | feat 60:316 | enc4(vis) 316:325 | enc4(cue) 325:361]
     (fields/reflectance_network.py:77-82) in kernel order: (feature part [256], other part [105] =
     [pts, normal, enc4(view), enc4(pl), enc4(vis), enc4(cue)])."""
     feat = torch.arange(60, 316)
-    misc = torch.cat([torch.arange(0, 3), torch.arange(30, 33), torch.arange(3, 30), torch.arange(33, 60),
-                      torch.arange(316, 325), torch.arange(325, 361)])
-    return feat, misc
+    parts = [torch.arange(0, 3), torch.arange(30, 33), torch.arange(3, 30), torch.arange(33, 60)]
+    if hints:  # without hints (pl-naive) the input simply ends after feat (fields/reflectance_network.py:77-82)
+        parts += [torch.arange(316, 325), torch.arange(325, 361)]
+    return feat, torch.cat(parts)
 
 
-def pack_color(d: Dict[str, torch.Tensor], precision: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+def pack_color(d: Dict[str, torch.Tensor], precision: int = 0, hints: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """-> (packed stages, biases [4*256+16]) in order C0a | C0b | C1 | C2 | C3 | C4 (fp32 or fp16 pairs, see pack_sdf)."""
     ps = pack_stage if precision == 0 else pack_stage_h3
-    fi, mi = color_input_permutation()
+    fi, mi = color_input_permutation(hints)
     w0 = d["col_w0"]
-    parts = [ps(w0[:, fi.to(w0.device)], 256, 256), ps(w0[:, mi.to(w0.device)], 256, 128)]
+    parts = [ps(w0[:, fi.to(w0.device)], 256, 256), ps(w0[:, mi.to(w0.device)], 256, 128 if hints else 64)]
     parts += [ps(d[f"col_w{l}"], 256, 256) for l in (1, 2, 3)]
     parts.append(ps(d["col_w4"], 32, 256))
     packed = torch.cat(parts)
-    assert packed.numel() == COL_PACKED_FLOATS * (1 if precision == 0 else 2)
+    assert packed.numel() == col_packed_floats(hints) * (1 if precision == 0 else 2)
     bias = torch.cat([d["col_b0"], d["col_b1"], d["col_b2"], d["col_b3"], _pad_vec(d["col_b4"], 16)])
     return packed.contiguous(), bias.contiguous()
 

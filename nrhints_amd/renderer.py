@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import _lib, autograd_core, packing
-from .config import NeuSModelConfig, unsupported_reason
+from .config import DepthComputationType, NeuSModelConfig, NormalComputationType, unsupported_reason
 from .containers import RayBundle, RenderOutput
 
 N_SAMPLES_TOTAL = 128
@@ -78,10 +78,10 @@ class SDFNetwork(nn.Module):
 class ReflectanceNetwork(nn.Module):
     """Parameter container of the reflectance MLP (fields/reflectance_network.py:26-66): 361 -> 4x256 -> 3."""
 
-    def __init__(self, d_feature: int, d_in: int, d_out: int, config, n_cue: int):
+    def __init__(self, d_feature: int, d_in: int, d_out: int, config, n_cue: int, shadow_hint: bool = True):
         super().__init__()
         pe3 = 3 * 2 * config.multi_res          # extra dims of enc(view) / enc(pl) beyond the raw vector
-        d0 = d_in + d_feature + 2 * pe3 + 1 * 2 * config.multi_res + n_cue * 2 * config.multi_res
+        d0 = d_in + d_feature + 2 * pe3 + (1 if shadow_hint else 0) * 2 * config.multi_res + n_cue * 2 * config.multi_res
         dims = [d0] + [config.d_hidden] * config.n_layers + [d_out]
         for l in range(len(dims) - 1):
             lin = nn.Linear(dims[l], dims[l + 1])
@@ -116,13 +116,16 @@ class NeuSHintRenderer(nn.Module):
         if why is not None:
             raise ValueError(f"NeuSHintRenderer (MI355X): unsupported configuration: {why}")
         self.config = config
-        self.has_shadow_hint = True
-        self.has_specular_hint = True
+        self.has_shadow_hint = bool(config.renderer.shadow_hint)
+        self.has_specular_hint = bool(config.renderer.specular_hint)
+        self._hints = 1 if self.has_shadow_hint else 0
+        self._normal_type = 1 if config.renderer.normal_type == NormalComputationType.Analytic else 0
+        self._depth_type = 1 if config.renderer.depth_type == DepthComputationType.MaximalWeightPoint else 0
         self.sdf_network = SDFNetwork(config.sdf_network)
         self.deviation_network = SingleVarianceNetwork(config.deviation_network.init_val)
-        n_cue = len(config.renderer.specular_roughness)
-        self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + 1 + n_cue, 3,
-                                                config.reflectance_network, n_cue)
+        n_cue = len(config.renderer.specular_roughness) if self.has_specular_hint else 0
+        self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + self._hints + n_cue, 3,
+                                                config.reflectance_network, n_cue, self.has_shadow_hint)
         self._packed = None
         self._packed_key = None
         self._ws = {}
@@ -139,10 +142,10 @@ class NeuSHintRenderer(nn.Module):
             with torch.no_grad():
                 state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
                 d = packing.dense_params(state)
-                packing.check_default_shapes(d)
+                packing.check_default_shapes(d, bool(self._hints))
                 prec = _lib.PRECISIONS[self.precision]
                 sw, sb, sh = packing.pack_sdf(d, prec)
-                cw, cb = packing.pack_color(d, prec)
+                cw, cb = packing.pack_color(d, prec, bool(self._hints))
                 inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6).item())
             self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s, precision=prec)
             self._packed_key = key
@@ -220,17 +223,19 @@ class NeuSHintRenderer(nn.Module):
             dense = packing.dense_params(dict(self.named_parameters()))
             core = autograd_core.render_core(
                 dense, self.deviation_network.variance, o_g.to(torch.float32), d_g.to(torch.float32),
-                pl_g.to(torch.float32), mid_z, dists, vis, cue[:, 0, :].contiguous(), cos_anneal,
-                background_rgb.to(device) if background_rgb is not None else None)
+                pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
+                cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
+                background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type))
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],
-                                normalized_analytic_normals=core["normalized_analytic_normals"], visibilities=vis,
-                                specular_cue=cue)
+                                normalized_analytic_normals=core["normalized_analytic_normals"],
+                                visibilities=vis if self._hints else None, specular_cue=cue if self._hints else None)
         s_val = torch.full((1, 1), 1.0 / pk["inv_s"], dtype=torch.float32, device=device).expand(n, T)
         return RenderOutput(rgb=rgb, depth=depth, weights=weights, s_val=s_val, inside_sphere=inside,
                             relax_inside_sphere=inside, analytic_normals=normals,
-                            normalized_analytic_normals=nhat, visibilities=vis, specular_cue=cue)
+                            normalized_analytic_normals=nhat, visibilities=vis if self._hints else None,
+                            specular_cue=cue if self._hints else None)
 
     # ---------------------------------------------------------------------------------------------
     def _render_chunks(self, o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints, want_samples: bool,
@@ -244,7 +249,8 @@ class NeuSHintRenderer(nn.Module):
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
         net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
-                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"])
+                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
+                          self._hints, self._normal_type, self._depth_type)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))

@@ -98,6 +98,15 @@ def perturb_state(state: dict, seed: int = 42, sigma: float = 0.02, sigma_pe: fl
     return out
 
 
+def naive_state(state: dict) -> dict:
+    """State dict of the `pl-naive` model (no shadow / specular hints: reflectance input 316 instead of 361 wide,
+    configs/main_config.py:67-76) derived deterministically from a full state: the hint columns of the first
+    reflectance layer are dropped."""
+    out = {k: np.array(v, copy=True) for k, v in state.items()}
+    out["color_network.lin0.weight_v"] = out["color_network.lin0.weight_v"][:, :316].copy()
+    return out
+
+
 def psnr(a, b) -> float:
     """10*log10(1/MSE), data range 1 (utils/metrics.py:8-9 via torchmetrics)."""
     a = np.asarray(a, dtype=np.float64)

@@ -108,3 +108,35 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
     if scheduler is not None:
         scheduler.step()
     return {k: float(v.detach()) for k, v in losses.items()}
+
+
+# ---- checkpoints in the reference's layout (trainer/trainer.py:149-158, 173-236) ---------------------------------------
+def checkpoint_state(renderer: nn.Module, optimizer, scheduler, global_step: int, world_size: int = 1,
+                     extra_pipeline_state: Optional[Dict[str, torch.Tensor]] = None) -> Dict:
+    """``model_states`` dict as the reference pickles it: the renderer's tensors live under the ``renderer.`` prefix of
+    the pipeline state dict (``ray_generator.*`` entries can be passed through ``extra_pipeline_state``)."""
+    pipeline = {"renderer." + k: v for k, v in renderer.state_dict().items()}
+    if extra_pipeline_state:
+        pipeline.update(extra_pipeline_state)
+    return {"world_size": world_size, "global_step": global_step, "pipeline": pipeline,
+            "optimizer": optimizer.state_dict() if optimizer is not None else None,
+            "scheduler": scheduler.state_dict() if scheduler is not None else None}
+
+
+def save_checkpoint(path: str, renderer, optimizer, scheduler, global_step: int, world_size: int = 1, **kw) -> None:
+    torch.save(checkpoint_state(renderer, optimizer, scheduler, global_step, world_size, **kw), path)
+
+
+def load_checkpoint(path_or_state, renderer, optimizer=None, scheduler=None, map_location="cpu") -> int:
+    """Load a checkpoint written by ``save_checkpoint`` OR by the reference trainer (released ``*_step_1000000.ckpt``):
+    picks the ``renderer.*`` entries of ``model_states['pipeline']``.  Returns the stored global step."""
+    st = torch.load(path_or_state, map_location=map_location, weights_only=False) if isinstance(path_or_state, str) \
+        else path_or_state
+    pipe = st["pipeline"]
+    sd = {k[len("renderer."):]: v for k, v in pipe.items() if k.startswith("renderer.")}
+    renderer.load_state_dict(sd)
+    if optimizer is not None and st.get("optimizer") is not None:
+        optimizer.load_state_dict(st["optimizer"])
+    if scheduler is not None and st.get("scheduler") is not None:
+        scheduler.load_state_dict(st["scheduler"])
+    return int(st.get("global_step", 0))

@@ -149,11 +149,13 @@ def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: boo
     return sdf, feat, dx3 * 3.0
 
 
-def color_forward(p: OracleParams, pts, normals, view, feat, pls, vis, cue) -> torch.Tensor:
+def color_forward(p: OracleParams, pts, normals, view, feat, pls, vis=None, cue=None) -> torch.Tensor:
     """Reflectance MLP, input order [pts, enc4(view), normals, enc4(pl), feat, enc4(vis), enc4(cue)]
-    (fields/reflectance_network.py:68-96)."""
-    x = torch.cat([pts, nerf_encode(view, 4), normals, nerf_encode(pls, 4), feat,
-                   nerf_encode(vis, 4), nerf_encode(cue, 4)], dim=-1)
+    (fields/reflectance_network.py:68-96); vis / cue are absent for the pl-naive model (:83-86)."""
+    parts = [pts, nerf_encode(view, 4), normals, nerf_encode(pls, 4), feat]
+    if vis is not None:
+        parts += [nerf_encode(vis, 4), nerf_encode(cue, 4)]
+    x = torch.cat(parts, dim=-1)
     for l in range(5):
         x = F.linear(x, p.col_w[l], p.col_b[l])
         if l < 4:
@@ -312,7 +314,8 @@ def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is_training=False,
                    global_step=0, anneal_end=50_000, t_rand_primary=None, t_rand_shadow=None,
-                   mode="minimal", keep_intermediates=False, differentiable=False) -> Dict[str, torch.Tensor]:
+                   mode="minimal", keep_intermediates=False, differentiable=False, hints=True,
+                   analytic_normal=False, depth_max_weight=False) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651)."""
     n = o.shape[0]
@@ -343,16 +346,22 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     weights = alpha * excl_cumprod_one_minus(alpha)            # :521-523
     wsum = weights.sum(-1, keepdim=True)
     with torch.no_grad():
-        depth = (mid * weights).sum(-1, keepdim=True)          # :531-533 (no_grad)
+        if depth_max_weight:                                   # DepthComputationType.MaximalWeightPoint (:534-538)
+            depth = torch.gather(mid, 1, torch.argmax(weights, dim=1, keepdim=True))
+        else:
+            depth = (mid * weights).sum(-1, keepdim=True)      # :531-533 (no_grad)
         hit = o + d * depth
-        vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode)  # :546-551, :379
+        vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode) \
+            if hints else None                                 # :546-551, :379
     n_hat = F.normalize(grad, dim=-1)                          # :584
     hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
-    with torch.no_grad():
-        cue = specular_cue(hit_n, pl, hit, d)                  # :589-615 (no_grad)
-    vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
-    cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
-    col = color_forward(p, pts, n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :626
+    vis_s = cue_s = None
+    if hints:
+        with torch.no_grad():
+            cue = specular_cue(hit_n, pl, hit, d)              # :589-615 (no_grad)
+        vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
+        cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
+    col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :621-626
     rgb = (col * weights[..., None]).sum(1)
     if background_rgb is not None:
         rgb = rgb + background_rgb * (1.0 - wsum)              # :635-637
@@ -360,7 +369,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                inside_sphere=inside, relax_inside_sphere=inside,            # :745 (quirk kept)
                analytic_normals=grad.reshape(n, 128, 3),
                normalized_analytic_normals=n_hat.reshape(n, 128, 3),
-               visibilities=vis, specular_cue=cue_s.reshape(n, 128, 4))
+               visibilities=vis, specular_cue=cue_s.reshape(n, 128, 4) if hints else None)
     if keep_intermediates:
         out.update(z_vals=z, mid_z=mid, sdf=sdf.reshape(n, 128), alpha=alpha, hit=hit, hit_normal=hit_n,
                    sampled_color=col, feat=feat)
@@ -372,7 +381,7 @@ def render_chunked(p, o, d, pl, near, far, chunk=512, **kw):
     pipelines/base_pipeline.py:110-120)."""
     outs = [render_forward(p, o[i:i + chunk], d[i:i + chunk], pl[i:i + chunk], near[i:i + chunk],
                            far[i:i + chunk], **kw) for i in range(0, o.shape[0], chunk)]
-    return {k: torch.cat([x[k] for x in outs], dim=0) for k in outs[0]}
+    return {k: (torch.cat([x[k] for x in outs], dim=0) if outs[0][k] is not None else None) for k in outs[0]}
 
 
 def train_loss(out, rgb_gt, igr_weight=0.1):

@@ -37,7 +37,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 103
+    assert lib.nrh_version() >= 104
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
@@ -379,3 +379,40 @@ def test_training_loop_descends():
     assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[1], losses
     moved = [k for k, v in student.named_parameters() if not torch.equal(v.detach(), before[k])]
     assert len(moved) == 46, len(moved)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_off_default_branches(scene_states, prec):
+    """pl-naive preset (no hints), Analytic normals, MaximalWeightPoint depth vs the imported reference
+    (tests/golden/render_variants_b.npz), eval and one training-gradient smoke for the pl-naive model."""
+    from nrhints_amd.synthetic import naive_state
+    g = load_npz("render_variants_b.npz")
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    R = na.NeuSRendererConfig
+    cfgs = {"pln": (R(shadow_hint=False, specular_hint=False), naive_state(scene_states["b"])),
+            "ana": (R(normal_type=na.NormalComputationType.Analytic), scene_states["b"]),
+            "mwp": (R(depth_type=na.DepthComputationType.MaximalWeightPoint), scene_states["b"])}
+    for vt, (rcfg, st) in cfgs.items():
+        model = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=rcfg), precision=prec)
+        model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+        model = model.cuda().eval()
+        with torch.no_grad():
+            out = model(rb, background_rgb=torch.ones(1, 3).cuda())
+        np.testing.assert_allclose(out.rgb.cpu().numpy(), g[f"{vt}.rgb"], rtol=0, atol=1e-4)
+        assert psnr(out.rgb.cpu().numpy(), g[f"{vt}.rgb"]) > 80.0
+        np.testing.assert_allclose(out.depth.cpu().numpy(), g[f"{vt}.depth"], rtol=0, atol=3e-4 if vt != "mwp" else 2e-2)
+        if vt == "mwp":   # argmax can legitimately flip between two near-equal weights: judged on the bulk
+            assert np.mean(np.abs(out.depth.cpu().numpy() - g["mwp.depth"]) > 3e-4) < 0.05
+        d = np.abs(out.weights.cpu().numpy() - g[f"{vt}.weights"])
+        assert d.mean() < 3e-5
+        if vt == "pln":
+            assert out.visibilities is None and out.specular_cue is None
+        else:
+            np.testing.assert_allclose(out.visibilities.cpu().numpy(), g[f"{vt}.visibilities"], rtol=0, atol=3e-3)
+    # gradients flow through the pl-naive model too
+    model = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=cfgs["pln"][0]), precision=prec)
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in cfgs["pln"][1].items()})
+    model = model.cuda()
+    out = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=1000)
+    out.rgb.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 103
+    assert lib.nrh_version() == 104
     sizes = (ctypes.c_int * 8)()
     assert lib.nrh_param_sizes(sizes) == 0
     assert sizes[7] in (4, 8)
@@ -54,10 +54,10 @@ def test_unsupported_configs_are_rejected():
     bad = [
         na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=64)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True)),
-        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=True, specular_hint=False)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(force_shadow_map=True)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=8)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.SphereTracing)),
-        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(normal_type=na.NormalComputationType.Analytic)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_importance_samples=32)),
     ]
     for cfg in bad:
@@ -65,6 +65,11 @@ def test_unsupported_configs_are_rejected():
         with pytest.raises(ValueError):
             na.NeuSHintRenderer(cfg)
     assert na.unsupported_reason(na.NeuSModelConfig()) is None
+    # the pl-naive preset and the cheap off-default branches are supported
+    naive = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False)))
+    assert naive.color_network.lin0.weight_v.shape == (256, 316) and sum(p.numel() for p in naive.parameters()) == 820_923 - 256 * 45
+    na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(normal_type=na.NormalComputationType.Analytic)))
+    na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.MaximalWeightPoint)))
 
 
 def test_no_cpu_fallback():

@@ -158,3 +158,20 @@ def test_training_gradients(scene_states):
             want = g["grad.rays." + nm]
             scale = max(np.abs(want).max(), 1e-8)
             assert np.abs(r.grad.numpy() - want).max() / scale < 2e-3, (tag, nm)
+
+
+def test_off_default_branches(scene_states):
+    """pl-naive (no hints), Analytic normals into the reflectance net, MaximalWeightPoint depth - vs the reference."""
+    from nrhints_amd.synthetic import naive_state
+    g = load_npz("render_variants_b.npz")
+    rays = [T(g[k]) for k in ("o", "d", "pl", "near", "far")]
+    kw = {"pln": dict(hints=False), "ana": dict(analytic_normal=True), "mwp": dict(depth_max_weight=True)}
+    for vt, opts in kw.items():
+        st = naive_state(scene_states["b"]) if vt == "pln" else scene_states["b"]
+        out = orc.render_forward(orc.params_from_state(st), *rays, background_rgb=torch.ones(1, 3), mode="as_written", **opts)
+        np.testing.assert_allclose(out["rgb"].numpy(), g[f"{vt}.rgb"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(out["depth"].numpy(), g[f"{vt}.depth"], rtol=0, atol=2e-4)
+        if vt == "pln":
+            assert out["visibilities"] is None and out["specular_cue"] is None and "pln.visibilities" not in g
+        else:
+            np.testing.assert_allclose(out["visibilities"].numpy(), g[f"{vt}.visibilities"], rtol=0, atol=2e-3)

@@ -82,3 +82,21 @@ def test_flat_grad_allreduce_two_ranks(tmp_path):
     total.backward()
     ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
     np.testing.assert_allclose(g0, ref, rtol=1e-5, atol=1e-7)
+
+
+def test_checkpoint_roundtrip_reference_layout(tmp_path, scene_states):
+    from nrhints_amd.training import load_checkpoint, save_checkpoint
+    m = na.NeuSHintRenderer()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in scene_states["b"].items()})
+    opt, sched = make_optimizer(m)
+    p = str(tmp_path / "step_0000123.ckpt")
+    save_checkpoint(p, m, opt, sched, global_step=123, world_size=2,
+                    extra_pipeline_state={"ray_generator.cam_pose_adjustment": torch.zeros(10, 6)})
+    raw = torch.load(p, weights_only=False)
+    assert set(raw) == {"world_size", "global_step", "pipeline", "optimizer", "scheduler"}
+    assert "renderer.sdf_network.lin0.weight_g" in raw["pipeline"] and len(raw["pipeline"]) == 47  # SURVEY §5 key contract
+    m2 = na.NeuSHintRenderer()
+    opt2, sched2 = make_optimizer(m2)
+    assert load_checkpoint(p, m2, opt2, sched2) == 123
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
