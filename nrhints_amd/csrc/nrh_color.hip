@@ -114,7 +114,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
         h.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
       };
-      run_stage<PREC, MKB, 8, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1, MKB), 32, smem, par, misc, part, pre, epi, wave, lane);
+      run_stage<PREC, MKB, 8, true, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1, MKB), 32, smem, par, misc, part, pre, epi, wave, lane);
     }
     // ---- C1..C3 ----
     for (int l = 1; l <= 3; ++l) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
         ho.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
       };
       const float* wn = (l < 3) ? a.w + col_off_C(l + 1, MKB) : a.w + col_off_C4(MKB);
-      run_stage<PREC, 16, 8, false>(a.w + col_off_C(l, MKB), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 16, 8, false, true>(a.w + col_off_C(l, MKB), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
       h = ho;
     }
     // ---- C4: 3 output rows (block 0, lanes q == 0 hold r = 0..2) + sigmoid ----

@@ -41,6 +41,9 @@ constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
 #ifndef NRH_ABL
 #define NRH_ABL 0             // bit 0: no LDS-DMA, 1: no barrier, 2: no MFMA, 3: no ds_read of A (f16x3), 4: trivial epilogue
 #endif
+#ifndef NRH_RAW_BARRIER
+#define NRH_RAW_BARRIER 0     // chunk barrier without vmcnt(0) (stores stay in flight): measured +3 % / -6 % (kbench7) -> off
+#endif
 constexpr int WG_WAVES = NRH_WG_WAVES;
 constexpr int MLP_THREADS = 64 * WG_WAVES;  // one 16-point tile per wave
 constexpr int TILE_PTS = 16;
@@ -148,7 +151,23 @@ struct Act<1, KB> {
 // LDS image of a chunk (both precisions 2*KB KiB):
 //   PREC 0: [obi 2][kb KB][lane 64] float4           - A of 4 consecutive 16x16x4 MFMAs
 //   PREC 1: [obi 2][s KB/2][hi|lo][lane 64] 8 x fp16 - A of one 16x16x32 MFMA (hi) / its low part
-template <int PREC, int KB, int NCH, bool HAS_INIT, typename Pre, typename Epi>
+// End-of-chunk barrier.  __syncthreads() drains vmcnt(0), i.e. it also waits for the acknowledgement of the stores the
+// epilogue just issued (sigma' scratch, feature tiles).  When the stage's pre() hook issued a global load AFTER the
+// LDS-DMA of the next chunk and the epilogue consumed it, that consumption already implied vmcnt <= (ops younger than
+// the load) - the in-order counter guarantees the DMA landed - so a bare s_barrier (+ lgkmcnt for the LDS reads) is
+// enough and the stores stay in flight.  Stages without such a load must use the draining form.
+template <bool PRE_LOADS>
+__device__ __forceinline__ void chunk_barrier() {
+#if NRH_RAW_BARRIER
+  if constexpr (PRE_LOADS) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return;
+  }
+#endif
+  __syncthreads();
+}
+
+template <int PREC, int KB, int NCH, bool HAS_INIT, bool PRE_LOADS = false, typename Pre, typename Epi>
 __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const float* __restrict__ wnext,
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
                                           const float* init, Pre&& pre, Epi&& epi, int wave, int lane) {
@@ -161,6 +180,7 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     } else if (wnext != nullptr) {
       dma_chunk(wnext, nxt, next_pieces, wave, lane);
     }
+    asm volatile("" ::: "memory");  // keep pre()'s loads younger than the DMA in the vmcnt order
     const auto pv = pre(ch);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (HAS_INIT) {
@@ -240,7 +260,7 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
       acc1 += c1 * LO_UNSCALE;
     }
     epi(ch, acc0, acc1, pv);
-    if (!(NRH_ABL & 2)) __syncthreads();  // waits this wave's LDS-DMA (vmcnt(0)) and orders the buffer swap
+    if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();  // the next chunk's weights are in LDS for every wave past this point
     par ^= 1;
   }
 }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         h.set_chunk(ch, h0, h1);
         if (MODE >= 1) dsig_store<PREC>(scr, 0, ch, lane, d0, d1);
       };
-      run_stage<PREC, 4, 8, false>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 4, 8, false, true>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, pre, epi, wave, lane);
     }
 
     // ---- steps 1..15: L1..L7, FEAT, R7..R1 share one 256x256 body ----
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
 
       if (MODE >= 1 && s == 9) {
         // start of the reverse chain: t_7 = sigma'_7 * (w_s / 3), written by L7's epilogue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own t_7 stores (the chunk barrier no longer drains)
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
           const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)));
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
           }
         }
       };
-      run_stage<PREC, 16, 8, false>(wcur, wnxt, npc, smem, par, h, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 16, 8, false, true>(wcur, wnxt, npc, smem, par, h, nullptr, pre, epi, wave, lane);
 
       if (s == 7) {
         // sdf head: (w_s . h8 + b_s) / scale   (fields/sdf_field.py:121)
