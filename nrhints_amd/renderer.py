@@ -104,6 +104,9 @@ class NeuSHintRenderer(nn.Module):
     #: matrix arithmetic of the MLP kernels: "f32" (v_mfma_f32_16x16x4_f32, exact fp32) or "f16x3" (three
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
     precision = "f16x3"
+    # backward of (sdf, feat, d sdf/dx): "manual" = hand-derived sweeps in torch ops, "hip" = the same sweeps in the HIP
+    # register-chain kernels (forward included), "autograd" = second-order autograd graph like the reference (A/B only)
+    sdf_backward = "manual"
 
     def __init__(self, config: NeuSModelConfig = None, precision: Optional[str] = None):
         super().__init__()
@@ -225,7 +228,8 @@ class NeuSHintRenderer(nn.Module):
                 dense, self.deviation_network.variance, o_g.to(torch.float32), d_g.to(torch.float32),
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
-                background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type))
+                background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
+                sdf_impl=self.sdf_backward)
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],

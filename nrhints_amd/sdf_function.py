@@ -1,0 +1,164 @@
+"""``SdfValueFeatGrad`` - a torch.autograd.Function for (sdf, feature, d sdf/dx) of the SDF network with a HAND-DERIVED
+backward, so that the training step needs no second-order autograd graph.
+
+Why: the loss reaches the network through three outputs - the value (alpha), the feature (colour net) and the spatial
+gradient g = d sdf/dx (alpha's cosine, the unit normal fed to the colour net, the eikonal term).  The reference obtains
+g with ``autograd.grad(create_graph=True)`` and lets autograd differentiate that graph again
+(fields/sdf_field.py:136-148, pipelines/base_pipeline.py:59-62).  Here the second-order part is written out:
+
+    <g_bar, g> is a JVP of the network in direction g_bar, so its parameter gradient is obtained by
+      * one FORWARD-direction sweep of "tangent adjoints"   tbar_l = W_l abar_l,   abar_{l+1} = s'_l * tbar_l
+      * one REVERSE sweep of value adjoints with a coupling term   zbar_l = s'_l * hbar_l + s''_l * a_{l+1} * tbar_l
+      * two plain GEMMs per layer for the weights:   dW_l = zbar_l^T x_l + t_l^T abar_l        (t_l = s'_l * a_{l+1})
+
+with s' = sigmoid(100 z), s'' = 100 s'(1 - s'), a_l the reverse-chain values of the forward pass.  Everything is a
+chain of 256-wide GEMMs with elementwise epilogues - the structure of the HIP register-chain kernels - plus library
+GEMMs for dW.  This file is the reference implementation of that backward in torch ops (GEMMs on rocBLAS); the forward
+runs in the HIP kernel when the inputs are on the GPU (``use_hip=True``).  DESIGN.md §8 tracks moving the two sweeps
+into HIP as well.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+N_LAYERS = 8
+SKIP = 4
+EMB = 39
+
+
+def _enc_parts(x3: torch.Tensor):
+    """Encoding entries e(x3) [P,39], first derivatives dc [P,39] and second derivatives d2c [P,39] w.r.t. the
+    coordinate each entry depends on; ``dim`` [39] says which coordinate that is (fields/encodings.py:168-174)."""
+    freqs = 2.0 ** torch.arange(6, dtype=x3.dtype, device=x3.device)
+    s = (x3[..., None] * freqs).reshape(x3.shape[0], -1)          # [P,18] d-major, k-minor
+    fr = freqs.repeat(3)                                            # [18]
+    sp = s + math.pi / 2.0
+    e = torch.cat([x3, torch.sin(s), torch.sin(sp)], dim=1)
+    dc = torch.cat([torch.ones_like(x3), torch.cos(s) * fr, torch.cos(sp) * fr], dim=1)
+    d2c = torch.cat([torch.zeros_like(x3), -torch.sin(s) * fr * fr, -torch.sin(sp) * fr * fr], dim=1)
+    dim = torch.cat([torch.arange(3), torch.arange(3).repeat_interleave(6), torch.arange(3).repeat_interleave(6)]).to(x3.device)
+    return e, dc, d2c, dim
+
+
+def _scatter_dims(v: torch.Tensor, dim: torch.Tensor) -> torch.Tensor:
+    """[P,39] -> [P,3]: sum the entries that depend on each coordinate."""
+    out = torch.zeros(v.shape[0], 3, dtype=v.dtype, device=v.device)
+    return out.index_add_(1, dim, v)
+
+
+class SdfValueFeatGrad(torch.autograd.Function):
+    """forward(pts [P,3], W0..W7, b0..b7, ws [1,256], bs [1], Wf [256,256], bf [256]) -> sdf [P,1], feat [P,256], g [P,3].
+    Weights are the dense (weight-norm-folded) matrices of ``packing.dense_params``; W4 is the UNSCALED layer-4 matrix."""
+
+    @staticmethod
+    def forward(ctx, pts, *params):
+        W: List[torch.Tensor] = list(params[0:8])
+        b: List[torch.Tensor] = list(params[8:16])
+        ws, bs, Wf, bf = params[16:20]
+        W = [w if l != SKIP else w / math.sqrt(2.0) for l, w in enumerate(W)]   # cat([h, e]) / sqrt(2) folded
+        x3 = pts * 3.0
+        e, dc, d2c, dim = _enc_parts(x3)
+        xs, s1 = [], []
+        x = e
+        for l in range(N_LAYERS):
+            if l == SKIP:
+                x = torch.cat([x, e], dim=1)
+            xs.append(x)
+            z = F.linear(x, W[l], b[l])
+            t = z * 100.0
+            ez = torch.exp(torch.clamp(t, max=80.0))
+            s1.append(torch.where(t > 20.0, torch.ones_like(t), ez / (ez + 1.0)))
+            x = F.softplus(z, beta=100)
+        h7 = x
+        sdf = F.linear(h7, ws, bs) / 3.0
+        feat = F.linear(h7, Wf, bf)
+        # reverse chain for g
+        a_next = (ws / 3.0).expand(pts.shape[0], -1)        # a_8
+        a_list = [None] * (N_LAYERS + 1)
+        a_list[N_LAYERS] = a_next
+        ge_skip = None
+        for l in range(N_LAYERS - 1, -1, -1):
+            a = (s1[l] * a_next) @ W[l]                       # a_l: gradient w.r.t. x_l
+            if l == SKIP:
+                ge_skip = a[:, 217:]
+                a_next = a[:, :217]
+            else:
+                a_next = a
+            a_list[l] = a_next                                # gradient w.r.t. h_{l-1} (or the embedding for l = 0)
+        ge = a_list[0] + ge_skip
+        g = 3.0 * _scatter_dims(ge * dc, dim)
+        ctx.save_for_backward(pts, *W, ws, Wf, *xs, *s1, *[a_list[l] for l in range(1, N_LAYERS + 1)], ge, dc, d2c, h7)
+        ctx.dim = dim
+        return sdf, feat, g
+
+    @staticmethod
+    def backward(ctx, sbar, fbar, gbar):
+        sv = ctx.saved_tensors
+        pts = sv[0]
+        W = list(sv[1:9])
+        ws, Wf = sv[9], sv[10]
+        xs = list(sv[11:19])
+        s1 = list(sv[19:27])
+        a_up = list(sv[27:35])          # a_up[l] = a_{l+1} restricted to h_l's width, l = 0..7
+        ge, dc, d2c, h7 = sv[35:39]
+        dim = ctx.dim
+        P = pts.shape[0]
+        sbar = torch.zeros(P, 1, dtype=pts.dtype, device=pts.device) if sbar is None else sbar
+        fbar = torch.zeros(P, 256, dtype=pts.dtype, device=pts.device) if fbar is None else fbar
+        gbar = torch.zeros(P, 3, dtype=pts.dtype, device=pts.device) if gbar is None else gbar
+
+        # ---- adjoint of g = 3 * sum_e ge[e] dc[e]: tangent adjoints run FORWARD through the layers ----
+        gb_e = gbar[:, dim]                                   # gbar of the coordinate each entry depends on
+        ge_bar = 3.0 * dc * gb_e                              # [P,39]
+        p3_bar = 3.0 * _scatter_dims(ge * d2c * gb_e, dim)    # through the encoding's second derivative
+        dW = [None] * N_LAYERS
+        coup = [None] * N_LAYERS
+        abar = ge_bar
+        ws_bar = torch.zeros_like(ws)
+        for l in range(N_LAYERS):
+            if l == SKIP:
+                abar = torch.cat([abar, ge_bar], dim=1)       # adjoint of a_4 = [a_4h, skip part]
+            tbar = abar @ W[l].t()                            # [P,out_l]
+            t_l = s1[l] * a_up[l]
+            dW[l] = t_l.t() @ abar                            # term 2 of dW_l
+            coup[l] = (100.0 * s1[l] * (1.0 - s1[l])) * a_up[l] * tbar
+            if l == N_LAYERS - 1:
+                ws_bar = ws_bar + (s1[l] * tbar).sum(0, keepdim=True) / 3.0
+            else:
+                abar = s1[l] * tbar                           # adjoint of a_{l+1} (h_l-wide)
+        # ---- value adjoints run in REVERSE ----
+        hbar = fbar @ Wf + sbar * (ws / 3.0)
+        Wf_bar = fbar.t() @ h7
+        bf_bar = fbar.sum(0)
+        ws_bar = ws_bar + (sbar * h7).sum(0, keepdim=True) / 3.0
+        bs_bar = sbar.sum(0).reshape(-1) / 3.0
+        db = [None] * N_LAYERS
+        e_skip_bar = None
+        for l in range(N_LAYERS - 1, -1, -1):
+            zbar = s1[l] * hbar + coup[l]
+            dW[l] = dW[l] + zbar.t() @ xs[l]
+            db[l] = zbar.sum(0)
+            xbar = zbar @ W[l]
+            if l == SKIP:
+                e_skip_bar = xbar[:, 217:]
+                hbar = xbar[:, :217]
+            else:
+                hbar = xbar
+        e_bar = hbar + e_skip_bar
+        p3_bar = p3_bar + _scatter_dims(e_bar * dc, dim)
+        dW[SKIP] = dW[SKIP] / math.sqrt(2.0)                  # back to the unscaled W4
+        return (p3_bar * 3.0, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
+
+
+def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, impl: str = "manual"):
+    """Convenience wrapper over the weight dict of ``packing.dense_params``.  ``impl``: "manual" = this file's torch
+    implementation of the sweeps."""
+    if impl != "manual":
+        raise ValueError(f"unknown sdf implementation {impl!r}")
+    args = [dense[f"sdf_w{l}"] for l in range(8)] + [dense[f"sdf_b{l}"] for l in range(8)] + \
+           [dense["sdf_head_w"], dense["sdf_head_b"], dense["feat_w"], dense["feat_b"]]
+    return SdfValueFeatGrad.apply(pts, *args)

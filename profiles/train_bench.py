@@ -16,6 +16,8 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     torch.manual_seed(0)
     student = na.NeuSHintRenderer().cuda()
+    if len(sys.argv) > 3:
+        student.sdf_backward = sys.argv[3]          # manual | hip | autograd
     teacher = na.NeuSHintRenderer()
     st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in student.state_dict().items()})
     teacher.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
@@ -37,7 +39,7 @@ def main():
     print(json.dumps({"metric": "training ray-steps/s (fwd+bwd+Adam, incl. teacher render)", "batch": batch, "steps": steps,
                       "value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2),
                       "loss_first3": [round(x, 5) for x in losses[:3]], "loss_last3": [round(x, 5) for x in losses[-3:]],
-                      "precision": student.precision}))
+                      "precision": student.precision, "sdf_backward": student.sdf_backward}))
 
 if __name__ == "__main__":
     main()

@@ -100,3 +100,33 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path, scene_states):
     assert load_checkpoint(p, m2, opt2, sched2) == 123
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_sdf_function_manual_backward_matches_second_order_autograd(scene_states):
+    """sdf_function.SdfValueFeatGrad (hand-derived tangent/adjoint sweeps) against the oracle's create_graph autograd
+    (the reference's formulation, fields/sdf_field.py:136-148) in fp64: gradients w.r.t. the points and all 40 raw
+    SDF-network parameters through value, feature, d sdf/dx and an eikonal term."""
+    import numpy as np
+    from nrhints_amd import packing
+    from nrhints_amd.sdf_function import sdf_value_feat_grad
+    from oracle import neus_oracle as O
+    torch.manual_seed(0)
+    state = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in scene_states["b"].items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in state.items() if k.startswith("sdf_network")}
+    pts = (torch.rand(40, 3, dtype=torch.float64) * 1.2 - 0.6)
+    cs, cf, cg = (torch.randn(40, k, dtype=torch.float64) for k in (1, 256, 3))
+
+    def loss_of(sdf, feat, g):
+        return (sdf * cs).sum() + (feat * cf).sum() + (g * cg).sum() + ((g.norm(dim=-1) - 1) ** 2).sum()
+
+    p1 = pts.clone().requires_grad_(True)
+    l1 = loss_of(*sdf_value_feat_grad(packing.dense_params({**state, **leaves}), p1))
+    g1 = torch.autograd.grad(l1, [p1] + list(leaves.values()))
+    P = O.params_from_state({**state, **leaves}, dtype=torch.float64)
+    p2 = pts.clone().requires_grad_(True)
+    sdf2, feat2 = O.sdf_forward(P, p2)
+    l2 = loss_of(sdf2, feat2, O.sdf_gradient_autograd(P, p2, create_graph=True))
+    g2 = torch.autograd.grad(l2, [p2] + list(leaves.values()))
+    assert abs(l1.item() - l2.item()) < 1e-10 * max(1.0, abs(l2.item()))
+    for name, a, b in zip(["pts"] + list(leaves), g1, g2):
+        assert (a - b).abs().max().item() <= 1e-10 * (b.abs().max().item() + 1e-30), name
