@@ -66,6 +66,33 @@ int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b
                  const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                  int sdf_stride, float* grad, float* feat, float* scratch, void* stream);
 
+/* ---- SDF network, training --------------------------------------------------------------------------------
+ * The reference differentiates d(sdf)/dp a second time with autograd (create_graph=True, fields/sdf_field.py:145;
+ * loss.backward(), pipelines/base_pipeline.py:59-62).  Here that second-order backward is two more register-chain
+ * sweeps over arrays the training forward saves (maths: nrhints_amd/sdf_function.py), and the weight gradients are
+ * plain GEMMs over the saved row-major arrays, done by the caller (rocBLAS):
+ *     dW_l = zbar[l]^T x_l + save_t[l]^T abar_in_l ,  db_l = colsum zbar[l]
+ *     x_0 = embedding, x_l = save_h[l-1];   abar_in_0 = gebar, abar_in_l = abar[l-1];   d w_s += colsum abar[7] / 3
+ * All [.][npts][256] arrays are row-major fp32; npts = nrays * n_per_ray must be a multiple of 16.
+ *
+ * nrh_sdf_train_forward: as nrh_sdf_eval mode 2 (sdf [npts], grad [npts,3]) with the feature ROW-MAJOR feat_rows
+ *   [npts,256], plus  save_h [8][npts][256] (softplus outputs; layer 3 already holds the skip concatenation),
+ *   save_s1 [8][npts][256] (sigmoid(100 z)), save_t [8][npts][256] (reverse-chain stage inputs),
+ *   save_ge [npts][128] (cols 0..38: d sdf/d embedding via layer 0; cols 73..111: via the skip connection).
+ * nrh_sdf_train_backward: given the adjoints  sbar [npts], fbar [npts,256], gbar [npts,3]  of the three outputs
+ *   writes  abar, coup, zbar [8][npts][256], gebar [npts][64] and pbar [npts,3] (adjoint of the points through the
+ *   value path; the caller adds the term through the encoding's second derivative, see sdf_function.py).
+ *   wt_feat: the feature head transposed, packed as one 256x256 stage (packing.pack_feat_transposed). */
+int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                          const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                          float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
+                          void* stream);
+int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
+                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
+                           const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
+                           const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
+                           void* stream);
+
 /* ---- hierarchical sampler (one launch = merge the previous 16 samples and/or draw 16 new ones) ------------
  * NeuSHintRenderer.up_sample (models/neus_hint_model.py:270-315) + sample_pdf (:21-65, det=True) +
  * cat_z_vals (:317-331) + section mid-points (:491-496, :416-418).

@@ -1,6 +1,7 @@
 // C ABI of libnrhints_hip.so (declared in include/nrhints_hip.h).  Single translation unit: the kernel sources
 // are included here so one hipcc invocation builds the whole library for gfx950.
 #include "nrh_sdf.hip"
+#include "nrh_sdf_train.hip"
 #include "nrh_color.hip"
 #include "nrh_rays.hip"
 
@@ -52,6 +53,9 @@ int ensure_attrs() {
   hipError_t e;
   const void* fns[] = {(const void*)nrh::sdf_kernel<0, 0>, (const void*)nrh::sdf_kernel<1, 0>, (const void*)nrh::sdf_kernel<2, 0>,
                        (const void*)nrh::sdf_kernel<0, 1>, (const void*)nrh::sdf_kernel<1, 1>, (const void*)nrh::sdf_kernel<2, 1>,
+                       (const void*)nrh::sdf_kernel<3, 0>, (const void*)nrh::sdf_kernel<3, 1>,
+                       (const void*)nrh::sdf_tangent_kernel<0>, (const void*)nrh::sdf_tangent_kernel<1>,
+                       (const void*)nrh::sdf_adjoint_kernel<0>, (const void*)nrh::sdf_adjoint_kernel<1>,
                        (const void*)nrh::color_kernel<0, 8>, (const void*)nrh::color_kernel<1, 8>,
                        (const void*)nrh::color_kernel<0, 4>, (const void*)nrh::color_kernel<1, 4>};
   e = hipSuccess;
@@ -120,6 +124,16 @@ int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const floa
   }
   timing_end(st, tl, timed);
   return check_launch("sdf_kernel");
+}
+
+// launch geometry shared by the per-point MLP kernels
+int mlp_launch_geometry(long long npts, int& groups_out, int& grid_out, const char* who) {
+  const long long groups = (npts + 16 * nrh::WG_WAVES - 1) / (16 * nrh::WG_WAVES);
+  if (groups > 0x7fffffffLL) return fail(NRH_E_INVALID, "%s: too many points", who);
+  groups_out = (int)groups;
+  grid_out = (int)(groups < mlp_grid() ? groups : mlp_grid());
+  if (grid_out <= 0) return fail(NRH_E_LAUNCH, "no HIP device%s", "");
+  return NRH_OK;
 }
 
 int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
@@ -194,7 +208,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 104; }
+int nrh_version(void) { return 105; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -243,6 +257,67 @@ int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b
                  int sdf_stride, float* grad, float* feat, float* scratch, void* stream) {
   return sdf_eval_impl(precision, mode, sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat,
                        scratch, (hipStream_t)stream);
+}
+
+int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                          const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                          float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
+                          void* stream) {
+  if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!sdf_w || !sdf_b || !sdf_head || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_s1 || !save_t || !save_ge)
+    return fail(NRH_E_INVALID, "nrh_sdf_train_forward: null pointer%s", "");
+  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: bad n_per_ray/stride%s", "");
+  if ((nrays * n_per_ray) % 16 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: the number of points must be a multiple of 16%s", "");
+  if (nrays == 0) return NRH_OK;
+  int rc = ensure_attrs();
+  if (rc) return rc;
+  nrh::SdfArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w = sdf_w; a.b = sdf_b; a.head = sdf_head; a.ro = ro; a.rd = rd; a.t = t; a.sdf = sdf; a.grad = grad; a.feat = feat_rows;
+  a.save_h = save_h; a.save_s1 = save_s1; a.save_t = save_t; a.save_ge = save_ge;
+  a.npts = nrays * n_per_ray;
+  a.n_per_ray = n_per_ray; a.t_stride = t_stride; a.sdf_stride = n_per_ray;
+  int grid = 0;
+  rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_sdf_train_forward");
+  if (rc) return rc;
+  const hipStream_t st = (hipStream_t)stream;
+  if (precision == 0) hipLaunchKernelGGL((nrh::sdf_kernel<3, 0>), dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((nrh::sdf_kernel<3, 1>), dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
+  return check_launch("sdf_kernel<3>");
+}
+
+int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
+                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
+                           const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
+                           const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
+                           void* stream) {
+  if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!sdf_w || !wt_feat || !sdf_head || !ro || !rd || !t || !save_s1 || !save_t || !gbar || !fbar || !sbar || !abar || !coup ||
+      !gebar || !zbar || !pbar)
+    return fail(NRH_E_INVALID, "nrh_sdf_train_backward: null pointer%s", "");
+  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: bad n_per_ray/stride%s", "");
+  if ((nrays * n_per_ray) % 16 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: the number of points must be a multiple of 16%s", "");
+  if (nrays == 0) return NRH_OK;
+  int rc = ensure_attrs();
+  if (rc) return rc;
+  nrh::SdfTrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w = sdf_w; a.wt_feat = wt_feat; a.head = sdf_head; a.ro = ro; a.rd = rd; a.t = t; a.s1 = save_s1; a.tt = save_t;
+  a.gbar = gbar; a.abar = abar; a.coup = coup; a.gebar = gebar; a.fbar = fbar; a.sbar = sbar; a.zbar = zbar; a.pbar = pbar;
+  a.npts = nrays * n_per_ray;
+  a.n_per_ray = n_per_ray; a.t_stride = t_stride;
+  int grid = 0;
+  rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_sdf_train_backward");
+  if (rc) return rc;
+  const hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid), blk(nrh::MLP_THREADS);
+  if (precision == 0) hipLaunchKernelGGL((nrh::sdf_tangent_kernel<0>), g, blk, nrh::MLP_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((nrh::sdf_tangent_kernel<1>), g, blk, nrh::MLP_LDS_BYTES, st, a);
+  rc = check_launch("sdf_tangent_kernel");
+  if (rc) return rc;
+  if (precision == 0) hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<0>), g, blk, nrh::MLP_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<1>), g, blk, nrh::MLP_LDS_BYTES, st, a);
+  return check_launch("sdf_adjoint_kernel");
 }
 
 int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const float* znew_in,

@@ -31,8 +31,13 @@ struct SdfArgs {
   const float* t;      // ray parameter of point (ray, j): t[ray * t_stride + j]
   float* sdf;          // sdf[ray * sdf_stride + j]
   float* grad;         // [npts,3] (MODE >= 1)
-  float* feat;         // [ntiles][16][64][4] D-layout tiles (MODE 2)
-  float* scratch;      // gridDim.x * WG_WAVES * SDF_SCRATCH_FLOATS_PER_WAVE (MODE >= 1)
+  float* feat;         // [ntiles][16][64][4] D-layout tiles (MODE 2) / row-major [npts][256] (MODE 3)
+  float* scratch;      // gridDim.x * WG_WAVES * SDF_SCRATCH_FLOATS_PER_WAVE (MODE 1, 2)
+  // MODE 3 (training forward): what the hand-derived backward needs, row-major so that library GEMMs can read it
+  float* save_h;       // [8][npts][256]  h_l = softplus(z_l) (layer 3: after the skip substitution, i.e. x_4)
+  float* save_s1;      // [8][npts][256]  sigma'_l = sigmoid(100 z_l) (0 on substituted entries); replaces the scratch
+  float* save_t;       // [8][npts][256]  t_l = sigma'_l * a_{l+1}, the reverse-chain stage inputs (t_7 = sigma'_7 w_s/3)
+  float* save_ge;      // [npts][128]     cols 0..63 a_0 (39 used), cols 64..111 = a_4[208..255] (skip part from col 73)
   long long npts;
   int n_per_ray;
   int t_stride;
@@ -89,6 +94,15 @@ __device__ __forceinline__ float* t7_ptr(float* scr, int blk, int lane) {
   return scr + ((PREC == 0) ? 7 * 16 * 256 : 7 * 2048) + (blk * 64 + lane) * 4;
 }
 
+// the lane's 4 consecutive features (block blk) of its point in a row-major [layer][npts][256] training array
+__device__ __forceinline__ float* rm_ptr(float* base, int l, long long npts, long long row, int blk, int q) {
+  return base + ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * q;
+}
+__device__ __forceinline__ const float* rm_ptr(const float* base, int l, long long npts, long long row, int blk, int q) {
+  return base + ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * q;
+}
+
+// MODE 0: sdf | 1: sdf + gradient | 2: + feature tiles (inference render) | 3: training forward (= 2 with row-major saves)
 template <int MODE, int PREC>
 __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,7 +110,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   int par = 0;
-  float* const scr = (MODE >= 1) ? a.scratch + (size_t)(blockIdx.x * WG_WAVES + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
+  constexpr bool TRAIN = MODE == 3;
+  float* const scr = (MODE == 1 || MODE == 2) ? a.scratch + (size_t)(blockIdx.x * WG_WAVES + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
   constexpr bool WANT_D = MODE >= 1;
 
   dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
@@ -110,6 +125,25 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     const long long ray = Pc / a.n_per_ray;
     const int jj = (int)(Pc - ray * a.n_per_ray);
     const float tt = a.t[ray * a.t_stride + jj];
+    // training saves: whole tiles only (npts % 16 == 0 is checked by the host); tiles past the end write nothing
+    const bool tile_ok = tile * TILE_PTS < a.npts;
+    const long long row = tile_ok ? tile * TILE_PTS + j : j;
+    auto ds_store = [&](int l, int ch, const f32x4 d0, const f32x4 d1) {
+      if constexpr (TRAIN) {
+        if (tile_ok) {
+          st_stream(reinterpret_cast<f32x4*>(rm_ptr(a.save_s1, l, a.npts, row, 2 * ch, q)), d0);
+          st_stream(reinterpret_cast<f32x4*>(rm_ptr(a.save_s1, l, a.npts, row, 2 * ch + 1, q)), d1);
+        }
+      } else {
+        dsig_store<PREC>(scr, l, ch, lane, d0, d1);
+      }
+    };
+    auto save_rows = [&](float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
+      if (tile_ok) {
+        st_stream(reinterpret_cast<f32x4*>(rm_ptr(base, l, a.npts, row, 2 * ch, q)), v0);
+        st_stream(reinterpret_cast<f32x4*>(rm_ptr(base, l, a.npts, row, 2 * ch + 1, q)), v1);
+      }
+    };
     float x3[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt) * 3.0f;  // inputs * scale
@@ -140,7 +174,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         softplus100_4<WANT_D>(acc0 + p.a0, h0, d0);
         softplus100_4<WANT_D>(acc1 + p.a1, h1, d1);
         h.set_chunk(ch, h0, h1);
-        if (MODE >= 1) dsig_store<PREC>(scr, 0, ch, lane, d0, d1);
+        if (MODE >= 1) ds_store(0, ch, d0, d1);
+        if constexpr (TRAIN) save_rows(a.save_h, 0, ch, h0, h1);
       };
       run_stage<PREC, 4, 8, false, true>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, pre, epi, wave, lane);
     }
@@ -174,8 +209,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own t_7 stores (the chunk barrier no longer drains)
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
-          const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)));
-          const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)));
+          f32x4 v0, v1;
+          if constexpr (TRAIN) {
+            v0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_t, 7, a.npts, row, 2 * ch, q)));
+            v1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_t, 7, a.npts, row, 2 * ch + 1, q)));
+          } else {
+            v0 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)));
+            v1 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)));
+          }
           h.set_chunk(ch, v0, v1);
         }
       }
@@ -191,7 +232,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             p.b1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
           }
         } else if (MODE >= 1) {
-          dsig_issue<PREC>(scr, 16 - s - 1, ch, lane, p);  // sigma' of the layer this stage's output feeds
+          // sigma' of the layer this stage's output feeds
+          if constexpr (TRAIN) {
+            p.a0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch, q)));
+            p.a1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch + 1, q)));
+          } else {
+            dsig_issue<PREC>(scr, 16 - s - 1, ch, lane, p);
+          }
         }
         return p;
       };
@@ -221,16 +268,22 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
               head_part += p.b0[r] * h0[r];
               head_part += p.b1[r] * h1[r];
             }
-            if (MODE >= 1) {
+            if constexpr (TRAIN) {
+              ds_store(7, ch, d0, d1);
+              save_rows(a.save_t, 7, ch, d0 * (p.b0 / 3.0f), d1 * (p.b1 / 3.0f));
+            } else if (MODE >= 1) {
               st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)), d0 * (p.b0 / 3.0f));
               st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)), d1 * (p.b1 / 3.0f));
             }
           } else if (MODE >= 1) {
-            dsig_store<PREC>(scr, s, ch, lane, d0, d1);
+            ds_store(s, ch, d0, d1);
           }
+          if constexpr (TRAIN) save_rows(a.save_h, s, ch, h0, h1);
           ho.set_chunk(ch, h0, h1);
         } else if (s == 8) {
-          if (MODE == 2) {
+          if constexpr (TRAIN) {
+            save_rows(a.feat, 0, ch, acc0 + p.a0, acc1 + p.a1);
+          } else if (MODE == 2) {
             if (tile * TILE_PTS < a.npts) {
               float* ft = a.feat + (size_t)tile * (16 * 256);
               st_stream(reinterpret_cast<f32x4*>(ft + ((2 * ch) * 64 + lane) * 4), acc0 + p.a0);
@@ -249,7 +302,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
               }
             }
             f32x4 d0, d1;
-            dsig_decode<PREC>(p, d0, d1);
+            if constexpr (TRAIN) {
+              d0 = p.a0;
+              d1 = p.a1;
+              save_rows(a.save_t, l - 1, ch, acc0 * d0, acc1 * d1);
+            } else {
+              dsig_decode<PREC>(p, d0, d1);
+            }
             ho.set_chunk(ch, acc0 * d0, acc1 * d1);
           }
         }
@@ -276,6 +335,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
       };
       run_stage<PREC, 16, 2, false>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 8, smem, par, h, nullptr, pre, epi, wave, lane);
 
+      if constexpr (TRAIN) {
+        if (tile_ok) {
+          float* gr = a.save_ge + (size_t)row * 128 + 4 * q;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(gr + b * 16) = f32x4{ge[b * 4], ge[b * 4 + 1], ge[b * 4 + 2], ge[b * 4 + 3]};
+#pragma unroll
+          for (int b = 0; b < 3; ++b) *reinterpret_cast<f32x4*>(gr + 64 + b * 16) = f32x4{skip[b * 4], skip[b * 4 + 1], skip[b * 4 + 2], skip[b * 4 + 3]};
+        }
+      }
       float dx[3] = {0.f, 0.f, 0.f};
       {
         float dc[39];

@@ -54,6 +54,47 @@ def sdf_at_points(mode: int, sdf_w, sdf_b, sdf_head, pts):
     return sdf_eval(mode, sdf_w, sdf_b, sdf_head, pts.contiguous(), zeros, t, 1)
 
 
+def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
+    """Training forward at free points [P,3] (P % 16 == 0): -> (sdf [P,1], feat [P,256] row-major, grad [P,3], saves)
+    where ``saves`` holds what ``sdf_train_backward`` and the weight-gradient GEMMs need (include/nrhints_hip.h)."""
+    lib = _lib.load()
+    n = pts.shape[0]
+    dev = pts.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    zeros3 = torch.zeros(n, 3, **f32)
+    zeros1 = torch.zeros(n, **f32)
+    sdf = torch.empty(n, 1, **f32)
+    grad = torch.empty(n, 3, **f32)
+    feat = torch.empty(n, 256, **f32)
+    saves = dict(h=torch.empty(8, n, 256, **f32), s1=torch.empty(8, n, 256, **f32), t=torch.empty(8, n, 256, **f32),
+                 ge=torch.empty(n, 128, **f32), zeros3=zeros3, zeros1=zeros1)
+    P = _lib.ptr
+    wp, prec = _wptr(sdf_w)
+    rc = lib.nrh_sdf_train_forward(prec, wp, P(sdf_b), P(sdf_head), P(pts), P(zeros3), P(zeros1), 1, 1, n, P(sdf), P(grad),
+                                   P(feat), P(saves["h"]), P(saves["s1"]), P(saves["t"]), P(saves["ge"]), _lib.stream_handle())
+    _lib.check(rc, "nrh_sdf_train_forward")
+    return sdf, feat, grad, saves
+
+
+def sdf_train_backward(sdf_w, wt_feat, sdf_head, pts, saves, sbar, fbar, gbar):
+    """The two backward sweeps -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3])."""
+    lib = _lib.load()
+    n = pts.shape[0]
+    f32 = dict(dtype=torch.float32, device=pts.device)
+    out = dict(abar=torch.empty(8, n, 256, **f32), coup=torch.empty(8, n, 256, **f32), zbar=torch.empty(8, n, 256, **f32),
+               gebar=torch.empty(n, 64, **f32), pbar=torch.empty(n, 3, **f32))
+    P = _lib.ptr
+    wp, prec = _wptr(sdf_w)
+    wtp, prec2 = _wptr(wt_feat)
+    if prec != prec2:
+        raise ValueError("sdf_w and wt_feat are packed for different precisions")
+    rc = lib.nrh_sdf_train_backward(prec, wp, wtp, P(sdf_head), P(pts), P(saves["zeros3"]), P(saves["zeros1"]), 1, 1, n,
+                                    P(saves["s1"]), P(saves["t"]), P(gbar), P(fbar), P(sbar), P(out["abar"]), P(out["coup"]),
+                                    P(out["gebar"]), P(out["zbar"]), P(out["pbar"]), _lib.stream_handle())
+    _lib.check(rc, "nrh_sdf_train_backward")
+    return out
+
+
 def sampler_step(ro, rd, z, s, n: int, *, znew_in=None, snew_in=None, upsample_inv_s: Optional[float] = None,
                  lin16=None, finalize: bool = False, last_dist: float = 2.0 / 64, last_dist_ray=None):
     """One launch of the hierarchical sampler.  ``z``/``s`` ([nrays,128]) are updated in place by a merge.

@@ -132,6 +132,12 @@ def pack_sdf(d: Dict[str, torch.Tensor], precision: int = 0) -> Tuple[torch.Tens
     return packed.contiguous(), bias.contiguous(), head.contiguous()
 
 
+def pack_feat_transposed(d: Dict[str, torch.Tensor], precision: int = 0) -> torch.Tensor:
+    """Wf^T as one regular 256x256 stage: first stage of the training value-adjoint sweep (hbar_7 = Wf^T fbar + ...)."""
+    ps = pack_stage if precision == 0 else pack_stage_h3
+    return ps(d["feat_w"].t(), 256, 256).contiguous()
+
+
 def color_input_permutation(hints: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Column indices of the reference's 361-wide reflectance input
     [pts 0:3 | enc4(view) 3:30 | normal 30:33 | enc4(pl) 33:60 | feat 60:316 | enc4(vis) 316:325 | enc4(cue) 325:361]

@@ -149,8 +149,9 @@ class NeuSHintRenderer(nn.Module):
                 prec = _lib.PRECISIONS[self.precision]
                 sw, sb, sh = packing.pack_sdf(d, prec)
                 cw, cb = packing.pack_color(d, prec, bool(self._hints))
+                wtf = packing.pack_feat_transposed(d, prec)
                 inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6).item())
-            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s, precision=prec)
+            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s, precision=prec, sdf_wt_feat=wtf)
             self._packed_key = key
         return self._packed
 
@@ -229,7 +230,7 @@ class NeuSHintRenderer(nn.Module):
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
-                sdf_impl=self.sdf_backward)
+                sdf_impl=self.sdf_backward, packed=pk)
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],

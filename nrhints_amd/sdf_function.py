@@ -154,9 +154,75 @@ class SdfValueFeatGrad(torch.autograd.Function):
         return (p3_bar * 3.0, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
 
 
-def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, impl: str = "manual"):
+class SdfValueFeatGradHip(torch.autograd.Function):
+    """Same contract as ``SdfValueFeatGrad`` with the forward and both backward sweeps in the HIP register-chain
+    kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are rocBLAS GEMMs over the saved
+    row-major arrays.  ``packed``: dict(sdf_w, sdf_b, sdf_head, sdf_wt_feat) packed from the SAME dense weights."""
+
+    @staticmethod
+    def forward(ctx, pts, packed, *params):
+        from . import ops
+        if not pts.is_cuda:
+            raise RuntimeError("sdf_backward='hip' needs the points on the GPU (no CPU fallback)")
+        n = pts.shape[0]
+        pad = (-n) % 16
+        p = pts.detach().to(torch.float32)
+        if pad:
+            p = torch.cat([p, p[-1:].expand(pad, 3)], dim=0)
+        p = p.contiguous()
+        sdf, feat, g, saves = ops.sdf_train_forward(packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], p)
+        ctx.packed, ctx.saves, ctx.p, ctx.n = packed, saves, p, n
+        ctx.shapes = [tuple(t.shape) for t in params]
+        return sdf[:n], feat[:n], g[:n]
+
+    @staticmethod
+    def backward(ctx, sbar, fbar, gbar):
+        from . import ops
+        packed, saves, p, n = ctx.packed, ctx.saves, ctx.p, ctx.n
+        m = p.shape[0]
+
+        def full(x, width):
+            out = torch.zeros(m, width, dtype=torch.float32, device=p.device)
+            if x is not None:
+                out[:n] = x.reshape(n, width)
+            return out
+
+        sb, fb, gb = full(sbar, 1), full(fbar, 256), full(gbar, 3)
+        r = ops.sdf_train_backward(packed["sdf_w"], packed["sdf_wt_feat"], packed["sdf_head"], p, saves, sb.reshape(-1), fb, gb)
+        zbar, abar, h, t = r["zbar"], r["abar"], saves["h"], saves["t"]
+        e, dc, d2c, dim = _enc_parts(p * 3.0)
+        ge = saves["ge"][:, :EMB] + saves["ge"][:, 73:73 + EMB]
+        p_bar = r["pbar"] + 9.0 * _scatter_dims(ge * d2c * gb[:, dim], dim)
+        dW, db = [], []
+        zsum = zbar.sum(1)                                        # [8,256]
+        for l in range(N_LAYERS):
+            x_l = e if l == 0 else h[l - 1]
+            ab_l = r["gebar"][:, :EMB] if l == 0 else abar[l - 1]
+            w = zbar[l].t() @ x_l
+            w.addmm_(t[l].t(), ab_l)
+            rows = ctx.shapes[l][0]
+            if l == SKIP:
+                w = w / math.sqrt(2.0)
+            dW.append(w[:rows])
+            db.append(zsum[l, :rows])
+        h7 = h[7]
+        ws_bar = ((abar[7].sum(0) + (sb * h7).sum(0)) / 3.0).reshape(1, 256)
+        bs_bar = sb.sum().reshape(1) / 3.0
+        Wf_bar = fb.t() @ h7
+        bf_bar = fb.sum(0)
+        ctx.saves = None
+        return (p_bar[:n].to(gbar.dtype if gbar is not None else torch.float32), None, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
+
+
+def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, impl: str = "manual", packed=None):
     """Convenience wrapper over the weight dict of ``packing.dense_params``.  ``impl``: "manual" = this file's torch
-    implementation of the sweeps."""
+    implementation of the sweeps, "hip" = the HIP kernels (``packed`` required)."""
+    if impl == "hip":
+        if packed is None:
+            raise ValueError("impl='hip' needs the packed parameters")
+        args = [dense[f"sdf_w{l}"] for l in range(8)] + [dense[f"sdf_b{l}"] for l in range(8)] + \
+               [dense["sdf_head_w"], dense["sdf_head_b"], dense["feat_w"], dense["feat_b"]]
+        return SdfValueFeatGradHip.apply(pts, packed, *args)
     if impl != "manual":
         raise ValueError(f"unknown sdf implementation {impl!r}")
     args = [dense[f"sdf_w{l}"] for l in range(8)] + [dense[f"sdf_b{l}"] for l in range(8)] + \
