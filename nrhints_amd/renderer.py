@@ -106,7 +106,7 @@ class NeuSHintRenderer(nn.Module):
     precision = "f16x3"
     # backward of (sdf, feat, d sdf/dx): "manual" = hand-derived sweeps in torch ops, "hip" = the same sweeps in the HIP
     # register-chain kernels (forward included), "autograd" = second-order autograd graph like the reference (A/B only)
-    sdf_backward = "manual"
+    sdf_backward = "hip"
 
     def __init__(self, config: NeuSModelConfig = None, precision: Optional[str] = None):
         super().__init__()

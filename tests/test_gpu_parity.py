@@ -285,7 +285,8 @@ def test_sdf_query_and_grid(scene):
     assert u[12, 12, 12] > 0 > u[0, 0, 0]  # -sdf: positive inside, negative outside
 
 
-def test_training_step_gradients(scene):
+@pytest.mark.parametrize("sdf_backward", ["hip", "manual", "autograd"])
+def test_training_step_gradients(scene, sdf_backward):
     """forward(is_training=True) + the reference's loss + backward: loss value and the gradient of every parameter
     tensor and of the rays against what the imported reference produced (tests/golden/train_*.npz)."""
     tag, model, packed, p32, _ = scene
@@ -294,6 +295,7 @@ def test_training_step_gradients(scene):
     for t_ in (rb.origins, rb.directions, rb.pl_positions):
         t_.requires_grad_(True)
     model.zero_grad()
+    model.sdf_backward = sdf_backward      # HIP sweeps (default) | same maths in torch ops | second-order autograd
     out = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["global_step"]),
                 _t_rand_primary=cu(g["t_rand_primary"]), _t_rand_shadow=cu(g["t_rand_shadow"]))
     gt = cu(g["rgb_gt"])
@@ -316,6 +318,7 @@ def test_training_step_gradients(scene):
         scale = max(np.abs(want).max(), 1e-8)
         assert np.abs(t_.grad.cpu().numpy() - want).max() / scale < 2e-2, nm
     model.zero_grad()
+    model.sdf_backward = type(model).sdf_backward
 
 
 def test_eval_image_products_and_raygen(scene):
