@@ -27,6 +27,29 @@ def _enc(x: torch.Tensor, n_freq: int) -> torch.Tensor:
     return torch.cat([x, torch.sin(torch.cat([s, s + math.pi / 2.0], dim=-1))], dim=-1)
 
 
+class _LinearBigK(torch.autograd.Function):
+    """F.linear whose weight gradient ([out x P] @ [P x in], P ~ 1e5 rows, tiny output) is computed as a batched GEMM
+    over S slabs of rows + a sum: the plain GEMM autograd would call launches ~32 workgroups on a 256-CU GPU."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        m = x.shape[0]
+        S = math.gcd(m, 32)
+        gw = torch.bmm(gy.reshape(S, m // S, -1).transpose(1, 2), x.reshape(S, m // S, -1)).sum(0)
+        return gy @ w, gw, gy.sum(0)
+
+
+def _linear(x, w, b):
+    return _LinearBigK.apply(x, w, b) if (x.is_cuda and x.shape[0] >= 4096) else F.linear(x, w, b)
+
+
 def _sdf_net(d: Dict[str, torch.Tensor], pts: torch.Tensor):
     e = _enc(pts * 3.0, 6)
     h = e
@@ -67,7 +90,7 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
         parts += [_enc(rep(vis), 4), _enc(rep(cue), 4)]
     x = torch.cat(parts, dim=-1)
     for l in range(5):
-        x = F.linear(x, d[f"col_w{l}"], d[f"col_b{l}"])
+        x = _linear(x, d[f"col_w{l}"], d[f"col_b{l}"])
         if l < 4:
             x = torch.relu(x)
     col = torch.sigmoid(x).reshape(n, T, 3)
