@@ -156,6 +156,27 @@ int nrh_render_forward(const NrhNet* net /* host */, const float* origins, const
                        float* normal_map, float* normalized_normal_map, float* workspace, long long workspace_floats,
                        void* stream);
 
+/* Training forward of the same path (NeuSHintRenderer.forward with is_training=True under autograd): identical to
+ * nrh_render_forward up to and including the shadow march - samplers, depth / hit point, visibility, specular cue -
+ * with the SDF network at the 128 section mid-points evaluated by the training kernel (nrh_sdf_train_forward), whose
+ * outputs land in `saves`.  The reflectance network and the compositing are NOT run: they, and everything else the
+ * loss differentiates (models/neus_hint_model.py:504-510, :521-525, :626-637), belong to the caller's backward pass,
+ * which feeds nrh_sdf_train_backward.  All per-sample outputs as in nrh_render_forward (optional ones may be null). */
+typedef struct NrhTrainSaves {
+  float* sdf;        /* [nrays,128]        sdf at the section mid-points */
+  float* feat_rows;  /* [nrays*128,256]    row-major feature */
+  float* save_h;     /* [8][nrays*128][256] */
+  float* save_s1;    /* [8][nrays*128][256] */
+  float* save_t;     /* [8][nrays*128][256] */
+  float* save_ge;    /* [nrays*128][128] */
+} NrhTrainSaves;
+int nrh_render_forward_train(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
+                             const float* nears, const float* fars, long long nrays, float cos_anneal,
+                             const float* t_rand_primary, const float* t_rand_shadow, int zero_hints, const float* lin64,
+                             const float* lin16, float* depth, float* weights, float* inside_sphere, float* analytic_normals,
+                             float* normalized_normals, float* visibilities, float* specular_cue, float* mid_z, float* dists,
+                             const NrhTrainSaves* saves, float* workspace, long long workspace_floats, void* stream);
+
 /* ---- pixel -> ray for one pinhole view ------------------------------------------------------------------------
  * RayGenerator.forward without pose / light deltas (camera/ray_generator.py:79-139): rows [row0, row0+nrows) of a
  * `width`-wide image, pose = row-major [3,4] camera-to-world (HOST pointer, 12 floats), pl = light position (HOST, 3).

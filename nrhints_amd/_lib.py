@@ -19,13 +19,18 @@ _ERRNAMES = {-1: "NRH_E_INVALID", -2: "NRH_E_LAUNCH", -3: "NRH_E_WORKSPACE", -4:
 EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param_sizes", "nrh_mlp_grid",
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
-            "nrh_sdf_train_forward", "nrh_sdf_train_backward")
+            "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train")
 
 
 class NrhNet(Structure):
     _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
                 ("normal_type", c_int), ("depth_type", c_int)]
+
+
+class NrhTrainSaves(Structure):
+    _fields_ = [("sdf", c_void_p), ("feat_rows", c_void_p), ("save_h", c_void_p), ("save_s1", c_void_p),
+                ("save_t", c_void_p), ("save_ge", c_void_p)]
 
 
 class HipExtensionMissing(RuntimeError):
@@ -65,6 +70,8 @@ def load():
     lib.nrh_render_workspace_floats.restype = c_longlong
     lib.nrh_render_forward.argtypes = [POINTER(NrhNet), P, P, P, P, P, c_longlong, P, c_float, P, P, c_int, P, P,
                                        P, P, P, P, P, P, P, P, P, P, P, P, P, c_longlong, P]
+    lib.nrh_render_forward_train.argtypes = [POINTER(NrhNet), P, P, P, P, P, c_longlong, c_float, P, P, c_int, P, P,
+                                             P, P, P, P, P, P, P, P, P, POINTER(NrhTrainSaves), P, c_longlong, P]
     lib.nrh_generate_rays.argtypes = [POINTER(c_float), POINTER(c_float), c_float, c_float, c_float, c_float, c_int,
                                       c_int, c_int, P, P, P, P, P, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]

@@ -61,7 +61,7 @@ def _sdf_net(d: Dict[str, torch.Tensor], pts: torch.Tensor):
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
-                background_rgb, analytic_normal: bool = False, sdf_impl: str = "manual", packed=None) -> Dict[str, torch.Tensor]:
+                background_rgb, analytic_normal: bool = False, sdf_impl: str = "manual", packed=None, pre=None) -> Dict[str, torch.Tensor]:
     """``d``: weight-norm-folded dense parameters WITH autograd history (packing.dense_params on the live
     nn.Parameters); mid_z / dists [N,128], vis [N,1], cue [N,4]: graph-less results of the HIP forward."""
     n, T = mid_z.shape
@@ -72,7 +72,7 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
         sdf, feat = _sdf_net(d, pts)
         (grad,) = torch.autograd.grad(sdf, pts, torch.ones_like(sdf), create_graph=True, retain_graph=True)
     else:                           # hand-derived backward (sdf_function.py): no double-backward graph
-        sdf, feat, grad = sdf_value_feat_grad(d, pts, impl=sdf_impl, packed=packed)
+        sdf, feat, grad = sdf_value_feat_grad(d, pts, impl=sdf_impl, packed=packed, pre=pre)
     inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
     view = dirs[:, None, :].expand(n, T, 3).reshape(-1, 3)
     true_cos = (view * grad).sum(-1, keepdim=True)

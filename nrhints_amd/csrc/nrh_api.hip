@@ -75,13 +75,13 @@ std::vector<TimedLaunch> g_timed;
 void timing_begin(int kind, hipStream_t st, TimedLaunch& t, bool& on) {
   on = (kind == g_time_kind);
   if (!on) return;
-  hipEventCreate(&t.a);
-  hipEventCreate(&t.b);
-  hipEventRecord(t.a, st);
+  (void)hipEventCreate(&t.a);
+  (void)hipEventCreate(&t.b);
+  (void)hipEventRecord(t.a, st);
 }
 void timing_end(hipStream_t st, TimedLaunch& t, bool on) {
   if (!on) return;
-  hipEventRecord(t.b, st);
+  (void)hipEventRecord(t.b, st);
   g_timed.push_back(t);
 }
 
@@ -208,7 +208,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 105; }
+int nrh_version(void) { return 106; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -229,7 +229,7 @@ int nrh_mlp_grid(void) { return mlp_grid(); }
 
 int nrh_kernel_timing_select(int kind) {
   if (kind < -1 || kind > 3) return fail(NRH_E_INVALID, "nrh_kernel_timing_select: kind must be -1..3%s", "");
-  for (auto& t : g_timed) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+  for (auto& t : g_timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   g_timed.clear();
   g_time_kind = kind;
   return NRH_OK;
@@ -243,8 +243,8 @@ int nrh_kernel_timing_read(double* total_ms, long long* launches) {
     if (hipEventSynchronize(t.b) != hipSuccess || hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess)
       return fail(NRH_E_LAUNCH, "nrh_kernel_timing_read: event query failed%s", "");
     tot += ms;
-    hipEventDestroy(t.a);
-    hipEventDestroy(t.b);
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
   }
   *total_ms = tot;
   *launches = (long long)g_timed.size();
@@ -380,13 +380,13 @@ long long nrh_render_workspace_floats(long long nrays) {
   return tot;
 }
 
-int nrh_render_forward(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
-                       const float* nears, const float* fars, long long nrays, const float* background,
-                       float cos_anneal, const float* t_rand_primary, const float* t_rand_shadow, int zero_hints,
-                       const float* lin64, const float* lin16, float* rgb, float* depth, float* weights,
-                       float* inside_sphere, float* analytic_normals, float* normalized_normals, float* visibilities,
-                       float* specular_cue, float* mid_z, float* dists, float* normal_map, float* normalized_normal_map,
-                       float* workspace, long long workspace_floats, void* stream) {
+static int render_forward_impl(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
+                               const float* nears, const float* fars, long long nrays, const float* background,
+                               float cos_anneal, const float* t_rand_primary, const float* t_rand_shadow, int zero_hints,
+                               const float* lin64, const float* lin16, float* rgb, float* depth, float* weights,
+                               float* inside_sphere, float* analytic_normals, float* normalized_normals, float* visibilities,
+                               float* specular_cue, float* mid_z, float* dists, float* normal_map, float* normalized_normal_map,
+                               const NrhTrainSaves* train, float* workspace, long long workspace_floats, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !net->col_w || !net->col_b)
     return fail(NRH_E_INVALID, "nrh_render_forward: null network pointer%s", "");
@@ -396,8 +396,10 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
       (net->depth_type != 0 && net->depth_type != 1))
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type / depth_type must be 0 or 1%s", "");
   const int no_hints = zero_hints || !net->hints;  // no shadow march: geometry warm-up, or the pl-naive model
-  if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || !rgb || !workspace)
+  if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || (!rgb && !train) || !workspace)
     return fail(NRH_E_INVALID, "nrh_render_forward: null pointer%s", "");
+  if (train && (!train->sdf || !train->feat_rows || !train->save_h || !train->save_s1 || !train->save_t || !train->save_ge))
+    return fail(NRH_E_INVALID, "nrh_render_forward_train: null pointer in NrhTrainSaves%s", "");
   if (nrays < 0 || nrays > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_render_forward: nrays out of range (chunk the call)%s", "");
   if (nrays == 0) return NRH_OK;
   if (workspace_floats < nrh_render_workspace_floats(nrays))
@@ -433,12 +435,19 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
                        o_tmid, o_dists, n, st);
   if (rc) return rc;
   // ---- render_core: sdf + feature + gradient at the 128 section mid-points ----
-  rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n, ws_sdf_c, 128,
-                     o_grad, ws_feat, scratch, st);
+  float* sdf_c = train ? train->sdf : ws_sdf_c;
+  if (train) {
+    // training: the same evaluation with the feature row-major and the arrays the backward sweeps need
+    rc = nrh_sdf_train_forward(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
+                               sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, stream);
+  } else {
+    rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n, sdf_c, 128,
+                       o_grad, ws_feat, scratch, st);
+  }
   if (rc) return rc;
   {
     nrh::CoreArgs c;
-    c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = ws_sdf_c; c.grad = o_grad; c.dists = o_dists;
+    c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = sdf_c; c.grad = o_grad; c.dists = o_dists;
     c.tmid = o_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
     c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
     c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal; c.shadow_offset = 1e-2f;
@@ -472,6 +481,7 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     rc = check_launch("shadow_finish_kernel");
     if (rc) return rc;
   }
+  if (train) return NRH_OK;  // reflectance + composite are differentiated by the caller
   // ---- reflectance + composite ----
   rc = color_eval_impl(net->precision, net->hints, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid,
                        net->normal_type ? o_grad : o_nhat, ws_raymisc, n, ws_color, st);
@@ -485,6 +495,32 @@ int nrh_render_forward(const NrhNet* net, const float* origins, const float* dir
     if (rc) return rc;
   }
   return NRH_OK;
+}
+
+int nrh_render_forward(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
+                       const float* nears, const float* fars, long long nrays, const float* background,
+                       float cos_anneal, const float* t_rand_primary, const float* t_rand_shadow, int zero_hints,
+                       const float* lin64, const float* lin16, float* rgb, float* depth, float* weights,
+                       float* inside_sphere, float* analytic_normals, float* normalized_normals, float* visibilities,
+                       float* specular_cue, float* mid_z, float* dists, float* normal_map, float* normalized_normal_map,
+                       float* workspace, long long workspace_floats, void* stream) {
+  return render_forward_impl(net, origins, directions, pl_positions, nears, fars, nrays, background, cos_anneal, t_rand_primary,
+                             t_rand_shadow, zero_hints, lin64, lin16, rgb, depth, weights, inside_sphere, analytic_normals,
+                             normalized_normals, visibilities, specular_cue, mid_z, dists, normal_map, normalized_normal_map,
+                             nullptr, workspace, workspace_floats, stream);
+}
+
+int nrh_render_forward_train(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
+                             const float* nears, const float* fars, long long nrays, float cos_anneal,
+                             const float* t_rand_primary, const float* t_rand_shadow, int zero_hints, const float* lin64,
+                             const float* lin16, float* depth, float* weights, float* inside_sphere, float* analytic_normals,
+                             float* normalized_normals, float* visibilities, float* specular_cue, float* mid_z, float* dists,
+                             const NrhTrainSaves* saves, float* workspace, long long workspace_floats, void* stream) {
+  if (!saves) return fail(NRH_E_INVALID, "nrh_render_forward_train: saves is null%s", "");
+  return render_forward_impl(net, origins, directions, pl_positions, nears, fars, nrays, nullptr, cos_anneal, t_rand_primary,
+                             t_rand_shadow, zero_hints, lin64, lin16, nullptr, depth, weights, inside_sphere, analytic_normals,
+                             normalized_normals, visibilities, specular_cue, mid_z, dists, nullptr, nullptr, saves, workspace,
+                             workspace_floats, stream);
 }
 
 }  // extern "C"

@@ -76,11 +76,13 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
     return sdf, feat, grad, saves
 
 
-def sdf_train_backward(sdf_w, wt_feat, sdf_head, pts, saves, sbar, fbar, gbar):
-    """The two backward sweeps -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3])."""
+def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sbar, fbar, gbar):
+    """The two backward sweeps at the points ro[ray] + rd[ray] * t[ray, j]
+    -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3])."""
     lib = _lib.load()
-    n = pts.shape[0]
-    f32 = dict(dtype=torch.float32, device=pts.device)
+    nrays = ro.shape[0]
+    n = nrays * n_per_ray
+    f32 = dict(dtype=torch.float32, device=ro.device)
     out = dict(abar=torch.empty(8, n, 256, **f32), coup=torch.empty(8, n, 256, **f32), zbar=torch.empty(8, n, 256, **f32),
                gebar=torch.empty(n, 64, **f32), pbar=torch.empty(n, 3, **f32))
     P = _lib.ptr
@@ -88,7 +90,7 @@ def sdf_train_backward(sdf_w, wt_feat, sdf_head, pts, saves, sbar, fbar, gbar):
     wtp, prec2 = _wptr(wt_feat)
     if prec != prec2:
         raise ValueError("sdf_w and wt_feat are packed for different precisions")
-    rc = lib.nrh_sdf_train_backward(prec, wp, wtp, P(sdf_head), P(pts), P(saves["zeros3"]), P(saves["zeros1"]), 1, 1, n,
+    rc = lib.nrh_sdf_train_backward(prec, wp, wtp, P(sdf_head), P(ro), P(rd), P(t), n_per_ray, n_per_ray, nrays,
                                     P(saves["s1"]), P(saves["t"]), P(gbar), P(fbar), P(sbar), P(out["abar"]), P(out["coup"]),
                                     P(out["gebar"]), P(out["zbar"]), P(out["pbar"]), _lib.stream_handle())
     _lib.check(rc, "nrh_sdf_train_backward")

@@ -13,6 +13,7 @@ current torch stream.  There is no PyTorch/CPU fallback: without the extension o
 from __future__ import annotations
 
 import math
+import ctypes
 from typing import Optional
 
 import numpy as np
@@ -107,6 +108,8 @@ class NeuSHintRenderer(nn.Module):
     # backward of (sdf, feat, d sdf/dx): "manual" = hand-derived sweeps in torch ops, "hip" = the same sweeps in the HIP
     # register-chain kernels (forward included), "autograd" = second-order autograd graph like the reference (A/B only)
     sdf_backward = "hip"
+    # largest training batch whose saved arrays (49 KB per sample point, fwd + bwd) are kept in one piece: 8192 rays = 51 GB
+    max_fused_train_rays = 8192
 
     def __init__(self, config: NeuSModelConfig = None, precision: Optional[str] = None):
         super().__init__()
@@ -215,9 +218,13 @@ class NeuSHintRenderer(nn.Module):
             if bg.numel() != 3:
                 raise ValueError("background_rgb must be [1,3]")
 
-        res = self._render_chunks(o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints,
-                                  want_samples=True, want_maps=False, want_mid=needs_grad)
-        rgb, depth, vis = res["rgb"], res["depth"], res["visibilities"]
+        fused_train = needs_grad and self.sdf_backward == "hip" and n <= self.max_fused_train_rays
+        if fused_train:
+            res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints)
+        else:
+            res = self._render_chunks(o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints,
+                                      want_samples=True, want_maps=False, want_mid=needs_grad)
+        rgb, depth, vis = res.get("rgb"), res["depth"], res["visibilities"]
         weights, inside, normals, nhat, cue = (res[k] for k in ("weights", "inside", "normals", "nhat", "cue"))
         mid_z, dists = res.get("mid_z"), res.get("dists")
         pk = self.packed_params(device)
@@ -230,7 +237,7 @@ class NeuSHintRenderer(nn.Module):
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
-                sdf_impl=self.sdf_backward, packed=pk)
+                sdf_impl=self.sdf_backward, packed=pk, pre=res.get("pre"))
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],
@@ -243,6 +250,38 @@ class NeuSHintRenderer(nn.Module):
                             specular_cue=cue if self._hints else None)
 
     # ---------------------------------------------------------------------------------------------
+    def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints):
+        """One nrh_render_forward_train call over the whole batch: the no-grad stages (samplers, hit point, shadow march,
+        cue) plus the training evaluation of the SDF network at the section mid-points, whose outputs and saved arrays
+        feed the backward sweeps directly (no second evaluation)."""
+        lib = _lib.load()
+        device = o.device
+        n = o.shape[0]
+        pk = self.packed_params(device)
+        lin64, lin16 = self._const(device)
+        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
+                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
+                          self._hints, self._normal_type, self._depth_type)
+        T = N_SAMPLES_TOTAL
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
+        out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
+                   nhat=new(n, T, 3), cue=new(n, T, 4), mid_z=new(n, T), dists=new(n, T))
+        pre = dict(sdf=new(n * T, 1), feat=new(n * T, 256), grad=out["normals"].reshape(n * T, 3),
+                   saves=dict(h=new(8, n * T, 256), s1=new(8, n * T, 256), t=new(8, n * T, 256), ge=new(n * T, 128)),
+                   ro=o, rd=d, t=out["mid_z"], n_per_ray=T)
+        P = _lib.ptr
+        sv = pre["saves"]
+        saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]))
+        ws = self._workspace(device, n)
+        rc = lib.nrh_render_forward_train(
+            net, P(o), P(d), P(pl), P(near), P(far), n, cos_anneal, P(t_rand_p) if t_rand_p is not None else None,
+            P(t_rand_s) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16), P(out["depth"]), P(out["weights"]),
+            P(out["inside"]), P(out["normals"]), P(out["nhat"]), P(out["visibilities"]), P(out["cue"]), P(out["mid_z"]),
+            P(out["dists"]), ctypes.byref(saves), P(ws), ws.numel(), _lib.stream_handle())
+        _lib.check(rc, "nrh_render_forward_train")
+        out["pre"] = pre
+        return out
+
     def _render_chunks(self, o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints, want_samples: bool,
                        want_maps: bool, want_mid: bool):
         """Enqueue nrh_render_forward per chunk of rays; returns a dict of freshly allocated output tensors.

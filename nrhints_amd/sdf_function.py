@@ -160,11 +160,19 @@ class SdfValueFeatGradHip(torch.autograd.Function):
     row-major arrays.  ``packed``: dict(sdf_w, sdf_b, sdf_head, sdf_wt_feat) packed from the SAME dense weights."""
 
     @staticmethod
-    def forward(ctx, pts, packed, *params):
+    def forward(ctx, pts, packed, pre, *params):
         from . import ops
         if not pts.is_cuda:
             raise RuntimeError("sdf_backward='hip' needs the points on the GPU (no CPU fallback)")
         n = pts.shape[0]
+        ctx.shapes = [tuple(t.shape) for t in params]
+        if pre is not None:
+            # the renderer's fused training call already evaluated the network at exactly these points
+            # (pts = ro + rd * t, same fp32 expression): adopt its outputs and saved arrays
+            ctx.packed, ctx.saves, ctx.n = packed, pre["saves"], n
+            ctx.rays = (pre["ro"], pre["rd"], pre["t"], pre["n_per_ray"])
+            ctx.p = pts.detach()
+            return pre["sdf"], pre["feat"], pre["grad"]
         pad = (-n) % 16
         p = pts.detach().to(torch.float32)
         if pad:
@@ -172,7 +180,7 @@ class SdfValueFeatGradHip(torch.autograd.Function):
         p = p.contiguous()
         sdf, feat, g, saves = ops.sdf_train_forward(packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], p)
         ctx.packed, ctx.saves, ctx.p, ctx.n = packed, saves, p, n
-        ctx.shapes = [tuple(t.shape) for t in params]
+        ctx.rays = (p, saves["zeros3"], saves["zeros1"], 1)
         return sdf[:n], feat[:n], g[:n]
 
     @staticmethod
@@ -182,13 +190,17 @@ class SdfValueFeatGradHip(torch.autograd.Function):
         m = p.shape[0]
 
         def full(x, width):
+            if x is not None and m == n:
+                return x.reshape(n, width).to(torch.float32).contiguous()
             out = torch.zeros(m, width, dtype=torch.float32, device=p.device)
             if x is not None:
                 out[:n] = x.reshape(n, width)
             return out
 
         sb, fb, gb = full(sbar, 1), full(fbar, 256), full(gbar, 3)
-        r = ops.sdf_train_backward(packed["sdf_w"], packed["sdf_wt_feat"], packed["sdf_head"], p, saves, sb.reshape(-1), fb, gb)
+        ro, rd, tt, npr = ctx.rays
+        r = ops.sdf_train_backward(packed["sdf_w"], packed["sdf_wt_feat"], packed["sdf_head"], ro, rd, tt, npr, saves,
+                                   sb.reshape(-1), fb, gb)
         zbar, abar, h, t = r["zbar"], r["abar"], saves["h"], saves["t"]
         e, dc, d2c, dim = _enc_parts(p * 3.0)
         ge = saves["ge"][:, :EMB] + saves["ge"][:, 73:73 + EMB]
@@ -219,10 +231,10 @@ class SdfValueFeatGradHip(torch.autograd.Function):
         Wf_bar = big_k(fb[None], h[7:8])[0]
         bf_bar = fb.sum(0)
         ctx.saves = None
-        return (p_bar[:n].to(gbar.dtype if gbar is not None else torch.float32), None, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
+        return (p_bar[:n], None, None, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
 
 
-def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, impl: str = "manual", packed=None):
+def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, impl: str = "manual", packed=None, pre=None):
     """Convenience wrapper over the weight dict of ``packing.dense_params``.  ``impl``: "manual" = this file's torch
     implementation of the sweeps, "hip" = the HIP kernels (``packed`` required)."""
     if impl == "hip":
@@ -230,7 +242,7 @@ def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, impl:
             raise ValueError("impl='hip' needs the packed parameters")
         args = [dense[f"sdf_w{l}"] for l in range(8)] + [dense[f"sdf_b{l}"] for l in range(8)] + \
                [dense["sdf_head_w"], dense["sdf_head_b"], dense["feat_w"], dense["feat_b"]]
-        return SdfValueFeatGradHip.apply(pts, packed, *args)
+        return SdfValueFeatGradHip.apply(pts, packed, pre, *args)
     if impl != "manual":
         raise ValueError(f"unknown sdf implementation {impl!r}")
     args = [dense[f"sdf_w{l}"] for l in range(8)] + [dense[f"sdf_b{l}"] for l in range(8)] + \

@@ -37,7 +37,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 105
+    assert lib.nrh_version() >= 106
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
