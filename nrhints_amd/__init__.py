@@ -7,10 +7,11 @@ it is missing (``nrhints_amd._lib.HipExtensionMissing``).
 """
 from .config import (DepthComputationType, NeuSModelConfig, NeuSRendererConfig, NormalComputationType,
                      ReflectanceNetConfig, SDFNetConfig, SingleVarianceNetConfig, unsupported_reason)
-from .containers import RayBundle, RenderOutput, td_concat
+from .containers import RawPixelBundle, RayBundle, RenderOutput, td_concat
+from .ray_generator import RayGenerator, RayGeneratorConfig
 from .renderer import NeuSHintRenderer
 
 __all__ = ["NeuSHintRenderer", "NeuSModelConfig", "NeuSRendererConfig", "SDFNetConfig", "ReflectanceNetConfig",
            "SingleVarianceNetConfig", "DepthComputationType", "NormalComputationType", "RayBundle", "RenderOutput",
-           "td_concat", "unsupported_reason"]
+           "td_concat", "unsupported_reason", "RawPixelBundle", "RayGenerator", "RayGeneratorConfig"]
 __version__ = "0.1.0"

@@ -119,3 +119,16 @@ class RenderOutput(TensorBatch):
     specular_cue: Optional[torch.Tensor] = None  # [*bs,128,4]
 
     _trailing: ClassVar[Dict[str, int]] = {"analytic_normals": 2, "normalized_analytic_normals": 2, "specular_cue": 2}
+
+
+@dataclass
+class RawPixelBundle(TensorBatch):
+    """Pixels before ray generation (data/data_loader.py:79-88): what the data loader hands to the ray generator."""
+    img_indices: Optional[torch.Tensor]      # [*bs,1] int64 training-view index, None for video / novel views
+    h_indices: torch.Tensor                  # [*bs,1] pixel row
+    w_indices: torch.Tensor                  # [*bs,1] pixel column
+    poses: torch.Tensor                      # [*bs,4,4] camera-to-world
+    pls: torch.Tensor                        # [*bs,3] point-light position
+    rgb_gt: Optional[torch.Tensor] = None    # [*bs,3]
+
+    _trailing: ClassVar[Dict[str, int]] = {"poses": 2}

@@ -1,0 +1,138 @@
+"""Pixel -> ray generation with learnable per-view pose / light refinement.
+
+Counterpart of ``RayGenerator`` (camera/ray_generator.py:42-150) and of the two exponential maps it uses
+(camera/lie_groups.py:26-122): same config fields, same parameter / buffer names (``cam_pose_adjustment`` [V,6] as
+(translation, so(3) vector), ``pl_adjustment`` [V,3], ``cam_pose_noise``, ``pl_noise``) so optimiser groups and
+checkpoints carry over (pipelines/base_pipeline.py:35-39, 103-105).  This is the differentiable host-side form for
+training batches (a few thousand scattered pixels, ~20 tiny ops); whole evaluation views without refinement go through
+the fused HIP ray kernel (``pipeline.generate_rays``).  Gradients w.r.t. the deltas arrive through the renderer's ray
+gradients (origins / directions / pl_positions), which the HIP training path provides.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Literal
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .containers import RawPixelBundle, RayBundle
+from .pipeline import CameraModel
+
+
+@dataclass(frozen=True)
+class RayGeneratorConfig:
+    """Field for field camera/ray_generator.py:14-38."""
+    override_near_far_from_sphere: bool = True
+    cam_opt_mode: Literal["off", "SO3xR3", "SE3"] = "off"
+    pl_opt: bool = False
+    opt_lr: float = 3e-5
+    cam_position_noise_std: float = 0.0
+    cam_orientation_noise_std: float = 0.0
+    pl_position_noise_std: float = 0.0
+
+
+def _hat(w: torch.Tensor) -> torch.Tensor:
+    """so(3) vectors [B,3] -> skew-symmetric matrices [B,3,3] with hat(w) x = w cross x."""
+    z = torch.zeros_like(w[:, 0])
+    return torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1], w[:, 0], z], dim=-1).reshape(-1, 3, 3)
+
+
+def exp_map_SO3xR3(tangent: torch.Tensor) -> torch.Tensor:
+    """[B,6] (translation, rotation vector) -> [B,3,4] = [R | t] with R = I + sin(th)/th K + (1-cos th)/th^2 K^2,
+    th = sqrt(max(|w|^2, 1e-4)) (the reference clamps the SQUARED norm, camera/lie_groups.py:39-43), t copied."""
+    w = tangent[:, 3:]
+    K = _hat(w)
+    th = (w * w).sum(1).clamp(min=1e-4).sqrt()
+    a = (th.sin() / th)[:, None, None]
+    b = ((1.0 - th.cos()) / (th * th))[:, None, None]
+    eye = torch.eye(3, dtype=w.dtype, device=w.device)[None]
+    R = eye + a * K + b * torch.bmm(K, K)
+    return torch.cat([R, tangent[:, :3, None]], dim=-1)
+
+
+def exp_map_SE3(tangent: torch.Tensor) -> torch.Tensor:
+    """[B,6] -> [B,3,4], the se(3) exponential with the reference's small-angle branches (theta < 1e-2,
+    camera/lie_groups.py:80-122): rational cosine, half-angle series for the other coefficients."""
+    v, w = tangent[:, :3], tangent[:, 3:]
+    th = torch.linalg.norm(w, dim=1, keepdim=True)          # [B,1]
+    th2 = th * th
+    small = th < 1e-2
+    one = torch.ones_like(th)
+    th_s, th2_s, th3_s = torch.where(small, one, th), torch.where(small, one, th2), torch.where(small, one, th2 * th)
+    sin = th.sin()
+    cos = torch.where(small, 8.0 / (4.0 + th2) - 1.0, th.cos())
+    a = torch.where(small, 0.5 * cos + 0.5, sin / th_s)                 # sin(th)/th
+    b = torch.where(small, 0.5 * a, (1.0 - cos) / th2_s)                # (1-cos th)/th^2
+    eye = torch.eye(3, dtype=w.dtype, device=w.device)[None]
+    R = b[:, :, None] * (w[:, :, None] * w[:, None, :]) + cos[:, :, None] * eye + a[:, :, None] * _hat(w)
+    a_t = torch.where(small, 1.0 - th2 / 6.0, a)
+    b_t = torch.where(small, 0.5 - th2 / 24.0, b)
+    c_t = torch.where(small, 1.0 / 6.0 - th2 / 120.0, (th - sin) / th3_s)
+    t = a_t * v + b_t * torch.linalg.cross(w, v, dim=1) + c_t * w * (w * v).sum(1, keepdim=True)
+    return torch.cat([R, t[:, :, None]], dim=-1)
+
+
+class RayGenerator(nn.Module):
+    """``forward(RawPixelBundle) -> RayBundle`` (camera/ray_generator.py:75-150)."""
+
+    def __init__(self, camera: CameraModel, num_cameras: int, config: RayGeneratorConfig = None, zn: float = 0.1,
+                 zf: float = 10.0):
+        super().__init__()
+        self.camera = camera
+        self.config = cfg = RayGeneratorConfig() if config is None else config
+        self.zn, self.zf = float(getattr(camera, "zn", zn)), float(getattr(camera, "zf", zf))
+        if cfg.cam_opt_mode not in ("off", "SO3xR3", "SE3"):
+            raise ValueError(f"Unknown camera pose optimization mode: {cfg.cam_opt_mode}")
+        if cfg.cam_opt_mode != "off":
+            self.cam_pose_adjustment = nn.Parameter(torch.zeros(num_cameras, 6))
+        if cfg.pl_opt:
+            self.pl_adjustment = nn.Parameter(torch.zeros(num_cameras, 3))
+        # synthetic-experiment noise, drawn once in the reference's order (pose first, then light; :61-73)
+        if cfg.cam_position_noise_std != 0.0 or cfg.cam_orientation_noise_std != 0.0:
+            if cfg.cam_position_noise_std < 0.0 or cfg.cam_orientation_noise_std < 0.0:
+                raise ValueError("noise stds must be >= 0")
+            std = torch.tensor([[cfg.cam_position_noise_std] * 3 + [cfg.cam_orientation_noise_std] * 3], dtype=torch.float32)
+            self.register_buffer("cam_pose_noise", exp_map_SE3(torch.normal(torch.zeros(num_cameras, 6), std)), persistent=True)
+        if cfg.pl_position_noise_std != 0.0:
+            if cfg.pl_position_noise_std < 0.0:
+                raise ValueError("noise stds must be >= 0")
+            self.register_buffer("pl_noise", torch.normal(torch.zeros(num_cameras, 3), cfg.pl_position_noise_std), persistent=True)
+
+    @staticmethod
+    def _compose(delta: torch.Tensor, R: torch.Tensor, t: torch.Tensor):
+        """Left-multiply the camera-to-world [R|t] by a [B,3,4] delta."""
+        dR, dt = delta[:, :3, :3], delta[:, :3, 3:]
+        return dR @ R, dt + dR @ t
+
+    def forward(self, pixel_bundle: RawPixelBundle) -> RayBundle:
+        cam, cfg = self.camera, self.config
+        x = pixel_bundle.w_indices[..., 0] + 0.5        # pixel centres (:79-80)
+        y = pixel_bundle.h_indices[..., 0] + 0.5
+        idx = None if pixel_bundle.img_indices is None else pixel_bundle.img_indices[..., 0]
+        dirs_cam = torch.stack([(x - cam.cx) / cam.fx, -(y - cam.cy) / cam.fy, -torch.ones_like(x)], dim=-1)
+        R, t = pixel_bundle.poses[:, :3, :3], pixel_bundle.poses[:, :3, 3:]
+        pls = pixel_bundle.pls
+        if idx is not None:     # novel / video views have no training-view index and get no refinement (:103-105)
+            if hasattr(self, "cam_pose_noise"):
+                R, t = self._compose(self.cam_pose_noise[idx], R, t)
+            if cfg.cam_opt_mode == "SO3xR3":
+                R, t = self._compose(exp_map_SO3xR3(self.cam_pose_adjustment[idx]), R, t)
+            elif cfg.cam_opt_mode == "SE3":
+                R, t = self._compose(exp_map_SE3(self.cam_pose_adjustment[idx]), R, t)
+            if hasattr(self, "pl_noise"):
+                pls = pls + self.pl_noise[idx]
+            if cfg.pl_opt:
+                pls = pls + self.pl_adjustment[idx]
+        d = F.normalize((dirs_cam[..., None, :] * R).sum(-1), dim=-1, p=2)      # R @ dir, unit length (:129-130)
+        o = t[..., 0]
+        if cfg.override_near_far_from_sphere:
+            # mid-point of the chord through the unit sphere, -/+ 1 (:135-139)
+            a = (d * d).sum(-1, keepdim=True)
+            b = 2.0 * (o * d).sum(-1, keepdim=True)
+            mid = 0.5 * (-b) / a
+            near, far = mid - 1.0, mid + 1.0
+        else:
+            near, far = self.zn * torch.ones_like(o[..., :1]), self.zf * torch.ones_like(o[..., :1])
+        return RayBundle(origins=o, directions=d, pl_positions=pls, nears=near, fars=far)

@@ -205,6 +205,9 @@ class SdfValueFeatGradHip(torch.autograd.Function):
         e, dc, d2c, dim = _enc_parts(p * 3.0)
         ge = saves["ge"][:, :EMB] + saves["ge"][:, 73:73 + EMB]
         p_bar = r["pbar"] + 9.0 * _scatter_dims(ge * d2c * gb[:, dim], dim)
+        if not any(ctx.needs_input_grad[3:]):       # frozen network (e.g. register_view): only the points' adjoint
+            ctx.saves = None
+            return (p_bar[:n], None, None) + (None,) * 20
         # weight gradients: [256 x P] @ [P x 256] GEMMs with a tiny output and a huge K.  A plain GEMM call launches
         # 16..32 workgroups for them (measured 44 TFLOP/s, 30 % of the step); splitting P into S batches fills the GPU.
         S = math.gcd(m, 32)

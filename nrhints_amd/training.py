@@ -111,6 +111,35 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
 
 
 # ---- checkpoints in the reference's layout (trainer/trainer.py:149-158, 173-236) ---------------------------------------
+def register_view(renderer, ray_generator, img_pixel_bundle, device, steps: int = 500, batch_size: int = 512,
+                  white_background: bool = True, lr: Optional[float] = None, generator: Optional[torch.Generator] = None,
+                  log=None) -> List[float]:
+    """Fit the ray generator's pose / light deltas of one view to its pixels with the renderer frozen in evaluation mode
+    (pipelines/base_pipeline.py:71-91): ``steps`` Adam steps over random ``batch_size``-pixel batches of the [H,W]
+    ``img_pixel_bundle`` with the summed L1 loss / (N + 1e-5).  The gradient reaches the deltas through the renderer's ray
+    gradients (origins / directions / pl_positions).  Returns the loss trajectory (one host sync per step, as upstream's
+    ``loss.item()`` print)."""
+    lr = ray_generator.config.opt_lr if lr is None else lr
+    optimizer = torch.optim.Adam(ray_generator.parameters(), lr=lr)
+    H, W = img_pixel_bundle.shape[0], img_pixel_bundle.shape[1]
+    bg = torch.full((1, 3), 1.0 if white_background else 0.0, device=device)
+    losses: List[float] = []
+    with torch.enable_grad():
+        for i in range(steps):
+            hi = torch.randint(0, H, (batch_size,), device="cpu", generator=generator)
+            wi = torch.randint(0, W, (batch_size,), device="cpu", generator=generator)
+            pb = img_pixel_bundle[hi, wi].to(device)
+            out = renderer(ray_generator(pb), background_rgb=bg, is_training=False)
+            loss = torch.nn.functional.l1_loss(out.rgb, pb.rgb_gt, reduction="sum") / (out.rgb.size(0) + 1e-5)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            losses.append(loss.item())
+            if log is not None:
+                log(f"register step: {i} loss: {losses[-1]}")
+    return losses
+
+
 def checkpoint_state(renderer: nn.Module, optimizer, scheduler, global_step: int, world_size: int = 1,
                      extra_pipeline_state: Optional[Dict[str, torch.Tensor]] = None) -> Dict:
     """``model_states`` dict as the reference pickles it: the renderer's tensors live under the ``renderer.`` prefix of

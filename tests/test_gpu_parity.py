@@ -466,3 +466,44 @@ def test_sdf_function_hip_backward(scene, npts):
         e_hip = (a.detach().cpu().double() - r).abs().max().item() / scale
         e_t32 = (b.detach().cpu().double() - r).abs().max().item() / scale
         assert e_hip <= 5.0 * e_t32 + 2e-5, (name, e_hip, e_t32)
+
+
+def test_register_view_recovers_pose_delta(scene_states):
+    """register_view (pipelines/base_pipeline.py:71-91) through the differentiable ray generator and the renderer's ray
+    gradients: a view rendered from a shifted camera is registered by optimising ``cam_pose_adjustment``; the L1 loss
+    must drop and the recovered translation must move towards the true shift."""
+    from nrhints_amd import RawPixelBundle, RayGenerator, RayGeneratorConfig
+    from nrhints_amd.pipeline import CameraModel
+    from nrhints_amd.training import register_view
+    st = scene_states["b"]
+    model = na.NeuSHintRenderer(na.NeuSModelConfig())
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+    model = model.cuda().eval()
+    H = W = 48
+    cam = CameraModel(H=H, W=W, cx=W / 2, cy=H / 2, fx=60.0, fy=60.0)
+    pos = torch.tensor([0.0, -3.5, 1.2])
+    fwd = -pos / pos.norm()
+    right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0])); right = right / right.norm()
+    up = torch.linalg.cross(right, fwd)
+    pose = torch.eye(4); pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = right, up, -fwd, pos
+    shift = torch.tensor([0.08, 0.0, -0.06])
+    hh, ww = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+
+    def bundle(p, rgb=None):
+        return RawPixelBundle(img_indices=torch.zeros(H, W, 1, dtype=torch.long), h_indices=hh[..., None], w_indices=ww[..., None],
+                              poses=p.expand(H, W, 4, 4), pls=torch.tensor([1.0, -3.0, 3.0]).expand(H, W, 3), rgb_gt=rgb)
+
+    true_pose = pose.clone(); true_pose[:3, 3] += shift
+    rg_true = RayGenerator(cam, 1, RayGeneratorConfig()).cuda()
+    with torch.no_grad():
+        gt = model(rg_true(bundle(true_pose).flatten().to("cuda")), background_rgb=torch.ones(1, 3).cuda()).rgb.reshape(H, W, 3).cpu()
+    rg = RayGenerator(cam, 1, RayGeneratorConfig(cam_opt_mode="SO3xR3")).cuda()
+    gen = torch.Generator().manual_seed(3)
+    losses = register_view(model, rg, bundle(pose, gt), "cuda", steps=120, batch_size=1024, lr=4e-3, generator=gen)
+    first, last = np.mean(losses[:10]), np.mean(losses[-10:])
+    assert last < 0.6 * first, (first, last)
+    t = rg.cam_pose_adjustment.detach().cpu()[0, :3]
+    assert (t - shift).norm() < 0.6 * shift.norm(), (t, shift)
+    # the renderer itself was not touched
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), T(np.asarray(st[k]))), k

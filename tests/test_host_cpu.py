@@ -130,3 +130,52 @@ def test_synthetic_rays_match_reference_near_far():
     np.testing.assert_allclose(mid[:, 0], -(o * d).sum(-1), atol=1e-4)
     o, d, pl, near, far = make_image_rays(8, 8, row0=2, row1=5)
     assert o.shape == (24, 3) and np.allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-6)
+
+
+def test_ray_generator_vs_reference_fixture():
+    """RayGenerator / exp maps against what the imported reference produced
+    (tests/golden/make_golden_raygen.py -> raygen.npz): rays, noise buffers (same RNG draws) and the gradients of a
+    fixed scalar w.r.t. cam_pose_adjustment / pl_adjustment, for off / SO3xR3 / SE3 / video / noise / z-plane configs."""
+    import numpy as np
+    from tests.conftest import load_npz
+    from nrhints_amd.containers import RawPixelBundle
+    from nrhints_amd.pipeline import CameraModel
+    from nrhints_amd.ray_generator import RayGenerator, RayGeneratorConfig, exp_map_SE3, exp_map_SO3xR3
+    g = load_npz("raygen.npz")
+    T = torch.from_numpy
+    tv = T(g["tangent"])
+    np.testing.assert_allclose(exp_map_SO3xR3(tv).numpy(), g["exp_SO3xR3"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(exp_map_SE3(tv).numpy(), g["exp_SE3"], rtol=0, atol=2e-7)
+    H, W, cx, cy, fx, fy, zn, zf = g["camera"]
+    cam = CameraModel(H=int(H), W=int(W), cx=float(cx), cy=float(cy), fx=float(fx), fy=float(fy))
+    c3 = T(g["probe"])
+    runs = {"off": (RayGeneratorConfig(), None, True),
+            "so3": (RayGeneratorConfig(cam_opt_mode="SO3xR3", pl_opt=True), None, True),
+            "se3": (RayGeneratorConfig(cam_opt_mode="SE3"), None, True),
+            "video": (RayGeneratorConfig(cam_opt_mode="SO3xR3", pl_opt=True), None, False),
+            "noise": (RayGeneratorConfig(cam_opt_mode="SO3xR3", cam_position_noise_std=0.02, cam_orientation_noise_std=0.03,
+                                         pl_position_noise_std=0.05), 11, True),
+            "zplanes": (RayGeneratorConfig(override_near_far_from_sphere=False), None, True)}
+    for tag, (cfg, seed, with_idx) in runs.items():
+        if seed is not None:
+            torch.manual_seed(seed)
+        rg = RayGenerator(cam, 5, cfg, zn=float(zn), zf=float(zf))
+        if hasattr(rg, "cam_pose_adjustment"):
+            rg.cam_pose_adjustment.data.copy_(T(g["adj"]))
+        if hasattr(rg, "pl_adjustment"):
+            rg.pl_adjustment.data.copy_(T(g["pladj"]))
+        for bname in ("cam_pose_noise", "pl_noise"):
+            if f"{tag}.{bname}" in g:
+                np.testing.assert_allclose(getattr(rg, bname).numpy(), g[f"{tag}.{bname}"], rtol=0, atol=2e-7)
+        pb = RawPixelBundle(img_indices=T(g["img_indices"]) if with_idx else None, h_indices=T(g["h_indices"]),
+                            w_indices=T(g["w_indices"]), poses=T(g["poses"]), pls=T(g["pls"]))
+        rb = rg(pb)
+        for k in ("origins", "directions", "pl_positions", "nears", "fars"):
+            np.testing.assert_allclose(getattr(rb, k).detach().numpy(), g[f"{tag}.{k}"], rtol=0, atol=3e-6, err_msg=f"{tag}.{k}")
+        names = [n for n, _ in rg.named_parameters()]
+        if names and with_idx:
+            loss = (rb.origins * c3).sum() + (rb.directions * c3.flip(0)).sum() * 2.0 + (rb.pl_positions * c3).sum() * 0.5 + \
+                   (rb.nears * rb.fars).sum() * 0.1
+            for n, gr in zip(names, torch.autograd.grad(loss, list(rg.parameters()))):
+                want = g[f"{tag}.grad.{n}"]
+                np.testing.assert_allclose(gr.numpy(), want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()), err_msg=f"{tag}.grad.{n}")
