@@ -75,10 +75,28 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // expf/log1pf pair costs ~300 VALU instructions per activation.  log2(1+e) instead of log1p(e) costs at most
 // 6e-8 * ln2/100 = 4e-10 ABSOLUTE error in h - below half an ulp of the O(1e-2..1) activations it feeds.
 // The "linear above 20" switch is taken on t*log2(e) > 20*log2(e); at the switch both branches agree to 2e-11.
+#ifndef NRH_SOFTPLUS_V2
+#define NRH_SOFTPLUS_V2 1     // branch-free form  max(z,0) + log2(1 + 2^-|t|) ln2/100  (no compare/select on the value path)
+#endif
 template <bool WANT_D>
 __device__ __forceinline__ void softplus100_4(const f32x4 z, f32x4& h, f32x4& d) {
   const f32x4 t = z * 144.26950408889634074f;  // 100 * log2(e)
   f32x4 e, l;
+#if NRH_SOFTPLUS_V2
+  // softplus(z) = max(z, 0) + log1p(exp(-|100 z|)) / 100: mathematically the reference's log1p(exp(100 z))/100 below its
+  // threshold and z (+ < 2e-11) above it, with no overflow for any z, so the "linear above 20" switch
+  // (fields/sdf_field.py:104, threshold 20) needs no compare/select.  sigma' = (z >= 0 ? 1 : e) / (1 + e).
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(-__builtin_fabsf(t[r]));
+  const f32x4 ope = e + 1.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) l[r] = __builtin_amdgcn_logf(ope[r]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    h[r] = __builtin_fmaf(l[r], 6.9314718055994530942e-3f, __builtin_fmaxf(z[r], 0.0f));
+    if (WANT_D) d[r] = (z[r] >= 0.0f ? 1.0f : e[r]) * __builtin_amdgcn_rcpf(ope[r]);
+  }
+#else
 #pragma unroll
   for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
   const f32x4 ope = e + 1.0f;
@@ -91,6 +109,7 @@ __device__ __forceinline__ void softplus100_4(const f32x4 z, f32x4& h, f32x4& d)
     h[r] = lin ? z[r] : l[r];
     if (WANT_D) d[r] = lin ? 1.0f : e[r] * __builtin_amdgcn_rcpf(ope[r]);
   }
+#endif
 }
 
 // sin for |x| up to a few 1e3: 3-term Cody-Waite reduction by pi/2 (fma) + cephes minimax kernels on

@@ -75,11 +75,20 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr float LO_SCALE = 2048.0f;
 constexpr float LO_UNSCALE = 1.0f / 2048.0f;
 
+#ifndef NRH_SPLIT_FMA
+#define NRH_SPLIT_FMA 1       // residual a - hi as one fma with the fp16 operand read in place (v_fma_mix_f32), no cvt back
+#endif
 __device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
 #if NRH_PKRTZ
   typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
   const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+#if NRH_SPLIT_FMA
+  const float ra = __builtin_fmaf((float)h.x, -LO_SCALE, a * LO_SCALE);
+  const float rb = __builtin_fmaf((float)h.y, -LO_SCALE, b * LO_SCALE);
+  const h16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+#else
   const h16x2 l = __builtin_amdgcn_cvt_pkrtz((a - (float)h.x) * LO_SCALE, (b - (float)h.y) * LO_SCALE);
+#endif
 #else
   const f16x2 h = {(_Float16)a, (_Float16)b};
   const f16x2 l = {(_Float16)((a - (float)h.x) * LO_SCALE), (_Float16)((b - (float)h.y) * LO_SCALE)};

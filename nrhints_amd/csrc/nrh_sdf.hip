@@ -270,10 +270,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             }
             if constexpr (TRAIN) {
               ds_store(7, ch, d0, d1);
-              save_rows(a.save_t, 7, ch, d0 * (p.b0 / 3.0f), d1 * (p.b1 / 3.0f));
+              save_rows(a.save_t, 7, ch, d0 * (p.b0 * (1.0f / 3.0f)), d1 * (p.b1 * (1.0f / 3.0f)));
             } else if (MODE >= 1) {
-              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)), d0 * (p.b0 / 3.0f));
-              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)), d1 * (p.b1 / 3.0f));
+              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)), d0 * (p.b0 * (1.0f / 3.0f)));
+              st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)), d1 * (p.b1 * (1.0f / 3.0f)));
             }
           } else if (MODE >= 1) {
             ds_store(s, ch, d0, d1);
