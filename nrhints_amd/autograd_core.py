@@ -84,12 +84,25 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
     weights = alpha * trans
     n_hat = F.normalize(grad, dim=-1)
-    rep = lambda x: x[:, None, :].expand(n, T, x.shape[-1]).reshape(n * T, -1)
-    parts = [pts, _enc(view, 4), grad if analytic_normal else n_hat, _enc(rep(pl), 4), feat]
+    # reflectance net, layer 0 by column blocks of the reference's 361-wide input
+    #   [pts 0:3 | enc(view) 3:30 | normal 30:33 | enc(pl) 33:60 | feat 60:316 | enc(vis) 316:325 | enc(cue) 325:361]
+    # (fields/reflectance_network.py:77-82): the view / light / visibility / cue encodings are constant along a ray, so
+    # their contribution is one [N,99] x [99,256] product broadcast over the 128 samples instead of a 361-wide
+    # concatenation per sample (190 MB at 1024 rays); autograd carries the ray gradients through the small per-ray part.
+    w0, b0 = d["col_w0"], d["col_b0"]
+    per_ray = [_enc(dirs, 4), _enc(pl, 4)]
+    cols = [torch.arange(3, 30), torch.arange(33, 60)]
     if vis is not None:  # vis / cue are None for the pl-naive model (no hints)
-        parts += [_enc(rep(vis), 4), _enc(rep(cue), 4)]
-    x = torch.cat(parts, dim=-1)
-    for l in range(5):
+        per_ray += [_enc(vis, 4), _enc(cue, 4)]
+        cols += [torch.arange(316, 325), torch.arange(325, 361)]
+    ray_cols = torch.cat(cols).to(w0.device)
+    pn_cols = torch.tensor([0, 1, 2, 30, 31, 32], device=w0.device)
+    normal = grad if analytic_normal else n_hat
+    x = _linear(feat, w0[:, 60:316], b0)                                                   # [P,256] the big block
+    x = x + _linear(torch.cat([pts, normal], dim=-1), w0[:, pn_cols], torch.zeros_like(b0))  # per-sample 6 columns
+    x = (x.reshape(n, T, -1) + (torch.cat(per_ray, dim=-1) @ w0[:, ray_cols].t())[:, None, :]).reshape(n * T, -1)
+    x = torch.relu(x)
+    for l in range(1, 5):
         x = _linear(x, d[f"col_w{l}"], d[f"col_b{l}"])
         if l < 4:
             x = torch.relu(x)

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -130,3 +131,60 @@ def test_sdf_function_manual_backward_matches_second_order_autograd(scene_states
     assert abs(l1.item() - l2.item()) < 1e-10 * max(1.0, abs(l2.item()))
     for name, a, b in zip(["pts"] + list(leaves), g1, g2):
         assert (a - b).abs().max().item() <= 1e-10 * (b.abs().max().item() + 1e-30), name
+
+
+@pytest.mark.parametrize("hints", [True, False])
+def test_render_core_matches_oracle_formulation(scene_states, hints):
+    """autograd_core.render_core (hand-derived SDF backward + the column-block form of the reflectance net's first layer)
+    against the reference formulation restated in the oracle - second-order autograd, 361-wide concatenated input
+    (models/neus_hint_model.py:504-510, :521-525, :621-637) - in fp64 on the CPU: rgb, weights, normals and the
+    gradients w.r.t. all 46 raw parameters and the rays."""
+    import numpy as np
+    from nrhints_amd import autograd_core, packing
+    from nrhints_amd.synthetic import naive_state
+    from oracle import neus_oracle as O
+    torch.manual_seed(1)
+    f64 = torch.float64
+    st = scene_states["b"] if hints else naive_state(scene_states["b"])
+    n, T_ = 4, 128
+    o = (torch.randn(n, 3, dtype=f64) * 0.2)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, dtype=f64), dim=-1)
+    pl = torch.randn(n, 3, dtype=f64) * 3.0
+    mid = torch.rand(n, T_, dtype=f64).sort(-1).values * 0.9
+    dists = torch.rand(n, T_, dtype=f64) * 0.02
+    vis = torch.rand(n, 1, dtype=f64) if hints else None
+    cue = torch.rand(n, 4, dtype=f64) if hints else None
+    bg = torch.ones(1, 3, dtype=f64)
+    gt = torch.rand(n, 3, dtype=f64)
+
+    def run(which):
+        leaves = {k: torch.tensor(np.asarray(v), dtype=f64).requires_grad_(True) for k, v in st.items()}
+        rays = [t.clone().requires_grad_(True) for t in (o, dirs, pl)]
+        if which == "core":
+            out = autograd_core.render_core(packing.dense_params(leaves), leaves["deviation_network.variance"], *rays, mid, dists,
+                                            vis, cue, 0.6, bg, sdf_impl="manual")
+            rgb, w, g = out["rgb"], out["weights"], out["analytic_normals"]
+        else:
+            P = O.params_from_state(leaves, dtype=f64)
+            ro, rd, rpl = rays
+            pts = (ro[:, None, :] + rd[:, None, :] * mid[..., None]).reshape(-1, 3)
+            sdf, feat = O.sdf_forward(P, pts)
+            grad = O.sdf_gradient_autograd(P, pts, create_graph=True)
+            view = rd[:, None, :].expand(n, T_, 3).reshape(-1, 3)
+            inv_s = torch.exp(P.variance * 10.0).clip(1e-6, 1e6)
+            alpha = O.alpha_from(sdf, grad, view, dists.reshape(-1, 1), inv_s, 0.6).reshape(n, T_)
+            w = alpha * O.excl_cumprod_one_minus(alpha)
+            rep = lambda x: x[:, None, :].expand(n, T_, x.shape[-1]).reshape(n * T_, -1)
+            col = O.color_forward(P, pts, torch.nn.functional.normalize(grad, dim=-1), view, feat, rep(rpl),
+                                  rep(vis) if hints else None, rep(cue) if hints else None).reshape(n, T_, 3)
+            rgb = (col * w[..., None]).sum(1) + bg * (1.0 - w.sum(-1, keepdim=True))
+            g = grad.reshape(n, T_, 3)
+        loss = (rgb - gt).abs().sum() / n + 0.1 * ((g.norm(dim=-1) - 1.0) ** 2).mean() + 0.01 * (w ** 2).sum()
+        grads = torch.autograd.grad(loss, list(leaves.values()) + rays)
+        return rgb.detach(), w.detach(), grads, list(leaves) + ["o", "d", "pl"]
+
+    rgb1, w1, g1, names = run("core")
+    rgb2, w2, g2, _ = run("oracle")
+    assert (rgb1 - rgb2).abs().max() < 1e-12 and (w1 - w2).abs().max() < 1e-12
+    for name, a, b in zip(names, g1, g2):
+        assert (a - b).abs().max().item() <= 1e-9 * (b.abs().max().item() + 1e-12), name
