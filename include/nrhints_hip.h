@@ -93,6 +93,19 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            void* stream);
 
+/* ---- alpha stage, training ---------------------------------------------------------------------------------
+ * NeuSHintRenderer.get_alpha + compositing weights + unit normals (models/neus_hint_model.py:339-356, :521-525, :584)
+ * for 128 samples per ray and the adjoint of exactly that (what autograd does in the reference's backward).
+ *   forward : sdf [nrays,128], grad [nrays*128,3], rd [nrays,3], dists [nrays,128] -> weights [nrays,128],
+ *             nhat [nrays*128,3]
+ *   backward: + weights_bar [nrays,128], nhat_bar [nrays*128,3] (may be null) -> sdf_bar, grad_bar, rd_bar [nrays,3],
+ *             invs_bar [nrays] (per-ray partial of the adjoint of inv_s; the caller sums and chains to `variance`) */
+int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                            float cos_anneal, long long nrays, float* weights, float* nhat, void* stream);
+int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                             float cos_anneal, long long nrays, const float* weights_bar, const float* nhat_bar,
+                             float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream);
+
 /* ---- hierarchical sampler (one launch = merge the previous 16 samples and/or draw 16 new ones) ------------
  * NeuSHintRenderer.up_sample (models/neus_hint_model.py:270-315) + sample_pdf (:21-65, det=True) +
  * cat_z_vals (:317-331) + section mid-points (:491-496, :416-418).

@@ -50,6 +50,59 @@ def _linear(x, w, b):
     return _LinearBigK.apply(x, w, b) if (x.is_cuda and x.shape[0] >= 4096) else F.linear(x, w, b)
 
 
+class AlphaWeightsNormalsHip(torch.autograd.Function):
+    """(sdf [P,1], grad [P,3], dirs [N,3], dists [N,128], variance) -> (weights [N,128], n_hat [P,3]) with the forward
+    and the adjoint in one HIP kernel each (csrc/nrh_rays_train.hip) - get_alpha, the exclusive transmittance product
+    and F.normalize of models/neus_hint_model.py:339-356, :521-525, :584 and what autograd derives from them."""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float):
+        from . import _lib
+        lib = _lib.load()
+        n = dirs.shape[0]
+        f32c = lambda t: t.detach().to(torch.float32).contiguous()
+        sdf_c, grad_c, dirs_c, dists_c = f32c(sdf), f32c(grad), f32c(dirs), f32c(dists)
+        weights = torch.empty(n, 128, dtype=torch.float32, device=dirs.device)
+        nhat = torch.empty(n * 128, 3, dtype=torch.float32, device=dirs.device)
+        P = _lib.ptr
+        _lib.check(lib.nrh_alpha_train_forward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), float(inv_s), float(cos_anneal), n,
+                                               P(weights), P(nhat), _lib.stream_handle()), "nrh_alpha_train_forward")
+        ctx.save_for_backward(sdf_c, grad_c, dirs_c, dists_c)
+        ctx.consts = (float(inv_s), float(cos_anneal))
+        return weights, nhat
+
+    @staticmethod
+    def backward(ctx, wbar, nbar):
+        from . import _lib
+        lib = _lib.load()
+        sdf_c, grad_c, dirs_c, dists_c = ctx.saved_tensors
+        inv_s, cos_anneal = ctx.consts
+        n = dirs_c.shape[0]
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dirs_c.device)
+        wbar = torch.zeros(n, 128, dtype=torch.float32, device=dirs_c.device) if wbar is None else wbar.to(torch.float32).contiguous()
+        nbar = None if nbar is None else nbar.to(torch.float32).contiguous()
+        sdf_bar, grad_bar, rd_bar, invs_bar = new(n * 128, 1), new(n * 128, 3), new(n, 3), new(n)
+        P = _lib.ptr
+        _lib.check(lib.nrh_alpha_train_backward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, n, P(wbar), P(nbar),
+                                                P(sdf_bar), P(grad_bar), P(rd_bar), P(invs_bar), _lib.stream_handle()),
+                   "nrh_alpha_train_backward")
+        # inv_s = clip(exp(10 variance), 1e-6, 1e6): d inv_s / d variance = 10 inv_s inside the clip range
+        var_bar = invs_bar.sum() * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)
+        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None
+
+
+_COL_INDEX = {}
+
+
+def _col_index(device, hints: bool):
+    """Column indices of the per-ray and of the (pts, normal) blocks in the reference's reflectance input, per device."""
+    key = (str(device), hints)
+    if key not in _COL_INDEX:
+        cols = [torch.arange(3, 30), torch.arange(33, 60)] + ([torch.arange(316, 325), torch.arange(325, 361)] if hints else [])
+        _COL_INDEX[key] = (torch.cat(cols).to(device), torch.tensor([0, 1, 2, 30, 31, 32], device=device))
+    return _COL_INDEX[key]
+
+
 def _sdf_net(d: Dict[str, torch.Tensor], pts: torch.Tensor):
     e = _enc(pts * 3.0, 6)
     h = e
@@ -74,16 +127,20 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     else:                           # hand-derived backward (sdf_function.py): no double-backward graph
         sdf, feat, grad = sdf_value_feat_grad(d, pts, impl=sdf_impl, packed=packed, pre=pre)
     inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
-    view = dirs[:, None, :].expand(n, T, 3).reshape(-1, 3)
-    true_cos = (view * grad).sum(-1, keepdim=True)
-    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + F.relu(-true_cos) * cos_anneal)
-    dd = dists.reshape(-1, 1)
-    c_prev = torch.sigmoid((sdf - iter_cos * dd * 0.5) * inv_s)
-    c_next = torch.sigmoid((sdf + iter_cos * dd * 0.5) * inv_s)
-    alpha = ((c_prev - c_next + 1e-5) / (c_prev + 1e-5)).clip(0.0, 1.0).reshape(n, T)
-    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
-    weights = alpha * trans
-    n_hat = F.normalize(grad, dim=-1)
+    if sdf_impl == "hip" and packed is not None:
+        # alpha, transmittance product, weights and unit normals: one HIP kernel forward, one for the adjoint
+        weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal)
+    else:
+        view = dirs[:, None, :].expand(n, T, 3).reshape(-1, 3)
+        true_cos = (view * grad).sum(-1, keepdim=True)
+        iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + F.relu(-true_cos) * cos_anneal)
+        dd = dists.reshape(-1, 1)
+        c_prev = torch.sigmoid((sdf - iter_cos * dd * 0.5) * inv_s)
+        c_next = torch.sigmoid((sdf + iter_cos * dd * 0.5) * inv_s)
+        alpha = ((c_prev - c_next + 1e-5) / (c_prev + 1e-5)).clip(0.0, 1.0).reshape(n, T)
+        trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
+        weights = alpha * trans
+        n_hat = F.normalize(grad, dim=-1)
     # reflectance net, layer 0 by column blocks of the reference's 361-wide input
     #   [pts 0:3 | enc(view) 3:30 | normal 30:33 | enc(pl) 33:60 | feat 60:316 | enc(vis) 316:325 | enc(cue) 325:361]
     # (fields/reflectance_network.py:77-82): the view / light / visibility / cue encodings are constant along a ray, so
@@ -91,12 +148,9 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     # concatenation per sample (190 MB at 1024 rays); autograd carries the ray gradients through the small per-ray part.
     w0, b0 = d["col_w0"], d["col_b0"]
     per_ray = [_enc(dirs, 4), _enc(pl, 4)]
-    cols = [torch.arange(3, 30), torch.arange(33, 60)]
     if vis is not None:  # vis / cue are None for the pl-naive model (no hints)
         per_ray += [_enc(vis, 4), _enc(cue, 4)]
-        cols += [torch.arange(316, 325), torch.arange(325, 361)]
-    ray_cols = torch.cat(cols).to(w0.device)
-    pn_cols = torch.tensor([0, 1, 2, 30, 31, 32], device=w0.device)
+    ray_cols, pn_cols = _col_index(w0.device, vis is not None)
     normal = grad if analytic_normal else n_hat
     x = _linear(feat, w0[:, 60:316], b0)                                                   # [P,256] the big block
     x = x + _linear(torch.cat([pts, normal], dim=-1), w0[:, pn_cols], torch.zeros_like(b0))  # per-sample 6 columns

@@ -4,6 +4,7 @@
 #include "nrh_sdf_train.hip"
 #include "nrh_color.hip"
 #include "nrh_rays.hip"
+#include "nrh_rays_train.hip"
 
 #include <stdio.h>
 #include <string.h>
@@ -208,7 +209,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 106; }
+int nrh_version(void) { return 107; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -318,6 +319,37 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   if (precision == 0) hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<0>), g, blk, nrh::MLP_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<1>), g, blk, nrh::MLP_LDS_BYTES, st, a);
   return check_launch("sdf_adjoint_kernel");
+}
+
+int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                            float cos_anneal, long long nrays, float* weights, float* nhat, void* stream) {
+  if (!sdf || !grad || !rd || !dists || !weights || !nhat) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::AlphaTrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.weights = weights; a.nhat = nhat;
+  const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
+  hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("alpha_train_kernel<fwd>");
+}
+
+int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                             float cos_anneal, long long nrays, const float* weights_bar, const float* nhat_bar,
+                             float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
+  if (!sdf || !grad || !rd || !dists || !weights_bar || !sdf_bar || !grad_bar || !rd_bar || !invs_bar)
+    return fail(NRH_E_INVALID, "nrh_alpha_train_backward: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_train_backward: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::AlphaTrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.weights_bar = weights_bar; a.nhat_bar = nhat_bar; a.sdf_bar = sdf_bar; a.grad_bar = grad_bar; a.rd_bar = rd_bar;
+  a.invs_bar = invs_bar;
+  const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
+  hipLaunchKernelGGL(nrh::alpha_train_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("alpha_train_kernel<bwd>");
 }
 
 int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const float* znew_in,

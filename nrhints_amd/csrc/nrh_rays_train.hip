@@ -1,0 +1,152 @@
+// Training counterpart of the per-ray alpha stage: alpha from the SDF, compositing weights and unit normals, and the
+// adjoint of exactly that (models/neus_hint_model.py:339-356 get_alpha, :521-525 weights, :584 normalize), one
+// wavefront per ray, two of the 128 samples per lane.  The adjoint kernel RECOMPUTES the forward quantities from the
+// same inputs (8 floats per sample) instead of saving them.  Replaces ~150 small PyTorch kernels per training step;
+// rgb = sum w c + bg (1 - sum w) (:635-637) stays three torch ops on top.
+//
+//   tc = d.g;  ic = -(relu(-tc/2 + 1/2)(1-ca) + relu(-tc) ca);  e+- = s +- ic delta/2;  pc = sig(e- S), nc = sig(e+ S)
+//   q = (pc - nc + 1e-5)/(pc + 1e-5);  alpha = clip(q, 0, 1);  f = 1 - alpha + 1e-7;  T_i = prod_{k<i} f_k;  w = alpha T
+//   n = g / max(|g|, 1e-12)
+#include "nrh_common.h"
+
+namespace nrh {
+
+constexpr int TRAIN_RAYS_PER_BLOCK = 4;
+
+struct AlphaTrainArgs {
+  const float* sdf;      // [N,128]
+  const float* grad;     // [N*128,3]
+  const float* rd;       // [N,3]
+  const float* dists;    // [N,128]
+  float inv_s;
+  float cos_anneal;
+  int nrays;
+  // forward outputs
+  float* weights;        // [N,128]
+  float* nhat;           // [N*128,3]
+  // adjoint inputs
+  const float* weights_bar;  // [N,128]
+  const float* nhat_bar;     // [N*128,3] or null
+  // adjoint outputs
+  float* sdf_bar;        // [N,128]
+  float* grad_bar;       // [N*128,3]
+  float* rd_bar;         // [N,3]
+  float* invs_bar;       // [N]   per-ray partial of d loss / d inv_s
+};
+
+// inclusive SUFFIX sum over the 128-long per-ray sequence (j0 = lane, j1 = lane + 64)
+__device__ __forceinline__ void suffix_sum_128(float x0, float x1, float& s0, float& s1) {
+  const int l = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t0 = __shfl_down(x0, o, 64), t1 = __shfl_down(x1, o, 64);
+    if (l + o < 64) { x0 += t0; x1 += t1; }
+  }
+  s1 = x1;
+  s0 = x0 + __shfl(x1, 0, 64);
+}
+
+template <bool ADJOINT>
+__global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * TRAIN_RAYS_PER_BLOCK + wave;
+  const bool active = ray_raw < a.nrays;
+  const long long ray = active ? ray_raw : a.nrays - 1;
+  const float dx = a.rd[ray * 3 + 0], dy = a.rd[ray * 3 + 1], dz = a.rd[ray * 3 + 2];
+  const float S = a.inv_s, ca = a.cos_anneal;
+
+  float s[2], g[2][3], del[2], tc[2], ic[2], en[2], ep[2], pc[2], nc[2], q[2], al[2], f[2], gn[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const long long P = ray * 128 + lane + 64 * e;
+    s[e] = a.sdf[P];
+    del[e] = a.dists[P];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[e][c] = a.grad[P * 3 + c];
+    tc[e] = dx * g[e][0] + dy * g[e][1] + dz * g[e][2];
+    ic[e] = -(fmaxf(-tc[e] * 0.5f + 0.5f, 0.0f) * (1.0f - ca) + fmaxf(-tc[e], 0.0f) * ca);
+    en[e] = s[e] + ic[e] * del[e] * 0.5f;
+    ep[e] = s[e] - ic[e] * del[e] * 0.5f;
+    pc[e] = sigmoidf_(ep[e] * S);
+    nc[e] = sigmoidf_(en[e] * S);
+    q[e] = (pc[e] - nc[e] + 1e-5f) / (pc[e] + 1e-5f);
+    al[e] = fminf(fmaxf(q[e], 0.0f), 1.0f);
+    f[e] = 1.0f - al[e] + 1e-7f;
+    gn[e] = fmaxf(sqrtf(g[e][0] * g[e][0] + g[e][1] * g[e][1] + g[e][2] * g[e][2]), 1e-12f);  // F.normalize eps
+  }
+  float T[2];
+  excl_prod_128(f[0], f[1], T[0], T[1]);
+  const float w[2] = {al[0] * T[0], al[1] * T[1]};
+
+  if (!ADJOINT) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const long long P = ray * 128 + lane + 64 * e;
+        a.weights[P] = w[e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.nhat[P * 3 + c] = g[e][c] / gn[e];
+      }
+    }
+    return;
+  }
+
+  // ---------------- adjoint ----------------
+  float wb[2], x[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    wb[e] = a.weights_bar[ray * 128 + lane + 64 * e];
+    x[e] = wb[e] * w[e];   // = Tbar_i T_i
+  }
+  float suf[2];
+  suffix_sum_128(x[0], x[1], suf[0], suf[1]);
+  float rdb[3] = {0.f, 0.f, 0.f}, Sb = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const long long P = ray * 128 + lane + 64 * e;
+    const float fbar = (suf[e] - x[e]) / f[e];                 // sum_{i>k} Tbar_i T_i / f_k  (cumprod backward)
+    const float abar = wb[e] * T[e] - fbar;
+    const float qbar = (q[e] >= 0.0f && q[e] <= 1.0f) ? abar : 0.0f;   // clamp passes the gradient on [min, max]
+    const float ipc = 1.0f / (pc[e] + 1e-5f);
+    const float pcb = qbar * (1.0f - q[e]) * ipc;
+    const float ncb = -qbar * ipc;
+    const float epS = pcb * pc[e] * (1.0f - pc[e]);
+    const float enS = ncb * nc[e] * (1.0f - nc[e]);
+    Sb += epS * ep[e] + enS * en[e];
+    const float epb = epS * S, enb = enS * S;
+    const float icb = (enb - epb) * del[e] * 0.5f;
+    const float u1 = -tc[e] * 0.5f + 0.5f, u2 = -tc[e];
+    const float u1b = (u1 > 0.0f) ? -icb * (1.0f - ca) : 0.0f;
+    const float u2b = (u2 > 0.0f) ? -icb * ca : 0.0f;
+    const float tcb = -0.5f * u1b - u2b;
+    float gb[3] = {tcb * dx, tcb * dy, tcb * dz};
+    rdb[0] += tcb * g[e][0];
+    rdb[1] += tcb * g[e][1];
+    rdb[2] += tcb * g[e][2];
+    if (a.nhat_bar) {
+      // n = g / max(|g|, eps):  gbar += (nbar - n (n . nbar)) / |g|   (0 through the clamp when |g| < eps)
+      const float nb[3] = {a.nhat_bar[P * 3 + 0], a.nhat_bar[P * 3 + 1], a.nhat_bar[P * 3 + 2]};
+      const float nx = g[e][0] / gn[e], ny = g[e][1] / gn[e], nz = g[e][2] / gn[e];
+      const float dot = nx * nb[0] + ny * nb[1] + nz * nb[2];
+      const bool clamped = gn[e] <= 1e-12f;
+      gb[0] += (nb[0] - (clamped ? 0.0f : nx * dot)) / gn[e];
+      gb[1] += (nb[1] - (clamped ? 0.0f : ny * dot)) / gn[e];
+      gb[2] += (nb[2] - (clamped ? 0.0f : nz * dot)) / gn[e];
+    }
+    if (active) {
+      a.sdf_bar[P] = enb + epb;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.grad_bar[P * 3 + c] = gb[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rdb[c] = wave_sum(rdb[c]);
+  Sb = wave_sum(Sb);
+  if (active && lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rd_bar[ray * 3 + c] = rdb[c];
+    a.invs_bar[ray] = Sb;
+  }
+}
+
+}  // namespace nrh

@@ -52,6 +52,23 @@ def pack_stage(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return wp.reshape(nch, 2, 16, kb, 4, 4).permute(0, 1, 3, 4, 2, 5).reshape(-1)
 
 
+def pack_stages(ws, rows: int, cols: int, precision: int) -> torch.Tensor:
+    """Several same-shape stages in one pass (a training step re-packs every step: ~10 small kernels per call, so the
+    15 regular 256x256 SDF stages go through as one [15,256,256] batch).  Equals the concatenation of the per-stage
+    packings, in order."""
+    src = ws if precision == 0 else [w.detach().float() for w in ws]      # the fp32 packing stays differentiable
+    w3 = torch.stack([torch.nn.functional.pad(w, (0, cols - w.shape[1], 0, rows - w.shape[0])) for w in src])
+    B = w3.shape[0]
+    if precision == 0:
+        nch, kb = rows // 32, cols // 16
+        return w3.reshape(B, nch, 2, 16, kb, 4, 4).permute(0, 1, 2, 4, 5, 3, 6).reshape(-1)
+    nch, ks = rows // 32, cols // 32
+    hi, lo = split_f16(w3)
+    both = torch.stack([hi, lo], 1)                                 # [B, part, rows, cols]
+    t = both.reshape(B, 2, nch, 2, 16, ks, 2, 4, 4).permute(0, 2, 3, 5, 1, 7, 4, 6, 8)
+    return t.reshape(-1).contiguous()
+
+
 LO_SCALE = 2048.0
 
 
@@ -120,12 +137,8 @@ def pack_sdf(d: Dict[str, torch.Tensor], precision: int = 0) -> Tuple[torch.Tens
     w = [d[f"sdf_w{i}"] for i in range(8)]
     w4 = w[4] / math.sqrt(2.0)           # cat([h, embed]) / sqrt(2) folded into the weights
     fwd = [w[0], w[1], w[2], w[3], w4, w[5], w[6], w[7]]
-    parts = [ps(fwd[0], 256, 64)]
-    parts += [ps(fwd[l], 256, 256) for l in range(1, 8)]
-    parts.append(ps(d["feat_w"], 256, 256))
-    parts += [ps(fwd[l].t(), 256, 256) for l in range(7, 0, -1)]
-    parts.append(ps(fwd[0].t(), 64, 256))
-    packed = torch.cat(parts)
+    regular = [fwd[l] for l in range(1, 8)] + [d["feat_w"]] + [fwd[l].t() for l in range(7, 0, -1)]
+    packed = torch.cat([ps(fwd[0], 256, 64), pack_stages(regular, 256, 256, precision), ps(fwd[0].t(), 64, 256)])
     assert packed.numel() == SDF_PACKED_FLOATS * (1 if precision == 0 else 2)
     bias = torch.cat([_pad_vec(d[f"sdf_b{i}"], 256) for i in range(8)] + [d["feat_b"]])
     head = torch.cat([d["sdf_head_w"].reshape(-1), d["sdf_head_b"].reshape(-1)])
@@ -155,9 +168,8 @@ def pack_color(d: Dict[str, torch.Tensor], precision: int = 0, hints: bool = Tru
     ps = pack_stage if precision == 0 else pack_stage_h3
     fi, mi = color_input_permutation(hints)
     w0 = d["col_w0"]
-    parts = [ps(w0[:, fi.to(w0.device)], 256, 256), ps(w0[:, mi.to(w0.device)], 256, 128 if hints else 64)]
-    parts += [ps(d[f"col_w{l}"], 256, 256) for l in (1, 2, 3)]
-    parts.append(ps(d["col_w4"], 32, 256))
+    parts = [ps(w0[:, fi.to(w0.device)], 256, 256), ps(w0[:, mi.to(w0.device)], 256, 128 if hints else 64),
+             pack_stages([d[f"col_w{l}"] for l in (1, 2, 3)], 256, 256, precision), ps(d["col_w4"], 32, 256)]
     packed = torch.cat(parts)
     assert packed.numel() == col_packed_floats(hints) * (1 if precision == 0 else 2)
     bias = torch.cat([d["col_b0"], d["col_b1"], d["col_b2"], d["col_b3"], _pad_vec(d["col_b4"], 16)])

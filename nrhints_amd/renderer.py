@@ -141,13 +141,14 @@ class NeuSHintRenderer(nn.Module):
     def _param_key(self, device):
         return (str(device), self.precision) + tuple((id(p), p._version) for p in self.parameters())
 
-    def packed_params(self, device):
-        """Fold weight-norm and pack for the kernels; cached until a parameter changes."""
+    def packed_params(self, device, dense=None):
+        """Fold weight-norm and pack for the kernels; cached until a parameter changes.  ``dense``: the already folded
+        matrices of the CURRENT parameters (the training forward folds them once, with autograd history)."""
         key = self._param_key(device)
         if self._packed_key != key:
             with torch.no_grad():
                 state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
-                d = packing.dense_params(state)
+                d = packing.dense_params(state) if dense is None else {k: v.detach().to(device=device, dtype=torch.float32) for k, v in dense.items()}
                 packing.check_default_shapes(d, bool(self._hints))
                 prec = _lib.PRECISIONS[self.precision]
                 sw, sb, sh = packing.pack_sdf(d, prec)
@@ -218,6 +219,11 @@ class NeuSHintRenderer(nn.Module):
             if bg.numel() != 3:
                 raise ValueError("background_rgb must be [1,3]")
 
+        dense = None
+        if needs_grad:
+            # fold weight-norm once, with autograd history; the kernels' packed copies are cut from the same matrices
+            dense = packing.dense_params(dict(self.named_parameters()))
+            self.packed_params(device, dense=dense)
         fused_train = needs_grad and self.sdf_backward == "hip" and n <= self.max_fused_train_rays
         if fused_train:
             res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints)
@@ -231,7 +237,6 @@ class NeuSHintRenderer(nn.Module):
         T = N_SAMPLES_TOTAL
         if needs_grad:
             # differentiable part (render_core) over the HIP results; see autograd_core.py
-            dense = packing.dense_params(dict(self.named_parameters()))
             core = autograd_core.render_core(
                 dense, self.deviation_network.variance, o_g.to(torch.float32), d_g.to(torch.float32),
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,

@@ -37,7 +37,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 106
+    assert lib.nrh_version() >= 107
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
@@ -507,3 +507,40 @@ def test_register_view_recovers_pose_delta(scene_states):
     # the renderer itself was not touched
     for k, v in model.state_dict().items():
         assert torch.equal(v.cpu(), T(np.asarray(st[k]))), k
+
+
+def test_alpha_train_kernels_vs_autograd(scene):
+    """AlphaWeightsNormalsHip (csrc/nrh_rays_train.hip: alpha, exclusive transmittance product, weights, unit normals and
+    their adjoint) against the same expressions differentiated by torch autograd in fp64
+    (models/neus_hint_model.py:339-356, :521-525, :584)."""
+    from nrhints_amd.autograd_core import AlphaWeightsNormalsHip
+    tag, model, packed, _, _ = scene
+    rs = np.random.RandomState(11)
+    n, T_ = 37, 128
+    sdf = rs.uniform(-0.02, 0.05, size=(n * T_, 1))
+    grad = rs.randn(n * T_, 3) * 0.7
+    grad[5] = 0.0                                      # F.normalize clamp branch
+    dirs = rs.randn(n, 3); dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    dists = rs.uniform(0.002, 0.03, size=(n, T_))
+    var = float(model.deviation_network.variance.item())
+    cw, cn = rs.randn(n, T_), rs.randn(n * T_, 3)
+    for ca in (0.0, 0.4, 1.0):
+        # fp64 autograd reference on the CPU
+        t64 = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+        s_, g_, d_, v_ = t64(sdf), t64(grad), t64(dirs), t64(np.array(var))
+        inv_s = torch.exp(v_ * 10.0).clip(1e-6, 1e6)
+        alpha = orc.alpha_from(s_, g_, d_[:, None, :].expand(n, T_, 3).reshape(-1, 3), torch.tensor(dists).reshape(-1, 1), inv_s, ca)
+        w_ref = alpha.reshape(n, T_) * orc.excl_cumprod_one_minus(alpha.reshape(n, T_))
+        n_ref = torch.nn.functional.normalize(g_, dim=-1)
+        ref = torch.autograd.grad((w_ref * torch.tensor(cw)).sum() + (n_ref * torch.tensor(cn)).sum(), [s_, g_, d_, v_])
+        # HIP
+        s2, g2, d2 = (cu(a.astype(np.float32)).requires_grad_(True) for a in (sdf, grad, dirs))
+        v2 = torch.tensor(var, device="cuda", requires_grad=True)
+        inv_s_f = float(torch.exp(v2.detach() * 10.0).clip(1e-6, 1e6).item())
+        w, nh = AlphaWeightsNormalsHip.apply(s2, g2, d2, cu(dists.astype(np.float32)), v2, inv_s_f, ca)
+        got = torch.autograd.grad((w * cu(cw.astype(np.float32))).sum() + (nh * cu(cn.astype(np.float32))).sum(), [s2, g2, d2, v2])
+        assert (w.cpu().double() - w_ref.detach()).abs().max() < 2e-5
+        assert (nh.cpu().double() - n_ref.detach()).abs().max() < 2e-6
+        for name, a, b in zip(("sdf", "grad", "dirs", "variance"), got, ref):
+            scale = b.abs().max().item() + 1e-30
+            assert (a.cpu().double() - b).abs().max().item() / scale < 2e-3, (name, ca)
