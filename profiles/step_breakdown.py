@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-category GPU time of ONE training step from a rocprofv3 kernel trace (profiles/prof_train.sh output).
+usage: python profiles/step_breakdown.py gpurun_out/prof_train_<tag>/train_kernel_trace.csv"""
+import collections, csv, sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "sdf_kernel<3" in r["Kernel_Name"]]
+
+
+def step_start(i):
+    while i > 0 and "coarse_z" not in rows[i]["Kernel_Name"]:
+        i -= 1
+    return i
+
+
+step = rows[step_start(idx[-2]):step_start(idx[-1])]
+dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+
+
+def cat(name):
+    if "nrh::" in name:
+        return name.split("(")[0].replace("void ", "")[:44]
+    if name.startswith("Cijk"):
+        return "rocBLAS GEMM " + name[5:14] + " " + name[name.index("MT"):name.index("MT") + 12]
+    for key, label in (("reduce_kernel", "torch reduce"), ("elementwise", "torch elementwise"), ("vectorized", "torch elementwise"),
+                       ("Cat", "torch cat"), ("copyBuffer", "memcpy/fill"), ("fillBuffer", "memcpy/fill"),
+                       ("multi_tensor", "adam/foreach"), ("index", "torch index/scatter")):
+        if key in name:
+            return label
+    return name[:44]
+
+
+agg = collections.defaultdict(lambda: [0, 0])
+for r in step:
+    k = cat(r["Kernel_Name"])
+    agg[k][0] += dur(r)
+    agg[k][1] += 1
+print(f"one training step: {len(step)} kernel launches, {sum(dur(r) for r in step) / 1e6:.3f} ms of kernel time")
+for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    if t > 5000:
+        print(f"{t / 1e6:8.3f} ms {n:5d}  {k}")
