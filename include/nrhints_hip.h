@@ -93,6 +93,23 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            void* stream);
 
+/* ---- reflectance network, training ------------------------------------------------------------------------
+ * ReflectanceNetwork.forward (fields/reflectance_network.py:68-96) on row-major inputs with the arrays its backward
+ * needs, and the adjoint sweep (what autograd does through the 5 linears, ReLUs and the sigmoid in the reference).
+ *   forward : feat_rows [P,256], pts [P,3], normal [P,3], raymisc [nrays, out[5]] (as nrh_color_eval)
+ *             -> color [P,3];  save_h [4][P][256] (ReLU outputs),  save_misc [P][128 | 64] (non-feature input, kernel order:
+ *             pts 3, normal 3, enc4(view) 27, enc4(pl) 27 (, enc4(vis) 9, enc4(cue) 36), zero padded)
+ *   backward: zbar4 [P,3] = adjoint of the pre-sigmoid output, col_wt = transposed stages
+ *             (packing.pack_color_transposed, nrh_color_transposed_floats(hints) floats or fp16 pairs)
+ *             -> zbar [4][P][256], fbar [P,256] (adjoint of feat), mbar [P][128 | 64] (adjoint of the non-feature input)
+ *   weight gradients are GEMMs over these arrays on the caller's side:  dW_l = zbar[l]^T save_h[l-1], ... */
+long long nrh_color_transposed_floats(int hints);
+int nrh_color_train_forward(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                            const float* pts, const float* normal, const float* raymisc, long long nrays, float* color,
+                            float* save_h, float* save_misc, void* stream);
+int nrh_color_train_backward(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
+                             long long nrays, float* zbar, float* fbar, float* mbar, void* stream);
+
 /* ---- alpha stage, training ---------------------------------------------------------------------------------
  * NeuSHintRenderer.get_alpha + compositing weights + unit normals (models/neus_hint_model.py:339-356, :521-525, :584)
  * for 128 samples per ray and the adjoint of exactly that (what autograd does in the reference's backward).

@@ -91,6 +91,76 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
         return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None
 
 
+class ColorNetHip(torch.autograd.Function):
+    """Reflectance net for 128 samples per ray with the forward and the adjoint sweep in the HIP register-chain kernels
+    (csrc/nrh_color.hip, TRAIN instantiation + color_adjoint_kernel) and the weight gradients as split-K GEMMs.
+    forward(feat [P,256], pts [P,3], normal [P,3], ray_enc [N,99|54], packed, w0..w4, b0..b4) -> colour [P,3]
+    (ray_enc = cat[enc4(view), enc4(pl) (, enc4(vis), enc4(cue))] per ray; its adjoint is returned per ray, so the
+    caller's autograd carries it on to the rays)."""
+
+    @staticmethod
+    def forward(ctx, feat, pts, normal, ray_enc, packed, *params):
+        from . import _lib, packing
+        lib = _lib.load()
+        hints = bool(packed["hints"])
+        dev = feat.device
+        n = ray_enc.shape[0]
+        Pn = n * 128
+        f32c = lambda t: t.detach().to(torch.float32).contiguous()
+        feat_c, pts_c, nrm_c = f32c(feat), f32c(pts), f32c(normal)
+        raymisc = torch.zeros(n, packing.RAYMISC_STRIDE, dtype=torch.float32, device=dev)
+        raymisc[:, :ray_enc.shape[1]] = ray_enc.detach()
+        mw = 128 if hints else 64
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        color, save_h, save_misc = new(Pn, 3), new(4, Pn, 256), new(Pn, mw)
+        P = _lib.ptr
+        cw = packed["col_w"]
+        _lib.check(lib.nrh_color_train_forward(packed["precision"], int(hints), P(cw, cw.dtype), P(packed["col_b"]), P(feat_c), P(pts_c),
+                                               P(nrm_c), P(raymisc), n, P(color), P(save_h), P(save_misc), _lib.stream_handle()),
+                   "nrh_color_train_forward")
+        ctx.save_for_backward(feat_c, color, save_h, save_misc)
+        ctx.packed, ctx.n, ctx.enc_width = packed, n, ray_enc.shape[1]
+        ctx.shapes = [tuple(t.shape) for t in params]
+        return color
+
+    @staticmethod
+    def backward(ctx, cbar):
+        from . import _lib, packing
+        from .sdf_function import _colsum
+        lib = _lib.load()
+        feat_c, color, save_h, save_misc = ctx.saved_tensors
+        packed, n = ctx.packed, ctx.n
+        hints = bool(packed["hints"])
+        Pn = n * 128
+        dev = feat_c.device
+        mw = save_misc.shape[1]
+        zbar4 = (cbar.to(torch.float32) * color * (1.0 - color)).contiguous()        # through the sigmoid
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        zbar, fbar, mbar = new(4, Pn, 256), new(Pn, 256), new(Pn, mw)
+        P = _lib.ptr
+        cwt = packed["col_wt"]
+        _lib.check(lib.nrh_color_train_backward(packed["precision"], int(hints), P(cwt, cwt.dtype), P(zbar4), P(save_h), n, P(zbar),
+                                                P(fbar), P(mbar), _lib.stream_handle()), "nrh_color_train_backward")
+        nm = 105 if hints else 60
+        grads_in = (fbar, mbar[:, 0:3], mbar[:, 3:6], mbar[:, 6:nm].reshape(n, 128, nm - 6).sum(1), None)
+        if not any(ctx.needs_input_grad[5:]):
+            return grads_in + (None,) * 10
+        S = math.gcd(Pn, 32)
+
+        def big_k(a3, b3):
+            L, ka, kb = a3.shape[0], a3.shape[-1], b3.shape[-1]
+            return torch.bmm(a3.reshape(L * S, Pn // S, ka).transpose(1, 2), b3.reshape(L * S, Pn // S, kb)).reshape(L, S, ka, kb).sum(1)
+
+        fi, mi = packing.color_input_permutation(hints)
+        w0_bar = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
+        w0_bar[:, fi.to(dev)] = big_k(zbar[0:1], feat_c[None])[0]
+        w0_bar[:, mi.to(dev)] = big_k(zbar[0:1], save_misc[None])[0][:, :nm]
+        w123 = big_k(zbar[1:4], save_h[0:3])
+        w4_bar = big_k(zbar4[None], save_h[3:4])[0]
+        zs = _colsum(zbar)
+        return grads_in + (w0_bar, w123[0], w123[1], w123[2], w4_bar, zs[0], zs[1], zs[2], zs[3], zbar4.sum(0))
+
+
 _COL_INDEX = {}
 
 
@@ -111,6 +181,25 @@ def _sdf_net(d: Dict[str, torch.Tensor], pts: torch.Tensor):
             h = torch.cat([h, e], dim=1) / math.sqrt(2.0)
         h = F.softplus(F.linear(h, d[f"sdf_w{l}"], d[f"sdf_b{l}"]), beta=100)
     return F.linear(h, d["sdf_head_w"], d["sdf_head_b"]) / 3.0, F.linear(h, d["feat_w"], d["feat_b"])
+
+
+def _color_net_torch(d, feat, pts, normal, per_ray, n, T, hints):
+    """Reflectance net in torch ops, layer 0 by column blocks of the reference's 361-wide input
+      [pts 0:3 | enc(view) 3:30 | normal 30:33 | enc(pl) 33:60 | feat 60:316 | enc(vis) 316:325 | enc(cue) 325:361]
+    (fields/reflectance_network.py:77-82): the view / light / visibility / cue encodings are constant along a ray, so
+    their contribution is one [N,99] x [99,256] product broadcast over the 128 samples instead of a 361-wide
+    concatenation per sample; autograd carries the ray gradients through the small per-ray part."""
+    w0, b0 = d["col_w0"], d["col_b0"]
+    ray_cols, pn_cols = _col_index(w0.device, hints)
+    x = _linear(feat, w0[:, 60:316], b0)                                                   # [P,256] the big block
+    x = x + _linear(torch.cat([pts, normal], dim=-1), w0[:, pn_cols], torch.zeros_like(b0))  # per-sample 6 columns
+    x = (x.reshape(n, T, -1) + (torch.cat(per_ray, dim=-1) @ w0[:, ray_cols].t())[:, None, :]).reshape(n * T, -1)
+    x = torch.relu(x)
+    for l in range(1, 5):
+        x = _linear(x, d[f"col_w{l}"], d[f"col_b{l}"])
+        if l < 4:
+            x = torch.relu(x)
+    return torch.sigmoid(x).reshape(n, T, 3)
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
@@ -141,26 +230,17 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
         trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
         weights = alpha * trans
         n_hat = F.normalize(grad, dim=-1)
-    # reflectance net, layer 0 by column blocks of the reference's 361-wide input
-    #   [pts 0:3 | enc(view) 3:30 | normal 30:33 | enc(pl) 33:60 | feat 60:316 | enc(vis) 316:325 | enc(cue) 325:361]
-    # (fields/reflectance_network.py:77-82): the view / light / visibility / cue encodings are constant along a ray, so
-    # their contribution is one [N,99] x [99,256] product broadcast over the 128 samples instead of a 361-wide
-    # concatenation per sample (190 MB at 1024 rays); autograd carries the ray gradients through the small per-ray part.
-    w0, b0 = d["col_w0"], d["col_b0"]
+    # per-ray part of the reflectance input: encodings of view direction, light position, visibility hint, specular cue
     per_ray = [_enc(dirs, 4), _enc(pl, 4)]
     if vis is not None:  # vis / cue are None for the pl-naive model (no hints)
         per_ray += [_enc(vis, 4), _enc(cue, 4)]
-    ray_cols, pn_cols = _col_index(w0.device, vis is not None)
     normal = grad if analytic_normal else n_hat
-    x = _linear(feat, w0[:, 60:316], b0)                                                   # [P,256] the big block
-    x = x + _linear(torch.cat([pts, normal], dim=-1), w0[:, pn_cols], torch.zeros_like(b0))  # per-sample 6 columns
-    x = (x.reshape(n, T, -1) + (torch.cat(per_ray, dim=-1) @ w0[:, ray_cols].t())[:, None, :]).reshape(n * T, -1)
-    x = torch.relu(x)
-    for l in range(1, 5):
-        x = _linear(x, d[f"col_w{l}"], d[f"col_b{l}"])
-        if l < 4:
-            x = torch.relu(x)
-    col = torch.sigmoid(x).reshape(n, T, 3)
+    if sdf_impl == "hip" and packed is not None and packed.get("col_wt") is not None:
+        # reflectance net: forward and adjoint sweep in the HIP register-chain kernels, dW as split-K GEMMs
+        col = ColorNetHip.apply(feat, pts, normal, torch.cat(per_ray, dim=-1), packed,
+                                *[d[f"col_w{l}"] for l in range(5)], *[d[f"col_b{l}"] for l in range(5)]).reshape(n, T, 3)
+    else:
+        col = _color_net_torch(d, feat, pts, normal, per_ray, n, T, vis is not None)
     rgb = (col * weights[..., None]).sum(1)
     if background_rgb is not None:
         rgb = rgb + background_rgb * (1.0 - weights.sum(-1, keepdim=True))

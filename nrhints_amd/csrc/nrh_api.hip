@@ -57,6 +57,10 @@ int ensure_attrs() {
                        (const void*)nrh::sdf_kernel<3, 0>, (const void*)nrh::sdf_kernel<3, 1>,
                        (const void*)nrh::sdf_tangent_kernel<0>, (const void*)nrh::sdf_tangent_kernel<1>,
                        (const void*)nrh::sdf_adjoint_kernel<0>, (const void*)nrh::sdf_adjoint_kernel<1>,
+                       (const void*)nrh::color_kernel<0, 8, true>, (const void*)nrh::color_kernel<1, 8, true>,
+                       (const void*)nrh::color_kernel<0, 4, true>, (const void*)nrh::color_kernel<1, 4, true>,
+                       (const void*)nrh::color_adjoint_kernel<0, 8>, (const void*)nrh::color_adjoint_kernel<1, 8>,
+                       (const void*)nrh::color_adjoint_kernel<0, 4>, (const void*)nrh::color_adjoint_kernel<1, 4>,
                        (const void*)nrh::color_kernel<0, 8>, (const void*)nrh::color_kernel<1, 8>,
                        (const void*)nrh::color_kernel<0, 4>, (const void*)nrh::color_kernel<1, 4>};
   e = hipSuccess;
@@ -209,7 +213,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 107; }
+int nrh_version(void) { return 108; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -227,6 +231,8 @@ int nrh_param_sizes(int* out) {
 }
 
 int nrh_mlp_grid(void) { return mlp_grid(); }
+
+long long nrh_color_transposed_floats(int hints) { return nrh::colt_packed_floats(hints ? 8 : 4); }
 
 int nrh_kernel_timing_select(int kind) {
   if (kind < -1 || kind > 3) return fail(NRH_E_INVALID, "nrh_kernel_timing_select: kind must be -1..3%s", "");
@@ -319,6 +325,60 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   if (precision == 0) hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<0>), g, blk, nrh::MLP_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<1>), g, blk, nrh::MLP_LDS_BYTES, st, a);
   return check_launch("sdf_adjoint_kernel");
+}
+
+int nrh_color_train_forward(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                            const float* pts, const float* normal, const float* raymisc, long long nrays, float* color,
+                            float* save_h, float* save_misc, void* stream) {
+  if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_color_train_forward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!col_w || !col_b || !feat_rows || !pts || !normal || !raymisc || !color || !save_h || !save_misc)
+    return fail(NRH_E_INVALID, "nrh_color_train_forward: null pointer%s", "");
+  if (nrays < 0) return fail(NRH_E_INVALID, "nrh_color_train_forward: nrays < 0%s", "");
+  if (nrays == 0) return NRH_OK;
+  int rc = ensure_attrs();
+  if (rc) return rc;
+  nrh::ColorArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w = col_w; a.b = col_b; a.feat = feat_rows; a.pts = pts; a.nhat = normal; a.raymisc = raymisc; a.color = color;
+  a.ro = pts; a.rd = pts; a.tmid = pts;  // unused in the training instantiation
+  a.save_h = save_h; a.save_misc = save_misc;
+  a.npts = nrays * 128;
+  int grid = 0;
+  rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_color_train_forward");
+  if (rc) return rc;
+  const hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid), blk(nrh::MLP_THREADS);
+  const int lds = nrh::MLP_LDS_BYTES;
+  if (precision == 0 && hints) hipLaunchKernelGGL((nrh::color_kernel<0, 8, true>), g, blk, lds, st, a);
+  else if (precision == 1 && hints) hipLaunchKernelGGL((nrh::color_kernel<1, 8, true>), g, blk, lds, st, a);
+  else if (precision == 0) hipLaunchKernelGGL((nrh::color_kernel<0, 4, true>), g, blk, lds, st, a);
+  else hipLaunchKernelGGL((nrh::color_kernel<1, 4, true>), g, blk, lds, st, a);
+  return check_launch("color_kernel<train>");
+}
+
+int nrh_color_train_backward(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
+                             long long nrays, float* zbar, float* fbar, float* mbar, void* stream) {
+  if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_color_train_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!col_wt || !zbar4 || !save_h || !zbar || !fbar || !mbar) return fail(NRH_E_INVALID, "nrh_color_train_backward: null pointer%s", "");
+  if (nrays < 0) return fail(NRH_E_INVALID, "nrh_color_train_backward: nrays < 0%s", "");
+  if (nrays == 0) return NRH_OK;
+  int rc = ensure_attrs();
+  if (rc) return rc;
+  nrh::ColorAdjArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wt = col_wt; a.zbar4 = zbar4; a.save_h = save_h; a.zbar = zbar; a.fbar = fbar; a.mbar = mbar;
+  a.npts = nrays * 128;
+  int grid = 0;
+  rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_color_train_backward");
+  if (rc) return rc;
+  const hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid), blk(nrh::MLP_THREADS);
+  const int lds = nrh::MLP_LDS_BYTES;
+  if (precision == 0 && hints) hipLaunchKernelGGL((nrh::color_adjoint_kernel<0, 8>), g, blk, lds, st, a);
+  else if (precision == 1 && hints) hipLaunchKernelGGL((nrh::color_adjoint_kernel<1, 8>), g, blk, lds, st, a);
+  else if (precision == 0) hipLaunchKernelGGL((nrh::color_adjoint_kernel<0, 4>), g, blk, lds, st, a);
+  else hipLaunchKernelGGL((nrh::color_adjoint_kernel<1, 4>), g, blk, lds, st, a);
+  return check_launch("color_adjoint_kernel");
 }
 
 int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,

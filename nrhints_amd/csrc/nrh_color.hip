@@ -15,13 +15,28 @@ namespace nrh {
 struct ColorArgs {
   const float* w;        // packed (COL_PACKED_FLOATS)
   const float* b;        // [4][256] + [16]
-  const float* feat;     // [ntiles][16][64][4]
+  const float* feat;     // [ntiles][16][64][4] D-layout tiles; TRAIN: row-major [npts][256]
   const float* ro;       // [nrays,3]
   const float* rd;       // [nrays,3]
   const float* tmid;     // [nrays,128]
   const float* nhat;     // [npts,3] normal fed to the net: unit normals (NormalizedAnalytic) or raw gradients (Analytic)
   const float* raymisc;  // [nrays,RAYMISC_STRIDE]
   float* color;          // [npts,3]
+  long long npts;
+  int ntile_groups;
+  // TRAIN (forward of a training step): sample points given directly, and what the adjoint + dW GEMMs need, row-major
+  const float* pts;      // [npts,3]
+  float* save_h;         // [4][npts][256]  ReLU outputs of layers 0..3
+  float* save_misc;      // [npts][16*MKB]  the non-feature part of the layer-0 input in kernel order
+};
+// adjoint sweep of the reflectance net (csrc/nrh_color.hip color_adjoint_kernel)
+struct ColorAdjArgs {
+  const float* wt;       // packed transposed stages  W4^T | W3^T | W2^T | W1^T | W0feat^T | W0misc^T
+  const float* zbar4;    // [npts,3]   adjoint of the pre-sigmoid output
+  const float* save_h;   // [4][npts][256]
+  float* zbar;           // [4][npts][256]  adjoints of the pre-ReLU outputs of layers 0..3
+  float* fbar;           // [npts][256]     adjoint of the feature input (feeds the SDF value sweep)
+  float* mbar;           // [npts][16*MKB]  adjoint of the non-feature input part
   long long npts;
   int ntile_groups;
 };
@@ -33,7 +48,7 @@ __device__ __forceinline__ f32x4 relu4(const f32x4 x) {
   return f32x4{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f), fmaxf(x[2], 0.0f), fmaxf(x[3], 0.0f)};
 }
 
-template <int PREC, int MKB>
+template <int PREC, int MKB, bool TRAIN = false>
 __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -50,15 +65,24 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
     const long long Pc = valid ? P : a.npts - 1;
     const long long tilec = Pc / TILE_PTS;
     const long long ray = Pc >> 7;  // 128 samples per ray
+    const bool tile_ok = tile * TILE_PTS < a.npts;   // TRAIN: whole tiles only (npts % 16 == 0)
+    auto save_rows = [&](float* base, int l, int width, int ch, const f32x4 v0, const f32x4 v1) {
+      if (tile_ok) {
+        float* p = base + ((size_t)l * (size_t)a.npts + (size_t)Pc) * width + 4 * q;
+        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0);
+        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
+      }
+    };
 
     // ---- C0a: feature part ----
     Act<PREC, 16> h;
     {
-      const float* ft = a.feat + (size_t)tilec * (16 * 256);
+      const float* ft = TRAIN ? a.feat + (size_t)Pc * 256 + 4 * q : a.feat + (size_t)tilec * (16 * 256) + lane * 4;
+      const int bs = TRAIN ? 16 : 256;   // floats between consecutive 16-feature blocks
 #pragma unroll
       for (int ch = 0; ch < 8; ++ch) {
-        const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(ft + ((2 * ch) * 64 + lane) * 4));
-        const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(ft + ((2 * ch + 1) * 64 + lane) * 4));
+        const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch) * bs));
+        const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch + 1) * bs));
         const float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         h.set_chunk(ch, o);
       }
@@ -79,7 +103,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       float pn[6];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        pn[c] = a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt;
+        pn[c] = TRAIN ? a.pts[Pc * 3 + c] : a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt;
         pn[3 + c] = a.nhat[Pc * 3 + c];
       }
       const float* rm = a.raymisc + ray * RAYMISC_STRIDE;
@@ -102,6 +126,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
           o[r8] = v;
         }
         misc.set_chunk(ch, o);
+        if constexpr (TRAIN) save_rows(a.save_misc, 0, 16 * MKB, ch, f32x4{o[0], o[1], o[2], o[3]}, f32x4{o[4], o[5], o[6], o[7]});
       }
     }
     {
@@ -112,7 +137,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
         return p;
       };
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
-        h.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
+        const f32x4 h0 = relu4(acc0 + p.b0), h1 = relu4(acc1 + p.b1);
+        h.set_chunk(ch, h0, h1);
+        if constexpr (TRAIN) save_rows(a.save_h, 0, 256, ch, h0, h1);
       };
       run_stage<PREC, MKB, 8, true, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1, MKB), 32, smem, par, misc, part, pre, epi, wave, lane);
     }
@@ -126,7 +153,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
         return p;
       };
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
-        ho.set_chunk(ch, relu4(acc0 + p.b0), relu4(acc1 + p.b1));
+        const f32x4 h0 = relu4(acc0 + p.b0), h1 = relu4(acc1 + p.b1);
+        ho.set_chunk(ch, h0, h1);
+        if constexpr (TRAIN) save_rows(a.save_h, l, 256, ch, h0, h1);
       };
       const float* wn = (l < 3) ? a.w + col_off_C(l + 1, MKB) : a.w + col_off_C4(MKB);
       run_stage<PREC, 16, 8, false, true>(a.w + col_off_C(l, MKB), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
@@ -148,6 +177,101 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
         }
       };
       run_stage<PREC, 16, 1, false>(a.w + col_off_C4(MKB), a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, pre, epi, wave, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// adjoint sweep:  zbar_3 = (W4^T zbar4) [h4 > 0];  zbar_{l-1} = (W_l^T zbar_l) [h_l > 0];  fbar = W0feat^T zbar_0;
+//                 mbar = W0misc^T zbar_0.   Weight gradients are GEMMs over zbar / save_h on the host side.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int COLT_C4_FLOATS = 8 * 2 * 2 * 256;   // W4^T: 256 rows, K = 32 (3 used)
+__host__ __device__ constexpr int colt_off_T(int l) { return COLT_C4_FLOATS + (3 - l) * SDF_REG_FLOATS; }  // l = 3, 2, 1
+constexpr int COLT_OFF_T0A = COLT_C4_FLOATS + 3 * SDF_REG_FLOATS;
+constexpr int COLT_OFF_T0B = COLT_C4_FLOATS + 4 * SDF_REG_FLOATS;
+__host__ __device__ constexpr int colt_packed_floats(int mkb) { return COLT_OFF_T0B + (mkb / 2) * 2 * 16 * 256; }
+
+template <int PREC, int MKB>
+__global__ __launch_bounds__(MLP_THREADS, 2) void color_adjoint_kernel(const ColorAdjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  int par = 0;
+  dma_chunk(a.wt, smem, 4, wave, lane);
+  __syncthreads();
+
+  for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
+    const long long tile = (long long)tg * WG_WAVES + wave;
+    const bool tile_ok = tile * TILE_PTS < a.npts;
+    const long long row = tile_ok ? tile * TILE_PTS + j : j;
+    auto rows_ptr = [&](const float* base, int l, int blk) {
+      return reinterpret_cast<const f32x4*>(base + ((size_t)l * (size_t)a.npts + (size_t)row) * 256 + blk * 16 + 4 * q);
+    };
+    auto store_rows = [&](float* base, int l, int width, int ch, const f32x4 v0, const f32x4 v1) {
+      if (tile_ok) {
+        float* p = base + ((size_t)l * (size_t)a.npts + (size_t)row) * width + 4 * q;
+        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0);
+        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
+      }
+    };
+    struct HPre { f32x4 h0, h1; };
+
+    // ---- T4: 3 -> 256 (the adjoint of the 3 outputs sits in block 0, lanes q == 0, registers 0..2) ----
+    Act<PREC, 2> z4;
+    {
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = (q == 0 && r < 3) ? a.zbar4[row * 3 + r] : 0.0f;
+      z4.set_chunk(0, o);
+    }
+    Act<PREC, 16> h;
+    {
+      auto pre = [&](int ch) {
+        HPre p;
+        p.h0 = ld_stream(rows_ptr(a.save_h, 3, 2 * ch));
+        p.h1 = ld_stream(rows_ptr(a.save_h, 3, 2 * ch + 1));
+        return p;
+      };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const HPre& p) {
+        f32x4 z0, z1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z0[r] = p.h0[r] > 0.0f ? acc0[r] : 0.0f; z1[r] = p.h1[r] > 0.0f ? acc1[r] : 0.0f; }
+        store_rows(a.zbar, 3, 256, ch, z0, z1);
+        h.set_chunk(ch, z0, z1);
+      };
+      run_stage<PREC, 2, 8, false, true>(a.wt, a.wt + colt_off_T(3), 32, smem, par, z4, nullptr, pre, epi, wave, lane);
+    }
+    // ---- T3, T2, T1 ----
+    for (int l = 3; l >= 1; --l) {
+      Act<PREC, 16> ho;
+      auto pre = [&](int ch) {
+        HPre p;
+        p.h0 = ld_stream(rows_ptr(a.save_h, l - 1, 2 * ch));
+        p.h1 = ld_stream(rows_ptr(a.save_h, l - 1, 2 * ch + 1));
+        return p;
+      };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const HPre& p) {
+        f32x4 z0, z1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z0[r] = p.h0[r] > 0.0f ? acc0[r] : 0.0f; z1[r] = p.h1[r] > 0.0f ? acc1[r] : 0.0f; }
+        store_rows(a.zbar, l - 1, 256, ch, z0, z1);
+        ho.set_chunk(ch, z0, z1);
+      };
+      const float* wn = (l > 1) ? a.wt + colt_off_T(l - 1) : a.wt + COLT_OFF_T0A;
+      run_stage<PREC, 16, 8, false, true>(a.wt + colt_off_T(l), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
+      h = ho;
+    }
+    // ---- T0a: adjoint of the feature input;  T0b: adjoint of the other inputs ----
+    {
+      auto pre = [&](int) { return 0; };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) { store_rows(a.fbar, 0, 256, ch, acc0, acc1); };
+      run_stage<PREC, 16, 8, false>(a.wt + COLT_OFF_T0A, a.wt + COLT_OFF_T0B, 32, smem, par, h, nullptr, pre, epi, wave, lane);
+    }
+    {
+      auto pre = [&](int) { return 0; };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) { store_rows(a.mbar, 0, 16 * MKB, ch, acc0, acc1); };
+      run_stage<PREC, 16, MKB / 2, false>(a.wt + COLT_OFF_T0B, a.wt, 4, smem, par, h, nullptr, pre, epi, wave, lane);
     }
   }
 }

@@ -176,6 +176,18 @@ def pack_color(d: Dict[str, torch.Tensor], precision: int = 0, hints: bool = Tru
     return packed.contiguous(), bias.contiguous()
 
 
+def pack_color_transposed(d: Dict[str, torch.Tensor], precision: int = 0, hints: bool = True) -> torch.Tensor:
+    """Stages of the reflectance net's adjoint sweep (csrc/nrh_color.hip color_adjoint_kernel), in execution order
+    W4^T (256 x 32, 3 columns used) | W3^T | W2^T | W1^T | W0[:, feat]^T | W0[:, other]^T (128 | 64 rows)."""
+    ps = pack_stage if precision == 0 else pack_stage_h3
+    fi, mi = color_input_permutation(hints)
+    w0 = d["col_w0"]
+    regular = [d["col_w3"].t(), d["col_w2"].t(), d["col_w1"].t(), w0[:, fi.to(w0.device)].t()]
+    parts = [ps(d["col_w4"].t(), 256, 32), pack_stages(regular, 256, 256, precision),
+             ps(w0[:, mi.to(w0.device)].t(), 128 if hints else 64, 256)]
+    return torch.cat(parts).contiguous()
+
+
 def feat_tiles_to_rows(tiles: torch.Tensor, npts: int) -> torch.Tensor:
     """D-layout feature tiles [ntiles,16(block),64(lane),4(r)] -> [npts,256]
     (lane = q*16 + j; feature = 16*block + 4*q + r; point = 16*tile + j)."""

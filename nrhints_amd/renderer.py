@@ -154,8 +154,10 @@ class NeuSHintRenderer(nn.Module):
                 sw, sb, sh = packing.pack_sdf(d, prec)
                 cw, cb = packing.pack_color(d, prec, bool(self._hints))
                 wtf = packing.pack_feat_transposed(d, prec)
+                cwt = packing.pack_color_transposed(d, prec, bool(self._hints)) if dense is not None else None
                 inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6).item())
-            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s, precision=prec, sdf_wt_feat=wtf)
+            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s, precision=prec, sdf_wt_feat=wtf, col_wt=cwt,
+                                hints=bool(self._hints))
             self._packed_key = key
         return self._packed
 

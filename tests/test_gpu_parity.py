@@ -37,7 +37,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 107
+    assert lib.nrh_version() >= 108
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
@@ -544,3 +544,52 @@ def test_alpha_train_kernels_vs_autograd(scene):
         for name, a, b in zip(("sdf", "grad", "dirs", "variance"), got, ref):
             scale = b.abs().max().item() + 1e-30
             assert (a.cpu().double() - b).abs().max().item() / scale < 2e-3, (name, ca)
+
+
+@pytest.mark.parametrize("hints", [True, False])
+def test_color_net_hip_vs_torch(scene_states, hints):
+    """ColorNetHip (training forward + adjoint sweep kernels of csrc/nrh_color.hip + split-K dW GEMMs) against the same
+    network in torch ops with autograd (fields/reflectance_network.py:68-96), both on the GPU, yardstick fp64 on the CPU."""
+    from nrhints_amd import autograd_core as ac
+    from nrhints_amd.synthetic import naive_state
+    st = scene_states["b"] if hints else naive_state(scene_states["b"])
+    cfg = na.NeuSModelConfig() if hints else na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False))
+    rs = np.random.RandomState(3)
+    n, T_ = 24, 128
+    feat = rs.randn(n * T_, 256) * 0.3
+    pts = rs.uniform(-0.8, 0.8, size=(n * T_, 3))
+    nrm = rs.randn(n * T_, 3); nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    enc_w = 99 if hints else 54
+    ray_enc = rs.uniform(-1, 1, size=(n, enc_w))
+    cc = rs.randn(n * T_, 3)
+    res = {}
+    for prec in ("f32", "f16x3", "torch32", "torch64"):
+        on_gpu = prec != "torch64"
+        dt = torch.float64 if prec == "torch64" else torch.float32
+        model = na.NeuSHintRenderer(cfg, precision=prec if prec in ("f32", "f16x3") else "f32")
+        model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+        model = model.to(dt)
+        if on_gpu:
+            model = model.cuda()
+        dev = "cuda" if on_gpu else "cpu"
+        leaves = {k: p for k, p in model.named_parameters() if k.startswith("color_network")}
+        dense = pk.dense_params(dict(model.named_parameters()))
+        tt = lambda a: torch.tensor(a, dtype=dt, device=dev, requires_grad=True)
+        f_, p_, n_, e_ = tt(feat), tt(pts), tt(nrm), tt(ray_enc)
+        if prec in ("f32", "f16x3"):
+            packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()), dense=dense)
+            col = ac.ColorNetHip.apply(f_, p_, n_, e_, packed, *[dense[f"col_w{l}"] for l in range(5)], *[dense[f"col_b{l}"] for l in range(5)])
+        else:
+            sizes = [27, 27, 9, 36] if hints else [27, 27]
+            col = ac._color_net_torch(dense, f_, p_, n_, list(torch.split(e_, sizes, dim=1)), n, T_, hints).reshape(-1, 3)
+        grads = torch.autograd.grad((col * torch.tensor(cc, dtype=dt, device=dev)).sum(), [f_, p_, n_, e_] + list(leaves.values()))
+        res[prec] = (col.detach().cpu().double(), [g.detach().cpu().double() for g in grads], ["feat", "pts", "normal", "ray_enc"] + list(leaves))
+    ref_col, ref_g, names = res["torch64"]
+    for prec in ("f32", "f16x3"):
+        col, g, _ = res[prec]
+        assert (col - ref_col).abs().max() < 5e-6, prec
+        for name, a, b32, r in zip(names, g, res["torch32"][1], ref_g):
+            scale = r.abs().max().item() + 1e-30
+            e_hip = (a - r).abs().max().item() / scale
+            e_t32 = (b32 - r).abs().max().item() / scale
+            assert e_hip <= 5.0 * e_t32 + 2e-5, (prec, name, e_hip, e_t32)
