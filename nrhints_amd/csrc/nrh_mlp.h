@@ -41,6 +41,9 @@ constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
 #ifndef NRH_ABL
 #define NRH_ABL 0             // bit 0: no LDS-DMA, 1: no barrier, 2: no MFMA, 3: no ds_read of A (f16x3), 4: trivial epilogue
 #endif
+#ifndef NRH_BARRIER_FIRST
+#define NRH_BARRIER_FIRST 0   // end-of-chunk barrier between the K loop and the epilogue instead of after the epilogue
+#endif
 #ifndef NRH_RAW_BARRIER
 #define NRH_RAW_BARRIER 0     // chunk barrier without vmcnt(0) (stores stay in flight): measured +3 % / -6 % (kbench7) -> off
 #endif
@@ -268,8 +271,15 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
       acc0 += c0 * LO_UNSCALE;
       acc1 += c1 * LO_UNSCALE;
     }
+#if NRH_BARRIER_FIRST
+    // barrier BEFORE the epilogue: its vmcnt(0) then drains the stores of the PREVIOUS chunk's epilogue (issued a whole K
+    // loop ago, long acknowledged) instead of the ones this epilogue is about to issue
+    if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();
+    epi(ch, acc0, acc1, pv);
+#else
     epi(ch, acc0, acc1, pv);
     if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();  // the next chunk's weights are in LDS for every wave past this point
+#endif
     par ^= 1;
   }
 }
