@@ -93,6 +93,16 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            void* stream);
 
+/* ---- weight-norm fold ---------------------------------------------------------------------------------------
+ * W = v * g / ||v||_row for up to 16 linears in one launch (old-style nn.utils.weight_norm, dim = 0:
+ * fields/sdf_field.py:81-82, fields/reflectance_network.py:61-62) and its adjoint in one launch.  rows / cols and the
+ * pointer arrays are HOST arrays of length nlayers; v [rows,cols], g [rows] (or [rows,1]), w / wbar / vbar as v,
+ * gbar as g; cols <= 384.  wbar[l] may be null (that layer's gradients are written as zero). */
+int nrh_weight_norm_fold(int nlayers, const int* rows, const int* cols, const float* const* v, const float* const* g,
+                         float* const* w, void* stream);
+int nrh_weight_norm_fold_backward(int nlayers, const int* rows, const int* cols, const float* const* v, const float* const* g,
+                                  const float* const* wbar, float* const* vbar, float* const* gbar, void* stream);
+
 /* ---- reflectance network, training ------------------------------------------------------------------------
  * ReflectanceNetwork.forward (fields/reflectance_network.py:68-96) on row-major inputs with the arrays its backward
  * needs, and the adjoint sweep (what autograd does through the 5 linears, ReLUs and the sigmoid in the reference).

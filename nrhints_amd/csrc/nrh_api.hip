@@ -5,6 +5,7 @@
 #include "nrh_color.hip"
 #include "nrh_rays.hip"
 #include "nrh_rays_train.hip"
+#include "nrh_fold.hip"
 
 #include <stdio.h>
 #include <string.h>
@@ -213,7 +214,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 108; }
+int nrh_version(void) { return 109; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -325,6 +326,45 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   if (precision == 0) hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<0>), g, blk, nrh::MLP_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((nrh::sdf_adjoint_kernel<1>), g, blk, nrh::MLP_LDS_BYTES, st, a);
   return check_launch("sdf_adjoint_kernel");
+}
+
+static int fold_launch(bool adjoint, int nlayers, const int* rows, const int* cols, const float* const* v, const float* const* g,
+                       float* const* w, const float* const* wbar, float* const* vbar, float* const* gbar, void* stream) {
+  const char* who = adjoint ? "nrh_weight_norm_fold_backward" : "nrh_weight_norm_fold";
+  if (nlayers <= 0 || nlayers > nrh::FOLD_MAX_LAYERS) return fail(NRH_E_INVALID, "%s: 1..16 layers", who);
+  if (!rows || !cols || !v || !g) return fail(NRH_E_INVALID, "%s: null pointer", who);
+  nrh::FoldArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nlayers = nlayers;
+  int total = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    if (rows[l] <= 0 || cols[l] <= 0 || cols[l] > nrh::FOLD_MAX_COLS) return fail(NRH_E_INVALID, "%s: bad layer shape (cols <= 384)", who);
+    if (!v[l] || !g[l]) return fail(NRH_E_INVALID, "%s: null layer pointer", who);
+    a.v[l] = v[l]; a.g[l] = g[l]; a.cols[l] = cols[l]; a.row_start[l] = total;
+    if (adjoint) {
+      if (!vbar || !gbar || !vbar[l] || !gbar[l]) return fail(NRH_E_INVALID, "%s: null output pointer", who);
+      a.wbar[l] = wbar ? wbar[l] : nullptr; a.vbar[l] = vbar[l]; a.gbar[l] = gbar[l];
+    } else {
+      if (!w || !w[l]) return fail(NRH_E_INVALID, "%s: null output pointer", who);
+      a.w[l] = w[l];
+    }
+    total += rows[l];
+  }
+  a.row_start[nlayers] = total;
+  const unsigned blocks = (unsigned)((total + 3) / 4);
+  if (adjoint) hipLaunchKernelGGL(nrh::fold_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(nrh::fold_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch(who);
+}
+
+int nrh_weight_norm_fold(int nlayers, const int* rows, const int* cols, const float* const* v, const float* const* g,
+                         float* const* w, void* stream) {
+  return fold_launch(false, nlayers, rows, cols, v, g, w, nullptr, nullptr, nullptr, stream);
+}
+
+int nrh_weight_norm_fold_backward(int nlayers, const int* rows, const int* cols, const float* const* v, const float* const* g,
+                                  const float* const* wbar, float* const* vbar, float* const* gbar, void* stream) {
+  return fold_launch(true, nlayers, rows, cols, v, g, nullptr, wbar, vbar, gbar, stream);
 }
 
 int nrh_color_train_forward(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,

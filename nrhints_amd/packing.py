@@ -116,6 +116,63 @@ def dense_params(state: Dict[str, torch.Tensor], prefix: str = "") -> Dict[str, 
     return out
 
 
+_FOLD_LAYERS = [f"sdf_network.lin{i}" for i in range(8)] + ["sdf_network.out_sdf", "sdf_network.out_feat"] + \
+               [f"color_network.lin{i}" for i in range(5)]
+_FOLD_KEYS = [(f"sdf_w{i}", f"sdf_b{i}") for i in range(8)] + [("sdf_head_w", "sdf_head_b"), ("feat_w", "feat_b")] + \
+             [(f"col_w{i}", f"col_b{i}") for i in range(5)]
+
+
+class WeightNormFoldHip(torch.autograd.Function):
+    """fold_weight_norm for all linears in ONE HIP launch, adjoint in one launch (csrc/nrh_fold.hip).
+    forward(g_0..g_{L-1}, v_0..v_{L-1}) -> (W_0..W_{L-1}); float32 CUDA tensors."""
+
+    @staticmethod
+    def _call(fn_name, vs, gs, *ptr_lists):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        L = len(vs)
+        IntArr, PtrArr = ctypes.c_int * L, ctypes.c_void_p * L
+        rows, cols = IntArr(*[v.shape[0] for v in vs]), IntArr(*[v.shape[1] for v in vs])
+        arr = lambda ts: PtrArr(*[(None if t is None else t.data_ptr()) for t in ts])
+        rc = getattr(lib, fn_name)(L, rows, cols, arr(vs), arr(gs), *[arr(p) for p in ptr_lists], _lib.stream_handle())
+        _lib.check(rc, fn_name)
+
+    @staticmethod
+    def forward(ctx, *gv):
+        L = len(gv) // 2
+        gs = [t.detach().contiguous() for t in gv[:L]]
+        vs = [t.detach().contiguous() for t in gv[L:]]
+        if not all(t.is_cuda and t.dtype == torch.float32 for t in gs + vs):
+            raise RuntimeError("WeightNormFoldHip needs float32 CUDA parameters")
+        ws = [torch.empty_like(v) for v in vs]
+        WeightNormFoldHip._call("nrh_weight_norm_fold", vs, gs, ws)
+        ctx.save_for_backward(*gs, *vs)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *wbars):
+        saved = ctx.saved_tensors
+        L = len(saved) // 2
+        gs, vs = list(saved[:L]), list(saved[L:])
+        wb = [None if t is None else t.to(torch.float32).contiguous() for t in wbars]
+        vbars = [torch.empty_like(v) for v in vs]
+        gbars = [torch.empty_like(g) for g in gs]
+        WeightNormFoldHip._call("nrh_weight_norm_fold_backward", vs, gs, wb, vbars, gbars)
+        return (*gbars, *vbars)
+
+
+def dense_params_hip(params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """``dense_params`` for live float32 CUDA parameters with the 15 folds (and their backward) in one launch each."""
+    gs = [params[n + ".weight_g"] for n in _FOLD_LAYERS]
+    vs = [params[n + ".weight_v"] for n in _FOLD_LAYERS]
+    ws = WeightNormFoldHip.apply(*gs, *vs)
+    out = {}
+    for (wk, bk), n, w in zip(_FOLD_KEYS, _FOLD_LAYERS, ws):
+        out[wk], out[bk] = w, params[n + ".bias"]
+    return out
+
+
 def check_default_shapes(d: Dict[str, torch.Tensor], hints: bool = True) -> None:
     """The kernels are compiled for the default nr-hints network shape."""
     want = {"sdf_w0": (256, 39), "sdf_w1": (256, 256), "sdf_w2": (256, 256), "sdf_w3": (217, 256),

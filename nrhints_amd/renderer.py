@@ -224,7 +224,9 @@ class NeuSHintRenderer(nn.Module):
         dense = None
         if needs_grad:
             # fold weight-norm once, with autograd history; the kernels' packed copies are cut from the same matrices
-            dense = packing.dense_params(dict(self.named_parameters()))
+            named = dict(self.named_parameters())
+            on_gpu_f32 = all(p.is_cuda and p.dtype == torch.float32 for p in named.values())
+            dense = packing.dense_params_hip(named) if on_gpu_f32 else packing.dense_params(named)
             self.packed_params(device, dense=dense)
         fused_train = needs_grad and self.sdf_backward == "hip" and n <= self.max_fused_train_rays
         if fused_train:

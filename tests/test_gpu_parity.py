@@ -37,7 +37,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 108
+    assert lib.nrh_version() >= 109
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
@@ -594,3 +594,28 @@ def test_color_net_hip_vs_torch(scene_states, hints):
             e_hip = ((a - r).norm() / (r.norm() + 1e-30)).item()
             e_t32 = ((b32 - r).norm() / (r.norm() + 1e-30)).item()
             assert e_hip <= 5.0 * e_t32 + 1e-3, (prec, name, e_hip, e_t32)
+
+
+def test_weight_norm_fold_hip(scene_states):
+    """One-launch fold of the 15 weight-normed linears and its adjoint (csrc/nrh_fold.hip) against the torch expression
+    v * g / ||v||_row and autograd (fields/sdf_field.py:81-82, old-style weight_norm, dim=0)."""
+    model = na.NeuSHintRenderer(na.NeuSModelConfig())
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in scene_states["b"].items()})
+    model = model.cuda()
+    named = dict(model.named_parameters())
+    ref = pk.dense_params(named)
+    got = pk.dense_params_hip(named)
+    rs = np.random.RandomState(0)
+    keys = [k for k in ref if "_w" in k]
+    probes = {k: cu(rs.randn(*ref[k].shape).astype(np.float32)) for k in keys}
+    for k in ref:
+        assert torch.allclose(got[k], ref[k], rtol=2e-6, atol=1e-7), k
+    prm = [p for n, p in named.items() if n.endswith("weight_g") or n.endswith("weight_v")]
+    g_ref = torch.autograd.grad(sum((ref[k] * probes[k]).sum() for k in keys), prm)
+    g_got = torch.autograd.grad(sum((got[k] * probes[k]).sum() for k in keys if k != "col_w2"), prm, allow_unused=True)
+    g_ref2 = torch.autograd.grad(sum((pk.dense_params(named)[k] * probes[k]).sum() for k in keys if k != "col_w2"), prm, allow_unused=True)
+    for (n, _), a, b in zip([(n, p) for n, p in named.items() if n.endswith("weight_g") or n.endswith("weight_v")], g_got, g_ref2):
+        if b is None:       # the layer left out of the loss: the one-launch adjoint writes zeros
+            assert a is not None and float(a.abs().max()) == 0.0, n
+        else:
+            assert torch.allclose(a, b, rtol=2e-4, atol=1e-6 * float(b.abs().max())), n
