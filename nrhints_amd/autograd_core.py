@@ -20,10 +20,20 @@ import torch.nn.functional as F
 from .sdf_function import sdf_value_feat_grad
 
 
+_FREQS = {}
+
+
+def _freqs(n_freq: int, like: torch.Tensor) -> torch.Tensor:
+    """2^k, k < n_freq, cached per (device, dtype): a training step encodes a dozen tensors."""
+    key = (n_freq, str(like.device), like.dtype)
+    if key not in _FREQS:
+        _FREQS[key] = 2.0 ** torch.arange(n_freq, dtype=like.dtype, device=like.device)
+    return _FREQS[key]
+
+
 def _enc(x: torch.Tensor, n_freq: int) -> torch.Tensor:
     """NeRF encoding with include_input (fields/encodings.py:168-174)."""
-    freqs = 2.0 ** torch.arange(n_freq, dtype=x.dtype, device=x.device)
-    s = (x[..., None] * freqs).reshape(*x.shape[:-1], -1)
+    s = (x[..., None] * _freqs(n_freq, x)).reshape(*x.shape[:-1], -1)
     return torch.cat([x, torch.sin(torch.cat([s, s + math.pi / 2.0], dim=-1))], dim=-1)
 
 

@@ -30,17 +30,23 @@ SKIP = 4
 EMB = 39
 
 
+_ENC_CONST = {}
+
+
 def _enc_parts(x3: torch.Tensor):
     """Encoding entries e(x3) [P,39], first derivatives dc [P,39] and second derivatives d2c [P,39] w.r.t. the
     coordinate each entry depends on; ``dim`` [39] says which coordinate that is (fields/encodings.py:168-174)."""
-    freqs = 2.0 ** torch.arange(6, dtype=x3.dtype, device=x3.device)
+    key = (str(x3.device), x3.dtype)
+    if key not in _ENC_CONST:
+        freqs = 2.0 ** torch.arange(6, dtype=x3.dtype, device=x3.device)
+        dim = torch.cat([torch.arange(3), torch.arange(3).repeat_interleave(6), torch.arange(3).repeat_interleave(6)]).to(x3.device)
+        _ENC_CONST[key] = (freqs, freqs.repeat(3), dim)
+    freqs, fr, dim = _ENC_CONST[key]
     s = (x3[..., None] * freqs).reshape(x3.shape[0], -1)          # [P,18] d-major, k-minor
-    fr = freqs.repeat(3)                                            # [18]
     sp = s + math.pi / 2.0
     e = torch.cat([x3, torch.sin(s), torch.sin(sp)], dim=1)
     dc = torch.cat([torch.ones_like(x3), torch.cos(s) * fr, torch.cos(sp) * fr], dim=1)
     d2c = torch.cat([torch.zeros_like(x3), -torch.sin(s) * fr * fr, -torch.sin(sp) * fr * fr], dim=1)
-    dim = torch.cat([torch.arange(3), torch.arange(3).repeat_interleave(6), torch.arange(3).repeat_interleave(6)]).to(x3.device)
     return e, dc, d2c, dim
 
 

@@ -95,3 +95,71 @@ def test_shape_guard(scene_states):
     d["sdf_w1"] = torch.zeros(64, 256)
     with pytest.raises(ValueError):
         pk.check_default_shapes(d)
+
+
+def _to_dlayout(rows):
+    """[16 points, F] row-major -> D-layout registers [F/4 regs, 64 lanes] (reg b*4+r of lane q*16+j = rows[j, 16b+4q+r])."""
+    F = rows.shape[1]
+    out = np.zeros((F // 4, 64))
+    for b in range(F // 16):
+        for r in range(4):
+            out[b * 4 + r] = rows[emu.J, 16 * b + 4 * emu.Q + r]
+    return out
+
+
+def _from_dlayout(regs):
+    nb = regs.shape[0] // 4
+    rows = np.zeros((16, nb * 16))
+    for b in range(nb):
+        for r in range(4):
+            rows[emu.J, 16 * b + 4 * emu.Q + r] = regs[b * 4 + r]
+    return rows
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_training_stage_packings_emulated(scene_states, precision):
+    """The packings only the training sweeps use - the transposed feature head (first stage of the SDF value sweep),
+    the transposed reflectance stages (colour adjoint sweep) and the batched packer - executed by the MFMA emulation
+    with the kernels' index arithmetic: every stage equals the dense transposed matrix product, and the whole colour
+    adjoint sweep equals the chain rule through the 5 linears (csrc/nrh_sdf_train.hip, csrc/nrh_color.hip)."""
+    st = {k: torch.from_numpy(np.asarray(v)).double() for k, v in scene_states["b"].items()}
+    d = pk.dense_params(st)
+    tol = 1e-12 if precision == 0 else 2e-6
+    rs = np.random.RandomState(5)
+    # batched packer == per-stage packer
+    ws = [d["sdf_w1"], d["sdf_w3"], d["col_w2"].t()]
+    ps = pk.pack_stage if precision == 0 else pk.pack_stage_h3
+    assert torch.equal(pk.pack_stages(ws, 256, 256, precision), torch.cat([ps(w, 256, 256) for w in ws]))
+    # transposed feature head: hbar = Wf^T fbar
+    fbar = rs.randn(16, 256)
+    out = emu.run_stage(pk.pack_feat_transposed(d, precision).numpy(), 16, 8, _to_dlayout(fbar))
+    np.testing.assert_allclose(_from_dlayout(out), fbar @ d["feat_w"].numpy(), rtol=0, atol=tol * 30)
+    # colour adjoint sweep
+    for hints in (True, False):
+        dd = dict(d)
+        if not hints:
+            dd["col_w0"] = d["col_w0"][:, :316]
+        wt = pk.pack_color_transposed(dd, precision, hints).numpy()
+        mkb = 8 if hints else 4
+        per = 1 if precision == 0 else 2          # elements per packed float slot
+        c4 = 8 * 2 * 2 * 256 * per
+        reg = pk.SDF_REG_FLOATS * per
+        assert wt.size == c4 + 4 * reg + (mkb // 2) * 2 * 16 * 256 * per
+        hs = [np.maximum(rs.randn(16, 256), 0.0) for _ in range(4)]
+        zbar4 = rs.randn(16, 3)
+        z4 = np.zeros((16, 32)); z4[:, :3] = zbar4
+        z = _from_dlayout(emu.run_stage(wt[:c4], 2, 8, _to_dlayout(z4))) * (hs[3] > 0)
+        z_ref = (zbar4 @ dd["col_w4"].numpy()) * (hs[3] > 0)
+        np.testing.assert_allclose(z, z_ref, rtol=0, atol=tol * 30)
+        for i, l in enumerate((3, 2, 1)):
+            z = _from_dlayout(emu.run_stage(wt[c4 + i * reg: c4 + (i + 1) * reg], 16, 8, _to_dlayout(z))) * (hs[l - 1] > 0)
+            z_ref = (z_ref @ dd[f"col_w{l}"].numpy()) * (hs[l - 1] > 0)
+            np.testing.assert_allclose(z, z_ref, rtol=0, atol=tol * 100)
+        fi, mi = pk.color_input_permutation(hints)
+        fb = _from_dlayout(emu.run_stage(wt[c4 + 3 * reg: c4 + 4 * reg], 16, 8, _to_dlayout(z)))
+        mb = _from_dlayout(emu.run_stage(wt[c4 + 4 * reg:], 16, mkb // 2, _to_dlayout(z)))
+        w0 = dd["col_w0"].numpy()
+        np.testing.assert_allclose(fb, z_ref @ w0[:, fi.numpy()], rtol=0, atol=tol * 100)
+        nm = 105 if hints else 60
+        np.testing.assert_allclose(mb[:, :nm], z_ref @ w0[:, mi.numpy()], rtol=0, atol=tol * 100)
+        assert np.abs(mb[:, nm:]).max() == 0.0
