@@ -51,7 +51,7 @@ class _LinearBigK(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         m = x.shape[0]
-        S = math.gcd(m, 32)
+        S = math.gcd(m, 64)
         gw = torch.bmm(gy.reshape(S, m // S, -1).transpose(1, 2), x.reshape(S, m // S, -1)).sum(0)
         return gy @ w, gw, gy.sum(0)
 
@@ -155,7 +155,7 @@ class ColorNetHip(torch.autograd.Function):
         grads_in = (fbar, mbar[:, 0:3], mbar[:, 3:6], mbar[:, 6:nm].reshape(n, 128, nm - 6).sum(1), None)
         if not any(ctx.needs_input_grad[5:]):
             return grads_in + (None,) * 10
-        S = math.gcd(Pn, 32)
+        S = math.gcd(Pn, 64)
 
         def big_k(a3, b3):
             L, ka, kb = a3.shape[0], a3.shape[-1], b3.shape[-1]

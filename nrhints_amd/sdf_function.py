@@ -224,8 +224,8 @@ class SdfValueFeatGradHip(torch.autograd.Function):
             ctx.saves = None
             return (p_bar[:n], None, None) + (None,) * 20
         # weight gradients: [256 x P] @ [P x 256] GEMMs with a tiny output and a huge K.  A plain GEMM call launches
-        # 16..32 workgroups for them (measured 44 TFLOP/s, 30 % of the step); splitting P into S batches fills the GPU.
-        S = math.gcd(m, 32)
+        # 16..32 workgroups for them (measured 44 TFLOP/s, 30 % of the step); splitting P into S = 64 batches fills the GPU (S = 32: 105, S = 64: 129 TFLOP/s).
+        S = math.gcd(m, 64)
 
         def big_k(a3, b3):          # [L,m,ka], [L,m,kb] -> [L,ka,kb] = sum over the m rows
             L, ka, kb = a3.shape[0], a3.shape[-1], b3.shape[-1]
