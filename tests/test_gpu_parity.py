@@ -4,6 +4,8 @@ Tolerances are float32 ones and are written next to each assertion.  The referen
 floor on this path: rgb <= 1e-5, depth 6e-5, visibilities 2.5e-4, per-sample weights up to
 3.7e-3 at isolated samples with mean 1e-6 - hence mean + outlier budgets for per-sample fields.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -619,3 +621,31 @@ def test_weight_norm_fold_hip(scene_states):
             assert a is not None and float(a.abs().max()) == 0.0, n
         else:
             assert torch.allclose(a, b, rtol=2e-4, atol=1e-6 * float(b.abs().max())), n
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_c_abi_standalone_program(scene_states, prec, tmp_path):
+    """examples/c_abi_render.cpp - a host program with no Python and no torch that links libnrhints_hip.so - renders a
+    scene file and must reproduce the Python host's result bit for bit (same kernels, same packed buffers)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from dump_scene import dump
+    from nrhints_amd import _lib
+    exe = os.path.join(os.path.dirname(_lib.LIB_PATH), "c_abi_render")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision=prec)
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in scene_states["b"].items()})
+    rays = make_rays(300, seed=4, spread=0.12)
+    scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    n = dump(scene, model, rays)
+    res = subprocess.run([exe, scene, out], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = np.fromfile(out, dtype=np.float32)
+    rgb, depth, vis = raw[:3 * n].reshape(n, 3), raw[3 * n:4 * n], raw[4 * n:5 * n]
+    ref = model.cuda().eval()
+    with torch.no_grad():
+        o = ref(_bundle(*rays), background_rgb=torch.ones(1, 3).cuda())
+    np.testing.assert_array_equal(rgb, o.rgb.cpu().numpy())
+    np.testing.assert_array_equal(depth, o.depth.cpu().numpy().reshape(-1))
+    np.testing.assert_array_equal(vis, o.visibilities.cpu().numpy().reshape(-1))
