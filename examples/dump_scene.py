@@ -21,15 +21,17 @@ MAGIC = 0x4e52483031
 
 
 def dump(path, model, rays, background=(1.0, 1.0, 1.0), cos_anneal=1.0):
-    """model: NeuSHintRenderer (any device); rays: (o, d, pl, near, far) numpy float32."""
-    state = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+    """model: NeuSHintRenderer; rays: (o, d, pl, near, far) numpy float32.  The weight-norm fold and the packing run on the
+    model's device (a GPU-resident model gives bit-identical buffers to the ones its own forward() uses; CPU and GPU
+    row norms differ in the last bit)."""
+    state = {k: v.detach().float() for k, v in model.state_dict().items()}
     d = packing.dense_params(state)
     prec = _lib.PRECISIONS[model.precision]
     hints = bool(model._hints)
     sw, sb, sh = packing.pack_sdf(d, prec)
     cw, cb = packing.pack_color(d, prec, hints)
     inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6))
-    blobs = [t.contiguous().numpy().tobytes() for t in (sw, sb, sh, cw, cb)]
+    blobs = [t.contiguous().cpu().numpy().tobytes() for t in (sw, sb, sh, cw, cb)]
     o, dr, pl, near, far = (np.ascontiguousarray(a, dtype=np.float32) for a in rays)
     n = o.shape[0]
     with open(path, "wb") as f:

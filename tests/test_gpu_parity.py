@@ -636,16 +636,16 @@ def test_c_abi_standalone_program(scene_states, prec, tmp_path):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision=prec)
     model.load_state_dict({k: T(np.asarray(v)) for k, v in scene_states["b"].items()})
+    model = model.cuda().eval()
     rays = make_rays(300, seed=4, spread=0.12)
     scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
-    n = dump(scene, model, rays)
+    n = dump(scene, model, rays)       # packed on the GPU, exactly the buffers model.forward() uses
     res = subprocess.run([exe, scene, out], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     raw = np.fromfile(out, dtype=np.float32)
     rgb, depth, vis = raw[:3 * n].reshape(n, 3), raw[3 * n:4 * n], raw[4 * n:5 * n]
-    ref = model.cuda().eval()
     with torch.no_grad():
-        o = ref(_bundle(*rays), background_rgb=torch.ones(1, 3).cuda())
+        o = model(_bundle(*rays), background_rgb=torch.ones(1, 3).cuda())
     np.testing.assert_array_equal(rgb, o.rgb.cpu().numpy())
     np.testing.assert_array_equal(depth, o.depth.cpu().numpy().reshape(-1))
     np.testing.assert_array_equal(vis, o.visibilities.cpu().numpy().reshape(-1))
