@@ -51,6 +51,10 @@ int nrh_mlp_grid(void);
  * nrh_kernel_timing_read: synchronises those events, returns their summed duration (ms) and count, and clears.
  * total_ms / launches are HOST pointers.  Not thread-safe; leave it off outside benchmarks. */
 int nrh_kernel_timing_select(int kind);
+/* Diagnosis builds only (-DNRH_TIMELINE=1, profiles/timeline.py): per-wave cycle totals of the four phases of an MLP
+ * chunk (weight-DMA issue + epilogue loads, K loop, epilogue, barrier) of the last SDF kernel launch,
+ * [workgroup][wave 8][counter 8] as unsigned 64-bit words copied to the HOST pointer.  NRH_E_UNSUPPORTED otherwise. */
+int nrh_debug_timeline_read(unsigned long long* out, int nwords);
 int nrh_kernel_timing_read(double* total_ms, long long* launches);
 
 /* ---- SDF network -------------------------------------------------------------------------------------------

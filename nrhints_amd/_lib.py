@@ -21,7 +21,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_backward",
-            "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward")
+            "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_debug_timeline_read")
 
 
 class NrhNet(Structure):
@@ -74,6 +74,7 @@ def load():
     PP = POINTER(c_void_p)
     lib.nrh_weight_norm_fold.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, P]
     lib.nrh_weight_norm_fold_backward.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, PP, PP, P]
+    lib.nrh_debug_timeline_read.argtypes = [POINTER(ctypes.c_ulonglong), c_int]
     lib.nrh_sampler_step.argtypes = [P, P, P, P, P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, c_int,
                                      c_int, c_int, P]
     lib.nrh_color_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, P, P, c_longlong, P, P]

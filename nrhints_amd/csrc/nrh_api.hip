@@ -214,7 +214,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 109; }
+int nrh_version(void) { return 110; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -234,6 +234,18 @@ int nrh_param_sizes(int* out) {
 int nrh_mlp_grid(void) { return mlp_grid(); }
 
 long long nrh_color_transposed_floats(int hints) { return nrh::colt_packed_floats(hints ? 8 : 4); }
+
+int nrh_debug_timeline_read(unsigned long long* out, int nwords) {
+#if NRH_TIMELINE
+  if (!out || nwords <= 0 || nwords > 1024 * 64) return fail(NRH_E_INVALID, "nrh_debug_timeline_read: bad arguments%s", "");
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nrh::g_timeline), (size_t)nwords * 8, 0, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(NRH_E_LAUNCH, "nrh_debug_timeline_read: copy failed%s", "");
+  return NRH_OK;
+#else
+  (void)out; (void)nwords;
+  return fail(NRH_E_UNSUPPORTED, "nrh_debug_timeline_read: library not built with -DNRH_TIMELINE=1%s", "");
+#endif
+}
 
 int nrh_kernel_timing_select(int kind) {
   if (kind < -1 || kind > 3) return fail(NRH_E_INVALID, "nrh_kernel_timing_select: kind must be -1..3%s", "");

@@ -19,8 +19,12 @@
 
 namespace nrh {
 
+#ifndef NRH_TIMELINE
+#define NRH_TIMELINE 0        // diagnosis build: per-wave cycle totals of the four phases of a chunk (s_memtime), see profiles/
+#endif
 constexpr int WBUF_BYTES = 32768;          // one LDS weight buffer (2 ob x 16 kb x 1 KiB)
-constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
+constexpr int TIMELINE_BYTES = NRH_TIMELINE ? 8 * 8 * 8 : 0;   // 8 waves x 8 counters (u64) behind the weight ring
+constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES + TIMELINE_BYTES;
 // ---- tuning knobs (compile-time; profiles/README.md records what each was measured to do) ----
 #ifndef NRH_WG_WAVES
 #define NRH_WG_WAVES 8        // waves per workgroup = 16-point tiles sharing one weight stream (8: +6..24 % vs 4)
@@ -50,6 +54,10 @@ constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
 constexpr int WG_WAVES = NRH_WG_WAVES;
 constexpr int MLP_THREADS = 64 * WG_WAVES;  // one 16-point tile per wave
 constexpr int TILE_PTS = 16;
+
+#if NRH_TIMELINE
+__device__ unsigned long long g_timeline[1024 * 64];   // [workgroup][wave][counter]: issue, K loop, epilogue, barrier (cycles), chunks
+#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -184,8 +192,15 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
                                           const float* init, Pre&& pre, Epi&& epi, int wave, int lane) {
   constexpr int PIECES = 2 * KB;
+#if NRH_TIMELINE
+  unsigned long long* tl = reinterpret_cast<unsigned long long*>(smem + 2 * WBUF_BYTES) + wave * 8;
+  auto tl_add = [&](int k, unsigned long long dt) { if (lane == 0) __hip_atomic_fetch_add(tl + k, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+#endif
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
+#if NRH_TIMELINE
+    const unsigned long long tl0 = __builtin_readcyclecounter();
+#endif
     char* nxt = smem + (par ^ 1) * WBUF_BYTES;
     if (ch + 1 < NCH) {
       dma_chunk(wsrc + (ch + 1) * PIECES * 256, nxt, PIECES, wave, lane);
@@ -194,6 +209,9 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     }
     asm volatile("" ::: "memory");  // keep pre()'s loads younger than the DMA in the vmcnt order
     const auto pv = pre(ch);
+#if NRH_TIMELINE
+    const unsigned long long tl1 = __builtin_readcyclecounter();
+#endif
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (HAS_INIT) {
       acc0 = f32x4{init[ch * 8 + 0], init[ch * 8 + 1], init[ch * 8 + 2], init[ch * 8 + 3]};
@@ -271,7 +289,15 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
       acc0 += c0 * LO_UNSCALE;
       acc1 += c1 * LO_UNSCALE;
     }
-#if NRH_BARRIER_FIRST
+#if NRH_TIMELINE
+    asm volatile("" : "+v"(acc0), "+v"(acc1));   // the K loop's results exist before the stamp
+    const unsigned long long tl2 = __builtin_readcyclecounter();
+    epi(ch, acc0, acc1, pv);
+    const unsigned long long tl3 = __builtin_readcyclecounter();
+    if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();
+    const unsigned long long tl4 = __builtin_readcyclecounter();
+    tl_add(0, tl1 - tl0); tl_add(1, tl2 - tl1); tl_add(2, tl3 - tl2); tl_add(3, tl4 - tl3); tl_add(4, 1);
+#elif NRH_BARRIER_FIRST
     // barrier BEFORE the epilogue: its vmcnt(0) then drains the stores of the PREVIOUS chunk's epilogue (issued a whole K
     // loop ago, long acknowledged) instead of the ones this epilogue is about to issue
     if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 109
+    assert lib.nrh_version() == 110
     sizes = (ctypes.c_int * 8)()
     assert lib.nrh_param_sizes(sizes) == 0
     assert sizes[7] in (4, 8)
