@@ -45,6 +45,14 @@ constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES + TIMELINE_BYTES;
 #ifndef NRH_ABL
 #define NRH_ABL 0             // bit 0: no LDS-DMA, 1: no barrier, 2: no MFMA, 3: no ds_read of A (f16x3), 4: trivial epilogue
 #endif
+#ifndef NRH_DMA_UNROLLED
+#define NRH_DMA_UNROLLED 0    // issue the (up to 4) DMA pieces of a wave as predicated straight-line code instead of a loop
+#endif
+#ifndef NRH_DMA_IN_KLOOP
+#define NRH_DMA_IN_KLOOP 0    // issue the next chunk's LDS-DMA pieces between the MFMAs of the K loop instead of before it:
+                              // s_memtime phases (profiles/r01/timeline_v1.log) showed every wave of the workgroup spending
+                              // 14-22 % of a chunk issuing 4 DMA pieces at the same moment, with no MFMA in flight anywhere
+#endif
 #ifndef NRH_BARRIER_FIRST
 #define NRH_BARRIER_FIRST 0   // end-of-chunk barrier between the K loop and the epilogue instead of after the epilogue
 #endif
@@ -69,6 +77,14 @@ __device__ __forceinline__ void dma_chunk(const float* __restrict__ src, char* d
   for (int k = wave; k < npieces; k += WG_WAVES) {
     __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 256 + lane * 4), (lptr_t)(dst_lds + k * 1024), 16, 0, 0);
   }
+}
+
+// piece i (of this wave's share) of a chunk copy: pieces wave, wave + 8, ... ; no-op past the end
+__device__ __forceinline__ void dma_piece(const float* __restrict__ src, char* dst_lds, int npieces, int i, int wave, int lane) {
+  if (NRH_ABL & 1) return;
+  const int k = wave + i * WG_WAVES;
+  if (src != nullptr && k < npieces)
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 256 + lane * 4), (lptr_t)(dst_lds + k * 1024), 16, 0, 0);
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -202,12 +218,21 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     const unsigned long long tl0 = __builtin_readcyclecounter();
 #endif
     char* nxt = smem + (par ^ 1) * WBUF_BYTES;
-    if (ch + 1 < NCH) {
-      dma_chunk(wsrc + (ch + 1) * PIECES * 256, nxt, PIECES, wave, lane);
-    } else if (wnext != nullptr) {
-      dma_chunk(wnext, nxt, next_pieces, wave, lane);
-    }
+    // what streams into the other buffer during this chunk: the stage's next chunk, or the first chunk of whatever runs next
+    const float* dsrc = (ch + 1 < NCH) ? wsrc + (ch + 1) * PIECES * 256 : wnext;
+    const int dn = (ch + 1 < NCH) ? PIECES : next_pieces;
+    constexpr int MAX_SHARE = (32 + WG_WAVES - 1) / WG_WAVES;   // pieces per wave of the largest chunk (32 KiB)
+#if !NRH_DMA_IN_KLOOP
+#if NRH_DMA_UNROLLED
+#pragma unroll
+    for (int i = 0; i < MAX_SHARE; ++i) dma_piece(dsrc, nxt, dn, i, wave, lane);
+#else
+    if (dsrc != nullptr) dma_chunk(dsrc, nxt, dn, wave, lane);
+#endif
     asm volatile("" ::: "memory");  // keep pre()'s loads younger than the DMA in the vmcnt order
+#else
+    static_assert(!NRH_RAW_BARRIER, "the raw chunk barrier needs the DMA issued before pre()'s loads");
+#endif
     const auto pv = pre(ch);
 #if NRH_TIMELINE
     const unsigned long long tl1 = __builtin_readcyclecounter();
@@ -241,6 +266,12 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, in.v[kb * 4 + 3], acc1, 0, 0, 0);
         a0 = n0;
         a1 = n1;
+#if NRH_DMA_IN_KLOOP
+        // piece i goes out after K block i * KB / MAX_SHARE (all of them after block 0 for the short stages)
+#pragma unroll
+        for (int i = 0; i < MAX_SHARE; ++i)
+          if (kb == (i * KB) / MAX_SHARE) dma_piece(dsrc, nxt, dn, i, wave, lane);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -282,6 +313,11 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
           c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c1, 0, 0, 0);
         }
+#if NRH_DMA_IN_KLOOP
+#pragma unroll
+        for (int i = 0; i < MAX_SHARE; ++i)
+          if (s == (i * KS) / MAX_SHARE) dma_piece(dsrc, nxt, dn, i, wave, lane);
+#endif
 #if NRH_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
 #endif
