@@ -179,3 +179,40 @@ def test_ray_generator_vs_reference_fixture():
             for n, gr in zip(names, torch.autograd.grad(loss, list(rg.parameters()))):
                 want = g[f"{tag}.grad.{n}"]
                 np.testing.assert_allclose(gr.numpy(), want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()), err_msg=f"{tag}.grad.{n}")
+
+
+def test_training_entry_points_validate_arguments_without_a_device():
+    """Error behaviour of the training entry points: bad arguments are rejected with NRH_E_INVALID (-1) /
+    NRH_E_UNSUPPORTED (-4) and a message BEFORE anything touches a device (so this runs on the CPU box), and zero-size
+    work is a successful no-op."""
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    err = lambda: lib.nrh_last_error_string().decode()
+    one = P(16)   # a non-null dummy pointer; never dereferenced on these paths
+    # null pointers
+    assert lib.nrh_sdf_train_forward(1, None, None, None, None, None, None, 1, 1, 16, None, None, None, None, None, None, None, None) == -1
+    assert "null" in err()
+    assert lib.nrh_sdf_train_backward(1, None, None, None, None, None, None, 1, 1, 16, None, None, None, None, None, None, None, None,
+                                      None, None, None) == -1 and "null" in err()
+    assert lib.nrh_alpha_train_forward(None, None, None, None, 1.0, 1.0, 4, None, None, None) == -1 and "null" in err()
+    assert lib.nrh_alpha_train_backward(None, None, None, None, 1.0, 1.0, 4, None, None, None, None, None, None, None) == -1
+    assert lib.nrh_color_train_forward(1, 1, None, None, None, None, None, None, 4, None, None, None, None) == -1 and "null" in err()
+    assert lib.nrh_color_train_backward(1, 1, None, None, None, 4, None, None, None, None) == -1 and "null" in err()
+    # bad precision / point count not a multiple of 16
+    assert lib.nrh_sdf_train_forward(7, one, one, one, one, one, one, 1, 1, 16, one, one, one, one, one, one, one, None) == -1
+    assert "precision" in err()
+    assert lib.nrh_sdf_train_forward(1, one, one, one, one, one, one, 1, 1, 17, one, one, one, one, one, one, one, None) == -1
+    assert "multiple of 16" in err()
+    assert lib.nrh_color_train_forward(3, 1, one, one, one, one, one, one, 4, one, one, one, None) == -1 and "precision" in err()
+    # zero rays: nothing to do, success
+    assert lib.nrh_sdf_train_forward(1, one, one, one, one, one, one, 1, 1, 0, one, one, one, one, one, one, one, None) == 0
+    assert lib.nrh_alpha_train_forward(one, one, one, one, 1.0, 1.0, 0, one, one, None) == 0
+    assert lib.nrh_color_train_backward(1, 1, one, one, one, 0, one, one, one, None) == 0
+    # fold: layer count and shape limits
+    IntArr, PtrArr = ctypes.c_int * 1, ctypes.c_void_p * 1
+    assert lib.nrh_weight_norm_fold(0, IntArr(4), IntArr(4), PtrArr(16), PtrArr(16), PtrArr(16), None) == -1
+    assert lib.nrh_weight_norm_fold(1, IntArr(4), IntArr(1000), PtrArr(16), PtrArr(16), PtrArr(16), None) == -1 and "384" in err()
+    # diagnosis hook is compiled out of the product build
+    buf = (ctypes.c_ulonglong * 8)()
+    assert lib.nrh_debug_timeline_read(buf, 8) == -4 and "NRH_TIMELINE" in err()
+    assert lib.nrh_color_transposed_floats(1) == 303104 and lib.nrh_color_transposed_floats(0) == 286720
