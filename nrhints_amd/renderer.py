@@ -108,7 +108,7 @@ class NeuSHintRenderer(nn.Module):
     # backward of (sdf, feat, d sdf/dx): "manual" = hand-derived sweeps in torch ops, "hip" = the same sweeps in the HIP
     # register-chain kernels (forward included), "autograd" = second-order autograd graph like the reference (A/B only)
     sdf_backward = "hip"
-    # largest training batch whose saved arrays (49 KB per sample point, fwd + bwd) are kept in one piece: 8192 rays = 51 GB
+    # largest training batch whose saved arrays (60 KB per sample point, fwd + bwd, both networks) are kept in one piece: 8192 rays = 63 GB
     max_fused_train_rays = 8192
 
     def __init__(self, config: NeuSModelConfig = None, precision: Optional[str] = None):
