@@ -107,7 +107,9 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
-    return {k: float(v.detach()) for k, v in losses.items()}
+    keys = list(losses)
+    vals = torch.stack([losses[k].detach().float().reshape(()) for k in keys]).tolist()      # one device-to-host copy
+    return dict(zip(keys, vals))
 
 
 # ---- checkpoints in the reference's layout (trainer/trainer.py:149-158, 173-236) ---------------------------------------
