@@ -245,6 +245,92 @@ def pack_color_transposed(d: Dict[str, torch.Tensor], precision: int = 0, hints:
     return torch.cat(parts).contiguous()
 
 
+# ---- one-gather packing plan --------------------------------------------------------------------------------------------
+# A training step re-packs every buffer after each optimiser step.  All packers above are pure index permutations (plus the
+# 1/sqrt(2) of W4 and the fp16 split), so they are run ONCE on tensors of element indices; after that a re-pack is one
+# gather + one divide + the split, for all buffers together (~10 launches instead of ~70).
+_W_KEYS = [w for w, _ in _FOLD_KEYS]
+_B_KEYS = [b for _, b in _FOLD_KEYS]
+
+
+def _h3_layout(wp: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """Element order of ONE part (hi or lo) of pack_stage_h3: [chunk][obi][s][lane = q*16+i][e = half*4+e4]."""
+    nch, ks = rows // 32, cols // 32
+    return wp.reshape(nch, 2, 16, ks, 2, 4, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1)
+
+
+class PackPlan:
+    """Index form of pack_sdf / pack_color / pack_feat_transposed / pack_color_transposed for one (precision, hints)."""
+
+    def __init__(self, dense: Dict[str, torch.Tensor], precision: int, hints: bool):
+        dev = dense["sdf_w0"].device
+        self.precision, self.hints = precision, hints
+        self.shapes = {k: tuple(dense[k].shape) for k in _W_KEYS + _B_KEYS}
+        # element indices (+1, so that the zero padding of the packers lands on slot 0 = the constant 0.0)
+        idx, off = {}, 1
+        for k in _W_KEYS + _B_KEYS:
+            n = int(torch.tensor(self.shapes[k]).prod())
+            idx[k] = (torch.arange(n, dtype=torch.float64) + off).reshape(self.shapes[k])
+            off += n
+        self.total = off
+        div = {k: torch.ones(self.shapes[k], dtype=torch.float64) for k in _W_KEYS + _B_KEYS}
+        div["sdf_w4"] = torch.full(self.shapes["sdf_w4"], math.sqrt(2.0), dtype=torch.float64)
+
+        def layouts(dd):
+            """The four weight buffers (fp32 layout, or the per-part fp16 layout) and the small fp32 vectors."""
+            if precision == 0:
+                ps = pack_stage
+                many = lambda ws, r, c: torch.cat([pack_stage(w, r, c) for w in ws])
+            else:
+                ps = lambda w, r, c: _h3_layout(torch.nn.functional.pad(w, (0, c - w.shape[1], 0, r - w.shape[0])), r, c)
+                many = lambda ws, r, c: torch.cat([ps(w, r, c) for w in ws])
+            w = [dd[f"sdf_w{i}"] for i in range(8)]
+            regular = [w[l] for l in range(1, 8)] + [dd["feat_w"]] + [w[l].t() for l in range(7, 0, -1)]
+            sdf = torch.cat([ps(w[0], 256, 64), many(regular, 256, 256), ps(w[0].t(), 64, 256)])
+            fi, mi = color_input_permutation(hints)
+            w0 = dd["col_w0"]
+            col = torch.cat([ps(w0[:, fi], 256, 256), ps(w0[:, mi], 256, 128 if hints else 64),
+                             many([dd[f"col_w{l}"] for l in (1, 2, 3)], 256, 256), ps(dd["col_w4"], 32, 256)])
+            wtf = ps(dd["feat_w"].t(), 256, 256)
+            colt = torch.cat([ps(dd["col_w4"].t(), 256, 32),
+                              many([dd["col_w3"].t(), dd["col_w2"].t(), dd["col_w1"].t(), w0[:, fi].t()], 256, 256),
+                              ps(w0[:, mi].t(), 128 if hints else 64, 256)])
+            sdf_b = torch.cat([_pad_vec(dd[f"sdf_b{i}"], 256) for i in range(8)] + [dd["feat_b"]])
+            col_b = torch.cat([dd["col_b0"], dd["col_b1"], dd["col_b2"], dd["col_b3"], _pad_vec(dd["col_b4"], 16)])
+            head = torch.cat([dd["sdf_head_w"].reshape(-1), dd["sdf_head_b"].reshape(-1)])
+            return [sdf, col, wtf, colt], [sdf_b, col_b, head]
+
+        wi, vi = layouts(idx)
+        wd, _ = layouts(div)
+        self.w_sizes = [t.numel() for t in wi]
+        self.v_sizes = [t.numel() for t in vi]
+        self.w_index = torch.cat(wi).to(torch.int64).to(dev)
+        wdiv = torch.cat(wd)
+        wdiv[wdiv == 0] = 1.0                                  # padding slots
+        self.w_div = wdiv.to(torch.float32).to(dev)
+        self.v_index = torch.cat(vi).to(torch.int64).to(dev)
+
+    def matches(self, dense, precision, hints) -> bool:
+        return precision == self.precision and hints == self.hints and \
+            all(tuple(dense[k].shape) == self.shapes[k] for k in self.shapes) and dense["sdf_w0"].device == self.w_index.device
+
+    def pack(self, dense: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """-> dict(sdf_w, col_w, sdf_wt_feat, col_wt, sdf_b, col_b, sdf_head), identical (bit for bit) to the direct packers."""
+        dev = self.w_index.device
+        flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=dev)] +
+                         [dense[k].detach().to(torch.float32).reshape(-1) for k in _W_KEYS + _B_KEYS])
+        x = flat[self.w_index] / self.w_div
+        if self.precision == 0:
+            packed, scale = x, 1
+        else:
+            hi, lo = split_f16(x)
+            packed = torch.stack([hi.reshape(-1, 512), lo.reshape(-1, 512)], dim=1).reshape(-1)
+            scale = 2
+        ws = torch.split(packed, [n * scale for n in self.w_sizes])
+        vs = torch.split(flat[self.v_index], self.v_sizes)
+        return dict(sdf_w=ws[0], col_w=ws[1], sdf_wt_feat=ws[2], col_wt=ws[3], sdf_b=vs[0], col_b=vs[1], sdf_head=vs[2])
+
+
 def feat_tiles_to_rows(tiles: torch.Tensor, npts: int) -> torch.Tensor:
     """D-layout feature tiles [ntiles,16(block),64(lane),4(r)] -> [npts,256]
     (lane = q*16 + j; feature = 16*block + 4*q + r; point = 16*tile + j)."""

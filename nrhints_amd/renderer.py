@@ -133,6 +133,7 @@ class NeuSHintRenderer(nn.Module):
         self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + self._hints + n_cue, 3,
                                                 config.reflectance_network, n_cue, self.has_shadow_hint)
         self._packed = None
+        self._pack_plan = None
         self._packed_key = None
         self._ws = {}
         self._consts = {}
@@ -145,19 +146,29 @@ class NeuSHintRenderer(nn.Module):
         """Fold weight-norm and pack for the kernels; cached until a parameter changes.  ``dense``: the already folded
         matrices of the CURRENT parameters (the training forward folds them once, with autograd history)."""
         key = self._param_key(device)
-        if self._packed_key != key:
+        stale = self._packed_key != key or (dense is not None and self._packed.get("col_wt") is None)
+        if stale:
             with torch.no_grad():
-                state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
-                d = packing.dense_params(state) if dense is None else {k: v.detach().to(device=device, dtype=torch.float32) for k, v in dense.items()}
-                packing.check_default_shapes(d, bool(self._hints))
                 prec = _lib.PRECISIONS[self.precision]
-                sw, sb, sh = packing.pack_sdf(d, prec)
-                cw, cb = packing.pack_color(d, prec, bool(self._hints))
-                wtf = packing.pack_feat_transposed(d, prec)
-                cwt = packing.pack_color_transposed(d, prec, bool(self._hints)) if dense is not None else None
-                inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6).item())
-            self._packed = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, inv_s=inv_s, precision=prec, sdf_wt_feat=wtf, col_wt=cwt,
-                                hints=bool(self._hints))
+                hints = bool(self._hints)
+                variance = self.deviation_network.variance.detach().to(device=device, dtype=torch.float32)
+                if dense is None:
+                    state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
+                    d = packing.dense_params(state)
+                    packing.check_default_shapes(d, hints)
+                    sw, sb, sh = packing.pack_sdf(d, prec)
+                    cw, cb = packing.pack_color(d, prec, hints)
+                    bufs = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb,
+                                sdf_wt_feat=packing.pack_feat_transposed(d, prec), col_wt=None)
+                else:
+                    # training: re-packed after every optimiser step -> the one-gather plan (packing.PackPlan)
+                    d = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in dense.items()}
+                    if self._pack_plan is None or not self._pack_plan.matches(d, prec, hints):
+                        packing.check_default_shapes(d, hints)
+                        self._pack_plan = packing.PackPlan(d, prec, hints)
+                    bufs = self._pack_plan.pack(d)
+                inv_s = float(torch.exp(variance * 10.0).clip(1e-6, 1e6).item())
+            self._packed = dict(bufs, inv_s=inv_s, precision=prec, hints=hints)
             self._packed_key = key
         return self._packed
 

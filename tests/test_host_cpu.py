@@ -216,3 +216,30 @@ def test_training_entry_points_validate_arguments_without_a_device():
     buf = (ctypes.c_ulonglong * 8)()
     assert lib.nrh_debug_timeline_read(buf, 8) == -4 and "NRH_TIMELINE" in err()
     assert lib.nrh_color_transposed_floats(1) == 303104 and lib.nrh_color_transposed_floats(0) == 286720
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("hints", [True, False])
+def test_pack_plan_equals_direct_packers(precision, hints):
+    """packing.PackPlan (the packers run once on element indices, then one gather per re-pack) reproduces pack_sdf /
+    pack_color / pack_feat_transposed / pack_color_transposed bit for bit, for a second set of weights too."""
+    from nrhints_amd.synthetic import naive_state
+    torch.manual_seed(3)
+    m = na.NeuSHintRenderer()
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    if not hints:
+        st = {k: torch.from_numpy(v) for k, v in naive_state({k: v.numpy() for k, v in st.items()}).items()}
+    d = pk.dense_params(st)
+    plan = pk.PackPlan(d, precision, hints)
+    for trial in range(2):
+        if trial == 1:
+            d = {k: v + 0.01 * torch.randn_like(v) for k, v in d.items()}
+        assert plan.matches(d, precision, hints) and not plan.matches(d, 1 - precision, hints)
+        got = plan.pack(d)
+        sw, sb, sh = pk.pack_sdf(d, precision)
+        cw, cb = pk.pack_color(d, precision, hints)
+        want = dict(sdf_w=sw, sdf_b=sb, sdf_head=sh, col_w=cw, col_b=cb, sdf_wt_feat=pk.pack_feat_transposed(d, precision),
+                    col_wt=pk.pack_color_transposed(d, precision, hints))
+        for k, v in want.items():
+            assert got[k].dtype == v.dtype and got[k].shape == v.shape and torch.equal(got[k], v), k
+            assert got[k].data_ptr() % 16 == 0, k
