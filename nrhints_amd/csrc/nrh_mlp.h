@@ -10,10 +10,14 @@
 //
 //        value[b*4 + r] on lane (j = l & 15, q = l >> 4)   <->   feature 16*b + 4*q + r of point j
 //
-// Weights are streamed once per workgroup (4 waves = 64 points) through a double-buffered 2 x 32 KiB
+// Weights are streamed once per workgroup (8 waves = 128 points) through a double-buffered 2 x 32 KiB
 // LDS ring by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction), in "chunks" of two
 // 16-row output blocks x all K blocks, pre-packed on the host so that the 64 lanes' float4 operands
 // of one (output block, K block) pair are one contiguous, conflict-free 1 KiB line.
+//
+// The same machinery runs every per-point chain of the path: SDF value / gradient / feature (nrh_sdf.hip), the
+// reflectance net (nrh_color.hip), and for training the tangent and adjoint sweeps of both networks (nrh_sdf_train.hip,
+// nrh_color.hip) - they differ only in the packed stages they stream and in their epilogues.
 #pragma once
 #include "nrh_common.h"
 
