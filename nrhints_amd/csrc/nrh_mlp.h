@@ -26,9 +26,15 @@ namespace nrh {
 #ifndef NRH_TIMELINE
 #define NRH_TIMELINE 0        // diagnosis build: per-wave cycle totals of the four phases of a chunk (s_memtime), see profiles/
 #endif
+#ifndef NRH_PAIRED
+#define NRH_PAIRED 0          // 4-slot weight ring with ONE workgroup barrier per TWO chunks (kernels whose stages all have an
+                              // even chunk count); 0 = 2-slot ring, barrier per chunk
+#endif
 constexpr int WBUF_BYTES = 32768;          // one LDS weight buffer (2 ob x 16 kb x 1 KiB)
 constexpr int TIMELINE_BYTES = NRH_TIMELINE ? 8 * 8 * 8 : 0;   // 8 waves x 8 counters (u64) behind the weight ring
-constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES + TIMELINE_BYTES;
+constexpr int RING_SLOTS = NRH_PAIRED ? 4 : 2;
+constexpr int MLP_LDS_BYTES = RING_SLOTS * WBUF_BYTES + TIMELINE_BYTES;
+static_assert(!(NRH_PAIRED && NRH_TIMELINE), "the timeline stamps assume the 2-slot ring");
 // ---- tuning knobs (compile-time; profiles/README.md records what each was measured to do) ----
 #ifndef NRH_WG_WAVES
 #define NRH_WG_WAVES 8        // waves per workgroup = 16-point tiles sharing one weight stream (8: +6..24 % vs 4)
@@ -207,7 +213,10 @@ __device__ __forceinline__ void chunk_barrier() {
   __syncthreads();
 }
 
-template <int PREC, int KB, int NCH, bool HAS_INIT, bool PRE_LOADS = false, typename Pre, typename Epi>
+// PAIRED: `par` is the ring slot (0..3) of the chunk about to be multiplied; at every even chunk the two chunks after the
+// next one are requested (from this stage, or the first two chunks of `wnext`, which therefore needs >= 2 chunks of
+// `next_pieces` KiB each, contiguous), and the workgroup barrier comes after every odd chunk.
+template <int PREC, int KB, int NCH, bool HAS_INIT, bool PRE_LOADS = false, bool PAIRED = false, typename Pre, typename Epi>
 __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const float* __restrict__ wnext,
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
                                           const float* init, Pre&& pre, Epi&& epi, int wave, int lane) {
@@ -226,6 +235,18 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     const float* dsrc = (ch + 1 < NCH) ? wsrc + (ch + 1) * PIECES * 256 : wnext;
     const int dn = (ch + 1 < NCH) ? PIECES : next_pieces;
     constexpr int MAX_SHARE = (32 + WG_WAVES - 1) / WG_WAVES;   // pieces per wave of the largest chunk (32 KiB)
+    if constexpr (PAIRED) {
+      static_assert(NCH % 2 == 0, "paired stages need an even chunk count");
+      static_assert(!NRH_DMA_IN_KLOOP, "not combined");
+      if ((ch & 1) == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = ch + 2 + jj;
+          const float* src = (j < NCH) ? wsrc + j * PIECES * 256 : (wnext != nullptr ? wnext + (j - NCH) * next_pieces * 256 : nullptr);
+          if (src != nullptr) dma_chunk(src, smem + ((par + 2 + jj) & 3) * WBUF_BYTES, (j < NCH) ? PIECES : next_pieces, wave, lane);
+        }
+      }
+    } else {
 #if !NRH_DMA_IN_KLOOP
 #if NRH_DMA_UNROLLED
 #pragma unroll
@@ -237,6 +258,7 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
 #else
     static_assert(!NRH_RAW_BARRIER, "the raw chunk barrier needs the DMA issued before pre()'s loads");
 #endif
+    }
     const auto pv = pre(ch);
 #if NRH_TIMELINE
     const unsigned long long tl1 = __builtin_readcyclecounter();
@@ -344,9 +366,13 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     epi(ch, acc0, acc1, pv);
 #else
     epi(ch, acc0, acc1, pv);
-    if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();  // the next chunk's weights are in LDS for every wave past this point
+    if constexpr (PAIRED) {
+      if (ch & 1) __syncthreads();     // chunks ch+1, ch+2 (requested one pair ago) are in LDS for every wave past this point
+    } else {
+      if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();  // the next chunk's weights are in LDS for every wave past this point
+    }
 #endif
-    par ^= 1;
+    par = PAIRED ? ((par + 1) & 3) : (par ^ 1);
   }
 }
 
