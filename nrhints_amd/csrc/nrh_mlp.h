@@ -26,15 +26,9 @@ namespace nrh {
 #ifndef NRH_TIMELINE
 #define NRH_TIMELINE 0        // diagnosis build: per-wave cycle totals of the four phases of a chunk (s_memtime), see profiles/
 #endif
-#ifndef NRH_PAIRED
-#define NRH_PAIRED 0          // 4-slot weight ring with ONE workgroup barrier per TWO chunks (kernels whose stages all have an
-                              // even chunk count); 0 = 2-slot ring, barrier per chunk
-#endif
 constexpr int WBUF_BYTES = 32768;          // one LDS weight buffer (2 ob x 16 kb x 1 KiB)
 constexpr int TIMELINE_BYTES = NRH_TIMELINE ? 8 * 8 * 8 : 0;   // 8 waves x 8 counters (u64) behind the weight ring
-constexpr int RING_SLOTS = NRH_PAIRED ? 4 : 2;
-constexpr int MLP_LDS_BYTES = RING_SLOTS * WBUF_BYTES + TIMELINE_BYTES;
-static_assert(!(NRH_PAIRED && NRH_TIMELINE), "the timeline stamps assume the 2-slot ring");
+constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES + TIMELINE_BYTES;
 // ---- tuning knobs (compile-time; profiles/README.md records what each was measured to do) ----
 #ifndef NRH_WG_WAVES
 #define NRH_WG_WAVES 8        // waves per workgroup = 16-point tiles sharing one weight stream (8: +6..24 % vs 4)
@@ -55,20 +49,6 @@ static_assert(!(NRH_PAIRED && NRH_TIMELINE), "the timeline stamps assume the 2-s
 #ifndef NRH_ABL
 #define NRH_ABL 0             // bit 0: no LDS-DMA, 1: no barrier, 2: no MFMA, 3: no ds_read of A (f16x3), 4: trivial epilogue
 #endif
-#ifndef NRH_DMA_UNROLLED
-#define NRH_DMA_UNROLLED 0    // issue the (up to 4) DMA pieces of a wave as predicated straight-line code instead of a loop
-#endif
-#ifndef NRH_DMA_IN_KLOOP
-#define NRH_DMA_IN_KLOOP 0    // issue the next chunk's LDS-DMA pieces between the MFMAs of the K loop instead of before it:
-                              // s_memtime phases (profiles/r01/timeline_v1.log) showed every wave of the workgroup spending
-                              // 14-22 % of a chunk issuing 4 DMA pieces at the same moment, with no MFMA in flight anywhere
-#endif
-#ifndef NRH_BARRIER_FIRST
-#define NRH_BARRIER_FIRST 0   // end-of-chunk barrier between the K loop and the epilogue instead of after the epilogue
-#endif
-#ifndef NRH_RAW_BARRIER
-#define NRH_RAW_BARRIER 0     // chunk barrier without vmcnt(0) (stores stay in flight): measured +3 % / -6 % (kbench7) -> off
-#endif
 constexpr int WG_WAVES = NRH_WG_WAVES;
 constexpr int MLP_THREADS = 64 * WG_WAVES;  // one 16-point tile per wave
 constexpr int TILE_PTS = 16;
@@ -87,14 +67,6 @@ __device__ __forceinline__ void dma_chunk(const float* __restrict__ src, char* d
   for (int k = wave; k < npieces; k += WG_WAVES) {
     __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 256 + lane * 4), (lptr_t)(dst_lds + k * 1024), 16, 0, 0);
   }
-}
-
-// piece i (of this wave's share) of a chunk copy: pieces wave, wave + 8, ... ; no-op past the end
-__device__ __forceinline__ void dma_piece(const float* __restrict__ src, char* dst_lds, int npieces, int i, int wave, int lane) {
-  if (NRH_ABL & 1) return;
-  const int k = wave + i * WG_WAVES;
-  if (src != nullptr && k < npieces)
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 256 + lane * 4), (lptr_t)(dst_lds + k * 1024), 16, 0, 0);
 }
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -197,26 +169,11 @@ struct Act<1, KB> {
 // LDS image of a chunk (both precisions 2*KB KiB):
 //   PREC 0: [obi 2][kb KB][lane 64] float4           - A of 4 consecutive 16x16x4 MFMAs
 //   PREC 1: [obi 2][s KB/2][hi|lo][lane 64] 8 x fp16 - A of one 16x16x32 MFMA (hi) / its low part
-// End-of-chunk barrier.  __syncthreads() drains vmcnt(0), i.e. it also waits for the acknowledgement of the stores the
-// epilogue just issued (sigma' scratch, feature tiles).  When the stage's pre() hook issued a global load AFTER the
-// LDS-DMA of the next chunk and the epilogue consumed it, that consumption already implied vmcnt <= (ops younger than
-// the load) - the in-order counter guarantees the DMA landed - so a bare s_barrier (+ lgkmcnt for the LDS reads) is
-// enough and the stores stay in flight.  Stages without such a load must use the draining form.
-template <bool PRE_LOADS>
-__device__ __forceinline__ void chunk_barrier() {
-#if NRH_RAW_BARRIER
-  if constexpr (PRE_LOADS) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    return;
-  }
-#endif
-  __syncthreads();
-}
-
-// PAIRED: `par` is the ring slot (0..3) of the chunk about to be multiplied; at every even chunk the two chunks after the
-// next one are requested (from this stage, or the first two chunks of `wnext`, which therefore needs >= 2 chunks of
-// `next_pieces` KiB each, contiguous), and the workgroup barrier comes after every odd chunk.
-template <int PREC, int KB, int NCH, bool HAS_INIT, bool PRE_LOADS = false, bool PAIRED = false, typename Pre, typename Epi>
+// PRE_LOADS documents that pre() issues global loads (kept for the call sites' readability; no effect on the code).
+// Variants of this loop that were measured and dropped (code in the commits named in profiles/README.md): chunk barrier
+// without the vmcnt drain, barrier before the epilogue, LDS-DMA issue inside the K loop / as straight-line code, a
+// 4-slot ring with one barrier per two chunks, deeper / pinned A-operand prefetch.
+template <int PREC, int KB, int NCH, bool HAS_INIT, bool PRE_LOADS = false, typename Pre, typename Epi>
 __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const float* __restrict__ wnext,
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
                                           const float* init, Pre&& pre, Epi&& epi, int wave, int lane) {
@@ -230,35 +187,14 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
 #if NRH_TIMELINE
     const unsigned long long tl0 = __builtin_readcyclecounter();
 #endif
+    // the other buffer receives the stage's next chunk, or the first chunk of whatever runs next, during this chunk
     char* nxt = smem + (par ^ 1) * WBUF_BYTES;
-    // what streams into the other buffer during this chunk: the stage's next chunk, or the first chunk of whatever runs next
-    const float* dsrc = (ch + 1 < NCH) ? wsrc + (ch + 1) * PIECES * 256 : wnext;
-    const int dn = (ch + 1 < NCH) ? PIECES : next_pieces;
-    constexpr int MAX_SHARE = (32 + WG_WAVES - 1) / WG_WAVES;   // pieces per wave of the largest chunk (32 KiB)
-    if constexpr (PAIRED) {
-      static_assert(NCH % 2 == 0, "paired stages need an even chunk count");
-      static_assert(!NRH_DMA_IN_KLOOP, "not combined");
-      if ((ch & 1) == 0) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int j = ch + 2 + jj;
-          const float* src = (j < NCH) ? wsrc + j * PIECES * 256 : (wnext != nullptr ? wnext + (j - NCH) * next_pieces * 256 : nullptr);
-          if (src != nullptr) dma_chunk(src, smem + ((par + 2 + jj) & 3) * WBUF_BYTES, (j < NCH) ? PIECES : next_pieces, wave, lane);
-        }
-      }
-    } else {
-#if !NRH_DMA_IN_KLOOP
-#if NRH_DMA_UNROLLED
-#pragma unroll
-    for (int i = 0; i < MAX_SHARE; ++i) dma_piece(dsrc, nxt, dn, i, wave, lane);
-#else
-    if (dsrc != nullptr) dma_chunk(dsrc, nxt, dn, wave, lane);
-#endif
-    asm volatile("" ::: "memory");  // keep pre()'s loads younger than the DMA in the vmcnt order
-#else
-    static_assert(!NRH_RAW_BARRIER, "the raw chunk barrier needs the DMA issued before pre()'s loads");
-#endif
+    if (ch + 1 < NCH) {
+      dma_chunk(wsrc + (ch + 1) * PIECES * 256, nxt, PIECES, wave, lane);
+    } else if (wnext != nullptr) {
+      dma_chunk(wnext, nxt, next_pieces, wave, lane);
     }
+    asm volatile("" ::: "memory");  // the weight stream goes out first, then the epilogue's loads
     const auto pv = pre(ch);
 #if NRH_TIMELINE
     const unsigned long long tl1 = __builtin_readcyclecounter();
@@ -292,12 +228,6 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, in.v[kb * 4 + 3], acc1, 0, 0, 0);
         a0 = n0;
         a1 = n1;
-#if NRH_DMA_IN_KLOOP
-        // piece i goes out after K block i * KB / MAX_SHARE (all of them after block 0 for the short stages)
-#pragma unroll
-        for (int i = 0; i < MAX_SHARE; ++i)
-          if (kb == (i * KB) / MAX_SHARE) dma_piece(dsrc, nxt, dn, i, wave, lane);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -339,11 +269,6 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
           c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c1, 0, 0, 0);
         }
-#if NRH_DMA_IN_KLOOP
-#pragma unroll
-        for (int i = 0; i < MAX_SHARE; ++i)
-          if (s == (i * KS) / MAX_SHARE) dma_piece(dsrc, nxt, dn, i, wave, lane);
-#endif
 #if NRH_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -356,23 +281,14 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     const unsigned long long tl2 = __builtin_readcyclecounter();
     epi(ch, acc0, acc1, pv);
     const unsigned long long tl3 = __builtin_readcyclecounter();
-    if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();
+    if (!(NRH_ABL & 2)) __syncthreads();
     const unsigned long long tl4 = __builtin_readcyclecounter();
     tl_add(0, tl1 - tl0); tl_add(1, tl2 - tl1); tl_add(2, tl3 - tl2); tl_add(3, tl4 - tl3); tl_add(4, 1);
-#elif NRH_BARRIER_FIRST
-    // barrier BEFORE the epilogue: its vmcnt(0) then drains the stores of the PREVIOUS chunk's epilogue (issued a whole K
-    // loop ago, long acknowledged) instead of the ones this epilogue is about to issue
-    if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();
-    epi(ch, acc0, acc1, pv);
 #else
     epi(ch, acc0, acc1, pv);
-    if constexpr (PAIRED) {
-      if (ch & 1) __syncthreads();     // chunks ch+1, ch+2 (requested one pair ago) are in LDS for every wave past this point
-    } else {
-      if (!(NRH_ABL & 2)) chunk_barrier<PRE_LOADS>();  // the next chunk's weights are in LDS for every wave past this point
-    }
+    if (!(NRH_ABL & 2)) __syncthreads();  // the next chunk's weights are in LDS for every wave past this point
 #endif
-    par = PAIRED ? ((par + 1) & 3) : (par ^ 1);
+    par ^= 1;
   }
 }
 

@@ -118,7 +118,6 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   if (threadIdx.x < 64) reinterpret_cast<unsigned long long*>(smem + 2 * WBUF_BYTES)[threadIdx.x] = 0ull;
 #endif
   dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
-  if (NRH_PAIRED) dma_chunk(a.w + SDF_OFF_L0 + 8 * 256, smem + WBUF_BYTES, 8, wave, lane);
   __syncthreads();
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         if (MODE >= 1) ds_store(0, ch, d0, d1);
         if constexpr (TRAIN) save_rows(a.save_h, 0, ch, h0, h1);
       };
-      run_stage<PREC, 4, 8, false, true, NRH_PAIRED>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 4, 8, false, true>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, pre, epi, wave, lane);
     }
 
     // ---- steps 1..15: L1..L7, FEAT, R7..R1 share one 256x256 body ----
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
 
       if (MODE >= 1 && s == 9) {
         // start of the reverse chain: t_7 = sigma'_7 * (w_s / 3), written by L7's epilogue
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own t_7 stores (the chunk barrier no longer drains)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own t_7 stores have landed
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
           f32x4 v0, v1;
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
           }
         }
       };
-      run_stage<PREC, 16, 8, false, true, NRH_PAIRED>(wcur, wnxt, npc, smem, par, h, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 16, 8, false, true>(wcur, wnxt, npc, smem, par, h, nullptr, pre, epi, wave, lane);
 
       if (s == 7) {
         // sdf head: (w_s . h8 + b_s) / scale   (fields/sdf_field.py:121)
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ge[ch * 8 + r] = acc0[r]; ge[ch * 8 + 4 + r] = acc1[r]; }
       };
-      run_stage<PREC, 16, 2, false, false, NRH_PAIRED>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 8, smem, par, h, nullptr, pre, epi, wave, lane);
+      run_stage<PREC, 16, 2, false>(a.w + SDF_OFF_R0, a.w + SDF_OFF_L0, 8, smem, par, h, nullptr, pre, epi, wave, lane);
 
       if constexpr (TRAIN) {
         if (tile_ok) {
