@@ -388,3 +388,16 @@ class NeuSHintRenderer(nn.Module):
             pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
             u[x0:x0 + slab] = (-self.sdf(pts)).reshape(xx.shape).cpu().numpy()
         return u
+
+    @torch.no_grad()
+    def extract_geometry(self, bound_min, bound_max, resolution: int, threshold: float = 0.0):
+        """Mesh of the zero level set -> (vertices [V,3] world coordinates, triangles [T,3]) as numpy arrays
+        (models/neus_hint_model.py:86-93, 753-758): dense ``-sdf`` grid from the HIP SDF kernel, then PyMCubes if it is
+        installed (the reference's triangulation), else the marching-tetrahedra routine of ``nrhints_amd.isosurface``."""
+        from .isosurface import extract_surface
+        u = self.extract_fields(bound_min, bound_max, resolution)
+        vertices, triangles = extract_surface(u, threshold)
+        b_min = np.asarray([float(bound_min[i]) for i in range(3)])
+        b_max = np.asarray([float(bound_max[i]) for i in range(3)])
+        vertices = vertices / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
+        return vertices, triangles

@@ -243,3 +243,30 @@ def test_pack_plan_equals_direct_packers(precision, hints):
         for k, v in want.items():
             assert got[k].dtype == v.dtype and got[k].shape == v.shape and torch.equal(got[k], v), k
             assert got[k].data_ptr() % 16 == 0, k
+
+
+def test_marching_tetrahedra_sphere_is_a_closed_oriented_manifold():
+    """nrhints_amd.isosurface.marching_tetrahedra (the PyMCubes stand-in of extract_geometry) on the -sdf grid of a sphere:
+    vertices on the sphere, every edge shared by exactly two triangles with opposite directions, normals outwards, area and
+    volume of the sphere; an empty level set gives an empty mesh."""
+    from nrhints_amd.isosurface import marching_tetrahedra
+    R, rad = 40, 0.55
+    g = np.linspace(-1.0, 1.0, R)
+    xx, yy, zz = np.meshgrid(g, g, g, indexing="ij")
+    u = -(np.sqrt((xx - 0.1) ** 2 + yy ** 2 + (zz + 0.05) ** 2) - rad)
+    v, f = marching_tetrahedra(u, 0.0)
+    vw = v / (R - 1) * 2.0 - 1.0
+    c = np.array([0.1, 0.0, -0.05])
+    assert np.abs(np.linalg.norm(vw - c, axis=1) - rad).max() < 2e-3
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    _, cnt = np.unique(np.sort(e, axis=1), axis=0, return_counts=True)
+    assert (cnt == 2).all()                                         # closed, manifold
+    _, cnt_d = np.unique(e, axis=0, return_counts=True)
+    assert (cnt_d == 1).all()                                       # consistently oriented
+    a, b, d = vw[f[:, 0]], vw[f[:, 1]], vw[f[:, 2]]
+    n = np.cross(b - a, d - a)
+    assert ((n * ((a + b + d) / 3 - c)).sum(1) > 0).all()           # outwards (from -sdf > 0 to < 0)
+    assert abs(0.5 * np.linalg.norm(n, axis=1).sum() - 4 * np.pi * rad ** 2) < 0.01 * 4 * np.pi * rad ** 2
+    assert abs(((a - c) * np.cross(b - c, d - c)).sum() / 6 - 4 / 3 * np.pi * rad ** 3) < 0.01 * 4 / 3 * np.pi * rad ** 3
+    v0, f0 = marching_tetrahedra(u - 10.0, 0.0)
+    assert v0.shape == (0, 3) and f0.shape == (0, 3)
