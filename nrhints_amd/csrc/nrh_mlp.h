@@ -172,7 +172,8 @@ struct Act<1, KB> {
 // PRE_LOADS documents that pre() issues global loads (kept for the call sites' readability; no effect on the code).
 // Variants of this loop that were measured and dropped (code in the commits named in profiles/README.md): chunk barrier
 // without the vmcnt drain, barrier before the epilogue, LDS-DMA issue inside the K loop / as straight-line code, a
-// 4-slot ring with one barrier per two chunks, deeper / pinned A-operand prefetch.
+// 4-slot ring with one barrier per two chunks, deeper / pinned A-operand prefetch, the epilogue of chunk c-1 interleaved
+// with the MFMAs of chunk c by sched_group_barrier.
 template <int PREC, int KB, int NCH, bool HAS_INIT, bool PRE_LOADS = false, typename Pre, typename Epi>
 __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const float* __restrict__ wnext,
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
@@ -291,80 +292,6 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     par ^= 1;
   }
 }
-
-#ifndef NRH_PIPE_EXPERIMENT
-#define NRH_PIPE_EXPERIMENT 0   // timing experiment, WRONG RESULTS (sampler kernel only, simplified epilogue): 1 = normal order,
-                                // 2 = the epilogue of chunk c-1 scheduled between the MFMAs of chunk c (sched_group_barrier)
-#endif
-#if NRH_PIPE_EXPERIMENT
-// f16x3 stage with the epilogue running one chunk late, interleaved with the next chunk's K loop by the scheduler.
-template <int KB, int NCH, bool PIPE, typename Pre, typename Epi, typename Pin>
-__device__ __forceinline__ void run_stage_pipe(const float* __restrict__ wsrc, const float* __restrict__ wnext, int next_pieces,
-                                               char* smem, int& par, const Act<1, KB>& in, Pre&& pre, Epi&& epi, Pin&& pin, int wave, int lane) {
-  constexpr int PIECES = 2 * KB, KS = KB / 2;
-  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
-  decltype(pre(0)) ppv = pre(0);
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    char* nxt = smem + (par ^ 1) * WBUF_BYTES;
-    if (ch + 1 < NCH) dma_chunk(wsrc + (ch + 1) * PIECES * 256, nxt, PIECES, wave, lane);
-    else if (wnext != nullptr) dma_chunk(wnext, nxt, next_pieces, wave, lane);
-    asm volatile("" ::: "memory");
-    const auto pv = pre(ch);
-    if (PIPE) asm volatile("" : "+v"(p0), "+v"(p1));   // the pending epilogue starts inside this region
-    __builtin_amdgcn_sched_barrier(0);
-    const u32x4* A = reinterpret_cast<const u32x4*>(smem + par * WBUF_BYTES);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, c0 = acc0, c1 = acc0;
-    u32x4 ra[2][4];   // A operands {hi0, lo0, hi1, lo1} of the current and the next K step
-    auto ldA = [&](int s, u32x4 (&r)[4]) {
-      r[0] = A[((0 * KS + s) * 2 + 0) * 64 + lane]; r[1] = A[((0 * KS + s) * 2 + 1) * 64 + lane];
-      r[2] = A[((1 * KS + s) * 2 + 0) * 64 + lane]; r[3] = A[((1 * KS + s) * 2 + 1) * 64 + lane];
-    };
-    ldA(0, ra[0]);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) ldA(s + 1, ra[(s + 1) & 1]);
-      const u32x4 bhu = {in.h[s * 4 + 0], in.h[s * 4 + 1], in.h[s * 4 + 2], in.h[s * 4 + 3]};
-      const u32x4 blu = {in.l[s * 4 + 0], in.l[s * 4 + 1], in.l[s * 4 + 2], in.l[s * 4 + 3]};
-      const f16x8 bh = __builtin_bit_cast(f16x8, bhu), bl = __builtin_bit_cast(f16x8, blu);
-      const f16x8 ah0 = __builtin_bit_cast(f16x8, ra[s & 1][0]), al0 = __builtin_bit_cast(f16x8, ra[s & 1][1]);
-      const f16x8 ah1 = __builtin_bit_cast(f16x8, ra[s & 1][2]), al1 = __builtin_bit_cast(f16x8, ra[s & 1][3]);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c1, 0, 0, 0);
-      if (!PIPE) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (PIPE) {
-      if (ch > 0) { epi(ch - 1, p0, p1, ppv); pin(ch - 1); }   // pin: the results exist before the fence below
-      // desired issue order: per K step 4 LDS reads, then (1 MFMA, 2 VALU) x 6
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // K step 0's operands
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // next step's operands go out first
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc0 += c0 * LO_UNSCALE;
-      acc1 += c1 * LO_UNSCALE;
-      p0 = acc0; p1 = acc1; ppv = pv;
-    } else {
-      acc0 += c0 * LO_UNSCALE;
-      acc1 += c1 * LO_UNSCALE;
-      epi(ch, acc0, acc1, pv);
-    }
-    __syncthreads();
-    par ^= 1;
-  }
-  if (PIPE) epi(NCH - 1, p0, p1, ppv);
-}
-#endif
 
 // ---------------- packed-buffer geometry of the SDF net (floats) ----------------
 // execution order: L0 | L1..L7 | FEAT | R7..R1 | R0        (R_l = W_l^T, the reverse chain)

@@ -316,29 +316,6 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
           }
         }
       };
-#if NRH_PIPE_EXPERIMENT
-      if constexpr (MODE == 0 && PREC == 1) {
-        // timing experiment (wrong results): plain softplus epilogue for every stage, normal vs pipelined order
-        auto pre_x = [&](int ch) {
-          PreV p;
-          p.a0 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch) * 16 + 4 * q);
-          p.a1 = *reinterpret_cast<const f32x4*>(a.b + s * 256 + (2 * ch + 1) * 16 + 4 * q);
-          return p;
-        };
-        auto epi_x = [&](int ch, f32x4 acc0, f32x4 acc1, const PreV& p) {
-          f32x4 h0, h1, d0, d1;
-          softplus100_4<false>(acc0 + p.a0, h0, d0);
-          softplus100_4<false>(acc1 + p.a1, h1, d1);
-          head_part += h0[0] + h1[0];
-          ho.set_chunk(ch, h0, h1);
-        };
-        auto pin_x = [&](int ch) {
-          asm volatile("" : "+v"(ho.h[ch * 4 + 0]), "+v"(ho.h[ch * 4 + 1]), "+v"(ho.h[ch * 4 + 2]), "+v"(ho.h[ch * 4 + 3]),
-                       "+v"(ho.l[ch * 4 + 0]), "+v"(ho.l[ch * 4 + 1]), "+v"(ho.l[ch * 4 + 2]), "+v"(ho.l[ch * 4 + 3]));
-        };
-        run_stage_pipe<16, 8, NRH_PIPE_EXPERIMENT == 2>(wcur, wnxt, npc, smem, par, h, pre_x, epi_x, pin_x, wave, lane);
-      } else
-#endif
       run_stage<PREC, 16, 8, false, true>(wcur, wnxt, npc, smem, par, h, nullptr, pre, epi, wave, lane);
 
       if (s == 7) {
