@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
   if (lin16.empty()) { fprintf(stderr, "truncated scene file\n"); return 1; }
 
   printf("%s | abi %d | %lld rays, precision %d, hints %d\n", nrh_build_info(), nrh_version(), n, precision, hints);
-  NrhNet net;
+  NrhNet net = {};
   void* dev[5];
   for (int i = 0; i < 5; ++i) {
     dev[i] = to_device(blobs[i]);

@@ -132,9 +132,10 @@ int nrh_color_train_backward(int precision, int hints, const float* col_wt, cons
  *   backward: + weights_bar [nrays,128], nhat_bar [nrays*128,3] (may be null) -> sdf_bar, grad_bar, rd_bar [nrays,3],
  *             invs_bar [nrays] (per-ray partial of the adjoint of inv_s; the caller sums and chains to `variance`) */
 int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
-                            float cos_anneal, long long nrays, float* weights, float* nhat, void* stream);
+                            float cos_anneal, const float* dyn_scalars /* as NrhNet.dyn_scalars, may be null */,
+                            long long nrays, float* weights, float* nhat, void* stream);
 int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
-                             float cos_anneal, long long nrays, const float* weights_bar, const float* nhat_bar,
+                             float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar, const float* nhat_bar,
                              float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream);
 
 /* ---- hierarchical sampler (one launch = merge the previous 16 samples and/or draw 16 new ones) ------------
@@ -187,6 +188,9 @@ typedef struct NrhNet {
                       no shadow march, reflectance input 316 wide, col_w packed accordingly */
   int normal_type; /* 0 = NormalizedAnalytic, 1 = Analytic normal fed to the reflectance net (models/neus_hint_model.py:621-625) */
   int depth_type;  /* 0 = AlphaBlend, 1 = MaximalWeightPoint (:528-538) */
+  const float* dyn_scalars; /* optional DEVICE [inv_s, cos_anneal]: when non-null it overrides `inv_s` above and the `cos_anneal`
+                               argument of the render calls, read by the kernels at run time - a captured hipGraph of a
+                               training step then follows the changing variance parameter and anneal schedule */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

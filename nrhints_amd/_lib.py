@@ -27,7 +27,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
 class NrhNet(Structure):
     _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
-                ("normal_type", c_int), ("depth_type", c_int)]
+                ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p)]
 
 
 class NrhTrainSaves(Structure):
@@ -65,8 +65,8 @@ def load():
     lib.nrh_sdf_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
     lib.nrh_sdf_train_forward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P]
     lib.nrh_sdf_train_backward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P, P]
-    lib.nrh_alpha_train_forward.argtypes = [P, P, P, P, c_float, c_float, c_longlong, P, P, P]
-    lib.nrh_alpha_train_backward.argtypes = [P, P, P, P, c_float, c_float, c_longlong, P, P, P, P, P, P, P]
+    lib.nrh_alpha_train_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P]
+    lib.nrh_alpha_train_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P]
     lib.nrh_color_transposed_floats.argtypes = [c_int]
     lib.nrh_color_transposed_floats.restype = c_longlong
     lib.nrh_color_train_forward.argtypes = [c_int, c_int, P, P, P, P, P, P, c_longlong, P, P, P, P]

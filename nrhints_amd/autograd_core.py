@@ -66,7 +66,7 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
     and F.normalize of models/neus_hint_model.py:339-356, :521-525, :584 and what autograd derives from them."""
 
     @staticmethod
-    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float):
+    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float, dyn=None):
         from . import _lib
         lib = _lib.load()
         n = dirs.shape[0]
@@ -75,10 +75,11 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
         weights = torch.empty(n, 128, dtype=torch.float32, device=dirs.device)
         nhat = torch.empty(n * 128, 3, dtype=torch.float32, device=dirs.device)
         P = _lib.ptr
-        _lib.check(lib.nrh_alpha_train_forward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), float(inv_s), float(cos_anneal), n,
+        _lib.check(lib.nrh_alpha_train_forward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), float(inv_s), float(cos_anneal), P(dyn), n,
                                                P(weights), P(nhat), _lib.stream_handle()), "nrh_alpha_train_forward")
         ctx.save_for_backward(sdf_c, grad_c, dirs_c, dists_c)
         ctx.consts = (float(inv_s), float(cos_anneal))
+        ctx.dyn = dyn
         return weights, nhat
 
     @staticmethod
@@ -93,12 +94,17 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
         nbar = None if nbar is None else nbar.to(torch.float32).contiguous()
         sdf_bar, grad_bar, rd_bar, invs_bar = new(n * 128, 1), new(n * 128, 3), new(n, 3), new(n)
         P = _lib.ptr
-        _lib.check(lib.nrh_alpha_train_backward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, n, P(wbar), P(nbar),
+        dyn = ctx.dyn
+        _lib.check(lib.nrh_alpha_train_backward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, P(dyn), n, P(wbar), P(nbar),
                                                 P(sdf_bar), P(grad_bar), P(rd_bar), P(invs_bar), _lib.stream_handle()),
                    "nrh_alpha_train_backward")
         # inv_s = clip(exp(10 variance), 1e-6, 1e6): d inv_s / d variance = 10 inv_s inside the clip range
-        var_bar = invs_bar.sum() * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)
-        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None
+        if dyn is not None:       # device-side inv_s (hipGraph mode): same chain rule without a host value
+            s_dev = dyn[0]
+            var_bar = invs_bar.sum() * torch.where((s_dev > 1e-6) & (s_dev < 1e6), 10.0 * s_dev, torch.zeros_like(s_dev))
+        else:
+            var_bar = invs_bar.sum() * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)
+        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None, None
 
 
 class ColorNetHip(torch.autograd.Function):
@@ -161,14 +167,27 @@ class ColorNetHip(torch.autograd.Function):
             L, ka, kb = a3.shape[0], a3.shape[-1], b3.shape[-1]
             return torch.bmm(a3.reshape(L * S, Pn // S, ka).transpose(1, 2), b3.reshape(L * S, Pn // S, kb)).reshape(L, S, ka, kb).sum(1)
 
-        fi, mi = packing.color_input_permutation(hints)
+        fi, mi = _col_perm(dev, hints)
         w0_bar = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
-        w0_bar[:, fi.to(dev)] = big_k(zbar[0:1], feat_c[None])[0]
-        w0_bar[:, mi.to(dev)] = big_k(zbar[0:1], save_misc[None])[0][:, :nm]
+        w0_bar[:, fi] = big_k(zbar[0:1], feat_c[None])[0]
+        w0_bar[:, mi] = big_k(zbar[0:1], save_misc[None])[0][:, :nm]
         w123 = big_k(zbar[1:4], save_h[0:3])
         w4_bar = big_k(zbar4[None], save_h[3:4])[0]
         zs = _colsum(zbar)
         return grads_in + (w0_bar, w123[0], w123[1], w123[2], w4_bar, zs[0], zs[1], zs[2], zs[3], zbar4.sum(0))
+
+
+_COL_PERM = {}
+
+
+def _col_perm(device, hints: bool):
+    """packing.color_input_permutation on the device, cached (no host-to-device copy inside a captured step)."""
+    key = (str(device), hints)
+    if key not in _COL_PERM:
+        from . import packing
+        fi, mi = packing.color_input_permutation(hints)
+        _COL_PERM[key] = (fi.to(device), mi.to(device))
+    return _COL_PERM[key]
 
 
 _COL_INDEX = {}
@@ -213,7 +232,7 @@ def _color_net_torch(d, feat, pts, normal, per_ray, n, T, hints):
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
-                background_rgb, analytic_normal: bool = False, sdf_impl: str = "manual", packed=None, pre=None) -> Dict[str, torch.Tensor]:
+                background_rgb, analytic_normal: bool = False, sdf_impl: str = "manual", packed=None, pre=None, dyn=None) -> Dict[str, torch.Tensor]:
     """``d``: weight-norm-folded dense parameters WITH autograd history (packing.dense_params on the live
     nn.Parameters); mid_z / dists [N,128], vis [N,1], cue [N,4]: graph-less results of the HIP forward."""
     n, T = mid_z.shape
@@ -228,7 +247,7 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
     if sdf_impl == "hip" and packed is not None:
         # alpha, transmittance product, weights and unit normals: one HIP kernel forward, one for the adjoint
-        weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal)
+        weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal, dyn)
     else:
         view = dirs[:, None, :].expand(n, T, 3).reshape(-1, 3)
         true_cos = (view * grad).sum(-1, keepdim=True)

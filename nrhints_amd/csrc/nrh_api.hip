@@ -214,7 +214,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 110; }
+int nrh_version(void) { return 111; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -434,13 +434,15 @@ int nrh_color_train_backward(int precision, int hints, const float* col_wt, cons
 }
 
 int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
-                            float cos_anneal, long long nrays, float* weights, float* nhat, void* stream) {
+                            float cos_anneal, const float* dyn_scalars, long long nrays, float* weights, float* nhat,
+                            void* stream) {
   if (!sdf || !grad || !rd || !dists || !weights || !nhat) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: null pointer%s", "");
   if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: nrays out of range%s", "");
   if (nrays == 0) return NRH_OK;
   nrh::AlphaTrainArgs a;
   memset(&a, 0, sizeof(a));
   a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.dyn = dyn_scalars;
   a.weights = weights; a.nhat = nhat;
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -448,7 +450,7 @@ int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd
 }
 
 int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
-                             float cos_anneal, long long nrays, const float* weights_bar, const float* nhat_bar,
+                             float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar, const float* nhat_bar,
                              float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
   if (!sdf || !grad || !rd || !dists || !weights_bar || !sdf_bar || !grad_bar || !rd_bar || !invs_bar)
     return fail(NRH_E_INVALID, "nrh_alpha_train_backward: null pointer%s", "");
@@ -457,6 +459,7 @@ int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* r
   nrh::AlphaTrainArgs a;
   memset(&a, 0, sizeof(a));
   a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.dyn = dyn_scalars;
   a.weights_bar = weights_bar; a.nhat_bar = nhat_bar; a.sdf_bar = sdf_bar; a.grad_bar = grad_bar; a.rd_bar = rd_bar;
   a.invs_bar = invs_bar;
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
@@ -595,6 +598,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     c.tmid = o_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
     c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
     c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal; c.shadow_offset = 1e-2f;
+    c.dyn = net->dyn_scalars;
     const double rough[4] = {0.02, 0.05, 0.13, 0.34};  // models/neus_hint_model.py:161
     for (int i = 0; i < 4; ++i) {
       const double k = (rough[i] + 1.0) * (rough[i] + 1.0) / 8.0, a2 = rough[i] * rough[i];
@@ -620,6 +624,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     nrh::ShadowArgs c;
     c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = ws_dists_s;
     c.cue = ws_cue; c.vis = o_vis; c.raymisc = ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
+    c.dyn = net->dyn_scalars;
     c.nrays = (int)n; c.zero_hints = no_hints;
     hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
     rc = check_launch("shadow_finish_kernel");

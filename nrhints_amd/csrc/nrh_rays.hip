@@ -227,6 +227,7 @@ struct CoreArgs {
   float* slast;         // [N] light distance / 64
   float* zs;            // [N,128] coarse shadow z (first 64)
   float inv_s, cos_anneal, shadow_offset;
+  const float* dyn;     // optional device [inv_s, cos_anneal] overriding the two values above (hipGraph-captured training steps)
   // per-roughness constants evaluated in double on the host, as Python does for the reference's scalars
   // (models/neus_hint_model.py:604, 609): k, 1 - k, a^2, a^2 - 1
   float kk[4], omk[4], a2[4], a2m1[4];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
     const long long P = ray * 128 + lane + 64 * e;
     const float gx = a.grad[P * 3 + 0], gy = a.grad[P * 3 + 1], gz = a.grad[P * 3 + 2];
     mid[e] = a.tmid[P];
-    al[e] = neus_alpha(a.sdf[P], gx, gy, gz, dx, dy, dz, a.dists[P], a.inv_s, a.cos_anneal);
+    al[e] = neus_alpha(a.sdf[P], gx, gy, gz, dx, dy, dz, a.dists[P], a.dyn ? a.dyn[0] : a.inv_s, a.dyn ? a.dyn[1] : a.cos_anneal);
     const float px = ox + dx * mid[e], py = oy + dy * mid[e], pz = oz + dz * mid[e];
     ins[e] = (sqrtf(px * px + py * py + pz * pz) < 1.0f) ? 1.0f : 0.0f;
     const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
@@ -364,6 +365,7 @@ struct ShadowArgs {
   float* vis;           // [N]
   float* raymisc;       // [N,RAYMISC_STRIDE]
   float inv_s, cos_anneal;
+  const float* dyn;     // optional device [inv_s, cos_anneal], see CoreArgs
   int nrays;
   int zero_hints;       // geometry warm-up: hints are zero (models/neus_hint_model.py:577-579, 617-619)
 };
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void shadow_finish_kernel(const ShadowArgs a) 
     for (int e = 0; e < 2; ++e) {
       const long long P = ray * 128 + lane + 64 * e;
       al[e] = neus_alpha(a.sdf[P], a.grad[P * 3 + 0], a.grad[P * 3 + 1], a.grad[P * 3 + 2], dx, dy, dz, a.dists[P],
-                         a.inv_s, a.cos_anneal);
+                         a.dyn ? a.dyn[0] : a.inv_s, a.dyn ? a.dyn[1] : a.cos_anneal);
     }
     float T0, T1;
     excl_prod_128(1.0f - al[0] + 1e-7f, 1.0f - al[1] + 1e-7f, T0, T1);

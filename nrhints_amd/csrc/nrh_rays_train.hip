@@ -20,6 +20,7 @@ struct AlphaTrainArgs {
   const float* dists;    // [N,128]
   float inv_s;
   float cos_anneal;
+  const float* dyn;      // optional device [inv_s, cos_anneal] overriding the two values above
   int nrays;
   // forward outputs
   float* weights;        // [N,128]
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
   const bool active = ray_raw < a.nrays;
   const long long ray = active ? ray_raw : a.nrays - 1;
   const float dx = a.rd[ray * 3 + 0], dy = a.rd[ray * 3 + 1], dz = a.rd[ray * 3 + 2];
-  const float S = a.inv_s, ca = a.cos_anneal;
+  const float S = a.dyn ? a.dyn[0] : a.inv_s, ca = a.dyn ? a.dyn[1] : a.cos_anneal;
 
   float s[2], g[2][3], del[2], tc[2], ic[2], en[2], ep[2], pc[2], nc[2], q[2], al[2], f[2], gn[2];
 #pragma unroll

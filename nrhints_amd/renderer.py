@@ -110,6 +110,9 @@ class NeuSHintRenderer(nn.Module):
     sdf_backward = "hip"
     # largest training batch whose saved arrays (60 KB per sample point, fwd + bwd, both networks) are kept in one piece: 8192 rays = 63 GB
     max_fused_train_rays = 8192
+    # hipGraph mode (training.GraphedTrainStep): a device tensor [inv_s, cos_anneal] that the kernels read at run time
+    # instead of the host floats baked into a captured launch; None = normal (eager) operation
+    dyn_scalars = None
 
     def __init__(self, config: NeuSModelConfig = None, precision: Optional[str] = None):
         super().__init__()
@@ -167,7 +170,11 @@ class NeuSHintRenderer(nn.Module):
                         packing.check_default_shapes(d, hints)
                         self._pack_plan = packing.PackPlan(d, prec, hints)
                     bufs = self._pack_plan.pack(d)
-                inv_s = float(torch.exp(variance * 10.0).clip(1e-6, 1e6).item())
+                if self.dyn_scalars is not None:      # no host sync: the kernels read inv_s from the device
+                    self.dyn_scalars[0:1].copy_(torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(1))
+                    inv_s = float("nan")
+                else:
+                    inv_s = float(torch.exp(variance * 10.0).clip(1e-6, 1e6).item())
             self._packed = dict(bufs, inv_s=inv_s, precision=prec, hints=hints)
             self._packed_key = key
         return self._packed
@@ -257,7 +264,7 @@ class NeuSHintRenderer(nn.Module):
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
-                sdf_impl=self.sdf_backward, packed=pk, pre=res.get("pre"))
+                sdf_impl=self.sdf_backward, packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars)
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],
@@ -281,7 +288,7 @@ class NeuSHintRenderer(nn.Module):
         lin64, lin16 = self._const(device)
         net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
                           _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
-                          self._hints, self._normal_type, self._depth_type)
+                          self._hints, self._normal_type, self._depth_type, _lib.ptr(self.dyn_scalars))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
@@ -314,7 +321,7 @@ class NeuSHintRenderer(nn.Module):
         lin64, lin16 = self._const(device)
         net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
                           _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
-                          self._hints, self._normal_type, self._depth_type)
+                          self._hints, self._normal_type, self._depth_type, _lib.ptr(self.dyn_scalars))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))

@@ -112,6 +112,100 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
     return dict(zip(keys, vals))
 
 
+class GraphedTrainStep:
+    """The whole optimisation step - forward, loss, backward, (gradient exchange,) Adam - captured ONCE into a hipGraph
+    and replayed: one graph launch per step instead of ~230 kernel launches issued from Python, which is what bounds
+    small batches (the reference's default is 512 rays per step, 64 per rank under 8-way DDP).
+
+    What changes between steps is read from device memory at run time: the batch (static ray / pixel buffers that
+    ``__call__`` copies into), 1/s and the cos-anneal ratio (``renderer.dyn_scalars``, see NrhNet.dyn_scalars) and the
+    learning rates (tensor-valued ``lr`` of a capturable Adam).  The jitter comes from the graph-safe device generator.
+    Frozen at capture time: the batch size, the precision / model configuration, whether the geometry warm-up is active
+    (re-create the object when ``global_step`` crosses ``geometry_warmup_end``).
+
+        step = GraphedTrainStep(renderer, batch_rays=512, background_rgb=bg, lr=5e-4)
+        for it in range(...): losses = step(ray_bundle, rgb_gt, global_step=it)     # dict of python floats
+    """
+
+    def __init__(self, renderer, batch_rays: int, background_rgb: torch.Tensor, lr: float = 5e-4, warm_up_end: int = 5_000,
+                 end_iter: int = 1_000_000, lr_alpha: float = 0.05, global_step: int = 0,
+                 grad_sync: Optional["FlatGradAllReduce"] = None, warmup_steps: int = 3):
+        dev = next(renderer.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedTrainStep needs the renderer on the GPU")
+        self.renderer, self.grad_sync = renderer, grad_sync
+        self.sched_args = (warm_up_end, end_iter, lr_alpha)
+        self.base_lr = lr
+        self.lr_t = torch.tensor(lr, dtype=torch.float32, device=dev)
+        self.optimizer = torch.optim.Adam([{"params": list(renderer.parameters()), "lr": self.lr_t}], capturable=True)
+        n = batch_rays
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        from .containers import RayBundle
+        self.rays = RayBundle(origins=z(n, 3), directions=z(n, 3), pl_positions=z(n, 3), nears=z(n, 1), fars=z(n, 1))
+        self.gt = z(n, 3)
+        self.bg = background_rgb.detach().to(dev, torch.float32).reshape(1, 3).clone()
+        renderer.dyn_scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._capture_step = global_step
+        self._set_host_scalars(global_step)
+        # sane static inputs for the warm-up / capture passes: a ring of rays looking at the origin
+        ang = torch.linspace(0.0, 6.2832, n, device=dev)
+        o = torch.stack([3.0 * torch.cos(ang), 3.0 * torch.sin(ang), torch.full_like(ang, 0.5)], dim=1)
+        d = torch.nn.functional.normalize(-o, dim=1)
+        self.rays.origins.copy_(o); self.rays.directions.copy_(d); self.rays.pl_positions.copy_(o * 1.3)
+        mid = -(o * d).sum(1, keepdim=True)
+        self.rays.nears.copy_(mid - 1.0); self.rays.fars.copy_(mid + 1.0)
+        self.gt.fill_(0.5)
+        self._keys: List[str] = []
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup_steps)):      # builds every cache (pack plan, workspace, constants) eagerly
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self._loss_vec = self._body()
+
+    def _set_host_scalars(self, global_step: int) -> None:
+        cfg = self.renderer.config
+        cos = min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0
+        self.renderer.dyn_scalars[1:2].fill_(cos)
+        self.lr_t.fill_(self.base_lr * lr_factor(global_step, *self.sched_args))
+
+    def _body(self) -> torch.Tensor:
+        out = self.renderer(self.rays, is_training=True, background_rgb=self.bg, global_step=self._capture_step)
+        losses = train_loss_dict(out, self.gt, self.renderer.config.igr_weight)
+        self.optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        self.optimizer.step()
+        self._keys = list(losses)
+        return torch.stack([losses[k].detach().float().reshape(()) for k in self._keys])
+
+    def __call__(self, ray_bundle, rgb_gt: torch.Tensor, global_step: int) -> Dict[str, float]:
+        n = self.gt.shape[0]
+        if ray_bundle.origins.shape[0] != n:
+            raise ValueError(f"this graph was captured for {n} rays per step, got {ray_bundle.origins.shape[0]}")
+        cfg = self.renderer.config
+        if (global_step < cfg.geometry_warmup_end) != (self._capture_step < cfg.geometry_warmup_end):
+            raise RuntimeError("geometry warm-up state changed since capture: create a new GraphedTrainStep")
+        for dst, src in ((self.rays.origins, ray_bundle.origins), (self.rays.directions, ray_bundle.directions),
+                         (self.rays.pl_positions, ray_bundle.pl_positions), (self.rays.nears, ray_bundle.nears),
+                         (self.rays.fars, ray_bundle.fars), (self.gt, rgb_gt)):
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        self._set_host_scalars(global_step)
+        self.graph.replay()
+        return dict(zip(self._keys, self._loss_vec.tolist()))
+
+    def release(self) -> None:
+        """Back to eager operation (drops the graph and the device-side scalars)."""
+        self.graph = None
+        self.renderer.dyn_scalars = None
+
+
 # ---- checkpoints in the reference's layout (trainer/trainer.py:149-158, 173-236) ---------------------------------------
 def register_view(renderer, ray_generator, img_pixel_bundle, device, steps: int = 500, batch_size: int = 512,
                   white_background: bool = True, lr: Optional[float] = None, generator: Optional[torch.Generator] = None,

@@ -17,7 +17,7 @@ def main():
     torch.manual_seed(0)
     student = na.NeuSHintRenderer().cuda()
     if len(sys.argv) > 3:
-        student.sdf_backward = sys.argv[3]          # manual | hip | autograd
+        student.sdf_backward = sys.argv[3] if sys.argv[3] != "graph" else "hip"         # manual | hip | autograd | graph
     teacher = na.NeuSHintRenderer()
     st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in student.state_dict().items()})
     teacher.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
@@ -32,17 +32,25 @@ def main():
         with torch.no_grad():
             batches.append((rb, teacher(rb, background_rgb=bg).rgb))
     losses, t0 = [], None
+    graphed = None
+    if len(sys.argv) > 3 and sys.argv[3] == "graph":       # the whole step captured into one hipGraph
+        from nrhints_amd.training import GraphedTrainStep
+        student.sdf_backward = "hip"
+        graphed = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000)
     for step, (rb, gt) in enumerate(batches):
         if step == 3:
             torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = train_step(student, rb, gt, bg, global_step=20000 + step, optimizer=opt, scheduler=sched)
+        if graphed is not None:
+            out = graphed(rb, gt, global_step=20000 + step)
+        else:
+            out = train_step(student, rb, gt, bg, global_step=20000 + step, optimizer=opt, scheduler=sched)
         losses.append(out["loss"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"metric": "training ray-steps/s (fwd+bwd+Adam)", "batch": batch, "steps": steps,
                       "value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2),
                       "loss_first3": [round(x, 5) for x in losses[:3]], "loss_last3": [round(x, 5) for x in losses[-3:]],
-                      "precision": student.precision, "sdf_backward": student.sdf_backward}))
+                      "precision": student.precision, "sdf_backward": student.sdf_backward, "hip_graph": graphed is not None}))
 
 if __name__ == "__main__":
     main()

@@ -39,7 +39,7 @@ def scene(request, scene_states):
 def test_native_library_loaded():
     from nrhints_amd import _lib
     lib = _lib.load()
-    assert lib.nrh_version() >= 110
+    assert lib.nrh_version() >= 111
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]
@@ -705,3 +705,40 @@ def test_extract_geometry_of_the_initial_sphere(scene_states):
     e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
     _, cnt = np.unique(np.sort(e, axis=1), axis=0, return_counts=True)
     assert (cnt == 2).all()
+
+
+def test_graphed_train_step(scene_states):
+    """training.GraphedTrainStep: forward + loss + backward + Adam captured into one hipGraph and replayed.  The replayed
+    step must train (loss on a fixed batch falls, held-out error against the teacher falls), follow the host-side schedule
+    through device scalars (learning rate, cos-anneal ratio) and leave the renderer usable eagerly afterwards."""
+    from nrhints_amd.training import GraphedTrainStep, lr_factor
+    torch.manual_seed(0)
+    student = na.NeuSHintRenderer(na.NeuSModelConfig())
+    student.load_state_dict({k: T(np.asarray(v)) for k, v in scene_states["a"].items()})
+    teacher = na.NeuSHintRenderer(na.NeuSModelConfig())
+    teacher.load_state_dict({k: T(np.asarray(v)) for k, v in scene_states["b"].items()})
+    student, teacher = student.cuda(), teacher.cuda().eval()
+    bg = torch.ones(1, 3).cuda()
+    n = 256
+    rb = _bundle(*make_rays(n, seed=21, spread=0.08))
+    rb_eval = _bundle(*make_rays(n, seed=22, spread=0.08))
+    with torch.no_grad():
+        gt, gt_eval = teacher(rb, background_rgb=bg).rgb, teacher(rb_eval, background_rgb=bg).rgb
+        err0 = float((student(rb_eval, background_rgb=bg).rgb - gt_eval).abs().mean())
+    before = {k: v.detach().clone() for k, v in student.state_dict().items()}
+    step = GraphedTrainStep(student, n, bg, lr=5e-4, warm_up_end=20, global_step=30000)
+    losses = [step(rb, gt, global_step=30000 + i)["loss"] for i in range(60)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < 0.8 * np.mean(losses[:10]), (losses[:3], losses[-3:])
+    assert abs(float(step.lr_t) - 5e-4 * lr_factor(30059, 20, 1_000_000, 0.05)) < 1e-9
+    assert abs(float(student.dyn_scalars[1]) - 30059 / 50000) < 1e-6
+    inv_s = float(torch.exp(student.deviation_network.variance.detach() * 10.0))
+    assert abs(float(student.dyn_scalars[0]) - inv_s) < 2e-2 * inv_s        # one step behind the parameter at most
+    with pytest.raises(ValueError):
+        step(_bundle(*make_rays(n // 2, seed=1)), gt[: n // 2], global_step=1)
+    step.release()
+    assert student.dyn_scalars is None
+    changed = sum(int(not torch.equal(before[k], v)) for k, v in student.state_dict().items())
+    assert changed == len(before)
+    with torch.no_grad():
+        err1 = float((student(rb_eval, background_rgb=bg).rgb - gt_eval).abs().mean())
+    assert err1 < err0, (err0, err1)

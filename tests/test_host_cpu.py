@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 110
+    assert lib.nrh_version() == 111
     sizes = (ctypes.c_int * 8)()
     assert lib.nrh_param_sizes(sizes) == 0
     assert sizes[7] in (4, 8)
@@ -194,8 +194,8 @@ def test_training_entry_points_validate_arguments_without_a_device():
     assert "null" in err()
     assert lib.nrh_sdf_train_backward(1, None, None, None, None, None, None, 1, 1, 16, None, None, None, None, None, None, None, None,
                                       None, None, None) == -1 and "null" in err()
-    assert lib.nrh_alpha_train_forward(None, None, None, None, 1.0, 1.0, 4, None, None, None) == -1 and "null" in err()
-    assert lib.nrh_alpha_train_backward(None, None, None, None, 1.0, 1.0, 4, None, None, None, None, None, None, None) == -1
+    assert lib.nrh_alpha_train_forward(None, None, None, None, 1.0, 1.0, None, 4, None, None, None) == -1 and "null" in err()
+    assert lib.nrh_alpha_train_backward(None, None, None, None, 1.0, 1.0, None, 4, None, None, None, None, None, None, None) == -1
     assert lib.nrh_color_train_forward(1, 1, None, None, None, None, None, None, 4, None, None, None, None) == -1 and "null" in err()
     assert lib.nrh_color_train_backward(1, 1, None, None, None, 4, None, None, None, None) == -1 and "null" in err()
     # bad precision / point count not a multiple of 16
@@ -206,7 +206,7 @@ def test_training_entry_points_validate_arguments_without_a_device():
     assert lib.nrh_color_train_forward(3, 1, one, one, one, one, one, one, 4, one, one, one, None) == -1 and "precision" in err()
     # zero rays: nothing to do, success
     assert lib.nrh_sdf_train_forward(1, one, one, one, one, one, one, 1, 1, 0, one, one, one, one, one, one, one, None) == 0
-    assert lib.nrh_alpha_train_forward(one, one, one, one, 1.0, 1.0, 0, one, one, None) == 0
+    assert lib.nrh_alpha_train_forward(one, one, one, one, 1.0, 1.0, None, 0, one, one, None) == 0
     assert lib.nrh_color_train_backward(1, 1, one, one, one, 0, one, one, one, None) == 0
     # fold: layer count and shape limits
     IntArr, PtrArr = ctypes.c_int * 1, ctypes.c_void_p * 1
