@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Instruction-schedule generator for the wide MLP machinery (csrc/nrh_mlp32.h, gfx950).
+
+hipcc cannot be talked into the schedule this kernel needs (one wave per SIMD: every VALU instruction of the epilogue has to
+sit in the 32-cycle shadow of an MFMA of the NEXT chunk, B operands have to stay in AGPRs across a loop), so the hot
+"windows" are emitted here as straight-line C++ in which
+
+  * every MFMA, every LDS read of a weight fragment and every AGPR write is an ``asm volatile`` with literal register
+    numbers (volatile asm statements keep their order), the LDS counter waits are computed by this script;
+  * the epilogue arithmetic stays ordinary C++ (hipcc allocates VGPRs and handles VALU hazards), cut into micro-operations
+    that a small list scheduler distributes over the MFMA slots; every value is pinned by an empty ``asm volatile`` at the
+    end of its slot and ``sched_barrier(0)`` closes the slot, so neither instruction selection nor the machine scheduler
+    moves work across slots.
+
+AGPR map (per wave): a[0:63] in.hi, a[64:127] in.lo, a[128:191] out.hi, a[192:255] out.lo; K step s reads a[4s:4s+3] and
+a[64+4s:64+4s+3].  hipcc never touches AGPRs in these kernels (-mllvm -amdgpu-mfma-vgpr-form, no spills; the build checks the
+disassembly for foreign v_accvgpr instructions).
+
+Usage: gen_mlp32.py <outdir>   ->  <outdir>/*.inc, included by nrh_sdf32.hip.
+"""
+import os
+import sys
+
+LU = "nrh32::LO_UNSCALE"
+MFMA = "v_mfma_f32_32x32x16_f16"
+
+
+class Op:
+    """One epilogue micro-operation: C++ statement(s), the values it defines (pinned at slot end) and its inputs."""
+
+    def __init__(self, code, defs=(), uses=(), cost=1, kind="valu"):
+        self.code, self.defs, self.uses, self.cost, self.kind = code, tuple(defs), tuple(uses), cost, kind
+        self.slot = None
+
+
+def aput(idx, val):
+    return Op(f'asm volatile("v_accvgpr_write_b32 a{idx}, %0" ::"v"({val}) : "a{idx}");', uses=(val,), kind="aput")
+
+
+def split_ops(i, v0, v1, out_hi, out_lo, pfx=""):
+    """hi/lo split of the pair (v0, v1) -> AGPRs out_hi / out_lo (nrh32::split2, spelled out per instruction)."""
+    n = f"{pfx}{i}"
+    ops = [
+        Op(f"nrh32::h16x2 hi{n} = __builtin_amdgcn_cvt_pkrtz({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1)),
+        Op(f"float H{n}a = {v0} * nrh32::LO_SCALE;", defs=(f"H{n}a",), uses=(v0,)),
+        Op(f"float H{n}b = {v1} * nrh32::LO_SCALE;", defs=(f"H{n}b",), uses=(v1,)),
+        Op(f"float R{n}a = __builtin_fmaf((float)hi{n}.x, -nrh32::LO_SCALE, H{n}a);", defs=(f"R{n}a",), uses=(f"hi{n}", f"H{n}a")),
+        Op(f"float R{n}b = __builtin_fmaf((float)hi{n}.y, -nrh32::LO_SCALE, H{n}b);", defs=(f"R{n}b",), uses=(f"hi{n}", f"H{n}b")),
+        Op(f"nrh32::h16x2 lo{n} = __builtin_amdgcn_cvt_pkrtz(R{n}a, R{n}b);", defs=(f"lo{n}",), uses=(f"R{n}a", f"R{n}b")),
+        aput(out_hi, f"hi{n}"),
+        aput(out_lo, f"lo{n}"),
+    ]
+    return ops
+
+
+def epi_fwd(c, hp, cp, want_d, out_base=128):
+    """Forward epilogue of chunk c: t (bias is in the accumulator) -> u = log2(1 + 2^t) -> hi/lo -> out; q = 1/(1+2^t)."""
+    ops = []
+    for i in range(8):
+        for r in (2 * i, 2 * i + 1):
+            ops += [
+                Op(f"float t{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"t{r}",)),
+                Op(f"float m{r} = __builtin_amdgcn_fmed3f(t{r}, 64.0f, -3.0e38f);", defs=(f"m{r}",), uses=(f"t{r}",)),
+                Op(f"float e{r} = __builtin_amdgcn_exp2f(m{r});", defs=(f"e{r}",), uses=(f"m{r}",), kind="trans"),
+                Op(f"float p{r} = 1.0f + e{r};", defs=(f"p{r}",), uses=(f"e{r}",)),
+                Op(f"float g{r} = __builtin_amdgcn_logf(p{r});", defs=(f"g{r}",), uses=(f"p{r}",), kind="trans"),
+                Op(f"float u{r} = __builtin_amdgcn_fmed3f(g{r}, t{r}, 3.0e38f);", defs=(f"u{r}",), uses=(f"g{r}", f"t{r}")),
+            ]
+            if want_d:
+                ops.append(Op(f"float q{r} = __builtin_amdgcn_rcpf(p{r});", defs=(f"q{r}",), uses=(f"p{r}",), kind="trans"))
+        ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i)
+        if want_d:
+            ops.append(Op(f"uint32_t qq{i} = nrh32::unorm16x2(q{2 * i}, q{2 * i + 1});", defs=(f"qq{i}",),
+                          uses=(f"q{2 * i}", f"q{2 * i + 1}")))
+            if i % 4 == 3:
+                w = [f"qq{i - 3 + k}" for k in range(4)]
+                ops.append(Op(f"W32_QSTORE({c}, {i // 4}, (nrh32::u32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
+    return ops
+
+
+def epi_rev(c, hp, cp, out_base=128):
+    """Reverse epilogue of chunk c: g = W^T t (accumulator) -> t' = g - g q, q = unorm16 from scratch -> hi/lo -> out."""
+    ops = []
+    for i in range(8):
+        for r in (2 * i, 2 * i + 1):
+            w = f"qw{r // 8}[{(r % 8) // 2}]"
+            ext = f"({w} >> 16)" if r & 1 else f"({w} & 0xffffu)"
+            ops += [
+                Op(f"float g{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"g{r}",)),
+                Op(f"float f{r} = (float){ext};", defs=(f"f{r}",), cost=2),
+                Op(f"float n{r} = g{r} * (-1.0f / 65535.0f);", defs=(f"n{r}",), uses=(f"g{r}",)),
+                Op(f"float u{r} = __builtin_fmaf(n{r}, f{r}, g{r});", defs=(f"u{r}",), uses=(f"n{r}", f"f{r}", f"g{r}")),
+            ]
+        ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i)
+    return ops
+
+
+def schedule(ops, nslots, per_slot):
+    """Greedy list schedule: an op may run in slot k if everything it uses was defined in a slot < k (or outside).
+    Returns (slots, tail): ops per slot, and what did not fit."""
+    defined_in = {}
+    for o in ops:
+        for d in o.defs:
+            defined_in[d] = o
+    slots = [[] for _ in range(nslots)]
+    todo = list(ops)
+    for k in range(nslots):
+        budget = per_slot(k) if callable(per_slot) else per_slot
+        rest = []
+        for o in todo:
+            ready = all((u not in defined_in) or (defined_in[u].slot is not None and defined_in[u].slot < k) for u in o.uses)
+            if ready and budget >= o.cost:
+                o.slot = k
+                slots[k].append(o)
+                budget -= o.cost
+            else:
+                rest.append(o)
+        todo = rest
+    return slots, todo
+
+
+def emit_ops(out, ops, ind="  "):
+    pins = []
+    for o in ops:
+        out.append(ind + o.code)
+        pins += [d for d in o.defs]
+    for d in pins:
+        out.append(ind + f'asm volatile("" ::"v"({d}));')
+
+
+class Window:
+    """K loop of one chunk (KS steps of 3 MFMAs) with filler ops in the MFMA shadows.
+
+    b_src 'agpr': B operands are a[4s..] / a[64+4s..];  'vgpr': u32x4 expressions (bh(s), bl(s)) given by name pattern.
+    hh_init: name of an f32x16 holding the start values (compiler-visible LDS loads), or None for zero."""
+
+    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa"):
+        self.ks, self.hh, self.cc, self.b_src, self.bvar, self.hh_zero, self.pf, self.wa = ks, hh, cc, b_src, bvar, hh_zero, pf, wa
+
+    def frag(self, s, part):
+        return f"fa{(s % (self.pf + 1)) * 2 + part}"
+
+    def emit(self, out, slots_ops, ind="  "):
+        ks, pf = self.ks, self.pf
+        nbuf = (pf + 1) * 2
+        out.append(ind + "nrh32::u32x4 " + ", ".join(f"fa{i}" for i in range(nbuf)) + ";")
+        issued = []  # LDS reads in issue order: (s, part)
+
+        def ds(s, part):
+            off = (2 * s + part) * 1024
+            out.append(ind + f'asm volatile("ds_read_b128 %0, %1 offset:{off}" : "=v"({self.frag(s, part)}) : "v"({self.wa}));')
+            issued.append((s, part))
+
+        def wait_for(s, part):
+            idx = issued.index((s, part))
+            return len(issued) - 1 - idx
+
+        for s in range(min(pf, ks)):
+            ds(s, 0)
+            ds(s, 1)
+        slot = 0
+        for s in range(ks):
+            for j in range(3):
+                # weight fragments of K step s + pf go out in the first two slots of step s (their buffer was last read by
+                # the MFMAs of step s - 1, all issued by now)
+                if s + pf < ks and j < 2:
+                    ds(s + pf, j)
+                part = 1 if j == 2 else 0
+                acc = self.hh if j == 0 else self.cc
+                first = (s == 0 and (j == 1 or (j == 0 and self.hh_zero)))
+                w = wait_for(s, part)
+                bpart = 1 if j == 1 else 0   # j=1: A_hi * B_lo, j=2: A_lo * B_hi
+                pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j != 1) else ""
+                if self.b_src == "agpr":
+                    base = 4 * s + (64 if bpart else 0)
+                    bop, bcons = f"a[{base}:{base + 3}]", ""
+                else:
+                    bop, bcons = "%2", f', "v"({self.bvar[bpart]}{s})'
+                if first:
+                    out.append(ind + f'asm volatile("{pre}{MFMA} %0, %1, {bop}, 0" : "=&v"({acc}) : "v"({self.frag(s, part)}){bcons});')
+                else:
+                    out.append(ind + f'asm volatile("{pre}{MFMA} %0, %1, {bop}, %0" : "+v"({acc}) : "v"({self.frag(s, part)}){bcons});')
+                if slots_ops is not None and slot < len(slots_ops) and slots_ops[slot]:
+                    emit_ops(out, slots_ops[slot], ind)
+                out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+                slot += 1
+        # slots beyond the K loop (short K loops: the epilogue is longer than the MFMA stream)
+        while slots_ops is not None and slot < len(slots_ops):
+            if slots_ops[slot]:
+                emit_ops(out, slots_ops[slot], ind)
+                out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
+            slot += 1
+
+
+def gen_stage(kind, want_d, ks, b_src, nv, hh_zero):
+    """A pipelined 8-chunk stage: window c runs the K loop of chunk c and the epilogue of chunk c - 1; drain at the end.
+    Hooks (macros defined by the including kernel): W32_SYNC(c), W32_FETCH(), W32_HINIT(c) (f32x16 start values, unless
+    hh_zero), W32_QSTORE / W32_QLOAD(c, half)."""
+    out = []
+    out.append(f"// generated by gen_mlp32.py: stage kind={kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv}")
+    out.append("{")
+    for c in range(8):
+        out.append(f"  nrh32::f32x16 hh{c}, cc{c};")
+    if kind == "rev":
+        for c in range(8):
+            out.append(f"  nrh32::u32x4 qa{c}, qb{c};")
+    for c in range(9):
+        out.append(f"  {{  // window {c}" if c < 8 else "  {  // drain")
+        epi = None
+        if c > 0 and not os.environ.get("NRH32_NOEPI"):
+            if kind == "fwd":
+                epi = epi_fwd(c - 1, f"hh{c - 1}", f"cc{c - 1}", want_d)
+            else:
+                epi = epi_rev(c - 1, f"hh{c - 1}", f"cc{c - 1}")
+        if c < 8:
+            if kind == "rev" and c > 0:
+                # the q words loaded in the previous window have landed before the next LDS-DMA batch goes out (hipcc does not
+                # see the asm DMA in its vmcnt bookkeeping; a later wait for these loads would drain the fresh batch too)
+                out.append(f'    asm volatile("" : "+v"(qa{c - 1}), "+v"(qb{c - 1}));')
+            out.append(f"    W32_SYNC({c});")
+            out.append("    W32_FETCH();")
+            if kind == "rev":
+                out.append(f"    qa{c} = W32_QLOAD({c}, 0); qb{c} = W32_QLOAD({c}, 1);")
+            if not hh_zero:
+                out.append(f"    hh{c} = W32_HINIT({c});")
+            out.append("    const uint32_t wa = W32_WADDR();")
+            if c > 0:
+                # the previous chunk's accumulators are read by VALU only from here on: >= 11 wait states after its last MFMA
+                out.append(f'    asm volatile("" : "+v"(hh{c - 1}), "+v"(cc{c - 1}));')
+            if kind == "rev" and c > 0:
+                out.append(f"    const nrh32::u32x4 qw0 = qa{c - 1}, qw1 = qb{c - 1};")
+            win = Window(ks, f"hh{c}", f"cc{c}", b_src=b_src, hh_zero=hh_zero)
+            if epi is not None:
+                slots, tail = schedule(epi, max(3 * ks, (len(epi) + nv - 1) // nv + 8), nv)
+            else:
+                slots, tail = None, []
+            win.emit(out, slots, "    ")
+            if tail:
+                out.append("    // epilogue work that did not fit the MFMA shadows")
+                emit_ops(out, tail, "    ")
+            out.append("    W32_NEXT();")
+        else:
+            # MFMA results -> VALU reads need 11 wait states; the asm carries the accumulators so that no read is scheduled above it
+            out.append(f'    asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh7), "+v"(cc7));')
+            if kind == "rev":
+                out.append("    asm volatile(\"\" : \"+v\"(qa7), \"+v\"(qb7));")
+                out.append("    const nrh32::u32x4 qw0 = qa7, qw1 = qb7;")
+            if epi is not None:
+                emit_ops(out, epi, "    ")
+        out.append("  }")
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def gen_kloop(ks, b_src, hh_zero):
+    """K loop only (no fillers): for the light stages whose epilogue is written by hand after it.  Needs hh, cc, wa."""
+    out = [f"// generated by gen_mlp32.py: bare K loop ks={ks} b={b_src}", "{"]
+    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero).emit(out, None, "  ")
+    out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh), "+v"(cc));   // MFMA results -> VALU reads: 11 wait states')
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def gen_swap():
+    out = ["// generated by gen_mlp32.py: out -> in (128 AGPR moves)"]
+    for i in range(128):
+        out.append(f'asm volatile("v_accvgpr_mov_b32 a{i}, a{128 + i}" ::: "a{i}");')
+    return "\n".join(out) + "\n"
+
+
+def gen_t7():
+    """t_7 = (1 - q_7) * a8 written straight into `in`: W32_A8(c) -> f32x16 (w_s / 3 in D32 layout), W32_QLOAD7(c, half)."""
+    out = ["// generated by gen_mlp32.py: T7 pass", "{"]
+    for c in range(8):
+        out.append(f"  {{  // chunk {c}")
+        out.append(f"    const nrh32::f32x16 a8 = W32_A8({c});")
+        out.append(f"    const nrh32::u32x4 qw0 = W32_QLOAD7({c}, 0), qw1 = W32_QLOAD7({c}, 1);")
+        ops = []
+        for r in range(16):
+            w = f"qw{r // 8}[{(r % 8) // 2}]"
+            ext = f"({w} >> 16)" if r & 1 else f"({w} & 0xffffu)"
+            ops += [Op(f"float f{r} = (float){ext};", defs=(f"f{r}",)),
+                    Op(f"float n{r} = a8[{r}] * (-1.0f / 65535.0f);", defs=(f"n{r}",)),
+                    Op(f"float u{r} = __builtin_fmaf(n{r}, f{r}, a8[{r}]);", defs=(f"u{r}",))]
+        for i in range(8):
+            ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", 8 * c + i, 64 + 8 * c + i)
+        for o in ops:
+            out.append("    " + o.code)
+        out.append("    __builtin_amdgcn_sched_barrier(0);")
+        out.append("  }")
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def gen_dump():
+    """debug: `in` AGPRs -> W32_DUMP(i, value) for i in 0..127"""
+    out = ["// generated by gen_mlp32.py: debug dump of a[0:127]"]
+    for i in range(128):
+        out.append(f'{{ uint32_t x; asm volatile("v_accvgpr_read_b32 %0, a{i}" : "=v"(x)); W32_DUMP({i}, x); __builtin_amdgcn_sched_barrier(0); }}')
+    return "\n".join(out) + "\n"
+
+
+def main():
+    outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen32")
+    os.makedirs(outdir, exist_ok=True)
+    nv = int(os.environ.get("NRH32_NV", "4"))
+    files = {
+        "fwd_d0.inc": gen_stage("fwd", False, 16, "agpr", nv, False),
+        "fwd_d1.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, False),
+        "l0_d0.inc": gen_stage("fwd", False, 3, "vgpr", 10, False),
+        "l0_d1.inc": gen_stage("fwd", True, 3, "vgpr", 10, False),
+        "rev.inc": gen_stage("rev", True, 16, "agpr", nv, True),
+        "kloop16.inc": gen_kloop(16, "agpr", False),
+        "kloop16z.inc": gen_kloop(16, "agpr", True),
+        "kloop3v.inc": gen_kloop(3, "vgpr", False),
+        "swap.inc": gen_swap(),
+        "t7.inc": gen_t7(),
+        "dump_in.inc": gen_dump(),
+    }
+    for name, text in files.items():
+        path = os.path.join(outdir, name)
+        old = open(path).read() if os.path.exists(path) else None
+        if old != text:
+            open(path, "w").write(text)
+    print(f"gen_mlp32: {len(files)} files in {outdir}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+// "Wide" per-point MLP machinery for gfx950, precision mode f16x3: one wavefront per SIMD, 512 registers, 32-point tiles.
+//
+// Same transposed register chain as nrh_mlp.h (H_out^T = W * H_in^T, activations never leave registers between layers),
+// re-shaped around what limited the 16-point / 2-waves-per-SIMD form:
+//   * v_mfma_f32_32x32x16_f16: a wave owns 32 points, so every weight fragment read from LDS feeds twice the FLOPs
+//     (half the ds_read_b128 and half the LDS-DMA pieces per FLOP) and MFMAs are 32 cycles apart: room for VALU fillers.
+//   * 4 waves per workgroup, ONE per SIMD (amdgpu_waves_per_eu(1,1)): 256 arch VGPRs + 256 AGPRs per wave.  The B operands
+//     (activations as packed fp16 hi/lo pairs: 128 registers for the layer input, 128 for the layer being produced) live in
+//     AGPRs - MFMA reads them there directly - so accumulators, weight fragments and all epilogue temporaries fit the
+//     arch VGPRs with no spill.  (Built with -mllvm -amdgpu-mfma-vgpr-form: accumulators stay in VGPRs, the VALU epilogue
+//     reads them without v_accvgpr_read.)
+//   * software pipeline inside the wave: the epilogue (activation, hi/lo split) of output chunk c-1 is issued between the
+//     MFMAs of chunk c - there is no second wave on the SIMD to overlap with, and none is needed.
+//   * scalar (non-packed) f32 VALU only: v_pk_*_f32 beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md).
+//   * the softplus(beta=100) layers run in a scaled domain u = h * 100/ln2: the accumulator IS t = 100 z / ln2, so
+//     u = log2(1 + 2^t) needs no multiply on either side, and 1 - sigma'(z) = 1 / (1 + 2^t) is one v_rcp_f32.
+//
+// Layouts (lane = 32*hf + j: point j of the tile, half hf):
+//   D32:  register r (0..15) of a 32-feature block  <->  feature (r & 3) + 8 * (r >> 2) + 4 * hf      (MFMA C/D fragment)
+//   B:    K step s = 2 * block + t uses registers 8t..8t+7 of that block as its 8 fp16 elements, i.e. element i of
+//         half hf is feature col32(s, hf, i) = 16 s + (i & 3) + 8 * (i >> 2) + 4 * hf - the weights absorb the permutation.
+//   A:    lane (row = lane & 31, hf) holds W[32 * chunk + row][col32(s, hf, 0..7)] as 8 fp16 (16 B): one ds_read_b128.
+//   chunk image in LDS / in the packed stream:  [s][hi | lo][lane 64] x 16 B   = KS * 2 KiB  (32 KiB for K = 256)
+#pragma once
+#include "nrh_common.h"
+
+namespace nrh32 {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef NRH32_ABL
+#define NRH32_ABL 0   // timing ablations for profiles/ubench (WRONG RESULTS): 1 no LDS-DMA, 2 no chunk barrier
+#endif
+constexpr int WAVES = 4;                  // one per SIMD
+constexpr int THREADS = 64 * WAVES;
+constexpr int TILE = 32;                  // points per wave
+constexpr int GROUP = TILE * WAVES;       // points per workgroup pass
+constexpr int SLOT_BYTES = 40960;         // one weight chunk: 32 output rows x K = 256, hi + lo (32 KiB), + 8 KiB for the
+                                          // skip part that rides with layer 4's chunks (nrh_sdf32.hip)
+constexpr int RING = 2;
+constexpr int NTAB = 11;                  // bias / constant tables, 256 floats each (see nrh_sdf32.hip)
+constexpr int LDS_RING = 0;
+constexpr int LDS_TAB = RING * SLOT_BYTES;
+constexpr int LDS_BYTES = LDS_TAB + NTAB * 1024;
+
+constexpr float LO_SCALE = 2048.0f;
+constexpr float LO_UNSCALE = 1.0f / 2048.0f;
+constexpr float IK = 144.26950408889634074f;   // 100 / ln 2: scaled domain t = z * IK, u = h * IK
+constexpr float KK = 6.9314718055994530942e-3f;  // ln 2 / 100
+
+__host__ __device__ constexpr int frow(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+__host__ __device__ constexpr int col32(int s, int hf, int i) { return 16 * s + (i & 3) + 8 * (i >> 2) + 4 * hf; }
+
+// ---- AGPR residency: values that are only ever MFMA B operands ----
+__device__ __forceinline__ uint32_t a_put(uint32_t v) {
+  uint32_t r;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t a_mov(uint32_t a) {
+  uint32_t r;
+  asm("v_accvgpr_mov_b32 %0, %1" : "=a"(r) : "a"(a));
+  return r;
+}
+
+// Activations of one layer for this wave's 32 points as MFMA B operands: K step s <- h[4s..4s+3] (hi), l[4s..4s+3] (lo)
+struct ActA {
+  uint32_t h[64], l[64];
+};
+
+// x = hi + lo / 2^11, two values per register
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  const float ra = __builtin_fmaf((float)h.x, -LO_SCALE, a * LO_SCALE);   // v_fma_mix_f32 on the packed fp16
+  const float rb = __builtin_fmaf((float)h.y, -LO_SCALE, b * LO_SCALE);
+  const h16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// ---- LDS-DMA of the weight stream ----
+// One 1 KiB piece: lane-linear 16 B per lane; global address = sbase + 16 * lane, LDS address = m0 (wave-uniform).
+__device__ __forceinline__ void dma_piece(const char* gbase, uint32_t lds_addr, uint32_t lane16) {
+  // wave-uniform by construction; readfirstlane makes it so for the compiler too (an "s" operand it believes divergent is
+  // otherwise printed as a VGPR)
+  if (NRH32_ABL & 1) return;
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  const uint64_t g = (uint64_t)gbase;
+  gbase = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(g >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)g));   // (readfirstlane returns int: no sign extension)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane16), "s"(gbase) : "memory");
+}
+// a chunk of np pieces (np % WAVES == 0): wave w moves pieces w, w + 4, ...
+__device__ __forceinline__ void dma_chunk(const char* gsrc, uint32_t lds_dst, int np, int wave, uint32_t lane16) {
+  for (int p = wave; p < np; p += WAVES) dma_piece(gsrc + p * 1024, lds_dst + p * 1024, lane16);
+}
+
+// wait until at most `keep` of this wave's VMEM operations (the youngest) are outstanding, then meet the other waves
+template <int KEEP>
+__device__ __forceinline__ void chunk_sync() {
+  if (NRH32_ABL & 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_off(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// 16 accumulator start values (D32 layout) from LDS: 4 x ds_read_b128 at base + g * gstride
+__device__ __forceinline__ f32x16 ld_init(const char* base, int gstride) {
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(base + g * gstride);
+    v[4 * g + 0] = x[0]; v[4 * g + 1] = x[1]; v[4 * g + 2] = x[2]; v[4 * g + 3] = x[3];
+  }
+  return v;
+}
+
+// K loop of one chunk: hh += Ahi * Bhi, cc += Ahi * Blo + Alo * Bhi  (cc is scaled by 2^11)
+template <int KS>
+__device__ __forceinline__ void kloop(const char* wb, const ActA& in, f32x16& hh, f32x16& cc, int lane) {
+  const u32x4* A = reinterpret_cast<const u32x4*>(wb) + lane;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const u32x4 ah = A[(2 * s) * 64], al = A[(2 * s + 1) * 64];
+    const u32x4 bhu = {in.h[4 * s], in.h[4 * s + 1], in.h[4 * s + 2], in.h[4 * s + 3]};
+    const u32x4 blu = {in.l[4 * s], in.l[4 * s + 1], in.l[4 * s + 2], in.l[4 * s + 3]};
+    const f16x8 bh = __builtin_bit_cast(f16x8, bhu), bl = __builtin_bit_cast(f16x8, blu);
+    hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), bh, hh, 0, 0, 0);
+    cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), bl, cc, 0, 0, 0);
+    cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), bh, cc, 0, 0, 0);
+  }
+}
+
+// interleave request to the machine scheduler for one fused window: per MFMA, NV VALU and (2 of 3 times) one ds_read
+template <int NMFMA, int NV>
+__device__ __forceinline__ void pipeline_hint() {
+#pragma unroll
+  for (int i = 0; i < NMFMA; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // MFMA
+    if (i % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);         // VALU
+  }
+}
+
+}  // namespace nrh32

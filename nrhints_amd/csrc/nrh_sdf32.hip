@@ -1,0 +1,360 @@
+// SDF network, precision mode f16x3, on the wide machinery of nrh_mlp32.h: value, appearance feature and analytic
+// d(sdf)/dx in one pass per point.  Same contract as nrh_sdf.hip (reference: fields/sdf_field.py:106-148, called from
+// models/neus_hint_model.py:325, :335-336, :504), different execution plan:
+//
+//   L0     emb -> 256                          softplus100 in the scaled domain (nrh_mlp32.h)
+//   L1..L7 256 -> 256                          L3 has 217 real rows.  The skip connection (the reference concatenates
+//          [h, emb] / sqrt2 in front of layer 4, fields/sdf_field.py:113-114) is a K split: W4's columns 217.. are zero in the
+//          main stage and every chunk of layer 4 carries 8 KiB more, E4 = W4[:, 217:] / sqrt2 in the embedding's K order,
+//          multiplied with the embedding (still in registers) into the accumulator start values - nothing is substituted
+//   FEAT   256 -> 256, no activation           MODE 2; written as the 16-point D-layout tiles the colour kernel reads
+//   HEAD   256 -> 1 (row 0 of a 32-row chunk)  sdf = (w_s . h8 + b_s) / 3
+//   T7     t_7 = sigma'_7 * w_s / 3            MODE >= 1 (no GEMM)
+//   R7..R1 t_{l-1} = sigma'_{l-1} * (W_l^T t_l)
+//   R4e    g_emb += W4[:, 217:]^T t_4 / sqrt2  (2 chunks, before R4)
+//   R0     g_emb += W0^T t_0, then the chain rule through the positional encoding and the input scale 3
+// 1 - sigma' = 1 / (1 + 2^t) travels from the forward to the reverse sweep as unorm16 through a per-wave scratch
+// (128 KiB per wave, L2 / Infinity-Cache resident).
+#include "nrh_mlp32.h"
+
+namespace nrh32 {
+
+struct Sdf32Args {
+  const char* w;        // weight stream of this MODE (sdf32_stream_bytes(MODE) bytes), chunks in execution order
+  const float* tab;     // [NTAB][256]: 0..7 b_l * IK (l = 3: rows >= 217 zero), 8 b_feat, 9 {b_s / 3, 0...}, 10 w_s / 3
+  const float* ro;      // [nrays,3]
+  const float* rd;      // [nrays,3]
+  const float* t;       // t[ray * t_stride + j]
+  float* sdf;           // sdf[ray * sdf_stride + j]
+  float* grad;          // [npts,3]                     (MODE >= 1)
+  float* feat;          // [ceil(npts/16)][16][64][4]   (MODE 2)
+  uint32_t* scratch;    // gridDim.x * WAVES * SCRATCH_WORDS_PER_WAVE (MODE >= 1)
+  long long npts;
+  int n_per_ray;
+  int t_stride;
+  int sdf_stride;
+  int ngroups;          // ceil(npts / GROUP)
+  uint32_t* dbg;        // diagnosis builds only (-DNRH32_DEBUG): intermediate state of workgroup 0's first pass, see profiles/ubench
+  int dbg_stage;
+};
+
+constexpr int SCRATCH_WORDS_PER_WAVE = 8 * 8 * 2 * 64 * 4;   // [layer][chunk][half][lane] uint4
+constexpr int SMALL_PIECES = 8;    // L0 chunks: 4 K steps stored (3 used) = 8 KiB
+constexpr int BIG_PIECES = 32;
+constexpr int L4_PIECES = 40;      // layer 4: 32 KiB main part + 8 KiB skip part (E4)
+__host__ __device__ constexpr int sdf32_stream_chunks(int mode) { return 8 + 56 + 1 + (mode == 2 ? 8 : 0) + (mode >= 1 ? 60 : 0); }
+__host__ __device__ constexpr long long sdf32_stream_bytes(int mode) {
+  long long n = 8LL * SMALL_PIECES + 48LL * BIG_PIECES + 8LL * L4_PIECES + BIG_PIECES;   // L0, L1..L7, HEAD
+  if (mode == 2) n += 8LL * BIG_PIECES;                                            // FEAT
+  if (mode >= 1) n += (56LL + 2 + 2) * BIG_PIECES;                                 // R7..R1, R4e, R0
+  return n * 1024;
+}
+
+// entry e of enc_6(x3) for this lane: e = hf ? e1 : e0 (both static); one sine per entry
+__device__ __forceinline__ float emb_entry(const float (&x)[3], int e0, int e1, int hf) {
+  float arg = 0.0f, raw = 0.0f;
+  int kind = 0;  // 0 zero, 1 raw input, 2 sine
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int e = c ? e1 : e0;
+    if (e < 0 || e >= 39) continue;
+    const bool mine = (hf == c);
+    if (e < 3) {
+      raw = mine ? x[e] : raw;
+      kind = mine ? 1 : kind;
+    } else {
+      int idx = e - 3;
+      const float ph = (idx >= 18) ? NRH_HALF_PI : 0.0f;
+      idx = idx % 18;
+      const float cand = x[idx / 6] * (float)(1 << (idx % 6)) + ph;
+      arg = mine ? cand : arg;
+      kind = mine ? 2 : kind;
+    }
+  }
+  const float s = nrh::sin_cw(arg);
+  return (kind == 2) ? s : ((kind == 1) ? raw : 0.0f);
+}
+// d(entry e)/d(x_dim(e)) for this lane's entry (what autograd of the encoding yields; 0 outside the 39 entries)
+__device__ __forceinline__ float emb_dentry(const float (&x)[3], int e0, int e1, int hf) {
+  float arg = 0.0f, fr = 0.0f;
+  int kind = 0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int e = c ? e1 : e0;
+    if (e < 0 || e >= 39) continue;
+    const bool mine = (hf == c);
+    if (e < 3) {
+      kind = mine ? 1 : kind;
+    } else {
+      int idx = e - 3;
+      const float ph = (idx >= 18) ? NRH_HALF_PI : 0.0f;
+      idx = idx % 18;
+      const float f = (float)(1 << (idx % 6));
+      const float cand = x[idx / 6] * f + ph;
+      arg = mine ? cand : arg;
+      fr = mine ? f : fr;
+      kind = mine ? 2 : kind;
+    }
+  }
+  const float c = nrh::cos_cw(arg) * fr;
+  return (kind == 2) ? c : ((kind == 1) ? 1.0f : 0.0f);
+}
+__host__ __device__ constexpr int emb_dim(int e) { return e < 3 ? e : ((e - 3) % 18) / 6; }
+
+__device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(a, b));
+}
+
+// MODE 0: sdf | 1: sdf + gradient | 2: + feature tiles
+template <int MODE>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdf32_kernel(const Sdf32Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, hf = lane >> 5;
+  const uint32_t lane16 = lane * 16;
+  constexpr bool WANT_D = MODE >= 1;
+  constexpr long long STREAM = sdf32_stream_bytes(MODE);
+
+  char* const ring = smem + LDS_RING;
+  const char* const tabs = smem + LDS_TAB;
+  const uint32_t ring_lds = lds_off(ring);
+  const uint32_t wlane = ring_lds + lane16;   // this lane's 16 B of every 1 KiB weight line, ring slot 0
+  // per-wave sigma' scratch: wave-uniform base (SGPRs) + this lane's 16 B, so every access is saddr + voffset (no 64-bit VGPR addresses)
+  char* const scr = WANT_D ? reinterpret_cast<char*>(a.scratch + (size_t)(blockIdx.x * WAVES + wave) * SCRATCH_WORDS_PER_WAVE) : nullptr;
+  auto scr_at = [&](int layer, int c, int half) {
+    typedef __attribute__((address_space(1))) char* gchar_p;     // explicitly global: a pointer that went through asm is
+    typedef __attribute__((address_space(1))) u32x4* gvec_p;     // generic otherwise, and flat_* accesses also count in lgkmcnt
+    gchar_p b = (gchar_p)scr;
+    asm volatile("" : "+s"(b));   // keeps the address arithmetic scalar and local (hipcc otherwise hoists 64-bit VGPR addresses)
+    return (gvec_p)(b + ((layer * 8 + c) * 2 + half) * 1024 + lane16);
+  };
+
+  // constant tables -> LDS (once per workgroup)
+  for (int i = threadIdx.x; i < NTAB * 64; i += THREADS)
+    reinterpret_cast<f32x4*>(smem + LDS_TAB)[i] = reinterpret_cast<const f32x4*>(a.tab)[i];
+
+  // the weight stream: chunk n sits in ring slot n & 1; wnext / cnext = global address / index in the pass of the next chunk
+  // to fetch (chunks 0..7 are L0's 8 KiB, 32..39 layer 4's 40 KiB, all others 32 KiB)
+  int n = 0, cnext = 0;
+  const char* wnext = a.w;
+  auto fetch = [&]() {   // issue the LDS-DMA of the next chunk of the stream into the slot chunk n - 1 occupied
+    const int np = cnext < 8 ? SMALL_PIECES : ((cnext >= 32 && cnext < 40) ? L4_PIECES : BIG_PIECES);
+    dma_chunk(wnext, ring_lds + ((n + 1) & 1) * SLOT_BYTES, np, wave, lane16);
+    wnext += np * 1024;
+    if (++cnext == sdf32_stream_chunks(MODE)) { cnext = 0; wnext = a.w; }
+  };
+  // first chunk of the stream
+  dma_chunk(wnext, ring_lds, SMALL_PIECES, wave, lane16);
+  wnext += SMALL_PIECES * 1024;
+  cnext = 1;
+
+  for (int tg = blockIdx.x; tg < a.ngroups; tg += gridDim.x) {
+    const long long tile = (long long)tg * WAVES + wave;
+    const long long P = tile * TILE + j;
+    const bool valid = P < a.npts;
+    const long long Pc = valid ? P : a.npts - 1;
+    const long long ray = Pc / a.n_per_ray;
+    const int jj = (int)(Pc - ray * a.n_per_ray);
+    const float tt = a.t[ray * a.t_stride + jj];
+    float x3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt) * 3.0f;  // inputs * scale
+
+    // ---- embedding as the B operand of E4 / L0: K step s, element i <-> entry col32(s, hf, i) ----
+    u32x4 ebh0, ebh1, ebh2, ebl0, ebl1, ebl2;
+    {
+      uint32_t eh[12], el[12];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float v0 = emb_entry(x3, col32(s, 0, 2 * p), col32(s, 1, 2 * p), hf);
+          const float v1 = emb_entry(x3, col32(s, 0, 2 * p + 1), col32(s, 1, 2 * p + 1), hf);
+          split2(v0, v1, eh[4 * s + p], el[4 * s + p]);
+          __builtin_amdgcn_sched_barrier(0);   // two sines at a time: hipcc otherwise runs all 24 side by side and spills
+        }
+      ebh0 = u32x4{eh[0], eh[1], eh[2], eh[3]}; ebl0 = u32x4{el[0], el[1], el[2], el[3]};
+      ebh1 = u32x4{eh[4], eh[5], eh[6], eh[7]}; ebl1 = u32x4{el[4], el[5], el[6], el[7]};
+      ebh2 = u32x4{eh[8], eh[9], eh[10], eh[11]}; ebl2 = u32x4{el[8], el[9], el[10], el[11]};
+    }
+    auto tab_init = [&](int table, int c) { return ld_init(tabs + table * 1024 + (32 * c + 4 * hf) * 4, 32); };
+#define W32_FETCH() fetch()
+#define W32_WADDR() (wlane + (n & 1) * SLOT_BYTES)
+#define W32_NEXT() ++n
+
+#ifdef NRH32_DEBUG
+    const bool dbg_on = a.dbg != nullptr && blockIdx.x == 0 && tg == blockIdx.x;
+    auto dbg_at = [&](int word) {   // wave-uniform part of the address through an opaque SGPR (nothing to hoist, nothing to spill)
+      typedef __attribute__((address_space(1))) uint32_t* gu32_p;
+      gu32_p d = (gu32_p)a.dbg;
+      asm volatile("" : "+s"(d));
+      return d + word;
+    };
+    auto dbg_in = [&](int section) {   // a[0:127] of every lane -> dbg[section][wave][i][lane]
+#define W32_DUMP(i, x) dbg_at(section * 32768 + (wave * 128 + (i)) * 64)[lane] = (x)
+#include "gen32/dump_in.inc"
+#undef W32_DUMP
+    };
+    if (dbg_on) {
+      const uint32_t eb[24] = {ebh0[0], ebh0[1], ebh0[2], ebh0[3], ebh1[0], ebh1[1], ebh1[2], ebh1[3], ebh2[0], ebh2[1], ebh2[2], ebh2[3],
+                               ebl0[0], ebl0[1], ebl0[2], ebl0[3], ebl1[0], ebl1[1], ebl1[2], ebl1[3], ebl2[0], ebl2[1], ebl2[2], ebl2[3]};
+#pragma unroll
+      for (int i = 0; i < 24; ++i) dbg_at(1 * 32768 + (wave * 128 + i) * 64)[lane] = eb[i];
+    }
+#endif
+    // the two q stores of the previous window's epilogue may stay in flight across the chunk barrier
+#define W32_SYNC(c) do { if (WANT_D && (c) >= 2) chunk_sync<2>(); else chunk_sync<0>(); } while (0)
+#define W32_QSTORE(c, half, val) __builtin_nontemporal_store((val), scr_at(qlayer, c, half))
+    // ---- L0 ----
+    {
+      const int qlayer = 0;
+#define W32_HINIT(c) tab_init(0, c)
+      if constexpr (WANT_D) {
+#include "gen32/l0_d1.inc"
+      } else {
+#include "gen32/l0_d0.inc"
+      }
+#undef W32_HINIT
+#include "gen32/swap.inc"
+    }
+#ifdef NRH32_DEBUG
+    if (dbg_on) { dbg_in(3); if (a.dbg_stage == 3) return; }
+#endif
+
+    // ---- L1..L7 ----
+    for (int l = 1; l <= 7; ++l) {
+      const int qlayer = l;
+      // start values: the bias table, and for layer 4 the skip part E4 * emb on top (9 MFMAs per chunk over the 8 KiB that
+      // follow the chunk's main 32 KiB in the ring slot)
+      auto hinit = [&](int c) {
+        f32x16 hh = tab_init(l, c);
+        if (l == 4) {
+          f32x16 cc;
+          const uint32_t wa = W32_WADDR() + 32768;
+#include "gen32/kloop3v.inc"
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hh[r] = __builtin_fmaf(cc[r], LO_UNSCALE, hh[r]);
+          asm volatile("s_nop 4" : "+v"(hh));   // VALU results -> MFMA SrcC
+        }
+        return hh;
+      };
+#define W32_HINIT(c) hinit(c)
+      if constexpr (WANT_D) {
+#include "gen32/fwd_d1.inc"
+      } else {
+#include "gen32/fwd_d0.inc"
+      }
+#undef W32_HINIT
+#include "gen32/swap.inc"
+#ifdef NRH32_DEBUG
+      if (dbg_on && l <= 2) { dbg_in(3 + l); if (a.dbg_stage == 3 + l) return; }
+      if (dbg_on && l == 7) dbg_in(6);
+#endif
+    }
+#undef W32_SYNC
+#undef W32_QSTORE
+
+    // ---- FEAT (MODE 2) and HEAD ----
+    if (MODE == 2) {
+      const long long t16 = 2 * tile + (j >> 4);
+      const bool t16_ok = t16 * 16 < a.npts;
+      float* const ft = a.feat + (size_t)t16 * 4096 + ((j & 15) + 16 * hf) * 4;
+      for (int c = 0; c < 8; ++c) {
+        chunk_sync<0>();
+        fetch();
+        f32x16 hh = tab_init(8, c), cc;
+        const uint32_t wa = W32_WADDR();
+#include "gen32/kloop16.inc"
+        if (t16_ok) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(cc[4 * g + r], LO_UNSCALE, hh[4 * g + r]);
+            // features 32c + 8g + 4hf + r  ->  16-row block 2c + (g >> 1), quarter 2 (g & 1) + hf of the 16-point tile
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ft + ((2 * c + (g >> 1)) * 64 + 32 * (g & 1)) * 4));
+          }
+        }
+        ++n;
+      }
+    }
+    {
+      chunk_sync<0>();
+      fetch();
+      f32x16 hh = tab_init(9, 0), cc;
+      const uint32_t wa = W32_WADDR();
+#include "gen32/kloop16.inc"
+      if (valid && hf == 0) a.sdf[ray * a.sdf_stride + jj] = __builtin_fmaf(cc[0], LO_UNSCALE, hh[0]);
+      ++n;
+    }
+
+    if constexpr (WANT_D) {
+      // ---- T7: t_7 = (1 - q_7) * w_s / 3, straight into `in` ----
+#define W32_A8(c) tab_init(10, c)
+#define W32_QLOAD7(c, half) __builtin_nontemporal_load(scr_at(7, c, half))   // nt: served by L2, never by a stale L1 line
+#include "gen32/t7.inc"
+#undef W32_A8
+#undef W32_QLOAD7
+
+      // g_emb chunk c (register r <-> entry 32c + frow(r, hf)) contracted with d enc / dx.  The 20 derivative values are
+      // recomputed for each of the two stages that need them (R4e, R0): keeping them live across R4..R1 costs more
+      // registers than 20 cosines cost time.
+      float dx[3] = {0.f, 0.f, 0.f};
+      auto epi_emb = [&](int c, const f32x16& hh, const f32x16& cc) {
+        float xx[3] = {x3[0], x3[1], x3[2]};
+        asm volatile("" : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]));   // not hoisted, not shared between the two stages
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (c == 1 && r >= 4) continue;
+          const int e0 = 32 * c + frow(r, 0), e1 = 32 * c + frow(r, 1);
+          if (e0 >= 39) continue;
+          const float v = __builtin_fmaf(cc[r], LO_UNSCALE, hh[r]) * emb_dentry(xx, e0, e1, hf);
+          const int d0 = emb_dim(e0), d1 = (e1 < 39) ? emb_dim(e1) : d0;
+          if (d0 == d1) {
+            dx[d0] += v;
+          } else {
+            dx[d0] += hf ? 0.0f : v;
+            dx[d1] += hf ? v : 0.0f;
+          }
+          if (r & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto emb_stage = [&]() {   // two 32-row chunks (R4e or R0) over the current `in`
+        for (int c = 0; c < 2; ++c) {
+          chunk_sync<0>();
+          fetch();
+          f32x16 hh, cc;
+          const uint32_t wa = W32_WADDR();
+#include "gen32/kloop16z.inc"
+          if (c == 0) epi_emb(0, hh, cc); else epi_emb(1, hh, cc);
+          ++n;
+        }
+      };
+
+      // ---- R7..R1 ----
+#define W32_SYNC(c) chunk_sync<0>()
+#define W32_QLOAD(c, half) __builtin_nontemporal_load(scr_at(l - 1, c, half))
+      for (int l = 7; l >= 1; --l) {
+        if (l == 4) emb_stage();
+#include "gen32/rev.inc"
+#include "gen32/swap.inc"
+      }
+#undef W32_SYNC
+#undef W32_QLOAD
+
+      // ---- R0 and the chain rule through the encoding ----
+      emb_stage();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dx[c] += __shfl_xor(dx[c], 32, 64);
+      if (valid && hf == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.grad[P * 3 + c] = dx[c] * 3.0f;  // d(3x)/dx
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch (never consumed) has landed before the LDS is released
+}
+
+}  // namespace nrh32

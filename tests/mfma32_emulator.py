@@ -1,0 +1,213 @@
+"""Numpy emulation of the wide f16x3 SDF kernel (csrc/nrh_sdf32.hip on csrc/nrh_mlp32.h): the SAME packed stream, lane /
+register / K-slot arithmetic, scaled softplus domain, hi/lo splits and unorm16 sigma' hand-off, in float64.  It lets the
+CPU suite prove packing order and the stage plan (E4 start values, zeroed skip columns, R4e, the encoding derivative)
+before anything runs on a GPU.  Test infrastructure only."""
+import math
+
+import numpy as np
+
+LANES = np.arange(64)
+J = LANES & 31
+HF = LANES >> 5
+HALF_PI32 = float(np.float32(math.pi / 2))
+IK = 100.0 / math.log(2.0)
+
+
+def frow(r, hf):
+    return (r & 3) + 8 * (r >> 2) + 4 * hf
+
+
+def col32(s, hf, i):
+    return 16 * s + (i & 3) + 8 * (i >> 2) + 4 * hf
+
+
+def mfma_32x32x16(a, b, c):
+    """a, b: [64, 8] per-lane operands; c: [16, 64] (reg, lane).  D[row][col] = sum over K slots (hf, i) of
+    A[lane = 32 hf + row][i] * B[lane = 32 hf + col][i];  D register r of lane (hf, col) is row frow(r, hf)."""
+    A = a.reshape(2, 32, 8).transpose(1, 0, 2).reshape(32, 16)
+    B = b.reshape(2, 32, 8).transpose(0, 2, 1).reshape(16, 32)
+    D = A @ B
+    out = c.copy()
+    for r in range(16):
+        out[r] += D[frow(r, HF), J]
+    return out
+
+
+def split16(x):
+    with np.errstate(over="ignore"):
+        hi = x.astype(np.float16)
+        lo = ((x - hi.astype(np.float64)) * 2048.0).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def enc_entry(x3, e):
+    """entry e of enc_6(x3) per point, x3 [32,3]; the cosine half as sin(x + float32(pi/2)) like the reference."""
+    if e < 0 or e >= 39:
+        return np.zeros(x3.shape[0])
+    if e < 3:
+        return x3[:, e]
+    idx = e - 3
+    ph = HALF_PI32 if idx >= 18 else 0.0
+    idx %= 18
+    return np.sin(x3[:, idx // 6] * (1 << (idx % 6)) + ph)
+
+
+def enc_dentry(x3, e):
+    if e < 0 or e >= 39:
+        return np.zeros(x3.shape[0])
+    if e < 3:
+        return np.ones(x3.shape[0])
+    idx = e - 3
+    ph = HALF_PI32 if idx >= 18 else 0.0
+    idx %= 18
+    fr = float(1 << (idx % 6))
+    return np.cos(x3[:, idx // 6] * fr + ph) * fr
+
+
+def emb_dim(e):
+    return e if e < 3 else ((e - 3) % 18) // 6
+
+
+class Stream:
+    def __init__(self, buf16):
+        self.buf = np.asarray(buf16, dtype=np.float64)
+        self.pos = 0
+
+    def chunk(self, ks_stored):
+        n = ks_stored * 2 * 64 * 8
+        c = self.buf[self.pos:self.pos + n].reshape(ks_stored, 2, 64, 8)
+        self.pos += n
+        return c
+
+
+def kloop(chunk, ks, bh, bl, hh):
+    """hh: [16,64] start values.  Returns hh + cc / 2048 pieces (hh, cc) after ks K steps; bh, bl: [ks][64,8]."""
+    cc = np.zeros((16, 64))
+    hh = hh.copy()
+    for s in range(ks):
+        ah, al = chunk[s, 0], chunk[s, 1]
+        hh = mfma_32x32x16(ah, bh[s], hh)
+        cc = mfma_32x32x16(ah, bl[s], cc)
+        cc = mfma_32x32x16(al, bh[s], cc)
+    return hh, cc
+
+
+def tab_init(tables, table, c):
+    """[16,64]: register r of lane (hf, j) <- tables[table][32 c + frow(r, hf)]"""
+    out = np.zeros((16, 64))
+    for r in range(16):
+        out[r] = tables[table][32 * c + frow(r, HF)]
+    return out
+
+
+def act_to_b(u):
+    """u: [8 chunks][16 regs, 64 lanes] -> per K step (16 of them) hi/lo [64,8]: step 2c+t <- registers 8t..8t+7."""
+    bh, bl = [], []
+    for c in range(8):
+        for t in range(2):
+            v = u[c][8 * t: 8 * t + 8].T            # [64, 8]
+            h, l = split16(v)
+            bh.append(h)
+            bl.append(l)
+    return bh, bl
+
+
+def unorm16(q):
+    return np.rint(np.clip(q, 0.0, 1.0) * 65535.0)
+
+
+def sdf32_tile(stream16, tables, pts, mode, trace=None):
+    """One 32-point tile through the MODE `mode` stream.  pts [32,3] float64.  -> sdf [32], grad [32,3] | None, feat | None."""
+    tables = np.asarray(tables, dtype=np.float64)
+    st = Stream(stream16)
+    x3 = pts * 3.0
+    x3l = x3[J]                                    # per lane
+    # embedding B operands: K step s, element i <-> entry col32(s, hf, i)
+    ebh, ebl = [], []
+    for s in range(3):
+        v = np.zeros((64, 8))
+        for i in range(8):
+            for hf in range(2):
+                e = col32(s, hf, i)
+                m = HF == hf
+                v[m, i] = enc_entry(x3l[m], e)
+        h, l = split16(v)
+        ebh.append(h)
+        ebl.append(l)
+    if trace is not None:
+        trace['eb'] = (ebh, ebl)
+    want_d = mode >= 1
+    qs = {}
+
+    def epi_fwd(layer, c, hh, cc):
+        t = hh + cc / 2048.0
+        e = np.exp2(np.minimum(t, 64.0))
+        p = 1.0 + e
+        if want_d:
+            qs[(layer, c)] = unorm16(1.0 / p)
+        return np.maximum(np.log2(p), t)
+
+    u = [epi_fwd(0, c, *kloop(st.chunk(4), 3, ebh, ebl, tab_init(tables, 0, c))) for c in range(8)]
+    if trace is not None:
+        trace['u'] = [u]
+    for l in range(1, 8):
+        bh, bl = act_to_b(u)
+        nu = []
+        for c in range(8):
+            main = st.chunk(16)
+            init = tab_init(tables, l, c)
+            if l == 4:       # the skip part rides behind the chunk's main 32 KiB: E4 * emb on top of the bias
+                hh, cc = kloop(st.chunk(4), 3, ebh, ebl, init)
+                init = hh + cc / 2048.0
+            nu.append(epi_fwd(l, c, *kloop(main, 16, bh, bl, init)))
+        u = nu
+        if trace is not None:
+            trace['u'].append(u)
+    bh, bl = act_to_b(u)
+    feat = None
+    if mode == 2:
+        feat = np.zeros((32, 256))
+        for c in range(8):
+            hh, cc = kloop(st.chunk(16), 16, bh, bl, tab_init(tables, 8, c))
+            v = hh + cc / 2048.0
+            for r in range(16):
+                feat[J, 32 * c + frow(r, HF)] = v[r]
+    hh, cc = kloop(st.chunk(16), 16, bh, bl, tab_init(tables, 9, 0))
+    sdf = (hh + cc / 2048.0)[0][HF == 0]
+    if not want_d:
+        assert st.pos == len(st.buf)
+        return sdf, None, None
+    # T7
+    tcur = []
+    for c in range(8):
+        a8 = tab_init(tables, 10, c)
+        tcur.append(a8 + (a8 * (-1.0 / 65535.0)) * qs[(7, c)])
+    dx = np.zeros((3, 64))
+
+    def emb_stage(bh, bl):
+        for c in range(2):
+            hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+            g = hh + cc / 2048.0
+            for r in range(16):
+                for hf in range(2):
+                    e = 32 * c + frow(r, hf)
+                    if e >= 39:
+                        continue
+                    m = HF == hf
+                    dx[emb_dim(e)][m] += g[r][m] * enc_dentry(x3l[m], e)
+
+    for l in range(7, 0, -1):
+        bh, bl = act_to_b(tcur)
+        if l == 4:
+            emb_stage(bh, bl)
+        nxt = []
+        for c in range(8):
+            hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+            g = hh + cc / 2048.0
+            nxt.append(g + (g * (-1.0 / 65535.0)) * qs[(l - 1, c)])
+        tcur = nxt
+    bh, bl = act_to_b(tcur)
+    emb_stage(bh, bl)
+    assert st.pos == len(st.buf)
+    grad = np.stack([(dx[d][HF == 0] + dx[d][HF == 1]) * 3.0 for d in range(3)], axis=1)
+    return sdf, grad, feat

@@ -1,0 +1,48 @@
+"""CPU proof for the wide f16x3 SDF kernel (csrc/nrh_sdf32.hip): the packed streams of nrhints_amd/packing32.py driven through
+a numpy emulation of the kernel's lane / register / K-slot arithmetic (tests/mfma32_emulator.py) against the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from nrhints_amd import packing as pk
+from nrhints_amd import packing32 as pk32
+from oracle import neus_oracle as orc
+from tests import mfma32_emulator as emu
+
+
+@pytest.fixture(scope="module", params=["a", "b"])
+def packed32(request, scene_states):
+    st = {k: torch.from_numpy(np.asarray(v)) for k, v in scene_states[request.param].items()}
+    d = pk.dense_params(st)
+    pk.check_default_shapes(d)
+    streams, tables = pk32.pack_sdf32(d)
+    return orc.params_from_state(scene_states[request.param], torch.float64), streams.numpy(), tables.numpy()
+
+
+def _stream(streams, mode):
+    o = pk32.stream_offset_bytes(mode) // 2
+    return streams[o:o + pk32.stream_bytes(mode) // 2]
+
+
+def test_stream_sizes():
+    assert pk32.stream_bytes(0) == (8 * 8 + 49 * 32 + 8 * 40) * 1024
+    assert pk32.stream_bytes(1) == pk32.stream_bytes(0) + 60 * 32 * 1024
+    assert pk32.stream_bytes(2) == pk32.stream_bytes(1) + 8 * 32 * 1024
+
+
+def test_sdf32_chain_emulated(packed32):
+    p64, streams, tables = packed32
+    assert streams.dtype == np.float16 and streams.size * 2 == sum(pk32.stream_bytes(m) for m in range(3))
+    rs = np.random.RandomState(5)
+    pts = (rs.rand(32, 3) * 2 - 1) * 0.8
+    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, torch.from_numpy(pts))
+    sdf, grad, feat = emu.sdf32_tile(_stream(streams, 2), tables, pts, 2)
+    # fp32-class: the weights are fp16 hi/lo pairs (22 bits) of the float32 parameters, the products drop lo*lo
+    np.testing.assert_allclose(sdf, o_sdf.numpy()[:, 0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(feat, o_feat.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(grad, o_grad.numpy(), rtol=0, atol=2e-4)    # unorm16 sigma' (7.6e-6 per layer) dominates
+    sdf1, grad1, _ = emu.sdf32_tile(_stream(streams, 1), tables, pts, 1)
+    np.testing.assert_array_equal(sdf1, sdf)
+    np.testing.assert_array_equal(grad1, grad)
+    sdf0, _, _ = emu.sdf32_tile(_stream(streams, 0), tables, pts, 0)
+    np.testing.assert_array_equal(sdf0, sdf)
