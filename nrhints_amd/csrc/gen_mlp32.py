@@ -134,22 +134,28 @@ class Window:
     b_src 'agpr': B operands are a[4s..] / a[64+4s..];  'vgpr': u32x4 expressions (bh(s), bl(s)) given by name pattern.
     hh_init: name of an f32x16 holding the start values (compiler-visible LDS loads), or None for zero."""
 
-    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa"):
+    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa", cd=None, use_ds=True):
         self.ks, self.hh, self.cc, self.b_src, self.bvar, self.hh_zero, self.pf, self.wa = ks, hh, cc, b_src, bvar, hh_zero, pf, wa
+        self.cd = cd            # third accumulator (A_lo * B_hi products) - no back-to-back dependent MFMAs; None: they go to cc
+        self.use_ds = use_ds    # False: micro-benchmarks without LDS traffic (fragments stay whatever they are)
 
     def frag(self, s, part):
         return f"fa{(s % (self.pf + 1)) * 2 + part}"
 
-    def emit(self, out, slots_ops, ind="  "):
+    def emit(self, out, slots_ops, ind="  ", dma=None):
+        """dma: {slot: [piece, ...]} - W32_DMA(piece) calls (LDS-DMA of a later block) issued in that slot"""
         ks, pf = self.ks, self.pf
+        dma = dma or {}
         nbuf = (pf + 1) * 2
         out.append(ind + "nrh32::u32x4 " + ", ".join(f"fa{i}" for i in range(nbuf)) + ";")
         issued = []  # LDS reads in issue order: (s, part)
 
         def ds(s, part):
             off = (2 * s + part) * 1024
-            out.append(ind + f'asm volatile("ds_read_b128 %0, %1 offset:{off}" : "=v"({self.frag(s, part)}) : "v"({self.wa}));')
             issued.append((s, part))
+            if not self.use_ds:
+                return
+            out.append(ind + f'asm volatile("ds_read_b128 %0, %1 offset:{off}" : "=v"({self.frag(s, part)}) : "v"({self.wa}));')
 
         def wait_for(s, part):
             idx = issued.index((s, part))
@@ -166,11 +172,11 @@ class Window:
                 if s + pf < ks and j < 2:
                     ds(s + pf, j)
                 part = 1 if j == 2 else 0
-                acc = self.hh if j == 0 else self.cc
-                first = (s == 0 and (j == 1 or (j == 0 and self.hh_zero)))
-                w = wait_for(s, part)
+                acc = self.hh if j == 0 else (self.cd if (j == 2 and self.cd) else self.cc)
+                first = (s == 0 and (j == 1 or (j == 2 and self.cd) or (j == 0 and self.hh_zero)))
+                w = wait_for(s, 1)           # one wait per K step: both fragments (hi was issued first) before the first MFMA
                 bpart = 1 if j == 1 else 0   # j=1: A_hi * B_lo, j=2: A_lo * B_hi
-                pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j != 1) else ""
+                pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j == 0 and self.use_ds) else ""
                 if self.b_src == "agpr":
                     base = 4 * s + (64 if bpart else 0)
                     bop, bcons = f"a[{base}:{base + 3}]", ""
@@ -180,6 +186,8 @@ class Window:
                     out.append(ind + f'asm volatile("{pre}{MFMA} %0, %1, {bop}, 0" : "=&v"({acc}) : "v"({self.frag(s, part)}){bcons});')
                 else:
                     out.append(ind + f'asm volatile("{pre}{MFMA} %0, %1, {bop}, %0" : "+v"({acc}) : "v"({self.frag(s, part)}){bcons});')
+                for piece in dma.get(slot, []):
+                    out.append(ind + f"W32_DMA({piece});")
                 if slots_ops is not None and slot < len(slots_ops) and slots_ops[slot]:
                     emit_ops(out, slots_ops[slot], ind)
                 out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
@@ -192,10 +200,15 @@ class Window:
             slot += 1
 
 
+DMA_SLOTS16 = {2 + 3 * k: [k] for k in range(8)}     # regular window: one piece of block n + 2 after the last MFMA of K steps 0..7
+
+
 def gen_stage(kind, want_d, ks, b_src, nv, hh_zero):
     """A pipelined 8-chunk stage: window c runs the K loop of chunk c and the epilogue of chunk c - 1; drain at the end.
-    Hooks (macros defined by the including kernel): W32_SYNC(c), W32_FETCH(), W32_HINIT(c) (f32x16 start values, unless
-    hh_zero), W32_QSTORE / W32_QLOAD(c, half)."""
+    ks = 16: one 32 KiB block per chunk.  ks = 3 (layer 0): four chunks per block (8 KiB each), the block changes at c = 4.
+    Hooks (macros of the including kernel): W32_SYNC(), W32_FETCH_SETUP(), W32_DMA(piece), W32_NEXT(), W32_WADDR(),
+    W32_HINIT(c) (f32x16 start values, unless hh_zero), W32_QSTORE(c, half, v), W32_QLOAD_ASM(dst, c, half)."""
+    small = ks != 16
     out = []
     out.append(f"// generated by gen_mlp32.py: stage kind={kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv}")
     out.append("{")
@@ -213,37 +226,43 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero):
             else:
                 epi = epi_rev(c - 1, f"hh{c - 1}", f"cc{c - 1}")
         if c < 8:
-            if kind == "rev" and c > 0:
-                # the q words loaded in the previous window have landed before the next LDS-DMA batch goes out (hipcc does not
-                # see the asm DMA in its vmcnt bookkeeping; a later wait for these loads would drain the fresh batch too)
-                out.append(f'    asm volatile("" : "+v"(qa{c - 1}), "+v"(qb{c - 1}));')
-            out.append(f"    W32_SYNC({c});")
-            out.append("    W32_FETCH();")
+            if not small or c % 4 == 0:
+                out.append("    W32_SYNC();")
+                out.append("    W32_FETCH_SETUP();")
             if kind == "rev":
-                out.append(f"    qa{c} = W32_QLOAD({c}, 0); qb{c} = W32_QLOAD({c}, 1);")
+                # asm loads: hipcc does not see them, so it never waits for them with vmcnt(0) (which would also drain the
+                # LDS-DMA pieces in flight); they are older than this window's 8 pieces: the next W32_SYNC covers them
+                out.append(f"    W32_QLOAD_ASM(qa{c}, {c}, 0); W32_QLOAD_ASM(qb{c}, {c}, 1);")
             if not hh_zero:
                 out.append(f"    hh{c} = W32_HINIT({c});")
-            out.append("    const uint32_t wa = W32_WADDR();")
+            out.append("    const uint32_t wa = W32_WADDR()" + (f" + {(c % 4) * 8192};" if small else ";"))
             if c > 0:
                 # the previous chunk's accumulators are read by VALU only from here on: >= 11 wait states after its last MFMA
                 out.append(f'    asm volatile("" : "+v"(hh{c - 1}), "+v"(cc{c - 1}));')
             if kind == "rev" and c > 0:
+                out.append(f'    asm volatile("" : "+v"(qa{c - 1}), "+v"(qb{c - 1}));')
                 out.append(f"    const nrh32::u32x4 qw0 = qa{c - 1}, qw1 = qb{c - 1};")
             win = Window(ks, f"hh{c}", f"cc{c}", b_src=b_src, hh_zero=hh_zero)
+            if small:
+                dma = {2: [2 * (c % 4)], 5: [2 * (c % 4) + 1]}
+            else:
+                dma = DMA_SLOTS16
             if epi is not None:
-                slots, tail = schedule(epi, max(3 * ks, (len(epi) + nv - 1) // nv + 8), nv)
+                budget = (lambda k: max(1, nv - 2) if k in dma else nv) if not small else nv
+                slots, tail = schedule(epi, max(3 * ks, (len(epi) + nv - 1) // nv + 8), budget)
             else:
                 slots, tail = None, []
-            win.emit(out, slots, "    ")
+            win.emit(out, slots, "    ", dma=dma)
             if tail:
                 out.append("    // epilogue work that did not fit the MFMA shadows")
                 emit_ops(out, tail, "    ")
-            out.append("    W32_NEXT();")
+            if not small or c % 4 == 3:
+                out.append("    W32_NEXT();")
         else:
             # MFMA results -> VALU reads need 11 wait states; the asm carries the accumulators so that no read is scheduled above it
             out.append(f'    asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh7), "+v"(cc7));')
             if kind == "rev":
-                out.append("    asm volatile(\"\" : \"+v\"(qa7), \"+v\"(qb7));")
+                out.append('    asm volatile("s_waitcnt vmcnt(8)" : "+v"(qa7), "+v"(qb7));   // the q loads of window 7 (older than its 8 DMA pieces)')
                 out.append("    const nrh32::u32x4 qw0 = qa7, qw1 = qb7;")
             if epi is not None:
                 emit_ops(out, epi, "    ")
@@ -253,9 +272,10 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero):
 
 
 def gen_kloop(ks, b_src, hh_zero):
-    """K loop only (no fillers): for the light stages whose epilogue is written by hand after it.  Needs hh, cc, wa."""
+    """K loop only (no fillers): for the light stages whose epilogue is written by hand after it.  Needs hh, cc, wa; the
+    16-step form consumes a streamed block and therefore also issues the 8 LDS-DMA pieces of block n + 2 (W32_DMA)."""
     out = [f"// generated by gen_mlp32.py: bare K loop ks={ks} b={b_src}", "{"]
-    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero).emit(out, None, "  ")
+    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
     out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh), "+v"(cc));   // MFMA results -> VALU reads: 11 wait states')
     out.append("}")
     return "\n".join(out) + "\n"

@@ -38,13 +38,16 @@ constexpr int WAVES = 4;                  // one per SIMD
 constexpr int THREADS = 64 * WAVES;
 constexpr int TILE = 32;                  // points per wave
 constexpr int GROUP = TILE * WAVES;       // points per workgroup pass
-constexpr int SLOT_BYTES = 40960;         // one weight chunk: 32 output rows x K = 256, hi + lo (32 KiB), + 8 KiB for the
-                                          // skip part that rides with layer 4's chunks (nrh_sdf32.hip)
-constexpr int RING = 2;
+constexpr int SLOT_BYTES = 32768;         // one weight block: 32 output rows x K = 256, hi + lo
+constexpr int RING = 3;                   // block n is consumed while n + 1 and n + 2 are in flight / landed
+constexpr int RESIDENT_BYTES = 49152;     // weights that stay in LDS for the whole launch (the skip part E4 of the SDF net)
 constexpr int NTAB = 11;                  // bias / constant tables, 256 floats each (see nrh_sdf32.hip)
 constexpr int LDS_RING = 0;
-constexpr int LDS_TAB = RING * SLOT_BYTES;
+constexpr int LDS_RESIDENT = RING * SLOT_BYTES;
+constexpr int LDS_TAB = LDS_RESIDENT + RESIDENT_BYTES;
 constexpr int LDS_BYTES = LDS_TAB + NTAB * 1024;
+static_assert(LDS_BYTES <= 163840, "LDS per workgroup");
+constexpr int WAVE_PIECES = SLOT_BYTES / 1024 / WAVES;   // LDS-DMA pieces per wave per block (8 KiB contiguous per wave)
 
 constexpr float LO_SCALE = 2048.0f;
 constexpr float LO_UNSCALE = 1.0f / 2048.0f;
@@ -81,21 +84,35 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
-// ---- LDS-DMA of the weight stream ----
-// One 1 KiB piece: lane-linear 16 B per lane; global address = sbase + 16 * lane, LDS address = m0 (wave-uniform).
-__device__ __forceinline__ void dma_piece(const char* gbase, uint32_t lds_addr, uint32_t lane16) {
-  // wave-uniform by construction; readfirstlane makes it so for the compiler too (an "s" operand it believes divergent is
-  // otherwise printed as a VGPR)
-  if (NRH32_ABL & 1) return;
-  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-  const uint64_t g = (uint64_t)gbase;
-  gbase = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(g >> 32)) << 32) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)g));   // (readfirstlane returns int: no sign extension)
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane16), "s"(gbase) : "memory");
+// two values in [0,1] -> unorm16 pair (v_cvt_pknorm_u16_f32: clamp, scale by 65535, round to nearest)
+__device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(a, b));
 }
-// a chunk of np pieces (np % WAVES == 0): wave w moves pieces w, w + 4, ...
-__device__ __forceinline__ void dma_chunk(const char* gsrc, uint32_t lds_dst, int np, int wave, uint32_t lane16) {
-  for (int p = wave; p < np; p += WAVES) dma_piece(gsrc + p * 1024, lds_dst + p * 1024, lane16);
+
+// ---- LDS-DMA of the weight stream ----
+// One 1 KiB piece: lane-linear 16 B per lane.  Global address = gp + OFF + 16 * lane, LDS address = m0 + OFF + 16 * lane: the
+// instruction offset moves BOTH (measured, profiles/ubench/dma_offset_test.hip), so four pieces share one (gp, m0) pair.
+// Issue cost is what matters here (one wave per SIMD: every issue slot is the MFMA stream's): M0 is rewritten each time
+// because nothing reserves it for us between asm statements.
+template <int OFF>
+__device__ __forceinline__ void dma_piece(const char* gp, uint32_t m0v, uint32_t lane16) {
+  if (NRH32_ABL & 1) return;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(m0v), "v"(lane16), "s"(gp), "n"(OFF));
+}
+// wave-uniform values the compiler may not believe to be uniform
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const char* uni(const char* p) {
+  const uint64_t g = (uint64_t)p;   // (readfirstlane returns int: no sign extension)
+  return (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(g >> 32)) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)g));
+}
+// this wave's 8 KiB share of a 32 KiB block, all at once (prologue only; in the windows the pieces are spread over MFMA slots)
+__device__ __forceinline__ void dma_block(const char* gsrc_w, uint32_t lds_w, uint32_t lane16) {
+  dma_piece<0>(gsrc_w, lds_w, lane16); dma_piece<1024>(gsrc_w, lds_w, lane16);
+  dma_piece<2048>(gsrc_w, lds_w, lane16); dma_piece<3072>(gsrc_w, lds_w, lane16);
+  dma_piece<0>(gsrc_w + 4096, lds_w + 4096, lane16); dma_piece<1024>(gsrc_w + 4096, lds_w + 4096, lane16);
+  dma_piece<2048>(gsrc_w + 4096, lds_w + 4096, lane16); dma_piece<3072>(gsrc_w + 4096, lds_w + 4096, lane16);
 }
 
 // wait until at most `keep` of this wave's VMEM operations (the youngest) are outstanding, then meet the other waves

@@ -39,15 +39,11 @@ struct Sdf32Args {
 };
 
 constexpr int SCRATCH_WORDS_PER_WAVE = 8 * 8 * 2 * 64 * 4;   // [layer][chunk][half][lane] uint4
-constexpr int SMALL_PIECES = 8;    // L0 chunks: 4 K steps stored (3 used) = 8 KiB
-constexpr int BIG_PIECES = 32;
-constexpr int L4_PIECES = 40;      // layer 4: 32 KiB main part + 8 KiB skip part (E4)
-__host__ __device__ constexpr int sdf32_stream_chunks(int mode) { return 8 + 56 + 1 + (mode == 2 ? 8 : 0) + (mode >= 1 ? 60 : 0); }
+// The stream of one MODE: a 48 KiB preamble that stays resident in LDS (E4: 8 chunks x 3 K steps), then 32 KiB blocks in
+// execution order: L0 x2 (four 8 KiB chunks each) | L1..L7 x56 | [FEAT x8] | HEAD | [R7 R6 R5 x24 | R4e x2 | R4..R1 x32 | R0 x2]
+__host__ __device__ constexpr int sdf32_stream_blocks(int mode) { return 2 + 56 + 1 + (mode == 2 ? 8 : 0) + (mode >= 1 ? 60 : 0); }
 __host__ __device__ constexpr long long sdf32_stream_bytes(int mode) {
-  long long n = 8LL * SMALL_PIECES + 48LL * BIG_PIECES + 8LL * L4_PIECES + BIG_PIECES;   // L0, L1..L7, HEAD
-  if (mode == 2) n += 8LL * BIG_PIECES;                                            // FEAT
-  if (mode >= 1) n += (56LL + 2 + 2) * BIG_PIECES;                                 // R7..R1, R4e, R0
-  return n * 1024;
+  return RESIDENT_BYTES + (long long)sdf32_stream_blocks(mode) * SLOT_BYTES;
 }
 
 // entry e of enc_6(x3) for this lane: e = hf ? e1 : e0 (both static); one sine per entry
@@ -101,11 +97,6 @@ __device__ __forceinline__ float emb_dentry(const float (&x)[3], int e0, int e1,
 }
 __host__ __device__ constexpr int emb_dim(int e) { return e < 3 ? e : ((e - 3) % 18) / 6; }
 
-__device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_u16(a, b));
-}
-
 // MODE 0: sdf | 1: sdf + gradient | 2: + feature tiles
 template <int MODE>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdf32_kernel(const Sdf32Args a) {
@@ -135,21 +126,42 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   for (int i = threadIdx.x; i < NTAB * 64; i += THREADS)
     reinterpret_cast<f32x4*>(smem + LDS_TAB)[i] = reinterpret_cast<const f32x4*>(a.tab)[i];
 
-  // the weight stream: chunk n sits in ring slot n & 1; wnext / cnext = global address / index in the pass of the next chunk
-  // to fetch (chunks 0..7 are L0's 8 KiB, 32..39 layer 4's 40 KiB, all others 32 KiB)
-  int n = 0, cnext = 0;
-  const char* wnext = a.w;
-  auto fetch = [&]() {   // issue the LDS-DMA of the next chunk of the stream into the slot chunk n - 1 occupied
-    const int np = cnext < 8 ? SMALL_PIECES : ((cnext >= 32 && cnext < 40) ? L4_PIECES : BIG_PIECES);
-    dma_chunk(wnext, ring_lds + ((n + 1) & 1) * SLOT_BYTES, np, wave, lane16);
-    wnext += np * 1024;
-    if (++cnext == sdf32_stream_chunks(MODE)) { cnext = 0; wnext = a.w; }
-  };
-  // first chunk of the stream
-  dma_chunk(wnext, ring_lds, SMALL_PIECES, wave, lane16);
-  wnext += SMALL_PIECES * 1024;
-  cnext = 1;
+  // resident weights (E4) -> LDS once per launch: 48 pieces, 12 per wave
+  for (int p = wave; p < RESIDENT_BYTES / 1024; p += WAVES)
+    dma_piece<0>(uni(a.w + p * 1024), uni(ring_lds + LDS_RESIDENT + p * 1024), lane16);
 
+  // the block stream: block n sits in ring slot n % 3; while it is consumed, n + 1 has landed or is landing and the pieces
+  // of n + 2 are issued (8 per wave: this wave owns bytes [8192 wave, +8192) of every block, in global memory and in LDS)
+  const char* const wblocks = a.w + RESIDENT_BYTES + wave * 8192;
+  const char* wfetch = wblocks;     // this wave's share of the next block to fetch
+  int bfetch = 0;                   // its index in the pass
+  uint32_t cur_off = 0, fetch_off = 0;   // ring offsets (bytes) of the block being consumed / being fetched
+  const char* fg0 = nullptr; const char* fg1 = nullptr;
+  uint32_t fm0 = 0, fm1 = 0;
+  auto fetch_setup = [&]() {        // addresses for the 8 pieces of the next block; the pieces go out in later MFMA slots
+    fg0 = uni(wfetch);
+    fg1 = uni(wfetch + 4096);
+    fm0 = uni(ring_lds + fetch_off + wave * 8192);
+    fm1 = fm0 + 4096;
+    wfetch += SLOT_BYTES;
+    if (++bfetch == sdf32_stream_blocks(MODE)) { bfetch = 0; wfetch = wblocks; }
+    fetch_off = (fetch_off == 2 * SLOT_BYTES) ? 0 : fetch_off + SLOT_BYTES;
+  };
+#define W32_DMA(i) dma_piece<((i) & 3) * 1024>(((i) < 4) ? fg0 : fg1, ((i) < 4) ? fm0 : fm1, lane16)
+  // blocks 0 and 1 up front
+  for (int b = 0; b < 2; ++b) {
+    fetch_setup();
+    W32_DMA(0); W32_DMA(1); W32_DMA(2); W32_DMA(3); W32_DMA(4); W32_DMA(5); W32_DMA(6); W32_DMA(7);
+  }
+
+#ifdef NRH32_TIMING
+  // diagnosis: shader cycles per stage family, summed over this wave's passes -> dbg[wave-global][8] (uint64)
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+#define NRH32_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define NRH32_STAMP(k) do { } while (0)
+#endif
   for (int tg = blockIdx.x; tg < a.ngroups; tg += gridDim.x) {
     const long long tile = (long long)tg * WAVES + wave;
     const long long P = tile * TILE + j;
@@ -180,9 +192,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       ebh2 = u32x4{eh[8], eh[9], eh[10], eh[11]}; ebl2 = u32x4{el[8], el[9], el[10], el[11]};
     }
     auto tab_init = [&](int table, int c) { return ld_init(tabs + table * 1024 + (32 * c + 4 * hf) * 4, 32); };
-#define W32_FETCH() fetch()
-#define W32_WADDR() (wlane + (n & 1) * SLOT_BYTES)
-#define W32_NEXT() ++n
+    // every streamed block is older than the 8 youngest VMEM operations of this wave when it is needed (the pieces of the
+    // block after it), so one static wait serves every window; the barrier makes the other waves' pieces visible and tells
+    // them that this wave is done with the previous block (whose slot the next pieces overwrite)
+#define W32_SYNC() chunk_sync<8>()
+#define W32_FETCH_SETUP() fetch_setup()
+#define W32_WADDR() (wlane + cur_off)
+#define W32_NEXT() (cur_off = (cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES)
 
 #ifdef NRH32_DEBUG
     const bool dbg_on = a.dbg != nullptr && blockIdx.x == 0 && tg == blockIdx.x;
@@ -204,9 +220,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       for (int i = 0; i < 24; ++i) dbg_at(1 * 32768 + (wave * 128 + i) * 64)[lane] = eb[i];
     }
 #endif
-    // the two q stores of the previous window's epilogue may stay in flight across the chunk barrier
-#define W32_SYNC(c) do { if (WANT_D && (c) >= 2) chunk_sync<2>(); else chunk_sync<0>(); } while (0)
 #define W32_QSTORE(c, half, val) __builtin_nontemporal_store((val), scr_at(qlayer, c, half))
+    NRH32_STAMP(0);   // setup: rays, embedding
     // ---- L0 ----
     {
       const int qlayer = 0;
@@ -223,16 +238,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if (dbg_on) { dbg_in(3); if (a.dbg_stage == 3) return; }
 #endif
 
+    NRH32_STAMP(1);   // L0
     // ---- L1..L7 ----
     for (int l = 1; l <= 7; ++l) {
       const int qlayer = l;
-      // start values: the bias table, and for layer 4 the skip part E4 * emb on top (9 MFMAs per chunk over the 8 KiB that
-      // follow the chunk's main 32 KiB in the ring slot)
+      // start values: the bias table, and for layer 4 the skip part E4 * emb on top (9 MFMAs per chunk over resident weights)
       auto hinit = [&](int c) {
         f32x16 hh = tab_init(l, c);
         if (l == 4) {
           f32x16 cc;
-          const uint32_t wa = W32_WADDR() + 32768;
+          const uint32_t wa = ring_lds + LDS_RESIDENT + c * 6144 + lane16;   // resident E4 chunk c: 3 K steps
 #include "gen32/kloop3v.inc"
 #pragma unroll
           for (int r = 0; r < 16; ++r) hh[r] = __builtin_fmaf(cc[r], LO_UNSCALE, hh[r]);
@@ -253,17 +268,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       if (dbg_on && l == 7) dbg_in(6);
 #endif
     }
-#undef W32_SYNC
 #undef W32_QSTORE
 
+    NRH32_STAMP(2);   // L1..L7
     // ---- FEAT (MODE 2) and HEAD ----
     if (MODE == 2) {
       const long long t16 = 2 * tile + (j >> 4);
       const bool t16_ok = t16 * 16 < a.npts;
       float* const ft = a.feat + (size_t)t16 * 4096 + ((j & 15) + 16 * hf) * 4;
       for (int c = 0; c < 8; ++c) {
-        chunk_sync<0>();
-        fetch();
+        W32_SYNC();
+        W32_FETCH_SETUP();
         f32x16 hh = tab_init(8, c), cc;
         const uint32_t wa = W32_WADDR();
 #include "gen32/kloop16.inc"
@@ -277,19 +292,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ft + ((2 * c + (g >> 1)) * 64 + 32 * (g & 1)) * 4));
           }
         }
-        ++n;
+        W32_NEXT();
       }
     }
     {
-      chunk_sync<0>();
-      fetch();
+      W32_SYNC();
+      W32_FETCH_SETUP();
       f32x16 hh = tab_init(9, 0), cc;
       const uint32_t wa = W32_WADDR();
 #include "gen32/kloop16.inc"
       if (valid && hf == 0) a.sdf[ray * a.sdf_stride + jj] = __builtin_fmaf(cc[0], LO_UNSCALE, hh[0]);
-      ++n;
+      W32_NEXT();
     }
 
+    NRH32_STAMP(3);   // FEAT + HEAD
     if constexpr (WANT_D) {
       // ---- T7: t_7 = (1 - q_7) * w_s / 3, straight into `in` ----
 #define W32_A8(c) tab_init(10, c)
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #undef W32_A8
 #undef W32_QLOAD7
 
+      NRH32_STAMP(4);   // T7
       // g_emb chunk c (register r <-> entry 32c + frow(r, hf)) contracted with d enc / dx.  The 20 derivative values are
       // recomputed for each of the two stages that need them (R4e, R0): keeping them live across R4..R1 costs more
       // registers than 20 cosines cost time.
@@ -323,37 +340,45 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       };
       auto emb_stage = [&]() {   // two 32-row chunks (R4e or R0) over the current `in`
         for (int c = 0; c < 2; ++c) {
-          chunk_sync<0>();
-          fetch();
+          W32_SYNC();
+          W32_FETCH_SETUP();
           f32x16 hh, cc;
           const uint32_t wa = W32_WADDR();
 #include "gen32/kloop16z.inc"
           if (c == 0) epi_emb(0, hh, cc); else epi_emb(1, hh, cc);
-          ++n;
+          W32_NEXT();
         }
       };
 
       // ---- R7..R1 ----
-#define W32_SYNC(c) chunk_sync<0>()
-#define W32_QLOAD(c, half) __builtin_nontemporal_load(scr_at(l - 1, c, half))
-      for (int l = 7; l >= 1; --l) {
-        if (l == 4) emb_stage();
+      // q words of chunk c of layer l - 1: asm loads (invisible to hipcc's vmcnt bookkeeping), nt: served by L2
+#define W32_QLOAD_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(lane16), "s"(qbase + (c) * 2048), "n"((half) * 1024))
+      for (int l = 7; l >= 0; --l) {   // l = 0: only R0 (one copy of emb_stage in the code: the kernels are I-cache sized)
+        if (l == 4 || l == 0) emb_stage();
+        if (l == 0) break;
+        const char* const qbase = uni(scr + (l - 1) * 16384);
 #include "gen32/rev.inc"
 #include "gen32/swap.inc"
       }
-#undef W32_SYNC
-#undef W32_QLOAD
+#undef W32_QLOAD_ASM
 
-      // ---- R0 and the chain rule through the encoding ----
-      emb_stage();
+      NRH32_STAMP(5);   // R7..R1 (+ R4e)
+      // ---- the chain rule through the encoding (R0 ran as the last pass of the loop above) ----
 #pragma unroll
       for (int c = 0; c < 3; ++c) dx[c] += __shfl_xor(dx[c], 32, 64);
       if (valid && hf == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.grad[P * 3 + c] = dx[c] * 3.0f;  // d(3x)/dx
       }
+      NRH32_STAMP(6);   // R0 + gradient out
     }
   }
+#ifdef NRH32_TIMING
+  if (a.dbg != nullptr && lane == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dbg) + (size_t)(blockIdx.x * WAVES + wave) * 8;
+    for (int k = 0; k < 8; ++k) o[k] = tacc[k];
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch (never consumed) has landed before the LDS is released
 }
 

@@ -9,10 +9,11 @@ previous layer lands in registers (no shuffle between layers).  hi = fp16(w), lo
 
 The kernels read ONE stream of chunks per evaluation mode, in execution order (csrc/nrh_sdf32.hip):
 
-    L0 x8 (8 KiB) | L1..L7 x56 (layer 4's chunks: 32 KiB + 8 KiB of E4) | [FEAT x8] | HEAD x1 | [R7 R6 R5 x24 | R4e x2 | R4..R1 x32 | R0 x2]
+    E4 (48 KiB, resident in LDS) | L0 x2 blocks (four 8 KiB chunks each) | L1..L7 x56 | [FEAT x8] | HEAD x1 |
+    [R7 R6 R5 x24 | R4e x2 | R4..R1 x32 | R0 x2]                                  (blocks of 32 KiB)
 
 E4 = W4[:, 217:] / sqrt2 is the skip connection's part of layer 4 (applied to the 39 embedding entries, in the embedding's K
-order); W4's main part has those columns zeroed.  The softplus layers work in the scaled domain t = z * 100/ln2,
+order, 3 K steps per chunk); W4's main part has those columns zeroed.  The softplus layers work in the scaled domain t = z * 100/ln2,
 u = h * 100/ln2 (see nrh_mlp32.h): L0 and E4 carry the factor 100/ln2, the head and the feature layer its inverse, biases
 are scaled, L1..L7 are unchanged.
 Torch ops only; not differentiable (evaluation kernels).
@@ -35,13 +36,15 @@ WAVES, TILE = 4, 32
 GROUP = WAVES * TILE
 
 
+RESIDENT_BYTES = 49152
+
+
+def stream_blocks(mode: int) -> int:
+    return 2 + 56 + 1 + (8 if mode == 2 else 0) + (60 if mode >= 1 else 0)
+
+
 def stream_bytes(mode: int) -> int:
-    n = 8 * 8 + 48 * 32 + 8 * 40 + 32
-    if mode == 2:
-        n += 8 * 32
-    if mode >= 1:
-        n += (56 + 2 + 2) * 32
-    return n * 1024
+    return RESIDENT_BYTES + stream_blocks(mode) * 32768
 
 
 def _cols(ks: int) -> torch.Tensor:
@@ -84,12 +87,10 @@ def sdf32_pieces(d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     w4e = w[4][:, 217:256] / r2                                    # skip part: applied to the 39 embedding entries
     fwd = [w[0], w[1], w[2], w[3], w4m, w[5], w[6], w[7]]
     p = {}
-    p["L0"] = pack_stage32(w[0] * IK, 256, SMALL_KS)            # 8 KiB chunks, 4 K steps stored, 3 used
+    p["E4"] = pack_stage32(w4e * IK, 256, 3)                     # 6 KiB chunks, resident
+    p["L0"] = pack_stage32(w[0] * IK, 256, SMALL_KS)            # 8 KiB chunks (4 K steps stored, 3 used): 2 blocks
     for l in range(1, 8):
         p[f"L{l}"] = pack_stage32(fwd[l], 256, BIG_KS)
-    # layer 4: chunk c = [main 32 KiB | E4 chunk c, 8 KiB]
-    e4 = pack_stage32(w4e * IK, 256, SMALL_KS).reshape(8, -1)
-    p["L4"] = torch.cat([p["L4"].reshape(8, -1), e4], dim=1).reshape(-1)
     p["FEAT"] = pack_stage32(f(d["feat_w"]) * KK, 256, BIG_KS)
     p["HEAD"] = pack_stage32(f(d["sdf_head_w"]).reshape(1, 256) * (KK / 3.0), 32, BIG_KS)
     for l in range(1, 8):
@@ -100,7 +101,7 @@ def sdf32_pieces(d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 def stream_order(mode: int):
-    order = ["L0"] + [f"L{l}" for l in range(1, 8)]
+    order = ["E4", "L0"] + [f"L{l}" for l in range(1, 8)]
     if mode == 2:
         order.append("FEAT")
     order.append("HEAD")

@@ -126,6 +126,27 @@ int main(int argc, char** argv) {
           efeat = fmax(efeat, fabs(v - e_feat[p * 256 + ft]));
         }
     }
+#ifdef NRH32_TIMING
+    {
+      unsigned long long* d_t;
+      const int nw = grid * nrh32::WAVES;
+      CK(hipMalloc(&d_t, nw * 64));
+      CK(hipMemset(d_t, 0, nw * 64));
+      a.dbg = reinterpret_cast<uint32_t*>(d_t);
+      launch();
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> ht(nw * 8);
+      CK(hipMemcpy(ht.data(), d_t, nw * 64, hipMemcpyDeviceToHost));
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
+      for (int w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) { acc[k] += (double)ht[w * 8 + k] / nw; }
+      for (int k = 0; k < 8; ++k) tot += acc[k];
+      const double passes = (double)a.ngroups / grid;
+      printf("  cycles per pass (mean over waves, %.1f passes): setup %.0f | L0 %.0f | L1..L7 %.0f | FEAT+HEAD %.0f | T7 %.0f | R7..R1+R4e %.0f | R0+out %.0f | total %.0f\n",
+             passes, acc[0] / passes, acc[1] / passes, acc[2] / passes, acc[3] / passes, acc[4] / passes, acc[5] / passes, acc[6] / passes, tot / passes);
+      a.dbg = nullptr;
+      CK(hipFree(d_t));
+    }
+#endif
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));

@@ -134,6 +134,7 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
         h, l = split16(v)
         ebh.append(h)
         ebl.append(l)
+    e4 = [st.chunk(3) for _ in range(8)]           # resident preamble
     if trace is not None:
         trace['eb'] = (ebh, ebl)
     want_d = mode >= 1
@@ -156,8 +157,8 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
         for c in range(8):
             main = st.chunk(16)
             init = tab_init(tables, l, c)
-            if l == 4:       # the skip part rides behind the chunk's main 32 KiB: E4 * emb on top of the bias
-                hh, cc = kloop(st.chunk(4), 3, ebh, ebl, init)
+            if l == 4:       # the skip part: resident E4 * emb on top of the bias
+                hh, cc = kloop(e4[c], 3, ebh, ebl, init)
                 init = hh + cc / 2048.0
             nu.append(epi_fwd(l, c, *kloop(main, 16, bh, bl, init)))
         u = nu

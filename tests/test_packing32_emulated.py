@@ -25,7 +25,7 @@ def _stream(streams, mode):
 
 
 def test_stream_sizes():
-    assert pk32.stream_bytes(0) == (8 * 8 + 49 * 32 + 8 * 40) * 1024
+    assert pk32.stream_bytes(0) == 49152 + 59 * 32768
     assert pk32.stream_bytes(1) == pk32.stream_bytes(0) + 60 * 32 * 1024
     assert pk32.stream_bytes(2) == pk32.stream_bytes(1) + 8 * 32 * 1024
 
