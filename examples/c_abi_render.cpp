@@ -32,8 +32,9 @@
   } while (0)
 
 // file layout (little endian): int64 header[10] = {magic, precision, hints, nrays, bytes of sdf_w, sdf_b, sdf_head,
-// col_w, col_b, reserved}; float inv_s; float cos_anneal; then the five buffers, then o, d, pl [n,3], near, far [n],
-// background [3], lin64 [64], lin16 [16] as float32
+// col_w, col_b, bytes of the wide block}; float inv_s; float cos_anneal; then the five buffers, then the wide block (0 bytes, or
+// the streams of the wide f16x3 SDF kernels followed by their [11][256] float32 tables: NrhNet.sdf_w32 / sdf_tab32), then
+// o, d, pl [n,3], near, far [n], background [3], lin64 [64], lin16 [16] as float32
 static const int64_t MAGIC = 0x4e52483031;  // "NRH01"
 
 static bool read_exact(FILE* f, void* dst, size_t bytes) { return fread(dst, 1, bytes, f) == bytes; }
@@ -66,6 +67,8 @@ int main(int argc, char** argv) {
     blobs[i].resize((size_t)hdr[4 + i]);
     if (!read_exact(f, blobs[i].data(), blobs[i].size())) { fprintf(stderr, "truncated scene file\n"); return 1; }
   }
+  std::vector<char> wide((size_t)hdr[9]);
+  if (!wide.empty() && !read_exact(f, wide.data(), wide.size())) { fprintf(stderr, "truncated scene file\n"); return 1; }
   auto read_f = [&](size_t count) {
     std::vector<float> v(count);
     if (!read_exact(f, v.data(), count * 4)) v.clear();
@@ -85,6 +88,14 @@ int main(int argc, char** argv) {
   }
   net.sdf_w = (const float*)dev[0]; net.sdf_b = (const float*)dev[1]; net.sdf_head = (const float*)dev[2];
   net.col_w = (const float*)dev[3]; net.col_b = (const float*)dev[4];
+  if (!wide.empty()) {
+    const long long stream_bytes = nrh_sdf_wide_stream_bytes();
+    if ((long long)wide.size() != stream_bytes + 11 * 256 * 4) { fprintf(stderr, "wide block has the wrong size for this library\n"); return 1; }
+    char* d_wide = to_device(wide);
+    if (!d_wide) { fprintf(stderr, "device upload failed\n"); return 2; }
+    net.sdf_w32 = d_wide;
+    net.sdf_tab32 = (const float*)(d_wide + stream_bytes);
+  }
   net.inv_s = inv_s; net.precision = precision; net.hints = hints; net.normal_type = 0; net.depth_type = 0;
   float *d_o = to_device(o), *d_d = to_device(d), *d_pl = to_device(pl), *d_near = to_device(nearv), *d_far = to_device(farv),
         *d_bg = to_device(bg), *d_l64 = to_device(lin64), *d_l16 = to_device(lin16);

@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nrhints_amd as na  # noqa: E402
-from nrhints_amd import _lib, packing  # noqa: E402
+from nrhints_amd import _lib, packing, packing32  # noqa: E402
 from nrhints_amd.synthetic import make_rays  # noqa: E402
 
 MAGIC = 0x4e52483031
@@ -32,13 +32,19 @@ def dump(path, model, rays, background=(1.0, 1.0, 1.0), cos_anneal=1.0):
     cw, cb = packing.pack_color(d, prec, hints)
     inv_s = float(torch.exp(state["deviation_network.variance"] * 10.0).clip(1e-6, 1e6))
     blobs = [t.contiguous().cpu().numpy().tobytes() for t in (sw, sb, sh, cw, cb)]
+    wide = b""
+    if prec == 1 and getattr(model, "wide_kernels", True):
+        # f16x3: the streams and tables of the wide SDF kernels (NrhNet.sdf_w32 / sdf_tab32) behind the five classic buffers
+        w32, tab32 = packing32.pack_sdf32(d)
+        wide = w32.contiguous().cpu().numpy().tobytes() + tab32.contiguous().cpu().numpy().tobytes()
     o, dr, pl, near, far = (np.ascontiguousarray(a, dtype=np.float32) for a in rays)
     n = o.shape[0]
     with open(path, "wb") as f:
-        f.write(struct.pack("<10q", MAGIC, prec, int(hints), n, *[len(b) for b in blobs], 0))
+        f.write(struct.pack("<10q", MAGIC, prec, int(hints), n, *[len(b) for b in blobs], len(wide)))
         f.write(struct.pack("<2f", inv_s, cos_anneal))
         for b in blobs:
             f.write(b)
+        f.write(wide)
         for a in (o, dr, pl, near.reshape(-1), far.reshape(-1), np.asarray(background, dtype=np.float32),
                   torch.linspace(0.0, 1.0, 64).numpy(), torch.linspace(0.0, 1.0, 16).numpy()):
             f.write(np.ascontiguousarray(a, dtype=np.float32).tobytes())

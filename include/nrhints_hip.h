@@ -51,10 +51,6 @@ int nrh_mlp_grid(void);
  * nrh_kernel_timing_read: synchronises those events, returns their summed duration (ms) and count, and clears.
  * total_ms / launches are HOST pointers.  Not thread-safe; leave it off outside benchmarks. */
 int nrh_kernel_timing_select(int kind);
-/* Diagnosis builds only (-DNRH_TIMELINE=1, profiles/timeline.py): per-wave cycle totals of the four phases of an MLP
- * chunk (weight-DMA issue + epilogue loads, K loop, epilogue, barrier) of the last SDF kernel launch,
- * [workgroup][wave 8][counter 8] as unsigned 64-bit words copied to the HOST pointer.  NRH_E_UNSUPPORTED otherwise. */
-int nrh_debug_timeline_read(unsigned long long* out, int nwords);
 int nrh_kernel_timing_read(double* total_ms, long long* launches);
 
 /* ---- SDF network -------------------------------------------------------------------------------------------
@@ -69,6 +65,17 @@ int nrh_kernel_timing_read(double* total_ms, long long* launches);
 int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                  const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                  int sdf_stride, float* grad, float* feat, float* scratch, void* stream);
+
+/* The same evaluation by the "wide" f16x3 kernels (csrc/nrh_mlp32.h, nrh_sdf32.hip: 32-point tiles, one wavefront per SIMD,
+ * activations resident in AGPRs, v_mfma_f32_32x32x16_f16).  Same arithmetic class as precision 1, same outputs and layouts;
+ * different packed parameters:  sdf_w32 = the three per-mode chunk streams back to back (nrh_sdf_wide_stream_bytes() bytes of
+ * fp16 hi/lo pairs, nrhints_amd/packing32.py: pack_sdf32), sdf_tab32 = [11][256] float32 bias / head tables.
+ * scratch as for nrh_sdf_eval (the same buffer serves both).  NrhNet.sdf_w32 / sdf_tab32 select these kernels inside
+ * nrh_render_forward for every SDF evaluation of the evaluation path when precision is 1. */
+int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
+                      int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, float* feat,
+                      float* scratch, void* stream);
+long long nrh_sdf_wide_stream_bytes(void);
 
 /* ---- SDF network, training --------------------------------------------------------------------------------
  * The reference differentiates d(sdf)/dp a second time with autograd (create_graph=True, fields/sdf_field.py:145;
@@ -191,6 +198,8 @@ typedef struct NrhNet {
   const float* dyn_scalars; /* optional DEVICE [inv_s, cos_anneal]: when non-null it overrides `inv_s` above and the `cos_anneal`
                                argument of the render calls, read by the kernels at run time - a captured hipGraph of a
                                training step then follows the changing variance parameter and anneal schedule */
+  const void* sdf_w32;      /* optional: packed streams of the wide f16x3 SDF kernels (see nrh_sdf_eval_wide); when both are   */
+  const float* sdf_tab32;   /* non-null and precision is 1, the evaluation path uses them for every SDF evaluation            */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

@@ -21,13 +21,14 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_backward",
-            "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_debug_timeline_read")
+            "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes")
 
 
 class NrhNet(Structure):
     _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
-                ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p)]
+                ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
+                ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p)]
 
 
 class NrhTrainSaves(Structure):
@@ -74,7 +75,8 @@ def load():
     PP = POINTER(c_void_p)
     lib.nrh_weight_norm_fold.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, P]
     lib.nrh_weight_norm_fold_backward.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, PP, PP, P]
-    lib.nrh_debug_timeline_read.argtypes = [POINTER(ctypes.c_ulonglong), c_int]
+    lib.nrh_sdf_eval_wide.argtypes = [c_int, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
+    lib.nrh_sdf_wide_stream_bytes.restype = c_longlong
     lib.nrh_sampler_step.argtypes = [P, P, P, P, P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, c_int,
                                      c_int, c_int, P]
     lib.nrh_color_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, P, P, c_longlong, P, P]
@@ -121,6 +123,17 @@ def ptr(t, dtype=None):
     return c_void_p(t.data_ptr())
 
 
-def stream_handle():
+def stream_handle(device=None):
+    """Current HIP stream of ``device`` (default: the current device).  The library caches per-device state by the CURRENT
+    device id, so callers working on another GPU wrap their calls in ``torch.cuda.device(tensor.device)``."""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True):
+    """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params)."""
+    w32 = pk.get("sdf_w32") if wide else None
+    return NrhNet(ptr(pk["sdf_w"], pk["sdf_w"].dtype), ptr(pk["sdf_b"]), ptr(pk["sdf_head"]),
+                  ptr(pk["col_w"], pk["col_w"].dtype), ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
+                  hints, normal_type, depth_type, ptr(dyn_scalars),
+                  ptr(w32, w32.dtype) if w32 is not None else None, ptr(pk.get("sdf_tab32")) if w32 is not None else None)

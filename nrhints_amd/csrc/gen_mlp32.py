@@ -289,12 +289,16 @@ def gen_swap():
 
 
 def gen_t7():
-    """t_7 = (1 - q_7) * a8 written straight into `in`: W32_A8(c) -> f32x16 (w_s / 3 in D32 layout), W32_QLOAD7(c, half)."""
+    """t_7 = (1 - q_7) * a8 written straight into `in`: W32_A8(c) -> f32x16 (w_s / 3 in D32 layout), W32_QLOAD7(c, half).
+    All 16 loads go out first (64 VGPRs, nothing else is live here): one exposed L2 latency instead of eight."""
     out = ["// generated by gen_mlp32.py: T7 pass", "{"]
+    for c in range(8):
+        out.append(f"  const nrh32::u32x4 q{c}a = W32_QLOAD7({c}, 0), q{c}b = W32_QLOAD7({c}, 1);")
+    out.append("  __builtin_amdgcn_sched_barrier(0);")
     for c in range(8):
         out.append(f"  {{  // chunk {c}")
         out.append(f"    const nrh32::f32x16 a8 = W32_A8({c});")
-        out.append(f"    const nrh32::u32x4 qw0 = W32_QLOAD7({c}, 0), qw1 = W32_QLOAD7({c}, 1);")
+        out.append(f"    const nrh32::u32x4 qw0 = q{c}a, qw1 = q{c}b;")
         ops = []
         for r in range(16):
             w = f"qw{r // 8}[{(r % 8) // 2}]"

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/nrhints_hip.h"
+#include "nrh_wide.h"
 
 namespace {
 
@@ -32,17 +33,27 @@ int check_launch(const char* what) {
   return NRH_OK;
 }
 
-int g_cus = 0;
-bool g_attr_done = false;
+// Per-device caches, indexed by the CURRENT device id (the caller makes the tensors' device current; nrhints_amd/_lib.py does).
+// Plain ints / bools written with the same value by every thread that races on them: idempotent, no lock needed.
+constexpr int MAX_DEVICES = 64;
+int g_cus[MAX_DEVICES] = {};
+bool g_attr_done[MAX_DEVICES] = {};
+
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return -1;
+  return dev;
+}
 
 int device_cus() {
-  if (g_cus == 0) {
-    int dev = 0;
+  const int dev = current_device();
+  if (dev < 0) return 0;
+  if (g_cus[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    g_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    g_cus[dev] = prop.multiProcessorCount;
   }
-  return g_cus;
+  return g_cus[dev];
 }
 
 int mlp_grid() {
@@ -51,7 +62,9 @@ int mlp_grid() {
 }
 
 int ensure_attrs() {
-  if (g_attr_done) return NRH_OK;
+  const int dev = current_device();
+  if (dev < 0) return fail(NRH_E_LAUNCH, "no HIP device%s", "");
+  if (g_attr_done[dev]) return NRH_OK;
   hipError_t e;
   const void* fns[] = {(const void*)nrh::sdf_kernel<0, 0>, (const void*)nrh::sdf_kernel<1, 0>, (const void*)nrh::sdf_kernel<2, 0>,
                        (const void*)nrh::sdf_kernel<0, 1>, (const void*)nrh::sdf_kernel<1, 1>, (const void*)nrh::sdf_kernel<2, 1>,
@@ -68,7 +81,7 @@ int ensure_attrs() {
   for (const void* f : fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
   if (e != hipSuccess) return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-  g_attr_done = true;
+  g_attr_done[dev] = true;
   return NRH_OK;
 }
 
@@ -91,9 +104,36 @@ void timing_end(hipStream_t st, TimedLaunch& t, bool on) {
   g_timed.push_back(t);
 }
 
+// wide f16x3 evaluation kernels (nrh_sdf32.hip): taken when the caller supplies their packed streams
+struct WideNet {
+  const void* streams = nullptr;
+  const float* tables = nullptr;
+};
+
 int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const float* head, const float* ro, const float* rd,
                   const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad,
-                  float* feat, float* scratch, hipStream_t st) {
+                  float* feat, float* scratch, hipStream_t st, const WideNet wide = WideNet()) {
+  if (prec == 1 && wide.streams && wide.tables) {
+    if (mode < 0 || mode > 2) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode must be 0, 1 or 2%s", "");
+    if (!ro || !rd || !t || !sdf) return fail(NRH_E_INVALID, "nrh_sdf_eval: null pointer%s", "");
+    if (mode >= 1 && (!grad || !scratch)) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode %s needs grad and scratch", mode == 1 ? "1" : "2");
+    if (mode == 2 && !feat) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode 2 needs feat%s", "");
+    if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray || sdf_stride < n_per_ray)
+      return fail(NRH_E_INVALID, "nrh_sdf_eval: bad n_per_ray/stride%s", "");
+    if (nrays == 0) return NRH_OK;
+    nrh32::WideSdfCall c;
+    c.mode = mode; c.streams = wide.streams; c.tables = wide.tables; c.ro = ro; c.rd = rd; c.t = t; c.sdf = sdf; c.grad = grad;
+    c.feat = feat; c.scratch = scratch; c.npts = nrays * n_per_ray; c.n_per_ray = n_per_ray; c.t_stride = t_stride;
+    c.sdf_stride = sdf_stride; c.max_grid = device_cus();
+    TimedLaunch tl;
+    bool timed;
+    timing_begin(mode, st, tl, timed);
+    const int wrc = nrh32::wide_sdf_launch(c, st);
+    timing_end(st, tl, timed);
+    if (wrc == -1) return fail(NRH_E_INVALID, "nrh_sdf_eval: too many points%s", "");
+    if (wrc) return fail(NRH_E_LAUNCH, "wide sdf kernel: no HIP device / attribute error%s", "");
+    return check_launch("sdf32_kernel");
+  }
   if (mode < 0 || mode > 2) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode must be 0, 1 or 2%s", "");
   if (prec < 0 || prec > 1) return fail(NRH_E_INVALID, "nrh_sdf_eval: precision must be 0 (f32) or 1 (f16x3)%s", "");
   if (!w || !b || !head || !ro || !rd || !t || !sdf) return fail(NRH_E_INVALID, "nrh_sdf_eval: null pointer%s", "");
@@ -183,8 +223,9 @@ int color_eval_impl(int prec, int hints, const float* w, const float* b, const f
 int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, float* s, float* znew, float* snew,
                 const float* lin16, const float* last_dist_ray, float last_dist, float* tmid, float* dists,
                 long long n, hipStream_t st) {
+  const WideNet wide{net->sdf_w32, net->sdf_tab32};
   int rc = sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, z, 128, 64, n, s, 128, nullptr, nullptr,
-                         nullptr, st);
+                         nullptr, st, wide);
   if (rc) return rc;
   for (int i = 0; i < 4; ++i) {
     nrh::StepArgs a;
@@ -199,7 +240,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
     const bool last = (i == 3);
     if (!last) {
       rc = sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, znew, 16, 16, n, snew, 16, nullptr, nullptr,
-                         nullptr, st);
+                         nullptr, st, wide);
       if (rc) return rc;
     }
     // launch B: merge (with sdf unless last); finalise after the last merge
@@ -214,7 +255,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 111; }
+int nrh_version(void) { return 120; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -234,18 +275,6 @@ int nrh_param_sizes(int* out) {
 int nrh_mlp_grid(void) { return mlp_grid(); }
 
 long long nrh_color_transposed_floats(int hints) { return nrh::colt_packed_floats(hints ? 8 : 4); }
-
-int nrh_debug_timeline_read(unsigned long long* out, int nwords) {
-#if NRH_TIMELINE
-  if (!out || nwords <= 0 || nwords > 1024 * 64) return fail(NRH_E_INVALID, "nrh_debug_timeline_read: bad arguments%s", "");
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nrh::g_timeline), (size_t)nwords * 8, 0, hipMemcpyDeviceToHost) != hipSuccess)
-    return fail(NRH_E_LAUNCH, "nrh_debug_timeline_read: copy failed%s", "");
-  return NRH_OK;
-#else
-  (void)out; (void)nwords;
-  return fail(NRH_E_UNSUPPORTED, "nrh_debug_timeline_read: library not built with -DNRH_TIMELINE=1%s", "");
-#endif
-}
 
 int nrh_kernel_timing_select(int kind) {
   if (kind < -1 || kind > 3) return fail(NRH_E_INVALID, "nrh_kernel_timing_select: kind must be -1..3%s", "");
@@ -278,6 +307,16 @@ int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b
   return sdf_eval_impl(precision, mode, sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat,
                        scratch, (hipStream_t)stream);
 }
+
+int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
+                      int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, float* feat,
+                      float* scratch, void* stream) {
+  if (!sdf_w32 || !sdf_tab32) return fail(NRH_E_INVALID, "nrh_sdf_eval_wide: null pointer%s", "");
+  return sdf_eval_impl(1, mode, nullptr, nullptr, nullptr, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat, scratch,
+                       (hipStream_t)stream, WideNet{sdf_w32, sdf_tab32});
+}
+
+long long nrh_sdf_wide_stream_bytes(void) { return nrh32::wide_sdf_stream_bytes_total(); }
 
 int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
@@ -589,7 +628,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
                                sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, stream);
   } else {
     rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n, sdf_c, 128,
-                       o_grad, ws_feat, scratch, st);
+                       o_grad, ws_feat, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
   }
   if (rc) return rc;
   {
@@ -617,7 +656,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
                      ws_dists_s, n, st);
     if (rc) return rc;
     rc = sdf_eval_impl(net->precision, 1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
-                       128, ws_grad_s, nullptr, scratch, st);
+                       128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
     if (rc) return rc;
   }
   {

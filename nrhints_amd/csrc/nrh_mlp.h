@@ -23,12 +23,8 @@
 
 namespace nrh {
 
-#ifndef NRH_TIMELINE
-#define NRH_TIMELINE 0        // diagnosis build: per-wave cycle totals of the four phases of a chunk (s_memtime), see profiles/
-#endif
 constexpr int WBUF_BYTES = 32768;          // one LDS weight buffer (2 ob x 16 kb x 1 KiB)
-constexpr int TIMELINE_BYTES = NRH_TIMELINE ? 8 * 8 * 8 : 0;   // 8 waves x 8 counters (u64) behind the weight ring
-constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES + TIMELINE_BYTES;
+constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES;
 // ---- tuning knobs (compile-time; profiles/README.md records what each was measured to do) ----
 #ifndef NRH_WG_WAVES
 #define NRH_WG_WAVES 8        // waves per workgroup = 16-point tiles sharing one weight stream (8: +6..24 % vs 4)
@@ -45,17 +41,10 @@ constexpr int MLP_LDS_BYTES = 2 * WBUF_BYTES + TIMELINE_BYTES;
 #ifndef NRH_PKRTZ
 #define NRH_PKRTZ 1           // v_cvt_pkrtz_f16_f32 for the hi/lo split (round-toward-zero hi, still exact hi+lo)
 #endif
-// ablation switches (WRONG RESULTS - timing experiments only, see profiles/README.md)
-#ifndef NRH_ABL
-#define NRH_ABL 0             // bit 0: no LDS-DMA, 1: no barrier, 2: no MFMA, 3: no ds_read of A (f16x3), 4: trivial epilogue
-#endif
 constexpr int WG_WAVES = NRH_WG_WAVES;
 constexpr int MLP_THREADS = 64 * WG_WAVES;  // one 16-point tile per wave
 constexpr int TILE_PTS = 16;
 
-#if NRH_TIMELINE
-__device__ unsigned long long g_timeline[1024 * 64];   // [workgroup][wave][counter]: issue, K loop, epilogue, barrier (cycles), chunks
-#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -63,7 +52,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Asynchronously copy `npieces` KiB (global, contiguous) into an LDS buffer; the waves of the workgroup interleave.
 __device__ __forceinline__ void dma_chunk(const float* __restrict__ src, char* dst_lds, int npieces, int wave,
                                           int lane) {
-  if (NRH_ABL & 1) return;
   for (int k = wave; k < npieces; k += WG_WAVES) {
     __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 256 + lane * 4), (lptr_t)(dst_lds + k * 1024), 16, 0, 0);
   }
@@ -179,15 +167,8 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
                                           int next_pieces, char* smem, int& par, const Act<PREC, KB>& in,
                                           const float* init, Pre&& pre, Epi&& epi, int wave, int lane) {
   constexpr int PIECES = 2 * KB;
-#if NRH_TIMELINE
-  unsigned long long* tl = reinterpret_cast<unsigned long long*>(smem + 2 * WBUF_BYTES) + wave * 8;
-  auto tl_add = [&](int k, unsigned long long dt) { if (lane == 0) __hip_atomic_fetch_add(tl + k, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-#endif
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-#if NRH_TIMELINE
-    const unsigned long long tl0 = __builtin_readcyclecounter();
-#endif
     // the other buffer receives the stage's next chunk, or the first chunk of whatever runs next, during this chunk
     char* nxt = smem + (par ^ 1) * WBUF_BYTES;
     if (ch + 1 < NCH) {
@@ -197,9 +178,6 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
     }
     asm volatile("" ::: "memory");  // the weight stream goes out first, then the epilogue's loads
     const auto pv = pre(ch);
-#if NRH_TIMELINE
-    const unsigned long long tl1 = __builtin_readcyclecounter();
-#endif
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (HAS_INIT) {
       acc0 = f32x4{init[ch * 8 + 0], init[ch * 8 + 1], init[ch * 8 + 2], init[ch * 8 + 3]};
@@ -235,7 +213,6 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
       constexpr int KS = KB / 2;
       const u32x4* A = reinterpret_cast<const u32x4*>(smem + par * WBUF_BYTES);
       auto ld = [&](int obi, int s, int part) {
-        if (NRH_ABL & 8) { u32x4 z = {(uint32_t)(obi + s), (uint32_t)part, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(z)); return z; }
         return A[((obi * KS + s) * 2 + part) * 64 + lane];
       };
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};  // cross terms, scaled by 2^11
@@ -260,16 +237,12 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
         const f16x8 bh = __builtin_bit_cast(f16x8, bhu), bl = __builtin_bit_cast(f16x8, blu);
         const f16x8 ah0 = __builtin_bit_cast(f16x8, ra[c][0]), al0 = __builtin_bit_cast(f16x8, ra[c][1]);
         const f16x8 ah1 = __builtin_bit_cast(f16x8, ra[c][2]), al1 = __builtin_bit_cast(f16x8, ra[c][3]);
-        if (NRH_ABL & 4) {
-          asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(ah0), "v"(ah1), "v"(al0), "v"(al1), "v"(bh), "v"(bl));
-        } else {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, c1, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c1, 0, 0, 0);
-        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, c1, 0, 0, 0);
 #if NRH_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -277,18 +250,8 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
       acc0 += c0 * LO_UNSCALE;
       acc1 += c1 * LO_UNSCALE;
     }
-#if NRH_TIMELINE
-    asm volatile("" : "+v"(acc0), "+v"(acc1));   // the K loop's results exist before the stamp
-    const unsigned long long tl2 = __builtin_readcyclecounter();
     epi(ch, acc0, acc1, pv);
-    const unsigned long long tl3 = __builtin_readcyclecounter();
-    if (!(NRH_ABL & 2)) __syncthreads();
-    const unsigned long long tl4 = __builtin_readcyclecounter();
-    tl_add(0, tl1 - tl0); tl_add(1, tl2 - tl1); tl_add(2, tl3 - tl2); tl_add(3, tl4 - tl3); tl_add(4, 1);
-#else
-    epi(ch, acc0, acc1, pv);
-    if (!(NRH_ABL & 2)) __syncthreads();  // the next chunk's weights are in LDS for every wave past this point
-#endif
+    __syncthreads();  // the next chunk's weights are in LDS for every wave past this point
     par ^= 1;
   }
 }

@@ -114,9 +114,6 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
   float* const scr = (MODE == 1 || MODE == 2) ? a.scratch + (size_t)(blockIdx.x * WG_WAVES + wave) * SDF_SCRATCH_FLOATS_PER_WAVE : nullptr;
   constexpr bool WANT_D = MODE >= 1;
 
-#if NRH_TIMELINE
-  if (threadIdx.x < 64) reinterpret_cast<unsigned long long*>(smem + 2 * WBUF_BYTES)[threadIdx.x] = 0ull;
-#endif
   dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
   __syncthreads();
 
@@ -376,11 +373,6 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
       }
     }
   }
-#if NRH_TIMELINE
-  __syncthreads();
-  if (threadIdx.x < 64 && blockIdx.x < 1024)
-    g_timeline[blockIdx.x * 64 + threadIdx.x] = reinterpret_cast<unsigned long long*>(smem + 2 * WBUF_BYTES)[threadIdx.x];
-#endif
 }
 
 }  // namespace nrh

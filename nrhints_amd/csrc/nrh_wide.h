@@ -1,0 +1,22 @@
+// Host-side interface between nrh_api.hip and the separately compiled wide-kernel translation unit (nrh_wide.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrh32 {
+
+struct WideSdfCall {
+  int mode;                 // 0 sdf | 1 + gradient | 2 + feature tiles
+  const void* streams;      // packing32.pack_sdf32: the three mode streams back to back
+  const float* tables;      // [11][256]
+  const float *ro, *rd, *t;
+  float *sdf, *grad, *feat;
+  void* scratch;            // >= wide_sdf_scratch_bytes(max_grid) bytes (modes 1, 2)
+  long long npts;
+  int n_per_ray, t_stride, sdf_stride;
+  int max_grid;             // workgroups (one per CU)
+};
+int wide_sdf_launch(const WideSdfCall& c, hipStream_t st);   // 0 ok, -1 invalid, -2 launch/device error
+long long wide_sdf_stream_bytes_total();
+long long wide_sdf_scratch_bytes(int grid);
+
+}  // namespace nrh32

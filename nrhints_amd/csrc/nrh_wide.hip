@@ -1,0 +1,42 @@
+// Translation unit of the wide (32-point tile, one wave per SIMD) f16x3 kernels.  Built separately from nrh_api.hip because
+// these kernels need their own code generation flags (-fno-slp-vectorize: no packed f32 VALU beside MFMAs;
+// -mllvm -amdgpu-mfma-vgpr-form: accumulators in arch VGPRs, the AGPR file belongs to the hand-placed B operands).
+#include "nrh_sdf32.hip"
+#include "nrh_wide.h"
+
+namespace nrh32 {
+
+static bool g_attr[16] = {};   // per device id: dynamic-LDS attribute set (idempotent; a race sets it twice)
+
+int wide_sdf_launch(const WideSdfCall& c, hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -2;
+  if (dev >= 0 && dev < 16 && !g_attr[dev]) {
+    const void* fns[3] = {(const void*)sdf32_kernel<0>, (const void*)sdf32_kernel<1>, (const void*)sdf32_kernel<2>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -2;
+    g_attr[dev] = true;
+  }
+  Sdf32Args a;
+  long long off = 0;
+  for (int m = 0; m < c.mode; ++m) off += sdf32_stream_bytes(m);
+  a.w = reinterpret_cast<const char*>(c.streams) + off;
+  a.tab = c.tables; a.ro = c.ro; a.rd = c.rd; a.t = c.t; a.sdf = c.sdf; a.grad = c.grad; a.feat = c.feat;
+  a.scratch = reinterpret_cast<uint32_t*>(c.scratch);
+  a.npts = c.npts; a.n_per_ray = c.n_per_ray; a.t_stride = c.t_stride; a.sdf_stride = c.sdf_stride;
+  const long long groups = (c.npts + GROUP - 1) / GROUP;
+  if (groups > 0x7fffffffLL) return -1;
+  a.ngroups = (int)groups;
+  a.dbg = nullptr; a.dbg_stage = 99;
+  const int grid = (int)(groups < c.max_grid ? groups : c.max_grid);
+  if (grid <= 0) return -2;
+  if (c.mode == 0) hipLaunchKernelGGL(sdf32_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
+  else if (c.mode == 1) hipLaunchKernelGGL(sdf32_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(sdf32_kernel<2>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
+  return 0;
+}
+
+long long wide_sdf_stream_bytes_total() { return sdf32_stream_bytes(0) + sdf32_stream_bytes(1) + sdf32_stream_bytes(2); }
+long long wide_sdf_scratch_bytes(int grid) { return (long long)grid * WAVES * SCRATCH_WORDS_PER_WAVE * 4; }
+
+}  // namespace nrh32

@@ -55,15 +55,23 @@ def _cols(ks: int) -> torch.Tensor:
     return 16 * s + (i & 3) + 8 * (i >> 2) + 4 * hf
 
 
-def pack_stage32(w: torch.Tensor, rows: int, ks: int) -> torch.Tensor:
-    """Dense [out, in] (zero-padded to [rows, 16 ks]) -> fp16 [rows/32 chunks][ks][2][64][8] flattened."""
-    assert rows % 32 == 0 and w.shape[0] <= rows and w.shape[1] <= 16 * ks
-    wp = torch.nn.functional.pad(w.detach().float(), (0, 16 * ks - w.shape[1], 0, rows - w.shape[0]))
+def _layout32(wp: torch.Tensor, rows: int, ks: int) -> torch.Tensor:
+    """Element order of ONE part (hi or lo) of a stage: [chunk][s][lane = 32 hf + row][i]; wp is [rows, 16 ks]."""
     g = wp[:, _cols(ks).to(wp.device)]                    # [rows, ks, 2, 8]
-    g = g.reshape(rows // 32, 32, ks, 2, 8).permute(0, 2, 3, 1, 4)      # [chunk, s, hf, row, i]; lane = 32 hf + row
-    g = g.reshape(rows // 32, ks, 64, 8)
-    hi, lo = split_f16(g)
-    return torch.stack([hi, lo], dim=2).reshape(-1)       # [chunk, s, part, lane, i]
+    return g.reshape(rows // 32, 32, ks, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+
+def _pad(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    assert w.shape[0] <= rows and w.shape[1] <= cols
+    return torch.nn.functional.pad(w, (0, cols - w.shape[1], 0, rows - w.shape[0]))
+
+
+def pack_stage32(w: torch.Tensor, rows: int, ks: int) -> torch.Tensor:
+    """Dense [out, in] (zero-padded to [rows, 16 ks]) -> fp16 [rows/32 chunks][ks][hi | lo][64][8] flattened."""
+    assert rows % 32 == 0
+    lay = _layout32(_pad(w.detach().float(), rows, 16 * ks), rows, ks)
+    hi, lo = split_f16(lay)
+    return torch.stack([hi.reshape(-1, 512), lo.reshape(-1, 512)], dim=1).reshape(-1)
 
 
 def sdf32_tables(d: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -79,25 +87,35 @@ def sdf32_tables(d: Dict[str, torch.Tensor]) -> torch.Tensor:
     return torch.stack(rows).contiguous()
 
 
-def sdf32_pieces(d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    f = lambda t: t.detach().float()
-    w = [f(d[f"sdf_w{l}"]) for l in range(8)]
-    r2 = math.sqrt(2.0)
-    w4m = torch.nn.functional.pad(w[4][:, :217] / r2, (0, 39))      # main part of layer 4: columns 217.. are zero
-    w4e = w[4][:, 217:256] / r2                                    # skip part: applied to the 39 embedding entries
+_SDF32_KEYS = [f"sdf_w{l}" for l in range(8)] + ["feat_w", "sdf_head_w"]
+
+
+def _stage_matrices(d: Dict[str, torch.Tensor], scaled: bool):
+    """name -> (dense [rows, 16 ks] matrix, rows, ks) of every stage, from the folded weights d.  scaled = False leaves out
+    every multiplication (used to lay out element indices); the scale factors are recovered by feeding all-ones."""
+    sc = (lambda t, k: t * k) if scaled else (lambda t, k: t)
+    w = [d[f"sdf_w{l}"] for l in range(8)]
+    r2 = 1.0 / math.sqrt(2.0)
+    # (one multiplication per element everywhere, so that the index plan below reproduces the direct packer bit for bit)
+    w4m = _pad(sc(w[4][:, :217], r2), 256, 256)                     # main part of layer 4: columns 217.. are zero
+    w4e_raw = w[4][:, 217:256]                                      # skip part: applied to the 39 embedding entries
+    w4e = sc(w4e_raw, r2)
     fwd = [w[0], w[1], w[2], w[3], w4m, w[5], w[6], w[7]]
-    p = {}
-    p["E4"] = pack_stage32(w4e * IK, 256, 3)                     # 6 KiB chunks, resident
-    p["L0"] = pack_stage32(w[0] * IK, 256, SMALL_KS)            # 8 KiB chunks (4 K steps stored, 3 used): 2 blocks
+    m = {"E4": (sc(w4e_raw, r2 * IK), 256, 3), "L0": (sc(w[0], IK), 256, SMALL_KS)}
     for l in range(1, 8):
-        p[f"L{l}"] = pack_stage32(fwd[l], 256, BIG_KS)
-    p["FEAT"] = pack_stage32(f(d["feat_w"]) * KK, 256, BIG_KS)
-    p["HEAD"] = pack_stage32(f(d["sdf_head_w"]).reshape(1, 256) * (KK / 3.0), 32, BIG_KS)
+        m[f"L{l}"] = (fwd[l], 256, BIG_KS)
+    m["FEAT"] = (sc(d["feat_w"], KK), 256, BIG_KS)
+    m["HEAD"] = (sc(d["sdf_head_w"].reshape(1, 256), KK / 3.0), 32, BIG_KS)
     for l in range(1, 8):
-        p[f"R{l}"] = pack_stage32(fwd[l].t(), 256, BIG_KS)
-    p["R4e"] = pack_stage32(w4e.t(), 64, BIG_KS)
-    p["R0"] = pack_stage32(w[0].t(), 64, BIG_KS)
-    return p
+        m[f"R{l}"] = (fwd[l].t(), 256, BIG_KS)
+    m["R4e"] = (w4e.t(), 64, BIG_KS)
+    m["R0"] = (w[0].t(), 64, BIG_KS)
+    return m
+
+
+def sdf32_pieces(d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    f = {k: d[k].detach().float() for k in _SDF32_KEYS}
+    return {k: pack_stage32(w, rows, ks) for k, (w, rows, ks) in _stage_matrices(f, True).items()}
 
 
 def stream_order(mode: int):
@@ -123,3 +141,36 @@ def pack_sdf32(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def stream_offset_bytes(mode: int) -> int:
     return sum(stream_bytes(m) for m in range(mode))
+
+
+class PackPlan32:
+    """Index form of pack_sdf32: the packers are index permutations plus constant factors, so they run ONCE on element
+    indices and on all-ones; afterwards a re-pack is one gather, one multiply and the fp16 split (a training step
+    re-packs after every optimiser step, also inside a captured hipGraph: no host data, no new index tensors)."""
+
+    def __init__(self, d: Dict[str, torch.Tensor]):
+        dev = d["sdf_w0"].device
+        self.shapes = {k: tuple(d[k].shape) for k in _SDF32_KEYS}
+        idx, ones, off = {}, {}, 1
+        for k in _SDF32_KEYS:
+            n = int(torch.tensor(self.shapes[k]).prod())
+            idx[k] = (torch.arange(n, dtype=torch.float64) + off).reshape(self.shapes[k])
+            ones[k] = torch.ones(self.shapes[k], dtype=torch.float64)
+            off += n
+        mi, ms = _stage_matrices(idx, False), _stage_matrices(ones, True)
+        lay = lambda m, k: _layout32(_pad(m[k][0], m[k][1], 16 * m[k][2]), m[k][1], m[k][2])
+        order = [k for mode in range(3) for k in stream_order(mode)]
+        self.index = torch.cat([lay(mi, k) for k in order]).to(torch.int64).to(dev)
+        self.scale = torch.cat([lay(ms, k) for k in order]).to(torch.float32).to(dev)
+        assert self.index.numel() * 4 == sum(stream_bytes(m) for m in range(3))
+
+    def matches(self, d) -> bool:
+        return all(tuple(d[k].shape) == self.shapes[k] for k in _SDF32_KEYS) and d["sdf_w0"].device == self.index.device
+
+    def pack(self, d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        dev = self.index.device
+        flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=dev)] +
+                         [d[k].detach().to(torch.float32).reshape(-1) for k in _SDF32_KEYS])
+        hi, lo = split_f16(flat[self.index] * self.scale)
+        streams = torch.stack([hi.reshape(-1, 512), lo.reshape(-1, 512)], dim=1).reshape(-1)
+        return streams, sdf32_tables(d)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib, autograd_core, packing
+from . import _lib, autograd_core, packing, packing32
 from .config import DepthComputationType, NeuSModelConfig, NormalComputationType, unsupported_reason
 from .containers import RayBundle, RenderOutput
 
@@ -105,6 +105,7 @@ class NeuSHintRenderer(nn.Module):
     #: matrix arithmetic of the MLP kernels: "f32" (v_mfma_f32_16x16x4_f32, exact fp32) or "f16x3" (three
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
     precision = "f16x3"
+    wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
     # backward of (sdf, feat, d sdf/dx): "manual" = hand-derived sweeps in torch ops, "hip" = the same sweeps in the HIP
     # register-chain kernels (forward included), "autograd" = second-order autograd graph like the reference (A/B only)
     sdf_backward = "hip"
@@ -137,6 +138,7 @@ class NeuSHintRenderer(nn.Module):
                                                 config.reflectance_network, n_cue, self.has_shadow_hint)
         self._packed = None
         self._pack_plan = None
+        self._pack_plan32 = None
         self._packed_key = None
         self._ws = {}
         self._consts = {}
@@ -170,6 +172,12 @@ class NeuSHintRenderer(nn.Module):
                         packing.check_default_shapes(d, hints)
                         self._pack_plan = packing.PackPlan(d, prec, hints)
                     bufs = self._pack_plan.pack(d)
+                if prec == 1:
+                    # the wide f16x3 evaluation kernels (csrc/nrh_sdf32.hip) read their own streams: every SDF evaluation
+                    # of the no-grad stages goes through them (samplers, shadow march, render_core at evaluation)
+                    if self._pack_plan32 is None or not self._pack_plan32.matches(d):
+                        self._pack_plan32 = packing32.PackPlan32(d)
+                    bufs["sdf_w32"], bufs["sdf_tab32"] = self._pack_plan32.pack(d)
                 if self.dyn_scalars is not None:      # no host sync: the kernels read inv_s from the device
                     self.dyn_scalars[0:1].copy_(torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(1))
                     inv_s = float("nan")
@@ -286,9 +294,7 @@ class NeuSHintRenderer(nn.Module):
         n = o.shape[0]
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
-        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
-                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
-                          self._hints, self._normal_type, self._depth_type, _lib.ptr(self.dyn_scalars))
+        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
@@ -319,9 +325,7 @@ class NeuSHintRenderer(nn.Module):
         n = o.shape[0]
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
-        net = _lib.NrhNet(_lib.ptr(pk["sdf_w"], pk["sdf_w"].dtype), _lib.ptr(pk["sdf_b"]), _lib.ptr(pk["sdf_head"]),
-                          _lib.ptr(pk["col_w"], pk["col_w"].dtype), _lib.ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
-                          self._hints, self._normal_type, self._depth_type, _lib.ptr(self.dyn_scalars))
+        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))

@@ -1,0 +1,120 @@
+"""GPU parity of the wide f16x3 SDF kernels (csrc/nrh_sdf32.hip: 32-point tiles, one wave per SIMD, AGPR-resident activations)
+through the C ABI (nrh_sdf_eval_wide): against the fp64 oracle, the golden fixtures the imported reference produced, and the
+16-point kernels on the same inputs.  Tolerances are float32 ones, written next to each assertion."""
+import numpy as np
+import pytest
+import torch
+
+import nrhints_amd as na
+from nrhints_amd import ops, packing as pk
+from nrhints_amd.synthetic import make_rays
+from oracle import neus_oracle as orc
+from tests.conftest import load_npz
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def cu(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).float().contiguous().cuda()
+
+
+@pytest.fixture(scope="module", params=["a", "b"])
+def wscene(request, scene_states):
+    st = scene_states[request.param]
+    model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision="f16x3")
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+    model = model.cuda().eval()
+    packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()))
+    assert packed["sdf_w32"].dtype == torch.float16 and packed["sdf_tab32"].shape == (11, 256)
+    return request.param, model, packed, orc.params_from_state(st, torch.float64)
+
+
+def _at_points(mode, packed, pts):
+    zeros = torch.zeros_like(pts)
+    t = torch.zeros(pts.shape[0], dtype=torch.float32, device=pts.device)
+    return ops.sdf_eval_wide(mode, packed["sdf_w32"], packed["sdf_tab32"], pts.contiguous(), zeros, t, 1)
+
+
+@pytest.mark.parametrize("npts", [1, 31, 33, 128, 129, 1000, 4096 + 5, 40000])
+def test_wide_sdf_modes_vs_oracle(wscene, npts):
+    tag, model, packed, p64 = wscene
+    g = torch.Generator().manual_seed(npts)
+    pts = (torch.rand(npts, 3, generator=g) * 2 - 1) * 0.95
+    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, pts.double())
+    for mode in (0, 1, 2):
+        sdf, grad, feat = _at_points(mode, packed, pts.cuda())
+        # fp16 hi/lo products, fp32 accumulation, 8 layers of K = 256: same class as the fp32 chain (measured 8e-7)
+        np.testing.assert_allclose(sdf.cpu().numpy()[:, 0], o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
+        if mode >= 1:
+            # unorm16 sigma' hand-off (7.6e-6 per layer) dominates; gradient magnitude ~1 (scene b up to ~3)
+            np.testing.assert_allclose(grad.cpu().numpy(), o_grad.numpy(), rtol=0, atol=1e-4 if tag == "a" else 5e-4)
+        if mode == 2:
+            f = pk.feat_tiles_to_rows(feat.cpu(), npts).numpy()
+            np.testing.assert_allclose(f, o_feat.numpy(), rtol=0, atol=3e-5)
+
+
+def test_wide_sdf_golden_fixture(wscene):
+    """Directly against what the imported reference produced (tests/golden/unit_*.npz)."""
+    tag, model, packed, _ = wscene
+    u = load_npz(f"unit_{tag}.npz")
+    sdf, grad, feat = _at_points(2, packed, cu(u["sdf_pts"]))
+    P = u["sdf_pts"].shape[0]
+    out = np.concatenate([sdf.cpu().numpy(), pk.feat_tiles_to_rows(feat.cpu(), P).numpy()], axis=1)
+    np.testing.assert_allclose(out, u["sdf_out_f64"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(out, u["sdf_out"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), u["sdf_grad_f64"], rtol=0, atol=1e-4 if tag == "a" else 5e-4)
+
+
+def test_wide_sdf_along_rays_strided(wscene):
+    """Ray-parametrised points with a row stride (the sampler's calling convention, 16 and 24 samples per ray)."""
+    tag, model, packed, p64 = wscene
+    o, d, pl, near, far = make_rays(50, seed=5, spread=0.1)
+    for nper in (16, 24):
+        z = np.zeros((50, 128), np.float32)
+        z[:, :nper] = near + (far - near) * np.linspace(0, 1, nper, dtype=np.float32)[None]
+        sdf, _, _ = ops.sdf_eval_wide(0, packed["sdf_w32"], packed["sdf_tab32"], cu(o), cu(d), cu(z), nper, t_stride=128)
+        pts = (T(o)[:, None] + T(d)[:, None] * T(z[:, :nper])[..., None]).reshape(-1, 3)
+        ref = orc.sdf_forward(p64, pts.double(), False)[0].reshape(50, nper)
+        np.testing.assert_allclose(sdf.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-6)
+
+
+def test_wide_matches_16_point_kernels(wscene):
+    """Same inputs through both f16x3 kernel families: two independent code paths, agreement at the float32 level."""
+    tag, model, packed, _ = wscene
+    g = torch.Generator().manual_seed(7)
+    pts = ((torch.rand(3000, 3, generator=g) * 2 - 1) * 0.9).cuda()
+    s32, g32, f32 = _at_points(2, packed, pts)
+    s16, g16, f16 = ops.sdf_at_points(2, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], pts)
+    np.testing.assert_allclose(s32.cpu().numpy(), s16.cpu().numpy(), rtol=0, atol=4e-6)
+    np.testing.assert_allclose(g32.cpu().numpy(), g16.cpu().numpy(), rtol=0, atol=2e-4 if tag == "a" else 8e-4)
+    np.testing.assert_allclose(f32.cpu().numpy(), f16.cpu().numpy(), rtol=0, atol=3e-5)
+
+
+def test_wide_deterministic_and_repeatable(wscene):
+    tag, model, packed, _ = wscene
+    g = torch.Generator().manual_seed(11)
+    pts = ((torch.rand(5000, 3, generator=g) * 2 - 1) * 0.9).cuda()
+    a = _at_points(2, packed, pts)
+    b = _at_points(2, packed, pts)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_render_wide_vs_16_point(wscene):
+    """The whole evaluation render with the SDF network on the wide kernels vs on the 16-point kernels."""
+    tag, model, packed, _ = wscene
+    o, d, pl, near, far = make_rays(300, seed=3, spread=0.1)
+    rb = na.RayBundle(origins=cu(o), directions=cu(d), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+    bg = torch.ones(1, 3, device="cuda")
+    with torch.no_grad():
+        model.wide_kernels = True
+        a = model(rb, is_training=False, background_rgb=bg)
+        model.wide_kernels = False
+        b = model(rb, is_training=False, background_rgb=bg)
+        model.wide_kernels = True
+    # both are fp32-class evaluations of the same network; the inverse-CDF sampler amplifies last-bit differences of the
+    # sdf at isolated samples (see test_gpu_parity.py), rgb stays at the reference's own fp32-vs-fp64 noise
+    assert float((a.rgb - b.rgb).abs().max()) < 5e-5
+    assert float((a.depth - b.depth).abs().max()) < 3e-4
+    assert float((a.visibilities - b.visibilities).abs().max()) < 3e-3

@@ -22,7 +22,10 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 111
+    assert lib.nrh_version() == 120
+    lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
+    from nrhints_amd import packing32 as pk32
+    assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
     sizes = (ctypes.c_int * 8)()
     assert lib.nrh_param_sizes(sizes) == 0
     assert sizes[7] in (4, 8)
@@ -212,9 +215,8 @@ def test_training_entry_points_validate_arguments_without_a_device():
     IntArr, PtrArr = ctypes.c_int * 1, ctypes.c_void_p * 1
     assert lib.nrh_weight_norm_fold(0, IntArr(4), IntArr(4), PtrArr(16), PtrArr(16), PtrArr(16), None) == -1
     assert lib.nrh_weight_norm_fold(1, IntArr(4), IntArr(1000), PtrArr(16), PtrArr(16), PtrArr(16), None) == -1 and "384" in err()
-    # diagnosis hook is compiled out of the product build
-    buf = (ctypes.c_ulonglong * 8)()
-    assert lib.nrh_debug_timeline_read(buf, 8) == -4 and "NRH_TIMELINE" in err()
+    # the wide-kernel entry validates its pointers before touching a device
+    assert lib.nrh_sdf_eval_wide(0, None, None, None, None, None, 1, 1, 1, None, 1, None, None, None, None) == -1 and "null" in err()
     assert lib.nrh_color_transposed_floats(1) == 303104 and lib.nrh_color_transposed_floats(0) == 286720
 
 
