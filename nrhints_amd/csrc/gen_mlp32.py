@@ -53,7 +53,7 @@ def split_ops(i, v0, v1, out_hi, out_lo, pfx=""):
     return ops
 
 
-def epi_fwd(c, hp, cp, want_d, out_base=128):
+def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE"):
     """Forward epilogue of chunk c: t (bias is in the accumulator) -> u = log2(1 + 2^t) -> hi/lo -> out; q = 1/(1+2^t)."""
     ops = []
     for i in range(8):
@@ -74,7 +74,7 @@ def epi_fwd(c, hp, cp, want_d, out_base=128):
                           uses=(f"q{2 * i}", f"q{2 * i + 1}")))
             if i % 4 == 3:
                 w = [f"qq{i - 3 + k}" for k in range(4)]
-                ops.append(Op(f"W32_QSTORE({c}, {i // 4}, (nrh32::u32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
+                ops.append(Op(f"{qstore}({c}, {i // 4}, (nrh32::u32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
     return ops
 
 
@@ -134,8 +134,9 @@ class Window:
     b_src 'agpr': B operands are a[4s..] / a[64+4s..];  'vgpr': u32x4 expressions (bh(s), bl(s)) given by name pattern.
     hh_init: name of an f32x16 holding the start values (compiler-visible LDS loads), or None for zero."""
 
-    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa", cd=None, use_ds=True):
+    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa", cd=None, use_ds=True, in_base=0):
         self.ks, self.hh, self.cc, self.b_src, self.bvar, self.hh_zero, self.pf, self.wa = ks, hh, cc, b_src, bvar, hh_zero, pf, wa
+        self.in_base = in_base  # AGPR set holding the B operands: 0 (a[0:127]) or 128 (a[128:255])
         self.cd = cd            # third accumulator (A_lo * B_hi products) - no back-to-back dependent MFMAs; None: they go to cc
         self.use_ds = use_ds    # False: micro-benchmarks without LDS traffic (fragments stay whatever they are)
 
@@ -178,7 +179,7 @@ class Window:
                 bpart = 1 if j == 1 else 0   # j=1: A_hi * B_lo, j=2: A_lo * B_hi
                 pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j == 0 and self.use_ds) else ""
                 if self.b_src == "agpr":
-                    base = 4 * s + (64 if bpart else 0)
+                    base = self.in_base + 4 * s + (64 if bpart else 0)
                     bop, bcons = f"a[{base}:{base + 3}]", ""
                 else:
                     bop, bcons = "%2", f', "v"({self.bvar[bpart]}{s})'
@@ -203,79 +204,120 @@ class Window:
 DMA_SLOTS16 = {2 + 3 * k: [k] for k in range(8)}     # regular window: one piece of block n + 2 after the last MFMA of K steps 0..7
 
 
-def gen_stage(kind, want_d, ks, b_src, nv, hh_zero):
-    """A pipelined 8-chunk stage: window c runs the K loop of chunk c and the epilogue of chunk c - 1; drain at the end.
+def acc_names(c):
+    """accumulators of chunk c: chunk 7's are the stage's pending pair (hp, cp), consumed by the NEXT stage's window 0"""
+    return ("hp", "cp") if c == 7 else (f"hh{c}", f"cc{c}")
+
+
+def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pend_in=True):
+    """A pipelined 8-chunk stage, ping-pong form: B operands from AGPR set `in_base`, results into set `out_base`; no copy.
+    Window c runs the K loop of chunk c and the epilogue of chunk c - 1; window 0 runs the epilogue of the PREVIOUS stage's
+    chunk 7 (pending in hp, cp [, qpa, qpb]), whose outputs are this stage's K steps 14 and 15 - they are only read by the
+    last six MFMAs of each window.  Chunk 7 of this stage stays pending in (hp, cp) for whoever comes next.
     ks = 16: one 32 KiB block per chunk.  ks = 3 (layer 0): four chunks per block (8 KiB each), the block changes at c = 4.
     Hooks (macros of the including kernel): W32_SYNC(), W32_FETCH_SETUP(), W32_DMA(piece), W32_NEXT(), W32_WADDR(),
-    W32_HINIT(c) (f32x16 start values, unless hh_zero), W32_QSTORE(c, half, v), W32_QLOAD_ASM(dst, c, half)."""
+    W32_HINIT(c) (f32x16 start values, unless hh_zero), W32_QSTORE(c, half, v) (this stage's layer), W32_QSTORE_P (the
+    previous stage's layer), W32_QLOAD_ASM(dst, c, half)."""
     small = ks != 16
     out = []
-    out.append(f"// generated by gen_mlp32.py: stage kind={kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv}")
+    out.append(f"// generated by gen_mlp32.py: stage kind={kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv} in=a{in_base} out=a{out_base}")
     out.append("{")
-    for c in range(8):
+    for c in range(7):
         out.append(f"  nrh32::f32x16 hh{c}, cc{c};")
     if kind == "rev":
-        for c in range(8):
+        for c in range(7):
             out.append(f"  nrh32::u32x4 qa{c}, qb{c};")
-    for c in range(9):
-        out.append(f"  {{  // window {c}" if c < 8 else "  {  // drain")
+    qn = lambda c: ("qpa", "qpb") if c == 7 else (f"qa{c}", f"qb{c}")
+    for c in range(8):
+        out.append(f"  {{  // window {c}")
+        hh, cc = acc_names(c)
+        prev = (c - 1) % 8
+        ph, pc = acc_names(prev)
+        has_epi = (c > 0 or pend_in) and not os.environ.get("NRH32_NOEPI")
+        if not small or c % 4 == 0:
+            out.append("    W32_SYNC();")
+            out.append("    W32_FETCH_SETUP();")
+        if c == 0 and has_epi:
+            # window 0 consumes the pending pair (and q words) of the previous stage; window 7 redefines those names
+            out.append("    nrh32::f32x16 ph0 = hp, pc0 = cp;")
+            ph, pc = "ph0", "pc0"
+            if kind == "rev":
+                out.append("    nrh32::u32x4 pqa = qpa, pqb = qpb;")
         epi = None
-        if c > 0 and not os.environ.get("NRH32_NOEPI"):
+        if has_epi:
+            ob = out_base if c > 0 else in_base          # the previous stage's output set is this stage's input set
             if kind == "fwd":
-                epi = epi_fwd(c - 1, f"hh{c - 1}", f"cc{c - 1}", want_d)
+                epi = epi_fwd(prev, ph, pc, want_d, out_base=ob, qstore=("W32_QSTORE" if c > 0 else "W32_QSTORE_P"))
             else:
-                epi = epi_rev(c - 1, f"hh{c - 1}", f"cc{c - 1}")
-        if c < 8:
-            if not small or c % 4 == 0:
-                out.append("    W32_SYNC();")
-                out.append("    W32_FETCH_SETUP();")
+                epi = epi_rev(prev, ph, pc, out_base=ob)
+        if kind == "rev":
+            # asm loads: hipcc does not see them, so it never waits for them with vmcnt(0) (which would also drain the
+            # LDS-DMA pieces in flight); they are older than this window's 8 pieces: the next W32_SYNC covers them
+            qa, qb = qn(c)
+            out.append(f"    W32_QLOAD_ASM({qa}, {c}, 0); W32_QLOAD_ASM({qb}, {c}, 1);")
+        if not hh_zero:
+            out.append(f"    {hh} = W32_HINIT({c});")
+        out.append("    const uint32_t wa = W32_WADDR()" + (f" + {(c % 4) * 8192};" if small else ";"))
+        if epi is not None:
+            # the previous chunk's accumulators are read by VALU only from here on: >= 11 wait states after its last MFMA
+            out.append(f'    asm volatile("" : "+v"({ph}), "+v"({pc}));')
             if kind == "rev":
-                # asm loads: hipcc does not see them, so it never waits for them with vmcnt(0) (which would also drain the
-                # LDS-DMA pieces in flight); they are older than this window's 8 pieces: the next W32_SYNC covers them
-                out.append(f"    W32_QLOAD_ASM(qa{c}, {c}, 0); W32_QLOAD_ASM(qb{c}, {c}, 1);")
-            if not hh_zero:
-                out.append(f"    hh{c} = W32_HINIT({c});")
-            out.append("    const uint32_t wa = W32_WADDR()" + (f" + {(c % 4) * 8192};" if small else ";"))
-            if c > 0:
-                # the previous chunk's accumulators are read by VALU only from here on: >= 11 wait states after its last MFMA
-                out.append(f'    asm volatile("" : "+v"(hh{c - 1}), "+v"(cc{c - 1}));')
-            if kind == "rev" and c > 0:
-                out.append(f'    asm volatile("" : "+v"(qa{c - 1}), "+v"(qb{c - 1}));')
-                out.append(f"    const nrh32::u32x4 qw0 = qa{c - 1}, qw1 = qb{c - 1};")
-            win = Window(ks, f"hh{c}", f"cc{c}", b_src=b_src, hh_zero=hh_zero)
-            if small:
-                dma = {2: [2 * (c % 4)], 5: [2 * (c % 4) + 1]}
-            else:
-                dma = DMA_SLOTS16
-            if epi is not None:
-                budget = (lambda k: max(1, nv - 2) if k in dma else nv) if not small else nv
-                slots, tail = schedule(epi, max(3 * ks, (len(epi) + nv - 1) // nv + 8), budget)
-            else:
-                slots, tail = None, []
-            win.emit(out, slots, "    ", dma=dma)
-            if tail:
-                out.append("    // epilogue work that did not fit the MFMA shadows")
-                emit_ops(out, tail, "    ")
-            if not small or c % 4 == 3:
-                out.append("    W32_NEXT();")
+                pa, pb = ("pqa", "pqb") if c == 0 else qn(prev)
+                out.append(f'    asm volatile("" : "+v"({pa}), "+v"({pb}));')
+                out.append(f"    const nrh32::u32x4 qw0 = {pa}, qw1 = {pb};")
+        win = Window(ks, hh, cc, b_src=b_src, hh_zero=hh_zero, in_base=in_base)
+        if small:
+            dma = {2: [2 * (c % 4)], 5: [2 * (c % 4) + 1]}
         else:
-            # MFMA results -> VALU reads need 11 wait states; the asm carries the accumulators so that no read is scheduled above it
-            out.append(f'    asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh7), "+v"(cc7));')
-            if kind == "rev":
-                out.append('    asm volatile("s_waitcnt vmcnt(8)" : "+v"(qa7), "+v"(qb7));   // the q loads of window 7 (older than its 8 DMA pieces)')
-                out.append("    const nrh32::u32x4 qw0 = qa7, qw1 = qb7;")
-            if epi is not None:
-                emit_ops(out, epi, "    ")
+            dma = DMA_SLOTS16
+        if epi is not None:
+            w_nv = nv + 2 if (c == 0 and not small) else nv      # window 0: everything has to sit before K step 14 (slot 42)
+            budget = (lambda k: max(1, w_nv - 2) if k in dma else w_nv) if not small else w_nv
+            nslots = max(3 * ks, (len(epi) + w_nv - 1) // w_nv + 8)
+            if c == 0 and not small:
+                budget0 = budget
+                budget = lambda k: (budget0(k) if k < 41 else 0)
+            slots, tail = schedule(epi, nslots, budget)
+            assert not (c == 0 and not small and tail), "pending epilogue does not fit ahead of K step 14"
+        else:
+            slots, tail = None, []
+        win.emit(out, slots, "    ", dma=dma)
+        if tail:
+            out.append("    // epilogue work that did not fit the MFMA shadows")
+            emit_ops(out, tail, "    ")
+        if not small or c % 4 == 3:
+            out.append("    W32_NEXT();")
         out.append("  }")
+    # whoever comes next may copy the pending registers: only after the last MFMAs have landed
+    out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hp), "+v"(cp));')
     out.append("}")
     return "\n".join(out) + "\n"
 
 
-def gen_kloop(ks, b_src, hh_zero):
+def gen_finish(kind, want_d, out_base):
+    """The pending chunk 7 of the last stage of a chain, on its own (no K loop to hide under): outputs into set `out_base`."""
+    out = [f"// generated by gen_mlp32.py: finish kind={kind} want_d={want_d} out=a{out_base}", "{"]
+    if kind == "fwd":
+        epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P")
+    else:
+        out.append('  asm volatile("s_waitcnt vmcnt(8)" : "+v"(qpa), "+v"(qpb));   // the q loads of window 7 (older than its 8 DMA pieces)')
+        out.append("  const nrh32::u32x4 qw0 = qpa, qw1 = qpb;")
+        epi = epi_rev(7, "hp", "cp", out_base=out_base)
+    slots, tail = schedule(epi, (len(epi) + 7) // 8 + 8, 8)
+    for ops in slots:
+        if ops:
+            emit_ops(out, ops, "  ")
+            out.append("  __builtin_amdgcn_sched_barrier(0);")
+    assert not tail
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def gen_kloop(ks, b_src, hh_zero, in_base=128):
     """K loop only (no fillers): for the light stages whose epilogue is written by hand after it.  Needs hh, cc, wa; the
     16-step form consumes a streamed block and therefore also issues the 8 LDS-DMA pieces of block n + 2 (W32_DMA)."""
     out = [f"// generated by gen_mlp32.py: bare K loop ks={ks} b={b_src}", "{"]
-    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
+    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero, in_base=in_base).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
     out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh), "+v"(cc));   // MFMA results -> VALU reads: 11 wait states')
     out.append("}")
     return "\n".join(out) + "\n"
@@ -289,13 +331,13 @@ def gen_swap():
 
 
 def gen_t7():
-    """t_7 = (1 - q_7) * a8 written straight into `in`: W32_A8(c) -> f32x16 (w_s / 3 in D32 layout), W32_QLOAD7(c, half).
-    All 16 loads go out first (64 VGPRs, nothing else is live here): one exposed L2 latency instead of eight."""
+    """t_7 = (1 - q_7) * a8 written straight into AGPR set 0 (R7's input): W32_A8(c) -> f32x16 (w_s / 3 in D32 layout),
+    W32_QLOAD7(c, half).  All loads go out first (56 VGPRs, nothing else is live here): one exposed L2 latency, not seven."""
     out = ["// generated by gen_mlp32.py: T7 pass", "{"]
-    for c in range(8):
+    for c in range(7):
         out.append(f"  const nrh32::u32x4 q{c}a = W32_QLOAD7({c}, 0), q{c}b = W32_QLOAD7({c}, 1);")
     out.append("  __builtin_amdgcn_sched_barrier(0);")
-    for c in range(8):
+    for c in range(7):   # chunk 7 becomes the pending pair of the reverse chain (hp = a8, cp = 0, q words): R7's window 0 finishes it
         out.append(f"  {{  // chunk {c}")
         out.append(f"    const nrh32::f32x16 a8 = W32_A8({c});")
         out.append(f"    const nrh32::u32x4 qw0 = q{c}a, qw1 = q{c}b;")
@@ -329,18 +371,25 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     nv = int(os.environ.get("NRH32_NV", "4"))
     files = {
-        "fwd_d0.inc": gen_stage("fwd", False, 16, "agpr", nv, False),
-        "fwd_d1.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, False),
-        "l0_d0.inc": gen_stage("fwd", False, 3, "vgpr", 10, False),
-        "l0_d1.inc": gen_stage("fwd", True, 3, "vgpr", 10, False),
-        "rev.inc": gen_stage("rev", True, 16, "agpr", nv, True),
+        "l0_d0.inc": gen_stage("fwd", False, 3, "vgpr", 10, False, in_base=0, out_base=0, pend_in=False),
+        "l0_d1.inc": gen_stage("fwd", True, 3, "vgpr", 10, False, in_base=0, out_base=0, pend_in=False),
+        "fwd_d0_p0.inc": gen_stage("fwd", False, 16, "agpr", nv, False, in_base=0, out_base=128),
+        "fwd_d0_p1.inc": gen_stage("fwd", False, 16, "agpr", nv, False, in_base=128, out_base=0),
+        "fwd_d1_p0.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, False, in_base=0, out_base=128),
+        "fwd_d1_p1.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, False, in_base=128, out_base=0),
+        "fwd_fin_d0.inc": gen_finish("fwd", False, 128),
+        "fwd_fin_d1.inc": gen_finish("fwd", True, 128),
+        "rev_p0.inc": gen_stage("rev", True, 16, "agpr", nv, True, in_base=0, out_base=128),
+        "rev_p1.inc": gen_stage("rev", True, 16, "agpr", nv, True, in_base=128, out_base=0),
+        "rev_fin.inc": gen_finish("rev", True, 128),
         "kloop16.inc": gen_kloop(16, "agpr", False),
         "kloop16z.inc": gen_kloop(16, "agpr", True),
         "kloop3v.inc": gen_kloop(3, "vgpr", False),
-        "swap.inc": gen_swap(),
         "t7.inc": gen_t7(),
-        "dump_in.inc": gen_dump(),
     }
+    for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc"):
+        if os.path.exists(os.path.join(outdir, stale)):
+            os.remove(os.path.join(outdir, stale))
     for name, text in files.items():
         path = os.path.join(outdir, name)
         old = open(path).read() if os.path.exists(path) else None

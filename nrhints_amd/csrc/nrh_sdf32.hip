@@ -11,7 +11,7 @@
 //   HEAD   256 -> 1 (row 0 of a 32-row chunk)  sdf = (w_s . h8 + b_s) / 3
 //   T7     t_7 = sigma'_7 * w_s / 3            MODE >= 1 (no GEMM)
 //   R7..R1 t_{l-1} = sigma'_{l-1} * (W_l^T t_l)
-//   R4e    g_emb += W4[:, 217:]^T t_4 / sqrt2  (2 chunks, before R4)
+//   R4e    g_emb += W4[:, 217:]^T t_4 / sqrt2  (2 chunks, after R4: both read t_4)
 //   R0     g_emb += W0^T t_0, then the chain rule through the positional encoding and the input scale 3
 // 1 - sigma' = 1 / (1 + 2^t) travels from the forward to the reverse sweep as unorm16 through a per-wave scratch
 // (128 KiB per wave, L2 / Infinity-Cache resident).
@@ -34,13 +34,13 @@ struct Sdf32Args {
   int t_stride;
   int sdf_stride;
   int ngroups;          // ceil(npts / GROUP)
-  uint32_t* dbg;        // diagnosis builds only (-DNRH32_DEBUG): intermediate state of workgroup 0's first pass, see profiles/ubench
-  int dbg_stage;
+  uint32_t* dbg;        // diagnosis builds only (-DNRH32_TIMING): per-wave cycle totals, see profiles/ubench/sdf32_bench.hip
+  int dbg_stage;        // unused
 };
 
 constexpr int SCRATCH_WORDS_PER_WAVE = 8 * 8 * 2 * 64 * 4;   // [layer][chunk][half][lane] uint4
 // The stream of one MODE: a 48 KiB preamble that stays resident in LDS (E4: 8 chunks x 3 K steps), then 32 KiB blocks in
-// execution order: L0 x2 (four 8 KiB chunks each) | L1..L7 x56 | [FEAT x8] | HEAD | [R7 R6 R5 x24 | R4e x2 | R4..R1 x32 | R0 x2]
+// execution order: L0 x2 (four 8 KiB chunks each) | L1..L7 x56 | [FEAT x8] | HEAD | [R7..R4 x32 | R4e x2 | R3..R1 x24 | R0 x2]
 __host__ __device__ constexpr int sdf32_stream_blocks(int mode) { return 2 + 56 + 1 + (mode == 2 ? 8 : 0) + (mode >= 1 ? 60 : 0); }
 __host__ __device__ constexpr long long sdf32_stream_bytes(int mode) {
   return RESIDENT_BYTES + (long long)sdf32_stream_blocks(mode) * SLOT_BYTES;
@@ -195,80 +195,78 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // every streamed block is older than the 8 youngest VMEM operations of this wave when it is needed (the pieces of the
     // block after it), so one static wait serves every window; the barrier makes the other waves' pieces visible and tells
     // them that this wave is done with the previous block (whose slot the next pieces overwrite)
+#ifdef NRH32_TIMING
+#define W32_SYNC() do { const unsigned long long s0_ = __builtin_readcyclecounter(); chunk_sync<8>(); tacc[7] += __builtin_readcyclecounter() - s0_; } while (0)
+#else
 #define W32_SYNC() chunk_sync<8>()
+#endif
 #define W32_FETCH_SETUP() fetch_setup()
 #define W32_WADDR() (wlane + cur_off)
 #define W32_NEXT() (cur_off = (cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES)
 
-#ifdef NRH32_DEBUG
-    const bool dbg_on = a.dbg != nullptr && blockIdx.x == 0 && tg == blockIdx.x;
-    auto dbg_at = [&](int word) {   // wave-uniform part of the address through an opaque SGPR (nothing to hoist, nothing to spill)
-      typedef __attribute__((address_space(1))) uint32_t* gu32_p;
-      gu32_p d = (gu32_p)a.dbg;
-      asm volatile("" : "+s"(d));
-      return d + word;
-    };
-    auto dbg_in = [&](int section) {   // a[0:127] of every lane -> dbg[section][wave][i][lane]
-#define W32_DUMP(i, x) dbg_at(section * 32768 + (wave * 128 + (i)) * 64)[lane] = (x)
-#include "gen32/dump_in.inc"
-#undef W32_DUMP
-    };
-    if (dbg_on) {
-      const uint32_t eb[24] = {ebh0[0], ebh0[1], ebh0[2], ebh0[3], ebh1[0], ebh1[1], ebh1[2], ebh1[3], ebh2[0], ebh2[1], ebh2[2], ebh2[3],
-                               ebl0[0], ebl0[1], ebl0[2], ebl0[3], ebl1[0], ebl1[1], ebl1[2], ebl1[3], ebl2[0], ebl2[1], ebl2[2], ebl2[3]};
-#pragma unroll
-      for (int i = 0; i < 24; ++i) dbg_at(1 * 32768 + (wave * 128 + i) * 64)[lane] = eb[i];
-    }
-#endif
-#define W32_QSTORE(c, half, val) __builtin_nontemporal_store((val), scr_at(qlayer, c, half))
     NRH32_STAMP(0);   // setup: rays, embedding
+    // The layers ping-pong between the two AGPR sets (a[0:127], a[128:255]): L0 writes set 0, L1 reads it and writes set 1,
+    // ... no copies.  The last chunk of every stage stays PENDING in (hp, cp): its epilogue runs in the MFMA shadows of the
+    // next stage's first window (its outputs are that stage's K steps 14 and 15, needed last).
+    f32x16 hp, cp;
+    // start values: the bias table, and for layer 4 the skip part E4 * emb on top (9 MFMAs per chunk over resident weights)
+    auto hinit = [&](int layer, int c) {
+      f32x16 hh = tab_init(layer, c);
+      if (layer == 4) {
+        f32x16 cc;
+        const uint32_t wa = ring_lds + LDS_RESIDENT + c * 6144 + lane16;   // resident E4 chunk c: 3 K steps
+#include "gen32/kloop3v.inc"
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hh[r] = __builtin_fmaf(cc[r], LO_UNSCALE, hh[r]);
+        asm volatile("s_nop 4" : "+v"(hh));   // VALU results -> MFMA SrcC
+      }
+      return hh;
+    };
+#define W32_QSTORE(c, half, val) __builtin_nontemporal_store((val), scr_at(qlayer, c, half))
+#define W32_QSTORE_P(c, half, val) __builtin_nontemporal_store((val), scr_at(qlayer - 1, c, half))
+#define W32_HINIT(c) hinit(qlayer, c)
     // ---- L0 ----
     {
       const int qlayer = 0;
-#define W32_HINIT(c) tab_init(0, c)
       if constexpr (WANT_D) {
 #include "gen32/l0_d1.inc"
       } else {
 #include "gen32/l0_d0.inc"
       }
-#undef W32_HINIT
-#include "gen32/swap.inc"
     }
-#ifdef NRH32_DEBUG
-    if (dbg_on) { dbg_in(3); if (a.dbg_stage == 3) return; }
-#endif
-
     NRH32_STAMP(1);   // L0
-    // ---- L1..L7 ----
-    for (int l = 1; l <= 7; ++l) {
-      const int qlayer = l;
-      // start values: the bias table, and for layer 4 the skip part E4 * emb on top (9 MFMAs per chunk over resident weights)
-      auto hinit = [&](int c) {
-        f32x16 hh = tab_init(l, c);
-        if (l == 4) {
-          f32x16 cc;
-          const uint32_t wa = ring_lds + LDS_RESIDENT + c * 6144 + lane16;   // resident E4 chunk c: 3 K steps
-#include "gen32/kloop3v.inc"
-#pragma unroll
-          for (int r = 0; r < 16; ++r) hh[r] = __builtin_fmaf(cc[r], LO_UNSCALE, hh[r]);
-          asm volatile("s_nop 4" : "+v"(hh));   // VALU results -> MFMA SrcC
+    // ---- L1..L7: odd layers read set 0 / write set 1, even layers the other way round ----
+    for (int l = 1; l <= 7; l += 2) {
+      {
+        const int qlayer = l;
+        if constexpr (WANT_D) {
+#include "gen32/fwd_d1_p0.inc"
+        } else {
+#include "gen32/fwd_d0_p0.inc"
         }
-        return hh;
-      };
-#define W32_HINIT(c) hinit(c)
-      if constexpr (WANT_D) {
-#include "gen32/fwd_d1.inc"
-      } else {
-#include "gen32/fwd_d0.inc"
       }
-#undef W32_HINIT
-#include "gen32/swap.inc"
-#ifdef NRH32_DEBUG
-      if (dbg_on && l <= 2) { dbg_in(3 + l); if (a.dbg_stage == 3 + l) return; }
-      if (dbg_on && l == 7) dbg_in(6);
-#endif
+      if (l == 7) break;
+      {
+        const int qlayer = l + 1;
+        if constexpr (WANT_D) {
+#include "gen32/fwd_d1_p1.inc"
+        } else {
+#include "gen32/fwd_d0_p1.inc"
+        }
+      }
     }
+    {
+      const int qlayer = 8;   // the pending chunk 7 of layer 7 -> set 1, where FEAT / HEAD read their input
+      if constexpr (WANT_D) {
+#include "gen32/fwd_fin_d1.inc"
+      } else {
+#include "gen32/fwd_fin_d0.inc"
+      }
+      (void)qlayer;
+    }
+#undef W32_HINIT
 #undef W32_QSTORE
+#undef W32_QSTORE_P
 
     NRH32_STAMP(2);   // L1..L7
     // ---- FEAT (MODE 2) and HEAD ----
@@ -307,10 +305,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
     NRH32_STAMP(3);   // FEAT + HEAD
     if constexpr (WANT_D) {
-      // ---- T7: t_7 = (1 - q_7) * w_s / 3, straight into `in` ----
+      // ---- T7: t_7 = (1 - q_7) * w_s / 3: chunks 0..6 straight into set 0 (R7's input), chunk 7 as R7's pending pair ----
+      u32x4 qpa, qpb;
 #define W32_A8(c) tab_init(10, c)
 #define W32_QLOAD7(c, half) __builtin_nontemporal_load(scr_at(7, c, half))   // nt: served by L2, never by a stale L1 line
+      qpa = W32_QLOAD7(7, 0);
+      qpb = W32_QLOAD7(7, 1);
 #include "gen32/t7.inc"
+      hp = W32_A8(7);
+      cp = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #undef W32_A8
 #undef W32_QLOAD7
 
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
           if (r & 1) __builtin_amdgcn_sched_barrier(0);
         }
       };
-      auto emb_stage = [&]() {   // two 32-row chunks (R4e or R0) over the current `in`
+      auto emb_stage = [&]() {   // two 32-row chunks (R4e or R0) over AGPR set 1
         for (int c = 0; c < 2; ++c) {
           W32_SYNC();
           W32_FETCH_SETUP();
@@ -353,17 +356,27 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // ---- R7..R1 ----
       // q words of chunk c of layer l - 1: asm loads (invisible to hipcc's vmcnt bookkeeping), nt: served by L2
 #define W32_QLOAD_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(lane16), "s"(qbase + (c) * 2048), "n"((half) * 1024))
-      for (int l = 7; l >= 0; --l) {   // l = 0: only R0 (one copy of emb_stage in the code: the kernels are I-cache sized)
-        if (l == 4 || l == 0) emb_stage();
-        if (l == 0) break;
-        const char* const qbase = uni(scr + (l - 1) * 16384);
-#include "gen32/rev.inc"
-#include "gen32/swap.inc"
+      // R7 R6 | R5 R4 R4e | R3 R2 | R1 finish R0: odd layers read set 0 / write set 1, even layers the other way round, so both
+      // embedding-gradient stages (after R4: t_4 is R4's input; after R1: t_0) read set 1 - one copy of emb_stage in the code
+      for (int k = 0; k < 4; ++k) {
+        {
+          const int l = 7 - 2 * k;
+          const char* const qbase = uni(scr + (l - 1) * 16384);
+#include "gen32/rev_p0.inc"
+        }
+        if (k == 3) {
+#include "gen32/rev_fin.inc"
+        } else {
+          const int l = 6 - 2 * k;
+          const char* const qbase = uni(scr + (l - 1) * 16384);
+#include "gen32/rev_p1.inc"
+        }
+        if (k == 1 || k == 3) emb_stage();
       }
 #undef W32_QLOAD_ASM
 
       NRH32_STAMP(5);   // R7..R1 (+ R4e)
-      // ---- the chain rule through the encoding (R0 ran as the last pass of the loop above) ----
+      // ---- the chain rule through the encoding ----
 #pragma unroll
       for (int c = 0; c < 3; ++c) dx[c] += __shfl_xor(dx[c], 32, 64);
       if (valid && hf == 0) {

@@ -10,7 +10,7 @@ previous layer lands in registers (no shuffle between layers).  hi = fp16(w), lo
 The kernels read ONE stream of chunks per evaluation mode, in execution order (csrc/nrh_sdf32.hip):
 
     E4 (48 KiB, resident in LDS) | L0 x2 blocks (four 8 KiB chunks each) | L1..L7 x56 | [FEAT x8] | HEAD x1 |
-    [R7 R6 R5 x24 | R4e x2 | R4..R1 x32 | R0 x2]                                  (blocks of 32 KiB)
+    [R7..R4 x32 | R4e x2 | R3..R1 x24 | R0 x2]                                  (blocks of 32 KiB)
 
 E4 = W4[:, 217:] / sqrt2 is the skip connection's part of layer 4 (applied to the 39 embedding entries, in the embedding's K
 order, 3 K steps per chunk); W4's main part has those columns zeroed.  The softplus layers work in the scaled domain t = z * 100/ln2,
@@ -124,7 +124,7 @@ def stream_order(mode: int):
         order.append("FEAT")
     order.append("HEAD")
     if mode >= 1:
-        order += ["R7", "R6", "R5", "R4e", "R4", "R3", "R2", "R1", "R0"]
+        order += ["R7", "R6", "R5", "R4", "R4e", "R3", "R2", "R1", "R0"]
     return order
 
 

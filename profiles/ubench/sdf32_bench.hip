@@ -64,27 +64,6 @@ int main(int argc, char** argv) {
   const void* fns[3] = {(const void*)nrh32::sdf32_kernel<0>, (const void*)nrh32::sdf32_kernel<1>, (const void*)nrh32::sdf32_kernel<2>};
   for (int m = 0; m < 3; ++m) CK(hipFuncSetAttribute(fns[m], hipFuncAttributeMaxDynamicSharedMemorySize, nrh32::LDS_BYTES));
 
-#ifdef NRH32_DEBUG
-  {
-    // diagnosis: intermediate state of workgroup 0's first pass -> gpurun_out/sdf32_dbg.bin (compare with profiles/ubench/check_sdf32_dbg.py)
-    const size_t words = 7 * 32768;
-    uint32_t* d_dbg;
-    CK(hipMalloc(&d_dbg, words * 4));
-    CK(hipMemset(d_dbg, 0, words * 4));
-    nrh32::Sdf32Args a;
-    a.w = d_w; a.tab = d_tab; a.ro = d_ro; a.rd = d_rd; a.t = d_t; a.sdf = d_sdf; a.grad = d_grad; a.feat = d_feat;
-    a.scratch = d_scr; a.npts = npts; a.n_per_ray = (int)nper; a.t_stride = (int)nper; a.sdf_stride = (int)nper;
-    a.ngroups = (int)((npts + nrh32::GROUP - 1) / nrh32::GROUP);
-    a.dbg = d_dbg; a.dbg_stage = argc > 3 ? atoi(argv[3]) : 99;
-    hipLaunchKernelGGL(nrh32::sdf32_kernel<0>, dim3(grid), dim3(nrh32::THREADS), nrh32::LDS_BYTES, 0, a);
-    CK(hipGetLastError());
-    CK(hipDeviceSynchronize());
-    std::vector<uint32_t> h(words);
-    CK(hipMemcpy(h.data(), d_dbg, words * 4, hipMemcpyDeviceToHost));
-    FILE* g = fopen("gpurun_out/sdf32_dbg.bin", "wb");
-    if (g) { fwrite(h.data(), 4, words, g); fclose(g); printf("wrote gpurun_out/sdf32_dbg.bin\n"); }
-  }
-#endif
   const double flop_pt[3] = {2.0 * 459008, 2.0 * (459008 + 459008), 2.0 * (524544 + 459008)};
   std::vector<float> h_sdf(npts), h_grad(npts * 3), h_feat((size_t)((npts + 15) / 16) * 4096);
   int bad = 0;
@@ -139,10 +118,10 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(ht.data(), d_t, nw * 64, hipMemcpyDeviceToHost));
       double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
       for (int w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) { acc[k] += (double)ht[w * 8 + k] / nw; }
-      for (int k = 0; k < 8; ++k) tot += acc[k];
+      for (int k = 0; k < 7; ++k) tot += acc[k];
       const double passes = (double)a.ngroups / grid;
-      printf("  cycles per pass (mean over waves, %.1f passes): setup %.0f | L0 %.0f | L1..L7 %.0f | FEAT+HEAD %.0f | T7 %.0f | R7..R1+R4e %.0f | R0+out %.0f | total %.0f\n",
-             passes, acc[0] / passes, acc[1] / passes, acc[2] / passes, acc[3] / passes, acc[4] / passes, acc[5] / passes, acc[6] / passes, tot / passes);
+      printf("  cycles per pass (mean over waves, %.1f passes): setup %.0f | L0 %.0f | L1..L7 %.0f | FEAT+HEAD %.0f | T7 %.0f | R7..R1+R4e %.0f | R0+out %.0f | total %.0f  (of which waiting in chunk_sync %.0f)\n",
+             passes, acc[0] / passes, acc[1] / passes, acc[2] / passes, acc[3] / passes, acc[4] / passes, acc[5] / passes, acc[6] / passes, tot / passes, acc[7] / passes);
       a.dbg = nullptr;
       CK(hipFree(d_t));
     }

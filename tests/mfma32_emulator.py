@@ -199,13 +199,13 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
 
     for l in range(7, 0, -1):
         bh, bl = act_to_b(tcur)
-        if l == 4:
-            emb_stage(bh, bl)
         nxt = []
         for c in range(8):
             hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
             g = hh + cc / 2048.0
             nxt.append(g + (g * (-1.0 / 65535.0)) * qs[(l - 1, c)])
+        if l == 4:           # R4e follows R4 in the stream: both read t_4
+            emb_stage(bh, bl)
         tcur = nxt
     bh, bl = act_to_b(tcur)
     emb_stage(bh, bl)
