@@ -239,9 +239,12 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             out.append("    W32_FETCH_SETUP();")
         if c == 0 and has_epi:
             # window 0 consumes the pending pair (and q words) of the previous stage; window 7 redefines those names
+            # (the empty asm orders any copy hipcc makes of these registers behind W32_SYNC: the q words were still in flight)
+            out.append('    asm volatile("" : "+v"(hp), "+v"(cp));')
             out.append("    nrh32::f32x16 ph0 = hp, pc0 = cp;")
             ph, pc = "ph0", "pc0"
             if kind == "rev":
+                out.append('    asm volatile("" : "+v"(qpa), "+v"(qpb));')
                 out.append("    nrh32::u32x4 pqa = qpa, pqb = qpb;")
         epi = None
         if has_epi:
@@ -290,6 +293,11 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         out.append("  }")
     # whoever comes next may copy the pending registers: only after the last MFMAs have landed
     out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hp), "+v"(cp));')
+    if kind == "rev":
+        # same for the pending q words (asm loads of window 7, in flight, invisible to hipcc): they have landed before
+        # anything may touch their registers (hipcc shuffles loop-carried registers at the loop edges - measured: 1-3 % of
+        # the tiles got stale words without this).  They are older than window 7's eight LDS-DMA pieces.
+        out.append('  asm volatile("s_waitcnt vmcnt(8)" : "+v"(qpa), "+v"(qpb));')
     out.append("}")
     return "\n".join(out) + "\n"
 
@@ -300,7 +308,7 @@ def gen_finish(kind, want_d, out_base):
     if kind == "fwd":
         epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P")
     else:
-        out.append('  asm volatile("s_waitcnt vmcnt(8)" : "+v"(qpa), "+v"(qpb));   // the q loads of window 7 (older than its 8 DMA pieces)')
+        out.append('  asm volatile("" : "+v"(qpa), "+v"(qpb));   // landed: the stage body ends with a wait for them')
         out.append("  const nrh32::u32x4 qw0 = qpa, qw1 = qpb;")
         epi = epi_rev(7, "hp", "cp", out_base=out_base)
     slots, tail = schedule(epi, (len(epi) + 7) // 8 + 8, 8)
@@ -332,10 +340,12 @@ def gen_swap():
 
 def gen_t7():
     """t_7 = (1 - q_7) * a8 written straight into AGPR set 0 (R7's input): W32_A8(c) -> f32x16 (w_s / 3 in D32 layout),
-    W32_QLOAD7(c, half).  All loads go out first (56 VGPRs, nothing else is live here): one exposed L2 latency, not seven."""
+    W32_QLOAD7_ASM(dst, c, half).  All loads go out first (56 VGPRs, nothing else is live here): one exposed L2 latency, not seven."""
     out = ["// generated by gen_mlp32.py: T7 pass", "{"]
     for c in range(7):
-        out.append(f"  const nrh32::u32x4 q{c}a = W32_QLOAD7({c}, 0), q{c}b = W32_QLOAD7({c}, 1);")
+        out.append(f"  nrh32::u32x4 q{c}a, q{c}b;")
+        out.append(f"  W32_QLOAD7_ASM(q{c}a, {c}, 0); W32_QLOAD7_ASM(q{c}b, {c}, 1);")
+    out.append('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // asm loads: the wait is ours')
     out.append("  __builtin_amdgcn_sched_barrier(0);")
     for c in range(7):   # chunk 7 becomes the pending pair of the reverse chain (hp = a8, cp = 0, q words): R7's window 0 finishes it
         out.append(f"  {{  // chunk {c}")

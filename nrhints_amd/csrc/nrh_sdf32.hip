@@ -307,15 +307,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if constexpr (WANT_D) {
       // ---- T7: t_7 = (1 - q_7) * w_s / 3: chunks 0..6 straight into set 0 (R7's input), chunk 7 as R7's pending pair ----
       u32x4 qpa, qpb;
+      const char* const q7base = uni(scr + 7 * 16384);
+      // nt: served by L2; asm: the destination registers are written straight by the load (no compiler copy of a value still
+      // in flight), the wait is in t7.inc
+#define W32_QLOAD7_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(lane16), "s"(q7base + ((c) * 2 + (half)) * 1024))
 #define W32_A8(c) tab_init(10, c)
-#define W32_QLOAD7(c, half) __builtin_nontemporal_load(scr_at(7, c, half))   // nt: served by L2, never by a stale L1 line
-      qpa = W32_QLOAD7(7, 0);
-      qpb = W32_QLOAD7(7, 1);
+      W32_QLOAD7_ASM(qpa, 7, 0);
+      W32_QLOAD7_ASM(qpb, 7, 1);
 #include "gen32/t7.inc"
       hp = W32_A8(7);
       cp = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #undef W32_A8
-#undef W32_QLOAD7
+#undef W32_QLOAD7_ASM
 
       NRH32_STAMP(4);   // T7
       // g_emb chunk c (register r <-> entry 32c + frow(r, hf)) contracted with d enc / dx.  The 20 derivative values are

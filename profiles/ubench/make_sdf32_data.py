@@ -13,10 +13,14 @@ from oracle import neus_oracle as orc
 
 def main():
     nrays = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    nper, ncheck = 128, 4096
+    nper = 128
+    ncheck = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+    scene = sys.argv[2] if len(sys.argv) > 2 else 'b'
     torch.manual_seed(0)
     base = na.NeuSHintRenderer()
-    st = perturb_state({k: v.detach().numpy().copy() for k, v in base.state_dict().items()})
+    st = {k: v.detach().numpy().copy() for k, v in base.state_dict().items()}
+    if scene == 'b':
+        st = perturb_state(st)
     d = pk.dense_params({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
     streams, tables = pk32.pack_sdf32(d)
     o, dd, pl, near, far = make_rays(nrays, seed=1, spread=0.1)
@@ -26,7 +30,7 @@ def main():
     pts32 = (o[:, None, :] + dd[:, None, :] * t[:, :, None]).reshape(-1, 3).astype(np.float32)
     p64 = orc.params_from_state(st, torch.float64)
     sdf, feat, grad = orc.sdf_forward_grad_analytic(p64, torch.from_numpy(pts32[:ncheck].astype(np.float64)))
-    out = os.path.join(ROOT, "profiles", "ubench", "data", "sdf32_case.bin")
+    out = os.path.join(ROOT, "profiles", "ubench", "data", sys.argv[4] if len(sys.argv) > 4 else "sdf32_case.bin")
     with open(out, "wb") as f:
         hdr = np.array([nrays, nper, ncheck, streams.numel(), tables.numel()], dtype=np.int64)
         f.write(hdr.tobytes())
