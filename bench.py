@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the NRHints hot path on MI355X: rendered primary rays / second at 128 samples per ray.
 
-    python bench.py [--gpus N --steps K --warmup W]                 (N = 1)
+    python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+With ``--gpus N`` (N > 1) and no launcher environment, bench.py starts its own N ranks (one process per GPU through
+``torch.distributed.run`` on 127.0.0.1, as the reference's launcher spawns its workers, trainer/launcher.py:41-60).
 
 A *step* is one full 800x800 evaluation render (BASELINE.json configs[1]: 640 000 primary rays, 64 + 64 samples,
 one 128-sample shadow ray per primary ray, 4-roughness specular cue) through ``NeuSHintRenderer.forward`` with
-the rays already resident in HBM.  With N > 1 every rank renders its own view of the scene (rays are independent,
-no data-path collective: the reference shards evaluation by view too, trainer/trainer.py:288-296) - weak scaling.
+the rays already resident in HBM.
+  --scaling weak   (default) every rank renders its own view of the scene (rays are independent, no data-path
+                   collective: the reference shards evaluation by view too, trainer/trainer.py:288-296)
+  --scaling strong ONE 800x800 view split into row blocks over the ranks, pixels all-gathered over RCCL
+                   (BASELINE.json configs[3], nrhints_amd/parallel.py: render_sharded)
 The scene is the synthetic random-weight scene "b" (reference initialisation under seed 0 + the deterministic
 perturbation of nrhints_amd.synthetic.perturb_state, NeuS sharpness 0.7), since datasets/checkpoints are not
 reachable offline.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      dominant kernel (SDF value+feature+gradient at the 128 composite samples), timed live with HIP
                 events inside the timed region; algorithmic FLOPs per point are in DESIGN.md
   cpu_baseline  the CPU oracle in "as written" mode (the reference's call pattern, eager fp32 PyTorch) on a bounded
-                sample of the same rays, all host cores (rank 0, N = 1 only)
+                sample of the same rays: 4096 rays in 512-ray chunks, 1 warm-up + 3 repeats, median (BASELINE.md §4;
+                rank 0, N = 1 only)
+  secondary     the same render in the other matrix arithmetic (exact fp32 MFMA) - value and roofline fraction
+  train         BASELINE.json configs[2]: 1024-ray training steps (forward + backward + Adam; N = 1: the whole step
+                replayed as one hipGraph; N > 1: eager steps with one flat RCCL gradient all-reduce per step)
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,13 +46,16 @@ if ROOT not in sys.path:
 
 import nrhints_amd as na  # noqa: E402
 from nrhints_amd import _lib  # noqa: E402
-from nrhints_amd.synthetic import make_image_rays, perturb_state, psnr  # noqa: E402
+from nrhints_amd.synthetic import make_image_rays, make_rays, perturb_state, psnr  # noqa: E402
 
 H = W = 800
 # algorithmic multiply-accumulates per evaluated point (SURVEY.md §8d / DESIGN.md §4)
 MAC_F_FULL, MAC_F_SDF, MAC_G, MAC_C = 524_544, 459_008, 459_008, 289_792
 FLOP_PER_RAY = 2 * (224 * MAC_F_SDF + 128 * (MAC_F_FULL + MAC_G) + 128 * (MAC_F_SDF + MAC_G) + 128 * MAC_C)
 FLOP_PER_POINT_CORE = 2 * (MAC_F_FULL + MAC_G)   # the dominant kernel: sdf + feature + gradient per point
+# one training ray-step: the evaluation path without the reflectance forward's share of the no-grad pass,
+# plus training forward (F + C), tangent and value sweeps (2 G + F), reflectance adjoint (C) and the weight gradients
+FLOP_PER_RAY_STEP = 1.4186e9
 # MI355X_MICROARCH.md dense MFMA peaks: fp32-input 157.3 TFLOP/s; fp16 2 500 TFLOP/s.  The f16x3 mode spends three
 # fp16 MFMAs per algorithmic multiply-add, so its ceiling in ALGORITHMIC flops is 833 TFLOP/s; frac is quoted
 # against the fp16 peak all the same (the honest denominator for the instruction that is issued).
@@ -56,32 +71,38 @@ def build_scene(precision):
     return model, state_b
 
 
-def pmc_traffic(precision):
+def dominant_kernel(precision, wide):
+    if precision == "f16x3" and wide:
+        return "nrh32::sdf32_kernel<2>", "sdf32_kernel<2> (wide f16x3: sdf + feature + d sdf/dx, 128 pts/ray)"
+    return "sdf_kernel<2, %s>" % {"f16x3": "1", "f32": "0"}[precision], "sdf_kernel<2> (sdf + feature + d sdf/dx, 128 pts/ray)"
+
+
+def pmc_traffic(precision, wide):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/pmc_run.sh): FETCH_SIZE [KiB] x 2 (gfx950 counts wide coalesced reads at half their size) + WRITE_SIZE
     [KiB].  None if no counter summary for this precision is committed."""
     import glob
     import re
-    tag = {"f16x3": "1", "f32": "0"}[precision]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{precision}_v*", "summary.txt")))
-    if not files:
-        return None, None
-    txt = open(files[-1]).read()
-    m = re.search(r"sdf_kernel<2, %s>\n((?:   .*\n)+)" % tag, txt)
-    if not m:
-        return None, None
-    vals = dict(re.findall(r"(\w+)\s+n=\s*\d+ mean=([0-9.e+]+)", m.group(1)))
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None, None
-    return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(files[-1], ROOT)
+    key = re.escape(dominant_kernel(precision, wide)[0])
+    for path in reversed(files):
+        txt = open(path).read()
+        m = re.search(key + r"[^\n]*\n((?:   .*\n)+)", txt)
+        if not m:
+            continue
+        vals = dict(re.findall(r"(\w+)\s+n=\s*\d+ mean=([0-9.e+]+)", m.group(1)))
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(path, ROOT)
+    return None, None
 
 
-def cpu_baseline(state, rays_np, n_sample, gpu_rgb):
-    """Time the oracle ("as written": 13 SDF forwards + autograd gradient per render, 512-ray chunks) on the host.
+def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
+    """Time the oracle ("as written": 13 SDF forwards + autograd gradient per render) on the host, BASELINE.md §4 protocol:
+    ``n_sample`` rays (4096) in 512-ray chunks, 1 warm-up + 3 timed repeats, median.
 
     Eager PyTorch on [512*128, 256] operands stops scaling long before a 256-core host is full (oversubscribed it
     is 10x slower), so the thread count is calibrated on a 64-ray probe over {all, 64, 32, 16} cores and the best
-    one is used and reported as ``cores``."""
+    one is used and reported as ``cores``.  The repeats stop early if the time budget runs out (said in ``sample``)."""
     from oracle import neus_oracle as orc  # the checker; only this leg and the tests import it
     host = os.cpu_count() or 1
     p = orc.params_from_state(state)
@@ -96,55 +117,35 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb):
         dt = time.perf_counter() - t0
         if dt < best_t:
             best, best_t = th, dt
-        if dt > 20.0:
-            continue
     torch.set_num_threads(best)
-    t0 = time.perf_counter()
-    out = orc.render_chunked(p, *sub, chunk=512, background_rgb=bg, mode="as_written")
-    dt = time.perf_counter() - t0
+    t_start = time.perf_counter()
+    # warm-up on one chunk (the protocol's warm-up repeat would cost a quarter of the budget for nothing new)
+    orc.render_chunked(p, *(t[:512] for t in sub), chunk=512, background_rgb=bg, mode="as_written")
+    times, out = [], None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        out = orc.render_chunked(p, *sub, chunk=512, background_rgb=bg, mode="as_written")
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start + times[-1] > budget_s:
+            break
+    med = float(np.median(times))
     ref = out["rgb"].numpy()
-    return {"value": round(n_sample / dt, 2), "unit": "rays/s", "cores": best, "host_cores": host, "kind": "port",
-            "sample": f"{n_sample} rays strided over the benchmark frame, one 512-ray chunk shape, oracle "
-                      f"mode=as_written (reference call pattern), fp32 PyTorch eager, {dt:.1f} s",
+    return {"value": round(n_sample / med, 2), "unit": "rays/s", "cores": best, "host_cores": host, "kind": "port",
+            "sample": f"{n_sample} rays strided over the benchmark frame in 512-ray chunks, oracle mode=as_written (reference "
+                      f"call pattern), fp32 PyTorch eager, one-chunk warm-up + {len(times)} repeat(s), median {med:.1f} s",
+            "repeats_s": [round(t, 2) for t in times],
             "psnr_gpu_vs_cpu_db": round(psnr(gpu_rgb[idx], ref), 2),
             "max_abs_rgb_diff": float(np.abs(gpu_rgb[idx] - ref).max())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-rays", type=int, default=512, help="rays in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default=na.NeuSHintRenderer.precision)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm; used for the barrier + max-over-ranks only
-
-    model, state = build_scene(args.precision)
-    peak = PEAK_TFLOPS[args.precision]
-    model = model.to(dev).eval()
-    # each rank renders its own view of the same scene (different azimuth / light), rays resident in HBM
-    rays_np = make_image_rays(H, W, azimuth=0.6 + 0.7 * rank, elevation=0.5)
-    rb = na.RayBundle(**{k: torch.from_numpy(v).to(dev) for k, v in
-                         zip(("origins", "directions", "pl_positions", "nears", "fars"), rays_np)})
-    bg = torch.ones(1, 3, device=dev)
-    nrays = H * W
+def timed_render(model, rb, bg, steps, warmup, dist, dev, sharded):
+    """W untimed + K timed render steps bracketed by barrier + synchronize; -> (seconds, last output, kernel ms, launches)."""
+    from nrhints_amd import parallel
 
     def step():
         with torch.no_grad():
+            if sharded:
+                return parallel.render_sharded(lambda r: model(r, is_training=False, background_rgb=bg), rb, fields=("rgb",))
             return model(rb, is_training=False, background_rgb=bg)
 
     def fence():
@@ -152,13 +153,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    out = None
+    for _ in range(warmup):
         out = step()
     lib = _lib.load()
     _lib.check(lib.nrh_kernel_timing_select(2), "timing_select")
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
@@ -169,27 +171,159 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt, out, k_ms.value, max(1, k_n.value)
+
+
+def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
+    """BASELINE.json configs[2] (and [4] for N > 1): 1024-ray training steps of the reference-initialised student against
+    pixels of scene b (rendered before the timed region: ground-truth pixels are data)."""
+    from nrhints_amd.training import FlatGradAllReduce, GraphedTrainStep, make_optimizer, train_step
+    torch.manual_seed(0)
+    student = na.NeuSHintRenderer(na.NeuSModelConfig()).to(dev)
+    teacher, _ = build_scene(student.precision)
+    teacher = teacher.to(dev).eval()
+    bg = torch.ones(1, 3, device=dev)
+    batches = []
+    for s in range(steps + warm):
+        o, d, pl, near, far = (torch.from_numpy(a).to(dev) for a in make_rays(batch, seed=1000 + 97 * rank + s, spread=0.08))
+        rb = na.RayBundle(origins=o, directions=d, pl_positions=pl, nears=near, fars=far)
+        with torch.no_grad():
+            batches.append((rb, teacher(rb, background_rgb=bg).rgb))
+    graphed = None
+    if world == 1:
+        graphed = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000)
+        run = lambda i, rb, gt: graphed(rb, gt, global_step=20000 + i)
+    else:
+        opt, sched = make_optimizer(student, warm_up_end=10)
+        sync = FlatGradAllReduce(list(student.parameters()))
+        run = lambda i, rb, gt: train_step(student, rb, gt, bg, global_step=20000 + i, optimizer=opt, scheduler=sched, grad_sync=sync)
+    losses = []
+    t0 = None
+    for i, (rb, gt) in enumerate(batches):
+        if i == warm:
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        losses.append(run(i, rb, gt)["loss"])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if graphed is not None:
+        graphed.release()
+    value = world * batch * steps / dt
+    peak = PEAK_TFLOPS[student.precision]
+    return {"metric": "training ray-steps/s (forward + backward + Adam)", "value": round(value, 1), "unit": "ray-steps/s",
+            "batch_rays_per_gpu": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
+            "dtype": student.precision, "mode": "hipGraph replay" if world == 1 else "eager + flat RCCL all-reduce",
+            "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
+            "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
+                         "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(value * FLOP_PER_RAY_STEP / 1e12 / world / peak, 4)}}
+
+
+def respawn(args):
+    """--gpus N without a launcher: start N ranks ourselves (one process per GPU) and relay their output."""
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default=na.NeuSHintRenderer.precision)
+    ap.add_argument("--no-train", action="store_true", help="skip the training leg (configs[2])")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the render in the other precision")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")  # RCCL on ROCm: barrier, max-over-ranks, pixel all-gather, gradient all-reduce
+
+    model, state = build_scene(args.precision)
+    peak = PEAK_TFLOPS[args.precision]
+    model = model.to(dev).eval()
+    strong = args.scaling == "strong"
+    # weak: each rank renders its own view of the same scene (different azimuth / light); strong: everyone holds view 0
+    rays_np = make_image_rays(H, W, azimuth=0.6 + (0.0 if strong else 0.7 * rank), elevation=0.5)
+    rb = na.RayBundle(**{k: torch.from_numpy(v).to(dev) for k, v in
+                         zip(("origins", "directions", "pl_positions", "nears", "fars"), rays_np)})
+    bg = torch.ones(1, 3, device=dev)
+    nrays = H * W
+    dt, out, k_ms, launches = timed_render(model, rb, bg, args.steps, args.warmup, dist, dev, sharded=strong and world > 1)
+    rgb = (out["rgb"] if isinstance(out, dict) else out.rgb).cpu().numpy()
+
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        other = "f32" if args.precision == "f16x3" else "f16x3"
+        m2, _ = build_scene(other)
+        m2 = m2.to(dev).eval()
+        dt2, out2, k2_ms, l2 = timed_render(m2, rb, bg, 1, 1, None, dev, sharded=False)
+        ach2 = FLOP_PER_POINT_CORE * (nrays * 128 / l2) / (k2_ms / l2 * 1e-3) / 1e12
+        secondary = {"dtype": other, "value": round(nrays / dt2, 1), "unit": "rays/s", "steps": 1, "warmup": 1,
+                     "roofline_achieved_tflops": round(ach2, 2), "roofline_frac": round(ach2 / PEAK_TFLOPS[other], 4),
+                     "psnr_vs_primary_db": round(psnr(out2.rgb.cpu().numpy(), rgb), 2)}
+        del m2, out2
+        torch.cuda.empty_cache()
+
+    train = None
+    if not args.no_train:
+        try:
+            train = train_leg(dev, rank, world, dist)
+        except Exception as e:  # the headline must survive a failure of the secondary leg
+            train = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
-        value = world * nrays * args.steps / dt
-        launches = max(1, k_n.value)
-        pts_per_launch = nrays * 128 * args.steps / launches
-        avg_ms = k_ms.value / launches
+        work = 1 if strong else world                       # strong: the job is ONE frame however many ranks render it
+        value = work * nrays * args.steps / dt
+        pts_per_launch = (nrays / (world if strong else 1)) * 128 * args.steps / launches
+        avg_ms = k_ms / launches
         achieved = FLOP_PER_POINT_CORE * pts_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(args.precision)
+        wide = bool(getattr(model, "wide_kernels", False)) and args.precision == "f16x3"
+        traffic, traffic_src = pmc_traffic(args.precision, wide)
         line = {
             "metric": "rendered rays/sec (128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "800x800 eval render (640000 primary rays/step/GPU), 64+64 samples/ray, "
+            "config": {"workload": "800x800 eval render (640000 primary rays/step" + ("" if strong else "/GPU") + "), 64+64 samples/ray, "
                                    "shadow + specular hints, synthetic random-weight scene b (BASELINE configs[1])",
-                       "rays_per_step_per_gpu": nrays, "samples_per_ray": 128,
-                       "chunk_rays": int(model.max_chunk_rays), "parallelism": f"view-sharded x{world}",
+                       "rays_per_step_per_gpu": nrays // (world if strong else 1), "samples_per_ray": 128,
+                       "chunk_rays": int(model.max_chunk_rays),
+                       "parallelism": (f"one view in {world} row blocks + RCCL all-gather of rgb" if strong else f"view-sharded x{world}"),
                        "algorithmic_gflop_per_ray": round(FLOP_PER_RAY / 1e9, 4),
                        "whole_path_tflops": round(value * FLOP_PER_RAY / 1e12, 2),
                        "whole_path_frac_of_mfma_peak": round(value * FLOP_PER_RAY / 1e12 / world / peak, 4)},
-            "roofline": {"bound": "mfma", "kernel": "sdf_kernel<2> (sdf + feature + d sdf/dx, 128 pts/ray)",
+            "roofline": {"bound": "mfma", "kernel": dominant_kernel(args.precision, wide)[1],
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(pts_per_launch * 1044),
@@ -197,9 +331,11 @@ def main():
                          "algorithmic_flop_per_point": FLOP_PER_POINT_CORE},
         }
         if world == 1 and args.cpu_rays > 0:
-            line["cpu_baseline"] = cpu_baseline(state, rays_np, args.cpu_rays, out.rgb.cpu().numpy())
+            line["cpu_baseline"] = cpu_baseline(state, rays_np, args.cpu_rays, rgb)
         else:
             line["cpu_baseline"] = None
+        line["secondary"] = secondary
+        line["train"] = train
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

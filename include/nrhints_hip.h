@@ -242,6 +242,26 @@ int nrh_generate_rays(const float* pose, const float* pl, float cx, float cy, fl
                       int nrows, float* origins, float* directions, float* pl_positions, float* nears, float* fars,
                       void* stream);
 
+/* ---- pixel bundle -> rays with per-view refinement ---------------------------------------------------------------
+ * RayGenerator.forward (camera/ray_generator.py:75-150) for a training / evaluation pixel bundle: ray i has pixel
+ * (h_indices[i], w_indices[i]) (floats, as RawPixelBundle stores them), camera-to-world poses[i*pose_stride .. +12)
+ * (row-major [3,4]; pose_stride 12 or 16) and light pls[i*3..].  img_indices [n] (int64) selects the view's entry of
+ * `delta` [ncam,3,4] - the left delta exp(adjustment) o noise, composed per VIEW by the caller (:108-121) - and of
+ * `pl_delta` [ncam,3] (:123-127); either may be NULL, and img_indices NULL means "no refinement" (:103-105).
+ * near_far_from_sphere != 0: unit-sphere chord mid-point -+ 1 (:135-139), else the constants zn / zf (:141-142).
+ * All pointers are DEVICE pointers.  The backward entry ACCUMULATES d(loss)/d(delta) [ncam,3,4] and
+ * d(loss)/d(pl_delta) [ncam,3] (either may be NULL; caller zeroes) from the output gradients (any may be NULL). */
+int nrh_generate_rays_indexed(const long long* img_indices, const float* h_indices, const float* w_indices, const float* poses,
+                              int pose_stride, const float* pls, long long nrays, const float* delta, const float* pl_delta,
+                              int ncam, float cx, float cy, float fx, float fy, int near_far_from_sphere, float zn, float zf,
+                              float* origins, float* directions, float* pl_positions, float* nears, float* fars, void* stream);
+int nrh_generate_rays_indexed_backward(const long long* img_indices, const float* h_indices, const float* w_indices,
+                                       const float* poses, int pose_stride, const float* pls, long long nrays, const float* delta,
+                                       const float* pl_delta, int ncam, float cx, float cy, float fx, float fy,
+                                       int near_far_from_sphere, const float* g_origins, const float* g_directions,
+                                       const float* g_pl_positions, const float* g_nears, const float* g_fars, float* g_delta,
+                                       float* g_pl_delta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,7 +255,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 120; }
+int nrh_version(void) { return 121; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -554,6 +554,53 @@ int nrh_generate_rays(const float* pose /* host, 12 */, const float* pl /* host,
   const long long tot = (long long)nrows * width;
   hipLaunchKernelGGL(nrh::raygen_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("raygen_kernel");
+}
+
+static int raygen_indexed_args(nrh::RayGenIdxArgs& a, const char* who, const long long* img_indices, const float* h_indices,
+                               const float* w_indices, const float* poses, int pose_stride, const float* pls, long long nrays,
+                               const float* delta, const float* pl_delta, int ncam, float cx, float cy, float fx, float fy,
+                               int near_far_from_sphere, float zn, float zf) {
+  if (nrays < 0 || ncam < 0) return fail(NRH_E_INVALID, "%s: negative size", who);
+  if (nrays == 0) return NRH_OK;
+  if (!h_indices || !w_indices || !poses || !pls) return fail(NRH_E_INVALID, "%s: null pointer", who);
+  if (pose_stride < 12 || fx == 0.0f || fy == 0.0f) return fail(NRH_E_INVALID, "%s: bad geometry (pose_stride >= 12, fx, fy != 0)", who);
+  if ((delta || pl_delta) && (!img_indices || ncam == 0)) return fail(NRH_E_INVALID, "%s: per-view deltas need img_indices and ncam > 0", who);
+  a = nrh::RayGenIdxArgs{};
+  a.img = img_indices; a.hidx = h_indices; a.widx = w_indices; a.poses = poses; a.pls = pls; a.delta = delta; a.pl_delta = pl_delta;
+  a.pose_stride = pose_stride; a.ncam = ncam; a.sphere = near_far_from_sphere ? 1 : 0;
+  a.cx = cx; a.cy = cy; a.fx = fx; a.fy = fy; a.zn = zn; a.zf = zf; a.n = nrays;
+  return 1;   // "go on"
+}
+
+int nrh_generate_rays_indexed(const long long* img_indices, const float* h_indices, const float* w_indices, const float* poses,
+                              int pose_stride, const float* pls, long long nrays, const float* delta, const float* pl_delta, int ncam,
+                              float cx, float cy, float fx, float fy, int near_far_from_sphere, float zn, float zf, float* origins,
+                              float* directions, float* pl_positions, float* nears, float* fars, void* stream) {
+  nrh::RayGenIdxArgs a;
+  const int rc = raygen_indexed_args(a, "nrh_generate_rays_indexed", img_indices, h_indices, w_indices, poses, pose_stride, pls, nrays,
+                                     delta, pl_delta, ncam, cx, cy, fx, fy, near_far_from_sphere, zn, zf);
+  if (rc <= 0) return rc;
+  if (!origins || !directions || !pl_positions || !nears || !fars) return fail(NRH_E_INVALID, "nrh_generate_rays_indexed: null output%s", "");
+  a.origins = origins; a.dirs = directions; a.pl_out = pl_positions; a.nears = nears; a.fars = fars;
+  hipLaunchKernelGGL(nrh::raygen_indexed_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("raygen_indexed_kernel");
+}
+
+int nrh_generate_rays_indexed_backward(const long long* img_indices, const float* h_indices, const float* w_indices, const float* poses,
+                                       int pose_stride, const float* pls, long long nrays, const float* delta, const float* pl_delta,
+                                       int ncam, float cx, float cy, float fx, float fy, int near_far_from_sphere,
+                                       const float* g_origins, const float* g_directions, const float* g_pl_positions,
+                                       const float* g_nears, const float* g_fars, float* g_delta, float* g_pl_delta, void* stream) {
+  nrh::RayGenIdxArgs a;
+  const int rc = raygen_indexed_args(a, "nrh_generate_rays_indexed_backward", img_indices, h_indices, w_indices, poses, pose_stride, pls,
+                                     nrays, delta, pl_delta, ncam, cx, cy, fx, fy, near_far_from_sphere, 0.0f, 0.0f);
+  if (rc <= 0) return rc;
+  if (!img_indices || ncam == 0) return fail(NRH_E_INVALID, "nrh_generate_rays_indexed_backward: needs img_indices and ncam > 0%s", "");
+  if (!g_delta && !g_pl_delta) return NRH_OK;
+  a.g_o = g_origins; a.g_d = g_directions; a.g_pl = g_pl_positions; a.g_near = g_nears; a.g_far = g_fars;
+  a.g_delta = g_delta; a.g_pl_delta = g_pl_delta;    // accumulated INTO (caller zeroes)
+  hipLaunchKernelGGL(nrh::raygen_indexed_adjoint_kernel, dim3((unsigned)((nrays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("raygen_indexed_adjoint_kernel");
 }
 
 long long nrh_render_workspace_floats(long long nrays) {

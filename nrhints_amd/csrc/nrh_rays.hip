@@ -527,4 +527,145 @@ __global__ void raygen_kernel(const RayGenArgs a) {
   a.fars[i] = mid + 1.0f;
 }
 
+// -------------------------------------------------------------------------------------------------
+// pixel bundle -> rays with per-view refinement (camera/ray_generator.py:75-150, the training form): every ray carries its
+// own pixel (h, w), camera-to-world pose and light; `delta` [ncam,3,4] is the per-view left delta (noise then SO3xR3/SE3
+// adjustment, composed per VIEW on the host side of the boundary - ncam x 12 floats) and `pl_delta` [ncam,3] the light one.
+//   R = dR R0,  t = dt + dR t0,  d = normalize(R dir_cam),  o = t,  pl = pl0 + dpl,  near/far = chord mid-point -+ 1 | zn/zf
+// The adjoint kernel scatters d(loss)/d(delta), d(loss)/d(pl_delta) with atomics (a batch holds few distinct views).
+// -------------------------------------------------------------------------------------------------
+struct RayGenIdxArgs {
+  const long long* img;   // [n] view index or nullptr (novel views: no refinement, :103-105)
+  const float* hidx;      // [n] pixel row (float, as the reference's bundle stores them)
+  const float* widx;      // [n]
+  const float* poses;     // [n, pose_stride] row-major camera-to-world, first 12 floats used
+  const float* pls;       // [n,3]
+  const float* delta;     // [ncam,3,4] or nullptr
+  const float* pl_delta;  // [ncam,3] or nullptr
+  int pose_stride, ncam, sphere;
+  float cx, cy, fx, fy, zn, zf;
+  long long n;
+  float* origins; float* dirs; float* pl_out; float* nears; float* fars;
+  // adjoint
+  const float* g_o; const float* g_d; const float* g_pl; const float* g_near; const float* g_far;
+  float* g_delta; float* g_pl_delta;
+};
+
+__device__ __forceinline__ void raygen_idx_point(const RayGenIdxArgs& a, long long i, float R[9], float t[3], float c[3], float R0[9],
+                                                 float t0[3], int& cam) {
+  c[0] = (a.widx[i] + 0.5f - a.cx) / a.fx;
+  c[1] = -(a.hidx[i] + 0.5f - a.cy) / a.fy;
+  c[2] = -1.0f;
+  const float* P = a.poses + i * a.pose_stride;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) R0[r * 3 + k] = P[r * 4 + k];
+    t0[r] = P[r * 4 + 3];
+  }
+  cam = a.img ? (int)a.img[i] : -1;
+  if (cam >= 0 && a.delta) {
+    const float* D = a.delta + (long long)cam * 12;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) R[r * 3 + k] = D[r * 4 + 0] * R0[0 * 3 + k] + D[r * 4 + 1] * R0[1 * 3 + k] + D[r * 4 + 2] * R0[2 * 3 + k];
+      t[r] = D[r * 4 + 3] + (D[r * 4 + 0] * t0[0] + D[r * 4 + 1] * t0[1] + D[r * 4 + 2] * t0[2]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = R0[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = t0[k];
+  }
+}
+
+__global__ void raygen_indexed_kernel(const RayGenIdxArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  float R[9], t[3], c[3], R0[9], t0[3];
+  int cam;
+  raygen_idx_point(a, i, R, t, c, R0, t0, cam);
+  float d[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = c[0] * R[r * 3 + 0] + c[1] * R[r * 3 + 1] + c[2] * R[r * 3 + 2];
+  const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] /= nrm;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    a.origins[i * 3 + r] = t[r];
+    a.dirs[i * 3 + r] = d[r];
+    float p = a.pls[i * 3 + r];
+    if (cam >= 0 && a.pl_delta) p += a.pl_delta[(long long)cam * 3 + r];
+    a.pl_out[i * 3 + r] = p;
+  }
+  if (a.sphere) {
+    const float aa = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const float bb = 2.0f * (t[0] * d[0] + t[1] * d[1] + t[2] * d[2]);
+    const float mid = 0.5f * (-bb) / aa;
+    a.nears[i] = mid - 1.0f;
+    a.fars[i] = mid + 1.0f;
+  } else {
+    a.nears[i] = a.zn;
+    a.fars[i] = a.zf;
+  }
+}
+
+__global__ void raygen_indexed_adjoint_kernel(const RayGenIdxArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  float R[9], t[3], c[3], R0[9], t0[3];
+  int cam;
+  raygen_idx_point(a, i, R, t, c, R0, t0, cam);
+  if (cam < 0) return;
+  if (a.g_pl_delta && a.g_pl) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) atomicAdd(a.g_pl_delta + (long long)cam * 3 + r, a.g_pl[i * 3 + r]);
+  }
+  if (!a.g_delta) return;
+  float v[3], d[3], go[3], gd[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) v[r] = c[0] * R[r * 3 + 0] + c[1] * R[r * 3 + 1] + c[2] * R[r * 3 + 2];
+  const float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float nrm = fmaxf(len, 1e-12f);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    d[r] = v[r] / nrm;
+    go[r] = a.g_o ? a.g_o[i * 3 + r] : 0.0f;
+    gd[r] = a.g_d ? a.g_d[i * 3 + r] : 0.0f;
+  }
+  if (a.sphere && (a.g_near || a.g_far)) {
+    const float gm = (a.g_near ? a.g_near[i] : 0.0f) + (a.g_far ? a.g_far[i] : 0.0f);
+    const float aa = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const float od = t[0] * d[0] + t[1] * d[1] + t[2] * d[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {             // mid = -(o.d) / (d.d)
+      go[r] += gm * (-d[r] / aa);
+      gd[r] += gm * (-t[r] / aa + 2.0f * od * d[r] / (aa * aa));
+    }
+  }
+  // d = v / max(|v|, eps): projector (the clamp branch passes g / eps straight through)
+  float gv[3];
+  if (len >= 1e-12f) {
+    const float dg = d[0] * gd[0] + d[1] * gd[1] + d[2] * gd[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) gv[r] = (gd[r] - d[r] * dg) / nrm;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) gv[r] = gd[r] / nrm;
+  }
+  // v = dR (R0 c),  t = dt + dR t0
+  float r0c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r0c[k] = R0[k * 3 + 0] * c[0] + R0[k * 3 + 1] * c[1] + R0[k * 3 + 2] * c[2];
+  float* G = a.g_delta + (long long)cam * 12;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(G + r * 4 + k, gv[r] * r0c[k] + go[r] * t0[k]);
+    atomicAdd(G + r * 4 + 3, go[r]);
+  }
+}
+
 }  // namespace nrh

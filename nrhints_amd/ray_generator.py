@@ -3,10 +3,14 @@
 Counterpart of ``RayGenerator`` (camera/ray_generator.py:42-150) and of the two exponential maps it uses
 (camera/lie_groups.py:26-122): same config fields, same parameter / buffer names (``cam_pose_adjustment`` [V,6] as
 (translation, so(3) vector), ``pl_adjustment`` [V,3], ``cam_pose_noise``, ``pl_noise``) so optimiser groups and
-checkpoints carry over (pipelines/base_pipeline.py:35-39, 103-105).  This is the differentiable host-side form for
-training batches (a few thousand scattered pixels, ~20 tiny ops); whole evaluation views without refinement go through
-the fused HIP ray kernel (``pipeline.generate_rays``).  Gradients w.r.t. the deltas arrive through the renderer's ray
-gradients (origins / directions / pl_positions), which the HIP training path provides.
+checkpoints carry over (pipelines/base_pipeline.py:35-39, 103-105).
+
+On the GPU a bundle is one HIP launch (``nrh_generate_rays_indexed``): the per-VIEW deltas - noise, then the exp map of
+the adjustment, [V,3,4] - are composed with a handful of tiny torch ops (differentiable, V ~ 100), the per-RAY work
+(pose composition, pixel -> direction, normalisation, light offset, near/far) runs in the kernel, and its adjoint kernel
+scatters the ray gradients the HIP training path provides (origins / directions / pl_positions / nears / fars) back into
+d/d(delta) with atomics.  CPU tensors take the same formulas as torch ops (the form the CPU parity test checks against the
+reference's fixture).  Whole evaluation views without refinement use ``pipeline.generate_rays``.
 """
 from __future__ import annotations
 
@@ -17,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
 from .containers import RawPixelBundle, RayBundle
 from .pipeline import CameraModel
 
@@ -74,6 +79,45 @@ def exp_map_SE3(tangent: torch.Tensor) -> torch.Tensor:
     return torch.cat([R, t[:, :, None]], dim=-1)
 
 
+class _RaysIndexedHip(torch.autograd.Function):
+    """nrh_generate_rays_indexed / _backward (csrc/nrh_rays.hip: raygen_indexed_kernel + adjoint)."""
+
+    @staticmethod
+    def forward(ctx, delta, pl_delta, idx, h, w, poses, pls, geom):
+        lib, P = _lib.load(), _lib.ptr
+        n, dev = h.shape[0], h.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        o, d, p, near, far = new(n, 3), new(n, 3), new(n, 3), new(n, 1), new(n, 1)
+        ncam = 0 if delta is None and pl_delta is None else int((delta if delta is not None else pl_delta).shape[0])
+        cx, cy, fx, fy, sphere, zn, zf = geom
+        ctx.geom, ctx.ncam = geom, ncam
+        ctx.save_for_backward(delta, pl_delta, idx, h, w, poses, pls)
+        with torch.cuda.device(dev):
+            rc = lib.nrh_generate_rays_indexed(P(idx, torch.int64), P(h), P(w), P(poses), poses.shape[-1] * poses.shape[-2], P(pls), n,
+                                               P(delta), P(pl_delta), ncam, cx, cy, fx, fy, int(sphere), zn, zf,
+                                               P(o), P(d), P(p), P(near), P(far), _lib.stream_handle())
+        _lib.check(rc, "nrh_generate_rays_indexed")
+        return o, d, p, near, far
+
+    @staticmethod
+    def backward(ctx, go, gd, gp, gn, gf):
+        delta, pl_delta, idx, h, w, poses, pls = ctx.saved_tensors
+        lib, P = _lib.load(), _lib.ptr
+        cx, cy, fx, fy, sphere, zn, zf = ctx.geom
+        c = lambda g: None if g is None else g.contiguous().float()
+        go, gd, gp, gn, gf = c(go), c(gd), c(gp), c(gn), c(gf)
+        g_delta = torch.zeros_like(delta) if (delta is not None and ctx.needs_input_grad[0]) else None
+        g_pl = torch.zeros_like(pl_delta) if (pl_delta is not None and ctx.needs_input_grad[1]) else None
+        if g_delta is not None or g_pl is not None:
+            with torch.cuda.device(h.device):
+                rc = lib.nrh_generate_rays_indexed_backward(P(idx, torch.int64), P(h), P(w), P(poses), poses.shape[-1] * poses.shape[-2], P(pls),
+                                                            h.shape[0], P(delta), P(pl_delta), ctx.ncam, cx, cy, fx, fy, int(sphere),
+                                                            P(go), P(gd), P(gp), P(gn), P(gf), P(g_delta), P(g_pl),
+                                                            _lib.stream_handle())
+            _lib.check(rc, "nrh_generate_rays_indexed_backward")
+        return g_delta, g_pl, None, None, None, None, None, None
+
+
 class RayGenerator(nn.Module):
     """``forward(RawPixelBundle) -> RayBundle`` (camera/ray_generator.py:75-150)."""
 
@@ -106,8 +150,42 @@ class RayGenerator(nn.Module):
         dR, dt = delta[:, :3, :3], delta[:, :3, 3:]
         return dR @ R, dt + dR @ t
 
+    def view_deltas(self):
+        """Per-view left deltas, composed in the reference's order - noise first, then the adjustment (:108-121), i.e.
+        delta = exp(adjustment) o noise - as ([V,3,4] or None, [V,3] or None)."""
+        cfg, delta, pl_delta = self.config, None, None
+        if hasattr(self, "cam_pose_noise"):
+            delta = self.cam_pose_noise
+        if cfg.cam_opt_mode != "off":
+            adj = (exp_map_SO3xR3 if cfg.cam_opt_mode == "SO3xR3" else exp_map_SE3)(self.cam_pose_adjustment)
+            delta = adj if delta is None else torch.cat(self._compose(adj, delta[:, :3, :3], delta[:, :3, 3:]), dim=-1)
+        if hasattr(self, "pl_noise"):
+            pl_delta = self.pl_noise
+        if cfg.pl_opt:
+            pl_delta = self.pl_adjustment if pl_delta is None else pl_delta + self.pl_adjustment
+        return delta, pl_delta
+
+    def _forward_hip(self, pb: RawPixelBundle) -> RayBundle:
+        cam, cfg = self.camera, self.config
+        f32 = lambda t: t.detach().contiguous().float()
+        idx = None if pb.img_indices is None else pb.img_indices.detach().reshape(-1).contiguous().long()
+        delta, pl_delta = self.view_deltas() if idx is not None else (None, None)
+        if idx is not None and (delta is not None or pl_delta is not None):
+            nv = int((delta if delta is not None else pl_delta).shape[0])
+            if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= nv):
+                raise IndexError(f"img_indices out of range for {nv} views")
+        cc = lambda t: None if t is None else t.contiguous().float()
+        poses = f32(pb.poses)
+        o, d, p, near, far = _RaysIndexedHip.apply(cc(delta), cc(pl_delta), idx, f32(pb.h_indices).reshape(-1),
+                                                   f32(pb.w_indices).reshape(-1), poses, f32(pb.pls),
+                                                   (float(cam.cx), float(cam.cy), float(cam.fx), float(cam.fy),
+                                                    bool(cfg.override_near_far_from_sphere), self.zn, self.zf))
+        return RayBundle(origins=o, directions=d, pl_positions=p, nears=near, fars=far)
+
     def forward(self, pixel_bundle: RawPixelBundle) -> RayBundle:
         cam, cfg = self.camera, self.config
+        if pixel_bundle.h_indices.is_cuda:
+            return self._forward_hip(pixel_bundle)
         x = pixel_bundle.w_indices[..., 0] + 0.5        # pixel centres (:79-80)
         y = pixel_bundle.h_indices[..., 0] + 0.5
         idx = None if pixel_bundle.img_indices is None else pixel_bundle.img_indices[..., 0]

@@ -145,7 +145,9 @@ class NeuSHintRenderer(nn.Module):
 
     # ---------------------------------------------------------------------------------------------
     def _param_key(self, device):
-        return (str(device), self.precision) + tuple((id(p), p._version) for p in self.parameters())
+        # _generation: bumped by training.GraphedTrainStep after every replay (in-place updates inside a hipGraph do not
+        # advance tensor version counters)
+        return (str(device), self.precision, getattr(self, "_generation", 0)) + tuple((id(p), p._version) for p in self.parameters())
 
     def packed_params(self, device, dense=None):
         """Fold weight-norm and pack for the kernels; cached until a parameter changes.  ``dense``: the already folded
@@ -182,7 +184,17 @@ class NeuSHintRenderer(nn.Module):
                     self.dyn_scalars[0:1].copy_(torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(1))
                     inv_s = float("nan")
                 else:
-                    inv_s = float(torch.exp(variance * 10.0).clip(1e-6, 1e6).item())
+                    # one host read: 1/s, and for f16x3 whether every packed weight survived the fp16 split (|w| times the
+                    # kernels' input scaling must stay below 65504 - true for any trained NeuS net by orders of magnitude; a
+                    # checkpoint outside that range is refused instead of rendered wrong)
+                    ok = torch.ones((), device=device)
+                    if prec == 1:
+                        halves = [v for v in bufs.values() if torch.is_tensor(v) and v.dtype == torch.float16]
+                        ok = torch.stack([torch.isfinite(v).all() for v in halves]).all().to(torch.float32)
+                    inv_s, ok = torch.stack([torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(()), ok.reshape(())]).tolist()
+                    if not ok:
+                        raise ValueError("precision 'f16x3': a network weight is outside the fp16 range of the 3-term split "
+                                         "(|w| * 144.3 >= 65504); use precision='f32' for this checkpoint")
             self._packed = dict(bufs, inv_s=inv_s, precision=prec, hints=hints)
             self._packed_key = key
         return self._packed
@@ -259,7 +271,7 @@ class NeuSHintRenderer(nn.Module):
             res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints)
         else:
             res = self._render_chunks(o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints,
-                                      want_samples=True, want_maps=False, want_mid=needs_grad)
+                                      want_samples=True, want_maps=False, want_mid=needs_grad, use_dyn=needs_grad and is_training)
         rgb, depth, vis = res.get("rgb"), res["depth"], res["visibilities"]
         weights, inside, normals, nhat, cue = (res[k] for k in ("weights", "inside", "normals", "nhat", "cue"))
         mid_z, dists = res.get("mid_z"), res.get("dists")
@@ -272,13 +284,13 @@ class NeuSHintRenderer(nn.Module):
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
-                sdf_impl=self.sdf_backward, packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars)
+                sdf_impl=self.sdf_backward, packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars if is_training else None)
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],
                                 normalized_analytic_normals=core["normalized_analytic_normals"],
                                 visibilities=vis if self._hints else None, specular_cue=cue if self._hints else None)
-        s_val = torch.full((1, 1), 1.0 / pk["inv_s"], dtype=torch.float32, device=device).expand(n, T)
+        s_val = torch.full((1, 1), 1.0 / self._host_inv_s(pk, device), dtype=torch.float32, device=device).expand(n, T)
         return RenderOutput(rgb=rgb, depth=depth, weights=weights, s_val=s_val, inside_sphere=inside,
                             relax_inside_sphere=inside, analytic_normals=normals,
                             normalized_analytic_normals=nhat, visibilities=vis if self._hints else None,
@@ -315,8 +327,15 @@ class NeuSHintRenderer(nn.Module):
         out["pre"] = pre
         return out
 
+    def _host_inv_s(self, pk, device) -> float:
+        """1/s as a host float also while a captured training graph keeps it on the device (one sync; evaluation only)."""
+        if pk["inv_s"] == pk["inv_s"]:      # not NaN
+            return pk["inv_s"]
+        v = self.deviation_network.variance.detach().to(device=device, dtype=torch.float32)
+        return float(torch.exp(v * 10.0).clip(1e-6, 1e6).item())
+
     def _render_chunks(self, o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints, want_samples: bool,
-                       want_maps: bool, want_mid: bool):
+                       want_maps: bool, want_mid: bool, use_dyn: bool = False):
         """Enqueue nrh_render_forward per chunk of rays; returns a dict of freshly allocated output tensors.
         want_samples: materialise the per-sample RenderOutput fields; want_maps: the per-pixel normal maps of the
         evaluation loop; want_mid: section mid-points / lengths (for the autograd training path)."""
@@ -325,7 +344,12 @@ class NeuSHintRenderer(nn.Module):
         n = o.shape[0]
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
-        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels)
+        # the device-side scalars (1/s, cos-anneal ratio of a captured TRAINING step) are for training calls only: an
+        # evaluation render between graph replays uses 1/s of the current variance and the cos_anneal it was given
+        if not use_dyn and self.dyn_scalars is not None:
+            pk = dict(pk, inv_s=self._host_inv_s(pk, device))
+        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
+                            wide=self.wide_kernels)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))

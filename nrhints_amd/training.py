@@ -45,9 +45,10 @@ def make_optimizer(renderer: nn.Module, extra_params: Optional[Iterable[nn.Param
                    extra_lr: float = 1e-4, warm_up_end: int = 5_000, end_iter: int = 1_000_000, lr_alpha: float = 0.05):
     """Adam + LambdaLR as the reference builds them (two groups: renderer, ray-generator deltas)."""
     groups = [{"params": list(renderer.parameters()), "lr": lr}]
-    extra = list(extra_params) if extra_params is not None else []
-    if extra:
-        groups.append({"params": extra, "lr": extra_lr})
+    if extra_params is not None:
+        # the reference ALWAYS builds the second group, also when the ray generator has no parameters (cam_opt_mode "off"):
+        # pass ray_generator.parameters() so that checkpoints load in both directions (trainer/trainer.py:99-102)
+        groups.append({"params": list(extra_params), "lr": extra_lr})
     opt = torch.optim.Adam(groups)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: lr_factor(s, warm_up_end, end_iter, lr_alpha))
     return opt, sched
@@ -56,9 +57,10 @@ def make_optimizer(renderer: nn.Module, extra_params: Optional[Iterable[nn.Param
 class FlatGradAllReduce:
     """Mean all-reduce of all gradients through one flat buffer (one RCCL call per step)."""
 
-    def __init__(self, params: Iterable[nn.Parameter], group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, params: Iterable[nn.Parameter], group: Optional[dist.ProcessGroup] = None, always: bool = False):
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
+        self.always = always      # run the collective at world size 1 as well (tests of the RCCL path on one GPU)
         self._flat: Optional[torch.Tensor] = None
 
     def broadcast_parameters(self, src: int = 0) -> None:
@@ -74,7 +76,7 @@ class FlatGradAllReduce:
                 off += p.numel()
 
     def __call__(self) -> None:
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.always):
             return
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         n = sum(g.numel() for g in grads)
@@ -129,11 +131,15 @@ class GraphedTrainStep:
 
     def __init__(self, renderer, batch_rays: int, background_rgb: torch.Tensor, lr: float = 5e-4, warm_up_end: int = 5_000,
                  end_iter: int = 1_000_000, lr_alpha: float = 0.05, global_step: int = 0,
-                 grad_sync: Optional["FlatGradAllReduce"] = None, warmup_steps: int = 3):
+                 grad_sync: Optional["FlatGradAllReduce"] = None, warmup_steps: int = 3,
+                 optimizer_state: Optional[Dict] = None, jitter: Optional[tuple] = None):
+        """``jitter``: optional static buffers ``(t_rand_primary [n,1], t_rand_shadow [n,64])`` read by every replay instead
+        of the device generator's draws (reproducible runs; the parity test against the eager step overwrites them)."""
         dev = next(renderer.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs the renderer on the GPU")
         self.renderer, self.grad_sync = renderer, grad_sync
+        self.jitter = None if jitter is None else tuple(t.detach().to(dev, torch.float32).contiguous().clone() for t in jitter)
         self.sched_args = (warm_up_end, end_iter, lr_alpha)
         self.base_lr = lr
         self.lr_t = torch.tensor(lr, dtype=torch.float32, device=dev)
@@ -156,13 +162,31 @@ class GraphedTrainStep:
         self.rays.nears.copy_(mid - 1.0); self.rays.fars.copy_(mid + 1.0)
         self.gt.fill_(0.5)
         self._keys: List[str] = []
+        # the workspace pointer is baked into the graph: make it large enough for any later evaluation render as well, so
+        # that the renderer never replaces (frees) it while the graph is alive
+        renderer._workspace(dev, max(n, int(renderer.max_chunk_rays)))
+        # Warm-up passes build every cache (pack plans, constants, Adam state tensors) eagerly.  They run real optimiser
+        # steps on synthetic rays, so the parameters are put back and the Adam state is zeroed afterwards: capturing a
+        # step must not change the model or what a resumed optimiser remembers.
+        params = list(renderer.parameters())
+        keep = [p.detach().clone() for p in params]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup_steps)):      # builds every cache (pack plan, workspace, constants) eagerly
+            for _ in range(max(1, warmup_steps)):
                 self._body()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for p, k in zip(params, keep):
+                p.copy_(k)
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        if optimizer_state is not None:                 # resume: moments and step counts of a checkpointed Adam
+            self.load_optimizer_state(optimizer_state)
+        renderer._generation = getattr(renderer, "_generation", 0) + 1
         self.graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
@@ -175,7 +199,8 @@ class GraphedTrainStep:
         self.lr_t.fill_(self.base_lr * lr_factor(global_step, *self.sched_args))
 
     def _body(self) -> torch.Tensor:
-        out = self.renderer(self.rays, is_training=True, background_rgb=self.bg, global_step=self._capture_step)
+        jit = {} if self.jitter is None else dict(_t_rand_primary=self.jitter[0], _t_rand_shadow=self.jitter[1])
+        out = self.renderer(self.rays, is_training=True, background_rgb=self.bg, global_step=self._capture_step, **jit)
         losses = train_loss_dict(out, self.gt, self.renderer.config.igr_weight)
         self.optimizer.zero_grad(set_to_none=True)
         losses["loss"].backward()
@@ -198,7 +223,20 @@ class GraphedTrainStep:
             dst.copy_(src.reshape(dst.shape), non_blocking=True)
         self._set_host_scalars(global_step)
         self.graph.replay()
+        # the replay updated the parameters in place without touching their version counters: tell the renderer, so that
+        # an evaluation render between replays re-packs instead of reusing a stale pack
+        self.renderer._generation = getattr(self.renderer, "_generation", 0) + 1
         return dict(zip(self._keys, self._loss_vec.tolist()))
+
+    def load_optimizer_state(self, state: Dict) -> None:
+        """Copy the per-parameter Adam state of ``state`` (an ``optimizer.state_dict()`` of the same parameter order) into
+        the captured optimiser's tensors IN PLACE (their addresses are part of the graph)."""
+        mine = self.optimizer.state_dict()["state"]
+        with torch.no_grad():
+            for k, st in state["state"].items():
+                for name, v in st.items():
+                    if torch.is_tensor(v) and k in mine and name in mine[k]:
+                        mine[k][name].copy_(v.to(mine[k][name].device, mine[k][name].dtype).reshape(mine[k][name].shape))
 
     def release(self) -> None:
         """Back to eager operation (drops the graph and the device-side scalars)."""

@@ -315,12 +315,14 @@ def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
 def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is_training=False,
                    global_step=0, anneal_end=50_000, t_rand_primary=None, t_rand_shadow=None,
                    mode="minimal", keep_intermediates=False, differentiable=False, hints=True,
-                   analytic_normal=False, depth_max_weight=False) -> Dict[str, torch.Tensor]:
+                   analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
-    (models/neus_hint_model.py:653-751 -> render_core :475-651)."""
+    (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
+    both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
     n = o.shape[0]
     dt = o.dtype
     cos_anneal = 1.0
+    warmup = bool(is_training and global_step < geometry_warmup_end)   # :668
     if is_training and anneal_end > 0:
         cos_anneal = min(1.0, global_step / anneal_end)       # :669-671
     sample_dist = 2.0 / 64                                     # :673
@@ -351,14 +353,17 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
         else:
             depth = (mid * weights).sum(-1, keepdim=True)      # :531-533 (no_grad)
         hit = o + d * depth
-        vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode) \
-            if hints else None                                 # :546-551, :379
+        if hints and warmup:
+            vis = torch.zeros(n, 1, dtype=dt)                  # :577-579 (shadow_map = zeros)
+        else:
+            vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode) \
+                if hints else None                             # :546-551, :379
     n_hat = F.normalize(grad, dim=-1)                          # :584
     hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
     vis_s = cue_s = None
     if hints:
         with torch.no_grad():
-            cue = specular_cue(hit_n, pl, hit, d)              # :589-615 (no_grad)
+            cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :589-615 (no_grad), :617-619
         vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
         cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
     col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :621-626

@@ -162,11 +162,12 @@ def _bundle(o, d, pl, near, far):
 
 def _check_against(out, g, sfx=""):
     rgb = out.rgb.cpu().numpy()
-    # headline tolerance of the fp32 path: rgb within 1e-4 absolute and PSNR(ours, reference) >= 80 dB
-    np.testing.assert_allclose(rgb, g["rgb" + sfx], rtol=0, atol=1e-4)
+    # headline tolerance (north_star): rgb within 1e-4 absolute and PSNR(ours, reference) >= 80 dB.  The assertions sit at
+    # ~3x the reference's own fp32-vs-fp64 distance on these fixtures (rgb 1e-5, depth 6e-5, visibilities 2.5e-4)
+    np.testing.assert_allclose(rgb, g["rgb" + sfx], rtol=0, atol=3e-5)
     assert psnr(rgb, g["rgb" + sfx]) > 80.0
-    np.testing.assert_allclose(out.depth.cpu().numpy(), g["depth" + sfx], rtol=0, atol=3e-4)
-    np.testing.assert_allclose(out.visibilities.cpu().numpy(), g["visibilities" + sfx], rtol=0, atol=3e-3)
+    np.testing.assert_allclose(out.depth.cpu().numpy(), g["depth" + sfx], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out.visibilities.cpu().numpy(), g["visibilities" + sfx], rtol=0, atol=8e-4)
     assert np.mean(out.inside_sphere.cpu().numpy() != g["inside_sphere" + sfx]) < 2e-3
     for k, mean_tol, max_tol in FIELDS_PER_SAMPLE:
         diff = np.abs(getattr(out, k).cpu().numpy() - g[k + sfx])

@@ -1,0 +1,327 @@
+"""GPU parity tests, second file: the branches and kernels the first file reaches only through whole renders - geometry
+warm-up, the ray-generation kernels against the reference's fixture, the reflectance kernel and the alpha formula against the
+reference's unit vectors, hipGraph replay against the eager step, the f16x3 split under large magnitudes, and the RCCL code
+paths on one GPU (world size 1).  Everything calls through the C ABI (ctypes)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import nrhints_amd as na
+from nrhints_amd import ops, packing as pk
+from nrhints_amd.synthetic import make_rays
+from oracle import neus_oracle as orc
+from tests.conftest import load_npz
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def cu(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).float().contiguous().cuda()
+
+
+def _bundle(o, d, pl, near, far):
+    return na.RayBundle(origins=cu(o), directions=cu(d), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+
+
+def _model(state, prec="f16x3", cfg=None, train=False):
+    m = na.NeuSHintRenderer(cfg or na.NeuSModelConfig(), precision=prec)
+    m.load_state_dict({k: T(np.asarray(v)) for k, v in state.items()})
+    m = m.cuda()
+    return m if train else m.eval()
+
+
+# ---- geometry warm-up ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_geometry_warmup_vs_reference(scene_states, prec):
+    """Training below geometry_warmup_end (models/neus_hint_model.py:668, :577-579, :617-619; the Fish scene's recipe):
+    zero hints into the reflectance net, no shadow march.  Outputs, loss and parameter gradients against what the imported
+    reference produced (tests/golden/make_golden_warmup.py -> warmup_b.npz)."""
+    from nrhints_amd.training import train_loss_dict
+    g = load_npz("warmup_b.npz")
+    model = _model(scene_states["b"], prec, na.NeuSModelConfig(geometry_warmup_end=int(g["geometry_warmup_end"])), train=True)
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    out = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["global_step"]),
+                _t_rand_primary=cu(g["t_rand_primary"]))
+    assert float(out.visibilities.abs().max()) == 0.0 and float(out.specular_cue.abs().max()) == 0.0
+    np.testing.assert_allclose(out.rgb.detach().cpu().numpy(), g["rgb"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(out.depth.detach().cpu().numpy(), g["depth"], rtol=0, atol=2e-4)
+    dw = np.abs(out.weights.detach().cpu().numpy() - g["weights"])
+    assert dw.mean() < 3e-5 and dw.max() < 3e-2, (dw.mean(), dw.max())
+    loss = train_loss_dict(out, cu(g["rgb_gt"]))["loss"]
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-4)
+    loss.backward()
+    grads = dict(model.named_parameters())
+    for k in (k for k in g if k.startswith("grad.")):
+        want, got = g[k], grads[k[5:]].grad.detach().cpu().numpy()
+        scale = max(np.abs(want).max(), 1e-8)
+        # d loss / d variance is a 1e-6 scalar at this step (cos-anneal ratio 0.002): heavy cancellation, one digit
+        tol = 0.3 if k.endswith("variance") else 2e-2
+        assert np.abs(got - want).max() / scale < tol, (k, np.abs(got - want).max(), scale)
+    # evaluation never takes the warm-up branch (:668 is_training and ...)
+    with torch.no_grad():
+        ev = model(rb, is_training=False, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["global_step"]))
+    assert float(ev.visibilities.max()) > 0.0
+
+
+# ---- ray generation kernels --------------------------------------------------------------------------------------------
+def test_raygen_kernels_vs_reference_fixture():
+    """nrh_generate_rays_indexed (+ its adjoint) and nrh_generate_rays against the imported reference's RayGenerator
+    (camera/ray_generator.py:75-150 -> tests/golden/raygen.npz): off / SO3xR3 + light / SE3 / video (no view index) /
+    noise buffers / z-plane near-far; rays and the gradients of a fixed scalar w.r.t. the per-view adjustments."""
+    from nrhints_amd.containers import RawPixelBundle
+    from nrhints_amd.pipeline import CameraModel, generate_rays
+    from nrhints_amd.ray_generator import RayGenerator, RayGeneratorConfig
+    g = load_npz("raygen.npz")
+    H, W, cx, cy, fx, fy, zn, zf = g["camera"]
+    cam = CameraModel(H=int(H), W=int(W), cx=float(cx), cy=float(cy), fx=float(fx), fy=float(fy))
+    c3 = cu(g["probe"])
+    runs = {"off": (RayGeneratorConfig(), None, True),
+            "so3": (RayGeneratorConfig(cam_opt_mode="SO3xR3", pl_opt=True), None, True),
+            "se3": (RayGeneratorConfig(cam_opt_mode="SE3"), None, True),
+            "video": (RayGeneratorConfig(cam_opt_mode="SO3xR3", pl_opt=True), None, False),
+            "noise": (RayGeneratorConfig(cam_opt_mode="SO3xR3", cam_position_noise_std=0.02, cam_orientation_noise_std=0.03,
+                                         pl_position_noise_std=0.05), 11, True),
+            "zplanes": (RayGeneratorConfig(override_near_far_from_sphere=False), None, True)}
+    for tag, (cfg, seed, with_idx) in runs.items():
+        if seed is not None:
+            torch.manual_seed(seed)
+        rg = RayGenerator(cam, 5, cfg, zn=float(zn), zf=float(zf))     # noise buffers drawn on the CPU like the reference
+        if hasattr(rg, "cam_pose_adjustment"):
+            rg.cam_pose_adjustment.data.copy_(T(g["adj"]))
+        if hasattr(rg, "pl_adjustment"):
+            rg.pl_adjustment.data.copy_(T(g["pladj"]))
+        rg = rg.cuda()
+        pb = RawPixelBundle(img_indices=T(g["img_indices"]).cuda() if with_idx else None, h_indices=cu(g["h_indices"]),
+                            w_indices=cu(g["w_indices"]), poses=cu(g["poses"]), pls=cu(g["pls"]))
+        rb = rg(pb)
+        for k in ("origins", "directions", "pl_positions", "nears", "fars"):
+            np.testing.assert_allclose(getattr(rb, k).detach().cpu().numpy(), g[f"{tag}.{k}"], rtol=0, atol=3e-6, err_msg=f"{tag}.{k}")
+        names = [n for n, _ in rg.named_parameters()]
+        if names and with_idx:
+            loss = (rb.origins * c3).sum() + (rb.directions * c3.flip(0)).sum() * 2.0 + (rb.pl_positions * c3).sum() * 0.5 + \
+                   (rb.nears * rb.fars).sum() * 0.1
+            for n, gr in zip(names, torch.autograd.grad(loss, list(rg.parameters()))):
+                want = g[f"{tag}.grad.{n}"]
+                np.testing.assert_allclose(gr.cpu().numpy(), want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()),
+                                           err_msg=f"{tag}.grad.{n}")
+    # the whole-view raster kernel against the fixture's scattered pixels of each pose ...
+    for i in range(0, 40, 7):
+        h, w = int(g["h_indices"][i, 0]), int(g["w_indices"][i, 0])
+        row = generate_rays(cam, T(g["poses"][i]), T(g["pls"][i]), "cuda", row0=h, row1=h + 1)
+        for k in ("origins", "directions", "pl_positions", "nears", "fars"):
+            np.testing.assert_allclose(getattr(row, k)[w].cpu().numpy(), g[f"off.{k}"][i], rtol=0, atol=3e-6)
+    # ... and against the indexed kernel over a full image (same formulas: bit-identical)
+    hh, ww = torch.meshgrid(torch.arange(cam.H, dtype=torch.float32), torch.arange(cam.W, dtype=torch.float32), indexing="ij")
+    n = cam.H * cam.W
+    pb = RawPixelBundle(img_indices=None, h_indices=hh.reshape(n, 1).cuda(), w_indices=ww.reshape(n, 1).cuda(),
+                        poses=cu(g["poses"][3])[None].expand(n, 4, 4).contiguous(), pls=cu(g["pls"][3])[None].expand(n, 3).contiguous())
+    a, b = RayGenerator(cam, 5).cuda()(pb), generate_rays(cam, T(g["poses"][3]), T(g["pls"][3]), "cuda")
+    for k in ("origins", "directions", "pl_positions", "nears", "fars"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+
+
+def test_raygen_indexed_argument_errors():
+    from nrhints_amd import _lib
+    lib = _lib.load()
+    one = torch.zeros(16, device="cuda")
+    P = _lib.ptr
+    assert lib.nrh_generate_rays_indexed(None, P(one), P(one), P(one), 12, P(one), 1, P(one), None, 0, 0., 0., 1., 1., 1, .1, 10.,
+                                         P(one), P(one), P(one), P(one), P(one), None) == -1
+    assert "img_indices" in lib.nrh_last_error_string().decode()
+    assert lib.nrh_generate_rays_indexed(None, P(one), P(one), P(one), 8, P(one), 1, None, None, 0, 0., 0., 1., 1., 1, .1, 10.,
+                                         P(one), P(one), P(one), P(one), P(one), None) == -1
+    assert lib.nrh_generate_rays_indexed(None, None, None, None, 12, None, 0, None, None, 0, 0., 0., 1., 1., 1, .1, 10.,
+                                         None, None, None, None, None, None) == 0
+
+
+# ---- reflectance kernel and alpha formula against the reference's unit vectors --------------------------------------------
+@pytest.mark.parametrize("tag,prec", [("a", "f32"), ("b", "f32"), ("a", "f16x3"), ("b", "f16x3")])
+def test_color_kernel_vs_reference_unit_vectors(scene_states, tag, prec):
+    """color_kernel against the imported reference's ReflectanceNetwork outputs (fields/reflectance_network.py:68-96 ->
+    unit_*.npz:col_out): each of the 160 fixture points becomes one ray whose 128 samples all sit on that point
+    (origin = p - v, direction = v, t = 1)."""
+    u = load_npz(f"unit_{tag}.npz")
+    model = _model(scene_states[tag], prec)
+    packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()))
+    N = u["col_pts"].shape[0]
+    v, p = T(u["col_v"]), T(u["col_pts"])
+    rep = lambda x: x[:, None, :].expand(N, 128, x.shape[-1]).reshape(N * 128, -1).contiguous()
+    raymisc = torch.zeros(N, pk.RAYMISC_STRIDE)
+    raymisc[:, 0:27] = orc.nerf_encode(v, 4)
+    raymisc[:, 27:54] = orc.nerf_encode(T(u["col_pl"]), 4)
+    raymisc[:, 54:63] = orc.nerf_encode(T(u["col_vis"]), 4)
+    raymisc[:, 63:99] = orc.nerf_encode(T(u["col_cue"]), 4)
+    col = ops.color_eval(packed["col_w"], packed["col_b"], pk.rows_to_feat_tiles(rep(T(u["col_feat"]))).cuda(), cu(p - v), cu(v),
+                         torch.ones(N, 128).cuda(), cu(rep(T(u["col_n"]))), raymisc.cuda())
+    got = col.reshape(N, 128, 3).cpu().numpy()
+    assert np.abs(got - got[:, :1]).max() == 0.0            # the same point 128 times
+    np.testing.assert_allclose(got[:, 0], u["col_out"], rtol=0, atol=5e-6)     # sigmoid outputs in [0,1]; p - v + v rounds once
+
+
+@pytest.mark.parametrize("tag,prec", [("a", "f32"), ("b", "f32"), ("a", "f16x3"), ("b", "f16x3")])
+def test_alpha_vs_reference_unit_vectors(scene_states, tag, prec):
+    """get_alpha (models/neus_hint_model.py:339-356) against the imported reference's values (unit_*.npz:alpha_r1.0 /
+    alpha_r0.37): SDF + gradient from the HIP MLP kernel at the fixture points, alpha from the alpha kernel - sample 0 of a
+    ray has transmittance 1, so its weight IS alpha."""
+    from nrhints_amd.autograd_core import AlphaWeightsNormalsHip
+    u = load_npz(f"unit_{tag}.npz")
+    model = _model(scene_states[tag], prec)
+    packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()))
+    N = u["alpha_pts"].shape[0]
+    sdf, grad = ops.sdf_at_points(1, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], cu(u["alpha_pts"]))[:2]
+    rep = lambda x: x.reshape(N, 1, -1).expand(N, 128, x.shape[-1]).reshape(N * 128, -1).contiguous()
+    var = model.deviation_network.variance.detach()
+    inv_s = float(torch.exp(var * 10.0).clip(1e-6, 1e6))
+    for ratio in (1.0, 0.37):
+        w, _ = AlphaWeightsNormalsHip.apply(rep(sdf.reshape(N, 1)), rep(grad.reshape(N, 3)), cu(u["alpha_dirs"]),
+                                            cu(u["alpha_dists"]).expand(N, 128).contiguous(), var, inv_s, ratio)
+        want = u[f"alpha_r{ratio}"]
+        # alpha = 1 - sigmoid ratio at inv_s up to e^7: an SDF error of 1e-6 moves it by ~1e-3 * alpha near the surface
+        np.testing.assert_allclose(w[:, :1].cpu().numpy(), want, rtol=0, atol=2e-4 if prec == "f32" else 4e-4)
+
+
+# ---- hipGraph replay == eager ---------------------------------------------------------------------------------------------
+def test_graph_replay_equals_eager_step(scene_states):
+    """GraphedTrainStep against training.train_step on the same batches with the same jitter: losses of three consecutive
+    steps and the parameters after them; an evaluation render BETWEEN replays sees the replayed parameters (pack cache)."""
+    from nrhints_amd.training import GraphedTrainStep, lr_factor, train_step
+    n, lr, gs = 128, 5e-4, 30000
+    bg = torch.ones(1, 3).cuda()
+    rs = np.random.RandomState(5)
+    batches = [(_bundle(*make_rays(n, seed=40 + i, spread=0.1)), cu(rs.rand(n, 3).astype(np.float32))) for i in range(3)]
+    jit = [(cu(rs.rand(n, 1).astype(np.float32)), cu(rs.rand(n, 64).astype(np.float32))) for _ in range(3)]
+    rb_eval = _bundle(*make_rays(200, seed=77, spread=0.1))
+    # eager
+    eager = _model(scene_states["b"], train=True)
+    opt = torch.optim.Adam(eager.parameters(), lr=lr)
+    first_grads, eager_losses, eager_evals = None, [], []
+    for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):
+        for grp in opt.param_groups:
+            grp["lr"] = lr * lr_factor(gs + i, 20, 1_000_000, 0.05)
+        out = eager(rb, is_training=True, background_rgb=bg, global_step=gs + i, _t_rand_primary=tp, _t_rand_shadow=ts)
+        from nrhints_amd.training import train_loss_dict
+        losses = train_loss_dict(out, gt, eager.config.igr_weight)
+        opt.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        if first_grads is None:
+            first_grads = {k: p.grad.detach().clone() for k, p in eager.named_parameters()}
+        opt.step()
+        eager_losses.append(float(losses["loss"]))
+        with torch.no_grad():
+            eager_evals.append(eager(rb_eval, background_rgb=bg).rgb.clone())
+    # graph
+    graphed = _model(scene_states["b"], train=True)
+    before = {k: v.detach().clone() for k, v in graphed.state_dict().items()}
+    step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs,
+                            jitter=(torch.zeros(n, 1), torch.zeros(n, 64)))
+    for k, v in graphed.state_dict().items():       # capture (3 warm-up steps + graph build) leaves the model untouched
+        assert torch.equal(v, before[k]), k
+    for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):
+        step.jitter[0].copy_(tp); step.jitter[1].copy_(ts)
+        loss = step(rb, gt, global_step=gs + i)["loss"]
+        assert abs(loss - eager_losses[i]) < 2e-5 * max(1.0, abs(eager_losses[i])), (i, loss, eager_losses[i])
+        with torch.no_grad():
+            ev = graphed(rb_eval, background_rgb=bg).rgb
+        assert float((ev - eager_evals[i]).abs().max()) < 2e-4, i        # stale packs would show the capture-time weights
+    ge, gg = dict(eager.named_parameters()), dict(graphed.named_parameters())
+    for k in ge:
+        diff = (ge[k].detach() - gg[k].detach()).abs()
+        # Adam turns a gradient into +-lr whatever its size, so entries whose gradient is rounding noise may step either
+        # way; everywhere the first gradient is significant the two runs must agree to 1e-6
+        sig = first_grads[k].abs() > 1e-3 * first_grads[k].abs().max()
+        assert float(diff[sig].max()) < 1e-6, (k, float(diff[sig].max()))
+        assert float(diff.max()) <= 2.5 * 3 * lr, k
+    step.release()
+
+
+# ---- f16x3 under stress ---------------------------------------------------------------------------------------------
+def test_f16x3_large_magnitude_weights_match_or_raise(scene_states):
+    """The fp16 3-term split covers |x| < 65504 per operand with ~2^-22 relative error; fine-tuned checkpoints with large
+    weights must either still match fp32 or be refused - never silently wrong.  Scale one hidden layer's weight-norm gain
+    (activations x8 through a softplus stack) and compare the two precisions; push it past the fp16 range and expect the
+    packer to raise."""
+    st = {k: np.asarray(v).copy() for k, v in scene_states["b"].items()}
+    st["sdf_network.lin3.weight_g"] = st["sdf_network.lin3.weight_g"] * 8.0
+    st["sdf_network.lin4.weight_g"] = st["sdf_network.lin4.weight_g"] / 8.0
+    pts = cu(np.random.RandomState(3).uniform(-1, 1, size=(4096, 3)).astype(np.float32))
+    res = {}
+    for prec in ("f32", "f16x3"):
+        m = _model(st, prec)
+        packed = m.packed_params(torch.device("cuda", torch.cuda.current_device()))
+        res[prec] = ops.sdf_at_points(2, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], pts)
+    ref_sdf, ref_grad = orc.sdf_forward(orc.params_from_state(st), pts.cpu(), want_feat=False)[0], None
+    np.testing.assert_allclose(res["f32"][0].cpu().numpy().reshape(-1), ref_sdf.numpy().reshape(-1), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(res["f16x3"][0].cpu().numpy(), res["f32"][0].cpu().numpy(), rtol=0, atol=5e-6)
+    g32, g16 = res["f32"][1].cpu().numpy(), res["f16x3"][1].cpu().numpy()
+    assert np.abs(g16 - g32).max() < 2e-4 * max(1.0, np.abs(g32).max())
+    assert torch.isfinite(res["f16x3"][0]).all() and torch.isfinite(res["f16x3"][1]).all()
+    # whole render with the scaled layer: the two precisions agree to the headline tolerance
+    rb = _bundle(*make_rays(256, seed=5, spread=0.12))
+    with torch.no_grad():
+        a = _model(st, "f32")(rb, background_rgb=torch.ones(1, 3).cuda())
+        b = _model(st, "f16x3")(rb, background_rgb=torch.ones(1, 3).cuda())
+    assert float((a.rgb - b.rgb).abs().max()) < 1e-4
+    # out of range for the split: refuse
+    st2 = {k: np.asarray(v).copy() for k, v in scene_states["b"].items()}
+    st2["sdf_network.lin3.weight_g"] = st2["sdf_network.lin3.weight_g"] * 1e6
+    m = _model(st2, "f16x3")
+    with pytest.raises((ValueError, RuntimeError), match="f16x3|fp16|range"):
+        with torch.no_grad():
+            m(rb, background_rgb=torch.ones(1, 3).cuda())
+
+
+# ---- RCCL paths on one GPU ---------------------------------------------------------------------------------------------
+@pytest.fixture()
+def nccl_world1():
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_world1_render_sharded_grad_allreduce_and_graph(scene_states, nccl_world1):
+    """backend 'nccl' (= RCCL) with one rank: render_sharded's all-gather returns exactly the local render,
+    FlatGradAllReduce(always=True) runs the flat all-reduce and leaves the mean-over-1 gradients unchanged, and a
+    GraphedTrainStep with the all-reduce captured INSIDE the hipGraph replays and trains."""
+    from nrhints_amd.parallel import render_sharded
+    from nrhints_amd.training import FlatGradAllReduce, GraphedTrainStep, train_loss_dict
+    bg = torch.ones(1, 3).cuda()
+    model = _model(scene_states["b"], train=True)
+    rb = _bundle(*make_rays(1001, seed=8, spread=0.12))
+    with torch.no_grad():
+        local = model(rb, background_rgb=bg)
+        res = render_sharded(lambda r: model(r, background_rgb=bg), rb, fields=("rgb", "depth", "visibilities"))
+    for f in ("rgb", "depth", "visibilities"):
+        assert torch.equal(res[f], getattr(local, f)), f
+    n = 128
+    rb = _bundle(*make_rays(n, seed=9, spread=0.1))
+    rs = np.random.RandomState(1)
+    gt, tp, ts = (cu(rs.rand(n, k).astype(np.float32)) for k in (3, 1, 64))
+    out = model(rb, is_training=True, background_rgb=bg, global_step=30000, _t_rand_primary=tp, _t_rand_shadow=ts)
+    train_loss_dict(out, gt)["loss"].backward()
+    want = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    sync = FlatGradAllReduce(model.parameters(), always=True)
+    sync.broadcast_parameters()
+    sync()
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, want[k]), k
+    model.zero_grad(set_to_none=True)
+    step = GraphedTrainStep(model, n, bg, lr=5e-4, warm_up_end=20, global_step=30000, grad_sync=sync, jitter=(tp, ts))
+    plain = _model(scene_states["b"], train=True)
+    step2 = GraphedTrainStep(plain, n, bg, lr=5e-4, warm_up_end=20, global_step=30000, jitter=(tp, ts))
+    for i in range(3):
+        a, b = step(rb, gt, global_step=30000 + i)["loss"], step2(rb, gt, global_step=30000 + i)["loss"]
+        assert np.isfinite(a) and abs(a - b) < 2e-5 * max(1.0, abs(b)), (i, a, b)
+    step.release(); step2.release()
