@@ -75,9 +75,11 @@ class FlatGradAllReduce:
                 p.copy_(flat[off: off + p.numel()].view_as(p))
                 off += p.numel()
 
-    def __call__(self) -> None:
-        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.always):
-            return
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always)
+
+    def pack(self) -> None:
+        """Gradients -> the flat buffer (graph-capturable: plain device copies)."""
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
@@ -86,14 +88,27 @@ class FlatGradAllReduce:
         for g in grads:
             self._flat[off: off + g.numel()].copy_(g.reshape(-1))
             off += g.numel()
+
+    def reduce(self) -> None:
+        """The one collective of a step (RCCL ring over xGMI; 5.1 MB of fp32 gradients for the default networks)."""
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def unpack(self) -> None:
+        """Flat buffer / world size -> gradients (graph-capturable)."""
         self._flat.div_(dist.get_world_size(self.group))
         off = 0
-        for p, g in zip(self.params, grads):
+        for p in self.params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-            p.grad.copy_(self._flat[off: off + g.numel()].view_as(p))
-            off += g.numel()
+            p.grad.copy_(self._flat[off: off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def __call__(self) -> None:
+        if not self._active():
+            return
+        self.pack()
+        self.reduce()
+        self.unpack()
 
 
 def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, optimizer, scheduler=None,
@@ -115,9 +130,10 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
 
 
 class GraphedTrainStep:
-    """The whole optimisation step - forward, loss, backward, (gradient exchange,) Adam - captured ONCE into a hipGraph
-    and replayed: one graph launch per step instead of ~230 kernel launches issued from Python, which is what bounds
-    small batches (the reference's default is 512 rays per step, 64 per rank under 8-way DDP).
+    """The whole optimisation step - forward, loss, backward, Adam - captured ONCE into a hipGraph and replayed: one graph
+    launch per step instead of ~230 kernel launches issued from Python, which is what bounds small batches (the reference's
+    default is 512 rays per step, 64 per rank under 8-way DDP).  With a gradient exchange (``grad_sync`` and more than one
+    rank) the step is two graphs around one eager RCCL all-reduce of the flat gradient buffer.
 
     What changes between steps is read from device memory at run time: the batch (static ray / pixel buffers that
     ``__call__`` copies into), 1/s and the cos-anneal ratio (``renderer.dyn_scalars``, see NrhNet.dyn_scalars) and the
@@ -187,10 +203,28 @@ class GraphedTrainStep:
         if optimizer_state is not None:                 # resume: moments and step counts of a checkpointed Adam
             self.load_optimizer_state(optimizer_state)
         renderer._generation = getattr(renderer, "_generation", 0) + 1
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph, self.graph_tail = torch.cuda.CUDAGraph(), None
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self._loss_vec = self._body()
+        # With a process group alive its watchdog thread polls events while we capture: legal only in thread-local capture mode
+        # (in the default global mode hipEventQuery from ANY thread invalidates the capture / kills the watchdog - measured).
+        mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
+        torch.cuda.synchronize(dev)
+        if self._sync_active():
+            # The collective stays OUTSIDE the graphs: graph 1 = forward + loss + backward + gradient flattening, one eager
+            # all-reduce on the same stream, graph 2 = unflatten + Adam - three launches per step instead of one.  (A captured
+            # single-rank RCCL all-reduce does replay on this stack, profiles/r02/rccl_graph_probe.log, but a collective inside
+            # a graph ties the replay to the communicator's lifetime and to RCCL's capture support per version; eager is the
+            # form that is correct by construction for the 8-GPU runs that cannot be rehearsed here.)
+            with torch.cuda.graph(self.graph, **mode):
+                self._loss_vec = self._body(upto="pack")
+            self.grad_sync.reduce()
+            self.graph_tail = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(self.graph_tail, pool=self.graph.pool(), **mode):
+                self._body(upto="tail")
+        else:
+            with torch.cuda.graph(self.graph, **mode):
+                self._loss_vec = self._body()
 
     def _set_host_scalars(self, global_step: int) -> None:
         cfg = self.renderer.config
@@ -198,17 +232,41 @@ class GraphedTrainStep:
         self.renderer.dyn_scalars[1:2].fill_(cos)
         self.lr_t.fill_(self.base_lr * lr_factor(global_step, *self.sched_args))
 
-    def _body(self) -> torch.Tensor:
-        jit = {} if self.jitter is None else dict(_t_rand_primary=self.jitter[0], _t_rand_shadow=self.jitter[1])
-        out = self.renderer(self.rays, is_training=True, background_rgb=self.bg, global_step=self._capture_step, **jit)
-        losses = train_loss_dict(out, self.gt, self.renderer.config.igr_weight)
-        self.optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
-        if self.grad_sync is not None:
-            self.grad_sync()
+    def _sync_active(self) -> bool:
+        return self.grad_sync is not None and self.grad_sync._active()
+
+    def _body(self, upto: str = "all") -> Optional[torch.Tensor]:
+        """One step; ``upto``: "all" (eager warm-up / single graph), "pack" (graph 1 of the split form: through gradient
+        flattening), "tail" (graph 2: unflatten + Adam)."""
+        sync = self._sync_active()
+        vec = None
+        if upto != "tail":
+            jit = {} if self.jitter is None else dict(_t_rand_primary=self.jitter[0], _t_rand_shadow=self.jitter[1])
+            # The forward runs on fresh leaf ALIASES of the parameters (same storage) and the gradients come from
+            # torch.autograd.grad.  A parameter's AccumulateGrad node is cached together with the stream it was first used on;
+            # a model that trained eagerly on the default stream before (and whose old autograd graph is still referenced
+            # somewhere) would make the engine synchronise the capture stream with the default stream - measured: a segfault
+            # at capture end when an RCCL process group is alive (profiles/r02/rccl_graph_probe_before_fix.log).
+            named = [(n, p) for n, p in self.renderer.named_parameters()]
+            alias = {n: p.detach().requires_grad_(p.requires_grad) for n, p in named}
+            out = torch.func.functional_call(self.renderer, alias, args=(self.rays,),
+                                             kwargs=dict(is_training=True, background_rgb=self.bg, global_step=self._capture_step, **jit))
+            losses = train_loss_dict(out, self.gt, self.renderer.config.igr_weight)
+            live = [(p, alias[n]) for n, p in named if p.requires_grad]
+            for (p, _), g in zip(live, torch.autograd.grad(losses["loss"], [a for _, a in live], allow_unused=True)):
+                p.grad = g
+            self._keys = list(losses)
+            vec = torch.stack([losses[k].detach().float().reshape(()) for k in self._keys])
+            if sync:
+                self.grad_sync.pack()
+            if upto == "pack":
+                return vec
+        if sync:
+            if upto == "all":
+                self.grad_sync.reduce()
+            self.grad_sync.unpack()
         self.optimizer.step()
-        self._keys = list(losses)
-        return torch.stack([losses[k].detach().float().reshape(()) for k in self._keys])
+        return vec
 
     def __call__(self, ray_bundle, rgb_gt: torch.Tensor, global_step: int) -> Dict[str, float]:
         n = self.gt.shape[0]
@@ -223,6 +281,9 @@ class GraphedTrainStep:
             dst.copy_(src.reshape(dst.shape), non_blocking=True)
         self._set_host_scalars(global_step)
         self.graph.replay()
+        if self.graph_tail is not None:
+            self.grad_sync.reduce()
+            self.graph_tail.replay()
         # the replay updated the parameters in place without touching their version counters: tell the renderer, so that
         # an evaluation render between replays re-packs instead of reusing a stale pack
         self.renderer._generation = getattr(self.renderer, "_generation", 0) + 1
@@ -240,7 +301,7 @@ class GraphedTrainStep:
 
     def release(self) -> None:
         """Back to eager operation (drops the graph and the device-side scalars)."""
-        self.graph = None
+        self.graph = self.graph_tail = None
         self.renderer.dyn_scalars = None
 
 

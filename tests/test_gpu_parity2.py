@@ -186,34 +186,39 @@ def test_alpha_vs_reference_unit_vectors(scene_states, tag, prec):
 
 # ---- hipGraph replay == eager ---------------------------------------------------------------------------------------------
 def test_graph_replay_equals_eager_step(scene_states):
-    """GraphedTrainStep against training.train_step on the same batches with the same jitter: losses of three consecutive
-    steps and the parameters after them; an evaluation render BETWEEN replays sees the replayed parameters (pack cache)."""
-    from nrhints_amd.training import GraphedTrainStep, lr_factor, train_step
+    """GraphedTrainStep against the eager step (training.train_step's sequence) on the same batches with the same jitter:
+    losses of three consecutive steps and the parameters after them; an evaluation render BETWEEN replays sees the replayed
+    parameters (pack cache).  The yardstick for "equal" is a SECOND eager run: the backward kernels accumulate with atomics,
+    and Adam turns a gradient into a step of ~lr whatever its size, so run-to-run rounding noise of small gradient entries is
+    amplified (entries that are pure noise may even step the other way, 2 lr per step)."""
+    from nrhints_amd.training import GraphedTrainStep, lr_factor, train_loss_dict
     n, lr, gs = 128, 5e-4, 30000
     bg = torch.ones(1, 3).cuda()
     rs = np.random.RandomState(5)
     batches = [(_bundle(*make_rays(n, seed=40 + i, spread=0.1)), cu(rs.rand(n, 3).astype(np.float32))) for i in range(3)]
     jit = [(cu(rs.rand(n, 1).astype(np.float32)), cu(rs.rand(n, 64).astype(np.float32))) for _ in range(3)]
     rb_eval = _bundle(*make_rays(200, seed=77, spread=0.1))
-    # eager
-    eager = _model(scene_states["b"], train=True)
-    opt = torch.optim.Adam(eager.parameters(), lr=lr)
-    first_grads, eager_losses, eager_evals = None, [], []
-    for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):
-        for grp in opt.param_groups:
-            grp["lr"] = lr * lr_factor(gs + i, 20, 1_000_000, 0.05)
-        out = eager(rb, is_training=True, background_rgb=bg, global_step=gs + i, _t_rand_primary=tp, _t_rand_shadow=ts)
-        from nrhints_amd.training import train_loss_dict
-        losses = train_loss_dict(out, gt, eager.config.igr_weight)
-        opt.zero_grad(set_to_none=True)
-        losses["loss"].backward()
-        if first_grads is None:
-            first_grads = {k: p.grad.detach().clone() for k, p in eager.named_parameters()}
-        opt.step()
-        eager_losses.append(float(losses["loss"]))
+
+    def run_eager():
+        model = _model(scene_states["b"], train=True)
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
         with torch.no_grad():
-            eager_evals.append(eager(rb_eval, background_rgb=bg).rgb.clone())
-    # graph
+            evals, losses = [model(rb_eval, background_rgb=bg).rgb.clone()], []
+        for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):
+            for grp in opt.param_groups:
+                grp["lr"] = lr * lr_factor(gs + i, 20, 1_000_000, 0.05)
+            out = model(rb, is_training=True, background_rgb=bg, global_step=gs + i, _t_rand_primary=tp, _t_rand_shadow=ts)
+            ld = train_loss_dict(out, gt, model.config.igr_weight)
+            opt.zero_grad(set_to_none=True)
+            ld["loss"].backward()
+            opt.step()
+            losses.append(float(ld["loss"].detach()))
+            with torch.no_grad():
+                evals.append(model(rb_eval, background_rgb=bg).rgb.clone())
+        return losses, evals, {k: p.detach().clone() for k, p in model.named_parameters()}
+
+    e_losses, e_evals, e_params = run_eager()
+    e2_losses, e2_evals, e2_params = run_eager()
     graphed = _model(scene_states["b"], train=True)
     before = {k: v.detach().clone() for k, v in graphed.state_dict().items()}
     step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs,
@@ -223,18 +228,22 @@ def test_graph_replay_equals_eager_step(scene_states):
     for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):
         step.jitter[0].copy_(tp); step.jitter[1].copy_(ts)
         loss = step(rb, gt, global_step=gs + i)["loss"]
-        assert abs(loss - eager_losses[i]) < 2e-5 * max(1.0, abs(eager_losses[i])), (i, loss, eager_losses[i])
+        assert abs(loss - e_losses[i]) < 2e-5 * max(1.0, abs(e_losses[i])) + 3 * abs(e_losses[i] - e2_losses[i]), (i, loss, e_losses[i])
         with torch.no_grad():
             ev = graphed(rb_eval, background_rgb=bg).rgb
-        assert float((ev - eager_evals[i]).abs().max()) < 2e-4, i        # stale packs would show the capture-time weights
-    ge, gg = dict(eager.named_parameters()), dict(graphed.named_parameters())
-    for k in ge:
-        diff = (ge[k].detach() - gg[k].detach()).abs()
-        # Adam turns a gradient into +-lr whatever its size, so entries whose gradient is rounding noise may step either
-        # way; everywhere the first gradient is significant the two runs must agree to 1e-6
-        sig = first_grads[k].abs() > 1e-3 * first_grads[k].abs().max()
-        assert float(diff[sig].max()) < 1e-6, (k, float(diff[sig].max()))
-        assert float(diff.max()) <= 2.5 * 3 * lr, k
+        # a stale pack would render the previous step's weights: the distance to the eager model at the SAME step must be
+        # far below one step's change, and no larger than a few times what two eager runs show between themselves
+        d_same, d_step = (ev - e_evals[i + 1]).abs(), (ev - e_evals[i]).abs()
+        d_noise = (e2_evals[i + 1] - e_evals[i + 1]).abs()
+        assert float(d_same.mean()) < 0.02 * float(d_step.mean()), (i, float(d_same.mean()), float(d_step.mean()))
+        assert float(d_same.mean()) < 3 * float(d_noise.mean()) + 2e-6 and float(d_same.max()) < 3 * float(d_noise.max()) + 2e-4, \
+            (i, float(d_same.mean()), float(d_noise.mean()), float(d_same.max()), float(d_noise.max()))
+    for k, p in graphed.named_parameters():
+        diff, noise = (p.detach() - e_params[k]).abs(), (e2_params[k] - e_params[k]).abs()
+        assert float(diff.mean()) < 3 * float(noise.mean()) + 1e-6, (k, float(diff.mean()), float(noise.mean()))
+        assert float(diff.max()) <= 2.5 * 3 * lr, (k, float(diff.max()))
+        moved = (p.detach() - before[k]).abs()
+        assert float(diff.mean()) < 0.02 * float(moved.mean()) + 1e-8, (k, float(diff.mean()), float(moved.mean()))
     step.release()
 
 
