@@ -143,8 +143,10 @@ class Window:
     def frag(self, s, part):
         return f"fa{(s % (self.pf + 1)) * 2 + part}"
 
-    def emit(self, out, slots_ops, ind="  ", dma=None):
-        """dma: {slot: [piece, ...]} - W32_DMA(piece) calls (LDS-DMA of a later block) issued in that slot"""
+    def emit(self, out, slots_ops, ind="  ", dma=None, head=None):
+        """dma: {slot: [piece, ...]} - W32_DMA(piece) calls (LDS-DMA of a later block) issued in that slot.
+        head: list of op lists emitted between the first LDS reads and the first MFMA (VALU work in the LDS latency: a SIMD
+        does not overlap one wave's VALU with its MFMAs anyway, so what sits here is free up to that latency)."""
         ks, pf = self.ks, self.pf
         dma = dma or {}
         nbuf = (pf + 1) * 2
@@ -165,6 +167,10 @@ class Window:
         for s in range(min(pf, ks)):
             ds(s, 0)
             ds(s, 1)
+        for ops in (head or []):
+            if ops:
+                emit_ops(out, ops, ind)
+                out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
         slot = 0
         for s in range(ks):
             for j in range(3):
@@ -202,6 +208,11 @@ class Window:
 
 
 DMA_SLOTS16 = {2 + 3 * k: [k] for k in range(8)}     # regular window: one piece of block n + 2 after the last MFMA of K steps 0..7
+
+
+# VALU ops placed ahead of a window's first MFMA, in HEAD_SLOTS dependency levels of HEAD_OPS each (see Window.emit)
+HEAD_SLOTS = int(os.environ.get("NRH32_HEAD_SLOTS", "0"))
+HEAD_OPS = int(os.environ.get("NRH32_HEAD_OPS", "10"))
 
 
 def acc_names(c):
@@ -246,7 +257,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             if kind == "rev":
                 out.append('    asm volatile("" : "+v"(qpa), "+v"(qpb));')
                 out.append("    nrh32::u32x4 pqa = qpa, pqb = qpb;")
-        epi = None
+        epi, head = None, None
         if has_epi:
             ob = out_base if c > 0 else in_base          # the previous stage's output set is this stage's input set
             if kind == "fwd":
@@ -280,11 +291,16 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             if c == 0 and not small:
                 budget0 = budget
                 budget = lambda k: (budget0(k) if k < 41 else 0)
-            slots, tail = schedule(epi, nslots, budget)
+            if HEAD_SLOTS and not small:
+                b1 = budget
+                slots, tail = schedule(epi, HEAD_SLOTS + nslots, lambda k: HEAD_OPS if k < HEAD_SLOTS else b1(k - HEAD_SLOTS))
+                head, slots = slots[:HEAD_SLOTS], slots[HEAD_SLOTS:]
+            else:
+                slots, tail = schedule(epi, nslots, budget)
             assert not (c == 0 and not small and tail), "pending epilogue does not fit ahead of K step 14"
         else:
             slots, tail = None, []
-        win.emit(out, slots, "    ", dma=dma)
+        win.emit(out, slots, "    ", dma=dma, head=head)
         if tail:
             out.append("    // epilogue work that did not fit the MFMA shadows")
             emit_ops(out, tail, "    ")

@@ -187,10 +187,11 @@ def test_alpha_vs_reference_unit_vectors(scene_states, tag, prec):
 # ---- hipGraph replay == eager ---------------------------------------------------------------------------------------------
 def test_graph_replay_equals_eager_step(scene_states):
     """GraphedTrainStep against the eager step (training.train_step's sequence) on the same batches with the same jitter:
-    losses of three consecutive steps and the parameters after them; an evaluation render BETWEEN replays sees the replayed
-    parameters (pack cache).  The yardstick for "equal" is a SECOND eager run: the backward kernels accumulate with atomics,
-    and Adam turns a gradient into a step of ~lr whatever its size, so run-to-run rounding noise of small gradient entries is
-    amplified (entries that are pure noise may even step the other way, 2 lr per step)."""
+    losses of three consecutive steps, the gradients and the parameters after every step; an evaluation render BETWEEN
+    replays sees the replayed parameters (pack cache).  The eager side uses the same optimiser arithmetic as the graph
+    (torch's capturable Adam, tensor lr): with it the replay reproduces the eager step to the last bit, while torch's default
+    Adam differs from its own capturable form by 1 ulp after one step - which the renderer then amplifies (a sample crossing
+    the surface changes sensitive gradient entries by ~1 %; profiles/r02/graph_vs_eager_probe.log)."""
     from nrhints_amd.training import GraphedTrainStep, lr_factor, train_loss_dict
     n, lr, gs = 128, 5e-4, 30000
     bg = torch.ones(1, 3).cuda()
@@ -198,27 +199,9 @@ def test_graph_replay_equals_eager_step(scene_states):
     batches = [(_bundle(*make_rays(n, seed=40 + i, spread=0.1)), cu(rs.rand(n, 3).astype(np.float32))) for i in range(3)]
     jit = [(cu(rs.rand(n, 1).astype(np.float32)), cu(rs.rand(n, 64).astype(np.float32))) for _ in range(3)]
     rb_eval = _bundle(*make_rays(200, seed=77, spread=0.1))
-
-    def run_eager():
-        model = _model(scene_states["b"], train=True)
-        opt = torch.optim.Adam(model.parameters(), lr=lr)
-        with torch.no_grad():
-            evals, losses = [model(rb_eval, background_rgb=bg).rgb.clone()], []
-        for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):
-            for grp in opt.param_groups:
-                grp["lr"] = lr * lr_factor(gs + i, 20, 1_000_000, 0.05)
-            out = model(rb, is_training=True, background_rgb=bg, global_step=gs + i, _t_rand_primary=tp, _t_rand_shadow=ts)
-            ld = train_loss_dict(out, gt, model.config.igr_weight)
-            opt.zero_grad(set_to_none=True)
-            ld["loss"].backward()
-            opt.step()
-            losses.append(float(ld["loss"].detach()))
-            with torch.no_grad():
-                evals.append(model(rb_eval, background_rgb=bg).rgb.clone())
-        return losses, evals, {k: p.detach().clone() for k, p in model.named_parameters()}
-
-    e_losses, e_evals, e_params = run_eager()
-    e2_losses, e2_evals, e2_params = run_eager()
+    eager = _model(scene_states["b"], train=True)
+    lr_t = torch.tensor(lr, device="cuda")
+    opt = torch.optim.Adam([{"params": list(eager.parameters()), "lr": lr_t}], capturable=True)
     graphed = _model(scene_states["b"], train=True)
     before = {k: v.detach().clone() for k, v in graphed.state_dict().items()}
     step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs,
@@ -226,24 +209,25 @@ def test_graph_replay_equals_eager_step(scene_states):
     for k, v in graphed.state_dict().items():       # capture (3 warm-up steps + graph build) leaves the model untouched
         assert torch.equal(v, before[k]), k
     for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):
+        lr_t.fill_(lr * lr_factor(gs + i, 20, 1_000_000, 0.05))
+        out = eager(rb, is_training=True, background_rgb=bg, global_step=gs + i, _t_rand_primary=tp, _t_rand_shadow=ts)
+        ld = train_loss_dict(out, gt, eager.config.igr_weight)
+        opt.zero_grad(set_to_none=True)
+        ld["loss"].backward()
+        grads = {k: p.grad.detach().clone() for k, p in eager.named_parameters()}
+        opt.step()
         step.jitter[0].copy_(tp); step.jitter[1].copy_(ts)
         loss = step(rb, gt, global_step=gs + i)["loss"]
-        assert abs(loss - e_losses[i]) < 2e-5 * max(1.0, abs(e_losses[i])) + 3 * abs(e_losses[i] - e2_losses[i]), (i, loss, e_losses[i])
+        assert abs(loss - float(ld["loss"].detach())) <= 1e-6 * abs(loss), (i, loss, float(ld["loss"].detach()))
+        for k, p in graphed.named_parameters():
+            scale = float(grads[k].abs().max()) + 1e-30
+            assert float((p.grad - grads[k]).abs().max()) <= 1e-6 * scale, (i, k)
+            assert float((p.detach() - dict(eager.named_parameters())[k].detach()).abs().max()) <= 2e-7, (i, k)
         with torch.no_grad():
-            ev = graphed(rb_eval, background_rgb=bg).rgb
-        # a stale pack would render the previous step's weights: the distance to the eager model at the SAME step must be
-        # far below one step's change, and no larger than a few times what two eager runs show between themselves
-        d_same, d_step = (ev - e_evals[i + 1]).abs(), (ev - e_evals[i]).abs()
-        d_noise = (e2_evals[i + 1] - e_evals[i + 1]).abs()
-        assert float(d_same.mean()) < 0.02 * float(d_step.mean()), (i, float(d_same.mean()), float(d_step.mean()))
-        assert float(d_same.mean()) < 3 * float(d_noise.mean()) + 2e-6 and float(d_same.max()) < 3 * float(d_noise.max()) + 2e-4, \
-            (i, float(d_same.mean()), float(d_noise.mean()), float(d_same.max()), float(d_noise.max()))
-    for k, p in graphed.named_parameters():
-        diff, noise = (p.detach() - e_params[k]).abs(), (e2_params[k] - e_params[k]).abs()
-        assert float(diff.mean()) < 3 * float(noise.mean()) + 1e-6, (k, float(diff.mean()), float(noise.mean()))
-        assert float(diff.max()) <= 2.5 * 3 * lr, (k, float(diff.max()))
-        moved = (p.detach() - before[k]).abs()
-        assert float(diff.mean()) < 0.02 * float(moved.mean()) + 1e-8, (k, float(diff.mean()), float(moved.mean()))
+            ev, ev_e = graphed(rb_eval, background_rgb=bg).rgb, eager(rb_eval, background_rgb=bg).rgb
+        assert float((ev - ev_e).abs().max()) < 2e-6, i            # a stale pack would render the previous step's weights
+    moved = max(float((p.detach() - before[k]).abs().max()) for k, p in graphed.named_parameters())
+    assert moved > 2 * lr
     step.release()
 
 
