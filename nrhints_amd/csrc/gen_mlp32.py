@@ -72,7 +72,7 @@ def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE"):
         if want_d:
             ops.append(Op(f"uint32_t qq{i} = nrh32::unorm16x2(q{2 * i}, q{2 * i + 1});", defs=(f"qq{i}",),
                           uses=(f"q{2 * i}", f"q{2 * i + 1}")))
-            if i % 4 == 3:
+            if i % 4 == 3 and not os.environ.get("NRH32_NOQSTORE"):      # (timing ablation: WRONG RESULTS)
                 w = [f"qq{i - 3 + k}" for k in range(4)]
                 ops.append(Op(f"{qstore}({c}, {i // 4}, (nrh32::u32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
     return ops
@@ -134,8 +134,11 @@ class Window:
     b_src 'agpr': B operands are a[4s..] / a[64+4s..];  'vgpr': u32x4 expressions (bh(s), bl(s)) given by name pattern.
     hh_init: name of an f32x16 holding the start values (compiler-visible LDS loads), or None for zero."""
 
-    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa", cd=None, use_ds=True, in_base=0):
+    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa", cd=None, use_ds=True, in_base=0,
+                 acc_all=False, bias=None):
         self.ks, self.hh, self.cc, self.b_src, self.bvar, self.hh_zero, self.pf, self.wa = ks, hh, cc, b_src, bvar, hh_zero, pf, wa
+        self.acc_all = acc_all  # every MFMA accumulates (hh and cc already hold partial sums)
+        self.bias = bias        # (a_word, b_quad): one extra MFMA hh += {a_word,0,0,0} * b_quad ahead of the last K step (the bias row, see gen_stage)
         self.in_base = in_base  # AGPR set holding the B operands: 0 (a[0:127]) or 128 (a[128:255])
         self.cd = cd            # third accumulator (A_lo * B_hi products) - no back-to-back dependent MFMAs; None: they go to cc
         self.use_ds = use_ds    # False: micro-benchmarks without LDS traffic (fragments stay whatever they are)
@@ -158,7 +161,10 @@ class Window:
             issued.append((s, part))
             if not self.use_ds:
                 return
-            out.append(ind + f'asm volatile("ds_read_b128 %0, %1 offset:{off}" : "=v"({self.frag(s, part)}) : "v"({self.wa}));')
+            # "memory": compiler-visible LDS loads (the bias word) stay where they are written - one that hipcc sinks between
+            # these reads would become one of the "N youngest" the K loop's lgkmcnt(N) waits deliberately leave in flight
+            clob = ' : "memory"' if self.bias else ""
+            out.append(ind + f'asm volatile("ds_read_b128 %0, %1 offset:{off}" : "=v"({self.frag(s, part)}) : "v"({self.wa}){clob});')
 
         def wait_for(s, part):
             idx = issued.index((s, part))
@@ -173,6 +179,14 @@ class Window:
                 out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
         slot = 0
         for s in range(ks):
+            if self.bias and s == ks - 1:
+                # The bias word is a compiler-visible LDS load from the top of the window; hipcc waits for it with lgkmcnt(0)
+                # (it cannot see the asm reads), which is free HERE: the last K step needs every outstanding fragment anyway.
+                # Not after the K loop: an MFMA result must not be the window's last write to hh (the next window's VALU
+                # reads follow within the 11 wait states when no barrier separates the windows - measured on layer 0).
+                out.append(ind + f"{{ const nrh32::u32x4 ba_ = {{{self.bias[0]}, 0u, 0u, 0u}};")
+                out.append(ind + f'  asm volatile("{MFMA} %0, %1, %2, %0" : "+v"({self.hh}) : "v"(ba_), "v"({self.bias[1]})); }}')
+                out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
             for j in range(3):
                 # weight fragments of K step s + pf go out in the first two slots of step s (their buffer was last read by
                 # the MFMAs of step s - 1, all issued by now)
@@ -180,7 +194,7 @@ class Window:
                     ds(s + pf, j)
                 part = 1 if j == 2 else 0
                 acc = self.hh if j == 0 else (self.cd if (j == 2 and self.cd) else self.cc)
-                first = (s == 0 and (j == 1 or (j == 2 and self.cd) or (j == 0 and self.hh_zero)))
+                first = (s == 0 and (j == 1 or (j == 2 and self.cd) or (j == 0 and self.hh_zero))) and not self.acc_all
                 w = wait_for(s, 1)           # one wait per K step: both fragments (hi was issued first) before the first MFMA
                 bpart = 1 if j == 1 else 0   # j=1: A_hi * B_lo, j=2: A_lo * B_hi
                 pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j == 0 and self.use_ds) else ""
@@ -220,7 +234,7 @@ def acc_names(c):
     return ("hp", "cp") if c == 7 else (f"hh{c}", f"cc{c}")
 
 
-def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pend_in=True):
+def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pend_in=True, bias_mfma=False, skip=False):
     """A pipelined 8-chunk stage, ping-pong form: B operands from AGPR set `in_base`, results into set `out_base`; no copy.
     Window c runs the K loop of chunk c and the epilogue of chunk c - 1; window 0 runs the epilogue of the PREVIOUS stage's
     chunk 7 (pending in hp, cp [, qpa, qpb]), whose outputs are this stage's K steps 14 and 15 - they are only read by the
@@ -269,7 +283,9 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             # LDS-DMA pieces in flight); they are older than this window's 8 pieces: the next W32_SYNC covers them
             qa, qb = qn(c)
             out.append(f"    W32_QLOAD_ASM({qa}, {c}, 0); W32_QLOAD_ASM({qb}, {c}, 1);")
-        if not hh_zero:
+        if bias_mfma:
+            out.append(f"    const uint32_t bw = W32_BIAS({c});")
+        elif not hh_zero:
             out.append(f"    {hh} = W32_HINIT({c});")
         out.append("    const uint32_t wa = W32_WADDR()" + (f" + {(c % 4) * 8192};" if small else ";"))
         if epi is not None:
@@ -279,7 +295,8 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
                 pa, pb = ("pqa", "pqb") if c == 0 else qn(prev)
                 out.append(f'    asm volatile("" : "+v"({pa}), "+v"({pb}));')
                 out.append(f"    const nrh32::u32x4 qw0 = {pa}, qw1 = {pb};")
-        win = Window(ks, hh, cc, b_src=b_src, hh_zero=hh_zero, in_base=in_base)
+        win = Window(ks, hh, cc, b_src=b_src, hh_zero=(hh_zero or bias_mfma), in_base=in_base,
+                     bias=(("bw", "W32_BCONST") if bias_mfma else None))
         if small:
             dma = {2: [2 * (c % 4)], 5: [2 * (c % 4) + 1]}
         else:
@@ -304,6 +321,8 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         if tail:
             out.append("    // epilogue work that did not fit the MFMA shadows")
             emit_ops(out, tail, "    ")
+        if skip:
+            out.append(f"    W32_SKIP({c}, {hh}, {cc});")
         if not small or c % 4 == 3:
             out.append("    W32_NEXT();")
         out.append("  }")
@@ -337,12 +356,13 @@ def gen_finish(kind, want_d, out_base):
     return "\n".join(out) + "\n"
 
 
-def gen_kloop(ks, b_src, hh_zero, in_base=128):
+def gen_kloop(ks, b_src, hh_zero, in_base=128, acc_all=False):
     """K loop only (no fillers): for the light stages whose epilogue is written by hand after it.  Needs hh, cc, wa; the
     16-step form consumes a streamed block and therefore also issues the 8 LDS-DMA pieces of block n + 2 (W32_DMA)."""
     out = [f"// generated by gen_mlp32.py: bare K loop ks={ks} b={b_src}", "{"]
-    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero, in_base=in_base).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
-    out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh), "+v"(cc));   // MFMA results -> VALU reads: 11 wait states')
+    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero, in_base=in_base, acc_all=acc_all).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
+    if not acc_all:
+        out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh), "+v"(cc));   // MFMA results -> VALU reads: 11 wait states')
     out.append("}")
     return "\n".join(out) + "\n"
 
@@ -396,13 +416,15 @@ def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen32")
     os.makedirs(outdir, exist_ok=True)
     nv = int(os.environ.get("NRH32_NV", "4"))
+    bm = True      # bias through one extra MFMA per window (see gen_stage); the older start-value form is gone from the kernel
+    nohinit = bool(os.environ.get("NRH32_NOHINIT"))      # timing ablation (WRONG RESULTS): forward windows start from zero
     files = {
-        "l0_d0.inc": gen_stage("fwd", False, 3, "vgpr", 10, False, in_base=0, out_base=0, pend_in=False),
-        "l0_d1.inc": gen_stage("fwd", True, 3, "vgpr", 10, False, in_base=0, out_base=0, pend_in=False),
-        "fwd_d0_p0.inc": gen_stage("fwd", False, 16, "agpr", nv, False, in_base=0, out_base=128),
-        "fwd_d0_p1.inc": gen_stage("fwd", False, 16, "agpr", nv, False, in_base=128, out_base=0),
-        "fwd_d1_p0.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, False, in_base=0, out_base=128),
-        "fwd_d1_p1.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, False, in_base=128, out_base=0),
+        "l0_d0.inc": gen_stage("fwd", False, 3, "vgpr", 10, False, in_base=0, out_base=0, pend_in=False, bias_mfma=bm),
+        "l0_d1.inc": gen_stage("fwd", True, 3, "vgpr", 10, False, in_base=0, out_base=0, pend_in=False, bias_mfma=bm),
+        "fwd_d0_p0.inc": gen_stage("fwd", False, 16, "agpr", nv, nohinit, in_base=0, out_base=128, bias_mfma=bm),
+        "fwd_d0_p1.inc": gen_stage("fwd", False, 16, "agpr", nv, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
+        "fwd_d1_p0.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, nohinit, in_base=0, out_base=128, bias_mfma=bm),
+        "fwd_d1_p1.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
         "fwd_fin_d0.inc": gen_finish("fwd", False, 128),
         "fwd_fin_d1.inc": gen_finish("fwd", True, 128),
         "rev_p0.inc": gen_stage("rev", True, 16, "agpr", nv, True, in_base=0, out_base=128),
@@ -411,6 +433,7 @@ def main():
         "kloop16.inc": gen_kloop(16, "agpr", False),
         "kloop16z.inc": gen_kloop(16, "agpr", True),
         "kloop3v.inc": gen_kloop(3, "vgpr", False),
+        "kloop3v_acc.inc": gen_kloop(3, "vgpr", False, acc_all=True),
         "t7.inc": gen_t7(),
     }
     for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc"):

@@ -158,7 +158,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // diagnosis: shader cycles per stage family, summed over this wave's passes -> dbg[wave-global][8] (uint64)
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_readcyclecounter();
-#define NRH32_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+// (s_memtime is an SMEM read: it returns out of order with LDS reads, so nothing of it may be in flight when a K loop starts
+// counting its LDS reads with lgkmcnt(N) - hence the drain after every stamp)
+#define NRH32_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define NRH32_STAMP(k) do { } while (0)
 #endif
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // block after it), so one static wait serves every window; the barrier makes the other waves' pieces visible and tells
     // them that this wave is done with the previous block (whose slot the next pieces overwrite)
 #ifdef NRH32_TIMING
-#define W32_SYNC() do { const unsigned long long s0_ = __builtin_readcyclecounter(); chunk_sync<8>(); tacc[7] += __builtin_readcyclecounter() - s0_; } while (0)
+#define W32_SYNC() do { const unsigned long long s0_ = __builtin_readcyclecounter(); chunk_sync<8>(); tacc[7] += __builtin_readcyclecounter() - s0_; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define W32_SYNC() chunk_sync<8>()
 #endif
@@ -209,22 +211,36 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // ... no copies.  The last chunk of every stage stays PENDING in (hp, cp): its epilogue runs in the MFMA shadows of the
     // next stage's first window (its outputs are that stage's K steps 14 and 15, needed last).
     f32x16 hp, cp;
-    // start values: the bias table, and for layer 4 the skip part E4 * emb on top (9 MFMAs per chunk over resident weights)
-    auto hinit = [&](int layer, int c) {
-      f32x16 hh = tab_init(layer, c);
-      if (layer == 4) {
-        f32x16 cc;
-        const uint32_t wa = ring_lds + LDS_RESIDENT + c * 6144 + lane16;   // resident E4 chunk c: 3 K steps
-#include "gen32/kloop3v.inc"
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hh[r] = __builtin_fmaf(cc[r], LO_UNSCALE, hh[r]);
-        asm volatile("s_nop 4" : "+v"(hh));   // VALU results -> MFMA SrcC
-      }
-      return hh;
+    // Every layer's windows start from zero and take their bias through one extra MFMA (gen_mlp32.py gen_stage, bias_mfma):
+    // table rows 0..7 hold one packed fp16 pair per output row, (b_hi | b_lo * 2^11 << 16), and the B operand is the constant
+    // [1, 2^-11, 0, ...] of the hf = 0 lanes.
+    const u32x4 bconst = {hf ? 0u : 0x10003c00u, 0u, 0u, 0u};
+    const char* const brow = tabs + (lane & 31) * 4;
+    // layer 4's skip part: E4 * emb on top of the window's sums, 9 MFMAs over the resident block (B operands in VGPRs)
+    auto skip_e4 = [&](int c, f32x16& hh, f32x16& cc) {
+      const uint32_t wa = ring_lds + LDS_RESIDENT + c * 6144 + lane16;   // resident E4 chunk c: 3 K steps
+#include "gen32/kloop3v_acc.inc"
     };
-#define W32_QSTORE(c, half, val) __builtin_nontemporal_store((val), scr_at(qlayer, c, half))
-#define W32_QSTORE_P(c, half, val) __builtin_nontemporal_store((val), scr_at(qlayer - 1, c, half))
-#define W32_HINIT(c) hinit(qlayer, c)
+#define W32_BIAS(c) (*reinterpret_cast<const uint32_t*>(brow + qlayer * 1024 + (c) * 128))
+#define W32_BCONST bconst
+#define W32_SKIP(c, HH, CC) do { if (qlayer == 4) skip_e4(c, HH, CC); } while (0)
+// cache policy of the sigma' scratch (128 KiB per wave, rewritten every pass): NRH32_QPOL bit 0 = plain (temporal) stores,
+// bit 1 = plain loads; default: plain stores, non-temporal loads (measured -2 % against non-temporal stores, profiles/r02/qpol_ab.log)
+#ifndef NRH32_QPOL
+#define NRH32_QPOL 1
+#endif
+#if NRH32_QPOL & 1
+#define W32_QST_(val, p) (*(p) = (val))
+#else
+#define W32_QST_(val, p) __builtin_nontemporal_store((val), (p))
+#endif
+#if NRH32_QPOL & 2
+#define W32_QLD_NT ""
+#else
+#define W32_QLD_NT " nt"
+#endif
+#define W32_QSTORE(c, half, val) W32_QST_((val), scr_at(qlayer, c, half))
+#define W32_QSTORE_P(c, half, val) W32_QST_((val), scr_at(qlayer - 1, c, half))
     // ---- L0 ----
     {
       const int qlayer = 0;
@@ -264,7 +280,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
       (void)qlayer;
     }
-#undef W32_HINIT
+#undef W32_BIAS
+#undef W32_BCONST
+#undef W32_SKIP
 #undef W32_QSTORE
 #undef W32_QSTORE_P
 
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const char* const q7base = uni(scr + 7 * 16384);
       // nt: served by L2; asm: the destination registers are written straight by the load (no compiler copy of a value still
       // in flight), the wait is in t7.inc
-#define W32_QLOAD7_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(lane16), "s"(q7base + ((c) * 2 + (half)) * 1024))
+#define W32_QLOAD7_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2" W32_QLD_NT : "=v"(dst) : "v"(lane16), "s"(q7base + ((c) * 2 + (half)) * 1024))
 #define W32_A8(c) tab_init(10, c)
       W32_QLOAD7_ASM(qpa, 7, 0);
       W32_QLOAD7_ASM(qpb, 7, 1);
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
       // ---- R7..R1 ----
       // q words of chunk c of layer l - 1: asm loads (invisible to hipcc's vmcnt bookkeeping), nt: served by L2
-#define W32_QLOAD_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(lane16), "s"(qbase + (c) * 2048), "n"((half) * 1024))
+#define W32_QLOAD_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" W32_QLD_NT : "=v"(dst) : "v"(lane16), "s"(qbase + (c) * 2048), "n"((half) * 1024))
       // R7 R6 | R5 R4 R4e | R3 R2 | R1 finish R0: odd layers read set 0 / write set 1, even layers the other way round, so both
       // embedding-gradient stages (after R4: t_4 is R4's input; after R1: t_0) read set 1 - one copy of emb_stage in the code
       for (int k = 0; k < 4; ++k) {

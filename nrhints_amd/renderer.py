@@ -190,7 +190,7 @@ class NeuSHintRenderer(nn.Module):
                     ok = torch.ones((), device=device)
                     if prec == 1:
                         halves = [v for v in bufs.values() if torch.is_tensor(v) and v.dtype == torch.float16]
-                        ok = torch.stack([torch.isfinite(v).all() for v in halves]).all().to(torch.float32)
+                        ok = torch.stack([torch.isfinite(v).all() for v in halves] + [packing32.tables_in_f16_range(d)]).all().to(torch.float32)
                     inv_s, ok = torch.stack([torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(()), ok.reshape(())]).tolist()
                     if not ok:
                         raise ValueError("precision 'f16x3': a network weight is outside the fp16 range of the 3-term split "

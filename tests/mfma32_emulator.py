@@ -118,7 +118,21 @@ def unorm16(q):
 
 def sdf32_tile(stream16, tables, pts, mode, trace=None):
     """One 32-point tile through the MODE `mode` stream.  pts [32,3] float64.  -> sdf [32], grad [32,3] | None, feat | None."""
-    tables = np.asarray(tables, dtype=np.float64)
+    raw = np.ascontiguousarray(np.asarray(tables, dtype=np.float32))
+    tables = raw.astype(np.float64)
+    # rows 0..7: one packed fp16 pair per output row, (b_hi | b_lo * 2^11 << 16); the kernel adds it through one extra MFMA
+    # with the B column [1, 2^-11, 0, ...]
+    bits = raw.view(np.uint32)
+    bias_hi = (bits & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+    bias_lo = (bits >> 16).astype(np.uint16).view(np.float16).astype(np.float64)
+
+    def bias_mfma(l, c):
+        out = np.zeros((16, 64))
+        for r in range(16):
+            row = 32 * c + frow(r, HF)
+            out[r] = bias_hi[l][row] + bias_lo[l][row] / 2048.0
+        return out
+
     st = Stream(stream16)
     x3 = pts * 3.0
     x3l = x3[J]                                    # per lane
@@ -148,7 +162,10 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
             qs[(layer, c)] = unorm16(1.0 / p)
         return np.maximum(np.log2(p), t)
 
-    u = [epi_fwd(0, c, *kloop(st.chunk(4), 3, ebh, ebl, tab_init(tables, 0, c))) for c in range(8)]
+    u = []
+    for c in range(8):
+        hh, cc = kloop(st.chunk(4), 3, ebh, ebl, np.zeros((16, 64)))
+        u.append(epi_fwd(0, c, hh + bias_mfma(0, c), cc))
     if trace is not None:
         trace['u'] = [u]
     for l in range(1, 8):
@@ -156,11 +173,12 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
         nu = []
         for c in range(8):
             main = st.chunk(16)
-            init = tab_init(tables, l, c)
-            if l == 4:       # the skip part: resident E4 * emb on top of the bias
-                hh, cc = kloop(e4[c], 3, ebh, ebl, init)
-                init = hh + cc / 2048.0
-            nu.append(epi_fwd(l, c, *kloop(main, 16, bh, bl, init)))
+            hh, cc = kloop(main, 16, bh, bl, np.zeros((16, 64)))
+            hh = hh + bias_mfma(l, c)
+            if l == 4:       # the skip part: resident E4 * emb on top of the window's sums
+                h2, c2 = kloop(e4[c], 3, ebh, ebl, np.zeros((16, 64)))
+                hh, cc = hh + h2, cc + c2
+            nu.append(epi_fwd(l, c, hh, cc))
         u = nu
         if trace is not None:
             trace['u'].append(u)
