@@ -42,10 +42,10 @@ def split_ops(i, v0, v1, out_hi, out_lo, pfx=""):
     n = f"{pfx}{i}"
     ops = [
         Op(f"nrh32::h16x2 hi{n} = __builtin_amdgcn_cvt_pkrtz({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1)),
-        Op(f"float H{n}a = {v0} * nrh32::LO_SCALE;", defs=(f"H{n}a",), uses=(v0,)),
-        Op(f"float H{n}b = {v1} * nrh32::LO_SCALE;", defs=(f"H{n}b",), uses=(v1,)),
-        Op(f"float R{n}a = __builtin_fmaf((float)hi{n}.x, -nrh32::LO_SCALE, H{n}a);", defs=(f"R{n}a",), uses=(f"hi{n}", f"H{n}a")),
-        Op(f"float R{n}b = __builtin_fmaf((float)hi{n}.y, -nrh32::LO_SCALE, H{n}b);", defs=(f"R{n}b",), uses=(f"hi{n}", f"H{n}b")),
+        # the residual goes out UNSCALED (v_fma_mix_f32 on the packed fp16): fp16 subnormals are honoured by the MFMA, and an
+        # activation below 2^-3 loses nothing that matters in absolute terms (|error| <= 2^-25), see nrh_mlp32.h
+        Op(f"float R{n}a = __builtin_fmaf((float)hi{n}.x, -1.0f, {v0});", defs=(f"R{n}a",), uses=(f"hi{n}", v0)),
+        Op(f"float R{n}b = __builtin_fmaf((float)hi{n}.y, -1.0f, {v1});", defs=(f"R{n}b",), uses=(f"hi{n}", v1)),
         Op(f"nrh32::h16x2 lo{n} = __builtin_amdgcn_cvt_pkrtz(R{n}a, R{n}b);", defs=(f"lo{n}",), uses=(f"R{n}a", f"R{n}b")),
         aput(out_hi, f"hi{n}"),
         aput(out_lo, f"lo{n}"),
@@ -192,11 +192,14 @@ class Window:
                 # the MFMAs of step s - 1, all issued by now)
                 if s + pf < ks and j < 2:
                     ds(s + pf, j)
-                part = 1 if j == 2 else 0
-                acc = self.hh if j == 0 else (self.cd if (j == 2 and self.cd) else self.cc)
-                first = (s == 0 and (j == 1 or (j == 2 and self.cd) or (j == 0 and self.hh_zero))) and not self.acc_all
+                # j = 0: A_hi * B_hi -> hh;  j = MID: A_lo * B_hi (A_lo is scaled by 2^11) -> cc;  the other: A_hi * B_lo (B_lo is
+                # unscaled) -> hh.  MID = 1 keeps the two hh updates of a K step apart (no back-to-back dependent MFMAs).
+                lo_a = (j == MID)
+                part = 1 if lo_a else 0
+                acc = (self.cd if self.cd else self.cc) if lo_a else self.hh
+                first = (s == 0 and (lo_a or (j == 0 and self.hh_zero))) and not self.acc_all
                 w = wait_for(s, 1)           # one wait per K step: both fragments (hi was issued first) before the first MFMA
-                bpart = 1 if j == 1 else 0   # j=1: A_hi * B_lo, j=2: A_lo * B_hi
+                bpart = 1 if (j > 0 and not lo_a) else 0
                 pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j == 0 and self.use_ds) else ""
                 if self.b_src == "agpr":
                     base = self.in_base + 4 * s + (64 if bpart else 0)
@@ -224,6 +227,7 @@ class Window:
 DMA_SLOTS16 = {2 + 3 * k: [k] for k in range(8)}     # regular window: one piece of block n + 2 after the last MFMA of K steps 0..7
 
 
+MID = int(os.environ.get("NRH32_MID", "1"))      # which of a K step's three MFMAs is the A_lo one (see Window.emit)
 # VALU ops placed ahead of a window's first MFMA, in HEAD_SLOTS dependency levels of HEAD_OPS each (see Window.emit)
 HEAD_SLOTS = int(os.environ.get("NRH32_HEAD_SLOTS", "0"))
 HEAD_OPS = int(os.environ.get("NRH32_HEAD_OPS", "10"))

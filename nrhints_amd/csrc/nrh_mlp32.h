@@ -57,28 +57,14 @@ constexpr float KK = 6.9314718055994530942e-3f;  // ln 2 / 100
 __host__ __device__ constexpr int frow(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 __host__ __device__ constexpr int col32(int s, int hf, int i) { return 16 * s + (i & 3) + 8 * (i >> 2) + 4 * hf; }
 
-// ---- AGPR residency: values that are only ever MFMA B operands ----
-__device__ __forceinline__ uint32_t a_put(uint32_t v) {
-  uint32_t r;
-  asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
-  return r;
-}
-__device__ __forceinline__ uint32_t a_mov(uint32_t a) {
-  uint32_t r;
-  asm("v_accvgpr_mov_b32 %0, %1" : "=a"(r) : "a"(a));
-  return r;
-}
-
-// Activations of one layer for this wave's 32 points as MFMA B operands: K step s <- h[4s..4s+3] (hi), l[4s..4s+3] (lo)
-struct ActA {
-  uint32_t h[64], l[64];
-};
-
-// x = hi + lo / 2^11, two values per register
+// Activations as MFMA B operands: x = hi + lo with the residual lo UNSCALED (fp16 subnormals are honoured by the MFMA on
+// gfx950, profiles/r01/denorm.log; |x - hi - lo| <= max(2^-22 |x|, 2^-25)), two values per register.  Weights (A operands)
+// keep lo scaled by 2^11 in the packed stream, so a product is hh += A_hi B_hi + A_hi B_lo and cc += A_lo B_hi with cc in
+// units of 2^-11 (one fused multiply-add joins them in the epilogue).
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-  const float ra = __builtin_fmaf((float)h.x, -LO_SCALE, a * LO_SCALE);   // v_fma_mix_f32 on the packed fp16
-  const float rb = __builtin_fmaf((float)h.y, -LO_SCALE, b * LO_SCALE);
+  const float ra = __builtin_fmaf((float)h.x, -1.0f, a);   // v_fma_mix_f32 on the packed fp16; exact
+  const float rb = __builtin_fmaf((float)h.y, -1.0f, b);
   const h16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
   hi = __builtin_bit_cast(uint32_t, h);
   lo = __builtin_bit_cast(uint32_t, l);
@@ -135,33 +121,6 @@ __device__ __forceinline__ f32x16 ld_init(const char* base, int gstride) {
     v[4 * g + 0] = x[0]; v[4 * g + 1] = x[1]; v[4 * g + 2] = x[2]; v[4 * g + 3] = x[3];
   }
   return v;
-}
-
-// K loop of one chunk: hh += Ahi * Bhi, cc += Ahi * Blo + Alo * Bhi  (cc is scaled by 2^11)
-template <int KS>
-__device__ __forceinline__ void kloop(const char* wb, const ActA& in, f32x16& hh, f32x16& cc, int lane) {
-  const u32x4* A = reinterpret_cast<const u32x4*>(wb) + lane;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const u32x4 ah = A[(2 * s) * 64], al = A[(2 * s + 1) * 64];
-    const u32x4 bhu = {in.h[4 * s], in.h[4 * s + 1], in.h[4 * s + 2], in.h[4 * s + 3]};
-    const u32x4 blu = {in.l[4 * s], in.l[4 * s + 1], in.l[4 * s + 2], in.l[4 * s + 3]};
-    const f16x8 bh = __builtin_bit_cast(f16x8, bhu), bl = __builtin_bit_cast(f16x8, blu);
-    hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), bh, hh, 0, 0, 0);
-    cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), bl, cc, 0, 0, 0);
-    cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), bh, cc, 0, 0, 0);
-  }
-}
-
-// interleave request to the machine scheduler for one fused window: per MFMA, NV VALU and (2 of 3 times) one ds_read
-template <int NMFMA, int NV>
-__device__ __forceinline__ void pipeline_hint() {
-#pragma unroll
-  for (int i = 0; i < NMFMA; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // MFMA
-    if (i % 3 != 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);         // VALU
-  }
 }
 
 }  // namespace nrh32

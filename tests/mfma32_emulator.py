@@ -36,7 +36,7 @@ def mfma_32x32x16(a, b, c):
 def split16(x):
     with np.errstate(over="ignore"):
         hi = x.astype(np.float16)
-        lo = ((x - hi.astype(np.float64)) * 2048.0).astype(np.float16)
+        lo = (x - hi.astype(np.float64)).astype(np.float16)      # activations: unscaled residual (fp16 subnormals count)
     return hi.astype(np.float64), lo.astype(np.float64)
 
 
@@ -87,8 +87,8 @@ def kloop(chunk, ks, bh, bl, hh):
     for s in range(ks):
         ah, al = chunk[s, 0], chunk[s, 1]
         hh = mfma_32x32x16(ah, bh[s], hh)
-        cc = mfma_32x32x16(ah, bl[s], cc)
-        cc = mfma_32x32x16(al, bh[s], cc)
+        hh = mfma_32x32x16(ah, bl[s], hh)          # B_lo is unscaled
+        cc = mfma_32x32x16(al, bh[s], cc)          # A_lo is scaled by 2^11
     return hh, cc
 
 
