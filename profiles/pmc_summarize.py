@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = row["Kernel_Name"].split("(")[0][-40:]
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(agg):
-    if "nrh::" not in k: continue
+    if "nrh" not in k: continue
     print(k)
     for c in sorted(agg[k]):
         v = agg[k][c]

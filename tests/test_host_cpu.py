@@ -272,3 +272,42 @@ def test_marching_tetrahedra_sphere_is_a_closed_oriented_manifold():
     assert abs(((a - c) * np.cross(b - c, d - c)).sum() / 6 - 4 / 3 * np.pi * rad ** 3) < 0.01 * 4 / 3 * np.pi * rad ** 3
     v0, f0 = marching_tetrahedra(u - 10.0, 0.0)
     assert v0.shape == (0, 3) and f0.shape == (0, 3)
+
+
+def test_integration_md_matches_the_binding():
+    """INTEGRATION.md §2 is the stub a maintainer copies: its NrhNet field list, the ABI revision, the argument count of its
+    nrh_render_forward call and its symbol table must agree with nrhints_amd/_lib.py (which the other tests check against
+    the built library and include/nrhints_hip.h)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"class NrhNet\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n", text, re.S).group(1)
+    fields = re.findall(r'\("(\w+)", ctypes\.(\w+)\)', block)
+    want = [(n, t.__name__) for n, t in _lib.NrhNet._fields_]
+    assert fields == want, (fields, want)
+    # the header declares the struct with the same members in the same order
+    hdr = open(os.path.join(root, "include", "nrhints_hip.h")).read()
+    body = re.search(r"typedef struct NrhNet \{(.*?)\} NrhNet;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    members = re.findall(r"(\w+)\s*;", body)
+    assert members == [n for n, _ in want], members
+    lib = _lib.load()
+    assert int(re.search(r"lib\.nrh_version\(\) == (\d+)", text).group(1)) == lib.nrh_version()
+    call = re.search(r"lib\.nrh_render_forward\((.*?)\)\nassert rc == 0", text, re.S).group(1)
+    call = re.sub(r"#[^\n]*", "", call)
+    depth, nargs, cur = 0, 0, ""
+    for ch in call:                      # top-level commas
+        depth += ch in "([" 
+        depth -= ch in ")]"
+        if ch == "," and depth == 0:
+            nargs += bool(cur.strip()); cur = ""
+        else:
+            cur += ch
+    nargs += bool(cur.strip())
+    assert nargs == len(lib.nrh_render_forward.argtypes), nargs
+    ctor = re.search(r"net = NrhNet\((.*?)\)\n", text).group(1)
+    assert len([a for a in re.split(r",\s*(?![^()]*\))", ctor) if a.strip()]) == len(want)
+    table = text[text.index("| C symbol | replaces |"):]
+    table = table[:table.index("\n\n")]
+    documented = set(re.findall(r"`(nrh_\w+)`", table))
+    assert documented == set(_lib.EXPORTED), (documented ^ set(_lib.EXPORTED))
