@@ -1,13 +1,12 @@
-"""Differentiable ``render_core`` on the GPU with torch autograd - the interim training path.
+"""Differentiable ``render_core``: what the loss differentiates, as autograd Functions over HIP kernels.
 
-The hand-written HIP kernels cover everything the reference evaluates WITHOUT a graph: the two hierarchical samplers,
-the 128-sample shadow march, depth / hit point and the specular cue (models/neus_hint_model.py:697, :531, :379, :589 -
-57 % of a training step's forward FLOPs).  What the loss differentiates - SDF + feature + d sdf/dx at the 128 section
-mid-points, alpha compositing and the reflectance net (:504-510, :521-525, :583-587, :626-637) - runs here as torch ops
-on the same device (rocBLAS GEMMs, autograd incl. the double backward through d sdf/dx) until the HIP backward kernels
-exist.  The mid-points, section lengths, visibility and cue arrive from the HIP call as constants.
-
-This is GPU PyTorch, not a CPU fallback, and it is only entered when a gradient is actually requested.
+The graph-less stages (both hierarchical samplers, the 128-sample shadow march, depth / hit point, specular cue:
+models/neus_hint_model.py:697, :531, :379, :589) run in ``nrh_render_forward_train``; this module wires the differentiable
+part - SDF + feature + d sdf/dx at the 128 section mid-points, alpha compositing and the reflectance net (:504-510,
+:521-525, :583-587, :626-637) - out of ``SdfValueFeatGradHip`` (sdf_function.py), ``AlphaWeightsNormalsHip`` and
+``ColorNetHip`` (forward and adjoint kernels, dW as rocBLAS split-K GEMMs).  What is left to torch ops: the per-ray
+encodings (tiny; they carry the ray gradients for pose refinement), ``rgb = sum w c + bg (1 - sum w)`` and the loss.
+It is only entered when a gradient is requested, and only on the GPU.
 """
 from __future__ import annotations
 
@@ -202,74 +201,28 @@ def _col_index(device, hints: bool):
     return _COL_INDEX[key]
 
 
-def _sdf_net(d: Dict[str, torch.Tensor], pts: torch.Tensor):
-    e = _enc(pts * 3.0, 6)
-    h = e
-    for l in range(8):
-        if l == 4:
-            h = torch.cat([h, e], dim=1) / math.sqrt(2.0)
-        h = F.softplus(F.linear(h, d[f"sdf_w{l}"], d[f"sdf_b{l}"]), beta=100)
-    return F.linear(h, d["sdf_head_w"], d["sdf_head_b"]) / 3.0, F.linear(h, d["feat_w"], d["feat_b"])
-
-
-def _color_net_torch(d, feat, pts, normal, per_ray, n, T, hints):
-    """Reflectance net in torch ops, layer 0 by column blocks of the reference's 361-wide input
-      [pts 0:3 | enc(view) 3:30 | normal 30:33 | enc(pl) 33:60 | feat 60:316 | enc(vis) 316:325 | enc(cue) 325:361]
-    (fields/reflectance_network.py:77-82): the view / light / visibility / cue encodings are constant along a ray, so
-    their contribution is one [N,99] x [99,256] product broadcast over the 128 samples instead of a 361-wide
-    concatenation per sample; autograd carries the ray gradients through the small per-ray part."""
-    w0, b0 = d["col_w0"], d["col_b0"]
-    ray_cols, pn_cols = _col_index(w0.device, hints)
-    x = _linear(feat, w0[:, 60:316], b0)                                                   # [P,256] the big block
-    x = x + _linear(torch.cat([pts, normal], dim=-1), w0[:, pn_cols], torch.zeros_like(b0))  # per-sample 6 columns
-    x = (x.reshape(n, T, -1) + (torch.cat(per_ray, dim=-1) @ w0[:, ray_cols].t())[:, None, :]).reshape(n * T, -1)
-    x = torch.relu(x)
-    for l in range(1, 5):
-        x = _linear(x, d[f"col_w{l}"], d[f"col_b{l}"])
-        if l < 4:
-            x = torch.relu(x)
-    return torch.sigmoid(x).reshape(n, T, 3)
-
-
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
-                background_rgb, analytic_normal: bool = False, sdf_impl: str = "manual", packed=None, pre=None, dyn=None) -> Dict[str, torch.Tensor]:
-    """``d``: weight-norm-folded dense parameters WITH autograd history (packing.dense_params on the live
-    nn.Parameters); mid_z / dists [N,128], vis [N,1], cue [N,4]: graph-less results of the HIP forward."""
+                background_rgb, analytic_normal: bool = False, packed=None, pre=None, dyn=None) -> Dict[str, torch.Tensor]:
+    """``d``: weight-norm-folded dense parameters WITH autograd history (packing.dense_params* on the live nn.Parameters);
+    mid_z / dists [N,128], vis [N,1], cue [N,4]: graph-less results of the HIP forward; ``packed``: the kernel buffers of the
+    same parameters.  Every network evaluation and its adjoint is a HIP kernel (there is no torch formulation in here; the
+    ones the kernels are tested against are tests/torch_backends.py)."""
+    if packed is None or packed.get("col_wt") is None:
+        raise ValueError("render_core needs the packed parameters incl. the transposed reflectance weights")
     n, T = mid_z.shape
     pts = (o[:, None, :] + dirs[:, None, :] * mid_z[..., None]).reshape(-1, 3)
-    if sdf_impl == "autograd":      # the reference's formulation: second-order autograd graph (kept for A/B tests)
-        if not pts.requires_grad:
-            pts.requires_grad_(True)
-        sdf, feat = _sdf_net(d, pts)
-        (grad,) = torch.autograd.grad(sdf, pts, torch.ones_like(sdf), create_graph=True, retain_graph=True)
-    else:                           # hand-derived backward (sdf_function.py): no double-backward graph
-        sdf, feat, grad = sdf_value_feat_grad(d, pts, impl=sdf_impl, packed=packed, pre=pre)
+    sdf, feat, grad = sdf_value_feat_grad(d, pts, packed=packed, pre=pre)
     inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
-    if sdf_impl == "hip" and packed is not None:
-        # alpha, transmittance product, weights and unit normals: one HIP kernel forward, one for the adjoint
-        weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal, dyn)
-    else:
-        view = dirs[:, None, :].expand(n, T, 3).reshape(-1, 3)
-        true_cos = (view * grad).sum(-1, keepdim=True)
-        iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + F.relu(-true_cos) * cos_anneal)
-        dd = dists.reshape(-1, 1)
-        c_prev = torch.sigmoid((sdf - iter_cos * dd * 0.5) * inv_s)
-        c_next = torch.sigmoid((sdf + iter_cos * dd * 0.5) * inv_s)
-        alpha = ((c_prev - c_next + 1e-5) / (c_prev + 1e-5)).clip(0.0, 1.0).reshape(n, T)
-        trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
-        weights = alpha * trans
-        n_hat = F.normalize(grad, dim=-1)
+    # alpha, transmittance product, weights and unit normals: one HIP kernel forward, one for the adjoint
+    weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal, dyn)
     # per-ray part of the reflectance input: encodings of view direction, light position, visibility hint, specular cue
     per_ray = [_enc(dirs, 4), _enc(pl, 4)]
     if vis is not None:  # vis / cue are None for the pl-naive model (no hints)
         per_ray += [_enc(vis, 4), _enc(cue, 4)]
     normal = grad if analytic_normal else n_hat
-    if sdf_impl == "hip" and packed is not None and packed.get("col_wt") is not None:
-        # reflectance net: forward and adjoint sweep in the HIP register-chain kernels, dW as split-K GEMMs
-        col = ColorNetHip.apply(feat, pts, normal, torch.cat(per_ray, dim=-1), packed,
-                                *[d[f"col_w{l}"] for l in range(5)], *[d[f"col_b{l}"] for l in range(5)]).reshape(n, T, 3)
-    else:
-        col = _color_net_torch(d, feat, pts, normal, per_ray, n, T, vis is not None)
+    # reflectance net: forward and adjoint sweep in the HIP register-chain kernels, dW as split-K GEMMs
+    col = ColorNetHip.apply(feat, pts, normal, torch.cat(per_ray, dim=-1), packed,
+                            *[d[f"col_w{l}"] for l in range(5)], *[d[f"col_b{l}"] for l in range(5)]).reshape(n, T, 3)
     rgb = (col * weights[..., None]).sum(1)
     if background_rgb is not None:
         rgb = rgb + background_rgb * (1.0 - weights.sum(-1, keepdim=True))

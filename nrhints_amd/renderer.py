@@ -106,10 +106,6 @@ class NeuSHintRenderer(nn.Module):
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
     precision = "f16x3"
     wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
-    # backward of (sdf, feat, d sdf/dx): "manual" = hand-derived sweeps in torch ops, "hip" = the same sweeps in the HIP
-    # register-chain kernels (forward included), "autograd" = second-order autograd graph like the reference (A/B only)
-    sdf_backward = "hip"
-    # largest training batch whose saved arrays (60 KB per sample point, fwd + bwd, both networks) are kept in one piece: 8192 rays = 63 GB
     max_fused_train_rays = 8192
     # hipGraph mode (training.GraphedTrainStep): a device tensor [inv_s, cos_anneal] that the kernels read at run time
     # instead of the host floats baked into a captured launch; None = normal (eager) operation
@@ -266,7 +262,7 @@ class NeuSHintRenderer(nn.Module):
             on_gpu_f32 = all(p.is_cuda and p.dtype == torch.float32 for p in named.values())
             dense = packing.dense_params_hip(named) if on_gpu_f32 else packing.dense_params(named)
             self.packed_params(device, dense=dense)
-        fused_train = needs_grad and self.sdf_backward == "hip" and n <= self.max_fused_train_rays
+        fused_train = needs_grad and n <= self.max_fused_train_rays
         if fused_train:
             res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints)
         else:
@@ -284,7 +280,7 @@ class NeuSHintRenderer(nn.Module):
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
-                sdf_impl=self.sdf_backward, packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars if is_training else None)
+                packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars if is_training else None)
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],

@@ -1,5 +1,5 @@
-"""``SdfValueFeatGrad`` - a torch.autograd.Function for (sdf, feature, d sdf/dx) of the SDF network with a HAND-DERIVED
-backward, so that the training step needs no second-order autograd graph.
+"""``SdfValueFeatGradHip`` - a torch.autograd.Function for (sdf, feature, d sdf/dx) of the SDF network with a HAND-DERIVED
+backward in HIP kernels, so that the training step needs no second-order autograd graph.
 
 Why: the loss reaches the network through three outputs - the value (alpha), the feature (colour net) and the spatial
 gradient g = d sdf/dx (alpha's cosine, the unit normal fed to the colour net, the eikonal term).  The reference obtains
@@ -11,11 +11,10 @@ g with ``autograd.grad(create_graph=True)`` and lets autograd differentiate that
       * one REVERSE sweep of value adjoints with a coupling term   zbar_l = s'_l * hbar_l + s''_l * a_{l+1} * tbar_l
       * two plain GEMMs per layer for the weights:   dW_l = zbar_l^T x_l + t_l^T abar_l        (t_l = s'_l * a_{l+1})
 
-with s' = sigmoid(100 z), s'' = 100 s'(1 - s'), a_l the reverse-chain values of the forward pass.  Everything is a
-chain of 256-wide GEMMs with elementwise epilogues - the structure of the HIP register-chain kernels - plus library
-GEMMs for dW.  This file is the reference implementation of that backward in torch ops (GEMMs on rocBLAS); the forward
-runs in the HIP kernel when the inputs are on the GPU (``use_hip=True``).  DESIGN.md §8 tracks moving the two sweeps
-into HIP as well.
+with s' = sigmoid(100 z), s'' = 100 s'(1 - s'), a_l the reverse-chain values of the forward pass.  Forward and both sweeps
+are the HIP register-chain kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are rocBLAS
+GEMMs over the saved row-major arrays.  The same maths in plain torch ops - the reference the kernels are tested against -
+lives with the tests (tests/torch_backends.py), not in the product.
 """
 from __future__ import annotations
 
@@ -63,110 +62,6 @@ def _colsum(x3: torch.Tensor) -> torch.Tensor:
     L, P, C = x3.shape
     S = math.gcd(P, 64)
     return x3.reshape(L, S, P // S, C).sum(2).sum(1)
-
-
-class SdfValueFeatGrad(torch.autograd.Function):
-    """forward(pts [P,3], W0..W7, b0..b7, ws [1,256], bs [1], Wf [256,256], bf [256]) -> sdf [P,1], feat [P,256], g [P,3].
-    Weights are the dense (weight-norm-folded) matrices of ``packing.dense_params``; W4 is the UNSCALED layer-4 matrix."""
-
-    @staticmethod
-    def forward(ctx, pts, *params):
-        W: List[torch.Tensor] = list(params[0:8])
-        b: List[torch.Tensor] = list(params[8:16])
-        ws, bs, Wf, bf = params[16:20]
-        W = [w if l != SKIP else w / math.sqrt(2.0) for l, w in enumerate(W)]   # cat([h, e]) / sqrt(2) folded
-        x3 = pts * 3.0
-        e, dc, d2c, dim = _enc_parts(x3)
-        xs, s1 = [], []
-        x = e
-        for l in range(N_LAYERS):
-            if l == SKIP:
-                x = torch.cat([x, e], dim=1)
-            xs.append(x)
-            z = F.linear(x, W[l], b[l])
-            t = z * 100.0
-            ez = torch.exp(torch.clamp(t, max=80.0))
-            s1.append(torch.where(t > 20.0, torch.ones_like(t), ez / (ez + 1.0)))
-            x = F.softplus(z, beta=100)
-        h7 = x
-        sdf = F.linear(h7, ws, bs) / 3.0
-        feat = F.linear(h7, Wf, bf)
-        # reverse chain for g
-        a_next = (ws / 3.0).expand(pts.shape[0], -1)        # a_8
-        a_list = [None] * (N_LAYERS + 1)
-        a_list[N_LAYERS] = a_next
-        ge_skip = None
-        for l in range(N_LAYERS - 1, -1, -1):
-            a = (s1[l] * a_next) @ W[l]                       # a_l: gradient w.r.t. x_l
-            if l == SKIP:
-                ge_skip = a[:, 217:]
-                a_next = a[:, :217]
-            else:
-                a_next = a
-            a_list[l] = a_next                                # gradient w.r.t. h_{l-1} (or the embedding for l = 0)
-        ge = a_list[0] + ge_skip
-        g = 3.0 * _scatter_dims(ge * dc, dim)
-        ctx.save_for_backward(pts, *W, ws, Wf, *xs, *s1, *[a_list[l] for l in range(1, N_LAYERS + 1)], ge, dc, d2c, h7)
-        ctx.dim = dim
-        return sdf, feat, g
-
-    @staticmethod
-    def backward(ctx, sbar, fbar, gbar):
-        sv = ctx.saved_tensors
-        pts = sv[0]
-        W = list(sv[1:9])
-        ws, Wf = sv[9], sv[10]
-        xs = list(sv[11:19])
-        s1 = list(sv[19:27])
-        a_up = list(sv[27:35])          # a_up[l] = a_{l+1} restricted to h_l's width, l = 0..7
-        ge, dc, d2c, h7 = sv[35:39]
-        dim = ctx.dim
-        P = pts.shape[0]
-        sbar = torch.zeros(P, 1, dtype=pts.dtype, device=pts.device) if sbar is None else sbar
-        fbar = torch.zeros(P, 256, dtype=pts.dtype, device=pts.device) if fbar is None else fbar
-        gbar = torch.zeros(P, 3, dtype=pts.dtype, device=pts.device) if gbar is None else gbar
-
-        # ---- adjoint of g = 3 * sum_e ge[e] dc[e]: tangent adjoints run FORWARD through the layers ----
-        gb_e = gbar[:, dim]                                   # gbar of the coordinate each entry depends on
-        ge_bar = 3.0 * dc * gb_e                              # [P,39]
-        p3_bar = 3.0 * _scatter_dims(ge * d2c * gb_e, dim)    # through the encoding's second derivative
-        dW = [None] * N_LAYERS
-        coup = [None] * N_LAYERS
-        abar = ge_bar
-        ws_bar = torch.zeros_like(ws)
-        for l in range(N_LAYERS):
-            if l == SKIP:
-                abar = torch.cat([abar, ge_bar], dim=1)       # adjoint of a_4 = [a_4h, skip part]
-            tbar = abar @ W[l].t()                            # [P,out_l]
-            t_l = s1[l] * a_up[l]
-            dW[l] = t_l.t() @ abar                            # term 2 of dW_l
-            coup[l] = (100.0 * s1[l] * (1.0 - s1[l])) * a_up[l] * tbar
-            if l == N_LAYERS - 1:
-                ws_bar = ws_bar + (s1[l] * tbar).sum(0, keepdim=True) / 3.0
-            else:
-                abar = s1[l] * tbar                           # adjoint of a_{l+1} (h_l-wide)
-        # ---- value adjoints run in REVERSE ----
-        hbar = fbar @ Wf + sbar * (ws / 3.0)
-        Wf_bar = fbar.t() @ h7
-        bf_bar = fbar.sum(0)
-        ws_bar = ws_bar + (sbar * h7).sum(0, keepdim=True) / 3.0
-        bs_bar = sbar.sum(0).reshape(-1) / 3.0
-        db = [None] * N_LAYERS
-        e_skip_bar = None
-        for l in range(N_LAYERS - 1, -1, -1):
-            zbar = s1[l] * hbar + coup[l]
-            dW[l] = dW[l] + zbar.t() @ xs[l]
-            db[l] = zbar.sum(0)
-            xbar = zbar @ W[l]
-            if l == SKIP:
-                e_skip_bar = xbar[:, 217:]
-                hbar = xbar[:, :217]
-            else:
-                hbar = xbar
-        e_bar = hbar + e_skip_bar
-        p3_bar = p3_bar + _scatter_dims(e_bar * dc, dim)
-        dW[SKIP] = dW[SKIP] / math.sqrt(2.0)                  # back to the unscaled W4
-        return (p3_bar * 3.0, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
 
 
 class SdfValueFeatGradHip(torch.autograd.Function):
@@ -252,17 +147,11 @@ class SdfValueFeatGradHip(torch.autograd.Function):
         return (p_bar[:n], None, None, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
 
 
-def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, impl: str = "manual", packed=None, pre=None):
-    """Convenience wrapper over the weight dict of ``packing.dense_params``.  ``impl``: "manual" = this file's torch
-    implementation of the sweeps, "hip" = the HIP kernels (``packed`` required)."""
-    if impl == "hip":
-        if packed is None:
-            raise ValueError("impl='hip' needs the packed parameters")
-        args = [dense[f"sdf_w{l}"] for l in range(8)] + [dense[f"sdf_b{l}"] for l in range(8)] + \
-               [dense["sdf_head_w"], dense["sdf_head_b"], dense["feat_w"], dense["feat_b"]]
-        return SdfValueFeatGradHip.apply(pts, packed, pre, *args)
-    if impl != "manual":
-        raise ValueError(f"unknown sdf implementation {impl!r}")
+def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, packed, pre=None):
+    """(sdf, feat, d sdf/dx) at ``pts`` through the HIP kernels, differentiable w.r.t. the points and the dense
+    (weight-norm-folded) weights of ``packing.dense_params``; ``packed``: the kernel buffers packed from those same weights."""
+    if packed is None:
+        raise ValueError("sdf_value_feat_grad needs the packed parameters (the HIP kernels are the only implementation)")
     args = [dense[f"sdf_w{l}"] for l in range(8)] + [dense[f"sdf_b{l}"] for l in range(8)] + \
            [dense["sdf_head_w"], dense["sdf_head_b"], dense["feat_w"], dense["feat_b"]]
-    return SdfValueFeatGrad.apply(pts, *args)
+    return SdfValueFeatGradHip.apply(pts, packed, pre, *args)

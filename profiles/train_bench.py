@@ -16,8 +16,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     torch.manual_seed(0)
     student = na.NeuSHintRenderer().cuda()
-    if len(sys.argv) > 3:
-        student.sdf_backward = sys.argv[3] if sys.argv[3] != "graph" else "hip"         # manual | hip | autograd | graph
+    backend = sys.argv[3] if len(sys.argv) > 3 else "hip"          # hip | graph | manual | autograd (the last two: tests/torch_backends.py)
     teacher = na.NeuSHintRenderer()
     st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in student.state_dict().items()})
     teacher.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
@@ -35,8 +34,14 @@ def main():
     graphed = None
     if len(sys.argv) > 3 and sys.argv[3] == "graph":       # the whole step captured into one hipGraph
         from nrhints_amd.training import GraphedTrainStep
-        student.sdf_backward = "hip"
         graphed = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000)
+    import contextlib
+    ctx = contextlib.nullcontext()
+    if backend in ("manual", "autograd"):
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from tests.torch_backends import use_torch_backend
+        ctx = use_torch_backend(student, backend)
+    ctx.__enter__()
     for step, (rb, gt) in enumerate(batches):
         if step == 3:
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -50,7 +55,7 @@ def main():
     print(json.dumps({"metric": "training ray-steps/s (fwd+bwd+Adam)", "batch": batch, "steps": steps,
                       "value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2),
                       "loss_first3": [round(x, 5) for x in losses[:3]], "loss_last3": [round(x, 5) for x in losses[-3:]],
-                      "precision": student.precision, "sdf_backward": student.sdf_backward, "hip_graph": graphed is not None}))
+                      "precision": student.precision, "sdf_backward": backend, "hip_graph": graphed is not None}))
 
 if __name__ == "__main__":
     main()

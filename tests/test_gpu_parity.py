@@ -298,9 +298,12 @@ def test_training_step_gradients(scene, sdf_backward):
     for t_ in (rb.origins, rb.directions, rb.pl_positions):
         t_.requires_grad_(True)
     model.zero_grad()
-    model.sdf_backward = sdf_backward      # HIP sweeps (default) | same maths in torch ops | second-order autograd
-    out = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["global_step"]),
-                _t_rand_primary=cu(g["t_rand_primary"]), _t_rand_shadow=cu(g["t_rand_shadow"]))
+    # HIP sweeps (the product) | the same maths in torch ops | second-order autograd like the reference (tests/torch_backends.py)
+    import contextlib
+    from tests.torch_backends import use_torch_backend
+    with (contextlib.nullcontext() if sdf_backward == "hip" else use_torch_backend(model, sdf_backward)):
+        out = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["global_step"]),
+                    _t_rand_primary=cu(g["t_rand_primary"]), _t_rand_shadow=cu(g["t_rand_shadow"]))
     gt = cu(g["rgb_gt"])
     rgb_loss = (out.rgb - gt).abs().sum() / (out.rgb.shape[0] + 1e-5)            # pipelines/base_pipeline.py:57-62
     ge = (torch.linalg.norm(out.analytic_normals, dim=-1) - 1.0) ** 2
@@ -324,7 +327,6 @@ def test_training_step_gradients(scene, sdf_backward):
         scale = max(np.abs(want).max(), 1e-8)
         assert np.abs(t_.grad.cpu().numpy() - want).max() / scale < 2e-2, nm
     model.zero_grad()
-    model.sdf_backward = type(model).sdf_backward
 
 
 def test_eval_image_products_and_raygen(scene):
@@ -434,6 +436,7 @@ def test_sdf_function_hip_backward(scene, npts):
     gradients w.r.t. the points and all 40 raw SDF-network parameters through value, feature, d sdf/dx and an
     eikonal term.  The yardstick is the error of the same maths in fp32 torch ops on the GPU ("manual")."""
     from nrhints_amd.sdf_function import sdf_value_feat_grad
+    from tests.torch_backends import sdf_value_feat_grad_manual
     tag, model, packed, _, p64 = scene
     rs = np.random.RandomState(5)
     pts_np = rs.uniform(-0.7, 0.7, size=(npts, 3))
@@ -456,7 +459,7 @@ def test_sdf_function_hip_backward(scene, npts):
         leaves = {k: p for k, p in model.named_parameters() if k.startswith("sdf_network")}
         dense = pk.dense_params(dict(model.named_parameters()))
         x = cu(pts_np.astype(np.float32)).requires_grad_(True)
-        sdf, feat, g = sdf_value_feat_grad(dense, x, impl=impl, packed=packed)
+        sdf, feat, g = sdf_value_feat_grad(dense, x, packed=packed) if impl == "hip" else sdf_value_feat_grad_manual(dense, x)
         grads = torch.autograd.grad(loss_of(sdf, feat, g, lambda a: cu(a.astype(np.float32))), [x] + [leaves[k] for k in names[1:]])
         return (sdf, feat, g), grads
 
@@ -555,6 +558,7 @@ def test_color_net_hip_vs_torch(scene_states, hints):
     network in torch ops with autograd (fields/reflectance_network.py:68-96), both on the GPU, yardstick fp64 on the CPU."""
     from nrhints_amd import autograd_core as ac
     from nrhints_amd.synthetic import naive_state
+    from tests.torch_backends import _color_net_torch
     st = scene_states["b"] if hints else naive_state(scene_states["b"])
     cfg = na.NeuSModelConfig() if hints else na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False))
     rs = np.random.RandomState(3)
@@ -584,7 +588,7 @@ def test_color_net_hip_vs_torch(scene_states, hints):
             col = ac.ColorNetHip.apply(f_, p_, n_, e_, packed, *[dense[f"col_w{l}"] for l in range(5)], *[dense[f"col_b{l}"] for l in range(5)])
         else:
             sizes = [27, 27, 9, 36] if hints else [27, 27]
-            col = ac._color_net_torch(dense, f_, p_, n_, list(torch.split(e_, sizes, dim=1)), n, T_, hints).reshape(-1, 3)
+            col = _color_net_torch(dense, f_, p_, n_, list(torch.split(e_, sizes, dim=1)), n, T_, hints).reshape(-1, 3)
         grads = torch.autograd.grad((col * torch.tensor(cc, dtype=dt, device=dev)).sum(), [f_, p_, n_, e_] + list(leaves.values()))
         res[prec] = (col.detach().cpu().double(), [g.detach().cpu().double() for g in grads], ["feat", "pts", "normal", "ray_enc"] + list(leaves))
     ref_col, ref_g, names = res["torch64"]

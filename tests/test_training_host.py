@@ -104,12 +104,12 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path, scene_states):
 
 
 def test_sdf_function_manual_backward_matches_second_order_autograd(scene_states):
-    """sdf_function.SdfValueFeatGrad (hand-derived tangent/adjoint sweeps) against the oracle's create_graph autograd
+    """tests/torch_backends.SdfValueFeatGrad (the hand-derived tangent/adjoint sweeps the HIP kernels implement) against the oracle's create_graph autograd
     (the reference's formulation, fields/sdf_field.py:136-148) in fp64: gradients w.r.t. the points and all 40 raw
     SDF-network parameters through value, feature, d sdf/dx and an eikonal term."""
     import numpy as np
     from nrhints_amd import packing
-    from nrhints_amd.sdf_function import sdf_value_feat_grad
+    from tests.torch_backends import sdf_value_feat_grad_manual as sdf_value_feat_grad
     from oracle import neus_oracle as O
     torch.manual_seed(0)
     state = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in scene_states["b"].items()}
@@ -135,13 +135,15 @@ def test_sdf_function_manual_backward_matches_second_order_autograd(scene_states
 
 @pytest.mark.parametrize("hints", [True, False])
 def test_render_core_matches_oracle_formulation(scene_states, hints):
-    """autograd_core.render_core (hand-derived SDF backward + the column-block form of the reflectance net's first layer)
+    """tests/torch_backends.render_core_torch (hand-derived SDF backward + the column-block form of the reflectance net's first layer:
+    the torch statement of what autograd_core.render_core computes with HIP kernels)
     against the reference formulation restated in the oracle - second-order autograd, 361-wide concatenated input
     (models/neus_hint_model.py:504-510, :521-525, :621-637) - in fp64 on the CPU: rgb, weights, normals and the
     gradients w.r.t. all 46 raw parameters and the rays."""
     import numpy as np
-    from nrhints_amd import autograd_core, packing
+    from nrhints_amd import packing
     from nrhints_amd.synthetic import naive_state
+    from tests.torch_backends import render_core_torch
     from oracle import neus_oracle as O
     torch.manual_seed(1)
     f64 = torch.float64
@@ -161,7 +163,7 @@ def test_render_core_matches_oracle_formulation(scene_states, hints):
         leaves = {k: torch.tensor(np.asarray(v), dtype=f64).requires_grad_(True) for k, v in st.items()}
         rays = [t.clone().requires_grad_(True) for t in (o, dirs, pl)]
         if which == "core":
-            out = autograd_core.render_core(packing.dense_params(leaves), leaves["deviation_network.variance"], *rays, mid, dists,
+            out = render_core_torch(packing.dense_params(leaves), leaves["deviation_network.variance"], *rays, mid, dists,
                                             vis, cue, 0.6, bg, sdf_impl="manual")
             rgb, w, g = out["rgb"], out["weights"], out["analytic_normals"]
         else:
