@@ -31,7 +31,7 @@
     }                                                                                  \
   } while (0)
 
-// file layout (little endian): int64 header[10] = {magic, precision, hints, nrays, bytes of sdf_w, sdf_b, sdf_head,
+// file layout (little endian): int64 header[10] = {magic, precision, hints | feat_fused << 1, nrays, bytes of sdf_w, sdf_b, sdf_head,
 // col_w, col_b, bytes of the wide block}; float inv_s; float cos_anneal; then the five buffers, then the wide block (0 bytes, or
 // the streams of the wide f16x3 SDF kernels followed by their [11][256] float32 tables: NrhNet.sdf_w32 / sdf_tab32), then
 // o, d, pl [n,3], near, far [n], background [3], lin64 [64], lin16 [16] as float32
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "bad scene file\n");
     return 1;
   }
-  const int precision = (int)hdr[1], hints = (int)hdr[2];
+  const int precision = (int)hdr[1], hints = (int)(hdr[2] & 1), feat_fused = (int)((hdr[2] >> 1) & 1);
   const long long n = hdr[3];
   std::vector<std::vector<char>> blobs(5);
   for (int i = 0; i < 5; ++i) {
@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
     if (!d_wide) { fprintf(stderr, "device upload failed\n"); return 2; }
     net.sdf_w32 = d_wide;
     net.sdf_tab32 = (const float*)(d_wide + stream_bytes);
+    net.feat_fused = feat_fused;   // the FEAT block of the streams already holds W0feat * W_feat (include/nrhints_hip.h)
   }
   net.inv_s = inv_s; net.precision = precision; net.hints = hints; net.normal_type = 0; net.depth_type = 0;
   float *d_o = to_device(o), *d_d = to_device(d), *d_pl = to_device(pl), *d_near = to_device(nearv), *d_far = to_device(farv),

@@ -35,12 +35,13 @@ def dump(path, model, rays, background=(1.0, 1.0, 1.0), cos_anneal=1.0):
     wide = b""
     if prec == 1 and getattr(model, "wide_kernels", True):
         # f16x3: the streams and tables of the wide SDF kernels (NrhNet.sdf_w32 / sdf_tab32) behind the five classic buffers
-        w32, tab32 = packing32.pack_sdf32(d)
+        # with the feature head multiplied into the reflectance net's first layer (NrhNet.feat_fused), as the renderer does
+        w32, tab32 = packing32.pack_sdf32_fused(d)
         wide = w32.contiguous().cpu().numpy().tobytes() + tab32.contiguous().cpu().numpy().tobytes()
     o, dr, pl, near, far = (np.ascontiguousarray(a, dtype=np.float32) for a in rays)
     n = o.shape[0]
     with open(path, "wb") as f:
-        f.write(struct.pack("<10q", MAGIC, prec, int(hints), n, *[len(b) for b in blobs], len(wide)))
+        f.write(struct.pack("<10q", MAGIC, prec, int(hints) | (2 if wide else 0), n, *[len(b) for b in blobs], len(wide)))
         f.write(struct.pack("<2f", inv_s, cos_anneal))
         for b in blobs:
             f.write(b)

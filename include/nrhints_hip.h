@@ -200,6 +200,10 @@ typedef struct NrhNet {
                                training step then follows the changing variance parameter and anneal schedule */
   const void* sdf_w32;      /* optional: packed streams of the wide f16x3 SDF kernels (see nrh_sdf_eval_wide); when both are   */
   const float* sdf_tab32;   /* non-null and precision is 1, the evaluation path uses them for every SDF evaluation            */
+  int feat_fused;           /* 1: the FEAT block of sdf_w32 / row 8 of sdf_tab32 hold W0feat * W_feat and W0feat * b_feat, the
+                               feature head multiplied into the feature block of the reflectance net's first layer (both are
+                               linear, fields/sdf_field.py:119-123 -> fields/reflectance_network.py:77-84): nrh_render_forward
+                               then skips that block in the reflectance kernel.  Evaluation only; 0 = plain feature head */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

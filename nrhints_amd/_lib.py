@@ -29,7 +29,7 @@ class NrhNet(Structure):
     _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
-                ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p)]
+                ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int)]
 
 
 class NrhTrainSaves(Structure):
@@ -135,10 +135,13 @@ def stream_handle(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True):
-    """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params)."""
-    w32 = pk.get("sdf_w32") if wide else None
+def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False):
+    """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
+    whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them."""
+    fused = bool(fused and wide and pk.get("sdf_w32f") is not None)
+    w32 = (pk.get("sdf_w32f") if fused else pk.get("sdf_w32")) if wide else None
+    tab = pk.get("sdf_tab32f") if fused else pk.get("sdf_tab32")
     return NrhNet(ptr(pk["sdf_w"], pk["sdf_w"].dtype), ptr(pk["sdf_b"]), ptr(pk["sdf_head"]),
                   ptr(pk["col_w"], pk["col_w"].dtype), ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
                   hints, normal_type, depth_type, ptr(dyn_scalars),
-                  ptr(w32, w32.dtype) if w32 is not None else None, ptr(pk.get("sdf_tab32")) if w32 is not None else None)
+                  ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused))

@@ -76,7 +76,8 @@ int ensure_attrs() {
                        (const void*)nrh::color_adjoint_kernel<0, 8>, (const void*)nrh::color_adjoint_kernel<1, 8>,
                        (const void*)nrh::color_adjoint_kernel<0, 4>, (const void*)nrh::color_adjoint_kernel<1, 4>,
                        (const void*)nrh::color_kernel<0, 8>, (const void*)nrh::color_kernel<1, 8>,
-                       (const void*)nrh::color_kernel<0, 4>, (const void*)nrh::color_kernel<1, 4>};
+                       (const void*)nrh::color_kernel<0, 4>, (const void*)nrh::color_kernel<1, 4>,
+                       (const void*)nrh::color_kernel<1, 8, false, true>, (const void*)nrh::color_kernel<1, 4, false, true>};
   e = hipSuccess;
   for (const void* f : fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
@@ -190,7 +191,7 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
 
 int color_eval_impl(int prec, int hints, const float* w, const float* b, const float* feat, const float* ro, const float* rd,
                     const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
-                    hipStream_t st) {
+                    hipStream_t st, int fused = 0) {
   if (!w || !b || !feat || !ro || !rd || !tmid || !nhat || !raymisc || !color)
     return fail(NRH_E_INVALID, "nrh_color_eval: null pointer%s", "");
   if (nrays == 0) return NRH_OK;
@@ -210,7 +211,10 @@ int color_eval_impl(int prec, int hints, const float* w, const float* b, const f
   timing_begin(3, st, tl, timed);
   const dim3 g(grid), blk(nrh::MLP_THREADS);
   const int lds = nrh::MLP_LDS_BYTES;
-  if (prec == 0 && hints) hipLaunchKernelGGL((nrh::color_kernel<0, 8>), g, blk, lds, st, a);
+  if (fused && prec != 1) return fail(NRH_E_INVALID, "fused feature block needs precision 1 (f16x3, wide SDF kernels)%s", "");
+  if (fused && hints) hipLaunchKernelGGL((nrh::color_kernel<1, 8, false, true>), g, blk, lds, st, a);
+  else if (fused) hipLaunchKernelGGL((nrh::color_kernel<1, 4, false, true>), g, blk, lds, st, a);
+  else if (prec == 0 && hints) hipLaunchKernelGGL((nrh::color_kernel<0, 8>), g, blk, lds, st, a);
   else if (prec == 1 && hints) hipLaunchKernelGGL((nrh::color_kernel<1, 8>), g, blk, lds, st, a);
   else if (prec == 0) hipLaunchKernelGGL((nrh::color_kernel<0, 4>), g, blk, lds, st, a);
   else if (prec == 1) hipLaunchKernelGGL((nrh::color_kernel<1, 4>), g, blk, lds, st, a);
@@ -255,7 +259,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 121; }
+int nrh_version(void) { return 122; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -718,8 +722,10 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   }
   if (train) return NRH_OK;  // reflectance + composite are differentiated by the caller
   // ---- reflectance + composite ----
+  // feat_fused: ws_feat holds W0feat * feature (the wide mode-2 stream was packed with the product matrix)
+  const int fused = (net->precision == 1 && net->feat_fused && net->sdf_w32 && net->sdf_tab32) ? 1 : 0;
   rc = color_eval_impl(net->precision, net->hints, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid,
-                       net->normal_type ? o_grad : o_nhat, ws_raymisc, n, ws_color, st);
+                       net->normal_type ? o_grad : o_nhat, ws_raymisc, n, ws_color, st, fused);
   if (rc) return rc;
   {
     nrh::CompositeArgs c;

@@ -48,14 +48,18 @@ __device__ __forceinline__ f32x4 relu4(const f32x4 x) {
   return f32x4{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f), fmaxf(x[2], 0.0f), fmaxf(x[3], 0.0f)};
 }
 
-template <int PREC, int MKB, bool TRAIN = false>
+// FUSED (evaluation with the wide SDF kernels): the tiles in `feat` already hold W0feat * feature - the SDF kernel's feature
+// head is linear and feeds this linear block directly, so the two matrices are multiplied at pack time
+// (packing32.pack_sdf32_fused) and stage C0a (a quarter of this kernel's MFMA work) disappears.
+template <int PREC, int MKB, bool TRAIN = false, bool FUSED = false>
 __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   int par = 0;
-  dma_chunk(a.w + COL_OFF_C0A, smem, 32, wave, lane);
+  if constexpr (FUSED) dma_chunk(a.w + COL_OFF_C0B, smem, 2 * MKB, wave, lane);
+  else dma_chunk(a.w + COL_OFF_C0A, smem, 32, wave, lane);
   __syncthreads();
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
@@ -76,19 +80,29 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
 
     // ---- C0a: feature part ----
     Act<PREC, 16> h;
-    {
-      const float* ft = TRAIN ? a.feat + (size_t)Pc * 256 + 4 * q : a.feat + (size_t)tilec * (16 * 256) + lane * 4;
-      const int bs = TRAIN ? 16 : 256;   // floats between consecutive 16-feature blocks
+    float part[64];
+    if constexpr (FUSED) {
+      // the tile holds this lane's share of W0feat * feature: rows (2 ch) * 16 + 4 q + r and (2 ch + 1) * 16 + 4 q + r
+      const float* ft = a.feat + (size_t)tilec * (16 * 256) + lane * 4;
 #pragma unroll
       for (int ch = 0; ch < 8; ++ch) {
-        const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch) * bs));
-        const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch + 1) * bs));
-        const float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        h.set_chunk(ch, o);
+        const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch) * 256));
+        const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch + 1) * 256));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { part[ch * 8 + r] = v0[r]; part[ch * 8 + 4 + r] = v1[r]; }
       }
-    }
-    float part[64];
-    {
+    } else {
+      {
+        const float* ft = TRAIN ? a.feat + (size_t)Pc * 256 + 4 * q : a.feat + (size_t)tilec * (16 * 256) + lane * 4;
+        const int bs = TRAIN ? 16 : 256;   // floats between consecutive 16-feature blocks
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+          const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch) * bs));
+          const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(ft + (2 * ch + 1) * bs));
+          const float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          h.set_chunk(ch, o);
+        }
+      }
       auto pre = [&](int) { return 0; };
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) {
 #pragma unroll
@@ -176,7 +190,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
           for (int r = 0; r < 3; ++r) a.color[P * 3 + r] = sigmoidf_(acc0[r] + p.b0[r]);
         }
       };
-      run_stage<PREC, 16, 1, false>(a.w + col_off_C4(MKB), a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, pre, epi, wave, lane);
+      if constexpr (FUSED)
+        run_stage<PREC, 16, 1, false>(a.w + col_off_C4(MKB), a.w + COL_OFF_C0B, 2 * MKB, smem, par, h, nullptr, pre, epi, wave, lane);
+      else
+        run_stage<PREC, 16, 1, false>(a.w + col_off_C4(MKB), a.w + COL_OFF_C0A, 32, smem, par, h, nullptr, pre, epi, wave, lane);
     }
   }
 }

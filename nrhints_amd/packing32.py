@@ -148,6 +148,23 @@ def pack_sdf32(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
     return torch.cat(streams).contiguous(), sdf32_tables(d)
 
 
+def fuse_feature_head(d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The feature head of the SDF net and the feature block of the reflectance net's first layer are two linear maps in a
+    row (fields/sdf_field.py:119-123 -> fields/reflectance_network.py:77-84, columns 60:316 of the 316 / 361-wide input):
+    replace (W_feat, b_feat) by (W0[:, 60:316] W_feat, W0[:, 60:316] b_feat), evaluated in fp64.  The mode-2 kernel then
+    returns that block's contribution to the first hidden layer and the reflectance kernel skips it (NrhNet.feat_fused)."""
+    w0f = d["col_w0"].detach().double()[:, 60:316]
+    out = dict(d)
+    out["feat_w"] = (w0f @ d["feat_w"].detach().double()).float()
+    out["feat_b"] = (w0f @ d["feat_b"].detach().double()).float()
+    return out
+
+
+def pack_sdf32_fused(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pack_sdf32 of the network with the fused feature head (evaluation renders only; modes 0 and 1 are unchanged)."""
+    return pack_sdf32(fuse_feature_head(d))
+
+
 def stream_offset_bytes(mode: int) -> int:
     return sum(stream_bytes(m) for m in range(mode))
 

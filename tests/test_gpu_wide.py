@@ -118,3 +118,35 @@ def test_render_wide_vs_16_point(wscene):
     assert float((a.rgb - b.rgb).abs().max()) < 5e-5
     assert float((a.depth - b.depth).abs().max()) < 3e-4
     assert float((a.visibilities - b.visibilities).abs().max()) < 3e-3
+
+
+def test_fused_feature_head(wscene, scene_states):
+    """NrhNet.feat_fused: the feature head multiplied into the feature block of the reflectance net's first layer at pack
+    time (packing32.fuse_feature_head; both maps are linear: fields/sdf_field.py:119-123 -> reflectance_network.py:77-84).
+    The mode-2 kernel with the fused streams returns W0feat * feature, and the evaluation render with the fused path equals
+    the render without it to fp32 round-off (same sampler decisions: the SDF values do not change at all)."""
+    from nrhints_amd import packing as pkg, packing32
+    tag, model, packed, _ = wscene
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = pkg.dense_params({k: v.detach().float().to(dev) for k, v in model.state_dict().items()})
+    w32f, tab32f = packing32.pack_sdf32_fused(d)
+    o, dd, pl, near, far = make_rays(64, seed=12, spread=0.1)
+    t = torch.rand(64, 128, device="cuda") * 2 + 2
+    plain = ops.sdf_eval_wide(2, packed["sdf_w32"], packed["sdf_tab32"], cu(o), cu(dd), t, 128)
+    fused = ops.sdf_eval_wide(2, w32f, tab32f, cu(o), cu(dd), t, 128)
+    assert torch.equal(plain[0], fused[0]) and torch.equal(plain[1], fused[1])          # sdf, gradient: same blocks
+    feat = pkg.feat_tiles_to_rows(plain[2], 64 * 128).double()
+    want = feat @ d["col_w0"].double()[:, 60:316].t()
+    got = pkg.feat_tiles_to_rows(fused[2], 64 * 128).double()
+    assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    rb = na.RayBundle(origins=cu(o), directions=cu(dd), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+    bg = torch.ones(1, 3, device="cuda")
+    with torch.no_grad():
+        assert model.fuse_feature_head
+        a = model(rb, is_training=False, background_rgb=bg)
+        assert model._packed.get("sdf_w32f") is not None
+        model.fuse_feature_head = False
+        b = model(rb, is_training=False, background_rgb=bg)
+        model.fuse_feature_head = True
+    assert torch.equal(a.weights, b.weights) and torch.equal(a.depth, b.depth) and torch.equal(a.visibilities, b.visibilities)
+    assert float((a.rgb - b.rgb).abs().max()) < 2e-6
