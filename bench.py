@@ -68,6 +68,8 @@ def build_scene(precision):
     state_a = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
     state_b = perturb_state(state_a)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_b.items()})
+    if os.environ.get("NRH_BENCH_NO_FUSE"):       # A/B of NrhNet.feat_fused (profiles/r02/fused_head_ab.log); not a product knob
+        model.fuse_feature_head = False
     return model, state_b
 
 
