@@ -378,14 +378,21 @@ def gen_swap():
     return "\n".join(out) + "\n"
 
 
-def gen_t7():
-    """t_7 = (1 - q_7) * a8 written straight into AGPR set 0 (R7's input): W32_A8(c) -> f32x16 (w_s / 3 in D32 layout),
-    W32_QLOAD7_ASM(dst, c, half).  All loads go out first (56 VGPRs, nothing else is live here): one exposed L2 latency, not seven."""
-    out = ["// generated by gen_mlp32.py: T7 pass", "{"]
+def gen_t7_loads():
+    """The q_7 words of chunks 0..6 for the T7 pass, issued from inside the HEAD window (W32_QLOAD7_ASM(dst, c, half)) so that
+    their L2 latency passes under HEAD's K loop: 56 VGPRs that nothing else needs there.  Declared by the kernel (T7Q_DECL)."""
+    out = ["// generated by gen_mlp32.py: T7 loads"]
     for c in range(7):
-        out.append(f"  nrh32::u32x4 q{c}a, q{c}b;")
-        out.append(f"  W32_QLOAD7_ASM(q{c}a, {c}, 0); W32_QLOAD7_ASM(q{c}b, {c}, 1);")
-    out.append('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // asm loads: the wait is ours')
+        out.append(f"W32_QLOAD7_ASM(q{c}a, {c}, 0); W32_QLOAD7_ASM(q{c}b, {c}, 1);")
+    return "\n".join(out) + "\n"
+
+
+def gen_t7():
+    """t_7 = (1 - q_7) * a8 written straight into AGPR set 0 (R7's input): W32_A8(c) -> f32x16 (w_s / 3 in D32 layout).  The q
+    words were requested in the HEAD window (gen_t7_loads); they are older than HEAD's eight LDS-DMA pieces."""
+    out = ["// generated by gen_mlp32.py: T7 pass", "{"]
+    regs = ", ".join(f'"+v"(q{c}{h})' for c in range(7) for h in "ab")
+    out.append(f'  asm volatile("s_waitcnt vmcnt(8)" : {regs}, "+v"(qpa), "+v"(qpb) :: "memory");   // asm loads: the wait is ours')
     out.append("  __builtin_amdgcn_sched_barrier(0);")
     for c in range(7):   # chunk 7 becomes the pending pair of the reverse chain (hp = a8, cp = 0, q words): R7's window 0 finishes it
         out.append(f"  {{  // chunk {c}")
@@ -439,6 +446,7 @@ def main():
         "kloop3v.inc": gen_kloop(3, "vgpr", False),
         "kloop3v_acc.inc": gen_kloop(3, "vgpr", False, acc_all=True),
         "t7.inc": gen_t7(),
+        "t7_loads.inc": gen_t7_loads(),
     }
     for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc"):
         if os.path.exists(os.path.join(outdir, stale)):

@@ -311,9 +311,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
         W32_NEXT();
       }
     }
+    // q_7 words for the T7 pass: requested inside the HEAD window, consumed after it (their L2 latency passes under HEAD's K loop)
+    u32x4 q0a, q0b, q1a, q1b, q2a, q2b, q3a, q3b, q4a, q4b, q5a, q5b, q6a, q6b, qpa, qpb;
+    const char* const q7base = uni(scr + 7 * 16384);
+    // nt: served by L2; asm: the destination registers are written straight by the load (no compiler copy of a value still in
+    // flight - checked in the build's ISA, profiles/tools/check_wide_isa.py), the wait is in t7.inc
+#define W32_QLOAD7_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2" W32_QLD_NT : "=v"(dst) : "v"(lane16), "s"(q7base + ((c) * 2 + (half)) * 1024))
     {
       W32_SYNC();
       W32_FETCH_SETUP();
+      if constexpr (WANT_D) {
+#include "gen32/t7_loads.inc"
+        W32_QLOAD7_ASM(qpa, 7, 0);
+        W32_QLOAD7_ASM(qpb, 7, 1);
+      }
       f32x16 hh = tab_init(9, 0), cc;
       const uint32_t wa = W32_WADDR();
 #include "gen32/kloop16.inc"
@@ -324,14 +335,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     NRH32_STAMP(3);   // FEAT + HEAD
     if constexpr (WANT_D) {
       // ---- T7: t_7 = (1 - q_7) * w_s / 3: chunks 0..6 straight into set 0 (R7's input), chunk 7 as R7's pending pair ----
-      u32x4 qpa, qpb;
-      const char* const q7base = uni(scr + 7 * 16384);
-      // nt: served by L2; asm: the destination registers are written straight by the load (no compiler copy of a value still
-      // in flight), the wait is in t7.inc
-#define W32_QLOAD7_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2" W32_QLD_NT : "=v"(dst) : "v"(lane16), "s"(q7base + ((c) * 2 + (half)) * 1024))
 #define W32_A8(c) tab_init(10, c)
-      W32_QLOAD7_ASM(qpa, 7, 0);
-      W32_QLOAD7_ASM(qpb, 7, 1);
 #include "gen32/t7.inc"
       hp = W32_A8(7);
       cp = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
