@@ -128,6 +128,22 @@ def ptr(t, dtype=None):
     return c_void_p(t.data_ptr())
 
 
+def on_tensor_device(fn):
+    """Decorator: run ``fn`` with the device of its first GPU tensor argument current, so that the C entry points (which
+    launch on the current stream of the CURRENT device and cache their per-device set-up by its id) see the tensors' GPU."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        import torch
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapped
+
+
 def stream_handle(device=None):
     """Current HIP stream of ``device`` (default: the current device).  The library caches per-device state by the CURRENT
     device id, so callers working on another GPU wrap their calls in ``torch.cuda.device(tensor.device)``."""

@@ -24,6 +24,7 @@ def _wptr(w):
     return _lib.ptr(w, w.dtype), (0 if w.dtype == torch.float32 else 1)
 
 
+@_lib.on_tensor_device
 def sdf_eval(mode: int, sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_stride: Optional[int] = None,
              scratch: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
     """SDF (mode 0), + gradient (mode 1), + feature (mode 2) at points ro[ray] + rd[ray] * t[ray, j].
@@ -47,6 +48,7 @@ def sdf_eval(mode: int, sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_str
     return sdf, grad, feat
 
 
+@_lib.on_tensor_device
 def sdf_eval_wide(mode: int, sdf_w32, sdf_tab32, ro, rd, t, n_per_ray: int, t_stride: Optional[int] = None,
                   scratch: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
     """``sdf_eval`` through the wide f16x3 kernels (csrc/nrh_sdf32.hip); sdf_w32 / sdf_tab32 from packing32.pack_sdf32."""
@@ -70,6 +72,7 @@ def sdf_eval_wide(mode: int, sdf_w32, sdf_tab32, ro, rd, t, n_per_ray: int, t_st
     return sdf, grad, feat
 
 
+@_lib.on_tensor_device
 def sdf_at_points(mode: int, sdf_w, sdf_b, sdf_head, pts):
     """Convenience: free points [P,3] (one 'ray' per point, t = 0)."""
     zeros = torch.zeros_like(pts)
@@ -77,6 +80,7 @@ def sdf_at_points(mode: int, sdf_w, sdf_b, sdf_head, pts):
     return sdf_eval(mode, sdf_w, sdf_b, sdf_head, pts.contiguous(), zeros, t, 1)
 
 
+@_lib.on_tensor_device
 def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
     """Training forward at free points [P,3] (P % 16 == 0): -> (sdf [P,1], feat [P,256] row-major, grad [P,3], saves)
     where ``saves`` holds what ``sdf_train_backward`` and the weight-gradient GEMMs need (include/nrhints_hip.h)."""
@@ -99,6 +103,7 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
     return sdf, feat, grad, saves
 
 
+@_lib.on_tensor_device
 def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sbar, fbar, gbar):
     """The two backward sweeps at the points ro[ray] + rd[ray] * t[ray, j]
     -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3])."""
@@ -120,6 +125,7 @@ def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sb
     return out
 
 
+@_lib.on_tensor_device
 def sampler_step(ro, rd, z, s, n: int, *, znew_in=None, snew_in=None, upsample_inv_s: Optional[float] = None,
                  lin16=None, finalize: bool = False, last_dist: float = 2.0 / 64, last_dist_ray=None):
     """One launch of the hierarchical sampler.  ``z``/``s`` ([nrays,128]) are updated in place by a merge.
@@ -141,6 +147,7 @@ def sampler_step(ro, rd, z, s, n: int, *, znew_in=None, snew_in=None, upsample_i
     return znew_out, tmid, dists
 
 
+@_lib.on_tensor_device
 def color_eval(col_w, col_b, feat_tiles, ro, rd, tmid, nhat, raymisc, hints: bool = True) -> torch.Tensor:
     """Reflectance MLP for nrays x 128 samples -> [nrays*128, 3] (``hints=False``: the 316-input pl-naive net)."""
     lib = _lib.load()

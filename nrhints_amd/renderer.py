@@ -220,6 +220,14 @@ class NeuSHintRenderer(nn.Module):
     def forward(self, ray_bundle: RayBundle, is_training: bool = False, background_rgb: Optional[torch.Tensor] = None,
                 global_step: int = 0, _t_rand_primary: Optional[torch.Tensor] = None,
                 _t_rand_shadow: Optional[torch.Tensor] = None) -> RenderOutput:
+        o = ray_bundle.origins
+        if torch.is_tensor(o) and o.is_cuda:
+            # every C call below launches on "the current stream of the current device": make that the rays' device
+            with torch.cuda.device(o.device):
+                return self._forward(ray_bundle, is_training, background_rgb, global_step, _t_rand_primary, _t_rand_shadow)
+        return self._forward(ray_bundle, is_training, background_rgb, global_step, _t_rand_primary, _t_rand_shadow)
+
+    def _forward(self, ray_bundle, is_training, background_rgb, global_step, _t_rand_primary, _t_rand_shadow) -> RenderOutput:
         lib = _lib.load()
         o, d, pl = ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions
         near, far = ray_bundle.nears, ray_bundle.fars
@@ -388,9 +396,10 @@ class NeuSHintRenderer(nn.Module):
             raise RuntimeError("NeuSHintRenderer (MI355X) runs on the GPU only")
         f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
         bg = f32(background_rgb.to(o.device)).reshape(-1) if background_rgb is not None else None
-        return self._render_chunks(f32(o), f32(d), f32(pl), f32(ray_bundle.nears).reshape(-1),
-                                   f32(ray_bundle.fars).reshape(-1), bg, 1.0, None, None, 0,
-                                   want_samples=False, want_maps=True, want_mid=False)
+        with torch.cuda.device(o.device):
+            return self._render_chunks(f32(o), f32(d), f32(pl), f32(ray_bundle.nears).reshape(-1),
+                                       f32(ray_bundle.fars).reshape(-1), bg, 1.0, None, None, 0,
+                                       want_samples=False, want_maps=True, want_mid=False)
 
     # ---------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -407,8 +416,9 @@ class NeuSHintRenderer(nn.Module):
         t = torch.zeros(n, dtype=torch.float32, device=pts.device)
         out = torch.empty(n, 1, dtype=torch.float32, device=pts.device)
         P = _lib.ptr
-        rc = lib.nrh_sdf_eval(pk["precision"], 0, P(pk["sdf_w"], pk["sdf_w"].dtype), P(pk["sdf_b"]), P(pk["sdf_head"]), P(pts), P(zeros3), P(t), 1, 1, n,
-                              P(out), 1, None, None, None, _lib.stream_handle())
+        with torch.cuda.device(pts.device):
+            rc = lib.nrh_sdf_eval(pk["precision"], 0, P(pk["sdf_w"], pk["sdf_w"].dtype), P(pk["sdf_b"]), P(pk["sdf_head"]), P(pts), P(zeros3), P(t), 1, 1, n,
+                                  P(out), 1, None, None, None, _lib.stream_handle())
         _lib.check(rc, "nrh_sdf_eval")
         return out
 
