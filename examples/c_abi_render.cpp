@@ -33,7 +33,8 @@
 
 // file layout (little endian): int64 header[10] = {magic, precision, hints | feat_fused << 1, nrays, bytes of sdf_w, sdf_b, sdf_head,
 // col_w, col_b, bytes of the wide block}; float inv_s; float cos_anneal; then the five buffers, then the wide block (0 bytes, or
-// the streams of the wide f16x3 SDF kernels followed by their [11][256] float32 tables: NrhNet.sdf_w32 / sdf_tab32), then
+// the streams of the wide f16x3 SDF kernels followed by their [11][256] float32 tables: NrhNet.sdf_w32 / sdf_tab32, optionally
+// followed by the reflectance net's block stream and its [5][256] tables: NrhNet.col_w32 / col_tab32), then
 // o, d, pl [n,3], near, far [n], background [3], lin64 [64], lin16 [16] as float32
 static const int64_t MAGIC = 0x4e52483031;  // "NRH01"
 
@@ -89,13 +90,21 @@ int main(int argc, char** argv) {
   net.sdf_w = (const float*)dev[0]; net.sdf_b = (const float*)dev[1]; net.sdf_head = (const float*)dev[2];
   net.col_w = (const float*)dev[3]; net.col_b = (const float*)dev[4];
   if (!wide.empty()) {
-    const long long stream_bytes = nrh_sdf_wide_stream_bytes();
-    if ((long long)wide.size() != stream_bytes + 11 * 256 * 4) { fprintf(stderr, "wide block has the wrong size for this library\n"); return 1; }
+    const long long stream_bytes = nrh_sdf_wide_stream_bytes(), sdf_part = stream_bytes + 11 * 256 * 4;
+    const long long col_bytes = nrh_color_wide_stream_bytes(), col_part = col_bytes + 5 * 256 * 4;
+    if ((long long)wide.size() != sdf_part && (long long)wide.size() != sdf_part + col_part) {
+      fprintf(stderr, "wide block has the wrong size for this library\n");
+      return 1;
+    }
     char* d_wide = to_device(wide);
     if (!d_wide) { fprintf(stderr, "device upload failed\n"); return 2; }
     net.sdf_w32 = d_wide;
     net.sdf_tab32 = (const float*)(d_wide + stream_bytes);
     net.feat_fused = feat_fused;   // the FEAT block of the streams already holds W0feat * W_feat (include/nrhints_hip.h)
+    if ((long long)wide.size() == sdf_part + col_part) {   // + the reflectance net's block stream and tables
+      net.col_w32 = d_wide + sdf_part;
+      net.col_tab32 = (const float*)(d_wide + sdf_part + col_bytes);
+    }
   }
   net.inv_s = inv_s; net.precision = precision; net.hints = hints; net.normal_type = 0; net.depth_type = 0;
   float *d_o = to_device(o), *d_d = to_device(d), *d_pl = to_device(pl), *d_near = to_device(nearv), *d_far = to_device(farv),

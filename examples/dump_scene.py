@@ -38,6 +38,9 @@ def dump(path, model, rays, background=(1.0, 1.0, 1.0), cos_anneal=1.0):
         # with the feature head multiplied into the reflectance net's first layer (NrhNet.feat_fused), as the renderer does
         w32, tab32 = packing32.pack_sdf32_fused(d)
         wide = w32.contiguous().cpu().numpy().tobytes() + tab32.contiguous().cpu().numpy().tobytes()
+        if hints and getattr(model, "wide_color", True):     # + the reflectance net for the wide kernel (NrhNet.col_w32 / col_tab32)
+            c32, ctab = packing32.pack_color32(d)
+            wide += c32.contiguous().cpu().numpy().tobytes() + ctab.contiguous().cpu().numpy().tobytes()
     o, dr, pl, near, far = (np.ascontiguousarray(a, dtype=np.float32) for a in rays)
     n = o.shape[0]
     with open(path, "wb") as f:

@@ -204,6 +204,9 @@ typedef struct NrhNet {
                                feature head multiplied into the feature block of the reflectance net's first layer (both are
                                linear, fields/sdf_field.py:119-123 -> fields/reflectance_network.py:77-84): nrh_render_forward
                                then skips that block in the reflectance kernel.  Evaluation only; 0 = plain feature head */
+  const void* col_w32;      /* optional, with feat_fused: the reflectance net as a block stream for the wide kernel          */
+  const float* col_tab32;   /* (packing32.pack_color32: nrh_color_wide_stream_bytes() bytes + [5][256] float32 tables); when   */
+                            /* both are non-null the evaluation render runs fields/reflectance_network.py:68-96 on it         */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);
@@ -265,6 +268,10 @@ int nrh_generate_rays_indexed_backward(const long long* img_indices, const float
                                        int near_far_from_sphere, const float* g_origins, const float* g_directions,
                                        const float* g_pl_positions, const float* g_nears, const float* g_fars, float* g_delta,
                                        float* g_pl_delta, void* stream);
+
+/* Bytes of the block stream NrhNet.col_w32 points to (33 blocks of 32 KiB: layer 0 without its feature block, layers 1-3,
+ * the 3-row output layer; layout in nrhints_amd/packing32.py, pack_color32). */
+long long nrh_color_wide_stream_bytes(void);
 
 #ifdef __cplusplus
 }

@@ -22,14 +22,15 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
-            "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward")
+            "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes")
 
 
 class NrhNet(Structure):
     _fields_ = [("sdf_w", c_void_p), ("sdf_b", c_void_p), ("sdf_head", c_void_p), ("col_w", c_void_p),
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
-                ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int)]
+                ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
+                ("col_w32", c_void_p), ("col_tab32", c_void_p)]
 
 
 class NrhTrainSaves(Structure):
@@ -93,6 +94,7 @@ def load():
                                               c_int, c_float, c_float, P, P, P, P, P, P]
     lib.nrh_generate_rays_indexed_backward.argtypes = [P, P, P, P, c_int, P, c_longlong, P, P, c_int, c_float, c_float, c_float,
                                                        c_float, c_int, P, P, P, P, P, P, P, P]
+    lib.nrh_color_wide_stream_bytes.restype = c_longlong
     lib.nrh_kernel_timing_select.argtypes = [c_int]
     lib.nrh_kernel_timing_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_longlong)]
     for name in EXPORTED:
@@ -151,13 +153,16 @@ def stream_handle(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False):
+def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
-    whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them."""
+    whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
+    ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""
     fused = bool(fused and wide and pk.get("sdf_w32f") is not None)
     w32 = (pk.get("sdf_w32f") if fused else pk.get("sdf_w32")) if wide else None
     tab = pk.get("sdf_tab32f") if fused else pk.get("sdf_tab32")
+    c32 = pk.get("col_w32") if (fused and wide_color) else None
     return NrhNet(ptr(pk["sdf_w"], pk["sdf_w"].dtype), ptr(pk["sdf_b"]), ptr(pk["sdf_head"]),
                   ptr(pk["col_w"], pk["col_w"].dtype), ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
                   hints, normal_type, depth_type, ptr(dyn_scalars),
-                  ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused))
+                  ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
+                  ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None)

@@ -95,6 +95,22 @@ def epi_rev(c, hp, cp, out_base=128):
     return ops
 
 
+def epi_relu(c, hp, cp, out_base=128, part=False):
+    """ReLU epilogue of chunk c (the reflectance net's hidden layers): t = hh + cc 2^-11 [+ the feature block's share pw0..pw3,
+    16 floats loaded a window earlier] -> max(t, 0) -> hi/lo -> out."""
+    ops = []
+    for i in range(8):
+        for r in (2 * i, 2 * i + 1):
+            ops.append(Op(f"float t{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"t{r}",)))
+            src = f"t{r}"
+            if part:
+                ops.append(Op(f"float s{r} = t{r} + __builtin_bit_cast(float, pw{r // 4}[{r % 4}]);", defs=(f"s{r}",), uses=(f"t{r}",)))
+                src = f"s{r}"
+            ops.append(Op(f"float u{r} = __builtin_amdgcn_fmed3f({src}, 0.0f, 3.0e38f);", defs=(f"u{r}",), uses=(src,)))
+        ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i)
+    return ops
+
+
 def schedule(ops, nslots, per_slot):
     """Greedy list schedule: an op may run in slot k if everything it uses was defined in a slot < k (or outside).
     Returns (slots, tail): ops per slot, and what did not fit."""
@@ -238,7 +254,22 @@ def acc_names(c):
     return ("hp", "cp") if c == 7 else (f"hh{c}", f"cc{c}")
 
 
-def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pend_in=True, bias_mfma=False, skip=False):
+# asm loads a stage issues per window for the epilogue that runs one window later: (register stems, macro)
+STAGE_LOADS = {"rev": (("qa", "qb"), "W32_QLOAD_ASM"), "relu_part": (("pa", "pb", "pc", "pd"), "W32_PLOAD_ASM")}
+
+
+def stage_epilogue(kind, c, ph, pc, want_d, out_base, qstore):
+    if kind == "fwd":
+        return epi_fwd(c, ph, pc, want_d, out_base=out_base, qstore=qstore)
+    if kind == "rev":
+        return epi_rev(c, ph, pc, out_base=out_base)
+    if kind in ("relu", "relu_part"):
+        return epi_relu(c, ph, pc, out_base=out_base, part=(kind == "relu_part"))
+    raise ValueError(kind)
+
+
+def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pend_in=True, bias_mfma=False, skip=False,
+              pend_kind=None):
     """A pipelined 8-chunk stage, ping-pong form: B operands from AGPR set `in_base`, results into set `out_base`; no copy.
     Window c runs the K loop of chunk c and the epilogue of chunk c - 1; window 0 runs the epilogue of the PREVIOUS stage's
     chunk 7 (pending in hp, cp [, qpa, qpb]), whose outputs are this stage's K steps 14 and 15 - they are only read by the
@@ -248,45 +279,48 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
     W32_HINIT(c) (f32x16 start values, unless hh_zero), W32_QSTORE(c, half, v) (this stage's layer), W32_QSTORE_P (the
     previous stage's layer), W32_QLOAD_ASM(dst, c, half)."""
     small = ks != 16
+    pend_kind = kind if pend_kind is None else pend_kind
+    loads, load_macro = STAGE_LOADS.get(kind, ((), None))            # what this stage's windows request
+    ploads = STAGE_LOADS.get(pend_kind, ((), None))[0]               # what arrives pending from the previous stage
+    wname = {"rev": "qw", "relu_part": "pw"}
     out = []
-    out.append(f"// generated by gen_mlp32.py: stage kind={kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv} in=a{in_base} out=a{out_base}")
+    out.append(f"// generated by gen_mlp32.py: stage kind={kind} pend={pend_kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv} in=a{in_base} out=a{out_base}")
     out.append("{")
     for c in range(7):
         out.append(f"  nrh32::f32x16 hh{c}, cc{c};")
-    if kind == "rev":
-        for c in range(7):
-            out.append(f"  nrh32::u32x4 qa{c}, qb{c};")
-    qn = lambda c: ("qpa", "qpb") if c == 7 else (f"qa{c}", f"qb{c}")
+    for c in range(7):
+        if loads:
+            out.append("  nrh32::u32x4 " + ", ".join(f"{st}{c}" for st in loads) + ";")
+    ln = lambda c, stems: [(f"{st[0]}p{st[1:]}" if c == 7 else f"{st}{c}") for st in stems]   # chunk 7: qpa, qpb / ppa..ppd
     for c in range(8):
         out.append(f"  {{  // window {c}")
         hh, cc = acc_names(c)
         prev = (c - 1) % 8
         ph, pc = acc_names(prev)
         has_epi = (c > 0 or pend_in) and not os.environ.get("NRH32_NOEPI")
+        ekind = kind if c > 0 else pend_kind
         if not small or c % 4 == 0:
             out.append("    W32_SYNC();")
             out.append("    W32_FETCH_SETUP();")
+        pnames = []
         if c == 0 and has_epi:
-            # window 0 consumes the pending pair (and q words) of the previous stage; window 7 redefines those names
-            # (the empty asm orders any copy hipcc makes of these registers behind W32_SYNC: the q words were still in flight)
+            # window 0 consumes the pending pair (and loaded words) of the previous stage; window 7 redefines those names
+            # (the empty asm orders any copy hipcc makes of these registers behind W32_SYNC: the words were still in flight)
             out.append('    asm volatile("" : "+v"(hp), "+v"(cp));')
             out.append("    nrh32::f32x16 ph0 = hp, pc0 = cp;")
             ph, pc = "ph0", "pc0"
-            if kind == "rev":
-                out.append('    asm volatile("" : "+v"(qpa), "+v"(qpb));')
-                out.append("    nrh32::u32x4 pqa = qpa, pqb = qpb;")
+            for nm in ln(7, ploads):
+                out.append(f'    asm volatile("" : "+v"({nm}));')
+                out.append(f"    nrh32::u32x4 c_{nm} = {nm};")
+                pnames.append(f"c_{nm}")
         epi, head = None, None
         if has_epi:
             ob = out_base if c > 0 else in_base          # the previous stage's output set is this stage's input set
-            if kind == "fwd":
-                epi = epi_fwd(prev, ph, pc, want_d, out_base=ob, qstore=("W32_QSTORE" if c > 0 else "W32_QSTORE_P"))
-            else:
-                epi = epi_rev(prev, ph, pc, out_base=ob)
-        if kind == "rev":
+            epi = stage_epilogue(ekind, prev, ph, pc, want_d, ob, "W32_QSTORE" if c > 0 else "W32_QSTORE_P")
+        if loads:
             # asm loads: hipcc does not see them, so it never waits for them with vmcnt(0) (which would also drain the
             # LDS-DMA pieces in flight); they are older than this window's 8 pieces: the next W32_SYNC covers them
-            qa, qb = qn(c)
-            out.append(f"    W32_QLOAD_ASM({qa}, {c}, 0); W32_QLOAD_ASM({qb}, {c}, 1);")
+            out.append("    " + " ".join(f"{load_macro}({nm}, {c}, {k});" for k, nm in enumerate(ln(c, loads))))
         if bias_mfma:
             out.append(f"    const uint32_t bw = W32_BIAS({c});")
         elif not hh_zero:
@@ -295,10 +329,12 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         if epi is not None:
             # the previous chunk's accumulators are read by VALU only from here on: >= 11 wait states after its last MFMA
             out.append(f'    asm volatile("" : "+v"({ph}), "+v"({pc}));')
-            if kind == "rev":
-                pa, pb = ("pqa", "pqb") if c == 0 else qn(prev)
-                out.append(f'    asm volatile("" : "+v"({pa}), "+v"({pb}));')
-                out.append(f"    const nrh32::u32x4 qw0 = {pa}, qw1 = {pb};")
+            estems = STAGE_LOADS.get(ekind, ((), None))[0]
+            if estems:
+                names = pnames if c == 0 else ln(prev, estems)
+                for k, nm in enumerate(names):
+                    out.append(f'    asm volatile("" : "+v"({nm}));')
+                    out.append(f"    const nrh32::u32x4 {wname[ekind]}{k} = {nm};")
         win = Window(ks, hh, cc, b_src=b_src, hh_zero=(hh_zero or bias_mfma), in_base=in_base,
                      bias=(("bw", "W32_BCONST") if bias_mfma else None))
         if small:
@@ -332,11 +368,12 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         out.append("  }")
     # whoever comes next may copy the pending registers: only after the last MFMAs have landed
     out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hp), "+v"(cp));')
-    if kind == "rev":
-        # same for the pending q words (asm loads of window 7, in flight, invisible to hipcc): they have landed before
+    if loads:
+        # same for the pending loaded words (asm loads of window 7, in flight, invisible to hipcc): they have landed before
         # anything may touch their registers (hipcc shuffles loop-carried registers at the loop edges - measured: 1-3 % of
         # the tiles got stale words without this).  They are older than window 7's eight LDS-DMA pieces.
-        out.append('  asm volatile("s_waitcnt vmcnt(8)" : "+v"(qpa), "+v"(qpb));')
+        regs = ", ".join(f'"+v"({nm})' for nm in ln(7, loads))
+        out.append(f'  asm volatile("s_waitcnt vmcnt(8)" : {regs});')
     out.append("}")
     return "\n".join(out) + "\n"
 
@@ -346,6 +383,8 @@ def gen_finish(kind, want_d, out_base):
     out = [f"// generated by gen_mlp32.py: finish kind={kind} want_d={want_d} out=a{out_base}", "{"]
     if kind == "fwd":
         epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P")
+    elif kind == "relu":
+        epi = epi_relu(7, "hp", "cp", out_base=out_base)
     else:
         out.append('  asm volatile("" : "+v"(qpa), "+v"(qpb));   // landed: the stage body ends with a wait for them')
         out.append("  const nrh32::u32x4 qw0 = qpa, qw1 = qpb;")
@@ -447,6 +486,14 @@ def main():
         "kloop3v_acc.inc": gen_kloop(3, "vgpr", False, acc_all=True),
         "t7.inc": gen_t7(),
         "t7_loads.inc": gen_t7_loads(),
+        # reflectance net on the same machinery (csrc/nrh_color32.hip): C0 (misc inputs, + the feature block's share loaded per
+        # window) -> C1 -> C2 -> C3 (ReLU), then the 3-row output chunk as a bare K loop
+        "col_c0.inc": gen_stage("relu_part", False, 16, "agpr", nv, True, in_base=0, out_base=128, pend_in=False, bias_mfma=True),
+        "col_c1.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=128, out_base=0, bias_mfma=True, pend_kind="relu_part"),
+        "col_c2.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=0, out_base=128, bias_mfma=True),
+        "col_c3.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=128, out_base=0, bias_mfma=True),
+        "col_fin.inc": gen_finish("relu", False, 0),
+        "kloop16_a0.inc": gen_kloop(16, "agpr", False, in_base=0),
     }
     for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc"):
         if os.path.exists(os.path.join(outdir, stale)):

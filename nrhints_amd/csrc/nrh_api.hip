@@ -259,7 +259,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 122; }
+int nrh_version(void) { return 123; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -607,6 +607,8 @@ int nrh_generate_rays_indexed_backward(const long long* img_indices, const float
   return check_launch("raygen_indexed_adjoint_kernel");
 }
 
+long long nrh_color_wide_stream_bytes(void) { return nrh32::wide_color_stream_bytes(); }
+
 long long nrh_render_workspace_floats(long long nrays) {
   if (nrays < 0) return -1;
   long long tot = 0;
@@ -724,8 +726,23 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   // ---- reflectance + composite ----
   // feat_fused: ws_feat holds W0feat * feature (the wide mode-2 stream was packed with the product matrix)
   const int fused = (net->precision == 1 && net->feat_fused && net->sdf_w32 && net->sdf_tab32) ? 1 : 0;
-  rc = color_eval_impl(net->precision, net->hints, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid,
-                       net->normal_type ? o_grad : o_nhat, ws_raymisc, n, ws_color, st, fused);
+  if (fused && net->hints && net->col_w32 && net->col_tab32) {
+    // the reflectance net on the wide machinery too (csrc/nrh_color32.hip)
+    nrh32::WideColorCall c;
+    c.stream = net->col_w32; c.tables = net->col_tab32; c.part = ws_feat; c.ro = origins; c.rd = directions; c.tmid = o_tmid;
+    c.nhat = net->normal_type ? o_grad : o_nhat; c.raymisc = ws_raymisc; c.color = ws_color; c.nrays = n;
+    c.raymisc_stride = nrh::RAYMISC_STRIDE; c.max_grid = device_cus();
+    TimedLaunch tl;
+    bool timed;
+    timing_begin(3, st, tl, timed);
+    const int wrc = nrh32::wide_color_launch(c, st);
+    timing_end(st, tl, timed);
+    if (wrc) return fail(wrc == -1 ? NRH_E_INVALID : NRH_E_LAUNCH, "wide reflectance kernel: launch failed%s", "");
+    rc = check_launch("color32_kernel");
+  } else {
+    rc = color_eval_impl(net->precision, net->hints, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid,
+                         net->normal_type ? o_grad : o_nhat, ws_raymisc, n, ws_color, st, fused);
+  }
   if (rc) return rc;
   {
     nrh::CompositeArgs c;

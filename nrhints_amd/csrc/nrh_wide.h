@@ -19,4 +19,16 @@ int wide_sdf_launch(const WideSdfCall& c, hipStream_t st);   // 0 ok, -1 invalid
 long long wide_sdf_stream_bytes_total();
 long long wide_sdf_scratch_bytes(int grid);
 
+struct WideColorCall {
+  const void* stream;       // packing32.pack_color32: 33 blocks
+  const float* tables;      // [5][256]
+  const float *part, *ro, *rd, *tmid, *nhat, *raymisc;
+  float* color;
+  long long nrays;
+  int raymisc_stride;
+  int max_grid;
+};
+int wide_color_launch(const WideColorCall& c, hipStream_t st);   // 0 ok, -1 invalid, -2 launch/device error
+long long wide_color_stream_bytes();
+
 }  // namespace nrh32

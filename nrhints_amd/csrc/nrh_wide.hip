@@ -2,6 +2,7 @@
 // these kernels need their own code generation flags (-fno-slp-vectorize: no packed f32 VALU beside MFMAs;
 // -mllvm -amdgpu-mfma-vgpr-form: accumulators in arch VGPRs, the AGPR file belongs to the hand-placed B operands).
 #include "nrh_sdf32.hip"
+#include "nrh_color32.hip"
 #include "nrh_wide.h"
 
 namespace nrh32 {
@@ -35,6 +36,25 @@ int wide_sdf_launch(const WideSdfCall& c, hipStream_t st) {
   else hipLaunchKernelGGL(sdf32_kernel<2>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
   return 0;
 }
+
+int wide_color_launch(const WideColorCall& c, hipStream_t st) {
+  static bool attr[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -2;
+  if (dev >= 0 && dev < 16 && !attr[dev]) {
+    if (hipFuncSetAttribute((const void*)color32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, COL32_LDS_BYTES) != hipSuccess) return -2;
+    attr[dev] = true;
+  }
+  if (c.nrays > 0x7fffffffLL) return -1;
+  Color32Args a;
+  a.w = reinterpret_cast<const char*>(c.stream); a.tab = c.tables; a.part = c.part; a.ro = c.ro; a.rd = c.rd; a.tmid = c.tmid;
+  a.nhat = c.nhat; a.raymisc = c.raymisc; a.color = c.color; a.nrays = (int)c.nrays; a.raymisc_stride = c.raymisc_stride;
+  const int grid = (int)(c.nrays < c.max_grid ? c.nrays : c.max_grid);
+  if (grid <= 0) return -2;
+  hipLaunchKernelGGL(color32_kernel, dim3(grid), dim3(THREADS), COL32_LDS_BYTES, st, a);
+  return 0;
+}
+long long wide_color_stream_bytes() { return color32_stream_bytes(); }
 
 long long wide_sdf_stream_bytes_total() { return sdf32_stream_bytes(0) + sdf32_stream_bytes(1) + sdf32_stream_bytes(2); }
 long long wide_sdf_scratch_bytes(int grid) { return (long long)grid * WAVES * SCRATCH_WORDS_PER_WAVE * 4; }

@@ -165,6 +165,51 @@ def pack_sdf32_fused(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Te
     return pack_sdf32(fuse_feature_head(d))
 
 
+# ---- the reflectance net on the wide machinery (csrc/nrh_color32.hip) -------------------------------------------------------
+COLOR32_BLOCKS = 33
+COLOR32_NTAB = 5
+
+
+def color32_stream_bytes() -> int:
+    return COLOR32_BLOCKS * 32768
+
+
+def _raymisc_columns() -> torch.Tensor:
+    """Column of the reference's 361-wide reflectance input (fields/reflectance_network.py:77-82) for each of the 99 per-ray
+    values in the kernels' raymisc order [enc(view) 27 | enc(pl) 27 | enc(vis) 9 | enc(cue) 36]."""
+    return torch.cat([torch.arange(3, 30), torch.arange(33, 60), torch.arange(316, 325), torch.arange(325, 361)])
+
+
+def color32_layer0(d: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """[256, 128]: layer 0 without its feature block in the kernel's column order - 0..2 point, 4..6 normal, 16 + m raymisc[m]
+    (csrc/nrh_color32.hip header); the feature block (columns 60:316) comes in through packing32.fuse_feature_head."""
+    w0 = d["col_w0"].detach().float()
+    if w0.shape[1] != 361:
+        raise ValueError("pack_color32: the wide reflectance kernel is built for the hinted model (361 inputs)")
+    m0 = torch.zeros(256, 128, dtype=torch.float32, device=w0.device)
+    m0[:, 0:3] = w0[:, 0:3]
+    m0[:, 4:7] = w0[:, 30:33]
+    m0[:, 16:16 + 99] = w0[:, _raymisc_columns().to(w0.device)]
+    return m0
+
+
+def pack_color32(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (stream: fp16 tensor, 33 blocks of 32 KiB: C0 (8; K steps 8..15 zero), C1, C2, C3 (8 each), C4 (1; rows 3..31 zero);
+    tables [5, 256] float32: rows 0..3 the biases of C0..C3 as packed fp16 pairs (see sdf32_tables), row 4 b4)."""
+    f = lambda t: t.detach().float()
+    blocks = [pack_stage32(color32_layer0(d), 256, BIG_KS)]
+    blocks += [pack_stage32(f(d[f"col_w{l}"]), 256, BIG_KS) for l in (1, 2, 3)]
+    blocks.append(pack_stage32(f(d["col_w4"]), 32, BIG_KS))
+    stream = torch.cat(blocks).contiguous()
+    assert stream.numel() * 2 == color32_stream_bytes(), stream.numel()
+    rows = []
+    for l in range(4):
+        hi, lo = split_f16(f(d[f"col_b{l}"]))
+        rows.append((hi.view(torch.int16).to(torch.int32) & 0xffff | (lo.view(torch.int16).to(torch.int32) << 16)).view(torch.float32))
+    rows.append(torch.nn.functional.pad(f(d["col_b4"]), (0, 256 - d["col_b4"].shape[0])))
+    return stream, torch.stack(rows).contiguous()
+
+
 def stream_offset_bytes(mode: int) -> int:
     return sum(stream_bytes(m) for m in range(mode))
 

@@ -106,6 +106,7 @@ class NeuSHintRenderer(nn.Module):
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
     precision = "f16x3"
     wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
+    wide_color = True          # ... and the reflectance net on the wide machinery as well (csrc/nrh_color32.hip; hinted model only)
     fuse_feature_head = True   # evaluation renders with the wide kernels: W0feat * W_feat multiplied at pack time (NrhNet.feat_fused)
     max_fused_train_rays = 8192
     # hipGraph mode (training.GraphedTrainStep): a device tensor [inv_s, cos_anneal] that the kernels read at run time
@@ -181,6 +182,8 @@ class NeuSHintRenderer(nn.Module):
                         # evaluation: a second set of streams with the feature head multiplied into the reflectance net's
                         # first layer (packing32.fuse_feature_head) - the render call then skips that block
                         bufs["sdf_w32f"], bufs["sdf_tab32f"] = packing32.pack_sdf32_fused(d)
+                        if hints and self.wide_color:
+                            bufs["col_w32"], bufs["col_tab32"] = packing32.pack_color32(d)
                 if self.dyn_scalars is not None:      # no host sync: the kernels read inv_s from the device
                     self.dyn_scalars[0:1].copy_(torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(1))
                     inv_s = float("nan")
@@ -358,7 +361,7 @@ class NeuSHintRenderer(nn.Module):
         if not use_dyn and self.dyn_scalars is not None:
             pk = dict(pk, inv_s=self._host_inv_s(pk, device))
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
-                            wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid)
+                            wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))

@@ -230,3 +230,58 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
     assert st.pos == len(st.buf)
     grad = np.stack([(dx[d][HF == 0] + dx[d][HF == 1]) * 3.0 for d in range(3)], axis=1)
     return sdf, grad, feat
+
+
+def color32_tile(stream16, tables, part, pts, nrm, raymisc):
+    """One 32-sample tile of the reflectance net through the colour block stream (csrc/nrh_color32.hip).
+    part [32,256]: the feature block's share of layer 0 (W0feat * feature); pts, nrm [32,3]; raymisc [>= 99].  -> rgb [32,3]."""
+    raw = np.ascontiguousarray(np.asarray(tables, dtype=np.float32))
+    bits = raw.view(np.uint32)
+    bias_hi = (bits & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+    bias_lo = (bits >> 16).astype(np.uint16).view(np.float16).astype(np.float64)
+
+    def bias(l, c):
+        out = np.zeros((16, 64))
+        for r in range(16):
+            row = 32 * c + frow(r, HF)
+            out[r] = bias_hi[l][row] + bias_lo[l][row] / 2048.0
+        return out
+
+    st = Stream(stream16)
+    # B operands of C0: K step 0 = point (hf 0) / normal (hf 1) in slots 0..2; K steps 1..7 = raymisc[16 (s-1) + 8 (i>>2) + 4 hf + (i&3)]
+    bh, bl = [], []
+    for s in range(16):
+        v = np.zeros((64, 8))
+        if s == 0:
+            for k in range(3):
+                v[:, k] = np.where(HF == 0, pts[J, k], nrm[J, k])
+        elif s < 8:
+            for i in range(8):
+                idx = 16 * (s - 1) + 8 * (i >> 2) + 4 * HF + (i & 3)
+                ok = idx < 99
+                v[:, i] = np.where(ok, np.asarray(raymisc, dtype=np.float64)[np.minimum(idx, 98)], 0.0)
+        h, l = split16(v)
+        bh.append(h)
+        bl.append(l)
+    u = []
+    for c in range(8):
+        hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+        t = hh + bias(0, c) + cc / 2048.0
+        for r in range(16):
+            t[r] += part[J, 32 * c + frow(r, HF)]
+        u.append(np.maximum(t, 0.0))
+    for l in range(1, 4):
+        bh, bl = act_to_b(u)
+        nu = []
+        for c in range(8):
+            hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+            nu.append(np.maximum(hh + bias(l, c) + cc / 2048.0, 0.0))
+        u = nu
+    bh, bl = act_to_b(u)
+    hh, cc = kloop(st.chunk(16), 16, bh, bl, tab_init(raw.astype(np.float64), 4, 0))
+    assert st.pos == len(st.buf)
+    v = hh + cc / 2048.0
+    rgb = np.zeros((32, 3))
+    for r in range(3):
+        rgb[:, r] = 1.0 / (1.0 + np.exp(-v[r][HF == 0]))
+    return rgb

@@ -150,3 +150,29 @@ def test_fused_feature_head(wscene, scene_states):
         model.fuse_feature_head = True
     assert torch.equal(a.weights, b.weights) and torch.equal(a.depth, b.depth) and torch.equal(a.visibilities, b.visibilities)
     assert float((a.rgb - b.rgb).abs().max()) < 2e-6
+
+
+def test_wide_reflectance_kernel(wscene):
+    """csrc/nrh_color32.hip (the reflectance net on the wide machinery, behind NrhNet.col_w32): the evaluation render with it
+    against the render with the 16-point reflectance kernel (same fused feature head) and against the one without either -
+    the SDF side is untouched (weights, depth, visibilities bit-equal), rgb agrees to fp32 round-off; and the colours
+    themselves against the fp64 oracle through the golden-fixture render test's tolerances elsewhere."""
+    tag, model, packed, _ = wscene
+    o, dd, pl, near, far = make_rays(257, seed=21, spread=0.1)
+    rb = na.RayBundle(origins=cu(o), directions=cu(dd), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+    bg = torch.ones(1, 3, device="cuda")
+    with torch.no_grad():
+        assert model.wide_color and model.fuse_feature_head
+        a = model(rb, is_training=False, background_rgb=bg)
+        assert model._packed.get("col_w32") is not None
+        a2 = model(rb, is_training=False, background_rgb=bg)
+        model.wide_color = False
+        b = model(rb, is_training=False, background_rgb=bg)
+        model.fuse_feature_head = False
+        c = model(rb, is_training=False, background_rgb=bg)
+        model.wide_color, model.fuse_feature_head = True, True
+    assert torch.equal(a.rgb, a2.rgb)                                   # deterministic
+    for x in (b, c):
+        assert torch.equal(a.weights, x.weights) and torch.equal(a.depth, x.depth) and torch.equal(a.visibilities, x.visibilities)
+        assert float((a.rgb - x.rgb).abs().max()) < 3e-6, float((a.rgb - x.rgb).abs().max())
+    assert torch.isfinite(a.rgb).all()

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 122
+    assert lib.nrh_version() == 123
     lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
     from nrhints_amd import packing32 as pk32
     assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
@@ -305,7 +305,7 @@ def test_integration_md_matches_the_binding():
             cur += ch
     nargs += bool(cur.strip())
     assert nargs == len(lib.nrh_render_forward.argtypes), nargs
-    ctor = re.search(r"net = NrhNet\((.*?)\)\n", text).group(1)
+    ctor = re.search(r"net = NrhNet\((.*?)\)\nws = ", text, re.S).group(1)
     assert len([a for a in re.split(r",\s*(?![^()]*\))", ctor) if a.strip()]) == len(want)
     table = text[text.index("| C symbol | replaces |"):]
     table = table[:table.index("\n\n")]

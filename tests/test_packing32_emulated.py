@@ -46,3 +46,30 @@ def test_sdf32_chain_emulated(packed32):
     np.testing.assert_array_equal(grad1, grad)
     sdf0, _, _ = emu.sdf32_tile(_stream(streams, 0), tables, pts, 0)
     np.testing.assert_array_equal(sdf0, sdf)
+
+
+def test_color32_chain_emulated(scene_states):
+    """The reflectance net's block stream (packing32.pack_color32 + fuse_feature_head) through the numpy emulation of
+    csrc/nrh_color32.hip against the fp64 oracle (fields/reflectance_network.py:68-96): column permutation of layer 0, the
+    fused feature block, packed fp16 biases, the 3-row output chunk."""
+    st = {k: torch.from_numpy(np.asarray(v)) for k, v in scene_states["b"].items()}
+    d = pk.dense_params(st)
+    stream, tables = pk32.pack_color32(d)
+    assert stream.numel() * 2 == pk32.color32_stream_bytes() and tables.shape == (5, 256)
+    p64 = orc.params_from_state(scene_states["b"], torch.float64)
+    g = torch.Generator().manual_seed(4)
+    pts = torch.rand(32, 3, generator=g, dtype=torch.float64) * 2 - 1
+    nrm = torch.nn.functional.normalize(torch.randn(32, 3, generator=g, dtype=torch.float64), dim=-1)
+    feat = torch.randn(32, 256, generator=g, dtype=torch.float64) * 0.3
+    view = torch.nn.functional.normalize(torch.randn(1, 3, generator=g, dtype=torch.float64), dim=-1)
+    pl = torch.randn(1, 3, generator=g, dtype=torch.float64) * 3
+    vis, cue = torch.rand(1, 1, generator=g, dtype=torch.float64), torch.rand(1, 4, generator=g, dtype=torch.float64) * 2
+    rep = lambda x: x.expand(32, x.shape[-1])
+    ref = orc.color_forward(p64, pts, nrm, rep(view), feat, rep(pl), rep(vis), rep(cue)).numpy()
+    raymisc = torch.cat([orc.nerf_encode(view, 4), orc.nerf_encode(pl, 4), orc.nerf_encode(vis, 4), orc.nerf_encode(cue, 4)], dim=-1)[0]
+    assert raymisc.shape[0] == 99
+    fd = pk32.fuse_feature_head(d)                      # part = W0feat (Wf h + bf): apply the fused head to the "feature" input
+    part = feat @ d["col_w0"].double()[:, 60:316].t()   # (feat here plays Wf h + bf: the fusion is linear in it)
+    got = emu.color32_tile(stream.numpy(), tables.numpy(), part.numpy(), pts.numpy(), nrm.numpy(), raymisc.numpy())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6)
+    assert fd["feat_w"].shape == (256, 256)
