@@ -37,15 +37,26 @@ def aput(idx, val):
     return Op(f'asm volatile("v_accvgpr_write_b32 a{idx}, %0" ::"v"({val}) : "a{idx}");', uses=(val,), kind="aput")
 
 
-def split_ops(i, v0, v1, out_hi, out_lo, pfx=""):
-    """hi/lo split of the pair (v0, v1) -> AGPRs out_hi / out_lo (nrh32::split2, spelled out per instruction)."""
+def split_ops(i, v0, v1, out_hi, out_lo, pfx="", scaled=False):
+    """hi/lo split of the pair (v0, v1) -> AGPRs out_hi / out_lo (nrh32::split2 / split2_scaled, spelled out per instruction).
+    scaled: the residual is multiplied by 2^11 before it is rounded to fp16 (the reflectance net's activations are O(0.01..1):
+    their unscaled residuals are fp16 subnormals, and those do not survive here - measured, profiles/r02/color32_lo_flush.log)."""
     n = f"{pfx}{i}"
-    ops = [
-        Op(f"nrh32::h16x2 hi{n} = __builtin_amdgcn_cvt_pkrtz({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1)),
-        # the residual goes out UNSCALED (v_fma_mix_f32 on the packed fp16): fp16 subnormals are honoured by the MFMA, and an
-        # activation below 2^-3 loses nothing that matters in absolute terms (|error| <= 2^-25), see nrh_mlp32.h
-        Op(f"float R{n}a = __builtin_fmaf((float)hi{n}.x, -1.0f, {v0});", defs=(f"R{n}a",), uses=(f"hi{n}", v0)),
-        Op(f"float R{n}b = __builtin_fmaf((float)hi{n}.y, -1.0f, {v1});", defs=(f"R{n}b",), uses=(f"hi{n}", v1)),
+    if scaled:
+        mid = [
+            Op(f"float H{n}a = {v0} * nrh32::LO_SCALE;", defs=(f"H{n}a",), uses=(v0,)),
+            Op(f"float H{n}b = {v1} * nrh32::LO_SCALE;", defs=(f"H{n}b",), uses=(v1,)),
+            Op(f"float R{n}a = __builtin_fmaf((float)hi{n}.x, -nrh32::LO_SCALE, H{n}a);", defs=(f"R{n}a",), uses=(f"hi{n}", f"H{n}a")),
+            Op(f"float R{n}b = __builtin_fmaf((float)hi{n}.y, -nrh32::LO_SCALE, H{n}b);", defs=(f"R{n}b",), uses=(f"hi{n}", f"H{n}b")),
+        ]
+    else:
+        # the residual goes out UNSCALED (v_fma_mix_f32 on the packed fp16): an SDF-net activation below 2^-3 loses nothing that
+        # matters in absolute terms (|error| <= 2^-25 if subnormals survive, <= 2^-12 |x| if they do not), see nrh_mlp32.h
+        mid = [
+            Op(f"float R{n}a = __builtin_fmaf((float)hi{n}.x, -1.0f, {v0});", defs=(f"R{n}a",), uses=(f"hi{n}", v0)),
+            Op(f"float R{n}b = __builtin_fmaf((float)hi{n}.y, -1.0f, {v1});", defs=(f"R{n}b",), uses=(f"hi{n}", v1)),
+        ]
+    ops = [Op(f"nrh32::h16x2 hi{n} = __builtin_amdgcn_cvt_pkrtz({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1))] + mid + [
         Op(f"nrh32::h16x2 lo{n} = __builtin_amdgcn_cvt_pkrtz(R{n}a, R{n}b);", defs=(f"lo{n}",), uses=(f"R{n}a", f"R{n}b")),
         aput(out_hi, f"hi{n}"),
         aput(out_lo, f"lo{n}"),
@@ -107,7 +118,7 @@ def epi_relu(c, hp, cp, out_base=128, part=False):
                 ops.append(Op(f"float s{r} = t{r} + __builtin_bit_cast(float, pw{r // 4}[{r % 4}]);", defs=(f"s{r}",), uses=(f"t{r}",)))
                 src = f"s{r}"
             ops.append(Op(f"float u{r} = __builtin_amdgcn_fmed3f({src}, 0.0f, 3.0e38f);", defs=(f"u{r}",), uses=(src,)))
-        ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i)
+        ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i, scaled=True)
     return ops
 
 
@@ -151,7 +162,8 @@ class Window:
     hh_init: name of an f32x16 holding the start values (compiler-visible LDS loads), or None for zero."""
 
     def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa", cd=None, use_ds=True, in_base=0,
-                 acc_all=False, bias=None):
+                 acc_all=False, bias=None, b_lo_scaled=False):
+        self.b_lo_scaled = b_lo_scaled   # B_lo carries a factor 2^11 as well (reflectance net): A_hi B_lo goes to cc, not hh
         self.ks, self.hh, self.cc, self.b_src, self.bvar, self.hh_zero, self.pf, self.wa = ks, hh, cc, b_src, bvar, hh_zero, pf, wa
         self.acc_all = acc_all  # every MFMA accumulates (hh and cc already hold partial sums)
         self.bias = bias        # (a_word, b_quad): one extra MFMA hh += {a_word,0,0,0} * b_quad ahead of the last K step (the bias row, see gen_stage)
@@ -212,8 +224,10 @@ class Window:
                 # unscaled) -> hh.  MID = 1 keeps the two hh updates of a K step apart (no back-to-back dependent MFMAs).
                 lo_a = (j == MID)
                 part = 1 if lo_a else 0
-                acc = (self.cd if self.cd else self.cc) if lo_a else self.hh
-                first = (s == 0 and (lo_a or (j == 0 and self.hh_zero))) and not self.acc_all
+                to_cc = lo_a or (self.b_lo_scaled and j > 0)          # which accumulator: everything with one scaled factor -> cc
+                acc = (self.cd if self.cd else self.cc) if to_cc else self.hh
+                first_cc = 1 if self.b_lo_scaled else MID              # the first MFMA of the window that writes cc
+                first = (s == 0 and ((to_cc and j == first_cc) or (j == 0 and self.hh_zero))) and not self.acc_all
                 w = wait_for(s, 1)           # one wait per K step: both fragments (hi was issued first) before the first MFMA
                 bpart = 1 if (j > 0 and not lo_a) else 0
                 pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j == 0 and self.use_ds) else ""
@@ -336,7 +350,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
                     out.append(f'    asm volatile("" : "+v"({nm}));')
                     out.append(f"    const nrh32::u32x4 {wname[ekind]}{k} = {nm};")
         win = Window(ks, hh, cc, b_src=b_src, hh_zero=(hh_zero or bias_mfma), in_base=in_base,
-                     bias=(("bw", "W32_BCONST") if bias_mfma else None))
+                     bias=(("bw", "W32_BCONST") if bias_mfma else None), b_lo_scaled=kind.startswith("relu"))
         if small:
             dma = {2: [2 * (c % 4)], 5: [2 * (c % 4) + 1]}
         else:
@@ -399,11 +413,11 @@ def gen_finish(kind, want_d, out_base):
     return "\n".join(out) + "\n"
 
 
-def gen_kloop(ks, b_src, hh_zero, in_base=128, acc_all=False):
+def gen_kloop(ks, b_src, hh_zero, in_base=128, acc_all=False, b_lo_scaled=False):
     """K loop only (no fillers): for the light stages whose epilogue is written by hand after it.  Needs hh, cc, wa; the
     16-step form consumes a streamed block and therefore also issues the 8 LDS-DMA pieces of block n + 2 (W32_DMA)."""
     out = [f"// generated by gen_mlp32.py: bare K loop ks={ks} b={b_src}", "{"]
-    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero, in_base=in_base, acc_all=acc_all).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
+    Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero, in_base=in_base, acc_all=acc_all, b_lo_scaled=b_lo_scaled).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
     if not acc_all:
         out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh), "+v"(cc));   // MFMA results -> VALU reads: 11 wait states')
     out.append("}")
@@ -493,7 +507,7 @@ def main():
         "col_c2.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=0, out_base=128, bias_mfma=True),
         "col_c3.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=128, out_base=0, bias_mfma=True),
         "col_fin.inc": gen_finish("relu", False, 0),
-        "kloop16_a0.inc": gen_kloop(16, "agpr", False, in_base=0),
+        "kloop16_a0.inc": gen_kloop(16, "agpr", False, in_base=0, b_lo_scaled=True),
     }
     for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc"):
         if os.path.exists(os.path.join(outdir, stale)):

@@ -609,6 +609,20 @@ int nrh_generate_rays_indexed_backward(const long long* img_indices, const float
 
 long long nrh_color_wide_stream_bytes(void) { return nrh32::wide_color_stream_bytes(); }
 
+int nrh_color_eval_wide(const void* col_w32, const float* col_tab32, const float* part_tiles, const float* ro, const float* rd,
+                        const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color, void* stream) {
+  if (!col_w32 || !col_tab32 || !part_tiles || !ro || !rd || !tmid || !nhat || !raymisc || !color)
+    return fail(NRH_E_INVALID, "nrh_color_eval_wide: null pointer%s", "");
+  if (nrays < 0) return fail(NRH_E_INVALID, "nrh_color_eval_wide: negative size%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh32::WideColorCall c;
+  c.stream = col_w32; c.tables = col_tab32; c.part = part_tiles; c.ro = ro; c.rd = rd; c.tmid = tmid; c.nhat = nhat;
+  c.raymisc = raymisc; c.color = color; c.nrays = nrays; c.raymisc_stride = nrh::RAYMISC_STRIDE; c.max_grid = device_cus();
+  const int wrc = nrh32::wide_color_launch(c, (hipStream_t)stream);
+  if (wrc) return fail(wrc == -1 ? NRH_E_INVALID : NRH_E_LAUNCH, "wide reflectance kernel: launch failed%s", "");
+  return check_launch("color32_kernel");
+}
+
 long long nrh_render_workspace_floats(long long nrays) {
   if (nrays < 0) return -1;
   long long tot = 0;

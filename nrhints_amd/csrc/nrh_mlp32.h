@@ -70,6 +70,16 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
+// the same with the residual scaled by 2^11 (kept out of the fp16 subnormal range; the reflectance net's convention)
+__device__ __forceinline__ void split2_scaled(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  const float ra = __builtin_fmaf((float)h.x, -LO_SCALE, a * LO_SCALE);
+  const float rb = __builtin_fmaf((float)h.y, -LO_SCALE, b * LO_SCALE);
+  const h16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 // two values in [0,1] -> unorm16 pair (v_cvt_pknorm_u16_f32: clamp, scale by 65535, round to nearest)
 __device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));

@@ -159,3 +159,17 @@ def color_eval(col_w, col_b, feat_tiles, ro, rd, tmid, nhat, raymisc, hints: boo
                             P(color), _lib.stream_handle())
     _lib.check(rc, "nrh_color_eval")
     return color
+
+
+@_lib.on_tensor_device
+def color_eval_wide(col_w32, col_tab32, part_tiles, ro, rd, tmid, nhat, raymisc) -> torch.Tensor:
+    """Reflectance MLP on the wide kernel for nrays x 128 samples -> [nrays*128, 3]; ``part_tiles``: W0feat * feature as
+    16-point D-layout tiles (packing.rows_to_feat_tiles); ``raymisc`` [nrays, 100] (+ 12 readable floats behind the last row)."""
+    lib = _lib.load()
+    nrays = ro.shape[0]
+    color = torch.empty(nrays * 128, 3, dtype=torch.float32, device=ro.device)
+    P = _lib.ptr
+    rc = lib.nrh_color_eval_wide(P(col_w32, col_w32.dtype), P(col_tab32), P(part_tiles), P(ro), P(rd), P(tmid), P(nhat), P(raymisc),
+                                 nrays, P(color), _lib.stream_handle())
+    _lib.check(rc, "nrh_color_eval_wide")
+    return color

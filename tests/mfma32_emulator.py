@@ -232,6 +232,36 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
     return sdf, grad, feat
 
 
+def split16_scaled(x):
+    """hi + lo / 2^11 with the residual scaled (the reflectance net's convention: its activations are small)"""
+    with np.errstate(over="ignore"):
+        hi = x.astype(np.float16)
+        lo = ((x - hi.astype(np.float64)) * 2048.0).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def kloop_scaled(chunk, ks, bh, bl, hh):
+    """K loop with BOTH residuals scaled by 2^11: hh += A_hi B_hi, cc += A_hi B_lo + A_lo B_hi"""
+    cc = np.zeros((16, 64))
+    hh = hh.copy()
+    for s in range(ks):
+        ah, al = chunk[s, 0], chunk[s, 1]
+        hh = mfma_32x32x16(ah, bh[s], hh)
+        cc = mfma_32x32x16(al, bh[s], cc)
+        cc = mfma_32x32x16(ah, bl[s], cc)
+    return hh, cc
+
+
+def act_to_b_scaled(u):
+    bh, bl = [], []
+    for c in range(8):
+        for t in range(2):
+            h, l = split16_scaled(u[c][8 * t: 8 * t + 8].T)
+            bh.append(h)
+            bl.append(l)
+    return bh, bl
+
+
 def color32_tile(stream16, tables, part, pts, nrm, raymisc):
     """One 32-sample tile of the reflectance net through the colour block stream (csrc/nrh_color32.hip).
     part [32,256]: the feature block's share of layer 0 (W0feat * feature); pts, nrm [32,3]; raymisc [>= 99].  -> rgb [32,3]."""
@@ -260,25 +290,25 @@ def color32_tile(stream16, tables, part, pts, nrm, raymisc):
                 idx = 16 * (s - 1) + 8 * (i >> 2) + 4 * HF + (i & 3)
                 ok = idx < 99
                 v[:, i] = np.where(ok, np.asarray(raymisc, dtype=np.float64)[np.minimum(idx, 98)], 0.0)
-        h, l = split16(v)
+        h, l = split16_scaled(v)
         bh.append(h)
         bl.append(l)
     u = []
     for c in range(8):
-        hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+        hh, cc = kloop_scaled(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
         t = hh + bias(0, c) + cc / 2048.0
         for r in range(16):
             t[r] += part[J, 32 * c + frow(r, HF)]
         u.append(np.maximum(t, 0.0))
     for l in range(1, 4):
-        bh, bl = act_to_b(u)
+        bh, bl = act_to_b_scaled(u)
         nu = []
         for c in range(8):
-            hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+            hh, cc = kloop_scaled(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
             nu.append(np.maximum(hh + bias(l, c) + cc / 2048.0, 0.0))
         u = nu
-    bh, bl = act_to_b(u)
-    hh, cc = kloop(st.chunk(16), 16, bh, bl, tab_init(raw.astype(np.float64), 4, 0))
+    bh, bl = act_to_b_scaled(u)
+    hh, cc = kloop_scaled(st.chunk(16), 16, bh, bl, tab_init(raw.astype(np.float64), 4, 0))
     assert st.pos == len(st.buf)
     v = hh + cc / 2048.0
     rgb = np.zeros((32, 3))

@@ -176,3 +176,38 @@ def test_wide_reflectance_kernel(wscene):
         assert torch.equal(a.weights, x.weights) and torch.equal(a.depth, x.depth) and torch.equal(a.visibilities, x.visibilities)
         assert float((a.rgb - x.rgb).abs().max()) < 3e-6, float((a.rgb - x.rgb).abs().max())
     assert torch.isfinite(a.rgb).all()
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.05, 8.0])
+def test_wide_reflectance_kernel_vs_oracle(wscene, scene_states, scale):
+    """nrh_color_eval_wide against the fp64 oracle (fields/reflectance_network.py:68-96) on free inputs of several magnitudes:
+    points on real rays, random unit normals, random features (-> part = W0feat * feature), random hints."""
+    from nrhints_amd import packing as pkg, packing32
+    from oracle import neus_oracle as orc
+    tag, model, packed, _ = wscene
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = pkg.dense_params({k: v.detach().float().to(dev) for k, v in model.state_dict().items()})
+    c32, ctab = packing32.pack_color32(d)
+    N = 5
+    o, dd, pl, near, far = make_rays(N, seed=31, spread=0.1)
+    g = torch.Generator().manual_seed(7)
+    tmid = torch.rand(N, 128, generator=g) * 2 + 2
+    nhat = torch.nn.functional.normalize(torch.randn(N * 128, 3, generator=g), dim=-1)
+    feat = torch.randn(N * 128, 256, generator=g) * 0.3 * scale
+    vis = torch.rand(N, 1, generator=g)
+    cue = torch.rand(N, 4, generator=g) * 2 * scale
+    T = torch.from_numpy
+    raymisc = torch.zeros(N + 1, pkg.RAYMISC_STRIDE)
+    raymisc[:N, 0:27] = orc.nerf_encode(T(dd), 4)
+    raymisc[:N, 27:54] = orc.nerf_encode(T(pl), 4)
+    raymisc[:N, 54:63] = orc.nerf_encode(vis, 4)
+    raymisc[:N, 63:99] = orc.nerf_encode(cue, 4)
+    part = (feat.double() @ d["col_w0"].double().cpu()[:, 60:316].t()).float()
+    col = ops.color_eval_wide(c32, ctab, pkg.rows_to_feat_tiles(part).cuda(), cu(o), cu(dd), tmid.cuda(), nhat.cuda().contiguous(),
+                              raymisc.cuda())
+    p64 = orc.params_from_state(scene_states[tag], torch.float64)
+    pts = (T(o)[:, None] + T(dd)[:, None] * tmid[..., None]).reshape(-1, 3)
+    rep = lambda x: x[:, None, :].expand(N, 128, x.shape[-1]).reshape(N * 128, -1)
+    ref = orc.color_forward(p64, pts.double(), nhat.double(), rep(T(dd)).double(), feat.double(), rep(T(pl)).double(), rep(vis).double(), rep(cue).double())
+    err = (col.cpu().double() - ref).abs()
+    assert float(err.max()) < 5e-6, (float(err.max()), float(err.mean()), int(err.reshape(N, 128, 3).amax(-1).argmax()))
