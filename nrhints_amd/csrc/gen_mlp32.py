@@ -40,7 +40,7 @@ def aput(idx, val):
 def split_ops(i, v0, v1, out_hi, out_lo, pfx="", scaled=False):
     """hi/lo split of the pair (v0, v1) -> AGPRs out_hi / out_lo (nrh32::split2 / split2_scaled, spelled out per instruction).
     scaled: the residual is multiplied by 2^11 before it is rounded to fp16 (the reflectance net's activations are O(0.01..1):
-    their unscaled residuals are fp16 subnormals, and those do not survive here - measured, profiles/r02/color32_lo_flush.log)."""
+    their unscaled residuals would all be fp16 subnormals; two more VALU per pair keep them in the normal range)."""
     n = f"{pfx}{i}"
     if scaled:
         mid = [
@@ -115,7 +115,7 @@ def epi_relu(c, hp, cp, out_base=128, part=False):
             ops.append(Op(f"float t{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"t{r}",)))
             src = f"t{r}"
             if part:
-                ops.append(Op(f"float s{r} = t{r} + __builtin_bit_cast(float, pw{r // 4}[{r % 4}]);", defs=(f"s{r}",), uses=(f"t{r}",)))
+                ops.append(Op(f"float s{r} = t{r} + pw{r // 4}[{r % 4}];", defs=(f"s{r}",), uses=(f"t{r}",)))
                 src = f"s{r}"
             ops.append(Op(f"float u{r} = __builtin_amdgcn_fmed3f({src}, 0.0f, 3.0e38f);", defs=(f"u{r}",), uses=(src,)))
         ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i, scaled=True)
@@ -270,6 +270,7 @@ def acc_names(c):
 
 # asm loads a stage issues per window for the epilogue that runs one window later: (register stems, macro)
 STAGE_LOADS = {"rev": (("qa", "qb"), "W32_QLOAD_ASM"), "relu_part": (("pa", "pb", "pc", "pd"), "W32_PLOAD_ASM")}
+LOAD_TYPE = {"rev": "nrh32::u32x4", "relu_part": "f32x4"}
 
 
 def stage_epilogue(kind, c, ph, pc, want_d, out_base, qstore):
@@ -304,7 +305,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         out.append(f"  nrh32::f32x16 hh{c}, cc{c};")
     for c in range(7):
         if loads:
-            out.append("  nrh32::u32x4 " + ", ".join(f"{st}{c}" for st in loads) + ";")
+            out.append(f"  {LOAD_TYPE[kind]} " + ", ".join(f"{st}{c}" for st in loads) + ";")
     ln = lambda c, stems: [(f"{st[0]}p{st[1:]}" if c == 7 else f"{st}{c}") for st in stems]   # chunk 7: qpa, qpb / ppa..ppd
     for c in range(8):
         out.append(f"  {{  // window {c}")
@@ -325,7 +326,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             ph, pc = "ph0", "pc0"
             for nm in ln(7, ploads):
                 out.append(f'    asm volatile("" : "+v"({nm}));')
-                out.append(f"    nrh32::u32x4 c_{nm} = {nm};")
+                out.append(f"    {LOAD_TYPE[pend_kind]} c_{nm} = {nm};")
                 pnames.append(f"c_{nm}")
         epi, head = None, None
         if has_epi:
@@ -348,7 +349,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
                 names = pnames if c == 0 else ln(prev, estems)
                 for k, nm in enumerate(names):
                     out.append(f'    asm volatile("" : "+v"({nm}));')
-                    out.append(f"    const nrh32::u32x4 {wname[ekind]}{k} = {nm};")
+                    out.append(f"    const {LOAD_TYPE[ekind]} {wname[ekind]}{k} = {nm};")
         win = Window(ks, hh, cc, b_src=b_src, hh_zero=(hh_zero or bias_mfma), in_base=in_base,
                      bias=(("bw", "W32_BCONST") if bias_mfma else None), b_lo_scaled=kind.startswith("relu"))
         if small:

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       __builtin_amdgcn_sched_barrier(0);
     }
     f32x16 hp, cp;
-    u32x4 ppa, ppb, ppc, ppd;
+    f32x4 ppa, ppb, ppc, ppd;
     const char* const pbase = uni(reinterpret_cast<const char*>(a.part) + tile * 32768);
     // feature-block share of chunk c, quad g (rows 32 c + 8 g + 4 hf + 0..3): asm loads (invisible to hipcc's vmcnt bookkeeping,
     // written straight into their registers), consumed one window later
