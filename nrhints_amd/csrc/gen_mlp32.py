@@ -284,7 +284,7 @@ def stage_epilogue(kind, c, ph, pc, want_d, out_base, qstore):
 
 
 def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pend_in=True, bias_mfma=False, skip=False,
-              pend_kind=None):
+              pend_kind=None, full_block=False):
     """A pipelined 8-chunk stage, ping-pong form: B operands from AGPR set `in_base`, results into set `out_base`; no copy.
     Window c runs the K loop of chunk c and the epilogue of chunk c - 1; window 0 runs the epilogue of the PREVIOUS stage's
     chunk 7 (pending in hp, cp [, qpa, qpb]), whose outputs are this stage's K steps 14 and 15 - they are only read by the
@@ -293,7 +293,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
     Hooks (macros of the including kernel): W32_SYNC(), W32_FETCH_SETUP(), W32_DMA(piece), W32_NEXT(), W32_WADDR(),
     W32_HINIT(c) (f32x16 start values, unless hh_zero), W32_QSTORE(c, half, v) (this stage's layer), W32_QSTORE_P (the
     previous stage's layer), W32_QLOAD_ASM(dst, c, half)."""
-    small = ks != 16
+    small = ks != 16 and not full_block      # full_block: fewer K steps, but still one 32 KiB block (and one sync) per chunk
     pend_kind = kind if pend_kind is None else pend_kind
     loads, load_macro = STAGE_LOADS.get(kind, ((), None))            # what this stage's windows request
     ploads = STAGE_LOADS.get(pend_kind, ((), None))[0]               # what arrives pending from the previous stage
@@ -503,7 +503,7 @@ def main():
         "t7_loads.inc": gen_t7_loads(),
         # reflectance net on the same machinery (csrc/nrh_color32.hip): C0 (misc inputs, + the feature block's share loaded per
         # window) -> C1 -> C2 -> C3 (ReLU), then the 3-row output chunk as a bare K loop
-        "col_c0.inc": gen_stage("relu_part", False, 16, "agpr", nv, True, in_base=0, out_base=128, pend_in=False, bias_mfma=True),
+        "col_c0.inc": gen_stage("relu_part", False, 8, "agpr", 6, True, in_base=0, out_base=128, pend_in=False, bias_mfma=True, full_block=True),
         "col_c1.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=128, out_base=0, bias_mfma=True, pend_kind="relu_part"),
         "col_c2.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=0, out_base=128, bias_mfma=True),
         "col_c3.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=128, out_base=0, bias_mfma=True),

@@ -16,7 +16,7 @@
 namespace nrh32 {
 
 struct Color32Args {
-  const char* w;          // block stream: C0 (8 blocks, K steps 8..15 of each are zero weights), C1, C2, C3 (8 each), C4 (1)
+  const char* w;          // block stream: C0 (8 blocks; only K steps 0..7 of each are read), C1, C2, C3 (8 each), C4 (1)
   const float* tab;       // [5][256]: rows 0..3 packed fp16 bias pairs of C0..C3, row 4 b4 (3 floats)
   const float* part;      // [ntiles16][16][64][4]  W0feat * feature (+ W0feat * b_feat), D-layout tiles of 16 points
   const float* ro;        // [nrays,3]
@@ -80,15 +80,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // this lane's 16 B inside a 16-point tile pair of `part`: sub-tile j >> 4, quarter hf (+ 2 for the odd half-blocks), point j & 15
   const uint32_t plane = (uint32_t)((j >> 4) * 16384 + hf * 256 + (j & 15) * 16);
   auto tab_row = [&](int table, int c) { return ld_init(tabs + table * 1024 + (32 * c + 4 * hf) * 4, 32); };
-
-  // C0 reads K steps 8..15 of set 0 against zero weights: whatever sits there must be finite (first pass: zero it; later passes
-  // find the previous ray's ReLU outputs there)
-#define Z4(N) asm volatile("v_accvgpr_write_b32 a" #N ", %0" ::"v"(0u) : "a" #N);
-#define Z16(A, B, C, D, E, F, G, H, I, J, K, L, M, N, O, P) Z4(A) Z4(B) Z4(C) Z4(D) Z4(E) Z4(F) Z4(G) Z4(H) Z4(I) Z4(J) Z4(K) Z4(L) Z4(M) Z4(N) Z4(O) Z4(P)
-  Z16(32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47) Z16(48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63)
-  Z16(96, 97, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111) Z16(112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127)
-#undef Z16
-#undef Z4
 
   for (int ray = blockIdx.x; ray < a.nrays; ray += gridDim.x) {
     const long long tile = (long long)ray * WAVES + wave;      // 32 consecutive samples of this ray
