@@ -70,6 +70,8 @@ def build_scene(precision):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_b.items()})
     if os.environ.get("NRH_BENCH_NO_FUSE"):       # A/B of NrhNet.feat_fused (profiles/r02/fused_head_ab.log); not a product knob
         model.fuse_feature_head = False
+    if os.environ.get("NRH_BENCH_CHUNK"):          # A/B of the rays-per-launch chunk (profiles/r02/chunk_rays_ab.log)
+        model.max_chunk_rays = int(os.environ["NRH_BENCH_CHUNK"])
     if os.environ.get("NRH_BENCH_NO_WIDE_COLOR"):  # A/B of the wide reflectance kernel (profiles/r02/wide_color_ab.log)
         model.wide_color = False
     return model, state_b

@@ -275,8 +275,8 @@ long long nrh_color_wide_stream_bytes(void);
 /* The reflectance net of the hinted model on the wide kernel (what nrh_render_forward runs when NrhNet.col_w32 is set):
  * ReflectanceNetwork.forward (fields/reflectance_network.py:68-96) at the 128 samples of `nrays` rays, with the feature block of
  * its first layer given as `part_tiles` = W0[:, 60:316] * feature (+ b_feat folded), D-layout tiles of 16 points as nrh_sdf_eval
- * mode 2 writes them with the fused streams (NrhNet.feat_fused); the other arguments as nrh_color_eval.  raymisc rows need
- * 112 readable floats (stride 100: the last row must be followed by 12 floats of allocated memory). */
+ * mode 2 writes them with the fused streams (NrhNet.feat_fused); the other arguments as nrh_color_eval (raymisc: rows of 100
+ * floats, 99 used). */
 int nrh_color_eval_wide(const void* col_w32, const float* col_tab32, const float* part_tiles, const float* ro, const float* rd,
                         const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color, void* stream);
 

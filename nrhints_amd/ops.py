@@ -164,7 +164,7 @@ def color_eval(col_w, col_b, feat_tiles, ro, rd, tmid, nhat, raymisc, hints: boo
 @_lib.on_tensor_device
 def color_eval_wide(col_w32, col_tab32, part_tiles, ro, rd, tmid, nhat, raymisc) -> torch.Tensor:
     """Reflectance MLP on the wide kernel for nrays x 128 samples -> [nrays*128, 3]; ``part_tiles``: W0feat * feature as
-    16-point D-layout tiles (packing.rows_to_feat_tiles); ``raymisc`` [nrays, 100] (+ 12 readable floats behind the last row)."""
+    16-point D-layout tiles (packing.rows_to_feat_tiles); ``raymisc`` [nrays, 100]."""
     lib = _lib.load()
     nrays = ro.shape[0]
     color = torch.empty(nrays * 128, 3, dtype=torch.float32, device=ro.device)

@@ -3,7 +3,7 @@
 The reference renders a test view as 1 250 chunks of 512 rays, copies each chunk's full ``RenderOutput`` (6.7 KB/ray) to
 the host, concatenates, and reduces the normal maps with an ``einsum`` on the CPU (pipelines/base_pipeline.py:107-133).
 Here one view is: rays generated on the device from (pose, intrinsics, light) by a HIP kernel
-(camera/ray_generator.py:79-139 without pose deltas), one pass through the renderer in 32 768-ray chunks, and the
+(camera/ray_generator.py:79-139 without pose deltas), one pass through the renderer in 131 072-ray chunks, and the
 per-pixel products - rgb, depth, shadow map, the two weighted normal maps - reduced inside the composite kernel, so a
 frame leaves the GPU as 15 floats per pixel.  PSNR is ``10 log10(1 / MSE)`` (utils/metrics.py:8-9).
 """

@@ -101,12 +101,13 @@ class SingleVarianceNetwork(nn.Module):
 
 class NeuSHintRenderer(nn.Module):
     #: rays per C call; bounds the workspace (about 145 KB per ray + 268 MB of gradient scratch)
-    max_chunk_rays = 32768
+    max_chunk_rays = 131072    # rays per nrh_render_forward call: 18 GB of workspace (HBM is 288 GB); +1.3 % over 32 768 (profiles/r02/chunk_rays_ab.log)
     #: matrix arithmetic of the MLP kernels: "f32" (v_mfma_f32_16x16x4_f32, exact fp32) or "f16x3" (three
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
     precision = "f16x3"
     wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
     wide_color = True          # ... and the reflectance net on the wide machinery as well (csrc/nrh_color32.hip; hinted model only)
+    max_eval_rays_while_graphed = 32768   # training.GraphedTrainStep pins the workspace: evaluation chunks while a graph is alive
     fuse_feature_head = True   # evaluation renders with the wide kernels: W0feat * W_feat multiplied at pack time (NrhNet.feat_fused)
     max_fused_train_rays = 8192
     # hipGraph mode (training.GraphedTrainStep): a device tensor [inv_s, cos_anneal] that the kernels read at run time
@@ -371,7 +372,7 @@ class NeuSHintRenderer(nn.Module):
             out.update(normal_map=new(n, 3), normalized_normal_map=new(n, 3))
         if want_mid:
             out.update(mid_z=new(n, T), dists=new(n, T))
-        chunk = max(1, min(self.max_chunk_rays, n))
+        chunk = max(1, min(self.max_chunk_rays if self.dyn_scalars is None else self.max_eval_rays_while_graphed, n))
         ws = self._workspace(device, chunk)
         stream = _lib.stream_handle()
         P = _lib.ptr

@@ -180,7 +180,7 @@ class GraphedTrainStep:
         self._keys: List[str] = []
         # the workspace pointer is baked into the graph: make it large enough for any later evaluation render as well, so
         # that the renderer never replaces (frees) it while the graph is alive
-        renderer._workspace(dev, max(n, int(renderer.max_chunk_rays)))
+        renderer._workspace(dev, max(n, int(renderer.max_eval_rays_while_graphed)))
         # Warm-up passes build every cache (pack plans, constants, Adam state tensors) eagerly.  They run real optimiser
         # steps on synthetic rays, so the parameters are put back and the Adam state is zeroed afterwards: capturing a
         # step must not change the model or what a resumed optimiser remembers.
