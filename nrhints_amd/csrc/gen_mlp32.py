@@ -122,6 +122,19 @@ def epi_relu(c, hp, cp, out_base=128, part=False):
     return ops
 
 
+def epi_feat(c, hp, cp, store="W32_FSTORE"):
+    """Feature-head epilogue of chunk c: v = hh + cc 2^-11, stored as four float4 (rows 32 c + 8 g + 4 hf + 0..3 of this lane's
+    point): W32_FSTORE(c, g, value).  No AGPR output - nothing reads the feature as a B operand."""
+    ops = []
+    for g in range(4):
+        for k in range(4):
+            r = 4 * g + k
+            ops.append(Op(f"float v{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"v{r}",)))
+        w = [f"v{4 * g + k}" for k in range(4)]
+        ops.append(Op(f"{store}({c}, {g}, (f32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
+    return ops
+
+
 def schedule(ops, nslots, per_slot):
     """Greedy list schedule: an op may run in slot k if everything it uses was defined in a slot < k (or outside).
     Returns (slots, tail): ops per slot, and what did not fit."""
@@ -280,6 +293,8 @@ def stage_epilogue(kind, c, ph, pc, want_d, out_base, qstore):
         return epi_rev(c, ph, pc, out_base=out_base)
     if kind in ("relu", "relu_part"):
         return epi_relu(c, ph, pc, out_base=out_base, part=(kind == "relu_part"))
+    if kind == "feat":
+        return epi_feat(c, ph, pc)
     raise ValueError(kind)
 
 
@@ -400,6 +415,8 @@ def gen_finish(kind, want_d, out_base):
         epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P")
     elif kind == "relu":
         epi = epi_relu(7, "hp", "cp", out_base=out_base)
+    elif kind == "feat":
+        epi = epi_feat(7, "hp", "cp")
     else:
         out.append('  asm volatile("" : "+v"(qpa), "+v"(qpb));   // landed: the stage body ends with a wait for them')
         out.append("  const nrh32::u32x4 qw0 = qpa, qw1 = qpb;")
@@ -499,6 +516,8 @@ def main():
         "kloop16z.inc": gen_kloop(16, "agpr", True),
         "kloop3v.inc": gen_kloop(3, "vgpr", False),
         "kloop3v_acc.inc": gen_kloop(3, "vgpr", False, acc_all=True),
+        "feat.inc": gen_stage("feat", False, 16, "agpr", nv, True, in_base=128, out_base=128, pend_in=False, bias_mfma=True),
+        "feat_fin.inc": gen_finish("feat", False, 128),
         "t7.inc": gen_t7(),
         "t7_loads.inc": gen_t7_loads(),
         # reflectance net on the same machinery (csrc/nrh_color32.hip): C0 (misc inputs, + the feature block's share loaded per

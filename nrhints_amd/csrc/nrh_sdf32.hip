@@ -292,24 +292,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const long long t16 = 2 * tile + (j >> 4);
       const bool t16_ok = t16 * 16 < a.npts;
       float* const ft = a.feat + (size_t)t16 * 4096 + ((j & 15) + 16 * hf) * 4;
-      for (int c = 0; c < 8; ++c) {
-        W32_SYNC();
-        W32_FETCH_SETUP();
-        f32x16 hh = tab_init(8, c), cc;
-        const uint32_t wa = W32_WADDR();
-#include "gen32/kloop16.inc"
-        if (t16_ok) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(cc[4 * g + r], LO_UNSCALE, hh[4 * g + r]);
-            // features 32c + 8g + 4hf + r  ->  16-row block 2c + (g >> 1), quarter 2 (g & 1) + hf of the 16-point tile
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ft + ((2 * c + (g >> 1)) * 64 + 32 * (g & 1)) * 4));
-          }
-        }
-        W32_NEXT();
+      // the feature head as a pipelined stage like the layers (epilogue of chunk c - 1 under the K loop of chunk c, bias through
+      // an MFMA): features 32c + 8g + 4hf + r  ->  16-row block 2c + (g >> 1), quarter 2 (g & 1) + hf of the 16-point tile
+#define W32_FSTORE(c, g, val) do { if (t16_ok) __builtin_nontemporal_store((val), reinterpret_cast<f32x4*>(ft + ((2 * (c) + ((g) >> 1)) * 64 + 32 * ((g) & 1)) * 4)); } while (0)
+#define W32_BIAS(c) (*reinterpret_cast<const uint32_t*>(brow + 8 * 1024 + (c) * 128))
+#define W32_BCONST bconst
+      {
+#include "gen32/feat.inc"
       }
+#include "gen32/feat_fin.inc"
+#undef W32_FSTORE
+#undef W32_BIAS
+#undef W32_BCONST
     }
     // q_7 words for the T7 pass: requested inside the HEAD window, consumed after it (their L2 latency passes under HEAD's K loop)
     u32x4 q0a, q0b, q1a, q1b, q2a, q2b, q3a, q3b, q4a, q4b, q5a, q5b, q6a, q6b, qpa, qpb;

@@ -77,7 +77,7 @@ def pack_stage32(w: torch.Tensor, rows: int, ks: int) -> torch.Tensor:
 def sdf32_tables(d: Dict[str, torch.Tensor]) -> torch.Tensor:
     """[NTAB, 256] float32: 0..7 the bias rows of the eight layers as ONE PACKED fp16 PAIR per output row,
     bits (b_hi | b_lo * 2^11 << 16) of b_l * IK (rows >= 217 of layer 3 zero) - the kernel adds them through one extra MFMA
-    per window (csrc/gen_mlp32.py, bias_mfma); 8 b_feat, 9 {b_s / 3, 0, ...}, 10 w_s / 3."""
+    per window (csrc/gen_mlp32.py, bias_mfma); 8 b_feat in the same packed form, 9 {b_s / 3, 0, ...}, 10 w_s / 3."""
     f = lambda t: t.detach().float()
     rows = []
     for l in range(8):
@@ -85,7 +85,8 @@ def sdf32_tables(d: Dict[str, torch.Tensor]) -> torch.Tensor:
         hi, lo = split_f16(b)       # b = hi + lo / 2^11
         b = (hi.view(torch.int16).to(torch.int32) & 0xffff | (lo.view(torch.int16).to(torch.int32) << 16)).view(torch.float32)
         rows.append(b)
-    rows.append(f(d["feat_b"]))
+    hi, lo = split_f16(f(d["feat_b"]))             # the feature head takes its bias the same way (row 8)
+    rows.append((hi.view(torch.int16).to(torch.int32) & 0xffff | (lo.view(torch.int16).to(torch.int32) << 16)).view(torch.float32))
     rows.append(torch.nn.functional.pad(f(d["sdf_head_b"]).reshape(1) / 3.0, (0, 255)))
     rows.append(f(d["sdf_head_w"]).reshape(256) / 3.0)
     return torch.stack(rows).contiguous()

@@ -120,7 +120,7 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
     """One 32-point tile through the MODE `mode` stream.  pts [32,3] float64.  -> sdf [32], grad [32,3] | None, feat | None."""
     raw = np.ascontiguousarray(np.asarray(tables, dtype=np.float32))
     tables = raw.astype(np.float64)
-    # rows 0..7: one packed fp16 pair per output row, (b_hi | b_lo * 2^11 << 16); the kernel adds it through one extra MFMA
+    # rows 0..8: one packed fp16 pair per output row, (b_hi | b_lo * 2^11 << 16); the kernel adds it through one extra MFMA
     # with the B column [1, 2^-11, 0, ...]
     bits = raw.view(np.uint32)
     bias_hi = (bits & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
@@ -187,8 +187,8 @@ def sdf32_tile(stream16, tables, pts, mode, trace=None):
     if mode == 2:
         feat = np.zeros((32, 256))
         for c in range(8):
-            hh, cc = kloop(st.chunk(16), 16, bh, bl, tab_init(tables, 8, c))
-            v = hh + cc / 2048.0
+            hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+            v = hh + bias_mfma(8, c) + cc / 2048.0
             for r in range(16):
                 feat[J, 32 * c + frow(r, HF)] = v[r]
     hh, cc = kloop(st.chunk(16), 16, bh, bl, tab_init(tables, 9, 0))
