@@ -40,7 +40,8 @@ def aput(idx, val):
 def split_ops(i, v0, v1, out_hi, out_lo, pfx="", scaled=False):
     """hi/lo split of the pair (v0, v1) -> AGPRs out_hi / out_lo (nrh32::split2 / split2_scaled, spelled out per instruction).
     scaled: the residual is multiplied by 2^11 before it is rounded to fp16 (the reflectance net's activations are O(0.01..1):
-    their unscaled residuals would all be fp16 subnormals; two more VALU per pair keep them in the normal range)."""
+    their unscaled residuals would all be fp16 subnormals - which the MFMA and v_cvt_pkrtz do honour (profiles/r02/denorm32.log) -
+    two more VALU per pair keep them in the normal range and their full 11 bits)."""
     n = f"{pfx}{i}"
     if scaled:
         mid = [

@@ -58,7 +58,7 @@ __host__ __device__ constexpr int frow(int r, int hf) { return (r & 3) + 8 * (r 
 __host__ __device__ constexpr int col32(int s, int hf, int i) { return 16 * s + (i & 3) + 8 * (i >> 2) + 4 * hf; }
 
 // Activations as MFMA B operands: x = hi + lo with the residual lo UNSCALED (fp16 subnormals are honoured by the MFMA on
-// gfx950, profiles/r01/denorm.log; |x - hi - lo| <= max(2^-22 |x|, 2^-25)), two values per register.  Weights (A operands)
+// gfx950 and so does v_cvt_pkrtz_f16_f32: profiles/r02/denorm32.log, ubench/denorm32.hip; |x - hi - lo| <= max(2^-22 |x|, 2^-25)), two values per register.  Weights (A operands)
 // keep lo scaled by 2^11 in the packed stream, so a product is hh += A_hi B_hi + A_hi B_lo and cc += A_lo B_hi with cc in
 // units of 2^-11 (one fused multiply-add joins them in the epilogue).
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
