@@ -71,7 +71,9 @@ int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b
  * different packed parameters:  sdf_w32 = the three per-mode chunk streams back to back (nrh_sdf_wide_stream_bytes() bytes of
  * fp16 hi/lo pairs, nrhints_amd/packing32.py: pack_sdf32), sdf_tab32 = [11][256] float32 bias / head tables.
  * scratch as for nrh_sdf_eval (the same buffer serves both).  NrhNet.sdf_w32 / sdf_tab32 select these kernels inside
- * nrh_render_forward for every SDF evaluation of the evaluation path when precision is 1. */
+ * nrh_render_forward for every SDF evaluation of the evaluation path when precision is 1.
+ * Additional mode 3 (wide kernels only): sdf + the derivative along the ray in forward mode (16 points and their 16 tangents per
+ * tile, no scratch); `grad` [npts,3] receives rd * (d sdf / dt) / |rd|^2, i.e. <rd, grad> equals <rd, true gradient>. */
 int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
                       int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, float* feat,
                       float* scratch, void* stream);
@@ -207,6 +209,9 @@ typedef struct NrhNet {
   const void* col_w32;      /* optional, with feat_fused: the reflectance net as a block stream for the wide kernel          */
   const float* col_tab32;   /* (packing32.pack_color32: nrh_color_wide_stream_bytes() bytes + [5][256] float32 tables); when   */
                             /* both are non-null the evaluation render runs fields/reflectance_network.py:68-96 on it         */
+  int shadow_jvp;           /* 1 (with sdf_w32): the shadow march's last evaluation uses nrh_sdf_eval mode 3 - value + derivative
+                               ALONG the ray in forward mode, returned as rd * (d sdf / dt) / |rd|^2 in place of the gradient:
+                               get_alpha only uses <dirs, gradients> (models/neus_hint_model.py:343) */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

@@ -30,7 +30,7 @@ class NrhNet(Structure):
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
                 ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
-                ("col_w32", c_void_p), ("col_tab32", c_void_p)]
+                ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int)]
 
 
 class NrhTrainSaves(Structure):
@@ -154,7 +154,7 @@ def stream_handle(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True):
+def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=True):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
     ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""
@@ -166,4 +166,5 @@ def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fu
                   ptr(pk["col_w"], pk["col_w"].dtype), ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
                   hints, normal_type, depth_type, ptr(dyn_scalars),
                   ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
-                  ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None)
+                  ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None,
+                  int(bool(shadow_jvp and w32 is not None)))

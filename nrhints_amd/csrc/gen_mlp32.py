@@ -65,8 +65,11 @@ def split_ops(i, v0, v1, out_hi, out_lo, pfx="", scaled=False):
     return ops
 
 
-def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE"):
-    """Forward epilogue of chunk c: t (bias is in the accumulator) -> u = log2(1 + 2^t) -> hi/lo -> out; q = 1/(1+2^t)."""
+def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE", jvp=False):
+    """Forward epilogue of chunk c: t (bias is in the accumulator) -> u = log2(1 + 2^t) -> hi/lo -> out; q = 1/(1+2^t).
+    jvp: the tile holds 16 points (columns 0..15) and their 16 tangents (columns 16..31, the directional derivative along the
+    ray): a tangent lane takes q from its point lane (16 lanes below: W32_SWAP = v_permlane16_swap) and writes (1 - q) t
+    instead of the softplus; W32_ISPT is the per-lane predicate "column < 16"."""
     ops = []
     for i in range(8):
         for r in (2 * i, 2 * i + 1):
@@ -76,10 +79,16 @@ def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE"):
                 Op(f"float e{r} = __builtin_amdgcn_exp2f(m{r});", defs=(f"e{r}",), uses=(f"m{r}",), kind="trans"),
                 Op(f"float p{r} = 1.0f + e{r};", defs=(f"p{r}",), uses=(f"e{r}",)),
                 Op(f"float g{r} = __builtin_amdgcn_logf(p{r});", defs=(f"g{r}",), uses=(f"p{r}",), kind="trans"),
-                Op(f"float u{r} = __builtin_amdgcn_fmed3f(g{r}, t{r}, 3.0e38f);", defs=(f"u{r}",), uses=(f"g{r}", f"t{r}")),
+                Op(f"float {'s' if jvp else 'u'}{r} = __builtin_amdgcn_fmed3f(g{r}, t{r}, 3.0e38f);", defs=(f"{'s' if jvp else 'u'}{r}",), uses=(f"g{r}", f"t{r}")),
             ]
-            if want_d:
+            if want_d or jvp:
                 ops.append(Op(f"float q{r} = __builtin_amdgcn_rcpf(p{r});", defs=(f"q{r}",), uses=(f"p{r}",), kind="trans"))
+            if jvp:
+                ops += [
+                    Op(f"float x{r} = W32_SWAP(q{r});", defs=(f"x{r}",), uses=(f"q{r}",)),
+                    Op(f"float w{r} = __builtin_fmaf(-t{r}, x{r}, t{r});", defs=(f"w{r}",), uses=(f"t{r}", f"x{r}")),
+                    Op(f"float u{r} = W32_ISPT ? s{r} : w{r};", defs=(f"u{r}",), uses=(f"s{r}", f"w{r}")),
+                ]
         ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i)
         if want_d:
             ops.append(Op(f"uint32_t qq{i} = nrh32::unorm16x2(q{2 * i}, q{2 * i + 1});", defs=(f"qq{i}",),
@@ -288,8 +297,8 @@ LOAD_TYPE = {"rev": "nrh32::u32x4", "relu_part": "f32x4"}
 
 
 def stage_epilogue(kind, c, ph, pc, want_d, out_base, qstore):
-    if kind == "fwd":
-        return epi_fwd(c, ph, pc, want_d, out_base=out_base, qstore=qstore)
+    if kind in ("fwd", "fwd_jvp"):
+        return epi_fwd(c, ph, pc, want_d, out_base=out_base, qstore=qstore, jvp=(kind == "fwd_jvp"))
     if kind == "rev":
         return epi_rev(c, ph, pc, out_base=out_base)
     if kind in ("relu", "relu_part"):
@@ -412,8 +421,8 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
 def gen_finish(kind, want_d, out_base):
     """The pending chunk 7 of the last stage of a chain, on its own (no K loop to hide under): outputs into set `out_base`."""
     out = [f"// generated by gen_mlp32.py: finish kind={kind} want_d={want_d} out=a{out_base}", "{"]
-    if kind == "fwd":
-        epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P")
+    if kind in ("fwd", "fwd_jvp"):
+        epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P", jvp=(kind == "fwd_jvp"))
     elif kind == "relu":
         epi = epi_relu(7, "hp", "cp", out_base=out_base)
     elif kind == "feat":
@@ -509,6 +518,11 @@ def main():
         "fwd_d1_p0.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, nohinit, in_base=0, out_base=128, bias_mfma=bm),
         "fwd_d1_p1.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
         "fwd_fin_d0.inc": gen_finish("fwd", False, 128),
+        # forward-mode variant for rays that only need the derivative along the ray (shadow march): 16 points + 16 tangents per tile
+        "l0_j.inc": gen_stage("fwd_jvp", False, 3, "vgpr", 12, False, in_base=0, out_base=0, pend_in=False, bias_mfma=bm),
+        "fwd_j_p0.inc": gen_stage("fwd_jvp", False, 16, "agpr", nv + 2, nohinit, in_base=0, out_base=128, bias_mfma=bm),
+        "fwd_j_p1.inc": gen_stage("fwd_jvp", False, 16, "agpr", nv + 2, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
+        "fwd_fin_j.inc": gen_finish("fwd_jvp", False, 128),
         "fwd_fin_d1.inc": gen_finish("fwd", True, 128),
         "rev_p0.inc": gen_stage("rev", True, 16, "agpr", nv, True, in_base=0, out_base=128),
         "rev_p1.inc": gen_stage("rev", True, 16, "agpr", nv, True, in_base=128, out_base=0),

@@ -115,9 +115,10 @@ int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const floa
                   const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad,
                   float* feat, float* scratch, hipStream_t st, const WideNet wide = WideNet()) {
   if (prec == 1 && wide.streams && wide.tables) {
-    if (mode < 0 || mode > 2) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode must be 0, 1 or 2%s", "");
+    if (mode < 0 || mode > 3) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode must be 0, 1, 2 or (wide kernels) 3%s", "");
     if (!ro || !rd || !t || !sdf) return fail(NRH_E_INVALID, "nrh_sdf_eval: null pointer%s", "");
-    if (mode >= 1 && (!grad || !scratch)) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode %s needs grad and scratch", mode == 1 ? "1" : "2");
+    if (mode == 3 && !grad) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode 3 needs grad%s", "");
+    if ((mode == 1 || mode == 2) && (!grad || !scratch)) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode %s needs grad and scratch", mode == 1 ? "1" : "2");
     if (mode == 2 && !feat) return fail(NRH_E_INVALID, "nrh_sdf_eval: mode 2 needs feat%s", "");
     if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray || sdf_stride < n_per_ray)
       return fail(NRH_E_INVALID, "nrh_sdf_eval: bad n_per_ray/stride%s", "");
@@ -128,7 +129,7 @@ int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const floa
     c.sdf_stride = sdf_stride; c.max_grid = device_cus();
     TimedLaunch tl;
     bool timed;
-    timing_begin(mode, st, tl, timed);
+    timing_begin(mode == 3 ? 1 : mode, st, tl, timed);
     const int wrc = nrh32::wide_sdf_launch(c, st);
     timing_end(st, tl, timed);
     if (wrc == -1) return fail(NRH_E_INVALID, "nrh_sdf_eval: too many points%s", "");
@@ -259,7 +260,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 extern "C" {
 
-int nrh_version(void) { return 123; }
+int nrh_version(void) { return 124; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -722,7 +723,9 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s,
                      ws_dists_s, n, st);
     if (rc) return rc;
-    rc = sdf_eval_impl(net->precision, 1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
+    // the shadow ray's alpha only needs <direction, gradient>: with the wide kernels that is mode 3 (forward mode, no scratch)
+    const int smode = (net->shadow_jvp && net->precision == 1 && net->sdf_w32 && net->sdf_tab32) ? 3 : 1;
+    rc = sdf_eval_impl(net->precision, smode, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
                        128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
     if (rc) return rc;
   }

@@ -97,7 +97,19 @@ __device__ __forceinline__ float emb_dentry(const float (&x)[3], int e0, int e1,
 }
 __host__ __device__ constexpr int emb_dim(int e) { return e < 3 ? e : ((e - 3) % 18) / 6; }
 
-// MODE 0: sdf | 1: sdf + gradient | 2: + feature tiles
+// lanes 16..31 / 48..63 <- the value of lanes 0..15 / 32..47 (v_permlane16_swap_b32: odd 16-lane rows of the first operand
+// trade places with the even rows of the second); the even rows keep their own value
+__device__ __forceinline__ float swap_rows16(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned v = r[0];
+  return __builtin_bit_cast(float, v);
+}
+
+// MODE 0: sdf | 1: sdf + gradient | 2: + feature tiles | 3: sdf + the derivative ALONG the ray, forward mode: a tile is 16 points
+// (columns 0..15) and their 16 tangents (columns 16..31) through the same forward chain - no sigma' scratch, no reverse chain.
+// `grad` receives rd * (d sdf / dt) / |rd|^2, so that <rd, grad> is the directional derivative the alpha formula of a shadow ray
+// needs (models/neus_hint_model.py:343, true_cos = (dirs * gradients).sum(-1); only that product is used, :379-432).
 template <int MODE>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdf32_kernel(const Sdf32Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,8 +117,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, hf = lane >> 5;
   const uint32_t lane16 = lane * 16;
-  constexpr bool WANT_D = MODE >= 1;
-  constexpr long long STREAM = sdf32_stream_bytes(MODE);
+  constexpr bool JVP = MODE == 3;
+  constexpr bool WANT_D = MODE == 1 || MODE == 2;
+  constexpr int SMODE = JVP ? 0 : MODE;              // which stream this mode consumes (3: the forward-only one)
+  constexpr long long STREAM = sdf32_stream_bytes(SMODE);
+  constexpr int TPTS = JVP ? 16 : TILE;              // points per wave tile
+  const bool is_pt = !JVP || j < 16;                 // JVP: point column (else: the tangent column of point j - 16)
 
   char* const ring = smem + LDS_RING;
   const char* const tabs = smem + LDS_TAB;
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     fm0 = uni(ring_lds + fetch_off + wave * 8192);
     fm1 = fm0 + 4096;
     wfetch += SLOT_BYTES;
-    if (++bfetch == sdf32_stream_blocks(MODE)) { bfetch = 0; wfetch = wblocks; }
+    if (++bfetch == sdf32_stream_blocks(SMODE)) { bfetch = 0; wfetch = wblocks; }
     fetch_off = (fetch_off == 2 * SLOT_BYTES) ? 0 : fetch_off + SLOT_BYTES;
   };
 #define W32_DMA(i) dma_piece<((i) & 3) * 1024>(((i) < 4) ? fg0 : fg1, ((i) < 4) ? fm0 : fm1, lane16)
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #endif
   for (int tg = blockIdx.x; tg < a.ngroups; tg += gridDim.x) {
     const long long tile = (long long)tg * WAVES + wave;
-    const long long P = tile * TILE + j;
+    const long long P = tile * TPTS + (JVP ? (j & 15) : j);
     const bool valid = P < a.npts;
     const long long Pc = valid ? P : a.npts - 1;
     const long long ray = Pc / a.n_per_ray;
@@ -175,6 +191,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     float x3[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt) * 3.0f;  // inputs * scale
+    float xd[3] = {0.f, 0.f, 0.f};       // JVP: d x3 / dt
+    if constexpr (JVP) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xd[c] = a.rd[ray * 3 + c] * 3.0f;
+    }
 
     // ---- embedding as the B operand of E4 / L0: K step s, element i <-> entry col32(s, hf, i) ----
     u32x4 ebh0, ebh1, ebh2, ebl0, ebl1, ebl2;
@@ -184,8 +205,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          const float v0 = emb_entry(x3, col32(s, 0, 2 * p), col32(s, 1, 2 * p), hf);
-          const float v1 = emb_entry(x3, col32(s, 0, 2 * p + 1), col32(s, 1, 2 * p + 1), hf);
+          float v0 = emb_entry(x3, col32(s, 0, 2 * p), col32(s, 1, 2 * p), hf);
+          float v1 = emb_entry(x3, col32(s, 0, 2 * p + 1), col32(s, 1, 2 * p + 1), hf);
+          if constexpr (JVP) {   // tangent columns: d entry / dt = entry'(x3) * d x3 / dt
+            auto dsel = [&](int e0, int e1) {
+              const float d0 = (e0 < 39) ? xd[emb_dim(e0 < 39 ? e0 : 0)] : 0.0f, d1 = (e1 < 39) ? xd[emb_dim(e1 < 39 ? e1 : 0)] : 0.0f;
+              return hf ? d1 : d0;
+            };
+            const float t0 = emb_dentry(x3, col32(s, 0, 2 * p), col32(s, 1, 2 * p), hf) * dsel(col32(s, 0, 2 * p), col32(s, 1, 2 * p));
+            const float t1 = emb_dentry(x3, col32(s, 0, 2 * p + 1), col32(s, 1, 2 * p + 1), hf) * dsel(col32(s, 0, 2 * p + 1), col32(s, 1, 2 * p + 1));
+            v0 = is_pt ? v0 : t0;
+            v1 = is_pt ? v1 : t1;
+          }
           split2(v0, v1, eh[4 * s + p], el[4 * s + p]);
           __builtin_amdgcn_sched_barrier(0);   // two sines at a time: hipcc otherwise runs all 24 side by side and spills
         }
@@ -214,8 +245,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // Every layer's windows start from zero and take their bias through one extra MFMA (gen_mlp32.py gen_stage, bias_mfma):
     // table rows 0..7 hold one packed fp16 pair per output row, (b_hi | b_lo * 2^11 << 16), and the B operand is the constant
     // [1, 2^-11, 0, ...] of the hf = 0 lanes.
-    const u32x4 bconst = {hf ? 0u : 0x10003c00u, 0u, 0u, 0u};
+    const u32x4 bconst = {(hf || !is_pt) ? 0u : 0x10003c00u, 0u, 0u, 0u};     // (tangent columns take no bias)
     const char* const brow = tabs + (lane & 31) * 4;
+    // JVP: a tangent lane reads its point lane's value 16 lanes below (v_permlane16_swap: odd rows of 16 <- even rows)
+#define W32_SWAP(x) swap_rows16(x)
+#define W32_ISPT is_pt
     // layer 4's skip part: E4 * emb on top of the window's sums, 9 MFMAs over the resident block (B operands in VGPRs)
     auto skip_e4 = [&](int c, f32x16& hh, f32x16& cc) {
       const uint32_t wa = ring_lds + LDS_RESIDENT + c * 6144 + lane16;   // resident E4 chunk c: 3 K steps
@@ -244,7 +278,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // ---- L0 ----
     {
       const int qlayer = 0;
-      if constexpr (WANT_D) {
+      if constexpr (JVP) {
+#include "gen32/l0_j.inc"
+      } else if constexpr (WANT_D) {
 #include "gen32/l0_d1.inc"
       } else {
 #include "gen32/l0_d0.inc"
@@ -255,7 +291,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     for (int l = 1; l <= 7; l += 2) {
       {
         const int qlayer = l;
-        if constexpr (WANT_D) {
+        if constexpr (JVP) {
+#include "gen32/fwd_j_p0.inc"
+        } else if constexpr (WANT_D) {
 #include "gen32/fwd_d1_p0.inc"
         } else {
 #include "gen32/fwd_d0_p0.inc"
@@ -264,7 +302,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       if (l == 7) break;
       {
         const int qlayer = l + 1;
-        if constexpr (WANT_D) {
+        if constexpr (JVP) {
+#include "gen32/fwd_j_p1.inc"
+        } else if constexpr (WANT_D) {
 #include "gen32/fwd_d1_p1.inc"
         } else {
 #include "gen32/fwd_d0_p1.inc"
@@ -273,7 +313,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
     {
       const int qlayer = 8;   // the pending chunk 7 of layer 7 -> set 1, where FEAT / HEAD read their input
-      if constexpr (WANT_D) {
+      if constexpr (JVP) {
+#include "gen32/fwd_fin_j.inc"
+      } else if constexpr (WANT_D) {
 #include "gen32/fwd_fin_d1.inc"
       } else {
 #include "gen32/fwd_fin_d0.inc"
@@ -285,6 +327,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #undef W32_SKIP
 #undef W32_QSTORE
 #undef W32_QSTORE_P
+#undef W32_SWAP
+#undef W32_ISPT
 
     NRH32_STAMP(2);   // L1..L7
     // ---- FEAT (MODE 2) and HEAD ----
@@ -320,9 +364,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
         W32_QLOAD7_ASM(qpb, 7, 1);
       }
       f32x16 hh = tab_init(9, 0), cc;
+      if constexpr (JVP) {     // tangent columns: the head is linear, its bias does not differentiate
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hh[r] = is_pt ? hh[r] : 0.0f;
+      }
       const uint32_t wa = W32_WADDR();
 #include "gen32/kloop16.inc"
-      if (valid && hf == 0) a.sdf[ray * a.sdf_stride + jj] = __builtin_fmaf(cc[0], LO_UNSCALE, hh[0]);
+      const float head = __builtin_fmaf(cc[0], LO_UNSCALE, hh[0]);
+      if constexpr (JVP) {
+        if (valid && hf == 0) {
+          if (is_pt) {
+            a.sdf[ray * a.sdf_stride + jj] = head;
+          } else {     // head = d sdf / dt of point j - 16
+            const float rx = a.rd[ray * 3 + 0], ry = a.rd[ray * 3 + 1], rz = a.rd[ray * 3 + 2];
+            const float k = head / (rx * rx + ry * ry + rz * rz);
+            a.grad[P * 3 + 0] = rx * k; a.grad[P * 3 + 1] = ry * k; a.grad[P * 3 + 2] = rz * k;
+          }
+        }
+      } else {
+        if (valid && hf == 0) a.sdf[ray * a.sdf_stride + jj] = head;
+      }
       W32_NEXT();
     }
 

@@ -13,19 +13,22 @@ int wide_sdf_launch(const WideSdfCall& c, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -2;
   if (dev >= 0 && dev < 16 && !g_attr[dev]) {
-    const void* fns[3] = {(const void*)sdf32_kernel<0>, (const void*)sdf32_kernel<1>, (const void*)sdf32_kernel<2>};
+    const void* fns[4] = {(const void*)sdf32_kernel<0>, (const void*)sdf32_kernel<1>, (const void*)sdf32_kernel<2>,
+                          (const void*)sdf32_kernel<3>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -2;
     g_attr[dev] = true;
   }
   Sdf32Args a;
   long long off = 0;
-  for (int m = 0; m < c.mode; ++m) off += sdf32_stream_bytes(m);
+  const int smode = c.mode == 3 ? 0 : c.mode;     // mode 3 (forward-mode derivative along the ray) consumes the forward-only stream
+  for (int m = 0; m < smode; ++m) off += sdf32_stream_bytes(m);
   a.w = reinterpret_cast<const char*>(c.streams) + off;
   a.tab = c.tables; a.ro = c.ro; a.rd = c.rd; a.t = c.t; a.sdf = c.sdf; a.grad = c.grad; a.feat = c.feat;
   a.scratch = reinterpret_cast<uint32_t*>(c.scratch);
   a.npts = c.npts; a.n_per_ray = c.n_per_ray; a.t_stride = c.t_stride; a.sdf_stride = c.sdf_stride;
-  const long long groups = (c.npts + GROUP - 1) / GROUP;
+  const int group = c.mode == 3 ? GROUP / 2 : GROUP;                  // mode 3: 16 points + 16 tangents per wave tile
+  const long long groups = (c.npts + group - 1) / group;
   if (groups > 0x7fffffffLL) return -1;
   a.ngroups = (int)groups;
   a.dbg = nullptr; a.dbg_stage = 99;
@@ -33,7 +36,8 @@ int wide_sdf_launch(const WideSdfCall& c, hipStream_t st) {
   if (grid <= 0) return -2;
   if (c.mode == 0) hipLaunchKernelGGL(sdf32_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
   else if (c.mode == 1) hipLaunchKernelGGL(sdf32_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(sdf32_kernel<2>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
+  else if (c.mode == 2) hipLaunchKernelGGL(sdf32_kernel<2>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(sdf32_kernel<3>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
   return 0;
 }
 

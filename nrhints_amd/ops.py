@@ -51,7 +51,8 @@ def sdf_eval(mode: int, sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_str
 @_lib.on_tensor_device
 def sdf_eval_wide(mode: int, sdf_w32, sdf_tab32, ro, rd, t, n_per_ray: int, t_stride: Optional[int] = None,
                   scratch: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """``sdf_eval`` through the wide f16x3 kernels (csrc/nrh_sdf32.hip); sdf_w32 / sdf_tab32 from packing32.pack_sdf32."""
+    """``sdf_eval`` through the wide f16x3 kernels (csrc/nrh_sdf32.hip); sdf_w32 / sdf_tab32 from packing32.pack_sdf32.
+    mode 3 (wide only): sdf + the derivative along the ray in forward mode; ``grad`` = rd * (d sdf / dt) / |rd|^2."""
     lib = _lib.load()
     nrays = ro.shape[0]
     t_stride = n_per_ray if t_stride is None else t_stride
@@ -60,14 +61,14 @@ def sdf_eval_wide(mode: int, sdf_w32, sdf_tab32, ro, rd, t, n_per_ray: int, t_st
     npts = nrays * n_per_ray
     grad = torch.empty(npts, 3, dtype=torch.float32, device=dev) if mode >= 1 else None
     feat = torch.empty(((npts + 15) // 16) * 4096, dtype=torch.float32, device=dev) if mode == 2 else None
-    if mode >= 1 and scratch is None:
+    if mode in (1, 2) and scratch is None:
         scratch = _scratch(dev)
     if sdf_w32.numel() * sdf_w32.element_size() != lib.nrh_sdf_wide_stream_bytes():
         raise ValueError("sdf_w32 has the wrong size for this library build")
     P = _lib.ptr
     with torch.cuda.device(dev):
         rc = lib.nrh_sdf_eval_wide(mode, P(sdf_w32, sdf_w32.dtype), P(sdf_tab32), P(ro), P(rd), P(t), t_stride, n_per_ray, nrays,
-                                   P(sdf), n_per_ray, P(grad), P(feat), P(scratch) if mode >= 1 else None, _lib.stream_handle(dev))
+                                   P(sdf), n_per_ray, P(grad), P(feat), P(scratch) if mode in (1, 2) else None, _lib.stream_handle(dev))
     _lib.check(rc, "nrh_sdf_eval_wide")
     return sdf, grad, feat
 

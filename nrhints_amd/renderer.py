@@ -106,6 +106,7 @@ class NeuSHintRenderer(nn.Module):
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
     precision = "f16x3"
     wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
+    shadow_jvp = True          # ... the shadow march's last SDF evaluation in forward mode (mode 3: derivative along the ray only)
     wide_color = True          # ... and the reflectance net on the wide machinery as well (csrc/nrh_color32.hip; hinted model only)
     max_eval_rays_while_graphed = 32768   # training.GraphedTrainStep pins the workspace: evaluation chunks while a graph is alive
     fuse_feature_head = True   # evaluation renders with the wide kernels: W0feat * W_feat multiplied at pack time (NrhNet.feat_fused)
@@ -362,7 +363,8 @@ class NeuSHintRenderer(nn.Module):
         if not use_dyn and self.dyn_scalars is not None:
             pk = dict(pk, inv_s=self._host_inv_s(pk, device))
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
-                            wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color)
+                            wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color,
+                            shadow_jvp=self.shadow_jvp)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))

@@ -315,3 +315,74 @@ def color32_tile(stream16, tables, part, pts, nrm, raymisc):
     for r in range(3):
         rgb[:, r] = 1.0 / (1.0 + np.exp(-v[r][HF == 0]))
     return rgb
+
+
+def sdf32_tile_jvp(stream16, tables, pts, dirs):
+    """MODE 3 of csrc/nrh_sdf32.hip: 16 points (columns 0..15) and their tangents along `dirs` (columns 16..31) through the
+    forward-only stream.  pts, dirs [16,3] float64.  -> sdf [16], d sdf / dt [16]."""
+    raw = np.ascontiguousarray(np.asarray(tables, dtype=np.float32))
+    tab = raw.astype(np.float64)
+    bits = raw.view(np.uint32)
+    bias_hi = (bits & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+    bias_lo = (bits >> 16).astype(np.uint16).view(np.float16).astype(np.float64)
+    is_pt = J < 16
+    pj = J & 15
+
+    def bias(l, c):
+        out = np.zeros((16, 64))
+        for r in range(16):
+            row = 32 * c + frow(r, HF)
+            out[r] = np.where(is_pt, bias_hi[l][row] + bias_lo[l][row] / 2048.0, 0.0)     # tangent columns take no bias
+        return out
+
+    st = Stream(stream16)
+    x3l = (pts * 3.0)[pj]
+    xdl = (dirs * 3.0)[pj]
+    ebh, ebl = [], []
+    for s in range(3):
+        v = np.zeros((64, 8))
+        for i in range(8):
+            for hf in range(2):
+                e = col32(s, hf, i)
+                m = HF == hf
+                val = enc_entry(x3l[m], e)
+                if e < 39:
+                    tan = enc_dentry(x3l[m], e) * xdl[m][:, emb_dim(e)]
+                    val = np.where(is_pt[m], val, tan)
+                v[m, i] = val
+        h, l = split16(v)
+        ebh.append(h)
+        ebl.append(l)
+    e4 = [st.chunk(3) for _ in range(8)]
+
+    def epi(hh, cc):
+        t = hh + cc / 2048.0
+        p = 1.0 + np.exp2(np.minimum(t, 64.0))
+        u = np.maximum(np.log2(p), t)
+        q = 1.0 / p
+        qs = np.empty_like(q)
+        qs[:, :] = q[:, (LANES - 16) % 64]            # what a tangent lane reads: its point lane, 16 below
+        return np.where(is_pt, u, t - t * qs)
+
+    u = []
+    for c in range(8):
+        hh, cc = kloop(st.chunk(4), 3, ebh, ebl, np.zeros((16, 64)))
+        u.append(epi(hh + bias(0, c), cc))
+    for l in range(1, 8):
+        bh, bl = act_to_b(u)
+        nu = []
+        for c in range(8):
+            hh, cc = kloop(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+            hh = hh + bias(l, c)
+            if l == 4:
+                h2, c2 = kloop(e4[c], 3, ebh, ebl, np.zeros((16, 64)))
+                hh, cc = hh + h2, cc + c2
+            nu.append(epi(hh, cc))
+        u = nu
+    bh, bl = act_to_b(u)
+    init = tab_init(tab, 9, 0)
+    init = np.where(is_pt, init, 0.0)
+    hh, cc = kloop(st.chunk(16), 16, bh, bl, init)
+    assert st.pos == len(st.buf)
+    v = (hh + cc / 2048.0)[0]
+    return v[(HF == 0) & is_pt], v[(HF == 0) & ~is_pt]

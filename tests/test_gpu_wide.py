@@ -211,3 +211,44 @@ def test_wide_reflectance_kernel_vs_oracle(wscene, scene_states, scale):
     ref = orc.color_forward(p64, pts.double(), nhat.double(), rep(T(dd)).double(), feat.double(), rep(T(pl)).double(), rep(vis).double(), rep(cue).double())
     err = (col.cpu().double() - ref).abs()
     assert float(err.max()) < 5e-6, (float(err.max()), float(err.mean()), int(err.reshape(N, 128, 3).amax(-1).argmax()))
+
+
+@pytest.mark.parametrize("npts_per_ray,nrays", [(128, 7), (16, 5), (1, 37)])
+def test_wide_jvp_mode_vs_oracle_and_reverse_mode(wscene, npts_per_ray, nrays):
+    """nrh_sdf_eval_wide mode 3 (value + derivative ALONG the ray in forward mode: 16 points + 16 tangents per tile, no sigma'
+    scratch) against the fp64 oracle and against mode 1 (reverse mode): same sdf bit for bit, <rd, grad> equal to fp32 round-off,
+    grad parallel to rd.  Ray directions are not unit length here."""
+    tag, model, packed, p64 = wscene
+    o, d, pl, near, far = make_rays(nrays, seed=5, spread=0.12)
+    d = d * np.linspace(0.5, 1.7, nrays, dtype=np.float32)[:, None]
+    t = torch.rand(nrays, npts_per_ray, device="cuda") * 2 + 1.5
+    s1, g1, _ = ops.sdf_eval_wide(1, packed["sdf_w32"], packed["sdf_tab32"], cu(o), cu(d), t, npts_per_ray)
+    s3, g3, _ = ops.sdf_eval_wide(3, packed["sdf_w32"], packed["sdf_tab32"], cu(o), cu(d), t, npts_per_ray)
+    assert torch.equal(s1, s3)
+    dd = cu(d)[:, None, :].expand(nrays, npts_per_ray, 3).reshape(-1, 3)
+    cos1, cos3 = (g1 * dd).sum(-1), (g3 * dd).sum(-1)
+    scale = float(g1.abs().max())
+    assert float((cos1 - cos3).abs().max()) < 3e-5 * max(1.0, scale), float((cos1 - cos3).abs().max())
+    assert float((torch.linalg.cross(g3, dd)).abs().max()) < 1e-6 * max(1.0, scale)            # parallel to the ray
+    pts = (torch.from_numpy(o)[:, None] + torch.from_numpy(d)[:, None] * t.cpu()[..., None]).reshape(-1, 3).double()
+    o_sdf, _, o_grad = orc.sdf_forward_grad_analytic(p64, pts)
+    np.testing.assert_allclose(s3.cpu().numpy().reshape(-1), o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(cos3.cpu().numpy(), (o_grad.numpy() * dd.cpu().numpy()).sum(-1), rtol=0, atol=5e-5 * max(1.0, scale))
+
+
+def test_render_with_and_without_shadow_jvp(wscene):
+    """The evaluation render with the shadow march's last evaluation in forward mode (NrhNet.shadow_jvp) against the reverse-mode
+    one: everything upstream of the shadow march is bit-equal, visibilities agree to fp32 round-off of <dir, grad>."""
+    tag, model, packed, _ = wscene
+    o, dd, pl, near, far = make_rays(300, seed=23, spread=0.1)
+    rb = na.RayBundle(origins=cu(o), directions=cu(dd), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+    bg = torch.ones(1, 3, device="cuda")
+    with torch.no_grad():
+        assert model.shadow_jvp
+        a = model(rb, is_training=False, background_rgb=bg)
+        model.shadow_jvp = False
+        b = model(rb, is_training=False, background_rgb=bg)
+        model.shadow_jvp = True
+    assert torch.equal(a.weights, b.weights) and torch.equal(a.depth, b.depth)
+    assert float((a.visibilities - b.visibilities).abs().max()) < 2e-4, float((a.visibilities - b.visibilities).abs().max())
+    assert float((a.rgb - b.rgb).abs().max()) < 2e-5

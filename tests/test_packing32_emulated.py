@@ -73,3 +73,17 @@ def test_color32_chain_emulated(scene_states):
     got = emu.color32_tile(stream.numpy(), tables.numpy(), part.numpy(), pts.numpy(), nrm.numpy(), raymisc.numpy())
     np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6)
     assert fd["feat_w"].shape == (256, 256)
+
+
+def test_sdf32_jvp_mode_emulated(packed32):
+    """MODE 3 (value + derivative along a direction in forward mode, 16 points + 16 tangents per tile) on the forward-only
+    stream against the fp64 oracle: sdf and <direction, gradient>."""
+    p64, streams, tables = packed32
+    rs = np.random.RandomState(9)
+    pts = (rs.rand(16, 3) * 2 - 1) * 0.8
+    dirs = rs.randn(16, 3)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    o_sdf, _, o_grad = orc.sdf_forward_grad_analytic(p64, torch.from_numpy(pts))
+    sdf, dd = emu.sdf32_tile_jvp(_stream(streams, 0), tables, pts, dirs)
+    np.testing.assert_allclose(sdf, o_sdf.numpy()[:, 0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(dd, (o_grad.numpy() * dirs).sum(-1), rtol=0, atol=2e-5)
