@@ -72,6 +72,8 @@ def build_scene(precision):
         model.fuse_feature_head = False
     if os.environ.get("NRH_BENCH_CHUNK"):          # A/B of the rays-per-launch chunk (profiles/r02/chunk_rays_ab.log)
         model.max_chunk_rays = int(os.environ["NRH_BENCH_CHUNK"])
+    if os.environ.get("NRH_BENCH_SHADOW_JVP"):     # A/B of the forward-mode shadow evaluation (profiles/r02/shadow_jvp_ab.log: slower)
+        model.shadow_jvp = True
     if os.environ.get("NRH_BENCH_NO_WIDE_COLOR"):  # A/B of the wide reflectance kernel (profiles/r02/wide_color_ab.log)
         model.wide_color = False
     return model, state_b

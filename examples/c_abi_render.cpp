@@ -101,7 +101,6 @@ int main(int argc, char** argv) {
     net.sdf_w32 = d_wide;
     net.sdf_tab32 = (const float*)(d_wide + stream_bytes);
     net.feat_fused = feat_fused;   // the FEAT block of the streams already holds W0feat * W_feat (include/nrhints_hip.h)
-    net.shadow_jvp = 1;            // shadow march: derivative along the ray in forward mode, as the Python host does
     if ((long long)wide.size() == sdf_part + col_part) {   // + the reflectance net's block stream and tables
       net.col_w32 = d_wide + sdf_part;
       net.col_tab32 = (const float*)(d_wide + sdf_part + col_bytes);

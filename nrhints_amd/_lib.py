@@ -154,7 +154,7 @@ def stream_handle(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=True):
+def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
     ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""

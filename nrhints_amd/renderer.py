@@ -106,7 +106,8 @@ class NeuSHintRenderer(nn.Module):
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
     precision = "f16x3"
     wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
-    shadow_jvp = True          # ... the shadow march's last SDF evaluation in forward mode (mode 3: derivative along the ray only)
+    shadow_jvp = False         # the shadow march's last SDF evaluation in forward mode (mode 3: derivative along the ray only, no
+                               # sigma' scratch): correct and tested, but 1.6 % slower per frame than reverse mode (profiles/r02/shadow_jvp_ab.log)
     wide_color = True          # ... and the reflectance net on the wide machinery as well (csrc/nrh_color32.hip; hinted model only)
     max_eval_rays_while_graphed = 32768   # training.GraphedTrainStep pins the workspace: evaluation chunks while a graph is alive
     fuse_feature_head = True   # evaluation renders with the wide kernels: W0feat * W_feat multiplied at pack time (NrhNet.feat_fused)

@@ -244,11 +244,11 @@ def test_render_with_and_without_shadow_jvp(wscene):
     rb = na.RayBundle(origins=cu(o), directions=cu(dd), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
     bg = torch.ones(1, 3, device="cuda")
     with torch.no_grad():
-        assert model.shadow_jvp
+        assert not model.shadow_jvp          # off by default: measured 1.6 % slower per frame than reverse mode
+        model.shadow_jvp = True
         a = model(rb, is_training=False, background_rgb=bg)
         model.shadow_jvp = False
         b = model(rb, is_training=False, background_rgb=bg)
-        model.shadow_jvp = True
     assert torch.equal(a.weights, b.weights) and torch.equal(a.depth, b.depth)
     assert float((a.visibilities - b.visibilities).abs().max()) < 2e-4, float((a.visibilities - b.visibilities).abs().max())
     assert float((a.rgb - b.rgb).abs().max()) < 2e-5
