@@ -311,3 +311,32 @@ def test_integration_md_matches_the_binding():
     table = table[:table.index("\n\n")]
     documented = set(re.findall(r"`(nrh_\w+)`", table))
     assert documented == set(_lib.EXPORTED), (documented ^ set(_lib.EXPORTED))
+
+
+def test_wide_kernel_isa_invariants(tmp_path):
+    """The wide kernels rely on things hipcc is only TRUSTED to do (profiles/tools/check_wide_isa.py): no AGPR reads or moves by
+    the compiler, no scratch, no packed-f32 VALU, and no instruction touching a register that an asm global load is still
+    filling.  Compile the translation unit to ISA and check (skipped where hipcc is not installed)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "nrhints_amd", "csrc")
+    if not os.path.exists(os.path.join(csrc, "gen32", "fwd_d0_p0.inc")):
+        subprocess.run([sys.executable, os.path.join(csrc, "gen_mlp32.py"), os.path.join(csrc, "gen32")], check=True, capture_output=True)
+    out = str(tmp_path / "wide.s")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fno-slp-vectorize", "-mllvm",
+                        "-amdgpu-mfma-vgpr-form", "--cuda-device-only", "-S", "-o", out, os.path.join(csrc, "nrh_wide.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    for name in ("sdf32_kernelILi0E", "sdf32_kernelILi1E", "sdf32_kernelILi2E", "sdf32_kernelILi3E", "color32_kernel"):
+        assert name in text, name
+    import re
+    assert all(int(m) == 0 for m in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)) and ".vgpr_spill_count" in text
+    assert all(int(m) == 0 for m in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))
+    chk = subprocess.run([sys.executable, os.path.join(root, "profiles", "tools", "check_wide_isa.py"), out], capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stdout + chk.stderr
