@@ -26,7 +26,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 rank 0, N = 1 only)
   secondary     the same render in the other matrix arithmetic (exact fp32 MFMA) - value and roofline fraction
   train         BASELINE.json configs[2]: 1024-ray training steps (forward + backward + Adam; N = 1: the whole step
-                replayed as one hipGraph; N > 1: eager steps with one flat RCCL gradient all-reduce per step)
+                replayed as one hipGraph, reported inside the headline line; N > 1: eager steps with one flat RCCL gradient
+                all-reduce per step, run AFTER the headline line is out and reported as a second JSON line on stderr)
 """
 import argparse
 import ctypes
@@ -303,12 +304,17 @@ def main():
         del m2, out2
         torch.cuda.empty_cache()
 
-    train = None
-    if not args.no_train:
+    def run_train_leg():
         try:
-            train = train_leg(dev, rank, world, dist)
+            return train_leg(dev, rank, world, dist)
         except Exception as e:  # the headline must survive a failure of the secondary leg
-            train = {"error": f"{type(e).__name__}: {e}"[:300]}
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # One rank: the training leg runs first and rides in the headline line.  Several ranks: a failure on ONE rank inside the
+    # leg (OOM, RCCL error) would leave the others blocked in its gradient all-reduce, so the headline line is printed BEFORE
+    # the leg starts and the leg's result follows as a second JSON line on stderr ({"train": ...}); nothing after the
+    # headline can keep it from being printed.
+    train = run_train_leg() if (not args.no_train and world == 1) else None
 
     if rank == 0:
         work = 1 if strong else world                       # strong: the job is ONE frame however many ranks render it
@@ -334,7 +340,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dominant_kernel(args.precision, wide)[1],
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(pts_per_launch * 1044),
+                         "traffic_source": traffic_src,
+                         "traffic_kind": "static: newest committed rocprofv3 --pmc summary of this command (profiles/pmc_run.sh), not collected in this run", "algorithmic_bytes_per_launch": int(pts_per_launch * 1044),
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
                          "algorithmic_flop_per_point": FLOP_PER_POINT_CORE},
         }
@@ -343,8 +350,12 @@ def main():
         else:
             line["cpu_baseline"] = None
         line["secondary"] = secondary
-        line["train"] = train
+        line["train"] = train if world == 1 or args.no_train else "second JSON line on stderr (multi-rank run)"
         print(json.dumps(line), flush=True)
+    if world > 1 and not args.no_train:
+        train = run_train_leg()
+        if rank == 0:
+            print(json.dumps({"train": train}), file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -4,7 +4,7 @@
   2. no scratch use, no packed-f32 VALU;
   3. a register written by an asm global_load (q words) is not read or written by anything before the next s_waitcnt vmcnt
      that covers it - here: before the next `s_waitcnt vmcnt(` at all (conservative).
-    python profiles/tools/check_wide_isa.py file.s
+    python nrhints_amd/csrc/check_wide_isa.py file.s   (the Makefile runs it on every build of nrh_wide.o)
 """
 import re, sys
 

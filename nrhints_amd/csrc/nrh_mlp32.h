@@ -90,11 +90,14 @@ __device__ __forceinline__ uint32_t unorm16x2(float a, float b) {
 // One 1 KiB piece: lane-linear 16 B per lane.  Global address = gp + OFF + 16 * lane, LDS address = m0 + OFF + 16 * lane: the
 // instruction offset moves BOTH (measured, profiles/ubench/dma_offset_test.hip), so four pieces share one (gp, m0) pair.
 // Issue cost is what matters here (one wave per SIMD: every issue slot is the MFMA stream's): M0 is rewritten each time
-// because nothing reserves it for us between asm statements.
+// because nothing reserves it for us between asm statements.  M0 cannot be named as a clobber (it is a RESERVED register for
+// hipcc: "inline asm clobber list contains reserved registers: m0", the entry is ignored) - the compiler's own M0 users in
+// these kernels (v_readlane / LDS-DMA it never emits itself) set it right before use; the "memory" clobber keeps ordinary
+// LDS reads of the ring from moving across the DMA issue.
 template <int OFF>
 __device__ __forceinline__ void dma_piece(const char* gp, uint32_t m0v, uint32_t lane16) {
   if (NRH32_ABL & 1) return;
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(m0v), "v"(lane16), "s"(gp), "n"(OFF));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(m0v), "v"(lane16), "s"(gp), "n"(OFF) : "memory");
 }
 // wave-uniform values the compiler may not believe to be uniform
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -563,7 +563,9 @@ __device__ __forceinline__ void raygen_idx_point(const RayGenIdxArgs& a, long lo
     for (int k = 0; k < 3; ++k) R0[r * 3 + k] = P[r * 4 + k];
     t0[r] = P[r * 4 + 3];
   }
-  cam = a.img ? (int)a.img[i] : -1;
+  // a view index outside [0, ncam) refines nothing (and scatters nothing in the adjoint): no out-of-range access for a bad index
+  const long long cam_raw = a.img ? a.img[i] : -1;
+  cam = (cam_raw >= 0 && cam_raw < (long long)a.ncam) ? (int)cam_raw : -1;
   if (cam >= 0 && a.delta) {
     const float* D = a.delta + (long long)cam * 12;
 #pragma unroll

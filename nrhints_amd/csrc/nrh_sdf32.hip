@@ -353,7 +353,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     u32x4 q0a, q0b, q1a, q1b, q2a, q2b, q3a, q3b, q4a, q4b, q5a, q5b, q6a, q6b, qpa, qpb;
     const char* const q7base = uni(scr + 7 * 16384);
     // nt: served by L2; asm: the destination registers are written straight by the load (no compiler copy of a value still in
-    // flight - checked in the build's ISA, profiles/tools/check_wide_isa.py), the wait is in t7.inc
+    // flight - checked in the build's ISA, csrc/check_wide_isa.py, run by the Makefile), the wait is in t7.inc
 #define W32_QLOAD7_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2" W32_QLD_NT : "=v"(dst) : "v"(lane16), "s"(q7base + ((c) * 2 + (half)) * 1024))
     {
       W32_SYNC();

@@ -170,10 +170,8 @@ class RayGenerator(nn.Module):
         f32 = lambda t: t.detach().contiguous().float()
         idx = None if pb.img_indices is None else pb.img_indices.detach().reshape(-1).contiguous().long()
         delta, pl_delta = self.view_deltas() if idx is not None else (None, None)
-        if idx is not None and (delta is not None or pl_delta is not None):
-            nv = int((delta if delta is not None else pl_delta).shape[0])
-            if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= nv):
-                raise IndexError(f"img_indices out of range for {nv} views")
+        # (no host-side range check of idx: the kernels treat a view index outside [0, ncam) as "no refinement" and scatter
+        # nothing for it in the adjoint, so a bad index cannot read or write out of range - and a training batch costs no host sync)
         cc = lambda t: None if t is None else t.contiguous().float()
         poses = f32(pb.poses)
         o, d, p, near, far = _RaysIndexedHip.apply(cc(delta), cc(pl_delta), idx, f32(pb.h_indices).reshape(-1),

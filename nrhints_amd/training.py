@@ -303,6 +303,10 @@ class GraphedTrainStep:
         """Back to eager operation (drops the graph and the device-side scalars)."""
         self.graph = self.graph_tail = None
         self.renderer.dyn_scalars = None
+        # the cached pack was made while 1/s lived on the device (its host copy is NaN): packs of the eager mode must not
+        # reuse it - a render after release() would otherwise run with inv_s = NaN and no device scalars
+        self.renderer._packed_key = None
+        self.renderer._generation = getattr(self.renderer, "_generation", 0) + 1
 
 
 # ---- checkpoints in the reference's layout (trainer/trainer.py:149-158, 173-236) ---------------------------------------

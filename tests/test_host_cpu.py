@@ -314,7 +314,7 @@ def test_integration_md_matches_the_binding():
 
 
 def test_wide_kernel_isa_invariants(tmp_path):
-    """The wide kernels rely on things hipcc is only TRUSTED to do (profiles/tools/check_wide_isa.py): no AGPR reads or moves by
+    """The wide kernels rely on things hipcc is only TRUSTED to do (nrhints_amd/csrc/check_wide_isa.py, also run by the Makefile): no AGPR reads or moves by
     the compiler, no scratch, no packed-f32 VALU, and no instruction touching a register that an asm global load is still
     filling.  Compile the translation unit to ISA and check (skipped where hipcc is not installed)."""
     import shutil
@@ -338,5 +338,5 @@ def test_wide_kernel_isa_invariants(tmp_path):
     import re
     assert all(int(m) == 0 for m in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)) and ".vgpr_spill_count" in text
     assert all(int(m) == 0 for m in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))
-    chk = subprocess.run([sys.executable, os.path.join(root, "profiles", "tools", "check_wide_isa.py"), out], capture_output=True, text=True)
+    chk = subprocess.run([sys.executable, os.path.join(csrc, "check_wide_isa.py"), out], capture_output=True, text=True)
     assert chk.returncode == 0, chk.stdout + chk.stderr
