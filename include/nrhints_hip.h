@@ -285,6 +285,34 @@ long long nrh_color_wide_stream_bytes(void);
 int nrh_color_eval_wide(const void* col_w32, const float* col_tab32, const float* part_tiles, const float* ro, const float* rd,
                         const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color, void* stream);
 
+/* ---- the per-ray stages of the evaluation render, one entry per kernel (what nrh_render_forward launches between its
+ * network evaluations; unit-testable against the reference's recorded intermediates, tests/golden/core_*.npz) -------------
+ * nrh_alpha_composite: NeuSHintRenderer.get_alpha + the compositing weights, depth / hit point, hit normal and Cook-Torrance
+ *   cue of render_core (models/neus_hint_model.py:339-356, :512-533, :583-616) and the shadow ray's set-up (:380-395).
+ *   In: origins / directions / pl_positions [n,3]; sdf, dists, mid_z [n,128]; grad [n*128,3] (d sdf/dx at the mid-points);
+ *   inv_s, cos_anneal; depth_type 0 AlphaBlend | 1 MaximalWeightPoint; zero_hints != 0: cue = 0 (geometry warm-up);
+ *   lin64 = torch.linspace(0,1,64); t_rand_shadow [n,64] or NULL (training jitter of the coarse shadow samples).
+ *   Out: weights, inside_sphere [n,128]; normalized_normals [n*128,3]; depth, weight_sum [n]; specular_cue [n,4] (per ray);
+ *   hit_points, hit_normals [n,3] (either may be NULL); shadow_dirs [n,3] = unit(hit - pl), shadow_last_dist [n] = |hit - pl| / 64,
+ *   shadow_z [n,128] (first 64: coarse shadow samples lin64 * |hit - pl| * (1 - 1e-2)).
+ * nrh_visibility: the tail of get_visibility (:417-432): alpha along the shadow ray from sdf / grad / dists [n,128 | n*128,3]
+ *   at its 128 section mid-points, visibilities [n] = transmittance in front of the last sample; plus the reflectance net's
+ *   per-ray inputs raymisc [n, 100] = enc4(view dir) 27 | enc4(light position) 27 | enc4(visibility) 9 | enc4(cue) 36
+ *   (fields/reflectance_network.py:70-84; fields/encodings.py:168-174).  zero_hints != 0: visibility and cue are zero.
+ * nrh_color_composite: rgb = sum_j c_j w_j + background (1 - sum_j w_j) (:635-637; background [3] or NULL) and, when asked
+ *   for, the per-pixel normal maps sum_j n_j w_j inside_j of the evaluation loop (pipelines/base_pipeline.py:125-131). */
+int nrh_alpha_composite(const float* origins, const float* directions, const float* pl_positions, const float* sdf, const float* grad,
+                        const float* dists, const float* mid_z, float inv_s, float cos_anneal, int depth_type, int zero_hints,
+                        const float* lin64, const float* t_rand_shadow, long long nrays, float* weights, float* inside_sphere,
+                        float* normalized_normals, float* depth, float* weight_sum, float* specular_cue, float* hit_points,
+                        float* hit_normals, float* shadow_dirs, float* shadow_last_dist, float* shadow_z, void* stream);
+int nrh_visibility(const float* directions, const float* pl_positions, const float* shadow_dirs, const float* sdf, const float* grad,
+                   const float* dists, const float* specular_cue, float inv_s, float cos_anneal, int zero_hints, long long nrays,
+                   float* visibilities, float* raymisc, void* stream);
+int nrh_color_composite(const float* sampled_color, const float* weights, const float* weight_sum, const float* background,
+                        const float* inside_sphere, const float* analytic_normals, const float* normalized_normals, long long nrays,
+                        float* rgb, float* normal_map, float* normalized_normal_map, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,8 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
-            "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide")
+            "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
+            "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite")
 
 
 class NrhNet(Structure):
@@ -96,6 +97,9 @@ def load():
                                                        c_float, c_int, P, P, P, P, P, P, P, P]
     lib.nrh_color_wide_stream_bytes.restype = c_longlong
     lib.nrh_color_eval_wide.argtypes = [P, P, P, P, P, P, P, P, c_longlong, P, P]
+    lib.nrh_alpha_composite.argtypes = [P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, P, P, c_longlong] + [P] * 12
+    lib.nrh_visibility.argtypes = [P, P, P, P, P, P, P, c_float, c_float, c_int, c_longlong, P, P, P]
+    lib.nrh_color_composite.argtypes = [P, P, P, P, P, P, P, c_longlong, P, P, P, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]
     lib.nrh_kernel_timing_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_longlong)]
     for name in EXPORTED:

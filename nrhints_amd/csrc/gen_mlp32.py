@@ -128,7 +128,7 @@ def epi_relu(c, hp, cp, out_base=128, part=False):
                 ops.append(Op(f"float s{r} = t{r} + pw{r // 4}[{r % 4}];", defs=(f"s{r}",), uses=(f"t{r}",)))
                 src = f"s{r}"
             ops.append(Op(f"float u{r} = __builtin_amdgcn_fmed3f({src}, 0.0f, 3.0e38f);", defs=(f"u{r}",), uses=(src,)))
-        ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i, scaled=True)
+        ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i, scaled=not COL_UNSCALED)
     return ops
 
 
@@ -280,6 +280,9 @@ class Window:
 DMA_SLOTS16 = {2 + 3 * k: [k] for k in range(8)}     # regular window: one piece of block n + 2 after the last MFMA of K steps 0..7
 
 
+# experiment: the reflectance net's activations with the UNSCALED residual as well - build with
+# NRH32_COL_UNSCALED=1 in the generator's environment AND -DNRH32_COL_UNSCALED=1 for nrh_color32.hip (profiles/tools/build_colu_variant.sh)
+COL_UNSCALED = bool(os.environ.get("NRH32_COL_UNSCALED"))
 MID = int(os.environ.get("NRH32_MID", "1"))      # which of a K step's three MFMAs is the A_lo one (see Window.emit)
 # VALU ops placed ahead of a window's first MFMA, in HEAD_SLOTS dependency levels of HEAD_OPS each (see Window.emit)
 HEAD_SLOTS = int(os.environ.get("NRH32_HEAD_SLOTS", "0"))
@@ -376,7 +379,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
                     out.append(f'    asm volatile("" : "+v"({nm}));')
                     out.append(f"    const {LOAD_TYPE[ekind]} {wname[ekind]}{k} = {nm};")
         win = Window(ks, hh, cc, b_src=b_src, hh_zero=(hh_zero or bias_mfma), in_base=in_base,
-                     bias=(("bw", "W32_BCONST") if bias_mfma else None), b_lo_scaled=kind.startswith("relu"))
+                     bias=(("bw", "W32_BCONST") if bias_mfma else None), b_lo_scaled=kind.startswith("relu") and not COL_UNSCALED)
         if small:
             dma = {2: [2 * (c % 4)], 5: [2 * (c % 4) + 1]}
         else:
@@ -542,7 +545,7 @@ def main():
         "col_c2.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=0, out_base=128, bias_mfma=True),
         "col_c3.inc": gen_stage("relu", False, 16, "agpr", nv, True, in_base=128, out_base=0, bias_mfma=True),
         "col_fin.inc": gen_finish("relu", False, 0),
-        "kloop16_a0.inc": gen_kloop(16, "agpr", False, in_base=0, b_lo_scaled=True),
+        "kloop16_a0.inc": gen_kloop(16, "agpr", False, in_base=0, b_lo_scaled=not COL_UNSCALED),
     }
     for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc"):
         if os.path.exists(os.path.join(outdir, stale)):

@@ -256,11 +256,24 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
   return NRH_OK;
 }
 
+// core_alpha_kernel with the renderer's constants (shadow_ray_offset 1e-2, the four specular roughness values of
+// models/neus_hint_model.py:161 evaluated in double like Python's scalars)
+int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
+  c.shadow_offset = 1e-2f;
+  const double rough[4] = {0.02, 0.05, 0.13, 0.34};
+  for (int i = 0; i < 4; ++i) {
+    const double k = (rough[i] + 1.0) * (rough[i] + 1.0) / 8.0, a2 = rough[i] * rough[i];
+    c.kk[i] = (float)k; c.omk[i] = (float)(1.0 - k); c.a2[i] = (float)a2; c.a2m1[i] = (float)(a2 - 1.0);
+  }
+  hipLaunchKernelGGL(nrh::core_alpha_kernel, dim3((unsigned)((c.nrays + 3) / 4)), dim3(256), 0, st, c);
+  return check_launch("core_alpha_kernel");
+}
+
 }  // namespace
 
 extern "C" {
 
-int nrh_version(void) { return 124; }
+int nrh_version(void) { return 125; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -704,18 +717,12 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = sdf_c; c.grad = o_grad; c.dists = o_dists;
     c.tmid = o_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
     c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
-    c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal; c.shadow_offset = 1e-2f;
-    c.dyn = net->dyn_scalars;
-    const double rough[4] = {0.02, 0.05, 0.13, 0.34};  // models/neus_hint_model.py:161
-    for (int i = 0; i < 4; ++i) {
-      const double k = (rough[i] + 1.0) * (rough[i] + 1.0) / 8.0, a2 = rough[i] * rough[i];
-      c.kk[i] = (float)k; c.omk[i] = (float)(1.0 - k); c.a2[i] = (float)a2; c.a2m1[i] = (float)(a2 - 1.0);
-    }
+    c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
+    c.dyn = net->dyn_scalars; c.hit = nullptr; c.hit_n = nullptr;
     c.zero_hints = no_hints;
     c.depth_max_weight = net->depth_type;
     c.nrays = (int)n;
-    hipLaunchKernelGGL(nrh::core_alpha_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
-    rc = check_launch("core_alpha_kernel");
+    rc = launch_core_alpha(c, st);
     if (rc) return rc;
   }
   // ---- shadow rays light -> hit point ----
@@ -770,6 +777,61 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     if (rc) return rc;
   }
   return NRH_OK;
+}
+
+// ---- unit entries of the evaluation render's per-ray stages (the kernels nrh_render_forward launches) ----
+int nrh_alpha_composite(const float* origins, const float* directions, const float* pl_positions, const float* sdf, const float* grad,
+                        const float* dists, const float* mid_z, float inv_s, float cos_anneal, int depth_type, int zero_hints,
+                        const float* lin64, const float* t_rand_shadow, long long nrays, float* weights, float* inside_sphere,
+                        float* normalized_normals, float* depth, float* weight_sum, float* specular_cue, float* hit_points,
+                        float* hit_normals, float* shadow_dirs, float* shadow_last_dist, float* shadow_z, void* stream) {
+  if (!origins || !directions || !pl_positions || !sdf || !grad || !dists || !mid_z || !lin64 || !weights || !inside_sphere ||
+      !normalized_normals || !depth || !weight_sum || !specular_cue || !shadow_dirs || !shadow_last_dist || !shadow_z)
+    return fail(NRH_E_INVALID, "nrh_alpha_composite: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_composite: nrays out of range%s", "");
+  if (depth_type != 0 && depth_type != 1) return fail(NRH_E_UNSUPPORTED, "nrh_alpha_composite: depth_type must be 0 (alpha blend) or 1 (maximal weight)%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::CoreArgs c;
+  memset(&c, 0, sizeof(c));
+  c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = sdf; c.grad = grad; c.dists = dists; c.tmid = mid_z;
+  c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = weights; c.inside = inside_sphere; c.nhat = normalized_normals;
+  c.depth = depth; c.wsum = weight_sum; c.cue = specular_cue; c.cue_b = nullptr; c.hit = hit_points; c.hit_n = hit_normals;
+  c.srd = shadow_dirs; c.slast = shadow_last_dist; c.zs = shadow_z; c.inv_s = inv_s; c.cos_anneal = cos_anneal; c.dyn = nullptr;
+  c.zero_hints = zero_hints ? 1 : 0; c.depth_max_weight = depth_type; c.nrays = (int)nrays;
+  return launch_core_alpha(c, (hipStream_t)stream);
+}
+
+int nrh_visibility(const float* directions, const float* pl_positions, const float* shadow_dirs, const float* sdf, const float* grad,
+                   const float* dists, const float* specular_cue, float inv_s, float cos_anneal, int zero_hints, long long nrays,
+                   float* visibilities, float* raymisc, void* stream) {
+  if (!directions || !pl_positions || !visibilities || !raymisc) return fail(NRH_E_INVALID, "nrh_visibility: null pointer%s", "");
+  if (!zero_hints && (!shadow_dirs || !sdf || !grad || !dists || !specular_cue))
+    return fail(NRH_E_INVALID, "nrh_visibility: null pointer%s (shadow-ray inputs are required unless zero_hints)", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_visibility: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::ShadowArgs c;
+  memset(&c, 0, sizeof(c));
+  c.rd = directions; c.pl = pl_positions; c.srd = shadow_dirs; c.sdf = sdf; c.grad = grad; c.dists = dists; c.cue = specular_cue;
+  c.vis = visibilities; c.raymisc = raymisc; c.inv_s = inv_s; c.cos_anneal = cos_anneal; c.dyn = nullptr;
+  c.nrays = (int)nrays; c.zero_hints = zero_hints ? 1 : 0;
+  hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((nrays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c);
+  return check_launch("shadow_finish_kernel");
+}
+
+int nrh_color_composite(const float* sampled_color, const float* weights, const float* weight_sum, const float* background,
+                        const float* inside_sphere, const float* analytic_normals, const float* normalized_normals, long long nrays,
+                        float* rgb, float* normal_map, float* normalized_normal_map, void* stream) {
+  if (!sampled_color || !weights || !weight_sum || !rgb) return fail(NRH_E_INVALID, "nrh_color_composite: null pointer%s", "");
+  if ((normal_map || normalized_normal_map) && (!inside_sphere || !analytic_normals || !normalized_normals))
+    return fail(NRH_E_INVALID, "nrh_color_composite: the normal maps need inside_sphere and both normal arrays%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_color_composite: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::CompositeArgs c;
+  memset(&c, 0, sizeof(c));
+  c.color = sampled_color; c.weights = weights; c.wsum = weight_sum; c.bg = background; c.rgb = rgb; c.nrays = (int)nrays;
+  c.inside = inside_sphere; c.grad = analytic_normals; c.nhat = normalized_normals; c.nmap = normal_map; c.nnmap = normalized_normal_map;
+  hipLaunchKernelGGL(nrh::composite_kernel, dim3((unsigned)((nrays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c);
+  return check_launch("composite_kernel");
 }
 
 int nrh_render_forward(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,

@@ -35,6 +35,12 @@ constexpr int COL32_LDS_TAB = RING * SLOT_BYTES;                 // 98304
 constexpr int COL32_LDS_BYTES = COL32_LDS_TAB + COL32_NTAB * 1024;  // 103424
 __host__ __device__ constexpr long long color32_stream_bytes() { return (long long)COL32_BLOCKS * SLOT_BYTES; }
 
+// NRH32_COL_UNSCALED (experiment builds only, with gen_mlp32.py run under NRH32_COL_UNSCALED=1): the unscaled residual here too
+#ifdef NRH32_COL_UNSCALED
+#define COL32_SPLIT split2
+#else
+#define COL32_SPLIT split2_scaled
+#endif
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void color32_kernel(const Color32Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -96,8 +102,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
       v[3] = 0.0f;
       uint32_t h0, l0, h1, l1;
-      split2_scaled(v[0], v[1], h0, l0);
-      split2_scaled(v[2], v[3], h1, l1);
+      COL32_SPLIT(v[0], v[1], h0, l0);
+      COL32_SPLIT(v[2], v[3], h1, l1);
       asm volatile("v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %4\n\tv_accvgpr_write_b32 a3, %4\n\t"
                    "v_accvgpr_write_b32 a64, %2\n\tv_accvgpr_write_b32 a65, %3\n\tv_accvgpr_write_b32 a66, %4\n\tv_accvgpr_write_b32 a67, %4"
                    ::"v"(h0), "v"(h1), "v"(l0), "v"(l1), "v"(0u) : "a0", "a1", "a2", "a3", "a64", "a65", "a66", "a67");
@@ -106,8 +112,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       {                                                                                                                    \
         const f32x4 m = *reinterpret_cast<const f32x4*>(rm + (OFF));                                                       \
         uint32_t mh0, ml0, mh1, ml1;                                                                                       \
-        split2_scaled(m[0], m[1], mh0, ml0);                                                                                      \
-        split2_scaled(m[2], m[3], mh1, ml1);                                                                                      \
+        COL32_SPLIT(m[0], m[1], mh0, ml0);                                                                                      \
+        COL32_SPLIT(m[2], m[3], mh1, ml1);                                                                                      \
         asm volatile("v_accvgpr_write_b32 a" #A0 ", %0\n\tv_accvgpr_write_b32 a" #A1 ", %1\n\tv_accvgpr_write_b32 a" #A2 ", %2\n\t"    \
                      "v_accvgpr_write_b32 a" #A3 ", %3" ::"v"(mh0), "v"(mh1), "v"(ml0), "v"(ml1) : "a" #A0, "a" #A1, "a" #A2, "a" #A3); \
       }
@@ -127,8 +133,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       {   // K step 7: only raymisc[96..98] exist (hf = 0, first half); index 99 is padding and what follows is the next ray's row
         const f32x4 m = *reinterpret_cast<const f32x4*>(a.raymisc + (long long)ray * a.raymisc_stride + 96);
         uint32_t mh0, ml0, mh1, ml1;
-        split2_scaled(hf ? 0.0f : m[0], hf ? 0.0f : m[1], mh0, ml0);
-        split2_scaled(hf ? 0.0f : m[2], 0.0f, mh1, ml1);
+        COL32_SPLIT(hf ? 0.0f : m[0], hf ? 0.0f : m[1], mh0, ml0);
+        COL32_SPLIT(hf ? 0.0f : m[2], 0.0f, mh1, ml1);
         asm volatile("v_accvgpr_write_b32 a28, %0\n\tv_accvgpr_write_b32 a29, %1\n\tv_accvgpr_write_b32 a92, %2\n\tv_accvgpr_write_b32 a93, %3\n\t"
                      "v_accvgpr_write_b32 a30, %4\n\tv_accvgpr_write_b32 a31, %4\n\tv_accvgpr_write_b32 a94, %4\n\tv_accvgpr_write_b32 a95, %4"
                      ::"v"(mh0), "v"(mh1), "v"(ml0), "v"(ml1), "v"(0u) : "a28", "a29", "a92", "a93", "a30", "a31", "a94", "a95");

@@ -223,6 +223,8 @@ struct CoreArgs {
   float* wsum;          // [N]
   float* cue;           // [N,4]
   float* cue_b;         // [N,128,4] broadcast copy (RenderOutput.specular_cue) or null
+  float* hit;           // [N,3] hit point o + d * depth (unit entry nrh_alpha_composite only) or null
+  float* hit_n;         // [N,3] unit hit normal normalize(sum_j n_j w_j) (unit entry only) or null
   float* srd;           // [N,3] shadow ray direction
   float* slast;         // [N] light distance / 64
   float* zs;            // [N,128] coarse shadow z (first 64)
@@ -347,6 +349,8 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
       a.srd[ray * 3 + 1] = svy / L;
       a.srd[ray * 3 + 2] = svz / L;
       a.slast[ray] = L / 64.0f;
+      if (a.hit) { a.hit[ray * 3 + 0] = hx; a.hit[ray * 3 + 1] = hy; a.hit[ray * 3 + 2] = hz; }
+      if (a.hit_n) { a.hit_n[ray * 3 + 0] = nx; a.hit_n[ray * 3 + 1] = ny; a.hit_n[ray * 3 + 2] = nz; }
     }
   }
 }

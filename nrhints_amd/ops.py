@@ -174,3 +174,56 @@ def color_eval_wide(col_w32, col_tab32, part_tiles, ro, rd, tmid, nhat, raymisc)
                                  nrays, P(color), _lib.stream_handle())
     _lib.check(rc, "nrh_color_eval_wide")
     return color
+
+
+@_lib.on_tensor_device
+def alpha_composite(ro, rd, pl, sdf, grad, dists, mid_z, inv_s: float, cos_anneal: float = 1.0, depth_type: int = 0,
+                    zero_hints: bool = False, t_rand_shadow=None):
+    """The evaluation render's alpha / compositing / hit point / specular-cue stage on its own (nrh_alpha_composite =
+    core_alpha_kernel) -> dict(weights, inside [n,128], nhat [n*128,3], depth, wsum [n], cue [n,4], hit, hit_normal [n,3],
+    shadow_dirs [n,3], shadow_last_dist [n], shadow_z [n,128])."""
+    lib = _lib.load()
+    n = ro.shape[0]
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=ro.device)
+    lin64 = torch.linspace(0.0, 1.0, 64).to(ro.device)
+    out = dict(weights=new(n, 128), inside=new(n, 128), nhat=new(n * 128, 3), depth=new(n), wsum=new(n), cue=new(n, 4),
+               hit=new(n, 3), hit_normal=new(n, 3), shadow_dirs=new(n, 3), shadow_last_dist=new(n), shadow_z=torch.zeros(n, 128, dtype=torch.float32, device=ro.device))
+    P = _lib.ptr
+    rc = lib.nrh_alpha_composite(P(ro), P(rd), P(pl), P(sdf), P(grad), P(dists), P(mid_z), float(inv_s), float(cos_anneal), int(depth_type),
+                                 int(bool(zero_hints)), P(lin64), P(t_rand_shadow), n, P(out["weights"]), P(out["inside"]), P(out["nhat"]),
+                                 P(out["depth"]), P(out["wsum"]), P(out["cue"]), P(out["hit"]), P(out["hit_normal"]), P(out["shadow_dirs"]),
+                                 P(out["shadow_last_dist"]), P(out["shadow_z"]), _lib.stream_handle())
+    _lib.check(rc, "nrh_alpha_composite")
+    return out
+
+
+@_lib.on_tensor_device
+def visibility(rd, pl, shadow_dirs, sdf, grad, dists, cue, inv_s: float, cos_anneal: float = 1.0, zero_hints: bool = False):
+    """Shadow-ray transmittance + the reflectance net's per-ray encodings (nrh_visibility = shadow_finish_kernel)
+    -> (visibilities [n], raymisc [n, RAYMISC_STRIDE])."""
+    from . import packing
+    lib = _lib.load()
+    n = rd.shape[0]
+    vis = torch.empty(n, dtype=torch.float32, device=rd.device)
+    raymisc = torch.zeros(n, packing.RAYMISC_STRIDE, dtype=torch.float32, device=rd.device)
+    P = _lib.ptr
+    rc = lib.nrh_visibility(P(rd), P(pl), P(shadow_dirs), P(sdf), P(grad), P(dists), P(cue), float(inv_s), float(cos_anneal),
+                            int(bool(zero_hints)), n, P(vis), P(raymisc), _lib.stream_handle())
+    _lib.check(rc, "nrh_visibility")
+    return vis, raymisc
+
+
+@_lib.on_tensor_device
+def color_composite(color, weights, wsum, background=None, inside=None, grad=None, nhat=None, maps: bool = False):
+    """rgb = sum c w + bg (1 - sum w) (+ the two weighted normal maps) (nrh_color_composite = composite_kernel)
+    -> (rgb [n,3], normal_map | None, normalized_normal_map | None)."""
+    lib = _lib.load()
+    n = weights.shape[0]
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=weights.device)
+    rgb = new(n, 3)
+    nm, nnm = (new(n, 3), new(n, 3)) if maps else (None, None)
+    P = _lib.ptr
+    rc = lib.nrh_color_composite(P(color), P(weights), P(wsum), P(background), P(inside), P(grad), P(nhat), n, P(rgb), P(nm), P(nnm),
+                                 _lib.stream_handle())
+    _lib.check(rc, "nrh_color_composite")
+    return rgb, nm, nnm

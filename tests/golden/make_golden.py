@@ -204,6 +204,34 @@ def main():
             trec["grad." + name] = prm.grad.detach().numpy().copy() if prm.grad is not None else np.zeros(0, np.float32)
         for nm, t in zip(("origins", "directions", "pl_positions"), rays_t):
             trec["grad.rays." + nm] = t.grad.detach().numpy().copy()
+        # the same step in float64 (same drawn jitter, same ground truth): the yardstick for the gradient tolerances -
+        # |grad32 - grad64| is the reference's OWN float32 noise on each tensor (tests derive their bounds from it)
+        replay = [d_.double() for d_ in drawn]
+
+        def replay_rand(*a, **k):
+            return replay.pop(0)
+
+        torch.rand = replay_rand
+        try:
+            rays64 = [torch.from_numpy(a).double().requires_grad_(i < 3) for i, a in enumerate((o, d, pl, near, far))]
+            rb64 = RayBundle(origins=rays64[0], directions=rays64[1], pl_positions=rays64[2], nears=rays64[3], fars=rays64[4])
+            r64 = m64(rb64, is_training=True, background_rgb=torch.ones(1, 3, dtype=torch.float64), global_step=20000)
+        finally:
+            torch.rand = real_rand
+        assert not replay
+        gt64 = gt.double()
+        rgb_loss64 = torch.nn.functional.l1_loss(r64.rgb, gt64, reduction="sum") / (N + 1e-5)
+        ge64 = (torch.linalg.norm(r64.analytic_normals, ord=2, dim=-1) - 1.0) ** 2
+        eik64 = (r64.relax_inside_sphere * ge64).sum() / (r64.relax_inside_sphere.sum() + 1e-5)
+        loss64 = rgb_loss64 + 0.1 * eik64
+        trec["loss_f64"] = loss64.detach().numpy()
+        m64.zero_grad()
+        loss64.backward()
+        for name, prm in m64.named_parameters():
+            trec["grad64." + name] = prm.grad.detach().numpy().copy() if prm.grad is not None else np.zeros(0, np.float64)
+        for nm, t in zip(("origins", "directions", "pl_positions"), rays64):
+            trec["grad64.rays." + nm] = t.grad.detach().numpy().copy()
+        m64.zero_grad()
         np.savez_compressed(os.path.join(HERE, f"train_{tag}.npz"), **trec)
         print("scene", tag, "done; rgb mean", float(rec["rgb"].mean()), "vis mean", float(rec["visibilities"].mean()))
 

@@ -262,7 +262,7 @@ def act_to_b_scaled(u):
     return bh, bl
 
 
-def color32_tile(stream16, tables, part, pts, nrm, raymisc):
+def color32_tile(stream16, tables, part, pts, nrm, raymisc, scaled=True):
     """One 32-sample tile of the reflectance net through the colour block stream (csrc/nrh_color32.hip).
     part [32,256]: the feature block's share of layer 0 (W0feat * feature); pts, nrm [32,3]; raymisc [>= 99].  -> rgb [32,3]."""
     raw = np.ascontiguousarray(np.asarray(tables, dtype=np.float32))
@@ -277,6 +277,8 @@ def color32_tile(stream16, tables, part, pts, nrm, raymisc):
             out[r] = bias_hi[l][row] + bias_lo[l][row] / 2048.0
         return out
 
+    # scaled=False: the experiment build with the unscaled residual (NRH32_COL_UNSCALED)
+    sp, kl, a2b = (split16_scaled, kloop_scaled, act_to_b_scaled) if scaled else (split16, kloop, act_to_b)
     st = Stream(stream16)
     # B operands of C0: K step 0 = point (hf 0) / normal (hf 1) in slots 0..2; K steps 1..7 = raymisc[16 (s-1) + 8 (i>>2) + 4 hf + (i&3)]
     bh, bl = [], []
@@ -290,25 +292,25 @@ def color32_tile(stream16, tables, part, pts, nrm, raymisc):
                 idx = 16 * (s - 1) + 8 * (i >> 2) + 4 * HF + (i & 3)
                 ok = idx < 99
                 v[:, i] = np.where(ok, np.asarray(raymisc, dtype=np.float64)[np.minimum(idx, 98)], 0.0)
-        h, l = split16_scaled(v)
+        h, l = sp(v)
         bh.append(h)
         bl.append(l)
     u = []
     for c in range(8):
-        hh, cc = kloop_scaled(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+        hh, cc = kl(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
         t = hh + bias(0, c) + cc / 2048.0
         for r in range(16):
             t[r] += part[J, 32 * c + frow(r, HF)]
         u.append(np.maximum(t, 0.0))
     for l in range(1, 4):
-        bh, bl = act_to_b_scaled(u)
+        bh, bl = a2b(u)
         nu = []
         for c in range(8):
-            hh, cc = kloop_scaled(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
+            hh, cc = kl(st.chunk(16), 16, bh, bl, np.zeros((16, 64)))
             nu.append(np.maximum(hh + bias(l, c) + cc / 2048.0, 0.0))
         u = nu
-    bh, bl = act_to_b_scaled(u)
-    hh, cc = kloop_scaled(st.chunk(16), 16, bh, bl, tab_init(raw.astype(np.float64), 4, 0))
+    bh, bl = a2b(u)
+    hh, cc = kl(st.chunk(16), 16, bh, bl, tab_init(raw.astype(np.float64), 4, 0))
     assert st.pos == len(st.buf)
     v = hh + cc / 2048.0
     rgb = np.zeros((32, 3))

@@ -252,3 +252,34 @@ def test_render_with_and_without_shadow_jvp(wscene):
     assert torch.equal(a.weights, b.weights) and torch.equal(a.depth, b.depth)
     assert float((a.visibilities - b.visibilities).abs().max()) < 2e-4, float((a.visibilities - b.visibilities).abs().max())
     assert float((a.rgb - b.rgb).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("level", ["residuals_subnormal", "all_subnormal"])
+def test_wide_sdf_subnormal_activations(scene_states, level):
+    """one layer's activations scaled so that EVERY fp16 residual the forward chain hands on is a subnormal
+    (level 1), or so that the hi halves are subnormals as well and the residuals fall below the smallest one (level 2), with
+    the next layer's gain raised so that these values decide the output (tests/stress_states.py).  The wide kernels ship the
+    UNSCALED residual (csrc/gen_mlp32.py split_ops) and rely on v_cvt_pkrtz, v_fma_mix, v_accvgpr_write and the MFMA honouring
+    fp16 subnormals end to end: a flush anywhere on that path shows as 6e-5 / 3e-4 in the sdf and 2e-4 / 8e-4 in the feature
+    (tests/test_packing32_emulated.py::test_sdf32_subnormal_stress_emulated), against the 5e-6 / 3e-5 asserted here."""
+    from tests.stress_states import subnormal_stress_state
+    st = subnormal_stress_state(scene_states["b"], level)
+    model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision="f16x3")
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+    model = model.cuda().eval()
+    packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()))
+    p64 = orc.params_from_state(st, torch.float64)
+    g = torch.Generator().manual_seed(77)
+    pts = (torch.rand(4096 + 19, 3, generator=g) * 2 - 1) * 0.9
+    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, pts.double())
+    for mode in (0, 1, 2):
+        sdf, grad, feat = _at_points(mode, packed, pts.cuda())
+        np.testing.assert_allclose(sdf.cpu().numpy()[:, 0], o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
+        if mode >= 1:
+            np.testing.assert_allclose(grad.cpu().numpy(), o_grad.numpy(), rtol=0, atol=5e-4)
+        if mode == 2:
+            np.testing.assert_allclose(pk.feat_tiles_to_rows(feat.cpu(), pts.shape[0]).numpy(), o_feat.numpy(), rtol=0, atol=3e-5)
+    # the 16-point f16x3 kernels (scaled residual) on the same state: the second, independent code path
+    s16, g16, f16 = ops.sdf_at_points(2, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], pts.cuda())
+    np.testing.assert_allclose(s16.cpu().numpy()[:, 0], o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(pk.feat_tiles_to_rows(f16.cpu(), pts.shape[0]).numpy(), o_feat.numpy(), rtol=0, atol=3e-5)

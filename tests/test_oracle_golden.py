@@ -204,3 +204,32 @@ def test_geometry_warmup_vs_reference(scene_states):
     out2 = orc.render_forward(p, *rays, background_rgb=torch.ones(1, 3), is_training=True, global_step=2000, geometry_warmup_end=1000,
                               t_rand_primary=T(g["t_rand_primary"]), t_rand_shadow=torch.full((32, 64), 0.5), mode="as_written")
     assert float(out2["visibilities"].max()) > 0.0
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_core_intermediates_vs_reference(tag):
+    """The oracle's per-ray functions against the intermediates the imported reference recorded inside render_core /
+    get_visibility (tests/golden/make_golden_core.py -> core_*.npz): alpha, weights, depth, hit normal, specular cue, the
+    shadow ray's alpha and visibility, the composite."""
+    g = load_npz(f"core_{tag}.npz")
+    Tn = torch.from_numpy
+    N = g["o"].shape[0]
+    d = Tn(g["d"])
+    dirs = d[:, None, :].expand(N, 128, 3).reshape(-1, 3)
+    alpha = orc.alpha_from(Tn(g["sdf"]).reshape(-1, 1), Tn(g["grad"]), dirs, Tn(g["dists"]).reshape(-1, 1), float(g["inv_s"]), 1.0).reshape(N, 128)
+    np.testing.assert_allclose(alpha.numpy(), g["alpha"], rtol=0, atol=1e-6)
+    w = alpha * orc.excl_cumprod_one_minus(alpha)
+    np.testing.assert_allclose(w.numpy(), g["weights"], rtol=0, atol=1e-6)
+    depth = (Tn(g["mid_z"]) * w).sum(-1, keepdim=True)
+    np.testing.assert_allclose(depth.numpy(), g["depth"], rtol=0, atol=1e-5)
+    nh = torch.nn.functional.normalize((Tn(g["nhat"]).reshape(N, 128, 3) * w[..., None]).sum(1), dim=-1)
+    np.testing.assert_allclose(nh.numpy(), g["hit_normal"], rtol=0, atol=1e-5)
+    cue = orc.specular_cue(Tn(g["hit_normal"]), Tn(g["pl"]), Tn(g["hit_points"]), d)
+    np.testing.assert_allclose(cue.numpy(), g["cue"], rtol=1e-5, atol=1e-7)
+    sdirs = Tn(g["s_dirs"])[:, None, :].expand(N, 128, 3).reshape(-1, 3)
+    sa = orc.alpha_from(Tn(g["s_sdf"]).reshape(-1, 1), Tn(g["s_grad"]), sdirs, Tn(g["s_dists"]).reshape(-1, 1), float(g["inv_s"]), 1.0).reshape(N, 128)
+    np.testing.assert_allclose(sa.numpy(), g["s_alpha"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(orc.excl_cumprod_one_minus(sa)[:, -1:].numpy(), g["vis"], rtol=0, atol=1e-6)
+    rgb = (Tn(g["sampled_color"]) * Tn(g["weights"])[..., None]).sum(1)
+    np.testing.assert_allclose((rgb + 1.0 - Tn(g["weights"]).sum(-1, keepdim=True)).numpy(), g["rgb"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rgb.numpy(), g["rgb_bg0"], rtol=0, atol=1e-6)

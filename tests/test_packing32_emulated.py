@@ -73,6 +73,9 @@ def test_color32_chain_emulated(scene_states):
     got = emu.color32_tile(stream.numpy(), tables.numpy(), part.numpy(), pts.numpy(), nrm.numpy(), raymisc.numpy())
     np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6)
     assert fd["feat_w"].shape == (256, 256)
+    # the experiment build with the UNSCALED activation residual (gen_mlp32.py NRH32_COL_UNSCALED): same plan, same accuracy class
+    got_u = emu.color32_tile(stream.numpy(), tables.numpy(), part.numpy(), pts.numpy(), nrm.numpy(), raymisc.numpy(), scaled=False)
+    np.testing.assert_allclose(got_u, ref, rtol=0, atol=3e-6)
 
 
 def test_sdf32_jvp_mode_emulated(packed32):
@@ -87,3 +90,40 @@ def test_sdf32_jvp_mode_emulated(packed32):
     sdf, dd = emu.sdf32_tile_jvp(_stream(streams, 0), tables, pts, dirs)
     np.testing.assert_allclose(sdf, o_sdf.numpy()[:, 0], rtol=0, atol=2e-6)
     np.testing.assert_allclose(dd, (o_grad.numpy() * dirs).sum(-1), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("level", ["residuals_subnormal", "all_subnormal"])
+def test_sdf32_subnormal_stress_emulated(scene_states, level):
+    """The stress states of tests/stress_states.py through the emulation: with fp16 subnormals honoured (numpy float16 does) the
+    wide kernel's plan stays at fp32 round-off against the fp64 oracle; with a split that flushes them it does NOT - so the GPU
+    test on the same states (tests/test_gpu_wide.py::test_wide_sdf_subnormal_activations) can tell the two apart."""
+    from tests.stress_states import subnormal_stress_state
+    st_np = subnormal_stress_state(scene_states["b"], level)
+    st = {k: torch.from_numpy(np.asarray(v)) for k, v in st_np.items()}
+    d = pk.dense_params(st)
+    streams, tables = pk32.pack_sdf32(d)
+    assert bool(pk32.tables_in_f16_range(d)) and bool(torch.isfinite(streams).all())      # the gain stays inside the fp16 split
+    p64 = orc.params_from_state(st_np, torch.float64)
+    rs = np.random.RandomState(5)
+    pts = (rs.rand(32, 3) * 2 - 1) * 0.8
+    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, torch.from_numpy(pts))
+    trace = {}
+    sdf, grad, feat = emu.sdf32_tile(_stream(streams.numpy(), 2), tables.numpy(), pts, 2, trace=trace)
+    u5 = np.abs(np.stack(trace["u"][5]))
+    assert u5.max() < (2.0 ** -3 if level == "residuals_subnormal" else 2.0 ** -12)        # the regime the test is named after
+    np.testing.assert_allclose(sdf, o_sdf.numpy()[:, 0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(feat, o_feat.numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(grad, o_grad.numpy(), rtol=0, atol=5e-4)
+    # the same plan with fp16 subnormals flushed to zero: visibly wrong
+    honest = emu.split16
+
+    def flushing(x):
+        hi, lo = honest(x)
+        return np.where(np.abs(hi) < 2.0 ** -14, 0.0, hi), np.where(np.abs(lo) < 2.0 ** -14, 0.0, lo)
+
+    emu.split16 = flushing
+    try:
+        sdf_f, _, feat_f = emu.sdf32_tile(_stream(streams.numpy(), 2), tables.numpy(), pts, 2)
+    finally:
+        emu.split16 = honest
+    assert np.abs(sdf_f - o_sdf.numpy()[:, 0]).max() > 2e-5 and np.abs(feat_f - o_feat.numpy()).max() > 1e-4
