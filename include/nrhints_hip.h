@@ -238,6 +238,8 @@ typedef struct NrhTrainSaves {
   float* save_s1;    /* [8][nrays*128][256] */
   float* save_t;     /* [8][nrays*128][256] */
   float* save_ge;    /* [nrays*128][128] */
+  float* raymisc;    /* optional [nrays,100]: the reflectance net's per-ray encodings enc4(view) | enc4(pl) | enc4(vis) | enc4(cue)
+                        (what nrh_visibility writes); NULL = kept in the workspace */
 } NrhTrainSaves;
 int nrh_render_forward_train(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
                              const float* nears, const float* fars, long long nrays, float cos_anneal,
@@ -312,6 +314,56 @@ int nrh_visibility(const float* directions, const float* pl_positions, const flo
 int nrh_color_composite(const float* sampled_color, const float* weights, const float* weight_sum, const float* background,
                         const float* inside_sphere, const float* analytic_normals, const float* normalized_normals, long long nrays,
                         float* rgb, float* normal_map, float* normalized_normal_map, void* stream);
+
+/* ---- the fused training step: weight gradients, loss and adjoint seeds without library GEMMs or framework ops ---------------
+ * nrh_dw_gemm: every dW = X^T Y of loss.backward() through the nn.Linear layers (fields/sdf_field.py:81-101,
+ *   fields/reflectance_network.py:52-66) as split-K MFMA GEMMs (v_mfma_f32_32x32x16_bf16, hi/lo 3-term products, fp32
+ *   accumulation) in ONE launch + one deterministic reduction launch.  A job is  out[i][j] = scale * sum_pairs sum_p A_k[p][i] B_k[p][j]
+ *   over the row-major arrays A_k [npts, lda_k], B_k [npts, ldb_k] (channels i < m, j < n exist, m, n <= 256; up to two pairs
+ *   accumulate into one product: dW_l = zbar_l^T x_l + t_l^T abar_l), written for i < rows, j < cols to out[i * ldo + col_map[j]]
+ *   (col_map NULL = identity) or, transposed, to out[j * ldo + i].  colsum_a / colsum_b (optional, [m] / [n]): scale_a * sum_p A_0[p][i]
+ *   and scale_b * sum_p B_0[p][j] - the bias gradients come for free.  `slabs` = work items the points are split into (the
+ *   launch has sum(slabs) workgroups: about one per CU in total).  `jobs` is a HOST array; all data pointers are DEVICE pointers.
+ *   workspace: nrh_dw_workspace_floats(jobs, njobs) floats, 16-byte aligned.  npts must be a multiple of 32. */
+typedef struct NrhDwJob {
+  const float* a[2];
+  const float* b[2];
+  int lda[2], ldb[2];
+  int npairs, m, n, slabs;
+  float* out;
+  const int* col_map;
+  int ldo, transpose, rows, cols;
+  float scale;
+  float* colsum_a;
+  float scale_a;
+  float* colsum_b;
+  float scale_b;
+} NrhDwJob;
+long long nrh_dw_workspace_floats(const NrhDwJob* jobs, int njobs);
+int nrh_dw_gemm(const NrhDwJob* jobs, int njobs, long long npts, float* workspace, long long workspace_floats, void* stream);
+/* enc_6(3 p) of the points p = ro[ray] + rd[ray] * t[ray * t_stride + j] as rows [npts][64] (39 used, fields/encodings.py:168-174):
+ * the B operand of layer 0's weight gradient. */
+int nrh_embedding_rows(const float* ro, const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* rows,
+                       void* stream);
+/* rgb = sum_j c_j w_j + background (1 - sum w) (models/neus_hint_model.py:635-637), the per-ray partial sums of the loss terms of
+ * pipelines/base_pipeline.py:57-62 (partials [n,4]: sum_c |rgb - gt|, sum_j inside (|g| - 1)^2, sum_j inside, sum_c (rgb - gt)^2) and
+ * the adjoint seeds of d loss: zbar_out [n*128,3] = w dl/drgb c (1 - c) (through the output sigmoid) and weights_bar [n,128].
+ * nrh_loss_finish reduces the partials (deterministic order) to out8 = {loss, rgb_loss, eikonal_loss, s_val, psnr,
+ * igr_weight / (sum inside + 1e-5), 0, 0}; entry 5 is the eikonal seed coefficient nrh_alpha_train_backward_fused takes. */
+int nrh_composite_loss(const float* sampled_color, const float* weights, const float* rgb_gt, const float* background,
+                       const float* analytic_normals, const float* inside_sphere, long long nrays, float* rgb, float* zbar_out,
+                       float* weights_bar, float* partials, void* stream);
+int nrh_loss_finish(const float* partials, long long nrays, float inv_s, const float* dyn_scalars, float igr_weight, float* out8,
+                    void* stream);
+/* nrh_alpha_train_backward with (a) strided rows of nhat_bar (the normal's three columns inside the reflectance adjoint's output)
+ * and (b) the eikonal term's seed added to grad_bar: eikonal_coef[0] * inside * 2 (|g| - 1) g / |g| (both NULL = plain adjoint). */
+int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                                   float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
+                                   const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
+                                   float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream);
+/* d loss / d variance from the per-ray partials of nrh_alpha_train_backward (inv_s = clip(exp(10 variance), 1e-6, 1e6),
+ * models/neus_hint_model.py:104-110): variance_bar[0] = 10 inv_s sum(invs_bar) inside the clip range, else 0. */
+int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const float* dyn_scalars, float* variance_bar, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,9 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
-            "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite")
+            "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite",
+            "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
+            "nrh_alpha_train_backward_fused", "nrh_variance_grad")
 
 
 class NrhNet(Structure):
@@ -36,7 +38,7 @@ class NrhNet(Structure):
 
 class NrhTrainSaves(Structure):
     _fields_ = [("sdf", c_void_p), ("feat_rows", c_void_p), ("save_h", c_void_p), ("save_s1", c_void_p),
-                ("save_t", c_void_p), ("save_ge", c_void_p)]
+                ("save_t", c_void_p), ("save_ge", c_void_p), ("raymisc", c_void_p)]
 
 
 class HipExtensionMissing(RuntimeError):
@@ -100,6 +102,14 @@ def load():
     lib.nrh_alpha_composite.argtypes = [P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, P, P, c_longlong] + [P] * 12
     lib.nrh_visibility.argtypes = [P, P, P, P, P, P, P, c_float, c_float, c_int, c_longlong, P, P, P]
     lib.nrh_color_composite.argtypes = [P, P, P, P, P, P, P, c_longlong, P, P, P, P]
+    lib.nrh_dw_workspace_floats.argtypes = [P, c_int]
+    lib.nrh_dw_workspace_floats.restype = c_longlong
+    lib.nrh_dw_gemm.argtypes = [P, c_int, c_longlong, P, c_longlong, P]
+    lib.nrh_embedding_rows.argtypes = [P, P, P, c_int, c_int, c_longlong, P, P]
+    lib.nrh_composite_loss.argtypes = [P, P, P, P, P, P, c_longlong, P, P, P, P, P]
+    lib.nrh_loss_finish.argtypes = [P, c_longlong, c_float, P, c_float, P, P]
+    lib.nrh_alpha_train_backward_fused.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, c_int, P, P, P, P, P, P, P]
+    lib.nrh_variance_grad.argtypes = [P, c_longlong, c_float, P, P, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]
     lib.nrh_kernel_timing_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_longlong)]
     for name in EXPORTED:

@@ -36,29 +36,6 @@ def _enc(x: torch.Tensor, n_freq: int) -> torch.Tensor:
     return torch.cat([x, torch.sin(torch.cat([s, s + math.pi / 2.0], dim=-1))], dim=-1)
 
 
-class _LinearBigK(torch.autograd.Function):
-    """F.linear whose weight gradient ([out x P] @ [P x in], P ~ 1e5 rows, tiny output) is computed as a batched GEMM
-    over S slabs of rows + a sum: the plain GEMM autograd would call launches ~32 workgroups on a 256-CU GPU."""
-
-    @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        return torch.addmm(b, x, w.t())
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        gy = gy.contiguous()
-        m = x.shape[0]
-        S = math.gcd(m, 64)
-        gw = torch.bmm(gy.reshape(S, m // S, -1).transpose(1, 2), x.reshape(S, m // S, -1)).sum(0)
-        return gy @ w, gw, gy.sum(0)
-
-
-def _linear(x, w, b):
-    return _LinearBigK.apply(x, w, b) if (x.is_cuda and x.shape[0] >= 4096) else F.linear(x, w, b)
-
-
 class AlphaWeightsNormalsHip(torch.autograd.Function):
     """(sdf [P,1], grad [P,3], dirs [N,3], dists [N,128], variance) -> (weights [N,128], n_hat [P,3]) with the forward
     and the adjoint in one HIP kernel each (csrc/nrh_rays_train.hip) - get_alpha, the exclusive transmittance product
@@ -141,7 +118,6 @@ class ColorNetHip(torch.autograd.Function):
     @staticmethod
     def backward(ctx, cbar):
         from . import _lib, packing
-        from .sdf_function import _colsum
         lib = _lib.load()
         feat_c, color, save_h, save_misc = ctx.saved_tensors
         packed, n = ctx.packed, ctx.n
@@ -160,45 +136,12 @@ class ColorNetHip(torch.autograd.Function):
         grads_in = (fbar, mbar[:, 0:3], mbar[:, 3:6], mbar[:, 6:nm].reshape(n, 128, nm - 6).sum(1), None)
         if not any(ctx.needs_input_grad[5:]):
             return grads_in + (None,) * 10
-        S = math.gcd(Pn, 64)
-
-        def big_k(a3, b3):
-            L, ka, kb = a3.shape[0], a3.shape[-1], b3.shape[-1]
-            return torch.bmm(a3.reshape(L * S, Pn // S, ka).transpose(1, 2), b3.reshape(L * S, Pn // S, kb)).reshape(L, S, ka, kb).sum(1)
-
-        fi, mi = _col_perm(dev, hints)
-        w0_bar = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
-        w0_bar[:, fi] = big_k(zbar[0:1], feat_c[None])[0]
-        w0_bar[:, mi] = big_k(zbar[0:1], save_misc[None])[0][:, :nm]
-        w123 = big_k(zbar[1:4], save_h[0:3])
-        w4_bar = big_k(zbar4[None], save_h[3:4])[0]
-        zs = _colsum(zbar)
-        return grads_in + (w0_bar, w123[0], w123[1], w123[2], w4_bar, zs[0], zs[1], zs[2], zs[3], zbar4.sum(0))
-
-
-_COL_PERM = {}
-
-
-def _col_perm(device, hints: bool):
-    """packing.color_input_permutation on the device, cached (no host-to-device copy inside a captured step)."""
-    key = (str(device), hints)
-    if key not in _COL_PERM:
-        from . import packing
-        fi, mi = packing.color_input_permutation(hints)
-        _COL_PERM[key] = (fi.to(device), mi.to(device))
-    return _COL_PERM[key]
-
-
-_COL_INDEX = {}
-
-
-def _col_index(device, hints: bool):
-    """Column indices of the per-ray and of the (pts, normal) blocks in the reference's reflectance input, per device."""
-    key = (str(device), hints)
-    if key not in _COL_INDEX:
-        cols = [torch.arange(3, 30), torch.arange(33, 60)] + ([torch.arange(316, 325), torch.arange(325, 361)] if hints else [])
-        _COL_INDEX[key] = (torch.cat(cols).to(device), torch.tensor([0, 1, 2, 30, 31, 32], device=device))
-    return _COL_INDEX[key]
+        # weight gradients: one split-K bf16x3 MFMA launch (csrc/nrh_dw.hip), bias gradients = its column sums
+        from . import dw
+        out = {f"w{l}": new(*ctx.shapes[l]) for l in range(5)}
+        out.update({f"b{l}": new(*ctx.shapes[5 + l]) for l in range(5)})
+        dw.run(dw.color_jobs(hints, zbar, zbar4, save_h, feat_c, save_misc, out), Pn)
+        return grads_in + tuple(out[f"w{l}"] for l in range(5)) + tuple(out[f"b{l}"] for l in range(5))
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,

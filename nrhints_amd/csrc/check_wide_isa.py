@@ -40,5 +40,45 @@ def main():
     for b in bad[:20]: print("  line %d: %s: %s" % b)
     return 1 if bad else 0
 
+def check_inflight_loads(path, kernel_regex):
+    """For kernels whose asm loads stay in flight ACROSS other waits (csrc/nrh_dw.hip: two K steps of loads outstanding): model
+    vmcnt as the in-order counter it is.  Every global_load appends its destination registers to the queue; `s_waitcnt vmcnt(N)`
+    retires all but the youngest N; any instruction in between that reads or writes a register of a queued load is reported.
+    The scan is linear in the text (block layout order): the kernel's loop is laid out in execution order, and the queue is
+    emptied at every vmcnt(0)."""
+    kern, bad, queue, nload = None, [], [], 0
+    for ln, line in enumerate(open(path), 1):
+        m = re.match(r"^(\w*" + kernel_regex + r"\w*):", line)
+        if m: kern, queue = m.group(1), []; continue
+        if kern is None: continue
+        if line.startswith(".Lfunc_end"): kern = None; continue
+        t = line.strip().replace(",", " ").split()
+        if not t or t[0][0] in ";.": continue
+        op = t[0]
+        if op.startswith("s_waitcnt"):
+            m = re.search(r"vmcnt\((\d+)\)", line)
+            if m:
+                n = int(m.group(1))
+                queue = queue[len(queue) - n:] if n else []
+            continue
+        used = set()
+        for tok in t[1:]: used |= regs_of(tok)
+        for regs, at in queue:
+            hit = used & regs
+            if hit:
+                bad.append((ln, f"touches v{sorted(hit)[0]}, still in flight from the load at line {at}", line.strip()))
+                break
+        if op.startswith("global_load"):
+            nload += 1
+            queue.append((regs_of(t[1]), ln))
+        elif op.startswith(("global_store", "global_atomic")):
+            queue.append((set(), ln))          # stores count in vmcnt too
+    print(f"{path}: {kernel_regex}: {nload} global loads checked against the in-order vmcnt model, {len(bad)} problem(s)")
+    for b in bad[:20]: print("  line %d: %s: %s" % b)
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--inflight":
+        sys.exit(check_inflight_loads(sys.argv[1], sys.argv[3]))
     sys.exit(main())

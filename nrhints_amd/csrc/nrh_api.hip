@@ -6,6 +6,8 @@
 #include "nrh_rays.hip"
 #include "nrh_rays_train.hip"
 #include "nrh_fold.hip"
+#include "nrh_dw.hip"
+#include "nrh_train_fused.hip"
 
 #include <stdio.h>
 #include <string.h>
@@ -273,7 +275,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 125; }
+int nrh_version(void) { return 126; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -509,19 +511,152 @@ int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd
 int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                              float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar, const float* nhat_bar,
                              float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
+  return nrh_alpha_train_backward_fused(sdf, grad, rd, dists, inv_s, cos_anneal, dyn_scalars, nrays, weights_bar, nhat_bar, 3, nullptr,
+                                        nullptr, sdf_bar, grad_bar, rd_bar, invs_bar, stream);
+}
+
+int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                                   float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
+                                   const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
+                                   float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
   if (!sdf || !grad || !rd || !dists || !weights_bar || !sdf_bar || !grad_bar || !rd_bar || !invs_bar)
     return fail(NRH_E_INVALID, "nrh_alpha_train_backward: null pointer%s", "");
   if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_train_backward: nrays out of range%s", "");
+  if (nhat_bar && nhat_bar_stride < 3) return fail(NRH_E_INVALID, "nrh_alpha_train_backward_fused: nhat_bar_stride must be >= 3%s", "");
+  if ((eikonal_coef != nullptr) != (inside_sphere != nullptr))
+    return fail(NRH_E_INVALID, "nrh_alpha_train_backward_fused: inside_sphere and eikonal_coef come together%s", "");
   if (nrays == 0) return NRH_OK;
   nrh::AlphaTrainArgs a;
   memset(&a, 0, sizeof(a));
   a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
   a.dyn = dyn_scalars;
   a.weights_bar = weights_bar; a.nhat_bar = nhat_bar; a.sdf_bar = sdf_bar; a.grad_bar = grad_bar; a.rd_bar = rd_bar;
-  a.invs_bar = invs_bar;
+  a.invs_bar = invs_bar; a.nbar_stride = nhat_bar_stride; a.inside = inside_sphere; a.eik_coef = eikonal_coef;
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("alpha_train_kernel<bwd>");
+}
+
+// ---- weight gradients (csrc/nrh_dw.hip) ----
+static int dw_total_slabs(const NrhDwJob* jobs, int njobs) {
+  int tot = 0;
+  for (int j = 0; j < njobs; ++j) tot += jobs[j].slabs;
+  return tot;
+}
+
+long long nrh_dw_workspace_floats(const NrhDwJob* jobs, int njobs) {
+  if (!jobs || njobs <= 0 || njobs > nrhdw::MAX_JOBS) return -1;
+  for (int j = 0; j < njobs; ++j)
+    if (jobs[j].slabs <= 0) return -1;
+  return (long long)dw_total_slabs(jobs, njobs) * (nrhdw::SLOT_FLOATS + nrhdw::CSUM_FLOATS);
+}
+
+int nrh_dw_gemm(const NrhDwJob* jobs, int njobs, long long npts, float* workspace, long long workspace_floats, void* stream) {
+  if (!jobs || !workspace) return fail(NRH_E_INVALID, "nrh_dw_gemm: null pointer%s", "");
+  if (njobs <= 0 || njobs > nrhdw::MAX_JOBS) return fail(NRH_E_INVALID, "nrh_dw_gemm: 1..24 jobs%s", "");
+  if (npts <= 0 || npts % nrhdw::KPTS != 0 || npts / nrhdw::KPTS > 0x7fffffffLL)
+    return fail(NRH_E_INVALID, "nrh_dw_gemm: the number of points must be a positive multiple of 32%s", "");
+  if (((uintptr_t)workspace & 15) != 0) return fail(NRH_E_INVALID, "nrh_dw_gemm: workspace must be 16-byte aligned%s", "");
+  const long long need = nrh_dw_workspace_floats(jobs, njobs);
+  if (need < 0 || workspace_floats < need) return fail(NRH_E_WORKSPACE, "nrh_dw_gemm: workspace too small%s (need %lld floats)", "", need);
+  nrhdw::DwArgs a;
+  nrhdw::ReduceArgs r;
+  memset(&a, 0, sizeof(a));
+  memset(&r, 0, sizeof(r));
+  const int nsteps = (int)(npts / nrhdw::KPTS);
+  int slab0 = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const NrhDwJob& q = jobs[j];
+    if (q.npairs < 1 || q.npairs > 2 || q.m < 1 || q.m > 256 || q.n < 1 || q.n > 256 || q.slabs < 1 || q.slabs > nsteps)
+      return fail(NRH_E_INVALID, "nrh_dw_gemm: bad job shape%s (job %lld)", "", (long long)j);
+    for (int k = 0; k < q.npairs; ++k) {
+      if (!q.a[k] || !q.b[k] || q.lda[k] < q.m || q.ldb[k] < q.n) return fail(NRH_E_INVALID, "nrh_dw_gemm: bad operand%s (job %lld)", "", (long long)j);
+      a.job[j].a[k] = q.a[k]; a.job[j].b[k] = q.b[k]; a.job[j].lda[k] = q.lda[k]; a.job[j].ldb[k] = q.ldb[k];
+    }
+    if (q.out && (q.rows < 1 || q.rows > q.m || q.cols < 1 || q.cols > q.n || q.ldo < 1))
+      return fail(NRH_E_INVALID, "nrh_dw_gemm: bad output shape%s (job %lld)", "", (long long)j);
+    if (q.col_map && q.transpose) return fail(NRH_E_INVALID, "nrh_dw_gemm: col_map with transpose%s", "");
+    a.job[j].npairs = q.npairs; a.job[j].m = q.m; a.job[j].n = q.n; a.job[j].slab0 = slab0; a.job[j].slabs = q.slabs;
+    a.job[j].colsum = (q.colsum_a ? 1 : 0) | (q.colsum_b ? 2 : 0);
+    nrhdw::OutDev& o = r.job[j];
+    o.out = q.out; o.col_map = q.col_map; o.colsum_a = q.colsum_a; o.colsum_b = q.colsum_b; o.ldo = q.ldo; o.transpose = q.transpose;
+    o.rows = q.out ? q.rows : q.m; o.cols = q.out ? q.cols : q.n; o.scale = q.scale; o.scale_a = q.scale_a; o.scale_b = q.scale_b;
+    o.slab0 = slab0; o.slabs = q.slabs;
+    slab0 += q.slabs;
+  }
+  a.njobs = njobs; a.nsteps = nsteps;
+  a.partial = workspace;
+  a.csum = workspace + (size_t)slab0 * nrhdw::SLOT_FLOATS;
+  r.njobs = njobs; r.partial = a.partial; r.csum = a.csum;
+  const int dev = current_device();
+  if (dev < 0) return fail(NRH_E_LAUNCH, "no HIP device%s", "");
+  static bool attr_done[MAX_DEVICES] = {};
+  if (!attr_done[dev]) {
+    if (hipFuncSetAttribute((const void*)nrhdw::dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nrhdw::FAST_LDS_BYTES) != hipSuccess)
+      return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed%s", "");
+    attr_done[dev] = true;
+  }
+  const hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(nrhdw::dw_kernel, dim3(slab0), dim3(nrhdw::THREADS), nrhdw::FAST_LDS_BYTES, st, a);
+  int rc = check_launch("dw_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nrhdw::dw_reduce_kernel, dim3(256, njobs), dim3(256), 0, st, r);
+  return check_launch("dw_reduce_kernel");
+}
+
+#ifdef NRH_DW_TIMING
+int nrh_dw_debug_read(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(nrhdw::g_dw_cycles), 64) != hipSuccess) return NRH_E_LAUNCH;
+  if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(nrhdw::g_dw_cycles), z, 64); }
+  return NRH_OK;
+}
+#endif
+
+int nrh_embedding_rows(const float* ro, const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* rows,
+                       void* stream) {
+  if (!ro || !rd || !t || !rows) return fail(NRH_E_INVALID, "nrh_embedding_rows: null pointer%s", "");
+  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_embedding_rows: bad n_per_ray/stride%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::EmbRowsArgs a;
+  a.ro = ro; a.rd = rd; a.t = t; a.out = rows; a.npts = nrays * n_per_ray; a.n_per_ray = n_per_ray; a.t_stride = t_stride;
+  const long long blocks = (a.npts * 64 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_embedding_rows: too many points%s", "");
+  hipLaunchKernelGGL(nrh::emb_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("emb_rows_kernel");
+}
+
+int nrh_composite_loss(const float* sampled_color, const float* weights, const float* rgb_gt, const float* background,
+                       const float* analytic_normals, const float* inside_sphere, long long nrays, float* rgb, float* zbar_out,
+                       float* weights_bar, float* partials, void* stream) {
+  if (!sampled_color || !weights || !rgb_gt || !analytic_normals || !inside_sphere || !rgb || !zbar_out || !weights_bar || !partials)
+    return fail(NRH_E_INVALID, "nrh_composite_loss: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_composite_loss: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::CompositeLossArgs a;
+  a.color = sampled_color; a.weights = weights; a.gt = rgb_gt; a.bg = background; a.grad = analytic_normals; a.inside = inside_sphere;
+  a.rgb = rgb; a.zbar4 = zbar_out; a.wbar = weights_bar; a.partial = partials; a.inv_n = (float)(1.0 / ((double)nrays + 1e-5));
+  a.nrays = (int)nrays;
+  hipLaunchKernelGGL(nrh::composite_loss_kernel, dim3((unsigned)((nrays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("composite_loss_kernel");
+}
+
+int nrh_loss_finish(const float* partials, long long nrays, float inv_s, const float* dyn_scalars, float igr_weight, float* out8,
+                    void* stream) {
+  if (!partials || !out8) return fail(NRH_E_INVALID, "nrh_loss_finish: null pointer%s", "");
+  if (nrays <= 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_loss_finish: nrays out of range%s", "");
+  nrh::LossFinishArgs a;
+  a.partial = partials; a.out = out8; a.dyn = dyn_scalars; a.inv_s = inv_s; a.igr_weight = igr_weight; a.nrays = (int)nrays;
+  hipLaunchKernelGGL(nrh::loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("loss_finish_kernel");
+}
+
+int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const float* dyn_scalars, float* variance_bar, void* stream) {
+  if (!invs_bar || !variance_bar) return fail(NRH_E_INVALID, "nrh_variance_grad: null pointer%s", "");
+  if (nrays <= 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_variance_grad: nrays out of range%s", "");
+  nrh::VarGradArgs a;
+  a.invs_bar = invs_bar; a.dyn = dyn_scalars; a.inv_s = inv_s; a.out = variance_bar; a.nrays = (int)nrays;
+  hipLaunchKernelGGL(nrh::variance_grad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("variance_grad_kernel");
 }
 
 int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const float* znew_in,
@@ -739,7 +874,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   {
     nrh::ShadowArgs c;
     c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = ws_dists_s;
-    c.cue = ws_cue; c.vis = o_vis; c.raymisc = ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
+    c.cue = ws_cue; c.vis = o_vis; c.raymisc = (train && train->raymisc) ? train->raymisc : ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
     c.dyn = net->dyn_scalars;
     c.nrays = (int)n; c.zero_hints = no_hints;
     hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);

@@ -33,6 +33,12 @@ struct AlphaTrainArgs {
   float* grad_bar;       // [N*128,3]
   float* rd_bar;         // [N,3]
   float* invs_bar;       // [N]   per-ray partial of d loss / d inv_s
+  // fused training step (nrhints_amd/train_fused.py): nhat_bar rows may be strided (the normal's columns of the reflectance
+  // adjoint's [P, 128] output), and the eikonal term's seed  igr / (sum inside + 1e-5) * inside * 2 (|g| - 1) g / |g|
+  // (pipelines/base_pipeline.py:59-62) is added to grad_bar here, where g is in registers anyway
+  int nbar_stride;       // floats between rows of nhat_bar (0 = 3)
+  const float* inside;   // [N,128] or null
+  const float* eik_coef; // device scalar igr_weight / (sum inside + 1e-5), or null
 };
 
 // inclusive SUFFIX sum over the 128-long per-ray sequence (j0 = lane, j1 = lane + 64)
@@ -126,13 +132,19 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
     rdb[2] += tcb * g[e][2];
     if (a.nhat_bar) {
       // n = g / max(|g|, eps):  gbar += (nbar - n (n . nbar)) / |g|   (0 through the clamp when |g| < eps)
-      const float nb[3] = {a.nhat_bar[P * 3 + 0], a.nhat_bar[P * 3 + 1], a.nhat_bar[P * 3 + 2]};
+      const long long nbs = a.nbar_stride ? a.nbar_stride : 3;
+      const float nb[3] = {a.nhat_bar[P * nbs + 0], a.nhat_bar[P * nbs + 1], a.nhat_bar[P * nbs + 2]};
       const float nx = g[e][0] / gn[e], ny = g[e][1] / gn[e], nz = g[e][2] / gn[e];
       const float dot = nx * nb[0] + ny * nb[1] + nz * nb[2];
       const bool clamped = gn[e] <= 1e-12f;
       gb[0] += (nb[0] - (clamped ? 0.0f : nx * dot)) / gn[e];
       gb[1] += (nb[1] - (clamped ? 0.0f : ny * dot)) / gn[e];
       gb[2] += (nb[2] - (clamped ? 0.0f : nz * dot)) / gn[e];
+    }
+    if (a.eik_coef) {
+      // (|g| - 1)^2 on relax_inside_sphere samples: d/dg = 2 (|g| - 1) g / |g|
+      const float k = a.eik_coef[0] * a.inside[P] * 2.0f * (gn[e] - 1.0f) / gn[e];
+      gb[0] += k * g[e][0]; gb[1] += k * g[e][1]; gb[2] += k * g[e][2];
     }
     if (active) {
       a.sdf_bar[P] = enb + epb;

@@ -1,0 +1,170 @@
+// Small per-ray / per-point kernels of the fused training step (nrhints_amd/train_fused.py): what round 2 left to ~300 torch
+// launches per step - the compositing sum, the loss and its adjoint seeds, the positional encoding as a GEMM operand, the
+// scalar reductions - as a handful of HIP launches.  Reference: models/neus_hint_model.py:635-637 (composite),
+// pipelines/base_pipeline.py:57-62 (L1 colour loss + eikonal loss), :64-69 (s_val, psnr), fields/encodings.py:168-174.
+#pragma once
+#include "nrh_common.h"
+
+namespace nrh {
+
+// ---- e = enc_6(3 p) as rows [P][64] (39 used, the rest zero): the B operand of layer 0's weight gradient ----------------
+struct EmbRowsArgs {
+  const float* ro; const float* rd; const float* t;   // p = ro[ray] + rd[ray] * t[ray * t_stride + j]
+  float* out;                                          // [npts][64]
+  long long npts;
+  int n_per_ray, t_stride;
+};
+__global__ __launch_bounds__(256) void emb_rows_kernel(const EmbRowsArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long P = i >> 6;
+  const int e = (int)(i & 63);
+  if (P >= a.npts) return;
+  const long long ray = P / a.n_per_ray;
+  const int jj = (int)(P - ray * a.n_per_ray);
+  const float tt = a.t[ray * a.t_stride + jj];
+  float v = 0.0f;
+  if (e < 39) {
+    const int d = e < 3 ? e : ((e - 3) % 18) / 6;
+    const float x = (a.ro[ray * 3 + d] + a.rd[ray * 3 + d] * tt) * 3.0f;
+    if (e < 3) v = x;
+    else {
+      const int idx = (e - 3) % 18;
+      v = sin_cw(x * (float)(1 << (idx % 6)) + ((e - 3) >= 18 ? NRH_HALF_PI : 0.0f));
+    }
+  }
+  a.out[i] = v;
+}
+
+// ---- composite + loss terms + the adjoint seeds of both (one wavefront per ray) ----------------------------------------------
+//   rgb = sum_j c_j w_j + bg (1 - sum_j w_j)                                     (models/neus_hint_model.py:635-637)
+//   rgb_loss = sum |rgb - gt| / (N + 1e-5);  eik = sum inside (|g| - 1)^2 / (sum inside + 1e-5);  loss = rgb_loss + igr * eik
+// d loss / d rgb = sign(rgb - gt) / (N + 1e-5) is known without any downstream information, so the same pass writes
+//   cbar_j = w_j dl/drgb  ->  zbar4 = cbar c (1 - c)   (through the reflectance net's output sigmoid)
+//   wbar_j = sum_c (c_jc - bg_c) dl/drgb_c
+// and the per-ray partial sums of the four scalars; the eikonal seed needs sum(inside) first and is added by the alpha adjoint.
+struct CompositeLossArgs {
+  const float* color;    // [N*128,3] sigmoid outputs
+  const float* weights;  // [N,128]
+  const float* gt;       // [N,3]
+  const float* bg;       // [3] or null
+  const float* grad;     // [N*128,3] analytic normals
+  const float* inside;   // [N,128]
+  float* rgb;            // [N,3]
+  float* zbar4;          // [N*128,3]
+  float* wbar;           // [N,128]
+  float* partial;        // [N,4]: sum_c |rgb - gt|, sum_j inside (|g| - 1)^2, sum_j inside, sum_c (rgb - gt)^2
+  float inv_n;           // 1 / (N + 1e-5)
+  int nrays;
+};
+__global__ __launch_bounds__(256) void composite_loss_kernel(const CompositeLossArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * 4 + wave;
+  const bool active = ray_raw < a.nrays;
+  const long long ray = active ? ray_raw : a.nrays - 1;
+  float c[2][3], w[2], acc[3] = {0.f, 0.f, 0.f}, ws = 0.0f, eik = 0.0f, cnt = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const long long P = ray * 128 + lane + 64 * e;
+    w[e] = a.weights[P];
+    ws += w[e];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c[e][k] = a.color[P * 3 + k]; acc[k] += c[e][k] * w[e]; }
+    const float gx = a.grad[P * 3 + 0], gy = a.grad[P * 3 + 1], gz = a.grad[P * 3 + 2];
+    const float ins = a.inside[P];
+    const float ge = sqrtf(gx * gx + gy * gy + gz * gz) - 1.0f;
+    eik += ins * (ge * ge);
+    cnt += ins;
+  }
+  ws = wave_sum(ws); eik = wave_sum(eik); cnt = wave_sum(cnt);
+  float dl[3], l1 = 0.0f, l2 = 0.0f, bgc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    bgc[k] = a.bg ? a.bg[k] : 0.0f;
+    const float rgb = wave_sum(acc[k]) + (a.bg ? bgc[k] * (1.0f - ws) : 0.0f);
+    const float diff = rgb - a.gt[ray * 3 + k];
+    l1 += fabsf(diff);
+    l2 += diff * diff;
+    dl[k] = (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f)) * a.inv_n;     // torch's abs backward: sign(x), sign(0) = 0
+    if (active && lane == 0) a.rgb[ray * 3 + k] = rgb;
+  }
+  if (!active) return;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const long long P = ray * 128 + lane + 64 * e;
+    float wb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      wb += (c[e][k] - bgc[k]) * dl[k];
+      a.zbar4[P * 3 + k] = (w[e] * dl[k]) * c[e][k] * (1.0f - c[e][k]);
+    }
+    a.wbar[P] = wb;
+  }
+  if (lane == 0) {
+    a.partial[ray * 4 + 0] = l1; a.partial[ray * 4 + 1] = eik; a.partial[ray * 4 + 2] = cnt; a.partial[ray * 4 + 3] = l2;
+  }
+}
+
+// one block: per-ray partials -> the loss dict (pipelines/base_pipeline.py:57-69) and the eikonal seed coefficient.
+// out[0] loss, [1] rgb_loss, [2] eikonal_loss, [3] s_val = 1 / inv_s, [4] psnr, [5] igr_weight / (sum inside + 1e-5)
+struct LossFinishArgs {
+  const float* partial;  // [N,4]
+  float* out;            // [8]
+  const float* dyn;      // optional device [inv_s, cos_anneal]
+  float inv_s, igr_weight;
+  int nrays;
+};
+__global__ __launch_bounds__(256) void loss_finish_kernel(const LossFinishArgs a) {
+  __shared__ float red[4][4];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = threadIdx.x; r < a.nrays; r += 256)       // fixed order per thread, fixed tree below: deterministic
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += a.partial[(size_t)r * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] = wave_sum(s[k]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wave][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    const float n = (float)a.nrays;
+    const float rgb_loss = t[0] / (n + 1e-5f);
+    const float eik = t[1] / (t[2] + 1e-5f);
+    const float S = a.dyn ? a.dyn[0] : a.inv_s;
+    a.out[0] = rgb_loss + eik * a.igr_weight;
+    a.out[1] = rgb_loss;
+    a.out[2] = eik;
+    a.out[3] = 1.0f / S;
+    a.out[4] = 10.0f * log10f(1.0f / (t[3] / (3.0f * n)));
+    a.out[5] = a.igr_weight / (t[2] + 1e-5f);
+    a.out[6] = 0.0f; a.out[7] = 0.0f;
+  }
+}
+
+// d loss / d variance = sum_rays invs_bar * d inv_s / d variance, inv_s = clip(exp(10 variance), 1e-6, 1e6)
+// (models/neus_hint_model.py:104-110, :337): 10 inv_s inside the clip range, 0 outside.  One block.
+struct VarGradArgs {
+  const float* invs_bar;  // [N]
+  const float* dyn;
+  float inv_s;
+  float* out;             // [1]
+  int nrays;
+};
+__global__ __launch_bounds__(256) void variance_grad_kernel(const VarGradArgs a) {
+  __shared__ float red[4];
+  float s = 0.0f;
+  for (int r = threadIdx.x; r < a.nrays; r += 256) s += a.invs_bar[r];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float S = a.dyn ? a.dyn[0] : a.inv_s;
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    a.out[0] = (S > 1e-6f && S < 1e6f) ? tot * 10.0f * S : 0.0f;
+  }
+}
+
+}  // namespace nrh

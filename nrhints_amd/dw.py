@@ -1,0 +1,159 @@
+"""Weight gradients of the training step through ``nrh_dw_gemm`` (csrc/nrh_dw.hip): every ``dW = X^T Y`` that
+``loss.backward()`` computes for the nn.Linear layers of the two networks (fields/sdf_field.py:81-101,
+fields/reflectance_network.py:52-66) as split-K bf16x3 MFMA GEMMs in one launch, bias gradients as by-products.
+
+This module only builds the job table (which saved array meets which, where the product goes) and sizes the K split; there is
+no other implementation behind it - without the HIP library it raises like everything else in the package.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+class NrhDwJob(ctypes.Structure):
+    """include/nrhints_hip.h: NrhDwJob"""
+    _fields_ = [("a", ctypes.c_void_p * 2), ("b", ctypes.c_void_p * 2), ("lda", ctypes.c_int * 2), ("ldb", ctypes.c_int * 2),
+                ("npairs", ctypes.c_int), ("m", ctypes.c_int), ("n", ctypes.c_int), ("slabs", ctypes.c_int),
+                ("out", ctypes.c_void_p), ("col_map", ctypes.c_void_p), ("ldo", ctypes.c_int), ("transpose", ctypes.c_int),
+                ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("scale", ctypes.c_float),
+                ("colsum_a", ctypes.c_void_p), ("scale_a", ctypes.c_float), ("colsum_b", ctypes.c_void_p), ("scale_b", ctypes.c_float)]
+
+
+class Job:
+    """out[i, j] = scale * sum_k sum_p A_k[p, i] B_k[p, j]  (A_k [P, lda], B_k [P, ldb] float32 row-major views)."""
+
+    def __init__(self, a: Sequence[torch.Tensor], b: Sequence[torch.Tensor], m: int, n: int, out: Optional[torch.Tensor] = None,
+                 rows: Optional[int] = None, cols: Optional[int] = None, transpose: bool = False, scale: float = 1.0,
+                 col_map: Optional[torch.Tensor] = None, colsum_a: Optional[torch.Tensor] = None, scale_a: float = 1.0,
+                 colsum_b: Optional[torch.Tensor] = None, scale_b: float = 1.0):
+        assert len(a) == len(b) and 1 <= len(a) <= 2
+        self.a, self.b, self.m, self.n, self.out = list(a), list(b), m, n, out
+        self.rows, self.cols = (m if rows is None else rows), (n if cols is None else cols)
+        self.transpose, self.scale, self.col_map = transpose, scale, col_map
+        self.colsum_a, self.scale_a, self.colsum_b, self.scale_b = colsum_a, scale_a, colsum_b, scale_b
+
+    def cost(self) -> float:
+        """relative time of one K step: 6 MFMAs per 32 output columns per wave + the load / split / LDS overhead of both operands"""
+        nf = 1 if self.n <= 32 else 2 if self.n <= 64 else 4 if self.n <= 128 else 8
+        # measured cycles per K step (profiles/r03/dw_phase_cycles.log): 3 300 on the fused fast path (full 256 x 256 operands),
+        # 5 000 on the general path whatever the column count (the A operand's conversion dominates)
+        full = self.m == 256 and self.n == 256
+        return len(self.a) * (1.0 if full else 1.5)
+
+
+def _rows(t: torch.Tensor):
+    """(pointer, leading dimension) of a [P, C] float32 view whose rows are contiguous"""
+    if t.dim() == 1:
+        t = t[:, None]
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError(f"dw operand must be a float32 GPU matrix with contiguous rows, got {tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    return t.data_ptr(), int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
+
+
+_WS: Dict[str, torch.Tensor] = {}
+
+
+def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
+    """One nrh_dw_gemm call for all jobs (two launches: split-K products, deterministic reduction).  The K split gives every job
+    a share of ``total_items`` workgroups (default: the device's CU count) in proportion to its cost."""
+    lib = _lib.load()
+    dev = jobs[0].a[0].device
+    with torch.cuda.device(dev):
+        if total_items is None:
+            # four work items per CU: the jobs' per-step costs differ by 2x and are only modelled roughly; short items level the
+            # tail (measured on the 1024-ray job table: 3.3 ms with one item per CU, 2.1 ms with four; profiles/r03/dw_bench_*.log)
+            total_items = 4 * max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
+        nsteps = npts // 32
+        costs = [j.cost() for j in jobs]
+        tot = sum(costs)
+        arr = (NrhDwJob * len(jobs))()
+        keep = []
+        for q, j, c in zip(arr, jobs, costs):
+            for k, (a, b) in enumerate(zip(j.a, j.b)):
+                if a.shape[0] != npts or b.shape[0] != npts:
+                    raise ValueError("dw operands must have one row per point")
+                q.a[k], q.lda[k] = _rows(a)
+                q.b[k], q.ldb[k] = _rows(b)
+            q.npairs, q.m, q.n = len(j.a), j.m, j.n
+            q.slabs = max(1, min(nsteps, int(round(total_items * c / tot))))
+            if j.out is not None:
+                if not (j.out.is_cuda and j.out.dtype == torch.float32 and j.out.is_contiguous()):
+                    raise ValueError("dw output must be a contiguous float32 GPU tensor")
+                q.out, q.ldo = j.out.data_ptr(), int(j.out.shape[-1])
+            q.transpose, q.rows, q.cols, q.scale = int(j.transpose), j.rows, j.cols, float(j.scale)
+            if j.col_map is not None:
+                if j.col_map.dtype != torch.int32 or not j.col_map.is_cuda:
+                    raise ValueError("col_map must be an int32 GPU tensor")
+                q.col_map = j.col_map.data_ptr()
+            if j.colsum_a is not None:
+                q.colsum_a, q.scale_a = j.colsum_a.data_ptr(), float(j.scale_a)
+            if j.colsum_b is not None:
+                q.colsum_b, q.scale_b = j.colsum_b.data_ptr(), float(j.scale_b)
+            keep.append(j)
+        need = int(lib.nrh_dw_workspace_floats(arr, len(jobs)))
+        if need < 0:
+            raise ValueError("nrh_dw_workspace_floats: bad job table")
+        key = str(dev)
+        ws = _WS.get(key)
+        if ws is None or ws.numel() < need:
+            _WS[key] = ws = torch.empty(need, dtype=torch.float32, device=dev)
+        rc = lib.nrh_dw_gemm(arr, len(jobs), npts, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_handle())
+        _lib.check(rc, "nrh_dw_gemm")
+
+
+_ONES: Dict[tuple, torch.Tensor] = {}
+
+
+def ones(n: int, device) -> torch.Tensor:
+    key = (str(device), n)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+_MAPS: Dict[tuple, tuple] = {}
+
+
+def color_col_maps(device, hints: bool):
+    """packing.color_input_permutation as int32 device tensors: destination columns of the feature block / the other block"""
+    key = (str(device), hints)
+    if key not in _MAPS:
+        from . import packing
+        fi, mi = packing.color_input_permutation(hints)
+        _MAPS[key] = (fi.to(torch.int32).to(device), mi.to(torch.int32).to(device))
+    return _MAPS[key]
+
+
+def sdf_jobs(shapes, h, t, zbar, abar, gebar, emb, sbar, fbar, out) -> List[Job]:
+    """Jobs for the SDF network's 8 layers and 2 heads (the maths: nrhints_amd/sdf_function.py).  h, t, zbar, abar [8,P,256];
+    gebar, emb [P,64]; sbar [P]; fbar [P,256]; ``out``: dict of preallocated gradient tensors dW0..7, db0..7, ws, bs, Wf, bf;
+    ``shapes``: the dense weights' shapes (layer 3 has 217 rows)."""
+    P = h.shape[1]
+    jobs = [Job([zbar[0], t[0]], [emb, gebar], 256, 39, out["dW0"], rows=shapes[0][0], colsum_a=out["db0"])]
+    for l in range(1, 8):
+        jobs.append(Job([zbar[l], t[l]], [h[l - 1], abar[l - 1]], 256, 256, out[f"dW{l}"], rows=shapes[l][0],
+                        scale=(1.0 / math.sqrt(2.0) if l == 4 else 1.0), colsum_a=out[f"db{l}"]))
+    jobs.append(Job([fbar], [h[7]], 256, 256, out["Wf"], colsum_a=out["bf"]))
+    # d w_s = (h_7^T sbar + sum_p abar_7) / 3,  d b_s = sum(sbar) / 3   (sdf = (w_s . h_7 + b_s) / 3)
+    jobs.append(Job([h[7], abar[7]], [sbar.reshape(P, 1), ones(P, h.device).reshape(P, 1)], 256, 1, out["ws"], transpose=True,
+                    scale=1.0 / 3.0, colsum_b=out["bs"], scale_b=1.0 / 3.0))
+    return jobs
+
+
+def color_jobs(hints: bool, zbar, zbar4, save_h, feat, save_misc, out) -> List[Job]:
+    """Jobs for the reflectance network's 5 layers.  zbar, save_h [4,P,256]; zbar4 [P,3]; feat [P,256]; save_misc [P,128|64];
+    ``out``: w0 [256,361|316], w1..w3 [256,256], w4 [3,256], b0..b3 [256], b4 [3]."""
+    fi, mi = color_col_maps(zbar.device, hints)
+    nm = 105 if hints else 60
+    jobs = [Job([zbar[0]], [feat], 256, 256, out["w0"], col_map=fi, colsum_a=out["b0"]),
+            Job([zbar[0]], [save_misc], 256, nm, out["w0"], col_map=mi)]
+    for l in (1, 2, 3):
+        jobs.append(Job([zbar[l]], [save_h[l - 1]], 256, 256, out[f"w{l}"], colsum_a=out[f"b{l}"]))
+    jobs.append(Job([save_h[3]], [zbar4], 256, 3, out["w4"], transpose=True, colsum_b=out["b4"]))
+    return jobs

@@ -312,7 +312,7 @@ class NeuSHintRenderer(nn.Module):
                             specular_cue=cue if self._hints else None)
 
     # ---------------------------------------------------------------------------------------------
-    def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints):
+    def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None):
         """One nrh_render_forward_train call over the whole batch: the no-grad stages (samplers, hit point, shadow march,
         cue) plus the training evaluation of the SDF network at the section mid-points, whose outputs and saved arrays
         feed the backward sweeps directly (no second evaluation)."""
@@ -331,7 +331,7 @@ class NeuSHintRenderer(nn.Module):
                    ro=o, rd=d, t=out["mid_z"], n_per_ray=T)
         P = _lib.ptr
         sv = pre["saves"]
-        saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]))
+        saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]), P(raymisc))
         ws = self._workspace(device, n)
         rc = lib.nrh_render_forward_train(
             net, P(o), P(d), P(pl), P(near), P(far), n, cos_anneal, P(t_rand_p) if t_rand_p is not None else None,

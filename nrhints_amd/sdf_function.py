@@ -56,14 +56,6 @@ def _scatter_dims(v: torch.Tensor, dim: torch.Tensor = None) -> torch.Tensor:
     return v[:, 0:3] + v[:, 3:21].reshape(P, 3, 6).sum(-1) + v[:, 21:39].reshape(P, 3, 6).sum(-1)
 
 
-def _colsum(x3: torch.Tensor) -> torch.Tensor:
-    """[L,P,C] -> [L,C] column sums in two stages (64 slabs of rows first): the one-stage reduction of a [8,131072,256]
-    array ran at 1.6 TB/s."""
-    L, P, C = x3.shape
-    S = math.gcd(P, 64)
-    return x3.reshape(L, S, P // S, C).sum(2).sum(1)
-
-
 class SdfValueFeatGradHip(torch.autograd.Function):
     """Same contract as ``SdfValueFeatGrad`` with the forward and both backward sweeps in the HIP register-chain
     kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are rocBLAS GEMMs over the saved
@@ -83,7 +75,7 @@ class SdfValueFeatGradHip(torch.autograd.Function):
             ctx.rays = (pre["ro"], pre["rd"], pre["t"], pre["n_per_ray"])
             ctx.p = pts.detach()
             return pre["sdf"], pre["feat"], pre["grad"]
-        pad = (-n) % 16
+        pad = (-n) % 32          # the sweep kernels take multiples of 16 points, the weight-gradient kernel multiples of 32
         p = pts.detach().to(torch.float32)
         if pad:
             p = torch.cat([p, p[-1:].expand(pad, 3)], dim=0)
@@ -112,39 +104,32 @@ class SdfValueFeatGradHip(torch.autograd.Function):
         r = ops.sdf_train_backward(packed["sdf_w"], packed["sdf_wt_feat"], packed["sdf_head"], ro, rd, tt, npr, saves,
                                    sb.reshape(-1), fb, gb)
         zbar, abar, h, t = r["zbar"], r["abar"], saves["h"], saves["t"]
-        e, dc, d2c, dim = _enc_parts(p * 3.0)
-        ge = saves["ge"][:, :EMB] + saves["ge"][:, 73:73 + EMB]
-        p_bar = r["pbar"] + 9.0 * gb * _scatter_dims(ge * d2c)   # gbar[dim(e)] is constant within a coordinate's entries
+        p_bar = None
+        if ctx.needs_input_grad[0]:       # only pose / light refinement asks for the points' adjoint
+            e, dc, d2c, dim = _enc_parts(p * 3.0)
+            ge = saves["ge"][:, :EMB] + saves["ge"][:, 73:73 + EMB]
+            p_bar = (r["pbar"] + 9.0 * gb * _scatter_dims(ge * d2c))[:n]   # gbar[dim(e)] is constant within a coordinate's entries
         if not any(ctx.needs_input_grad[3:]):       # frozen network (e.g. register_view): only the points' adjoint
             ctx.saves = None
-            return (p_bar[:n], None, None) + (None,) * 20
-        # weight gradients: [256 x P] @ [P x 256] GEMMs with a tiny output and a huge K.  A plain GEMM call launches
-        # 16..32 workgroups for them (measured 44 TFLOP/s, 30 % of the step); splitting P into S = 64 batches fills the GPU (S = 32: 105, S = 64: 129 TFLOP/s).
-        S = math.gcd(m, 64)
-
-        def big_k(a3, b3):          # [L,m,ka], [L,m,kb] -> [L,ka,kb] = sum over the m rows
-            L, ka, kb = a3.shape[0], a3.shape[-1], b3.shape[-1]
-            prod = torch.bmm(a3.reshape(L * S, m // S, ka).transpose(1, 2), b3.reshape(L * S, m // S, kb))
-            return prod.reshape(L, S, ka, kb).sum(1)
-
-        w_rest = big_k(zbar[1:], h[:7]) + big_k(t[1:], abar[:7])                               # layers 1..7
-        w_0 = big_k(zbar[:1], e[None]) + big_k(t[:1], r["gebar"][None, :, :EMB])               # layer 0 [1,256,39]
-        zsum = _colsum(zbar)                                      # [8,256]
-        dW, db = [], []
+            return (p_bar, None, None) + (None,) * 20
+        # weight gradients: [256 x P] @ [P x 256] products with a tiny output and a huge reduction - one split-K bf16x3 MFMA
+        # launch for all layers and heads (csrc/nrh_dw.hip, nrhints_amd/dw.py), the bias gradients are its column sums
+        from . import _lib, dw
+        dev = p.device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        out = {}
         for l in range(N_LAYERS):
-            w = w_0[0] if l == 0 else w_rest[l - 1]
-            rows = ctx.shapes[l][0]
-            if l == SKIP:
-                w = w / math.sqrt(2.0)
-            dW.append(w[:rows])
-            db.append(zsum[l, :rows])
-        h7 = h[7]
-        ws_bar = ((_colsum(abar[7:8])[0] + big_k(h[7:8], sb[None])[0, :, 0]) / 3.0).reshape(1, 256)
-        bs_bar = sb.sum().reshape(1) / 3.0
-        Wf_bar = big_k(fb[None], h[7:8])[0]
-        bf_bar = _colsum(fb[None])[0]
+            out[f"dW{l}"], out[f"db{l}"] = new(*ctx.shapes[l]), new(ctx.shapes[l][0])
+        out["ws"], out["bs"], out["Wf"], out["bf"] = new(1, 256), new(1), new(256, 256), new(256)
+        emb = new(m, 64)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.nrh_embedding_rows(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(tt), npr, npr, ro.shape[0], _lib.ptr(emb), _lib.stream_handle()),
+                       "nrh_embedding_rows")
+            dw.run(dw.sdf_jobs(ctx.shapes[:N_LAYERS], h, t, zbar, abar, r["gebar"], emb, sb.reshape(-1), fb, out), m)
         ctx.saves = None
-        return (p_bar[:n], None, None, *dW, *db, ws_bar, bs_bar, Wf_bar, bf_bar)
+        return (p_bar, None, None, *[out[f"dW{l}"] for l in range(N_LAYERS)], *[out[f"db{l}"] for l in range(N_LAYERS)],
+                out["ws"], out["bs"], out["Wf"], out["bf"])
 
 
 def sdf_value_feat_grad(dense: Dict[str, torch.Tensor], pts: torch.Tensor, packed, pre=None):

@@ -1,0 +1,170 @@
+"""The training step without autograd: forward, loss and the whole backward as a fixed sequence of HIP launches.
+
+``forward() + loss.backward()`` through the autograd Functions of autograd_core.py stays the drop-in path (it is what the
+reference's trainer calls, pipelines/base_pipeline.py:41-69, trainer/trainer.py:269-283).  This module is the same computation
+with nothing left to the framework between the kernels: no autograd graph, no library GEMM, no elementwise torch op on the
+per-sample arrays.  The loss is part of it (its adjoint seeds are known without any downstream information), so one call
+returns the loss dict AND leaves ``.grad`` on all 46 parameter tensors:
+
+    fold weight-norm (1 launch) -> re-pack -> nrh_render_forward_train (samplers, SDF training forward, alpha, shadow march,
+    per-ray encodings) -> reflectance forward -> composite + loss + seeds (2) -> reflectance adjoint -> alpha adjoint (+ eikonal
+    seed) -> SDF tangent + value sweeps -> positional encoding rows -> ALL weight gradients in one split-K bf16x3 launch
+    (csrc/nrh_dw.hip) + its reduction -> d variance -> weight-norm adjoint (1)
+
+Restrictions (the autograd path covers the rest): GPU float32 parameters, normal_type NormalizedAnalytic, gradients for the
+parameters only (pose refinement needs the ray gradients: autograd path), at most ``max_fused_train_rays`` rays per call.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, dw, ops, packing
+
+LOSS_KEYS = ("loss", "rgb_loss", "eikonal_loss", "s_val", "psnr")
+
+
+def supported(renderer, ray_bundle) -> Optional[str]:
+    """None if the fused step applies, else the reason it does not."""
+    if renderer._normal_type != 0:
+        return "normal_type Analytic"
+    if any(t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
+        return "ray gradients requested (pose / light refinement)"
+    if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
+        return "more rays than max_fused_train_rays"
+    if ray_bundle.origins.shape[0] == 0:
+        return "empty batch"
+    ps = list(renderer.parameters())
+    if not all(p.is_cuda and p.dtype == torch.float32 for p in ps):
+        return "parameters must be float32 on the GPU"
+    if not all(p.requires_grad for p in ps):
+        return "frozen parameters"
+    return None
+
+
+class _Buffers:
+    """Per-(device, rays) arrays of a step, allocated once and reused (a captured graph bakes their addresses in)."""
+
+    def __init__(self, dev, n: int, hints: bool, shapes: Dict[str, tuple]):
+        T, P = 128, n * 128
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.n, self.dev = n, dev
+        mw = 128 if hints else 64
+        self.raymisc = torch.zeros(n, packing.RAYMISC_STRIDE, dtype=torch.float32, device=dev)
+        self.pts = new(P, 3)
+        self.color, self.save_h, self.save_misc = new(P, 3), new(4, P, 256), new(P, mw)
+        self.rgb, self.zbar4, self.wbar, self.partial, self.loss8 = new(n, 3), new(P, 3), new(n, T), new(n, 4), new(8)
+        self.czbar, self.fbar, self.mbar = new(4, P, 256), new(P, 256), new(P, mw)
+        self.sdf_bar, self.grad_bar, self.rd_bar, self.invs_bar = new(P), new(P, 3), new(n, 3), new(n)
+        self.emb = new(P, 64)
+        self.var_bar = new(1)
+        g = {}
+        for l in range(8):
+            g[f"dW{l}"], g[f"db{l}"] = new(*shapes[f"sdf_w{l}"]), new(*shapes[f"sdf_b{l}"])
+        g["ws"], g["bs"], g["Wf"], g["bf"] = new(1, 256), new(1), new(256, 256), new(256)
+        for l in range(5):
+            g[f"w{l}"], g[f"b{l}"] = new(*shapes[f"col_w{l}"]), new(*shapes[f"col_b{l}"])
+        self.g = g
+
+
+_BUF: Dict[tuple, _Buffers] = {}
+
+
+def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_rgb: Optional[torch.Tensor], global_step: int,
+                        igr_weight: Optional[float] = None, t_rand_primary=None, t_rand_shadow=None) -> torch.Tensor:
+    """Forward (training mode) + loss + backward of one batch.  Returns the loss vector [8] on the device
+    (``LOSS_KEYS`` = entries 0..4) and sets ``.grad`` of every renderer parameter (overwriting, like zero_grad + backward)."""
+    why = supported(renderer, ray_bundle)
+    if why is not None:
+        raise ValueError(f"fused training step not applicable: {why}")
+    lib = _lib.load()
+    P_ = _lib.ptr
+    cfg = renderer.config
+    igr = float(cfg.igr_weight if igr_weight is None else igr_weight)
+    f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
+    o, d, pl = f32(ray_bundle.origins), f32(ray_bundle.directions), f32(ray_bundle.pl_positions)
+    near, far = f32(ray_bundle.nears).reshape(-1), f32(ray_bundle.fars).reshape(-1)
+    dev, n = o.device, o.shape[0]
+    with torch.cuda.device(dev), torch.no_grad():
+        stream = _lib.stream_handle()
+        cos_anneal = min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0
+        zero_hints = 1 if global_step < cfg.geometry_warmup_end else 0
+        t_p = f32(t_rand_primary).reshape(-1) if t_rand_primary is not None else torch.rand(n, device=dev)
+        t_s = None
+        if not zero_hints and renderer._hints:
+            t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(n, 64, device=dev)
+        # ---- parameters: fold weight-norm (one launch), re-pack ----
+        named = dict(renderer.named_parameters())
+        gs = [named[k + ".weight_g"].detach() for k in packing._FOLD_LAYERS]
+        vs = [named[k + ".weight_v"].detach() for k in packing._FOLD_LAYERS]
+        ws = [torch.empty_like(v) for v in vs]
+        packing.WeightNormFoldHip._call("nrh_weight_norm_fold", vs, gs, ws)
+        dense = {}
+        for (wk, bk), k, w in zip(packing._FOLD_KEYS, packing._FOLD_LAYERS, ws):
+            dense[wk], dense[bk] = w, named[k + ".bias"].detach()
+        pk = renderer.packed_params(dev, dense=dense)
+        hints = bool(renderer._hints)
+        key = (str(dev), n, hints)
+        B = _BUF.get(key)
+        if B is None:
+            B = _BUF[key] = _Buffers(dev, n, hints, {k: tuple(v.shape) for k, v in dense.items()})
+        # ---- no-grad stages + SDF training forward (one C call) ----
+        res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc)
+        pre, sv = res["pre"], res["pre"]["saves"]
+        Pn = n * 128
+        # ---- reflectance forward ----
+        pts3 = B.pts.view(n, 128, 3)                       # p = o + d * t with separate roundings, as the SDF kernels form it
+        torch.mul(d[:, None, :], res["mid_z"][..., None], out=pts3)
+        pts3.add_(o[:, None, :])
+        cw = pk["col_w"]
+        _lib.check(lib.nrh_color_train_forward(pk["precision"], int(hints), P_(cw, cw.dtype), P_(pk["col_b"]), P_(pre["feat"]), P_(B.pts),
+                                               P_(res["nhat"].view(Pn, 3)), P_(B.raymisc), n, P_(B.color), P_(B.save_h), P_(B.save_misc),
+                                               stream), "nrh_color_train_forward")
+        # ---- composite, loss, adjoint seeds ----
+        bg = f32(background_rgb.to(dev)).reshape(-1) if background_rgb is not None else None
+        gt = f32(rgb_gt)
+        _lib.check(lib.nrh_composite_loss(P_(B.color), P_(res["weights"]), P_(gt), P_(bg), P_(res["normals"].view(Pn, 3)), P_(res["inside"]),
+                                          n, P_(B.rgb), P_(B.zbar4), P_(B.wbar), P_(B.partial), stream), "nrh_composite_loss")
+        dyn = renderer.dyn_scalars
+        inv_s = pk["inv_s"]
+        _lib.check(lib.nrh_loss_finish(P_(B.partial), n, float(inv_s), P_(dyn), igr, P_(B.loss8), stream), "nrh_loss_finish")
+        # ---- reflectance adjoint sweep ----
+        cwt = pk["col_wt"]
+        _lib.check(lib.nrh_color_train_backward(pk["precision"], int(hints), P_(cwt, cwt.dtype), P_(B.zbar4), P_(B.save_h), n, P_(B.czbar),
+                                                P_(B.fbar), P_(B.mbar), stream), "nrh_color_train_backward")
+        # ---- alpha stage adjoint (+ the eikonal seed; the unit normal's adjoint are columns 3..5 of mbar) ----
+        mw = B.mbar.shape[1]
+        nbar = ctypes.c_void_p(B.mbar.data_ptr() + 12)
+        _lib.check(lib.nrh_alpha_train_backward_fused(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), float(inv_s),
+                                                      float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, mw, P_(res["inside"]),
+                                                      ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
+                                                      P_(B.invs_bar), stream), "nrh_alpha_train_backward_fused")
+        _lib.check(lib.nrh_variance_grad(P_(B.invs_bar), n, float(inv_s), P_(dyn), P_(B.var_bar), stream), "nrh_variance_grad")
+        # ---- SDF network: tangent + value sweeps ----
+        r = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], o, d, res["mid_z"], 128, sv, B.sdf_bar, B.fbar, B.grad_bar)
+        _lib.check(lib.nrh_embedding_rows(P_(o), P_(d), P_(res["mid_z"]), 128, 128, n, P_(B.emb), stream), "nrh_embedding_rows")
+        # ---- every weight gradient: one split-K launch + its reduction ----
+        shapes = [tuple(dense[f"sdf_w{l}"].shape) for l in range(8)]
+        jobs = dw.sdf_jobs(shapes, sv["h"], sv["t"], r["zbar"], r["abar"], r["gebar"], B.emb, B.sdf_bar, B.fbar, B.g) + \
+            dw.color_jobs(hints, B.czbar, B.zbar4, B.save_h, pre["feat"], B.save_misc, B.g)
+        dw.run(jobs, Pn)
+        # ---- weight-norm adjoint -> .grad ----
+        g = B.g
+        wbars = [g[f"dW{l}"] for l in range(8)] + [g["ws"], g["Wf"]] + [g[f"w{l}"] for l in range(5)]
+        bbars = [g[f"db{l}"] for l in range(8)] + [g["bs"], g["bf"]] + [g[f"b{l}"] for l in range(5)]
+        vbars = [torch.empty_like(v) for v in vs]
+        gbars = [torch.empty_like(x) for x in gs]
+        packing.WeightNormFoldHip._call("nrh_weight_norm_fold_backward", vs, gs, wbars, vbars, gbars)
+        # (the bias / variance gradients ARE the persistent buffers: like backward() after zero_grad(), every call overwrites them)
+        for k, vb, gb, bb in zip(packing._FOLD_LAYERS, vbars, gbars, bbars):
+            named[k + ".weight_v"].grad, named[k + ".weight_g"].grad = vb, gb
+            named[k + ".bias"].grad = bb.view(named[k + ".bias"].shape)
+        named["deviation_network.variance"].grad = B.var_bar.view(())
+        return B.loss8
+
+
+def loss_dict(loss8: torch.Tensor) -> Dict[str, float]:
+    """One device-to-host copy -> the reference's loss dict (pipelines/base_pipeline.py:63-69) as python floats."""
+    return dict(zip(LOSS_KEYS, loss8[:5].tolist()))

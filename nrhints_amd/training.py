@@ -112,21 +112,31 @@ class FlatGradAllReduce:
 
 
 def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, optimizer, scheduler=None,
-               grad_sync: Optional[FlatGradAllReduce] = None) -> Dict[str, float]:
+               grad_sync: Optional[FlatGradAllReduce] = None, fused: Optional[bool] = None) -> Dict[str, float]:
     """One optimisation step (trainer/trainer.py:269-283): forward (training mode), loss, backward, gradient mean over
-    ranks, Adam, schedule.  Returns python floats of the loss dict (one host sync, as the reference's psnr .item())."""
-    out = renderer(ray_bundle, is_training=True, background_rgb=background_rgb, global_step=global_step)
-    losses = train_loss_dict(out, rgb_gt, renderer.config.igr_weight)
-    optimizer.zero_grad(set_to_none=True)
-    losses["loss"].backward()
+    ranks, Adam, schedule.  Returns python floats of the loss dict (one host sync, as the reference's psnr .item()).
+    ``fused``: forward + loss + backward as one fixed sequence of HIP launches without autograd (train_fused.py); None = use it
+    whenever it applies (renderer parameters only, no ray gradients), False = the autograd path."""
+    from . import train_fused
+    if fused is None:
+        fused = train_fused.supported(renderer, ray_bundle) is None
+    if fused:
+        optimizer.zero_grad(set_to_none=True)
+        loss8 = train_fused.train_step_backward(renderer, ray_bundle, rgb_gt, background_rgb, global_step)
+        keys, vec = list(train_fused.LOSS_KEYS), loss8[:5]
+    else:
+        out = renderer(ray_bundle, is_training=True, background_rgb=background_rgb, global_step=global_step)
+        losses = train_loss_dict(out, rgb_gt, renderer.config.igr_weight)
+        optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        keys = list(losses)
+        vec = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
     if grad_sync is not None:
         grad_sync()
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
-    keys = list(losses)
-    vals = torch.stack([losses[k].detach().float().reshape(()) for k in keys]).tolist()      # one device-to-host copy
-    return dict(zip(keys, vals))
+    return dict(zip(keys, vec.tolist()))      # one device-to-host copy
 
 
 class GraphedTrainStep:
@@ -148,13 +158,14 @@ class GraphedTrainStep:
     def __init__(self, renderer, batch_rays: int, background_rgb: torch.Tensor, lr: float = 5e-4, warm_up_end: int = 5_000,
                  end_iter: int = 1_000_000, lr_alpha: float = 0.05, global_step: int = 0,
                  grad_sync: Optional["FlatGradAllReduce"] = None, warmup_steps: int = 3,
-                 optimizer_state: Optional[Dict] = None, jitter: Optional[tuple] = None):
+                 optimizer_state: Optional[Dict] = None, jitter: Optional[tuple] = None, fused: Optional[bool] = None):
         """``jitter``: optional static buffers ``(t_rand_primary [n,1], t_rand_shadow [n,64])`` read by every replay instead
         of the device generator's draws (reproducible runs; the parity test against the eager step overwrites them)."""
         dev = next(renderer.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs the renderer on the GPU")
         self.renderer, self.grad_sync = renderer, grad_sync
+        self.fused = fused            # None: the autograd-free step of train_fused.py whenever it applies; False: autograd
         self.jitter = None if jitter is None else tuple(t.detach().to(dev, torch.float32).contiguous().clone() for t in jitter)
         self.sched_args = (warm_up_end, end_iter, lr_alpha)
         self.base_lr = lr
@@ -240,7 +251,19 @@ class GraphedTrainStep:
         flattening), "tail" (graph 2: unflatten + Adam)."""
         sync = self._sync_active()
         vec = None
-        if upto != "tail":
+        from . import train_fused
+        use_fused = (train_fused.supported(self.renderer, self.rays) is None) if self.fused is None else bool(self.fused)
+        if upto != "tail" and use_fused:
+            loss8 = train_fused.train_step_backward(
+                self.renderer, self.rays, self.gt, self.bg, self._capture_step,
+                t_rand_primary=None if self.jitter is None else self.jitter[0], t_rand_shadow=None if self.jitter is None else self.jitter[1])
+            self._keys = list(train_fused.LOSS_KEYS)
+            vec = loss8[:5]
+            if sync:
+                self.grad_sync.pack()
+            if upto == "pack":
+                return vec
+        elif upto != "tail":
             jit = {} if self.jitter is None else dict(_t_rand_primary=self.jitter[0], _t_rand_shadow=self.jitter[1])
             # The forward runs on fresh leaf ALIASES of the parameters (same storage) and the gradients come from
             # torch.autograd.grad.  A parameter's AccumulateGrad node is cached together with the stream it was first used on;

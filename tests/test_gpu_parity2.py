@@ -206,7 +206,7 @@ def test_graph_replay_equals_eager_step(scene_states):
     graphed = _model(scene_states["b"], train=True)
     before = {k: v.detach().clone() for k, v in graphed.state_dict().items()}
     step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs,
-                            jitter=(torch.zeros(n, 1), torch.zeros(n, 64)))
+                            jitter=(torch.zeros(n, 1), torch.zeros(n, 64)), fused=False)   # autograd path on both sides (fused: test_gpu_train_fused.py)
     for k, v in graphed.state_dict().items():       # capture (3 warm-up steps + graph build) leaves the model untouched
         assert torch.equal(v, before[k]), k
     for i, ((rb, gt), (tp, ts)) in enumerate(zip(batches, jit)):

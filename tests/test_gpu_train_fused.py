@@ -1,0 +1,285 @@
+"""GPU tests of the autograd-free training step (nrhints_amd/train_fused.py) and of its new kernels, each against an
+independent witness: the split-K bf16x3 weight-gradient GEMMs (csrc/nrh_dw.hip) against float64 products, the composite + loss +
+seed kernels against torch autograd of the reference's loss expressions, the extended alpha adjoint against autograd, and the
+whole step against the gradients the imported reference recorded (tests/golden/train_*.npz) and against the autograd path."""
+import numpy as np
+import pytest
+import torch
+
+import nrhints_amd as na
+from nrhints_amd import _lib, dw, train_fused
+from nrhints_amd.synthetic import make_rays
+from oracle import neus_oracle as orc
+from tests.conftest import grad_bound, load_npz
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def cu(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).float().contiguous().cuda()
+
+
+def _bundle(o, d, pl, near, far):
+    return na.RayBundle(origins=cu(o), directions=cu(d), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+
+
+def _model(state, prec="f16x3", cfg=None):
+    m = na.NeuSHintRenderer(cfg or na.NeuSModelConfig(), precision=prec)
+    m.load_state_dict({k: T(np.asarray(v)) for k, v in state.items()})
+    return m.cuda()
+
+
+def _wide_range(rs, P, C, scale):
+    """adjoint-like data: heavy-tailed per point and per channel (what an fp16 split could not hold without a per-tensor scale)"""
+    return (rs.randn(P, C) * np.exp(rs.randn(P, 1) * 2.0) * np.exp(rs.randn(1, C) * 1.5) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("P", [32, 2048, 131072 + 32 * 7])
+def test_dw_gemm_vs_float64(P):
+    """Every job shape of the training step in one nrh_dw_gemm call: two-pair full products, the 39-column layer-0 product, a
+    one-column product with a column sum, a row-limited and scaled product, column maps, the transposed 3-column product; against
+    float64 products of the same float32 data.  Error model of the bf16x3 split: operands rounded to 16 mantissa bits, products
+    exact, fp32 accumulation: |err| <= 2^-16 sum_p |a b| worst case, a few 1e-6 of the entry in practice (asserted: 3e-5 of
+    sum |a b|, and 3e-5 of the matrix scale)."""
+    rs = np.random.RandomState(P % 1000)
+    A1, A2 = cu(_wide_range(rs, P, 256, 1e-6)), cu(_wide_range(rs, P, 256, 1e-3))
+    B1 = cu(np.log1p(np.exp(rs.randn(P, 256).astype(np.float32) * 3)) * 0.1)          # activation-like
+    B2 = cu(_wide_range(rs, P, 256, 1e-4))
+    E, GE = cu(rs.randn(P, 64).astype(np.float32)), cu(_wide_range(rs, P, 64, 1e-5))
+    sb = cu(_wide_range(rs, P, 1, 1e-4)[:, 0])
+    M3 = cu(_wide_range(rs, P, 3, 1e-2))
+    misc = cu(rs.randn(P, 128).astype(np.float32))
+    new = lambda *s: torch.full(s, float("nan"), dtype=torch.float32, device="cuda")
+    out = dict(full=new(256, 256), bfull=new(256), l0=new(256, 39), bl0=new(256), rows=new(217, 256), brows=new(217), ws=new(1, 256), bs=new(1),
+               w0=new(256, 361), b0=new(256), w4=new(3, 256), b4=new(3))
+    fi, mi = dw.color_col_maps(torch.device("cuda"), True)
+    jobs = [dw.Job([A1, A2], [B1, B2], 256, 256, out["full"], colsum_a=out["bfull"]),
+            dw.Job([A1, A2], [E, GE], 256, 39, out["l0"], colsum_a=out["bl0"]),
+            dw.Job([A2], [B1], 256, 256, out["rows"], rows=217, scale=2.0 ** -0.5, colsum_a=out["brows"]),
+            dw.Job([B1, A2], [sb.reshape(P, 1), dw.ones(P, "cuda").reshape(P, 1)], 256, 1, out["ws"], transpose=True, scale=1.0 / 3.0,
+                   colsum_b=out["bs"], scale_b=1.0 / 3.0),
+            dw.Job([A1], [B1], 256, 256, out["w0"], col_map=fi, colsum_a=out["b0"]),
+            dw.Job([A1], [misc], 256, 105, out["w0"], col_map=mi),
+            dw.Job([B1], [M3], 256, 3, out["w4"], transpose=True, colsum_b=out["b4"])]
+    dw.run(jobs, P)
+    torch.cuda.synchronize()
+    d = lambda t: t.double().cpu()
+    a1, a2, b1, b2, e, ge, s_, m3, mc = (d(x) for x in (A1, A2, B1, B2, E, GE, sb, M3, misc))
+
+    def check(got, ref, absref, what):
+        err = (d(got) - ref).abs()
+        assert bool(torch.isfinite(d(got)).all()), what
+        assert float((err / (absref + 1e-300)).max()) < 3e-5, (what, float((err / (absref + 1e-300)).max()))
+        assert float(err.max()) < 3e-5 * float(ref.abs().max()), (what, float(err.max()), float(ref.abs().max()))
+
+    check(out["full"], a1.t() @ b1 + a2.t() @ b2, a1.abs().t() @ b1.abs() + a2.abs().t() @ b2.abs(), "two-pair product")
+    check(out["l0"], a1.t() @ e[:, :39] + a2.t() @ ge[:, :39], a1.abs().t() @ e[:, :39].abs() + a2.abs().t() @ ge[:, :39].abs(), "39 columns")
+    check(out["rows"], (a2.t() @ b1)[:217] * 2.0 ** -0.5, (a2.abs().t() @ b1.abs())[:217], "217 rows, scaled")
+    check(out["ws"], ((b1.t() @ s_[:, None] + a2.sum(0)[:, None]) / 3.0).t(), ((b1.abs().t() @ s_.abs()[:, None] + a2.abs().sum(0)[:, None]) / 3).t(), "head")
+    w0 = torch.zeros(256, 361, dtype=torch.float64)
+    w0[:, fi.cpu().long()] = a1.t() @ b1
+    w0[:, mi.cpu().long()] = a1.t() @ mc[:, :105]
+    w0a = torch.zeros(256, 361, dtype=torch.float64)
+    w0a[:, fi.cpu().long()] = a1.abs().t() @ b1.abs()
+    w0a[:, mi.cpu().long()] = a1.abs().t() @ mc[:, :105].abs()
+    check(out["w0"], w0, w0a, "column maps")
+    check(out["w4"], m3.t() @ b1, m3.abs().t() @ b1.abs(), "transposed 3 columns")
+    # column sums are plain fp32 sums in a fixed order
+    for got, ref, ab in ((out["bfull"], a1.sum(0), a1.abs().sum(0)), (out["brows"], a2.sum(0)[:217], a2.abs().sum(0)[:217]),
+                         (out["bs"], s_.sum(0, keepdim=True) / 3, s_.abs().sum(0, keepdim=True) / 3), (out["b4"], m3.sum(0), m3.abs().sum(0))):
+        assert float(((d(got) - ref).abs() / ab).max()) < 2e-6
+    # deterministic: the same call again gives the same bits
+    first = {k: v.clone() for k, v in out.items()}
+    dw.run(jobs, P)
+    for k in out:
+        assert torch.equal(first[k], out[k]), k
+
+
+def test_embedding_rows_vs_oracle():
+    lib = _lib.load()
+    n, npr = 37, 128
+    o, dd, pl, near, far = make_rays(n, seed=3, spread=0.1)
+    t = torch.rand(n, npr) * 2 + 2
+    rows = torch.empty(n * npr, 64, device="cuda")
+    P = _lib.ptr
+    o_, d_, t_ = cu(o), cu(dd), t.cuda()           # (kept alive: a temporary's memory would be handed to the next allocation)
+    _lib.check(lib.nrh_embedding_rows(P(o_), P(d_), P(t_), npr, npr, n, P(rows), _lib.stream_handle()), "emb")
+    torch.cuda.synchronize()
+    pts = (T(o)[:, None] + T(dd)[:, None] * t[..., None]).reshape(-1, 3)
+    want = orc.nerf_encode(pts.double() * 3.0, 6)
+    # sine of arguments up to 3 * 32 * |p| ~ 300: the float32 argument itself carries 300 * 2^-24 = 2e-5 of rounding
+    assert float((rows[:, :39].cpu().double() - want).abs().max()) < 3e-5
+    assert float((rows[:, :3].cpu().double() - want[:, :3]).abs().max()) < 2e-6      # the raw coordinates
+    assert float(rows[:, 39:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("bg_on", [True, False])
+def test_composite_loss_kernels_vs_autograd(bg_on):
+    """nrh_composite_loss + nrh_loss_finish against torch autograd (float64) of the reference's expressions:
+    rgb (:635-637), L1 colour loss / eikonal loss / psnr (pipelines/base_pipeline.py:57-69) and d loss / d (colour logits, weights)."""
+    lib = _lib.load()
+    rs = np.random.RandomState(2)
+    n, igr, inv_s = 203, 0.1, 437.0
+    col = rs.rand(n * 128, 3)
+    w = rs.rand(n, 128) * 0.02
+    gt = rs.rand(n, 3)
+    gt[3] = 0.25                                          # (an exact hit of the L1 kink is exercised through rgb == gt below)
+    nrm = rs.randn(n * 128, 3) * 0.8
+    ins = (rs.rand(n, 128) < 0.7).astype(np.float64)
+    bg = np.array([1.0, 0.5, 0.0])
+    t64 = lambda a, g=False: torch.tensor(a, dtype=torch.float64, requires_grad=g)
+    c_, w_, g_ = t64(col, True), t64(w, True), t64(nrm, True)
+    rgb = (c_.reshape(n, 128, 3) * w_[..., None]).sum(1)
+    if bg_on:
+        rgb = rgb + t64(bg) * (1.0 - w_.sum(-1, keepdim=True))
+    rgb_loss = (rgb - t64(gt)).abs().sum() / (n + 1e-5)
+    eik = (t64(ins) * (torch.linalg.norm(g_.reshape(n, 128, 3), dim=-1) - 1.0) ** 2).sum() / (t64(ins).sum() + 1e-5)
+    loss = rgb_loss + igr * eik
+    cb, wb, gb = torch.autograd.grad(loss, [c_, w_, g_])
+    f = lambda a: cu(np.asarray(a, dtype=np.float32))
+    new = lambda *s: torch.empty(*s, device="cuda")
+    o_rgb, zbar4, wbar, part, loss8 = new(n, 3), new(n * 128, 3), new(n, 128), new(n, 4), new(8)
+    P = _lib.ptr
+    col_, w_g, gt_, bg_, nrm_, ins_ = f(col), f(w), f(gt), f(bg), f(nrm), f(ins)      # kept alive across the calls
+    _lib.check(lib.nrh_composite_loss(P(col_), P(w_g), P(gt_), P(bg_) if bg_on else None, P(nrm_), P(ins_), n, P(o_rgb), P(zbar4),
+                                      P(wbar), P(part), _lib.stream_handle()), "composite_loss")
+    _lib.check(lib.nrh_loss_finish(P(part), n, inv_s, None, igr, P(loss8), _lib.stream_handle()), "loss_finish")
+    np.testing.assert_allclose(o_rgb.cpu().numpy(), rgb.detach().numpy(), rtol=0, atol=2e-6)
+    got = loss8.cpu().double().numpy()
+    np.testing.assert_allclose(got[0], loss.item(), rtol=2e-6)
+    np.testing.assert_allclose(got[1], rgb_loss.item(), rtol=2e-6)
+    np.testing.assert_allclose(got[2], eik.item(), rtol=2e-6)
+    np.testing.assert_allclose(got[3], 1.0 / inv_s, rtol=1e-6)
+    np.testing.assert_allclose(got[4], (10.0 * torch.log10(1.0 / ((rgb - t64(gt)) ** 2).mean())).item(), rtol=1e-5)
+    np.testing.assert_allclose(got[5], igr / (ins.sum() + 1e-5), rtol=1e-6)
+    # seeds: zbar4 = d loss / d (pre-sigmoid colour) = cbar c (1 - c); wbar = d loss / d w
+    np.testing.assert_allclose(zbar4.cpu().numpy(), (cb * c_.detach() * (1 - c_.detach())).numpy(), rtol=1e-5, atol=1e-10)   # values ~1e-5
+    np.testing.assert_allclose(wbar.cpu().numpy(), wb.numpy(), rtol=1e-4, atol=1e-9)
+    # the eikonal seed through the extended alpha adjoint: everything else zero
+    sdf = f(rs.uniform(-0.02, 0.05, size=(n, 128)))
+    dirs = rs.randn(n, 3); dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    dists = f(rs.uniform(0.002, 0.03, size=(n, 128)))
+    sb, gbar, rdb, ib = new(n * 128), new(n * 128, 3), new(n, 3), new(n)
+    zeros = torch.zeros(n, 128, device="cuda")
+    import ctypes
+    dirs_ = f(dirs)
+    _lib.check(lib.nrh_alpha_train_backward_fused(P(sdf), P(nrm_), P(dirs_), P(dists), inv_s, 1.0, None, n, P(zeros), None, 3, P(ins_),
+                                                  ctypes.c_void_p(loss8.data_ptr() + 20), P(sb), P(gbar), P(rdb), P(ib), _lib.stream_handle()),
+               "alpha_fused")
+    np.testing.assert_allclose(gbar.cpu().numpy(), gb.numpy(), rtol=2e-5, atol=1e-10)
+    assert float(sb.abs().max()) == 0.0
+
+
+def test_alpha_adjoint_strided_normal_bar():
+    """nhat_bar given as columns 3..5 of a [P,128] array (the reflectance adjoint's output) == the contiguous copy."""
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    n = 19
+    f = lambda a: cu(np.asarray(a, dtype=np.float32))
+    sdf, grad = f(rs.uniform(-0.02, 0.05, size=(n, 128))), f(rs.randn(n * 128, 3) * 0.7)
+    dirs = rs.randn(n, 3); dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    dists, wb = f(rs.uniform(0.002, 0.03, size=(n, 128))), f(rs.randn(n, 128))
+    mbar = f(rs.randn(n * 128, 128))
+    nb = mbar[:, 3:6].contiguous()
+    new = lambda *s: torch.empty(*s, device="cuda")
+    P = _lib.ptr
+    import ctypes
+    outs = []
+    dirs_ = f(dirs)
+    for ptr, stride in ((P(nb), 3), (ctypes.c_void_p(mbar.data_ptr() + 12), 128)):
+        o = [new(n * 128), new(n * 128, 3), new(n, 3), new(n)]
+        _lib.check(lib.nrh_alpha_train_backward_fused(P(sdf), P(grad), P(dirs_), P(dists), 300.0, 0.6, None, n, P(wb), ptr, stride, None, None,
+                                                      *(P(x) for x in o), _lib.stream_handle()), "alpha_fused")
+        outs.append(o)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_fused_step_gradients_vs_reference(scene_states, tag, prec):
+    """train_fused.train_step_backward against what the imported reference produced for the same batch and jitter
+    (tests/golden/train_*.npz): loss dict, and the gradient of every parameter tensor against the reference's float64 gradient within
+    the bound derived from the reference's own float32 noise (tests/conftest.py grad_bound)."""
+    g = load_npz(f"train_{tag}.npz")
+    model = _model(scene_states[tag], prec)
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    assert train_fused.supported(model, rb) is None
+    loss8 = train_fused.train_step_backward(model, rb, cu(g["rgb_gt"]), torch.ones(1, 3).cuda(), int(g["global_step"]),
+                                            t_rand_primary=cu(g["t_rand_primary"]), t_rand_shadow=cu(g["t_rand_shadow"]))
+    ld = train_fused.loss_dict(loss8)
+    np.testing.assert_allclose(ld["loss"], g["loss"], rtol=2e-4)
+    np.testing.assert_allclose(ld["rgb_loss"], g["rgb_loss"], rtol=2e-4)
+    np.testing.assert_allclose(ld["eikonal_loss"], g["eikonal_loss"], rtol=2e-3)
+    report = []
+    for name, prm in model.named_parameters():
+        assert prm.grad is not None and prm.grad.shape == prm.shape, name
+        tol, scale = grad_bound(g["grad." + name], g["grad64." + name])
+        err = float(np.abs(prm.grad.detach().cpu().numpy().astype(np.float64) - g["grad64." + name]).max())
+        report.append((err / tol, name, err / scale, tol / scale))
+    bad = [r for r in report if r[0] >= 1.0]
+    assert not bad, "gradient outside its derived bound (ratio, tensor, err/scale, bound/scale): " + repr(sorted(bad, reverse=True)[:8])
+
+
+def test_fused_step_equals_autograd_path(scene_states):
+    """Same batch, same jitter through the autograd Functions (forward + train_loss_dict + backward) and through the fused
+    sequence: same kernels for the sweeps and the weight gradients, so the results agree to fp32 round-off of the few
+    elementwise expressions that moved from torch into the composite / loss kernels."""
+    from nrhints_amd.training import train_loss_dict
+    n = 256
+    rs = np.random.RandomState(3)
+    rb = _bundle(*make_rays(n, seed=12, spread=0.1))
+    gt, tp, ts = (cu(rs.rand(n, k).astype(np.float32)) for k in (3, 1, 64))
+    bg = torch.ones(1, 3).cuda()
+    a, b = _model(scene_states["b"]), _model(scene_states["b"])
+    out = a(rb, is_training=True, background_rgb=bg, global_step=30000, _t_rand_primary=tp, _t_rand_shadow=ts)
+    la = train_loss_dict(out, gt, a.config.igr_weight)
+    la["loss"].backward()
+    loss8 = train_fused.train_step_backward(b, rb, gt, bg, 30000, t_rand_primary=tp, t_rand_shadow=ts)
+    lb = train_fused.loss_dict(loss8)
+    for k in ("loss", "rgb_loss", "eikonal_loss", "s_val", "psnr"):
+        np.testing.assert_allclose(lb[k], float(la[k]), rtol=5e-6, err_msg=k)
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pb.grad).abs().max()) / scale < 1e-4, (name, float((pa.grad - pb.grad).abs().max()) / scale)
+
+
+def test_fused_training_descends_and_graph_replays(scene_states):
+    """Eight fused optimisation steps on a fixed batch bring the loss down, every parameter moves; and a GraphedTrainStep over the
+    fused body replays bit-identically to eager fused steps with the same optimiser arithmetic."""
+    from nrhints_amd.training import GraphedTrainStep, lr_factor, make_optimizer, train_step
+    from nrhints_amd.synthetic import perturb_state
+    torch.manual_seed(0)
+    student = na.NeuSHintRenderer().cuda()
+    teacher = _model(scene_states["b"]).eval()
+    rb = _bundle(*make_rays(256, seed=5, spread=0.08))
+    bg = torch.ones(1, 3).cuda()
+    with torch.no_grad():
+        gt = teacher(rb, background_rgb=bg).rgb
+    before = {k: v.detach().clone() for k, v in student.named_parameters()}
+    opt, sched = make_optimizer(student, lr=1e-3, warm_up_end=1)
+    torch.manual_seed(1)
+    losses = [train_step(student, rb, gt, bg, 50_000, opt, sched, fused=True)["loss"] for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[1], losses
+    assert sum(not torch.equal(v.detach(), before[k]) for k, v in student.named_parameters()) == 46
+    # graph replay == eager, both fused
+    n, lr, gs = 128, 5e-4, 30000
+    rs = np.random.RandomState(5)
+    batches = [(_bundle(*make_rays(n, seed=40 + i, spread=0.1)), cu(rs.rand(n, 3).astype(np.float32))) for i in range(3)]
+    tp, ts = cu(rs.rand(n, 1).astype(np.float32)), cu(rs.rand(n, 64).astype(np.float32))
+    eager, graphed = _model(scene_states["b"]), _model(scene_states["b"])
+    lr_t = torch.tensor(lr, device="cuda")
+    opt = torch.optim.Adam([{"params": list(eager.parameters()), "lr": lr_t}], capturable=True)
+    step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs, jitter=(tp, ts), fused=True)
+    for i, (rb_i, gt_i) in enumerate(batches):
+        lr_t.fill_(lr * lr_factor(gs + i, 20, 1_000_000, 0.05))
+        opt.zero_grad(set_to_none=True)
+        l8 = train_fused.train_step_backward(eager, rb_i, gt_i, bg, gs + i, t_rand_primary=tp, t_rand_shadow=ts)
+        want = train_fused.loss_dict(l8)
+        opt.step()
+        got = step(rb_i, gt_i, global_step=gs + i)
+        assert got["loss"] == want["loss"], (i, got["loss"], want["loss"])
+        for (k, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+            assert torch.equal(pe.detach(), pg.detach()), (i, k)
+    step.release()

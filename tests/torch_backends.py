@@ -21,8 +21,56 @@ import torch
 import torch.nn.functional as F
 
 from nrhints_amd import autograd_core
-from nrhints_amd.autograd_core import _col_index, _enc, _linear
-from nrhints_amd.sdf_function import EMB, N_LAYERS, SKIP, _colsum, _enc_parts, _scatter_dims  # noqa: F401
+from nrhints_amd.autograd_core import _enc
+from nrhints_amd.sdf_function import EMB, N_LAYERS, SKIP, _enc_parts, _scatter_dims  # noqa: F401
+
+
+# ---- helpers of the torch formulations (test infrastructure: library GEMMs and torch reductions live here, not in the product) ----
+class _LinearBigK(torch.autograd.Function):
+    """F.linear whose weight gradient ([out x P] @ [P x in], P ~ 1e5 rows, tiny output) is computed as a batched GEMM
+    over S slabs of rows + a sum: the plain GEMM autograd would call launches ~32 workgroups on a 256-CU GPU."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        m = x.shape[0]
+        S = math.gcd(m, 64)
+        gw = torch.bmm(gy.reshape(S, m // S, -1).transpose(1, 2), x.reshape(S, m // S, -1)).sum(0)
+        return gy @ w, gw, gy.sum(0)
+
+
+def _linear(x, w, b):
+    return _LinearBigK.apply(x, w, b) if (x.is_cuda and x.shape[0] >= 4096) else F.linear(x, w, b)
+
+
+
+_COL_INDEX = {}
+
+
+def _col_index(device, hints: bool):
+    """Column indices of the per-ray and of the (pts, normal) blocks in the reference's reflectance input, per device."""
+    key = (str(device), hints)
+    if key not in _COL_INDEX:
+        cols = [torch.arange(3, 30), torch.arange(33, 60)] + ([torch.arange(316, 325), torch.arange(325, 361)] if hints else [])
+        _COL_INDEX[key] = (torch.cat(cols).to(device), torch.tensor([0, 1, 2, 30, 31, 32], device=device))
+    return _COL_INDEX[key]
+
+
+
+def _colsum(x3: torch.Tensor) -> torch.Tensor:
+    """[L,P,C] -> [L,C] column sums in two stages (64 slabs of rows first): the one-stage reduction of a [8,131072,256]
+    array ran at 1.6 TB/s."""
+    L, P, C = x3.shape
+    S = math.gcd(P, 64)
+    return x3.reshape(L, S, P // S, C).sum(2).sum(1)
+
+
 
 
 class SdfValueFeatGrad(torch.autograd.Function):
