@@ -443,8 +443,10 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
       float a = 0.0f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) a += xv[g][i];
-      if (g >> 1) sum1 = __builtin_fmaf(a, flag, sum1);
-      else sum0 = __builtin_fmaf(a, flag, sum0);
+      // (a select, not a multiplication by 0: past the end of the item the rows are stale LDS content, possibly NaN)
+      a = flag != 0.0f ? a : 0.0f;
+      if (g >> 1) sum1 += a;
+      else sum0 += a;
     }
   };
 
@@ -528,6 +530,52 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
   cs[c0 + 1] = sum1;
 }
 
+// ---- the thin path: products with at most four columns (the SDF head: h_7^T sbar + abar_7^T 1; the reflectance net's output layer
+// transposed: save_h_3^T zbar4) are matrix-VECTOR work - 256 x n multiply-adds per point against 1 KiB of A to read - so they run as
+// plain float32 FMAs straight from global memory, thread t = channel t of A, no LDS, no conversion (exact fp32 products).
+__device__ __forceinline__ void dw_item_thin(const JobDev& J, const int slab, const int nsteps_all, float* __restrict__ part,
+                                             float* __restrict__ csum) {
+  const int tid = threadIdx.x;
+  const int s0 = (int)((long long)nsteps_all * slab / J.slabs), s1 = (int)((long long)nsteps_all * (slab + 1) / J.slabs);
+  const int c = tid < J.m ? tid : J.m - 1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, sa = 0.0f, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int pair = 0; pair < J.npairs; ++pair) {
+    const int lda = J.lda[pair], ldb = J.ldb[pair], n = J.n;
+    const float* A = J.a[pair] + (size_t)s0 * KSTEP * lda + c;
+    const float* B = J.b[pair] + (size_t)s0 * KSTEP * ldb;
+    for (int s = s0; s < s1; ++s) {
+      float a[KSTEP];
+#pragma unroll
+      for (int i = 0; i < KSTEP; ++i) a[i] = __builtin_nontemporal_load(A + (size_t)i * lda);
+#pragma unroll
+      for (int i = 0; i < KSTEP; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = j < n ? B[i * ldb + j] : 0.0f;          // wave-uniform address: scalar loads
+          acc[j] = __builtin_fmaf(a[i], b, acc[j]);
+          if (pair == 0 && tid == 0) sb[j] += b;
+        }
+        if (pair == 0) sa += a[i];
+      }
+      A += (size_t)KSTEP * lda;
+      B += (size_t)KSTEP * ldb;
+    }
+  }
+  if (tid < J.m) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(size_t)tid * 256 + j] = acc[j];
+    csum[tid] = sa;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(size_t)tid * 256 + j] = 0.0f;
+    csum[tid] = 0.0f;
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) csum[256 + j] = sb[j];
+  }
+}
+
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dw_kernel(const DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int item = blockIdx.x;
@@ -541,6 +589,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   float* cs = a.csum + (size_t)item * CSUM_FLOATS;
   const bool full = J.m == 256 && J.n == 256 && J.lda[0] == 256 && J.ldb[0] == 256 && (J.npairs == 1 || (J.lda[1] == 256 && J.ldb[1] == 256));
   if (full) dw_item_fast(J, slab, a.nsteps, part, cs, smem);
+  else if (J.n <= 4) dw_item_thin(J, slab, a.nsteps, part, cs);
   else if (J.n <= 32) dw_item<1>(J, slab, a.nsteps, part, cs, smem);
   else if (J.n <= 64) dw_item<2>(J, slab, a.nsteps, part, cs, smem);
   else if (J.n <= 128) dw_item<4>(J, slab, a.nsteps, part, cs, smem);

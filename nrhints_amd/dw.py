@@ -43,6 +43,10 @@ class Job:
         nf = 1 if self.n <= 32 else 2 if self.n <= 64 else 4 if self.n <= 128 else 8
         # measured cycles per K step (profiles/r03/dw_phase_cycles.log): 3 300 on the fused fast path (full 256 x 256 operands),
         # 5 000 on the general path whatever the column count (the A operand's conversion dominates)
+        # 5 000 on the general path whatever the column count (the A operand's conversion dominates); products with <= 4 columns
+        # stream A once through plain FMAs (thin path)
+        if self.n <= 4:
+            return len(self.a) * 1.0       # (latency-bound per workgroup: it needs as many items as an MFMA job to fill the chip)
         full = self.m == 256 and self.n == 256
         return len(self.a) * (1.0 if full else 1.5)
 
