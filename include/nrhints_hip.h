@@ -365,6 +365,17 @@ int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const fl
  * models/neus_hint_model.py:104-110): variance_bar[0] = 10 inv_s sum(invs_bar) inside the clip range, else 0. */
 int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const float* dyn_scalars, float* variance_bar, void* stream);
 
+/* ---- re-packing of the kernel buffers after an optimiser step (one launch per buffer instead of ~70 framework ops) ------------
+ * nrh_pack_gather: out[e] = f(flat[index[e]]) for e < n over a fixed index plan (nrhints_amd/packing.py PackPlan, packing32.py
+ *   PackPlan32; index 0 addresses the constant 0.0 in front of the flattened weights): mode 0 float32 copy; mode 1 x = v / factor[e];
+ *   mode 2 x = v * factor[e]; modes 1, 2 write fp16 (hi, lo = (x - hi) * 2^11) as 512-element blocks [hi | lo] (n % 512 == 0).
+ *   Same roundings as the torch expressions of the packers: the result is bit-identical to them.
+ * nrh_sdf32_tables: packing32.sdf32_tables - the [11][256] bias / head tables of the wide SDF kernels from the eight bias vectors
+ *   (HOST array of 8 device pointers + their lengths), b_feat [256], b_s [1], w_s [256]. */
+int nrh_pack_gather(const float* flat, const int* index, const float* factor, long long n, int mode, void* out, void* stream);
+int nrh_sdf32_tables(const float* const* sdf_bias, const int* rows, const float* feat_b, const float* head_b, const float* head_w,
+                     float* tables, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,7 +275,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 126; }
+int nrh_version(void) { return 127; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -436,6 +436,30 @@ int nrh_weight_norm_fold(int nlayers, const int* rows, const int* cols, const fl
 int nrh_weight_norm_fold_backward(int nlayers, const int* rows, const int* cols, const float* const* v, const float* const* g,
                                   const float* const* wbar, float* const* vbar, float* const* gbar, void* stream) {
   return fold_launch(true, nlayers, rows, cols, v, g, nullptr, wbar, vbar, gbar, stream);
+}
+
+int nrh_pack_gather(const float* flat, const int* index, const float* factor, long long n, int mode, void* out, void* stream) {
+  if (!flat || !index || !out || (mode != 0 && !factor)) return fail(NRH_E_INVALID, "nrh_pack_gather: null pointer%s", "");
+  if (mode < 0 || mode > 2 || n < 0) return fail(NRH_E_INVALID, "nrh_pack_gather: mode must be 0, 1 or 2%s", "");
+  if (mode != 0 && (n & 511)) return fail(NRH_E_INVALID, "nrh_pack_gather: fp16 packs come in blocks of 512 elements%s", "");
+  if (n == 0) return NRH_OK;
+  nrh::PackGatherArgs a;
+  a.flat = flat; a.index = index; a.factor = factor; a.out = out; a.n = n; a.mode = mode;
+  hipLaunchKernelGGL(nrh::pack_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("pack_gather_kernel");
+}
+
+int nrh_sdf32_tables(const float* const* sdf_bias, const int* rows, const float* feat_b, const float* head_b, const float* head_w,
+                     float* tables, void* stream) {
+  if (!sdf_bias || !rows || !feat_b || !head_b || !head_w || !tables) return fail(NRH_E_INVALID, "nrh_sdf32_tables: null pointer%s", "");
+  nrh::TablesArgs a;
+  for (int l = 0; l < 8; ++l) {
+    if (!sdf_bias[l] || rows[l] < 1 || rows[l] > 256) return fail(NRH_E_INVALID, "nrh_sdf32_tables: bad bias row%s", "");
+    a.bias[l] = sdf_bias[l]; a.rows[l] = rows[l];
+  }
+  a.feat_b = feat_b; a.head_b = head_b; a.head_w = head_w; a.out = tables;
+  hipLaunchKernelGGL(nrh::sdf32_tables_kernel, dim3(11), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("sdf32_tables_kernel");
 }
 
 int nrh_color_train_forward(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,

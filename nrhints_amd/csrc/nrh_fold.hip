@@ -83,3 +83,63 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldArgs a) {
 }
 
 }  // namespace nrh
+
+// ---- re-packing after an optimiser step: the index plans of nrhints_amd/packing.py / packing32.py as ONE launch each -------------
+// A packed buffer is out[e] = f(flat[index[e]]) for a fixed index plan (element permutations, zero padding = index 0) with
+//   mode 0: float32 copy;  mode 1: x = flat[i] / factor[e];  mode 2: x = flat[i] * factor[e];  modes 1, 2: x -> fp16 hi + lo with
+//   lo = (x - hi) * 2^11, stored as 512-element blocks [hi 512 | lo 512] (the f16x3 kernels' stream layout).
+// Same roundings as the torch expressions they replace (round-to-nearest conversions, IEEE division): bit-identical packs.
+namespace nrh {
+
+struct PackGatherArgs {
+  const float* flat;
+  const int* index;
+  const float* factor;
+  void* out;
+  long long n;
+  int mode;
+};
+
+__global__ __launch_bounds__(256) void pack_gather_kernel(const PackGatherArgs a) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.n) return;
+  const float v = a.flat[a.index[e]];
+  if (a.mode == 0) {
+    reinterpret_cast<float*>(a.out)[e] = v;
+    return;
+  }
+  const float x = a.mode == 1 ? v / a.factor[e] : v * a.factor[e];
+  const _Float16 hi = (_Float16)x;
+  const _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+  _Float16* o = reinterpret_cast<_Float16*>(a.out) + (e >> 9) * 1024 + (e & 511);
+  o[0] = hi;
+  o[512] = lo;
+}
+
+// packing32.sdf32_tables: [11][256] float32 - rows 0..7 one packed fp16 pair (hi | lo * 2^11 << 16) of b_l * 100 / ln 2 per output
+// row (rows past the layer's size zero), row 8 the same of b_feat (unscaled), row 9 {b_s / 3, 0...}, row 10 w_s / 3
+struct TablesArgs {
+  const float* bias[8];
+  int rows[8];
+  const float* feat_b;
+  const float* head_b;
+  const float* head_w;
+  float* out;
+};
+__device__ __forceinline__ float pack_pair_f16(float x) {
+  const _Float16 hi = (_Float16)x;
+  const _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+  const uint32_t bits = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
+  return __builtin_bit_cast(float, bits);
+}
+__global__ __launch_bounds__(256) void sdf32_tables_kernel(const TablesArgs a) {
+  const int r = blockIdx.x, c = threadIdx.x;
+  float v;
+  if (r < 8) v = pack_pair_f16(c < a.rows[r] ? a.bias[r][c] * 144.26950408889634074f : 0.0f);
+  else if (r == 8) v = pack_pair_f16(a.feat_b[c]);
+  else if (r == 9) v = c == 0 ? a.head_b[0] / 3.0f : 0.0f;
+  else v = a.head_w[c] / 3.0f;
+  a.out[r * 256 + c] = v;
+}
+
+}  // namespace nrh

@@ -315,10 +315,33 @@ class PackPlan:
             all(tuple(dense[k].shape) == self.shapes[k] for k in self.shapes) and dense["sdf_w0"].device == self.w_index.device
 
     def pack(self, dense: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """-> dict(sdf_w, col_w, sdf_wt_feat, col_wt, sdf_b, col_b, sdf_head), identical (bit for bit) to the direct packers."""
+        """-> dict(sdf_w, col_w, sdf_wt_feat, col_wt, sdf_b, col_b, sdf_head), identical (bit for bit) to the direct packers.
+        On the GPU: one concatenation + two launches of nrh_pack_gather (csrc/nrh_fold.hip); the torch expressions below are
+        the host-side form of the same plan (CPU tests, and the definition the kernel is tested against)."""
         dev = self.w_index.device
         flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=dev)] +
                          [dense[k].detach().to(torch.float32).reshape(-1) for k in _W_KEYS + _B_KEYS])
+        if dev.type == "cuda":
+            from . import _lib
+            lib = _lib.load()
+            if getattr(self, "_w_index32", None) is None:
+                self._w_index32, self._v_index32 = self.w_index.to(torch.int32), self.v_index.to(torch.int32)
+            nw, nv = self.w_index.numel(), self.v_index.numel()
+            P = _lib.ptr
+            with torch.cuda.device(dev):
+                if self.precision == 0:
+                    packed, scale = flat[self.w_index] / self.w_div, 1      # exact-fp32 mode: plain float32 stages
+                else:
+                    packed = torch.empty(2 * nw, dtype=torch.float16, device=dev)
+                    _lib.check(lib.nrh_pack_gather(P(flat), P(self._w_index32, torch.int32), P(self.w_div), nw, 1, P(packed, torch.float16),
+                                                   _lib.stream_handle()), "nrh_pack_gather")
+                    scale = 2
+                vflat = torch.empty(nv, dtype=torch.float32, device=dev)
+                _lib.check(lib.nrh_pack_gather(P(flat), P(self._v_index32, torch.int32), None, nv, 0, P(vflat), _lib.stream_handle()),
+                           "nrh_pack_gather")
+            ws = torch.split(packed, [n * scale for n in self.w_sizes])
+            vs = torch.split(vflat, self.v_sizes)
+            return dict(sdf_w=ws[0], col_w=ws[1], sdf_wt_feat=ws[2], col_wt=ws[3], sdf_b=vs[0], col_b=vs[1], sdf_head=vs[2])
         x = flat[self.w_index] / self.w_div
         if self.precision == 0:
             packed, scale = x, 1

@@ -243,6 +243,26 @@ class PackPlan32:
         dev = self.index.device
         flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=dev)] +
                          [d[k].detach().to(torch.float32).reshape(-1) for k in _SDF32_KEYS])
+        if dev.type == "cuda":
+            # one launch for the streams, one for the tables (csrc/nrh_fold.hip); below: the same plan in torch ops (host side)
+            import ctypes
+            from . import _lib
+            lib = _lib.load()
+            if getattr(self, "_index32", None) is None:
+                self._index32 = self.index.to(torch.int32)
+            n = self.index.numel()
+            streams = torch.empty(2 * n, dtype=torch.float16, device=dev)
+            tables = torch.empty(NTAB, 256, dtype=torch.float32, device=dev)
+            P = _lib.ptr
+            f32c = lambda t: t.detach().to(torch.float32).contiguous()
+            bias = [f32c(d[f"sdf_b{l}"]) for l in range(8)]
+            fb, hb, hw = f32c(d["feat_b"]), f32c(d["sdf_head_b"]).reshape(-1), f32c(d["sdf_head_w"]).reshape(-1)
+            with torch.cuda.device(dev):
+                _lib.check(lib.nrh_pack_gather(P(flat), P(self._index32, torch.int32), P(self.scale), n, 2, P(streams, torch.float16),
+                                               _lib.stream_handle()), "nrh_pack_gather")
+                _lib.check(lib.nrh_sdf32_tables((ctypes.c_void_p * 8)(*[b.data_ptr() for b in bias]), (ctypes.c_int * 8)(*[b.numel() for b in bias]),
+                                                P(fb), P(hb), P(hw), P(tables), _lib.stream_handle()), "nrh_sdf32_tables")
+            return streams, tables
         hi, lo = split_f16(flat[self.index] * self.scale)
         streams = torch.stack([hi.reshape(-1, 512), lo.reshape(-1, 512)], dim=1).reshape(-1)
         return streams, sdf32_tables(d)

@@ -283,3 +283,23 @@ def test_fused_training_descends_and_graph_replays(scene_states):
         for (k, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
             assert torch.equal(pe.detach(), pg.detach()), (i, k)
     step.release()
+
+
+def test_pack_plans_on_gpu_bit_identical(scene_states):
+    """nrh_pack_gather / nrh_sdf32_tables (the re-pack of a training step as three launches) against the torch form of the same
+    index plans on the CPU: every packed buffer bit for bit (same conversions, same IEEE division)."""
+    from nrhints_amd import packing as pk, packing32 as pk32
+    st = {k: T(np.asarray(v)) for k, v in scene_states["b"].items()}
+    d_cpu = pk.dense_params(st)
+    d_gpu = {k: v.cuda() for k, v in d_cpu.items()}
+    for prec in (0, 1):
+        want = pk.PackPlan(d_cpu, prec, True).pack(d_cpu)
+        got = pk.PackPlan(d_gpu, prec, True).pack(d_gpu)
+        for k in want:
+            a, b = want[k], got[k].cpu()
+            assert a.dtype == b.dtype and torch.equal(a.view(torch.int16 if a.dtype == torch.float16 else torch.int32),
+                                                      b.view(torch.int16 if b.dtype == torch.float16 else torch.int32)), (prec, k)
+    ws, wt = pk32.PackPlan32(d_cpu).pack(d_cpu)
+    gs, gt = pk32.PackPlan32(d_gpu).pack(d_gpu)
+    assert torch.equal(ws.view(torch.int16), gs.cpu().view(torch.int16))
+    assert torch.equal(wt.view(torch.int32), gt.cpu().view(torch.int32))
