@@ -70,9 +70,10 @@ def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
     dev = jobs[0].a[0].device
     with torch.cuda.device(dev):
         if total_items is None:
-            # four work items per CU: the jobs' per-step costs differ by 2x and are only modelled roughly; short items level the
-            # tail (measured on the 1024-ray job table: 3.3 ms with one item per CU, 2.1 ms with four; profiles/r03/dw_bench_*.log)
-            total_items = 4 * max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
+            # three work items per CU: the jobs' per-step costs are only modelled roughly and short items level the tail, while
+            # every item costs 256 KiB of partial sums to write and reduce (measured on the 1024-ray job table: 1.70 / 2.05 / 1.56 /
+            # 1.58 ms with 1 / 2 / 3 / 4 items per CU; profiles/r03/dw_bench_items.log)
+            total_items = 3 * max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
         nsteps = npts // 32
         costs = [j.cost() for j in jobs]
         tot = sum(costs)

@@ -138,8 +138,21 @@ def stream_order(mode: int):
     return order
 
 
+_PLANS = {}
+
+
 def pack_sdf32(d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (streams: fp16 tensor holding the three mode streams back to back [mode 0 | mode 1 | mode 2], tables [11, 256])."""
+    """-> (streams: fp16 tensor holding the three mode streams back to back [mode 0 | mode 1 | mode 2], tables [11, 256]).
+    GPU tensors go through the index plan and its HIP launches (PackPlan32.pack), so that every stream set of a renderer - plain
+    and fused feature head - is packed by the same arithmetic: torch's float32 -> float16 conversion on the GPU does not round
+    the residuals' fp16 subnormals like the CPU's (and like nrh_pack_gather) - measured: renders with the two stream sets
+    stopped being bit-equal when only one of them came from torch ops."""
+    if d["sdf_w0"].is_cuda:
+        key = str(d["sdf_w0"].device)
+        plan = _PLANS.get(key)
+        if plan is None or not plan.matches(d):
+            plan = _PLANS[key] = PackPlan32(d)
+        return plan.pack(d)
     p = sdf32_pieces(d)
     streams = []
     for mode in range(3):
