@@ -806,6 +806,39 @@ long long nrh_render_workspace_floats(long long nrays) {
   return tot;
 }
 
+// The reference's sphere_trace (models/neus_hint_model.py:359-372): up to `iterations` rounds of "evaluate the SDF at every ray's
+// point, advance the rays that have not stopped".  The loop ends early when a round moved no ray; the flag is read back every
+// 4th round (one stream synchronisation each), so this call cannot be captured into a hipGraph.
+static int sphere_trace_impl(const NrhNet* net, const float* origins, const float* directions, long long n, int iterations,
+                             float threshold, float far_, float* pts, float* depth, float* sdf, float* zero_t, int* moved,
+                             hipStream_t st) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(NRH_E_UNSUPPORTED, "DepthComputationType.SphereTracing reads a flag back per few iterations and cannot be captured into a graph%s", "");
+  if (hipMemcpyAsync(pts, origins, sizeof(float) * 3 * n, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemsetAsync(depth, 0, sizeof(float) * n, st) != hipSuccess || hipMemsetAsync(zero_t, 0, sizeof(float) * n, st) != hipSuccess)
+    return fail(NRH_E_LAUNCH, "sphere trace: memset/memcpy failed%s", "");
+  nrh::TraceArgs a;
+  a.rd = directions; a.sdf = sdf; a.pts = pts; a.depth = depth; a.moved = moved; a.threshold = threshold; a.far_ = far_; a.nrays = (int)n;
+  for (int it = 0; it < iterations; ++it) {
+    int rc = sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, pts, directions, zero_t, 1, 1, n, sdf, 1, nullptr,
+                           nullptr, nullptr, st, WideNet{net->sdf_w32, net->sdf_tab32});
+    if (rc) return rc;
+    const bool probe = (it & 3) == 3 || it + 1 == iterations;
+    if (probe && hipMemsetAsync(moved, 0, sizeof(int), st) != hipSuccess) return fail(NRH_E_LAUNCH, "sphere trace: memset failed%s", "");
+    hipLaunchKernelGGL(nrh::sphere_trace_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    rc = check_launch("sphere_trace_step_kernel");
+    if (rc) return rc;
+    if (probe) {
+      int h = 1;
+      if (hipMemcpyAsync(&h, moved, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(NRH_E_LAUNCH, "sphere trace: flag read-back failed%s", "");
+      if (!h) break;
+    }
+  }
+  return NRH_OK;
+}
+
 static int render_forward_impl(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
                                const float* nears, const float* fars, long long nrays, const float* background,
                                float cos_anneal, const float* t_rand_primary, const float* t_rand_shadow, int zero_hints,
@@ -819,8 +852,8 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   if (net->precision < 0 || net->precision > 1)
     return fail(NRH_E_INVALID, "nrh_render_forward: net->precision must be 0 (f32) or 1 (f16x3)%s", "");
   if ((net->hints != 0 && net->hints != 1) || (net->normal_type != 0 && net->normal_type != 1) ||
-      (net->depth_type != 0 && net->depth_type != 1))
-    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type / depth_type must be 0 or 1%s", "");
+      net->depth_type < 0 || net->depth_type > 2)
+    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type must be 0 or 1, depth_type 0, 1 or 2%s", "");
   const int no_hints = zero_hints || !net->hints;  // no shadow march: geometry warm-up, or the pl-naive model
   if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || (!rgb && !train) || !workspace)
     return fail(NRH_E_INVALID, "nrh_render_forward: null pointer%s", "");
@@ -877,9 +910,20 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     c.tmid = o_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
     c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
     c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
-    c.dyn = net->dyn_scalars; c.hit = nullptr; c.hit_n = nullptr;
+    c.dyn = net->dyn_scalars; c.hit = nullptr; c.hit_n = nullptr; c.depth_in = nullptr; c.hit_in = nullptr;
+    if (net->depth_type == 2) {
+      // DepthComputationType.SphereTracing: the shadow-stage arrays are free until the core kernel has run
+      float* q = ws_grad_s;
+      float* st_pts = q; q += round64(3 * n);
+      float* st_depth = q; q += round64(n);
+      float* st_sdf = q; q += round64(n);
+      float* st_zero = q; q += round64(n);
+      rc = sphere_trace_impl(net, origins, directions, n, 2000, 1e-4f, 100.0f, st_pts, st_depth, st_sdf, st_zero, (int*)q, st);
+      if (rc) return rc;
+      c.depth_in = st_depth; c.hit_in = st_pts;
+    }
     c.zero_hints = no_hints;
-    c.depth_max_weight = net->depth_type;
+    c.depth_max_weight = net->depth_type == 1;
     c.nrays = (int)n;
     rc = launch_core_alpha(c, st);
     if (rc) return rc;

@@ -12,6 +12,36 @@ namespace nrh {
 constexpr int RAYS_PER_BLOCK = 4;
 
 // -------------------------------------------------------------------------------------------------
+// One iteration of the reference's sphere tracer (models/neus_hint_model.py:359-372) after the SDF has been evaluated at the
+// current points: rays with |sdf| < threshold or depth > far stay, the others advance by sdf along the ray.  A ray that has
+// stopped never moves again (its point, hence its sdf, no longer changes), so iterating past "all converged" changes nothing
+// and the host may test the flag only every few iterations.
+struct TraceArgs {
+  const float* rd;    // [N,3]
+  const float* sdf;   // [N] at pts
+  float* pts;         // [N,3] in/out
+  float* depth;       // [N] in/out
+  int* moved;         // device flag, set to 1 when any ray advanced
+  float threshold, far_;
+  int nrays;
+};
+
+__global__ __launch_bounds__(256) void sphere_trace_step_kernel(const TraceArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool adv = false;
+  if (i < a.nrays) {
+    const float s = a.sdf[i], dep = a.depth[i];
+    adv = !(fabsf(s) < a.threshold || dep > a.far_);
+    if (adv) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.pts[i * 3LL + c] = __fadd_rn(a.pts[i * 3LL + c], __fmul_rn(s, a.rd[i * 3LL + c]));  // pts + sdf * d, unfused
+      a.depth[i] = __fadd_rn(dep, s);
+    }
+  }
+  if (__any(adv) && lane_id() == 0) atomicOr(a.moved, 1);
+}
+
+// -------------------------------------------------------------------------------------------------
 // coarse z:  z_j = near + (far - near) * lin64[j]   (+ one jitter per ray in training)
 // -------------------------------------------------------------------------------------------------
 struct CoarseArgs {
@@ -225,6 +255,8 @@ struct CoreArgs {
   float* cue_b;         // [N,128,4] broadcast copy (RenderOutput.specular_cue) or null
   float* hit;           // [N,3] hit point o + d * depth (unit entry nrh_alpha_composite only) or null
   float* hit_n;         // [N,3] unit hit normal normalize(sum_j n_j w_j) (unit entry only) or null
+  const float* depth_in;  // [N] DepthComputationType.SphereTracing: depth and hit point come from the tracer (:527-528) ...
+  const float* hit_in;    // [N,3] ... instead of the compositing weights; both null otherwise
   float* srd;           // [N,3] shadow ray direction
   float* slast;         // [N] light distance / 64
   float* zs;            // [N,128] coarse shadow z (first 64)
@@ -280,7 +312,11 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
   const float hnz = wave_sum(nh[0][2] * w0 + nh[1][2] * w1);
 
   // ---- per-ray quantities (computed redundantly on all lanes; cheap) ----
-  const float hx = ox + dx * depth, hy = oy + dy * depth, hz = oz + dz * depth;  // hit point
+  float hx = ox + dx * depth, hy = oy + dy * depth, hz = oz + dz * depth;  // hit point
+  if (a.depth_in) {
+    depth = a.depth_in[ray];
+    hx = a.hit_in[ray * 3 + 0]; hy = a.hit_in[ray * 3 + 1]; hz = a.hit_in[ray * 3 + 2];
+  }
   const float plx = a.pl[ray * 3 + 0], ply = a.pl[ray * 3 + 1], plz = a.pl[ray * 3 + 2];
   const float hnn = fmaxf(sqrtf(hnx * hnx + hny * hny + hnz * hnz), 1e-12f);
   const float nx = hnx / hnn, ny = hny / hnn, nz = hnz / hnn;

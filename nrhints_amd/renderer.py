@@ -350,10 +350,11 @@ class NeuSHintRenderer(nn.Module):
         return float(torch.exp(v * 10.0).clip(1e-6, 1e6).item())
 
     def _render_chunks(self, o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints, want_samples: bool,
-                       want_maps: bool, want_mid: bool, use_dyn: bool = False):
+                       want_maps: bool, want_mid: bool, use_dyn: bool = False, want_ray_cue: bool = False):
         """Enqueue nrh_render_forward per chunk of rays; returns a dict of freshly allocated output tensors.
         want_samples: materialise the per-sample RenderOutput fields; want_maps: the per-pixel normal maps of the
-        evaluation loop; want_mid: section mid-points / lengths (for the autograd training path)."""
+        evaluation loop; want_mid: section mid-points / lengths (for the autograd training path); want_ray_cue: the
+        specular hint once per ray, [n,4] (the reference's [n,128,4] specular_cue is that row repeated per sample)."""
         lib = _lib.load()
         device = o.device
         n = o.shape[0]
@@ -376,6 +377,10 @@ class NeuSHintRenderer(nn.Module):
         if want_mid:
             out.update(mid_z=new(n, T), dists=new(n, T))
         chunk = max(1, min(self.max_chunk_rays if self.dyn_scalars is None else self.max_eval_rays_while_graphed, n))
+        cue_scratch = None
+        if want_ray_cue and not want_samples:
+            out.update(cue_ray=new(n, 4))
+            cue_scratch = new(chunk, T, 4)
         ws = self._workspace(device, chunk)
         stream = _lib.stream_handle()
         P = _lib.ptr
@@ -388,13 +393,19 @@ class NeuSHintRenderer(nn.Module):
                 P(t_rand_p[sl]) if t_rand_p is not None else None,
                 P(t_rand_s[sl]) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16),
                 P(out["rgb"][sl]), P(out["depth"][sl]), opt("weights", sl), opt("inside", sl), opt("normals", sl),
-                opt("nhat", sl), P(out["visibilities"][sl]), opt("cue", sl), opt("mid_z", sl), opt("dists", sl),
+                opt("nhat", sl), P(out["visibilities"][sl]), P(cue_scratch) if cue_scratch is not None else opt("cue", sl),
+                opt("mid_z", sl), opt("dists", sl),
                 opt("normal_map", sl), opt("normalized_normal_map", sl), P(ws), ws.numel(), stream)
             _lib.check(rc, "nrh_render_forward")
+            if cue_scratch is not None:
+                out["cue_ray"][sl] = cue_scratch[:m, 0, :]
+        if want_ray_cue and want_samples:
+            out["cue_ray"] = out["cue"][:, 0, :]
         return out
 
     @torch.no_grad()
-    def render_products(self, ray_bundle: RayBundle, background_rgb: Optional[torch.Tensor] = None):
+    def render_products(self, ray_bundle: RayBundle, background_rgb: Optional[torch.Tensor] = None,
+                        specular_cue: bool = False):
         """Evaluation fast path: per-PIXEL products only - rgb, depth, shadow map (visibilities) and the two weighted
         normal maps in world space - 15 floats per ray instead of the 1 669 of a full RenderOutput
         (what pipelines/base_pipeline.py:110-133 copies to the host per 512-ray chunk and reduces on the CPU)."""
@@ -406,7 +417,8 @@ class NeuSHintRenderer(nn.Module):
         with torch.cuda.device(o.device):
             return self._render_chunks(f32(o), f32(d), f32(pl), f32(ray_bundle.nears).reshape(-1),
                                        f32(ray_bundle.fars).reshape(-1), bg, 1.0, None, None, 0,
-                                       want_samples=False, want_maps=True, want_mid=False)
+                                       want_samples=False, want_maps=True, want_mid=False,
+                                       want_ray_cue=specular_cue and bool(self._hints))
 
     # ---------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -153,12 +153,22 @@ class GraphedTrainStep:
 
         step = GraphedTrainStep(renderer, batch_rays=512, background_rgb=bg, lr=5e-4)
         for it in range(...): losses = step(ray_bundle, rgb_gt, global_step=it)     # dict of python floats
+
+    With ``ray_generator`` the graph starts one stage earlier, at the data loader's ``RawPixelBundle`` (view index, pixel, pose,
+    light): ray generation and - when pose / light refinement is on - its adjoint are captured too, and Adam gets the reference's
+    SECOND parameter group (the ray generator's deltas at ``ray_lr``, trainer/trainer.py:99-102; both groups follow the same
+    warm-up / cosine factor, as ``LambdaLR`` scales every group).  The group exists even when the ray generator has no
+    parameters, so optimiser checkpoints have the reference's two-group layout either way.
+
+        step = GraphedTrainStep(renderer, 512, bg, ray_generator=rg, ray_lr=rg.config.opt_lr)
+        for it in range(...): losses = step(pixel_bundle, pixel_bundle.rgb_gt, global_step=it)
     """
 
     def __init__(self, renderer, batch_rays: int, background_rgb: torch.Tensor, lr: float = 5e-4, warm_up_end: int = 5_000,
                  end_iter: int = 1_000_000, lr_alpha: float = 0.05, global_step: int = 0,
                  grad_sync: Optional["FlatGradAllReduce"] = None, warmup_steps: int = 3,
-                 optimizer_state: Optional[Dict] = None, jitter: Optional[tuple] = None, fused: Optional[bool] = None):
+                 optimizer_state: Optional[Dict] = None, jitter: Optional[tuple] = None, fused: Optional[bool] = None,
+                 ray_generator: Optional[nn.Module] = None, ray_lr: float = 1e-4):
         """``jitter``: optional static buffers ``(t_rand_primary [n,1], t_rand_shadow [n,64])`` read by every replay instead
         of the device generator's draws (reproducible runs; the parity test against the eager step overwrites them)."""
         dev = next(renderer.parameters()).device
@@ -170,11 +180,20 @@ class GraphedTrainStep:
         self.sched_args = (warm_up_end, end_iter, lr_alpha)
         self.base_lr = lr
         self.lr_t = torch.tensor(lr, dtype=torch.float32, device=dev)
-        self.optimizer = torch.optim.Adam([{"params": list(renderer.parameters()), "lr": self.lr_t}], capturable=True)
+        self.ray_generator, self.base_ray_lr = ray_generator, ray_lr
+        self.ray_lr_t = torch.tensor(ray_lr, dtype=torch.float32, device=dev)
+        groups = [{"params": list(renderer.parameters()), "lr": self.lr_t}]
+        if ray_generator is not None:
+            groups.append({"params": list(ray_generator.parameters()), "lr": self.ray_lr_t})
+        self.optimizer = torch.optim.Adam(groups, capturable=True)
         n = batch_rays
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
-        from .containers import RayBundle
+        from .containers import RawPixelBundle, RayBundle
         self.rays = RayBundle(origins=z(n, 3), directions=z(n, 3), pl_positions=z(n, 3), nears=z(n, 1), fars=z(n, 1))
+        self.pixels = None
+        if ray_generator is not None:
+            self.pixels = RawPixelBundle(img_indices=torch.zeros(n, 1, dtype=torch.int64, device=dev), h_indices=z(n, 1),
+                                         w_indices=z(n, 1), poses=z(n, 4, 4), pls=z(n, 3), rgb_gt=None)
         self.gt = z(n, 3)
         self.bg = background_rgb.detach().to(dev, torch.float32).reshape(1, 3).clone()
         renderer.dyn_scalars = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -188,6 +207,17 @@ class GraphedTrainStep:
         mid = -(o * d).sum(1, keepdim=True)
         self.rays.nears.copy_(mid - 1.0); self.rays.fars.copy_(mid + 1.0)
         self.gt.fill_(0.5)
+        if self.pixels is not None:
+            # the same ring as pixels: the principal point of cameras that look at the origin (camera looks along its -z axis)
+            cam = ray_generator.camera
+            up0 = torch.tensor([0.0, 0.0, 1.0], device=dev).expand_as(d)
+            right = torch.nn.functional.normalize(torch.linalg.cross(d, up0), dim=1)
+            up = torch.linalg.cross(right, d)
+            self.pixels.poses[:, :3, 0], self.pixels.poses[:, :3, 1], self.pixels.poses[:, :3, 2] = right, up, -d
+            self.pixels.poses[:, :3, 3] = o
+            self.pixels.poses[:, 3, 3] = 1.0
+            self.pixels.h_indices.fill_(float(cam.cy) - 0.5); self.pixels.w_indices.fill_(float(cam.cx) - 0.5)
+            self.pixels.pls.copy_(o * 1.3)
         self._keys: List[str] = []
         # the workspace pointer is baked into the graph: make it large enough for any later evaluation render as well, so
         # that the renderer never replaces (frees) it while the graph is alive
@@ -195,7 +225,7 @@ class GraphedTrainStep:
         # Warm-up passes build every cache (pack plans, constants, Adam state tensors) eagerly.  They run real optimiser
         # steps on synthetic rays, so the parameters are put back and the Adam state is zeroed afterwards: capturing a
         # step must not change the model or what a resumed optimiser remembers.
-        params = list(renderer.parameters())
+        params = list(renderer.parameters()) + (list(ray_generator.parameters()) if ray_generator is not None else [])
         keep = [p.detach().clone() for p in params]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -242,6 +272,7 @@ class GraphedTrainStep:
         cos = min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0
         self.renderer.dyn_scalars[1:2].fill_(cos)
         self.lr_t.fill_(self.base_lr * lr_factor(global_step, *self.sched_args))
+        self.ray_lr_t.fill_(self.base_ray_lr * lr_factor(global_step, *self.sched_args))
 
     def _sync_active(self) -> bool:
         return self.grad_sync is not None and self.grad_sync._active()
@@ -252,10 +283,17 @@ class GraphedTrainStep:
         sync = self._sync_active()
         vec = None
         from . import train_fused
-        use_fused = (train_fused.supported(self.renderer, self.rays) is None) if self.fused is None else bool(self.fused)
+        rays, rg_live = self.rays, []
+        if upto != "tail" and self.ray_generator is not None:
+            # ray generation is part of the step: on aliases of the deltas for the same reason as the renderer's parameters below
+            rg_named = list(self.ray_generator.named_parameters())
+            rg_alias = {n: p.detach().requires_grad_(p.requires_grad) for n, p in rg_named}
+            rays = torch.func.functional_call(self.ray_generator, rg_alias, args=(self.pixels,))
+            rg_live = [(p, rg_alias[n]) for n, p in rg_named if p.requires_grad]
+        use_fused = (train_fused.supported(self.renderer, rays) is None) if self.fused is None else bool(self.fused)
         if upto != "tail" and use_fused:
             loss8 = train_fused.train_step_backward(
-                self.renderer, self.rays, self.gt, self.bg, self._capture_step,
+                self.renderer, rays, self.gt, self.bg, self._capture_step,
                 t_rand_primary=None if self.jitter is None else self.jitter[0], t_rand_shadow=None if self.jitter is None else self.jitter[1])
             self._keys = list(train_fused.LOSS_KEYS)
             vec = loss8[:5]
@@ -272,10 +310,10 @@ class GraphedTrainStep:
             # at capture end when an RCCL process group is alive (profiles/r02/rccl_graph_probe_before_fix.log).
             named = [(n, p) for n, p in self.renderer.named_parameters()]
             alias = {n: p.detach().requires_grad_(p.requires_grad) for n, p in named}
-            out = torch.func.functional_call(self.renderer, alias, args=(self.rays,),
+            out = torch.func.functional_call(self.renderer, alias, args=(rays,),
                                              kwargs=dict(is_training=True, background_rgb=self.bg, global_step=self._capture_step, **jit))
             losses = train_loss_dict(out, self.gt, self.renderer.config.igr_weight)
-            live = [(p, alias[n]) for n, p in named if p.requires_grad]
+            live = [(p, alias[n]) for n, p in named if p.requires_grad] + rg_live
             for (p, _), g in zip(live, torch.autograd.grad(losses["loss"], [a for _, a in live], allow_unused=True)):
                 p.grad = g
             self._keys = list(losses)
@@ -292,15 +330,29 @@ class GraphedTrainStep:
         return vec
 
     def __call__(self, ray_bundle, rgb_gt: torch.Tensor, global_step: int) -> Dict[str, float]:
+        """``ray_bundle``: a RayBundle, or - for a step built with ``ray_generator`` - the RawPixelBundle of the batch."""
         n = self.gt.shape[0]
-        if ray_bundle.origins.shape[0] != n:
-            raise ValueError(f"this graph was captured for {n} rays per step, got {ray_bundle.origins.shape[0]}")
         cfg = self.renderer.config
         if (global_step < cfg.geometry_warmup_end) != (self._capture_step < cfg.geometry_warmup_end):
             raise RuntimeError("geometry warm-up state changed since capture: create a new GraphedTrainStep")
-        for dst, src in ((self.rays.origins, ray_bundle.origins), (self.rays.directions, ray_bundle.directions),
-                         (self.rays.pl_positions, ray_bundle.pl_positions), (self.rays.nears, ray_bundle.nears),
-                         (self.rays.fars, ray_bundle.fars), (self.gt, rgb_gt)):
+        if self.pixels is not None:
+            pb = ray_bundle
+            if not hasattr(pb, "h_indices"):
+                raise TypeError("this step was built with a ray generator: pass the batch's RawPixelBundle")
+            if pb.h_indices.shape[0] != n:
+                raise ValueError(f"this graph was captured for {n} rays per step, got {pb.h_indices.shape[0]}")
+            if pb.img_indices is None:
+                raise ValueError("training pixels carry their view index (img_indices)")
+            pairs = ((self.pixels.img_indices, pb.img_indices), (self.pixels.h_indices, pb.h_indices),
+                     (self.pixels.w_indices, pb.w_indices), (self.pixels.poses, pb.poses), (self.pixels.pls, pb.pls),
+                     (self.gt, rgb_gt))
+        else:
+            if ray_bundle.origins.shape[0] != n:
+                raise ValueError(f"this graph was captured for {n} rays per step, got {ray_bundle.origins.shape[0]}")
+            pairs = ((self.rays.origins, ray_bundle.origins), (self.rays.directions, ray_bundle.directions),
+                     (self.rays.pl_positions, ray_bundle.pl_positions), (self.rays.nears, ray_bundle.nears),
+                     (self.rays.fars, ray_bundle.fars), (self.gt, rgb_gt))
+        for dst, src in pairs:
             dst.copy_(src.reshape(dst.shape), non_blocking=True)
         self._set_host_scalars(global_step)
         self.graph.replay()

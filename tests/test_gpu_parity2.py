@@ -386,3 +386,122 @@ def test_color_composite_entry_vs_reference(tag):
     for got, field in ((nm, g["analytic_normals"]), (nnm, g["nhat"].reshape(-1, 128, 3))):
         want = np.einsum("nij,ni,ni->nj", field.astype(np.float64), g["weights"].astype(np.float64), g["inside_sphere"].astype(np.float64))
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=5e-6 * max(1.0, float(np.abs(want).max())))
+
+
+def test_get_eval_dicts_vs_reference_fixture(scene_states):
+    """The evaluation loop's products against the dictionaries the reference's own ``get_eval_dicts`` returned for one 24 x 32
+    view of scene b (tests/golden/evaldict_b.npz, recorded by importing pipelines/base_pipeline.py:93-160): same keys, shapes and
+    dtypes; rgb / depth / shadow map / the two camera-space normal maps / the specular hint within the end-to-end render
+    tolerances of test_gpu_parity.py (the sampler places samples at fp32 noise); PSNR against the same ground truth; and the
+    uint8 images its trainer would write (trainer/trainer.py:343-352) equal up to one code value at pixels whose float value
+    sits on a code boundary."""
+    from nrhints_amd.pipeline import CameraModel, get_eval_dicts, to_uint8_images
+    fx = load_npz("evaldict_b.npz")
+    H, W, cx, cy, fxx, fyy = fx["camera"]
+    cam = CameraModel(H=int(H), W=int(W), cx=float(cx), cy=float(cy), fx=float(fxx), fy=float(fyy))
+    model = _model(scene_states["b"])
+    img, metrics, tensors = get_eval_dicts(model, cam, T(fx["pose"]), T(fx["pl"]), rgb_gt=T(fx["rgb_gt"]).cuda())
+    want_img = {k[4:]: v for k, v in fx.items() if k.startswith("img.")}
+    want_t = {k[7:]: v for k, v in fx.items() if k.startswith("tensor.")}
+    assert set(img) == set(want_img) and set(tensors) == set(want_t) and set(metrics) == {"psnr"}
+    for k, v in want_img.items():
+        assert img[k].shape == v.shape and img[k].dtype == v.dtype, k
+    for k, v in want_t.items():
+        assert tensors[k].shape == v.shape and tensors[k].dtype == v.dtype, k
+    tol = {"rgb": 1e-4, "shadow_map": 2e-3, "analytic_normals": 2e-3, "normalized_analytic_normals": 2e-3, "rgb_gt": 0.0}
+    for k, v in want_img.items():
+        err = float(np.abs(img[k].astype(np.float64) - v).max())
+        assert err <= tol[k], (k, err)
+    assert float(np.abs(tensors["depth"] - want_t["depth"]).max()) < 2e-3
+    assert float(np.abs(tensors["specular_hint"] - want_t["specular_hint"]).max()) < 2e-4
+    assert abs(metrics["psnr"] - float(fx["psnr"])) < 1e-4
+    u8 = to_uint8_images(img)
+    for k in want_img:
+        want = fx["u8." + k]
+        assert u8[k].shape == want.shape and u8[k].dtype == np.uint8, k
+        diff = np.abs(u8[k].astype(np.int32) - want.astype(np.int32))
+        assert int(diff.max()) <= 1 and float((diff > 0).mean()) < 0.02, (k, int(diff.max()), float((diff > 0).mean()))
+
+
+def _orbit_pixels(n, ncam, seed, H=48, W=64):
+    """A training batch as the data loader hands it over (data/data_loader.py:183-192): random pixels of ``ncam`` orbit cameras."""
+    from nrhints_amd import RawPixelBundle
+    rs = np.random.RandomState(seed)
+    az = np.linspace(0.2, 5.0, ncam)
+    poses = np.zeros((ncam, 4, 4), dtype=np.float32)
+    for i, a in enumerate(az):
+        pos = 3.6 * np.array([np.cos(0.4) * np.cos(a), np.cos(0.4) * np.sin(a), np.sin(0.4)])
+        fwd = -pos / np.linalg.norm(pos)
+        right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+        poses[i, :3, :3] = np.stack([right, np.cross(right, fwd), -fwd], axis=1)
+        poses[i, :3, 3], poses[i, 3, 3] = pos, 1.0
+    pls = (poses[:, :3, 3] * 1.2 + np.array([0.3, -0.2, 0.5])).astype(np.float32)
+    img = rs.randint(0, ncam, size=n)
+    return RawPixelBundle(img_indices=T(img[:, None]).long().cuda(), h_indices=cu(rs.randint(8, H - 8, size=(n, 1)).astype(np.float32)),
+                          w_indices=cu(rs.randint(8, W - 8, size=(n, 1)).astype(np.float32)), poses=cu(poses[img]), pls=cu(pls[img]),
+                          rgb_gt=cu(rs.rand(n, 3).astype(np.float32)))
+
+
+@pytest.mark.parametrize("refine", [True, False])
+def test_graph_with_ray_generator_group(scene_states, refine):
+    """GraphedTrainStep(ray_generator=...): the step starts at the RawPixelBundle, and Adam carries the reference's second parameter
+    group (trainer/trainer.py:99-102).  With pose + light refinement on (cam_opt_mode SO3xR3, pl_opt) the replay must equal
+    the eager sequence ray generator -> renderer -> loss -> backward -> two-group capturable Adam on the same batches and jitter:
+    losses, the deltas' gradients and values, the renderer's parameters - to the last bits on the first step; the ray generator's
+    adjoint scatters into the per-view deltas with atomics, so from the second step on the two runs differ by summation order
+    in the deltas' last bit, which the renderer amplifies (see test_graph_replay_equals_eager_step).  With refinement off the group is empty, the fused
+    autograd-free step runs inside the graph, and the optimiser state still has the two-group layout."""
+    from nrhints_amd import RayGenerator, RayGeneratorConfig
+    from nrhints_amd.pipeline import CameraModel
+    from nrhints_amd.training import GraphedTrainStep, lr_factor, train_loss_dict
+    n, ncam, lr, rlr, gs = 128, 3, 5e-4, 1e-3, 30000
+    cam = CameraModel(H=48, W=64, cx=32.0, cy=24.0, fx=150.0, fy=150.0)
+    cfg = RayGeneratorConfig(cam_opt_mode="SO3xR3", pl_opt=True) if refine else RayGeneratorConfig()
+    bg = torch.ones(1, 3).cuda()
+    rs = np.random.RandomState(9)
+    batches = [_orbit_pixels(n, ncam, 60 + i) for i in range(3)]
+    jit = [(cu(rs.rand(n, 1).astype(np.float32)), cu(rs.rand(n, 64).astype(np.float32))) for _ in range(3)]
+    eager, graphed = _model(scene_states["b"], train=True), _model(scene_states["b"], train=True)
+    rg_e, rg_g = RayGenerator(cam, ncam, cfg).cuda(), RayGenerator(cam, ncam, cfg).cuda()
+    if refine:
+        with torch.no_grad():
+            for rg in (rg_e, rg_g):
+                rg.cam_pose_adjustment.copy_(T(np.random.RandomState(1).randn(ncam, 6).astype(np.float32)) * 0.01)
+                rg.pl_adjustment.copy_(T(np.random.RandomState(2).randn(ncam, 3).astype(np.float32)) * 0.02)
+    lr_t, rlr_t = torch.tensor(lr, device="cuda"), torch.tensor(rlr, device="cuda")
+    opt = torch.optim.Adam([{"params": list(eager.parameters()), "lr": lr_t}, {"params": list(rg_e.parameters()), "lr": rlr_t}],
+                           capturable=True)
+    step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs, jitter=(torch.zeros(n, 1), torch.zeros(n, 64)),
+                            ray_generator=rg_g, ray_lr=rlr)
+    groups = step.optimizer.state_dict()["param_groups"]
+    assert len(groups) == 2 and len(groups[1]["params"]) == (2 if refine else 0)
+    for (k, a), (_, b) in zip(rg_g.named_parameters(), rg_e.named_parameters()):
+        assert torch.equal(a, b), k                                  # capture left the deltas untouched
+    with pytest.raises(TypeError):
+        step(_bundle(*make_rays(n, seed=1)), batches[0].rgb_gt, global_step=gs)
+    for i, (pb, (tp, ts)) in enumerate(zip(batches, jit)):
+        f = lr_factor(gs + i, 20, 1_000_000, 0.05)
+        lr_t.fill_(lr * f); rlr_t.fill_(rlr * f)
+        out = eager(rg_e(pb), is_training=True, background_rgb=bg, global_step=gs + i, _t_rand_primary=tp, _t_rand_shadow=ts)
+        ld = train_loss_dict(out, pb.rgb_gt, eager.config.igr_weight)
+        opt.zero_grad(set_to_none=True)
+        ld["loss"].backward()
+        opt.step()
+        step.jitter[0].copy_(tp); step.jitter[1].copy_(ts)
+        loss = step(pb, pb.rgb_gt, global_step=gs + i)["loss"]
+        want = float(ld["loss"].detach())
+        # refine: autograd path on both sides (bit-equal as test_graph_replay_equals_eager_step); off: fused step vs autograd
+        assert abs(loss - want) <= (1e-6 if refine and i == 0 else 2e-5) * abs(want), (i, loss, want)
+        assert abs(float(step.ray_lr_t) - rlr * f) < 1e-10
+        for (k, a), (_, b) in zip(rg_g.named_parameters(), rg_e.named_parameters()):
+            scale = float(b.grad.abs().max()) + 1e-30
+            assert float((a.grad - b.grad).abs().max()) <= (1e-6 if i == 0 else 5e-3) * scale, (i, k)
+            assert float((a.detach() - b.detach()).abs().max()) <= (2e-7 if i == 0 else 5e-6), (i, k)
+        if refine:
+            for (k, a), (_, b) in zip(graphed.named_parameters(), eager.named_parameters()):
+                assert float((a.detach() - b.detach()).abs().max()) <= (2e-7 if i == 0 else 5e-6), (i, k)
+    if refine:
+        assert float(rg_g.cam_pose_adjustment.grad.abs().max()) > 0 and float(rg_g.pl_adjustment.grad.abs().max()) > 0
+        moved = float((rg_g.pl_adjustment.detach() - T(np.random.RandomState(2).randn(ncam, 3).astype(np.float32)).cuda() * 0.02).abs().max())
+        assert moved > rlr
+    step.release()

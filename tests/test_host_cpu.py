@@ -340,3 +340,13 @@ def test_wide_kernel_isa_invariants(tmp_path):
     assert all(int(m) == 0 for m in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))
     chk = subprocess.run([sys.executable, os.path.join(csrc, "check_wide_isa.py"), out], capture_output=True, text=True)
     assert chk.returncode == 0, chk.stdout + chk.stderr
+
+
+def test_uint8_image_products_match_reference_fixture():
+    """``to_uint8_images`` on the reference's own float images reproduces the uint8 arrays recorded with them
+    (trainer/trainer.py:343-352 applied by make_golden_evaldict.py inside the reference process)."""
+    from nrhints_amd.pipeline import to_uint8_images
+    fx = load_npz("evaldict_b.npz")
+    got = to_uint8_images({k[4:]: v for k, v in fx.items() if k.startswith("img.")})
+    for k, v in got.items():
+        assert v.dtype == np.uint8 and np.array_equal(v, fx["u8." + k]), k
