@@ -196,7 +196,7 @@ typedef struct NrhNet {
   int hints;       /* 1 = shadow + specular hints (nr-hints presets); 0 = none (pl-naive preset, configs/main_config.py:67-76):
                       no shadow march, reflectance input 316 wide, col_w packed accordingly */
   int normal_type; /* 0 = NormalizedAnalytic, 1 = Analytic normal fed to the reflectance net (models/neus_hint_model.py:621-625) */
-  int depth_type;  /* 0 = AlphaBlend, 1 = MaximalWeightPoint (:528-538) */
+  int depth_type;  /* 0 = AlphaBlend, 1 = MaximalWeightPoint, 2 = SphereTracing (:526-538) */
   const float* dyn_scalars; /* optional DEVICE [inv_s, cos_anneal]: when non-null it overrides `inv_s` above and the `cos_anneal`
                                argument of the render calls, read by the kernels at run time - a captured hipGraph of a
                                training step then follows the changing variance parameter and anneal schedule */
@@ -303,6 +303,16 @@ int nrh_color_eval_wide(const void* col_w32, const float* col_tab32, const float
  *   (fields/reflectance_network.py:70-84; fields/encodings.py:168-174).  zero_hints != 0: visibility and cue are zero.
  * nrh_color_composite: rgb = sum_j c_j w_j + background (1 - sum_j w_j) (:635-637; background [3] or NULL) and, when asked
  *   for, the per-pixel normal maps sum_j n_j w_j inside_j of the evaluation loop (pipelines/base_pipeline.py:125-131). */
+long long nrh_sphere_trace_workspace_floats(long long nrays);
+/* NeuSHintRenderer.sphere_trace (models/neus_hint_model.py:359-372; what DepthComputationType.SphereTracing calls with
+ * iterations 2000, threshold 1e-4, far 100, :527-528): from the ray origins, every ray advances by the SDF at its point until
+ * |sdf| < threshold or its travelled depth exceeds far_depth.  Out: points [n,3], depths [n].  One SDF launch + one step kernel
+ * per iteration; the "a ray moved" flag is read back every 4th iteration (a stream synchronisation - not graph-capturable),
+ * and the loop ends at the first read-back that saw no movement (further iterations would change nothing).
+ * nrh_render_forward runs it by itself when NrhNet.depth_type == 2. */
+int nrh_sphere_trace(const NrhNet* net, const float* origins, const float* directions, long long nrays, int iterations,
+                     float threshold, float far_depth, float* points, float* depths, float* workspace, long long workspace_floats,
+                     void* stream);
 int nrh_alpha_composite(const float* origins, const float* directions, const float* pl_positions, const float* sdf, const float* grad,
                         const float* dists, const float* mid_z, float inv_s, float cos_anneal, int depth_type, int zero_hints,
                         const float* lin64, const float* t_rand_shadow, long long nrays, float* weights, float* inside_sphere,
@@ -364,6 +374,28 @@ int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const fl
 /* d loss / d variance from the per-ray partials of nrh_alpha_train_backward (inv_s = clip(exp(10 variance), 1e-6, 1e6),
  * models/neus_hint_model.py:104-110): variance_bar[0] = 10 inv_s sum(invs_bar) inside the clip range, else 0. */
 int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const float* dyn_scalars, float* variance_bar, void* stream);
+
+/* ---- the optimiser step (trainer/trainer.py:99-102, 281: torch.optim.Adam over two parameter groups) in one launch ------------
+ * Arithmetic and state layout of torch.optim.Adam's capturable implementation (float32 `step` scalar per tensor on the device,
+ * exp_avg `m`, exp_avg_sq `v`; no amsgrad / weight decay / maximize):
+ *   step += 1;  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;  a = -(lr / (1 - b1^step));
+ *   p += m / (sqrt(v) / (sqrt(1 - b2^step) a) + eps / a)
+ * tensors_dev: DEVICE array of `ntensors` descriptors; chunks_dev: DEVICE int pairs (tensor index, chunk index), one per block of
+ * 2048 elements, `nchunks` of them (sum over tensors of ceil(n / 2048)); per-group (`ngroups` <= 4) HOST arrays lr / beta1 /
+ * beta2 / eps, and optionally lr_dev: HOST array of device pointers to the group's learning rate (read at run time: hipGraph
+ * replays follow the schedule without re-capture), NULL entries fall back to lr[g]. */
+typedef struct NrhAdamTensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  float* step;
+  long long n;
+  int group;
+  int reserved;
+} NrhAdamTensor;
+int nrh_adam_step(const NrhAdamTensor* tensors_dev, int ntensors, const int* chunks_dev, int nchunks, int ngroups, const double* lr,
+                  const float* const* lr_dev, const double* beta1, const double* beta2, const double* eps, void* stream);
 
 /* ---- re-packing of the kernel buffers after an optimiser step (one launch per buffer instead of ~70 framework ops) ------------
  * nrh_pack_gather: out[e] = f(flat[index[e]]) for e < n over a fixed index plan (nrhints_amd/packing.py PackPlan, packing32.py

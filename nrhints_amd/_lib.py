@@ -23,9 +23,9 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
-            "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite",
+            "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite", "nrh_sphere_trace", "nrh_sphere_trace_workspace_floats",
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
-            "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables")
+            "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step")
 
 
 class NrhNet(Structure):
@@ -34,6 +34,11 @@ class NrhNet(Structure):
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
                 ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
                 ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int)]
+
+
+class NrhAdamTensor(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("step", c_void_p), ("n", c_longlong),
+                ("group", c_int), ("reserved", c_int)]
 
 
 class NrhTrainSaves(Structure):
@@ -100,6 +105,9 @@ def load():
     lib.nrh_color_wide_stream_bytes.restype = c_longlong
     lib.nrh_color_eval_wide.argtypes = [P, P, P, P, P, P, P, P, c_longlong, P, P]
     lib.nrh_alpha_composite.argtypes = [P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, P, P, c_longlong] + [P] * 12
+    lib.nrh_sphere_trace_workspace_floats.argtypes = [c_longlong]
+    lib.nrh_sphere_trace_workspace_floats.restype = c_longlong
+    lib.nrh_sphere_trace.argtypes = [POINTER(NrhNet), P, P, c_longlong, c_int, c_float, c_float, P, P, P, c_longlong, P]
     lib.nrh_visibility.argtypes = [P, P, P, P, P, P, P, c_float, c_float, c_int, c_longlong, P, P, P]
     lib.nrh_color_composite.argtypes = [P, P, P, P, P, P, P, c_longlong, P, P, P, P]
     lib.nrh_dw_workspace_floats.argtypes = [P, c_int]
@@ -110,6 +118,8 @@ def load():
     lib.nrh_loss_finish.argtypes = [P, c_longlong, c_float, P, c_float, P, P]
     lib.nrh_alpha_train_backward_fused.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, c_int, P, P, P, P, P, P, P]
     lib.nrh_variance_grad.argtypes = [P, c_longlong, c_float, P, P, P]
+    lib.nrh_adam_step.argtypes = [P, c_int, P, c_int, c_int, POINTER(ctypes.c_double), POINTER(c_void_p), POINTER(ctypes.c_double),
+                                  POINTER(ctypes.c_double), POINTER(ctypes.c_double), P]
     lib.nrh_pack_gather.argtypes = [P, P, P, c_longlong, c_int, P, P]
     lib.nrh_sdf32_tables.argtypes = [POINTER(c_void_p), POINTER(c_int), P, P, P, P, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]

@@ -1,0 +1,116 @@
+"""``torch.optim.Adam`` whose ``step()`` is ONE HIP launch over all parameter tensors (csrc/nrh_adam.hip, nrh_adam_step).
+
+The reference trains with ``torch.optim.Adam`` over two parameter groups (trainer/trainer.py:99-102, step at :281).  torch's
+capturable implementation spends ~100 small kernels per step on the renderer's 46 tensors (0.5 ms of a 7 ms step on MI355X,
+profiles/r03/train_graph_step_v1.txt); this subclass keeps the optimiser object - parameter groups, ``state_dict()`` layout
+(``step`` float32 scalar on the device, ``exp_avg``, ``exp_avg_sq``), ``load_state_dict``, LR schedulers - and replaces the
+arithmetic by one kernel with the same operation order.  The per-tensor descriptor table lives on the device and is rebuilt only
+when a pointer changes (never in steady state: the fused training step writes gradients into persistent buffers); when the
+gradients do move every step (the autograd path allocates them) the object falls back to torch's implementation for good -
+same state, same arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+CHUNK = 2048
+
+
+class HipAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, capturable=True, foreach=False)
+        if len(self.param_groups) > 4:
+            raise ValueError("HipAdam: at most 4 parameter groups")
+        self._key = None
+        self._table = self._chunks = None
+        self._keep: List[torch.Tensor] = []
+        self._counts = (0, 0)
+        self._rebuilt_last = False
+        self._torch_path = False     # gradients that move every step (autograd allocates them): torch's own implementation
+
+    def _entries(self):
+        ents = []
+        for gi, group in enumerate(self.param_groups):
+            if group.get("amsgrad") or group.get("weight_decay", 0) or group.get("maximize"):
+                raise ValueError("HipAdam implements plain Adam (no amsgrad / weight decay / maximize)")
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise ValueError("HipAdam: parameters must be contiguous float32 CUDA tensors")
+                if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == p.numel()):
+                    raise ValueError("HipAdam: gradients must be contiguous float32 CUDA tensors of the parameter's size")
+                st = self.state[p]
+                if len(st) == 0:       # torch.optim.Adam._init_group, capturable layout
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                ents.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
+                             p.numel(), gi))
+        return ents
+
+    def _upload(self, ents, dev) -> None:
+        n = len(ents)
+        tab = (_lib.NrhAdamTensor * max(n, 1))()
+        pairs = []
+        for i, (p, g, m, v, s, numel, gi) in enumerate(ents):
+            tab[i] = _lib.NrhAdamTensor(p, g, m, v, s, numel, gi, 0)
+            pairs += [(i, c) for c in range((numel + CHUNK - 1) // CHUNK)]
+        host_t = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone().pin_memory()
+        host_c = torch.tensor(pairs if pairs else [(0, 0)], dtype=torch.int32).reshape(-1).pin_memory()
+        # (pinned staging buffers stay alive with the device copies: a copy captured into a hipGraph re-reads them at every replay)
+        self._keep = [host_t, host_c]
+        self._table = host_t.to(dev, non_blocking=True)
+        self._chunks = host_c.to(dev, non_blocking=True)
+        self._counts = (n, len(pairs))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._torch_path:
+            return super().step()
+        ents = self._entries()
+        if not ents:
+            return loss
+        dev = next(p for g in self.param_groups for p in g["params"] if p.grad is not None).device
+        key = tuple(ents)
+        if key != self._key:
+            if self._rebuilt_last and self._key is not None and not torch.cuda.is_current_stream_capturing():
+                # second consecutive step with new addresses: a descriptor upload per step costs more than it saves
+                self._torch_path = True
+                return super().step()
+            self._upload(ents, dev)
+            self._key, self._rebuilt_last = key, True
+        else:
+            self._rebuilt_last = False
+        ng = len(self.param_groups)
+        D, VP = ctypes.c_double * ng, ctypes.c_void_p * ng
+        lr_val, lr_ptr = [], []
+        for group in self.param_groups:
+            lr = group["lr"]
+            if torch.is_tensor(lr):
+                if not (lr.is_cuda and lr.dtype == torch.float32):
+                    raise ValueError("HipAdam: a tensor learning rate must be a float32 CUDA scalar")
+                lr_val.append(0.0); lr_ptr.append(lr.data_ptr())
+            else:
+                lr_val.append(float(lr)); lr_ptr.append(None)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.nrh_adam_step(ctypes.c_void_p(self._table.data_ptr()), self._counts[0], ctypes.c_void_p(self._chunks.data_ptr()),
+                                   self._counts[1], ng, D(*lr_val), VP(*lr_ptr), D(*[float(g["betas"][0]) for g in self.param_groups]),
+                                   D(*[float(g["betas"][1]) for g in self.param_groups]), D(*[float(g["eps"]) for g in self.param_groups]),
+                                   _lib.stream_handle())
+        _lib.check(rc, "nrh_adam_step")
+        # the kernel wrote the parameters behind autograd's back: advance their version counters, as an in-place torch op would
+        # (the renderer's pack cache and autograd's saved-tensor checks key on them)
+        torch.autograd.graph.increment_version([p for g in self.param_groups for p in g["params"] if p.grad is not None])
+        return loss

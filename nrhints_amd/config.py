@@ -110,11 +110,16 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
         (r.n_shadow_samples == 64 and r.n_shadow_importance_samples == 64,
          "n_shadow_samples/n_shadow_importance_samples must be 64/64"),
         (r.n_shadow_importance_clip == -1, "only the hit-point shadow mode (n_shadow_importance_clip=-1) is implemented"),
-        (r.shadow_hint == r.specular_hint and not r.force_shadow_map and not r.force_specular_cue,
-         "shadow_hint and specular_hint must be both on (nr-hints) or both off (pl-naive); force_* dumps are not implemented"),
+        # force_* only adds the hint to has_*_hint (models/neus_hint_model.py:239-240): a no-op when the hint is on; with the hint
+        # off the reference itself cannot run - the reflectance net's first layer is sized for the hint (:246-250) but built
+        # without it (:256-257), so ReflectanceNetwork.forward never appends it (fields/reflectance_network.py:82-86) and lin0
+        # fails on the shape
+        (not (r.force_shadow_map and not r.shadow_hint),
+         "force_shadow_map without shadow_hint fails in the reference itself (reflectance lin0 is sized for a visibility input "
+         "that ReflectanceNetwork.forward never appends); enable shadow_hint"),
+        (not (r.force_specular_cue and not r.specular_hint),
+         "force_specular_cue without specular_hint fails in the reference itself (same lin0 shape mismatch); enable specular_hint"),
         (list(r.specular_roughness) == [0.02, 0.05, 0.13, 0.34], "specular_roughness must be the default 4 values"),
-        (r.depth_type in (DepthComputationType.AlphaBlend, DepthComputationType.MaximalWeightPoint),
-         "DepthComputationType.SphereTracing is not implemented"),
         (not r.shadow_hint_gradient and not r.specular_hint_gradient, "hint gradients are not implemented"),
         (abs(r.shadow_ray_offset - 1e-2) < 1e-12, "shadow_ray_offset must be 1e-2"),
     ]

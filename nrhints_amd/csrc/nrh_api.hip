@@ -8,6 +8,7 @@
 #include "nrh_fold.hip"
 #include "nrh_dw.hip"
 #include "nrh_train_fused.hip"
+#include "nrh_adam.hip"
 
 #include <stdio.h>
 #include <string.h>
@@ -275,7 +276,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 127; }
+int nrh_version(void) { return 129; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -982,7 +983,48 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   return NRH_OK;
 }
 
+// ---- Adam in one launch (csrc/nrh_adam.hip) ----
+int nrh_adam_step(const NrhAdamTensor* tensors_dev, int ntensors, const int* chunks_dev, int nchunks, int ngroups, const double* lr,
+                  const float* const* lr_dev, const double* beta1, const double* beta2, const double* eps, void* stream) {
+  static_assert(sizeof(NrhAdamTensor) == sizeof(nrhadam::Tensor), "NrhAdamTensor layout");
+  if (ntensors == 0 || nchunks == 0) return NRH_OK;
+  if (!tensors_dev || !chunks_dev || !lr || !beta1 || !beta2 || !eps || ntensors < 0 || nchunks < 0)
+    return fail(NRH_E_INVALID, "nrh_adam_step: null pointer / negative count%s", "");
+  if (ngroups < 1 || ngroups > nrhadam::MAX_GROUPS) return fail(NRH_E_INVALID, "nrh_adam_step: 1..4 parameter groups%s", "");
+  nrhadam::Args a;
+  memset(&a, 0, sizeof(a));
+  a.tensors = (const nrhadam::Tensor*)tensors_dev; a.chunks = chunks_dev; a.ntensors = ntensors;
+  for (int g = 0; g < ngroups; ++g) {
+    // scalars rounded to float32 as torch does with python floats (1 - beta in double first)
+    a.lr[g] = (float)lr[g]; a.lr_ptr[g] = lr_dev ? lr_dev[g] : nullptr; a.b1[g] = (float)beta1[g]; a.b2[g] = (float)beta2[g];
+    a.w1[g] = (float)(1.0 - beta1[g]); a.w2[g] = (float)(1.0 - beta2[g]); a.eps[g] = (float)eps[g];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(nrhadam::adam_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, a);
+  int rc = check_launch("adam_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(nrhadam::adam_bump_kernel, dim3((unsigned)((ntensors + 63) / 64)), dim3(64), 0, st, a.tensors, ntensors);
+  return check_launch("adam_bump_kernel");
+}
+
 // ---- unit entries of the evaluation render's per-ray stages (the kernels nrh_render_forward launches) ----
+long long nrh_sphere_trace_workspace_floats(long long nrays) { return nrays < 0 ? -1 : 2 * round64(nrays) + 64; }
+
+int nrh_sphere_trace(const NrhNet* net, const float* origins, const float* directions, long long nrays, int iterations,
+                     float threshold, float far_depth, float* points, float* depths, float* workspace, long long workspace_floats,
+                     void* stream) {
+  if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !origins || !directions || !points || !depths || !workspace)
+    return fail(NRH_E_INVALID, "nrh_sphere_trace: null pointer%s", "");
+  if (net->precision < 0 || net->precision > 1) return fail(NRH_E_INVALID, "nrh_sphere_trace: net->precision must be 0 or 1%s", "");
+  if (nrays < 0 || nrays > (1LL << 24) || iterations < 0) return fail(NRH_E_INVALID, "nrh_sphere_trace: nrays / iterations out of range%s", "");
+  if (workspace_floats < nrh_sphere_trace_workspace_floats(nrays)) return fail(NRH_E_WORKSPACE, "nrh_sphere_trace: workspace too small%s", "");
+  if (nrays == 0) return NRH_OK;
+  float* sdf = workspace;
+  float* zero_t = sdf + round64(nrays);
+  return sphere_trace_impl(net, origins, directions, nrays, iterations, threshold, far_depth, points, depths, sdf, zero_t,
+                           (int*)(zero_t + round64(nrays)), (hipStream_t)stream);
+}
+
 int nrh_alpha_composite(const float* origins, const float* directions, const float* pl_positions, const float* sdf, const float* grad,
                         const float* dists, const float* mid_z, float inv_s, float cos_anneal, int depth_type, int zero_hints,
                         const float* lin64, const float* t_rand_shadow, long long nrays, float* weights, float* inside_sphere,

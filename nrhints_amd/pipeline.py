@@ -95,14 +95,14 @@ def get_eval_dicts(renderer, camera: CameraModel, pose: torch.Tensor, pl: torch.
 
     View registration (``register_view``, the 500 Adam steps on the ray-generator deltas when camera / light refinement is on)
     is the caller's job - it is a training loop over `RayGenerator` parameters, see training.py."""
-    want_cue = specular_hint and bool(getattr(renderer, "_hints", 0))
+    want_cue = specular_hint and bool(getattr(renderer, "has_specular_hint", False))
     out = render_image(renderer, camera, pose, pl, white_background=white_background, rgb_gt=rgb_gt, specular_hint=want_cue)
     host = lambda t: t.detach().cpu().numpy()
     img = {"rgb": host(out["rgb"]), "analytic_normals": host(out["analytic_normals"]),
            "normalized_analytic_normals": host(out["normalized_analytic_normals"])}
     if rgb_gt is not None:
         img["rgb_gt"] = host(rgb_gt)
-    if getattr(renderer, "_hints", 0):
+    if getattr(renderer, "has_shadow_hint", False):
         img["shadow_map"] = host(out["shadow_map"])
     metrics = {"psnr": out["psnr"]} if rgb_gt is not None else {}
     tensors = {"depth": host(out["depth"])}

@@ -129,13 +129,17 @@ class NeuSHintRenderer(nn.Module):
         self.config = config
         self.has_shadow_hint = bool(config.renderer.shadow_hint)
         self.has_specular_hint = bool(config.renderer.specular_hint)
-        self._hints = 1 if self.has_shadow_hint else 0
+        # one hint without the other (shadow_hint != specular_hint) runs on the kernels of the full nr-hints model: the missing
+        # hint's columns of the reflectance net's first layer are zero (see _pad_hint_columns), its output is reported as None
+        self._hints = 1 if (self.has_shadow_hint or self.has_specular_hint) else 0
+        self._mixed_hints = self.has_shadow_hint != self.has_specular_hint
         self._normal_type = 1 if config.renderer.normal_type == NormalComputationType.Analytic else 0
-        self._depth_type = 1 if config.renderer.depth_type == DepthComputationType.MaximalWeightPoint else 0
+        self._depth_type = {DepthComputationType.AlphaBlend: 0, DepthComputationType.MaximalWeightPoint: 1,
+                            DepthComputationType.SphereTracing: 2}[config.renderer.depth_type]
         self.sdf_network = SDFNetwork(config.sdf_network)
         self.deviation_network = SingleVarianceNetwork(config.deviation_network.init_val)
         n_cue = len(config.renderer.specular_roughness) if self.has_specular_hint else 0
-        self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + self._hints + n_cue, 3,
+        self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + int(self.has_shadow_hint) + n_cue, 3,
                                                 config.reflectance_network, n_cue, self.has_shadow_hint)
         self._packed = None
         self._pack_plan = None
@@ -150,6 +154,19 @@ class NeuSHintRenderer(nn.Module):
         # advance tensor version counters)
         return (str(device), self.precision, getattr(self, "_generation", 0)) + tuple((id(p), p._version) for p in self.parameters())
 
+    def _pad_hint_columns(self, dense):
+        """Reflectance net with ONE hint (fields/reflectance_network.py:44-52: 316 + 9 visibility or + 36 cue input columns):
+        its first layer as the 361-column matrix of the two-hint layout, the missing hint's columns zero - the kernels then add
+        exact zeros for that hint.  Differentiable (plain cat), so the autograd training path sees the right gradient."""
+        if not self._mixed_hints:
+            return dense
+        w0 = dense["col_w0"]
+        if self.has_shadow_hint:       # [.., vis 9] -> [.., vis 9, cue 36 = 0]
+            w0 = torch.cat([w0, w0.new_zeros(w0.shape[0], 36)], dim=1)
+        else:                          # [.., cue 36] -> [.., vis 9 = 0, cue 36]
+            w0 = torch.cat([w0[:, :316], w0.new_zeros(w0.shape[0], 9), w0[:, 316:]], dim=1)
+        return dict(dense, col_w0=w0)
+
     def packed_params(self, device, dense=None):
         """Fold weight-norm and pack for the kernels; cached until a parameter changes.  ``dense``: the already folded
         matrices of the CURRENT parameters (the training forward folds them once, with autograd history)."""
@@ -162,7 +179,7 @@ class NeuSHintRenderer(nn.Module):
                 variance = self.deviation_network.variance.detach().to(device=device, dtype=torch.float32)
                 if dense is None:
                     state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
-                    d = packing.dense_params(state)
+                    d = self._pad_hint_columns(packing.dense_params(state))
                     packing.check_default_shapes(d, hints)
                     sw, sb, sh = packing.pack_sdf(d, prec)
                     cw, cb = packing.pack_color(d, prec, hints)
@@ -279,7 +296,7 @@ class NeuSHintRenderer(nn.Module):
             # fold weight-norm once, with autograd history; the kernels' packed copies are cut from the same matrices
             named = dict(self.named_parameters())
             on_gpu_f32 = all(p.is_cuda and p.dtype == torch.float32 for p in named.values())
-            dense = packing.dense_params_hip(named) if on_gpu_f32 else packing.dense_params(named)
+            dense = self._pad_hint_columns(packing.dense_params_hip(named) if on_gpu_f32 else packing.dense_params(named))
             self.packed_params(device, dense=dense)
         fused_train = needs_grad and n <= self.max_fused_train_rays
         if fused_train:
@@ -304,12 +321,13 @@ class NeuSHintRenderer(nn.Module):
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],
                                 normalized_analytic_normals=core["normalized_analytic_normals"],
-                                visibilities=vis if self._hints else None, specular_cue=cue if self._hints else None)
+                                visibilities=vis if self.has_shadow_hint else None,
+                                specular_cue=cue if self.has_specular_hint else None)
         s_val = torch.full((1, 1), 1.0 / self._host_inv_s(pk, device), dtype=torch.float32, device=device).expand(n, T)
         return RenderOutput(rgb=rgb, depth=depth, weights=weights, s_val=s_val, inside_sphere=inside,
                             relax_inside_sphere=inside, analytic_normals=normals,
-                            normalized_analytic_normals=nhat, visibilities=vis if self._hints else None,
-                            specular_cue=cue if self._hints else None)
+                            normalized_analytic_normals=nhat, visibilities=vis if self.has_shadow_hint else None,
+                            specular_cue=cue if self.has_specular_hint else None)
 
     # ---------------------------------------------------------------------------------------------
     def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None):
@@ -421,6 +439,29 @@ class NeuSHintRenderer(nn.Module):
                                        want_ray_cue=specular_cue and bool(self._hints))
 
     # ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sphere_trace(self, rays_o: torch.Tensor, rays_d: torch.Tensor, num_iterations: int, convergence_threshold: float,
+                     far: float):
+        """``NeuSHintRenderer.sphere_trace`` (models/neus_hint_model.py:359-372) -> (points [N,3], depths [N,1])."""
+        lib = _lib.load()
+        if not rays_o.is_cuda:
+            raise RuntimeError("NeuSHintRenderer.sphere_trace runs on the GPU only")
+        o = rays_o.detach().to(torch.float32).contiguous()
+        d = rays_d.detach().to(torch.float32).contiguous()
+        n, dev = o.shape[0], o.device
+        pk = self.packed_params(dev)
+        if self.dyn_scalars is not None:
+            pk = dict(pk, inv_s=self._host_inv_s(pk, dev))
+        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, None, wide=self.wide_kernels)
+        pts, depth = torch.empty(n, 3, dtype=torch.float32, device=dev), torch.empty(n, 1, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.nrh_sphere_trace_workspace_floats(n)), dtype=torch.float32, device=dev)
+        P = _lib.ptr
+        with torch.cuda.device(dev):
+            rc = lib.nrh_sphere_trace(net, P(o), P(d), n, int(num_iterations), float(convergence_threshold), float(far), P(pts), P(depth),
+                                      P(ws), ws.numel(), _lib.stream_handle())
+        _lib.check(rc, "nrh_sphere_trace")
+        return pts, depth
+
     @torch.no_grad()
     def sdf(self, pts: torch.Tensor) -> torch.Tensor:
         """SDF values at free points [P,3] -> [P,1] (SDFNetwork.sdf; used by extract_fields,

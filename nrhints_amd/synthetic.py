@@ -107,6 +107,16 @@ def naive_state(state: dict) -> dict:
     return out
 
 
+def one_hint_state(state: dict, shadow: bool) -> dict:
+    """State dict of a model with ONE hint (shadow_hint xor specular_hint), derived from a full nr-hints state: the other hint's
+    input columns of the first reflectance layer are dropped (fields/reflectance_network.py:44-52: [.., feature 316 | visibility
+    encoding 9 | cue encoding 36])."""
+    out = {k: np.array(v, copy=True) for k, v in state.items()}
+    v = out["color_network.lin0.weight_v"]
+    out["color_network.lin0.weight_v"] = (v[:, :325] if shadow else np.concatenate([v[:, :316], v[:, 325:]], axis=1)).copy()
+    return out
+
+
 def psnr(a, b) -> float:
     """10*log10(1/MSE), data range 1 (utils/metrics.py:8-9 via torchmetrics)."""
     a = np.asarray(a, dtype=np.float64)

@@ -30,6 +30,8 @@ def supported(renderer, ray_bundle) -> Optional[str]:
     """None if the fused step applies, else the reason it does not."""
     if renderer._normal_type != 0:
         return "normal_type Analytic"
+    if getattr(renderer, "_mixed_hints", False):
+        return "one hint without the other (zero-padded first reflectance layer)"
     if any(t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
         return "ray gradients requested (pose / light refinement)"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
@@ -67,9 +69,10 @@ class _Buffers:
         for l in range(5):
             g[f"w{l}"], g[f"b{l}"] = new(*shapes[f"col_w{l}"]), new(*shapes[f"col_b{l}"])
         self.g = g
-
-
-_BUF: Dict[tuple, _Buffers] = {}
+        # weight-norm gradients (what .grad of weight_v / weight_g points at): persistent like the bias gradients above, so that
+        # an optimiser working from a pointer table (adam.HipAdam) never sees a new address
+        self.vbars = {k: new(*s) for k, s in shapes.items() if k.startswith("v:")}
+        self.gbars = {k: new(*s) for k, s in shapes.items() if k.startswith("g:")}
 
 
 def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_rgb: Optional[torch.Tensor], global_step: int,
@@ -107,9 +110,13 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         pk = renderer.packed_params(dev, dense=dense)
         hints = bool(renderer._hints)
         key = (str(dev), n, hints)
-        B = _BUF.get(key)
+        cache = renderer.__dict__.setdefault("_fused_buffers", {})     # per renderer: .grad aliases these arrays
+        B = cache.get(key)
         if B is None:
-            B = _BUF[key] = _Buffers(dev, n, hints, {k: tuple(v.shape) for k, v in dense.items()})
+            shapes = {k: tuple(v.shape) for k, v in dense.items()}
+            shapes.update({"v:" + k: tuple(v.shape) for k, v in zip(packing._FOLD_LAYERS, vs)})
+            shapes.update({"g:" + k: tuple(x.shape) for k, x in zip(packing._FOLD_LAYERS, gs)})
+            B = cache[key] = _Buffers(dev, n, hints, shapes)
         # ---- no-grad stages + SDF training forward (one C call) ----
         res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc)
         pre, sv = res["pre"], res["pre"]["saves"]
@@ -154,8 +161,8 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         g = B.g
         wbars = [g[f"dW{l}"] for l in range(8)] + [g["ws"], g["Wf"]] + [g[f"w{l}"] for l in range(5)]
         bbars = [g[f"db{l}"] for l in range(8)] + [g["bs"], g["bf"]] + [g[f"b{l}"] for l in range(5)]
-        vbars = [torch.empty_like(v) for v in vs]
-        gbars = [torch.empty_like(x) for x in gs]
+        vbars = [B.vbars["v:" + k] for k in packing._FOLD_LAYERS]
+        gbars = [B.gbars["g:" + k] for k in packing._FOLD_LAYERS]
         packing.WeightNormFoldHip._call("nrh_weight_norm_fold_backward", vs, gs, wbars, vbars, gbars)
         # (the bias / variance gradients ARE the persistent buffers: like backward() after zero_grad(), every call overwrites them)
         for k, vb, gb, bb in zip(packing._FOLD_LAYERS, vbars, gbars, bbars):

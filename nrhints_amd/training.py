@@ -42,14 +42,23 @@ def lr_factor(step: int, warm_up_end: int = 5_000, end_iter: int = 1_000_000, lr
 
 
 def make_optimizer(renderer: nn.Module, extra_params: Optional[Iterable[nn.Parameter]] = None, lr: float = 5e-4,
-                   extra_lr: float = 1e-4, warm_up_end: int = 5_000, end_iter: int = 1_000_000, lr_alpha: float = 0.05):
-    """Adam + LambdaLR as the reference builds them (two groups: renderer, ray-generator deltas)."""
+                   extra_lr: float = 1e-4, warm_up_end: int = 5_000, end_iter: int = 1_000_000, lr_alpha: float = 0.05,
+                   hip: Optional[bool] = None):
+    """Adam + LambdaLR as the reference builds them (two groups: renderer, ray-generator deltas).  ``hip``: the optimiser step
+    as one HIP launch (adam.HipAdam: same state layout, same arithmetic as torch's capturable Adam); None = whenever the
+    renderer lives on the GPU."""
     groups = [{"params": list(renderer.parameters()), "lr": lr}]
     if extra_params is not None:
         # the reference ALWAYS builds the second group, also when the ray generator has no parameters (cam_opt_mode "off"):
         # pass ray_generator.parameters() so that checkpoints load in both directions (trainer/trainer.py:99-102)
         groups.append({"params": list(extra_params), "lr": extra_lr})
-    opt = torch.optim.Adam(groups)
+    if hip is None:
+        hip = all(p.is_cuda and p.dtype == torch.float32 for g in groups for p in g["params"]) and len(groups[0]["params"]) > 0
+    if hip:
+        from .adam import HipAdam
+        opt = HipAdam(groups)
+    else:
+        opt = torch.optim.Adam(groups)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: lr_factor(s, warm_up_end, end_iter, lr_alpha))
     return opt, sched
 
@@ -185,7 +194,6 @@ class GraphedTrainStep:
         groups = [{"params": list(renderer.parameters()), "lr": self.lr_t}]
         if ray_generator is not None:
             groups.append({"params": list(ray_generator.parameters()), "lr": self.ray_lr_t})
-        self.optimizer = torch.optim.Adam(groups, capturable=True)
         n = batch_rays
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
         from .containers import RawPixelBundle, RayBundle
@@ -195,6 +203,16 @@ class GraphedTrainStep:
             self.pixels = RawPixelBundle(img_indices=torch.zeros(n, 1, dtype=torch.int64, device=dev), h_indices=z(n, 1),
                                          w_indices=z(n, 1), poses=z(n, 4, 4), pls=z(n, 3), rgb_gt=None)
         self.gt = z(n, 3)
+        # the fused step's gradients live at fixed addresses: Adam as one launch (adam.HipAdam); the autograd path allocates its
+        # gradients per step and keeps torch's capturable Adam
+        from . import train_fused
+        refines = ray_generator is not None and any(p.requires_grad for p in ray_generator.parameters())
+        self._use_fused = (train_fused.supported(renderer, self.rays) is None and not refines) if fused is None else bool(fused)
+        if self._use_fused:
+            from .adam import HipAdam
+            self.optimizer = HipAdam(groups)
+        else:
+            self.optimizer = torch.optim.Adam(groups, capturable=True)
         self.bg = background_rgb.detach().to(dev, torch.float32).reshape(1, 3).clone()
         renderer.dyn_scalars = torch.zeros(2, dtype=torch.float32, device=dev)
         self._capture_step = global_step
@@ -290,7 +308,7 @@ class GraphedTrainStep:
             rg_alias = {n: p.detach().requires_grad_(p.requires_grad) for n, p in rg_named}
             rays = torch.func.functional_call(self.ray_generator, rg_alias, args=(self.pixels,))
             rg_live = [(p, rg_alias[n]) for n, p in rg_named if p.requires_grad]
-        use_fused = (train_fused.supported(self.renderer, rays) is None) if self.fused is None else bool(self.fused)
+        use_fused = self._use_fused
         if upto != "tail" and use_fused:
             loss8 = train_fused.train_step_backward(
                 self.renderer, rays, self.gt, self.bg, self._capture_step,

@@ -151,10 +151,12 @@ def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: boo
 
 def color_forward(p: OracleParams, pts, normals, view, feat, pls, vis=None, cue=None) -> torch.Tensor:
     """Reflectance MLP, input order [pts, enc4(view), normals, enc4(pl), feat, enc4(vis), enc4(cue)]
-    (fields/reflectance_network.py:68-96); vis / cue are absent for the pl-naive model (:83-86)."""
+    (fields/reflectance_network.py:68-96); vis / cue are absent for the pl-naive model, either one for a one-hint model (:83-86)."""
     parts = [pts, nerf_encode(view, 4), normals, nerf_encode(pls, 4), feat]
     if vis is not None:
-        parts += [nerf_encode(vis, 4), nerf_encode(cue, 4)]
+        parts.append(nerf_encode(vis, 4))
+    if cue is not None:
+        parts.append(nerf_encode(cue, 4))
     x = torch.cat(parts, dim=-1)
     for l in range(5):
         x = F.linear(x, p.col_w[l], p.col_b[l])
@@ -309,19 +311,38 @@ def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
     return torch.stack(out, dim=-1)
 
 
+def sphere_trace(p: OracleParams, o, d, iterations: int = 2000, threshold: float = 1e-4, far: float = 100.0):
+    """``NeuSHintRenderer.sphere_trace`` (models/neus_hint_model.py:359-372): from the ray origins, advance each ray by the SDF
+    at its point until |sdf| < threshold or the travelled depth exceeds ``far``; -> (points [N,3], depths [N,1])."""
+    pts, depths = o, torch.zeros(o.shape[0], 1, dtype=o.dtype)
+    with torch.no_grad():
+        for _ in range(iterations):
+            sdf = sdf_forward(p, pts, want_feat=False)[0]
+            conv = (sdf.abs() < threshold) | (depths > far)
+            pts = torch.where(conv, pts, pts + sdf * d)
+            depths = torch.where(conv, depths, depths + sdf)
+            if bool(conv.all()):
+                break
+    return pts, depths
+
+
 # --------------------------------------------------------------------------------------
 # the renderer
 # --------------------------------------------------------------------------------------
 def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is_training=False,
                    global_step=0, anneal_end=50_000, t_rand_primary=None, t_rand_shadow=None,
                    mode="minimal", keep_intermediates=False, differentiable=False, hints=True,
-                   analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0) -> Dict[str, torch.Tensor]:
+                   analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0,
+                   depth_sphere_tracing=False, shadow_hint=None, specular_hint=None) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
     n = o.shape[0]
     dt = o.dtype
     cos_anneal = 1.0
+    # ``hints`` switches both hints; shadow_hint / specular_hint override it one by one (config.renderer.shadow_hint / specular_hint)
+    shadow_hint = hints if shadow_hint is None else shadow_hint
+    specular_hint = hints if specular_hint is None else specular_hint
     warmup = bool(is_training and global_step < geometry_warmup_end)   # :668
     if is_training and anneal_end > 0:
         cos_anneal = min(1.0, global_step / anneal_end)       # :669-671
@@ -348,23 +369,27 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     weights = alpha * excl_cumprod_one_minus(alpha)            # :521-523
     wsum = weights.sum(-1, keepdim=True)
     with torch.no_grad():
-        if depth_max_weight:                                   # DepthComputationType.MaximalWeightPoint (:534-538)
+        if depth_sphere_tracing:                               # DepthComputationType.SphereTracing (:527-528)
+            hit, depth = sphere_trace(p, o, d, 2000, 1e-4, 100.0)
+        elif depth_max_weight:                                 # DepthComputationType.MaximalWeightPoint (:534-538)
             depth = torch.gather(mid, 1, torch.argmax(weights, dim=1, keepdim=True))
+            hit = o + d * depth
         else:
             depth = (mid * weights).sum(-1, keepdim=True)      # :531-533 (no_grad)
-        hit = o + d * depth
-        if hints and warmup:
+            hit = o + d * depth
+        if shadow_hint and warmup:
             vis = torch.zeros(n, 1, dtype=dt)                  # :577-579 (shadow_map = zeros)
         else:
             vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode) \
-                if hints else None                             # :546-551, :379
+                if shadow_hint else None                       # :546-551, :379
     n_hat = F.normalize(grad, dim=-1)                          # :584
     hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
     vis_s = cue_s = None
-    if hints:
+    if shadow_hint:
+        vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
+    if specular_hint:
         with torch.no_grad():
             cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :589-615 (no_grad), :617-619
-        vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
         cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
     col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :621-626
     rgb = (col * weights[..., None]).sum(1)
@@ -374,7 +399,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                inside_sphere=inside, relax_inside_sphere=inside,            # :745 (quirk kept)
                analytic_normals=grad.reshape(n, 128, 3),
                normalized_analytic_normals=n_hat.reshape(n, 128, 3),
-               visibilities=vis, specular_cue=cue_s.reshape(n, 128, 4) if hints else None)
+               visibilities=vis, specular_cue=cue_s.reshape(n, 128, 4) if specular_hint else None)
     if keep_intermediates:
         out.update(z_vals=z, mid_z=mid, sdf=sdf.reshape(n, 128), alpha=alpha, hit=hit, hit_normal=hit_n,
                    sampled_color=col, feat=feat)

@@ -3,6 +3,7 @@
 usage: python profiles/step_breakdown.py gpurun_out/prof_train_<tag>/train_kernel_trace.csv"""
 import collections, csv, sys
 
+DETAIL = len(sys.argv) > 2 and sys.argv[2] == "detail"
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "sdf_kernel<3" in r["Kernel_Name"]]
@@ -19,10 +20,14 @@ dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 
 
 def cat(name):
-    if "nrh::" in name:
+    if "nrh::" in name or "nrhdw::" in name or "nrhadam::" in name or "nrh32::" in name:
         return name.split("(")[0].replace("void ", "")[:44]
     if name.startswith("Cijk"):
         return "rocBLAS GEMM " + name[5:14] + " " + name[name.index("MT"):name.index("MT") + 12]
+    if DETAIL and "at::native" in name:
+        import re
+        f = re.findall(r"at::native::(?:\(anonymous namespace\)::)?(?:binary_internal::)?(\w+(?:Functor|Kernel|kernel|Copy\w*|Op)\w*)", name)
+        return "torch: " + "/".join(dict.fromkeys(f[-3:]))[:70] if f else "torch: " + name[:60]
     for key, label in (("reduce_kernel", "torch reduce"), ("elementwise", "torch elementwise"), ("vectorized", "torch elementwise"),
                        ("Cat", "torch cat"), ("copyBuffer", "memcpy/fill"), ("fillBuffer", "memcpy/fill"),
                        ("multi_tensor", "adam/foreach"), ("index", "torch index/scatter")):
@@ -38,5 +43,5 @@ for r in step:
     agg[k][1] += 1
 print(f"one training step: {len(step)} kernel launches, {sum(dur(r) for r in step) / 1e6:.3f} ms of kernel time")
 for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-    if t > 5000:
+    if t > 5000 or DETAIL:
         print(f"{t / 1e6:8.3f} ms {n:5d}  {k}")

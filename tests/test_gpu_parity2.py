@@ -13,7 +13,7 @@ import nrhints_amd as na
 from nrhints_amd import ops, packing as pk
 from nrhints_amd.synthetic import make_rays
 from oracle import neus_oracle as orc
-from tests.conftest import load_npz
+from tests.conftest import grad_bound, load_npz
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
@@ -505,3 +505,97 @@ def test_graph_with_ray_generator_group(scene_states, refine):
         moved = float((rg_g.pl_adjustment.detach() - T(np.random.RandomState(2).randn(ncam, 3).astype(np.float32)).cuda() * 0.02).abs().max())
         assert moved > rlr
     step.release()
+
+
+# ---- further off-default branches ---------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_sphere_tracing_depth(scene_states, prec):
+    """DepthComputationType.SphereTracing (models/neus_hint_model.py:359-372, :527-528) against the reference's recorded run: the
+    tracer on its own (nrh_sphere_trace through NeuSHintRenderer.sphere_trace) and the evaluation render whose hit points,
+    shadow rays and specular cue come from it.  Rays that hit agree to the convergence threshold's order (a ray may stop one
+    iteration apart when |sdf| sits at 1e-4); rays that miss run on to depth > 100 with ~50-long last steps, compared relatively."""
+    g = load_npz("render_branches_b.npz")
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    model = _model(scene_states["b"], prec, cfg=na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.SphereTracing)))
+    pts, dep = model.sphere_trace(rb.origins, rb.directions, 2000, 1e-4, 100.0)
+    want_d, want_p = g["st.trace_depths"], g["st.trace_pts"]
+    hit = want_d[:, 0] < 100.0
+    np.testing.assert_allclose(dep.cpu().numpy()[hit], want_d[hit], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(pts.cpu().numpy()[hit], want_p[hit], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(dep.cpu().numpy()[~hit], want_d[~hit], rtol=2e-3, atol=0)
+    assert bool((dep.cpu().numpy()[~hit] > 100.0).all())
+    # zero iterations: the origins, depth 0
+    p0, d0 = model.sphere_trace(rb.origins, rb.directions, 0, 1e-4, 100.0)
+    assert torch.equal(p0, rb.origins) and float(d0.abs().max()) == 0.0
+    with torch.no_grad():
+        out = model(rb, background_rgb=torch.ones(1, 3).cuda())
+    got_d = out.depth.cpu().numpy()
+    np.testing.assert_allclose(got_d[hit], g["st.depth"][hit], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(got_d[~hit], g["st.depth"][~hit], rtol=2e-3, atol=0)
+    # the hints are driven by the traced hit point: compare where the ray hit (a miss puts the "hit point" > 100 away, where the
+    # shadow ray's geometry amplifies the last-step difference)
+    np.testing.assert_allclose(out.visibilities.cpu().numpy()[hit], g["st.visibilities"][hit], rtol=0, atol=3e-3)
+    np.testing.assert_allclose(out.specular_cue.cpu().numpy()[hit], g["st.specular_cue"][hit], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(out.rgb.cpu().numpy()[hit], g["st.rgb"][hit], rtol=0, atol=1e-4)
+    assert np.abs(out.rgb.cpu().numpy() - g["st.rgb"]).max() < 2e-3
+    # training runs through the same C path (depth is not differentiated, :359); a captured graph refuses loudly
+    model.train()
+    o = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=1000)
+    o.rgb.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_one_hint_models_and_force_flags(scene_states, prec):
+    """shadow_hint without specular_hint and the reverse (the kernels of the two-hint model with the missing hint's first-layer
+    columns zero), and force_shadow_map / force_specular_cue: evaluation against the reference's recorded outputs, one training
+    step's loss and gradients against its float64 run with bounds derived from its own float32 run (conftest.grad_bound)."""
+    from nrhints_amd.synthetic import one_hint_state
+    from nrhints_amd.training import train_loss_dict
+    g = load_npz("render_branches_b.npz")
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    R, sb = na.NeuSRendererConfig, scene_states["b"]
+    cases = {"sho": (R(shadow_hint=True, specular_hint=False), one_hint_state(sb, True)),
+             "spo": (R(shadow_hint=False, specular_hint=True), one_hint_state(sb, False)),
+             "frc": (R(force_shadow_map=True, force_specular_cue=True), sb)}
+    bg = torch.ones(1, 3).cuda()
+    for vt, (rcfg, st) in cases.items():
+        model = _model(st, prec, cfg=na.NeuSModelConfig(renderer=rcfg))
+        with torch.no_grad():
+            out = model(rb, background_rgb=bg)
+        np.testing.assert_allclose(out.rgb.cpu().numpy(), g[f"{vt}.rgb"], rtol=0, atol=1e-4, err_msg=vt)
+        np.testing.assert_allclose(out.depth.cpu().numpy(), g[f"{vt}.depth"], rtol=0, atol=3e-4, err_msg=vt)
+        if vt == "spo":
+            assert out.visibilities is None
+        else:
+            np.testing.assert_allclose(out.visibilities.cpu().numpy(), g[f"{vt}.visibilities"], rtol=0, atol=3e-3, err_msg=vt)
+        if vt == "sho":
+            assert out.specular_cue is None
+        else:
+            np.testing.assert_allclose(out.specular_cue.cpu().numpy(), g[f"{vt}.specular_cue"], rtol=0, atol=3e-4, err_msg=vt)
+    for bad in (R(shadow_hint=False, specular_hint=False, force_shadow_map=True), R(shadow_hint=False, specular_hint=False, force_specular_cue=True)):
+        with pytest.raises(ValueError, match="fails in the reference itself"):     # recorded: RuntimeError on the lin0 shape
+            na.NeuSHintRenderer(na.NeuSModelConfig(renderer=bad))
+    assert str(g["force_shadow_only.outcome"]).startswith("RuntimeError")
+    # one training step per one-hint model
+    tb = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    for vt, shadow in (("sho", True), ("spo", False)):
+        rcfg, st = cases[vt]
+        model = _model(st, prec, cfg=na.NeuSModelConfig(renderer=rcfg), train=True)
+        out = model(tb, is_training=True, background_rgb=bg, global_step=int(g["t.global_step"]),
+                    _t_rand_primary=cu(g[f"{vt}.t_rand_primary"]), _t_rand_shadow=cu(g[f"{vt}.t_rand_shadow"]) if shadow else None)
+        np.testing.assert_allclose(out.rgb.detach().cpu().numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=1e-4)
+        ld = train_loss_dict(out, cu(g["t.rgb_gt"]), 0.1)
+        np.testing.assert_allclose(float(ld["loss"]), float(g[f"{vt}.loss"]), rtol=2e-4)
+        ld["loss"].backward()
+        named = dict(model.named_parameters())
+        keys = [k for k in g if k.startswith(f"{vt}.grad.") and ".rays." not in k]
+        assert len(keys) == 11
+        for k in keys:
+            name = k[len(vt) + 6:]
+            want64 = g[k.replace(".grad.", ".grad64.")]
+            bound, scale = grad_bound(g[k], want64, factor=4.0)      # 32 rays: one coarse draw of the reference's own noise
+            got = named[name].grad.detach().cpu().numpy().astype(np.float64)
+            assert got.shape == want64.shape, (vt, name)
+            err = float(np.abs(got - want64).max())
+            assert err <= bound, (vt, name, err, bound, scale)

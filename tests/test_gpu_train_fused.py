@@ -303,3 +303,54 @@ def test_pack_plans_on_gpu_bit_identical(scene_states):
     gs, gt = pk32.PackPlan32(d_gpu).pack(d_gpu)
     assert torch.equal(ws.view(torch.int16), gs.cpu().view(torch.int16))
     assert torch.equal(wt.view(torch.int32), gt.cpu().view(torch.int32))
+
+
+def test_hip_adam_equals_torch_capturable_adam():
+    """adam.HipAdam (nrh_adam_step: one launch for all tensors) against torch.optim.Adam(capturable=True) on the same parameters
+    and gradients over several steps, two parameter groups with different (tensor and float) learning rates: same state layout,
+    parameters / moments equal to a few ulp (the kernel follows torch's operation order; fma contraction may differ), and the
+    state dict loads into a plain torch Adam."""
+    from nrhints_amd.adam import HipAdam
+    rs = np.random.RandomState(0)
+    shapes = [(256, 39), (256, 1), (256,), (), (3, 256), (217, 256), (5000,)]
+    mk = lambda: [torch.nn.Parameter(cu(rs0.randn(*s).astype(np.float32) if s else np.float32(rs0.randn()))) for s in shapes]
+    rs0 = np.random.RandomState(1); pa = mk()
+    rs0 = np.random.RandomState(1); pb = mk()
+    lr_t = torch.tensor(5e-4, device="cuda")
+    ga = [{"params": pa[:5], "lr": lr_t}, {"params": pa[5:], "lr": 1e-3}]
+    gb = [{"params": pb[:5], "lr": lr_t}, {"params": pb[5:], "lr": 1e-3}]
+    hip, ref = HipAdam(ga), torch.optim.Adam(gb, capturable=True)
+    grads = [torch.empty_like(p) for p in pa]
+    for p, g in zip(pa, grads):
+        p.grad = g
+    for it in range(5):
+        lr_t.fill_(5e-4 * (it + 1) / 5)
+        for g, q in zip(grads, pb):
+            g.copy_(cu(rs.randn(*g.shape).astype(np.float32) if g.dim() else np.float32(rs.randn())) * (10.0 ** rs.randint(-6, 1)))
+            q.grad = g.clone()
+        hip.step(); ref.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            tol = 4e-7 * float(b.detach().abs().max()) + 1e-9
+            assert float((a.detach() - b.detach()).abs().max()) <= tol, (it, i)
+    assert not hip._torch_path                      # fixed gradient addresses: the one-launch path all along
+    sa, sb = hip.state_dict(), ref.state_dict()
+    assert sa["state"].keys() == sb["state"].keys() and len(sa["param_groups"]) == 2
+    for k in sa["state"]:
+        assert float(sa["state"][k]["step"]) == 5.0 == float(sb["state"][k]["step"])
+        for name in ("exp_avg", "exp_avg_sq"):
+            x, y = sa["state"][k][name], sb["state"][k][name]
+            assert float((x - y).abs().max()) <= 4e-7 * float(y.abs().max()) + 1e-30, (k, name)
+    torch.optim.Adam(gb, capturable=True).load_state_dict(sa)
+    # gradients that move every step: falls back to torch's implementation, results unchanged
+    hip2, ref2 = HipAdam([{"params": pa, "lr": 1e-3}]), torch.optim.Adam([{"params": pb, "lr": 1e-3}], capturable=True)
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            b.copy_(a)
+    for it in range(3):
+        for a, b in zip(pa, pb):
+            a.grad = torch.randn_like(a)
+            b.grad = a.grad.clone()
+        hip2.step(); ref2.step()
+    assert hip2._torch_path
+    for a, b in zip(pa, pb):
+        assert float((a.detach() - b.detach()).abs().max()) <= 4e-7 * float(b.detach().abs().max()) + 1e-9

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 127
+    assert lib.nrh_version() == 129
     lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
     from nrhints_amd import packing32 as pk32
     assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
@@ -57,10 +57,10 @@ def test_unsupported_configs_are_rejected():
     bad = [
         na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=64)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True)),
-        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=True, specular_hint=False)),
-        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(force_shadow_map=True)),
+        # force_* without the hint: the reference itself fails (tests/golden/render_branches_b.npz records its RuntimeError)
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False, force_shadow_map=True)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=True, specular_hint=False, force_specular_cue=True)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=8)),
-        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.SphereTracing)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_importance_samples=32)),
     ]
     for cfg in bad:
@@ -73,6 +73,17 @@ def test_unsupported_configs_are_rejected():
     assert naive.color_network.lin0.weight_v.shape == (256, 316) and sum(p.numel() for p in naive.parameters()) == 820_923 - 256 * 45
     na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(normal_type=na.NormalComputationType.Analytic)))
     na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.MaximalWeightPoint)))
+    na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.SphereTracing)))
+    na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(force_shadow_map=True, force_specular_cue=True)))
+    # one hint without the other: the reference's layer shapes (fields/reflectance_network.py:44-52)
+    sho = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=True, specular_hint=False)))
+    spo = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=True)))
+    assert sho.color_network.lin0.weight_v.shape == (256, 325) and spo.color_network.lin0.weight_v.shape == (256, 352)
+    full = {k: torch.randn(256, 361) for k in ("col_w0",)}
+    assert sho._pad_hint_columns({"col_w0": full["col_w0"][:, :325]})["col_w0"].shape == (256, 361)
+    padded = spo._pad_hint_columns({"col_w0": torch.cat([full["col_w0"][:, :316], full["col_w0"][:, 325:]], dim=1)})["col_w0"]
+    assert torch.equal(padded[:, :316], full["col_w0"][:, :316]) and torch.equal(padded[:, 325:], full["col_w0"][:, 325:])
+    assert float(padded[:, 316:325].abs().max()) == 0.0
 
 
 def test_no_cpu_fallback():

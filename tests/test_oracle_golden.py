@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import neus_oracle as orc
-from tests.conftest import load_npz
+from tests.conftest import grad_bound, load_npz
 from nrhints_amd.synthetic import psnr
 
 T = torch.from_numpy
@@ -233,3 +233,59 @@ def test_core_intermediates_vs_reference(tag):
     rgb = (Tn(g["sampled_color"]) * Tn(g["weights"])[..., None]).sum(1)
     np.testing.assert_allclose((rgb + 1.0 - Tn(g["weights"]).sum(-1, keepdim=True)).numpy(), g["rgb"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(rgb.numpy(), g["rgb_bg0"], rtol=0, atol=1e-6)
+
+
+def test_more_off_default_branches(scene_states):
+    """SphereTracing depth, one hint without the other, force_* flags - the oracle vs the reference's recorded outputs
+    (tests/golden/render_branches_b.npz, make_golden_branches.py)."""
+    from nrhints_amd.synthetic import one_hint_state
+    g = load_npz("render_branches_b.npz")
+    rays = [T(g[k]) for k in ("o", "d", "pl", "near", "far")]
+    sb = scene_states["b"]
+    # the tracer on its own: same trajectory in the same arithmetic
+    pts, dep = orc.sphere_trace(orc.params_from_state(sb), rays[0], rays[1], 2000, 1e-4, 100.0)
+    # rtol: rays that miss run on to depth > 100 (their last steps are ~50 long, so an fp32 ulp there is ~1e-5 of the depth)
+    np.testing.assert_allclose(dep.numpy(), g["st.trace_depths"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(pts.numpy(), g["st.trace_pts"], rtol=1e-4, atol=2e-4)
+    hit = g["st.trace_depths"][:, 0] < 100.0
+    assert 0.2 < hit.mean() < 1.0                                  # both outcomes are in the batch
+    assert np.abs(g["st.trace_depths"] - g["st.trace_depths_f64"])[hit].max() < 2e-4   # the reference's own fp32 noise on hits
+    cases = {"st": (dict(depth_sphere_tracing=True), sb), "frc": (dict(), sb),
+             "sho": (dict(shadow_hint=True, specular_hint=False), one_hint_state(sb, True)),
+             "spo": (dict(shadow_hint=False, specular_hint=True), one_hint_state(sb, False))}
+    for vt, (opts, st) in cases.items():
+        out = orc.render_forward(orc.params_from_state(st), *rays, background_rgb=torch.ones(1, 3), mode="as_written", **opts)
+        np.testing.assert_allclose(out["rgb"].numpy(), g[f"{vt}.rgb"], rtol=0, atol=5e-5, err_msg=vt)
+        np.testing.assert_allclose(out["depth"].numpy(), g[f"{vt}.depth"], rtol=1e-4 if vt == "st" else 0, atol=2e-4, err_msg=vt)
+        if vt == "spo":
+            assert out["visibilities"] is None and g["spo.visibilities"].size == 0
+        else:
+            np.testing.assert_allclose(out["visibilities"].numpy(), g[f"{vt}.visibilities"], rtol=0, atol=2e-3, err_msg=vt)
+        if vt == "sho":
+            assert out["specular_cue"] is None and g["sho.specular_cue"].size == 0
+        else:
+            np.testing.assert_allclose(out["specular_cue"].numpy(), g[f"{vt}.specular_cue"], rtol=0, atol=2e-4, err_msg=vt)
+    # force_* on top of the hints changes nothing; without the hint the reference itself fails on the layer shape
+    assert str(g["force_shadow_only.outcome"]).startswith("RuntimeError") and str(g["force_specular_only.outcome"]).startswith("RuntimeError")
+
+
+def test_one_hint_training_step_vs_reference(scene_states):
+    """One training step of the shadow-only and specular-only models: loss and the recorded gradient tensors."""
+    from nrhints_amd.synthetic import one_hint_state
+    g = load_npz("render_branches_b.npz")
+    rays = [T(g["t." + k]) for k in ("o", "d", "pl", "near", "far")]
+    for vt, shadow in (("sho", True), ("spo", False)):
+        st = {k: T(np.asarray(v)).clone().requires_grad_(True) for k, v in one_hint_state(scene_states["b"], shadow).items()}
+        out = orc.render_forward(orc.params_from_state(st), *rays, background_rgb=torch.ones(1, 3), is_training=True,
+                                 global_step=int(g["t.global_step"]), t_rand_primary=T(g[f"{vt}.t_rand_primary"]),
+                                 t_rand_shadow=T(g[f"{vt}.t_rand_shadow"]) if shadow else None, mode="as_written",
+                                 differentiable=True, shadow_hint=shadow, specular_hint=not shadow)
+        np.testing.assert_allclose(out["rgb"].detach().numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=5e-5)
+        loss, _, _ = orc.train_loss(out, T(g["t.rgb_gt"]))
+        np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)
+        loss.backward()
+        for k in (k for k in g if k.startswith(f"{vt}.grad.") and ".rays." not in k):
+            name = k[len(vt) + 6:]
+            bound, scale = grad_bound(g[k], g[k.replace(".grad.", ".grad64.")])
+            err = float(np.abs(st[name].grad.numpy() - g[k.replace(".grad.", ".grad64.")]).max())
+            assert err <= bound, (vt, name, err, bound, scale)
