@@ -376,10 +376,11 @@ int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const fl
 int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const float* dyn_scalars, float* variance_bar, void* stream);
 
 /* ---- the optimiser step (trainer/trainer.py:99-102, 281: torch.optim.Adam over two parameter groups) in one launch ------------
- * Arithmetic and state layout of torch.optim.Adam's capturable implementation (float32 `step` scalar per tensor on the device,
- * exp_avg `m`, exp_avg_sq `v`; no amsgrad / weight decay / maximize):
- *   step += 1;  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;  a = -(lr / (1 - b1^step));
- *   p += m / (sqrt(v) / (sqrt(1 - b2^step) a) + eps / a)
+ * Arithmetic of torch.optim.Adam's default implementation (what the reference runs; bias corrections in double), state layout
+ * of its capturable one (float32 `step` scalar per tensor on the device, exp_avg `m`, exp_avg_sq `v`; no amsgrad / weight
+ * decay / maximize):
+ *   step += 1;  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;
+ *   p += -(lr / (1 - b1^step)) * (m / (sqrt(v) / sqrt(1 - b2^step) + eps))
  * tensors_dev: DEVICE array of `ntensors` descriptors; chunks_dev: DEVICE int pairs (tensor index, chunk index), one per block of
  * 2048 elements, `nchunks` of them (sum over tensors of ceil(n / 2048)); per-group (`ngroups` <= 4) HOST arrays lr / beta1 /
  * beta2 / eps, and optionally lr_dev: HOST array of device pointers to the group's learning rate (read at run time: hipGraph

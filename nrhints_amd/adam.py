@@ -4,10 +4,12 @@ The reference trains with ``torch.optim.Adam`` over two parameter groups (traine
 capturable implementation spends ~100 small kernels per step on the renderer's 46 tensors (0.5 ms of a 7 ms step on MI355X,
 profiles/r03/train_graph_step_v1.txt); this subclass keeps the optimiser object - parameter groups, ``state_dict()`` layout
 (``step`` float32 scalar on the device, ``exp_avg``, ``exp_avg_sq``), ``load_state_dict``, LR schedulers - and replaces the
-arithmetic by one kernel with the same operation order.  The per-tensor descriptor table lives on the device and is rebuilt only
+arithmetic by one kernel in the operation order of torch's DEFAULT Adam, the one the reference runs (bias corrections as
+double scalars; the capturable variant's division by the learning rate turns lr = 0 - step 0 of the warm-up - into NaN for
+entries without gradient history).  The per-tensor descriptor table lives on the device and is rebuilt only
 when a pointer changes (never in steady state: the fused training step writes gradients into persistent buffers); when the
-gradients do move every step (the autograd path allocates them) the object falls back to torch's implementation for good -
-same state, same arithmetic.
+gradients do move every step (the autograd path allocates them) they are copied into buffers of the optimiser's own first
+(one multi-tensor launch).
 """
 from __future__ import annotations
 
@@ -31,10 +33,10 @@ class HipAdam(torch.optim.Adam):
         self._keep: List[torch.Tensor] = []
         self._counts = (0, 0)
         self._rebuilt_last = False
-        self._torch_path = False     # gradients that move every step (autograd allocates them): torch's own implementation
+        self._stage = None           # gradients that move every step (autograd allocates them): staged through fixed buffers
 
     def _entries(self):
-        ents = []
+        ents, grads = [], []
         for gi, group in enumerate(self.param_groups):
             if group.get("amsgrad") or group.get("weight_decay", 0) or group.get("maximize"):
                 raise ValueError("HipAdam implements plain Adam (no amsgrad / weight decay / maximize)")
@@ -53,7 +55,8 @@ class HipAdam(torch.optim.Adam):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 ents.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
                              p.numel(), gi))
-        return ents
+                grads.append(g)
+        return ents, grads
 
     def _upload(self, ents, dev) -> None:
         n = len(ents)
@@ -76,18 +79,22 @@ class HipAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if self._torch_path:
-            return super().step()
-        ents = self._entries()
+        ents, grads = self._entries()
         if not ents:
             return loss
-        dev = next(p for g in self.param_groups for p in g["params"] if p.grad is not None).device
+        dev = grads[0].device
+        if self._stage is not None and len(self._stage) == len(grads) and all(s.shape == g.shape for s, g in zip(self._stage, grads)):
+            torch._foreach_copy_(self._stage, grads)
+            ents = [(e[0], s.data_ptr()) + e[2:] for e, s in zip(ents, self._stage)]
         key = tuple(ents)
         if key != self._key:
-            if self._rebuilt_last and self._key is not None and not torch.cuda.is_current_stream_capturing():
-                # second consecutive step with new addresses: a descriptor upload per step costs more than it saves
-                self._torch_path = True
-                return super().step()
+            if self._rebuilt_last and self._key is not None and self._stage is None and not torch.cuda.is_current_stream_capturing():
+                # second consecutive step with new gradient addresses: from now on the gradients are copied (one multi-tensor
+                # launch) into buffers of our own, so that the descriptor table is uploaded once
+                self._stage = [torch.empty_like(g) for g in grads]
+                torch._foreach_copy_(self._stage, grads)
+                ents = [(e[0], s.data_ptr()) + e[2:] for e, s in zip(ents, self._stage)]
+                key = tuple(ents)
             self._upload(ents, dev)
             self._key, self._rebuilt_last = key, True
         else:

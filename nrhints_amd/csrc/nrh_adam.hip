@@ -1,10 +1,13 @@
 // Adam over a fixed list of parameter tensors in ONE launch (trainer/trainer.py:99-102 builds torch.optim.Adam over two parameter
 // groups; torch's capturable implementation issues ~100 small kernels per step for the 46 tensors of the renderer - 0.5 ms of a
-// 7 ms training step).  Arithmetic of torch.optim.adam._multi_tensor_adam, capturable branch (no amsgrad / weight decay /
-// maximize), in the same float32 operation order:
+// 7 ms training step).  Arithmetic of torch.optim.Adam as the reference runs it (default, non-capturable branch of
+// torch.optim.adam._multi_tensor_adam; no amsgrad / weight decay / maximize): the bias corrections are host-precision scalars
+// there (python floats), the tensor operations float32 in this order:
 //   step += 1;  m += (g - m) (1 - b1);  v = v b2 + (1 - b2) g g
-//   bc1 = 1 - b1^step;  bc2 = 1 - b2^step;  a = -(lr / bc1)
-//   p += m / (sqrt(v) / (sqrt(bc2) a) + eps / a)
+//   bc1 = 1 - b1^step;  bc2 = 1 - b2^step   (double);   step_size = lr / bc1
+//   p += -step_size * (m / (sqrt(v) / sqrt(bc2) + eps))
+// (torch's CAPTURABLE branch divides by the learning rate - sqrt(v) / (sqrt(bc2) * -step_size) - which is 0 / -0 = NaN for an
+// entry with zero gradient history under lr = 0, the first step of the reference's warm-up schedule; not reproduced here.)
 // One block = one chunk of 2048 elements of one tensor (chunk table built by the host once per parameter list); the step
 // counters are bumped by a second, one-block launch after every chunk has read them.
 #include "nrh_common.h"
@@ -28,9 +31,9 @@ struct Tensor {          // mirrors NrhAdamTensor (include/nrhints_hip.h)
 struct Args {
   const Tensor* tensors;
   const int* chunks;      // [nchunks][2]: tensor index, element offset / CHUNK
-  float lr[MAX_GROUPS];
   const float* lr_ptr[MAX_GROUPS];   // device learning rate per group (overrides lr) or null
-  float b1[MAX_GROUPS], b2[MAX_GROUPS], w1[MAX_GROUPS], w2[MAX_GROUPS], eps[MAX_GROUPS];
+  double b1d[MAX_GROUPS], b2d[MAX_GROUPS], lrd[MAX_GROUPS];
+  float b2[MAX_GROUPS], w1[MAX_GROUPS], w2[MAX_GROUPS], eps[MAX_GROUPS];
   int ntensors;
 };
 
@@ -38,12 +41,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const Args a) {
   const int ti = a.chunks[2 * blockIdx.x], off = a.chunks[2 * blockIdx.x + 1];
   const Tensor t = a.tensors[ti];
   const int gi = t.group;
-  const float lr = a.lr_ptr[gi] ? a.lr_ptr[gi][0] : a.lr[gi];
-  const float b1 = a.b1[gi], b2 = a.b2[gi], eps = a.eps[gi];
-  const float step = t.step[0] + 1.0f;
-  const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
-  const float neg = -(lr / bc1);
-  const float den_scale = sqrtf(bc2) * neg, eps_term = eps / neg;
+  const double lr = a.lr_ptr[gi] ? (double)a.lr_ptr[gi][0] : a.lrd[gi];
+  const float b2 = a.b2[gi], eps = a.eps[gi];
+  const double step = (double)t.step[0] + 1.0;
+  const double bc1 = 1.0 - pow(a.b1d[gi], step), bc2 = 1.0 - pow(a.b2d[gi], step);
+  const float neg_step_size = -(float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   const float w1 = a.w1[gi], w2 = a.w2[gi];
   const long long base = (long long)off * CHUNK;
 #pragma unroll
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const Args a) {
       const float v = __fmul_rn(t.v[i], b2) + __fmul_rn(__fmul_rn(w2, g), g);   // mul_(b2).addcmul_(g, g, value = 1 - b2)
       t.m[i] = m;
       t.v[i] = v;
-      t.p[i] = t.p[i] + m / (sqrtf(v) / den_scale + eps_term);     // addcdiv_(m, denom)
+      t.p[i] = t.p[i] + neg_step_size * (m / (sqrtf(v) / bc2_sqrt + eps));     // addcdiv_(m, denom, value = -step_size)
     }
   }
 }

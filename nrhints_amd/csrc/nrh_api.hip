@@ -996,7 +996,7 @@ int nrh_adam_step(const NrhAdamTensor* tensors_dev, int ntensors, const int* chu
   a.tensors = (const nrhadam::Tensor*)tensors_dev; a.chunks = chunks_dev; a.ntensors = ntensors;
   for (int g = 0; g < ngroups; ++g) {
     // scalars rounded to float32 as torch does with python floats (1 - beta in double first)
-    a.lr[g] = (float)lr[g]; a.lr_ptr[g] = lr_dev ? lr_dev[g] : nullptr; a.b1[g] = (float)beta1[g]; a.b2[g] = (float)beta2[g];
+    a.lrd[g] = lr[g]; a.lr_ptr[g] = lr_dev ? lr_dev[g] : nullptr; a.b1d[g] = beta1[g]; a.b2d[g] = beta2[g]; a.b2[g] = (float)beta2[g];
     a.w1[g] = (float)(1.0 - beta1[g]); a.w2[g] = (float)(1.0 - beta2[g]); a.eps[g] = (float)eps[g];
   }
   hipStream_t st = (hipStream_t)stream;

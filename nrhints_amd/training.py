@@ -45,7 +45,7 @@ def make_optimizer(renderer: nn.Module, extra_params: Optional[Iterable[nn.Param
                    extra_lr: float = 1e-4, warm_up_end: int = 5_000, end_iter: int = 1_000_000, lr_alpha: float = 0.05,
                    hip: Optional[bool] = None):
     """Adam + LambdaLR as the reference builds them (two groups: renderer, ray-generator deltas).  ``hip``: the optimiser step
-    as one HIP launch (adam.HipAdam: same state layout, same arithmetic as torch's capturable Adam); None = whenever the
+    as one HIP launch (adam.HipAdam: the arithmetic of torch's default Adam, state layout of its capturable form); None = whenever the
     renderer lives on the GPU."""
     groups = [{"params": list(renderer.parameters()), "lr": lr}]
     if extra_params is not None:
@@ -156,7 +156,7 @@ class GraphedTrainStep:
 
     What changes between steps is read from device memory at run time: the batch (static ray / pixel buffers that
     ``__call__`` copies into), 1/s and the cos-anneal ratio (``renderer.dyn_scalars``, see NrhNet.dyn_scalars) and the
-    learning rates (tensor-valued ``lr`` of a capturable Adam).  The jitter comes from the graph-safe device generator.
+    learning rates (tensor-valued ``lr`` of adam.HipAdam).  The jitter comes from the graph-safe device generator.
     Frozen at capture time: the batch size, the precision / model configuration, whether the geometry warm-up is active
     (re-create the object when ``global_step`` crosses ``geometry_warmup_end``).
 
@@ -203,16 +203,13 @@ class GraphedTrainStep:
             self.pixels = RawPixelBundle(img_indices=torch.zeros(n, 1, dtype=torch.int64, device=dev), h_indices=z(n, 1),
                                          w_indices=z(n, 1), poses=z(n, 4, 4), pls=z(n, 3), rgb_gt=None)
         self.gt = z(n, 3)
-        # the fused step's gradients live at fixed addresses: Adam as one launch (adam.HipAdam); the autograd path allocates its
-        # gradients per step and keeps torch's capturable Adam
+        # Adam as one launch (adam.HipAdam: the arithmetic of torch's default Adam with device-side learning rates).  The fused
+        # step's gradients live at fixed addresses; the autograd path's are staged through the optimiser's own buffers
         from . import train_fused
+        from .adam import HipAdam
         refines = ray_generator is not None and any(p.requires_grad for p in ray_generator.parameters())
         self._use_fused = (train_fused.supported(renderer, self.rays) is None and not refines) if fused is None else bool(fused)
-        if self._use_fused:
-            from .adam import HipAdam
-            self.optimizer = HipAdam(groups)
-        else:
-            self.optimizer = torch.optim.Adam(groups, capturable=True)
+        self.optimizer = HipAdam(groups)
         self.bg = background_rgb.detach().to(dev, torch.float32).reshape(1, 3).clone()
         renderer.dyn_scalars = torch.zeros(2, dtype=torch.float32, device=dev)
         self._capture_step = global_step

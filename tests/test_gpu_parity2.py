@@ -189,10 +189,10 @@ def test_alpha_vs_reference_unit_vectors(scene_states, tag, prec):
 def test_graph_replay_equals_eager_step(scene_states):
     """GraphedTrainStep against the eager step (training.train_step's sequence) on the same batches with the same jitter:
     losses of three consecutive steps, the gradients and the parameters after every step; an evaluation render BETWEEN
-    replays sees the replayed parameters (pack cache).  The eager side uses the same optimiser arithmetic as the graph
-    (torch's capturable Adam, tensor lr): with it the replay reproduces the eager step to the last bit, while torch's default
-    Adam differs from its own capturable form by 1 ulp after one step - which the renderer then amplifies (a sample crossing
-    the surface changes sensitive gradient entries by ~1 %; profiles/r02/graph_vs_eager_probe.log)."""
+    replays sees the replayed parameters (pack cache).  The eager side uses the same optimiser as the graph (adam.HipAdam,
+    tensor lr): with it the replay reproduces the eager step to the last bit, while two Adam implementations that differ by
+    1 ulp after one step diverge visibly - the renderer amplifies it (a sample crossing the surface changes sensitive gradient
+    entries by ~1 %; profiles/r02/graph_vs_eager_probe.log)."""
     from nrhints_amd.training import GraphedTrainStep, lr_factor, train_loss_dict
     n, lr, gs = 128, 5e-4, 30000
     bg = torch.ones(1, 3).cuda()
@@ -202,7 +202,8 @@ def test_graph_replay_equals_eager_step(scene_states):
     rb_eval = _bundle(*make_rays(200, seed=77, spread=0.1))
     eager = _model(scene_states["b"], train=True)
     lr_t = torch.tensor(lr, device="cuda")
-    opt = torch.optim.Adam([{"params": list(eager.parameters()), "lr": lr_t}], capturable=True)
+    from nrhints_amd.adam import HipAdam
+    opt = HipAdam([{"params": list(eager.parameters()), "lr": lr_t}])
     graphed = _model(scene_states["b"], train=True)
     before = {k: v.detach().clone() for k, v in graphed.state_dict().items()}
     step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs,
@@ -469,8 +470,8 @@ def test_graph_with_ray_generator_group(scene_states, refine):
                 rg.cam_pose_adjustment.copy_(T(np.random.RandomState(1).randn(ncam, 6).astype(np.float32)) * 0.01)
                 rg.pl_adjustment.copy_(T(np.random.RandomState(2).randn(ncam, 3).astype(np.float32)) * 0.02)
     lr_t, rlr_t = torch.tensor(lr, device="cuda"), torch.tensor(rlr, device="cuda")
-    opt = torch.optim.Adam([{"params": list(eager.parameters()), "lr": lr_t}, {"params": list(rg_e.parameters()), "lr": rlr_t}],
-                           capturable=True)
+    from nrhints_amd.adam import HipAdam
+    opt = HipAdam([{"params": list(eager.parameters()), "lr": lr_t}, {"params": list(rg_e.parameters()), "lr": rlr_t}])
     step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs, jitter=(torch.zeros(n, 1), torch.zeros(n, 64)),
                             ray_generator=rg_g, ray_lr=rlr)
     groups = step.optimizer.state_dict()["param_groups"]

@@ -270,7 +270,8 @@ def test_fused_training_descends_and_graph_replays(scene_states):
     tp, ts = cu(rs.rand(n, 1).astype(np.float32)), cu(rs.rand(n, 64).astype(np.float32))
     eager, graphed = _model(scene_states["b"]), _model(scene_states["b"])
     lr_t = torch.tensor(lr, device="cuda")
-    opt = torch.optim.Adam([{"params": list(eager.parameters()), "lr": lr_t}], capturable=True)
+    from nrhints_amd.adam import HipAdam
+    opt = HipAdam([{"params": list(eager.parameters()), "lr": lr_t}])        # the optimiser GraphedTrainStep uses around the fused body
     step = GraphedTrainStep(graphed, n, bg, lr=lr, warm_up_end=20, global_step=gs, jitter=(tp, ts), fused=True)
     for i, (rb_i, gt_i) in enumerate(batches):
         lr_t.fill_(lr * lr_factor(gs + i, 20, 1_000_000, 0.05))
@@ -305,34 +306,38 @@ def test_pack_plans_on_gpu_bit_identical(scene_states):
     assert torch.equal(wt.view(torch.int32), gt.cpu().view(torch.int32))
 
 
-def test_hip_adam_equals_torch_capturable_adam():
-    """adam.HipAdam (nrh_adam_step: one launch for all tensors) against torch.optim.Adam(capturable=True) on the same parameters
-    and gradients over several steps, two parameter groups with different (tensor and float) learning rates: same state layout,
-    parameters / moments equal to a few ulp (the kernel follows torch's operation order; fma contraction may differ), and the
-    state dict loads into a plain torch Adam."""
+def test_hip_adam_equals_torch_adam():
+    """adam.HipAdam (nrh_adam_step: one launch for all tensors) against torch.optim.Adam - the default implementation the
+    reference trains with - on the same parameters and gradients over several steps, two parameter groups with different
+    learning rates (a device tensor on the HIP side: graph replays read it at run time), INCLUDING lr = 0 with all-zero gradient
+    entries (step 0 of the warm-up schedule; torch's capturable variant returns NaN there): parameters / moments equal to a few
+    ulp, same state keys, and the state dict loads into a plain torch Adam."""
     from nrhints_amd.adam import HipAdam
     rs = np.random.RandomState(0)
     shapes = [(256, 39), (256, 1), (256,), (), (3, 256), (217, 256), (5000,)]
-    mk = lambda: [torch.nn.Parameter(cu(rs0.randn(*s).astype(np.float32) if s else np.float32(rs0.randn()))) for s in shapes]
-    rs0 = np.random.RandomState(1); pa = mk()
-    rs0 = np.random.RandomState(1); pb = mk()
-    lr_t = torch.tensor(5e-4, device="cuda")
-    ga = [{"params": pa[:5], "lr": lr_t}, {"params": pa[5:], "lr": 1e-3}]
-    gb = [{"params": pb[:5], "lr": lr_t}, {"params": pb[5:], "lr": 1e-3}]
-    hip, ref = HipAdam(ga), torch.optim.Adam(gb, capturable=True)
+    mk = lambda r: [torch.nn.Parameter(cu(r.randn(*s).astype(np.float32) if s else np.array(r.randn(), dtype=np.float32))) for s in shapes]
+    pa, pb = mk(np.random.RandomState(1)), mk(np.random.RandomState(1))
+    lr_t = torch.tensor(0.0, device="cuda")
+    hip = HipAdam([{"params": pa[:5], "lr": lr_t}, {"params": pa[5:], "lr": 1e-3}])
+    ref = torch.optim.Adam([{"params": pb[:5], "lr": 0.0}, {"params": pb[5:], "lr": 1e-3}])
     grads = [torch.empty_like(p) for p in pa]
     for p, g in zip(pa, grads):
         p.grad = g
     for it in range(5):
-        lr_t.fill_(5e-4 * (it + 1) / 5)
+        lr0 = 5e-4 * it / 5                                   # 0 on the first step
+        lr_t.fill_(lr0)
+        ref.param_groups[0]["lr"] = lr0
         for g, q in zip(grads, pb):
-            g.copy_(cu(rs.randn(*g.shape).astype(np.float32) if g.dim() else np.float32(rs.randn())) * (10.0 ** rs.randint(-6, 1)))
+            g.copy_(cu(rs.randn(*g.shape).astype(np.float32) if g.dim() else np.array(rs.randn(), dtype=np.float32)) * (10.0 ** rs.randint(-6, 1)))
+            if g.dim() == 2:
+                g[:3].zero_()                                 # entries that never see a gradient
             q.grad = g.clone()
         hip.step(); ref.step()
         for i, (a, b) in enumerate(zip(pa, pb)):
+            assert bool(torch.isfinite(a).all()), (it, i)
             tol = 4e-7 * float(b.detach().abs().max()) + 1e-9
             assert float((a.detach() - b.detach()).abs().max()) <= tol, (it, i)
-    assert not hip._torch_path                      # fixed gradient addresses: the one-launch path all along
+    assert hip._stage is None                       # fixed gradient addresses: no staging copy
     sa, sb = hip.state_dict(), ref.state_dict()
     assert sa["state"].keys() == sb["state"].keys() and len(sa["param_groups"]) == 2
     for k in sa["state"]:
@@ -340,17 +345,17 @@ def test_hip_adam_equals_torch_capturable_adam():
         for name in ("exp_avg", "exp_avg_sq"):
             x, y = sa["state"][k][name], sb["state"][k][name]
             assert float((x - y).abs().max()) <= 4e-7 * float(y.abs().max()) + 1e-30, (k, name)
-    torch.optim.Adam(gb, capturable=True).load_state_dict(sa)
-    # gradients that move every step: falls back to torch's implementation, results unchanged
-    hip2, ref2 = HipAdam([{"params": pa, "lr": 1e-3}]), torch.optim.Adam([{"params": pb, "lr": 1e-3}], capturable=True)
+    torch.optim.Adam([{"params": pb[:5]}, {"params": pb[5:]}]).load_state_dict(sa)
+    # gradients that move every step: staged through the optimiser's own buffers, results unchanged
+    hip2, ref2 = HipAdam([{"params": pa, "lr": 1e-3}]), torch.optim.Adam([{"params": pb, "lr": 1e-3}])
     with torch.no_grad():
         for a, b in zip(pa, pb):
             b.copy_(a)
-    for it in range(3):
+    for it in range(4):
         for a, b in zip(pa, pb):
             a.grad = torch.randn_like(a)
             b.grad = a.grad.clone()
         hip2.step(); ref2.step()
-    assert hip2._torch_path
+    assert hip2._stage is not None
     for a, b in zip(pa, pb):
         assert float((a.detach() - b.detach()).abs().max()) <= 4e-7 * float(b.detach().abs().max()) + 1e-9
