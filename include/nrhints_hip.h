@@ -240,6 +240,9 @@ typedef struct NrhTrainSaves {
   float* save_ge;    /* [nrays*128][128] */
   float* raymisc;    /* optional [nrays,100]: the reflectance net's per-ray encodings enc4(view) | enc4(pl) | enc4(vis) | enc4(cue)
                         (what nrh_visibility writes); NULL = kept in the workspace */
+  float* shadow_mid_z;  /* optional [nrays,128]: section mid-points along the shadow ray light -> hit point ... */
+  float* shadow_dists;  /* optional [nrays,128]: ... and section lengths (get_visibility :411-415), for callers that differentiate
+                           the visibility hint (renderer.shadow_hint_gradient); NULL = kept in the workspace */
 } NrhTrainSaves;
 int nrh_render_forward_train(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
                              const float* nears, const float* fars, long long nrays, float cos_anneal,

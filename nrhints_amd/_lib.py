@@ -43,7 +43,8 @@ class NrhAdamTensor(Structure):
 
 class NrhTrainSaves(Structure):
     _fields_ = [("sdf", c_void_p), ("feat_rows", c_void_p), ("save_h", c_void_p), ("save_s1", c_void_p),
-                ("save_t", c_void_p), ("save_ge", c_void_p), ("raymisc", c_void_p)]
+                ("save_t", c_void_p), ("save_ge", c_void_p), ("raymisc", c_void_p), ("shadow_mid_z", c_void_p),
+                ("shadow_dists", c_void_p)]
 
 
 class HipExtensionMissing(RuntimeError):

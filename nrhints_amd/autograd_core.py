@@ -144,12 +144,61 @@ class ColorNetHip(torch.autograd.Function):
         return grads_in + tuple(out[f"w{l}"] for l in range(5)) + tuple(out[f"b{l}"] for l in range(5))
 
 
+def _alpha(sdf, grad, dirs, dists, inv_s, cos_anneal: float):
+    """NeuSHintRenderer.get_alpha (models/neus_hint_model.py:339-356) as differentiable torch expressions; [P,1] / [P,3] inputs."""
+    true_cos = (dirs * grad).sum(-1, keepdim=True)
+    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + F.relu(-true_cos) * cos_anneal)
+    est_next = sdf + iter_cos * dists * 0.5
+    est_prev = sdf - iter_cos * dists * 0.5
+    prev_cdf, next_cdf = torch.sigmoid(est_prev * inv_s), torch.sigmoid(est_next * inv_s)
+    return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+
+
+def _specular_cue(hit_normal, pl, hit, dirs, roughness) -> torch.Tensor:
+    """Cook-Torrance specular cue per roughness (models/neus_hint_model.py:589-615), differentiable in the hit normal, the
+    light position and the view direction; [N,3] inputs -> [N, len(roughness)]."""
+    lit = F.normalize(pl - hit, dim=-1, p=2)
+    view = F.normalize(-dirs, dim=-1, p=2)
+    half = F.normalize(lit + view, dim=-1, p=2)
+    n_l = (hit_normal * lit).sum(-1).clip(0.0, 1.0)
+    n_v = (hit_normal * view).sum(-1).clip(0.0, 1.0)
+    n_h = (hit_normal * half).sum(-1).clip(0.0, 1.0)
+    h_v = (half * view).sum(-1).clip(0.0, 1.0)
+    n_h2 = torch.pow(n_h, 2)
+    out = []
+    for r in roughness:
+        k = (r + 1.0) * (r + 1.0) / 8.0
+        g = (n_v / (n_v * (1.0 - k) + k)) * (n_l / (n_l * (1.0 - k) + k))
+        a2 = r * r
+        ndf = a2 / (torch.pi * torch.pow(n_h2 * (a2 - 1.0) + 1.0, 2))
+        f = 0.04 + 0.96 * torch.pow(1.0 - h_v, 5)
+        out.append(ndf * g * f / (4.0 * n_v + 1e-3))
+    return torch.stack(out, dim=-1)
+
+
+def _visibility(d, packed, variance, pl, hit, mid_z, dists, cos_anneal: float) -> torch.Tensor:
+    """The differentiable tail of get_visibility (models/neus_hint_model.py:411-432) for renderer.shadow_hint_gradient: alpha at
+    the 128 section mid-points of the shadow ray light -> hit point (sections from the graph-less HIP sampler; the reference
+    detaches its importance samples too, :313), transmittance in front of the last one.  The SDF network and d sdf/dx at the
+    shadow points run through the same HIP forward / backward sweeps as the primary samples (sdf_value_feat_grad)."""
+    n, T = mid_z.shape
+    sd = hit - pl
+    srd = sd / torch.linalg.norm(sd, ord=2, dim=-1, keepdim=True)
+    pts = (pl[:, None, :] + srd[:, None, :] * mid_z[..., None]).reshape(-1, 3)
+    sdf, _, grad = sdf_value_feat_grad(d, pts, packed=packed)
+    inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
+    alpha = _alpha(sdf, grad, srd[:, None, :].expand(n, T, 3).reshape(-1, 3), dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, T)
+    return torch.prod(1.0 - alpha[:, :-1] + 1e-7, dim=-1, keepdim=True)     # taus[..., -1:] of :428-432
+
+
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
-                background_rgb, analytic_normal: bool = False, packed=None, pre=None, dyn=None) -> Dict[str, torch.Tensor]:
+                background_rgb, analytic_normal: bool = False, packed=None, pre=None, dyn=None, hint_grad=None) -> Dict[str, torch.Tensor]:
     """``d``: weight-norm-folded dense parameters WITH autograd history (packing.dense_params* on the live nn.Parameters);
     mid_z / dists [N,128], vis [N,1], cue [N,4]: graph-less results of the HIP forward; ``packed``: the kernel buffers of the
     same parameters.  Every network evaluation and its adjoint is a HIP kernel (there is no torch formulation in here; the
-    ones the kernels are tested against are tests/torch_backends.py)."""
+    ones the kernels are tested against are tests/torch_backends.py).  ``hint_grad`` (renderer.shadow_hint_gradient /
+    specular_hint_gradient, off by default): dict(hit, specular, shadow, roughness) - the hints are then re-derived here as
+    differentiable functions of the network (and of the rays) instead of entering as constants."""
     if packed is None or packed.get("col_wt") is None:
         raise ValueError("render_core needs the packed parameters incl. the transposed reflectance weights")
     n, T = mid_z.shape
@@ -158,6 +207,12 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
     # alpha, transmittance product, weights and unit normals: one HIP kernel forward, one for the adjoint
     weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal, dyn)
+    if hint_grad is not None:
+        if hint_grad.get("shadow") is not None:
+            vis = _visibility(d, packed, variance, pl, hint_grad["hit"], hint_grad["shadow"]["mid_z"], hint_grad["shadow"]["dists"], cos_anneal)
+        if hint_grad.get("specular"):
+            hit_n = F.normalize((n_hat.reshape(n, T, 3) * weights[..., None]).sum(1), dim=-1, p=2)      # :586-587
+            cue = _specular_cue(hit_n, pl, hint_grad["hit"], dirs, hint_grad["roughness"])
     # per-ray part of the reflectance input: encodings of view direction, light position, visibility hint, specular cue
     per_ray = [_enc(dirs, 4), _enc(pl, 4)]
     if vis is not None:  # vis / cue are None for the pl-naive model (no hints)

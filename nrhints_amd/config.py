@@ -120,7 +120,6 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
         (not (r.force_specular_cue and not r.specular_hint),
          "force_specular_cue without specular_hint fails in the reference itself (same lin0 shape mismatch); enable specular_hint"),
         (list(r.specular_roughness) == [0.02, 0.05, 0.13, 0.34], "specular_roughness must be the default 4 values"),
-        (not r.shadow_hint_gradient and not r.specular_hint_gradient, "hint gradients are not implemented"),
         (abs(r.shadow_ray_offset - 1e-2) < 1e-12, "shadow_ray_offset must be 1e-2"),
     ]
     for ok, why in checks:

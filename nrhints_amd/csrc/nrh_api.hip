@@ -879,6 +879,9 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   float* o_depth = depth ? depth : ws_depth;
   float* o_vis = visibilities ? visibilities : ws_vis;
   float* o_cue_b = specular_cue;  // optional broadcast copy
+  // shadow_hint_gradient: the caller differentiates the shadow ray's alpha itself and needs its section mid-points / lengths
+  float* o_tmid_s = (train && train->shadow_mid_z) ? train->shadow_mid_z : ws_tmid_s;
+  float* o_dists_s = (train && train->shadow_dists) ? train->shadow_dists : ws_dists_s;
   float* o_tmid = mid_z ? mid_z : ws_tmid;
   float* o_dists = dists ? dists : ws_dists;
 
@@ -931,18 +934,18 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   }
   // ---- shadow rays light -> hit point ----
   if (!no_hints) {
-    rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s,
-                     ws_dists_s, n, st);
+    rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, o_tmid_s,
+                     o_dists_s, n, st);
     if (rc) return rc;
     // the shadow ray's alpha only needs <direction, gradient>: with the wide kernels that is mode 3 (forward mode, no scratch)
     const int smode = (net->shadow_jvp && net->precision == 1 && net->sdf_w32 && net->sdf_tab32) ? 3 : 1;
-    rc = sdf_eval_impl(net->precision, smode, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
+    rc = sdf_eval_impl(net->precision, smode, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, o_tmid_s, 128, 128, n, ws_sdf_s,
                        128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
     if (rc) return rc;
   }
   {
     nrh::ShadowArgs c;
-    c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = ws_dists_s;
+    c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = o_dists_s;
     c.cue = ws_cue; c.vis = o_vis; c.raymisc = (train && train->raymisc) ? train->raymisc : ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
     c.dyn = net->dyn_scalars;
     c.nrays = (int)n; c.zero_hints = no_hints;

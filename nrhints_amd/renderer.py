@@ -299,8 +299,17 @@ class NeuSHintRenderer(nn.Module):
             dense = self._pad_hint_columns(packing.dense_params_hip(named) if on_gpu_f32 else packing.dense_params(named))
             self.packed_params(device, dense=dense)
         fused_train = needs_grad and n <= self.max_fused_train_rays
+        rcfg = cfg.renderer
+        shadow_grad = bool(needs_grad and rcfg.shadow_hint_gradient and self.has_shadow_hint and not zero_hints)
+        specular_grad = bool(needs_grad and rcfg.specular_hint_gradient and self.has_specular_hint and not zero_hints)
+        if (shadow_grad or specular_grad) and not fused_train:
+            raise ValueError(f"hint gradients need the batch in one training call (at most max_fused_train_rays = {self.max_fused_train_rays} rays)")
+        if shadow_grad and any(t.requires_grad for t in (o_g, d_g, pl_g)):
+            # the reference's coarse shadow samples scale with |hit - light| (:386-387), so d visibility / d light has a term through
+            # the sample positions; the shadow sections come out of the HIP sampler as constants here
+            raise NotImplementedError("shadow_hint_gradient together with ray gradients (pose / light refinement) is not implemented")
         if fused_train:
-            res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints)
+            res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, want_shadow=shadow_grad)
         else:
             res = self._render_chunks(o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints,
                                       want_samples=True, want_maps=False, want_mid=needs_grad, use_dyn=needs_grad and is_training)
@@ -316,7 +325,8 @@ class NeuSHintRenderer(nn.Module):
                 pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
-                packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars if is_training else None)
+                packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars if is_training else None,
+                hint_grad=self._hint_grad_inputs(o, d, depth, res, shadow_grad, specular_grad))
             return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
                                 inside_sphere=inside, relax_inside_sphere=inside,
                                 analytic_normals=core["analytic_normals"],
@@ -329,8 +339,20 @@ class NeuSHintRenderer(nn.Module):
                             normalized_analytic_normals=nhat, visibilities=vis if self.has_shadow_hint else None,
                             specular_cue=cue if self.has_specular_hint else None)
 
+    def _hint_grad_inputs(self, o, d, depth, res, shadow_grad: bool, specular_grad: bool):
+        """What render_core needs to differentiate the hints (renderer.shadow_hint_gradient / specular_hint_gradient,
+        models/neus_hint_model.py:379, :589): the graph-less hit point and, for the visibility, the shadow ray's sections."""
+        if not (shadow_grad or specular_grad):
+            return None
+        if self._depth_type == 2:      # SphereTracing: the hit point is the tracer's last point (:527-528), not o + d * depth
+            hit = self.sphere_trace(o, d, 2000, 1e-4, 100.0)[0]
+        else:
+            hit = o + d * depth.reshape(-1, 1)     # :533, :538 (under no_grad there too)
+        return dict(hit=hit, specular=specular_grad, shadow=dict(mid_z=res["shadow_mid_z"], dists=res["shadow_dists"]) if shadow_grad else None,
+                    roughness=[float(r) for r in self.config.renderer.specular_roughness])
+
     # ---------------------------------------------------------------------------------------------
-    def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None):
+    def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None, want_shadow=False):
         """One nrh_render_forward_train call over the whole batch: the no-grad stages (samplers, hit point, shadow march,
         cue) plus the training evaluation of the SDF network at the section mid-points, whose outputs and saved arrays
         feed the backward sweeps directly (no second evaluation)."""
@@ -349,7 +371,10 @@ class NeuSHintRenderer(nn.Module):
                    ro=o, rd=d, t=out["mid_z"], n_per_ray=T)
         P = _lib.ptr
         sv = pre["saves"]
-        saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]), P(raymisc))
+        if want_shadow:       # shadow_hint_gradient: the shadow ray's sections, for the differentiable visibility of render_core
+            out.update(shadow_mid_z=new(n, T), shadow_dists=new(n, T))
+        saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]), P(raymisc),
+                                   P(out.get("shadow_mid_z")), P(out.get("shadow_dists")))
         ws = self._workspace(device, n)
         rc = lib.nrh_render_forward_train(
             net, P(o), P(d), P(pl), P(near), P(far), n, cos_anneal, P(t_rand_p) if t_rand_p is not None else None,

@@ -263,9 +263,11 @@ def _sdf_and_grad(p, pts, mode, want_feat, differentiable=False):
     return sdf, feat, grad
 
 
-def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=None, mode="minimal"):
+def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=None, mode="minimal", differentiable=False):
     """Shadow ray light -> hit point, transmittance before the last sample
-    (models/neus_hint_model.py:373-432)."""
+    (models/neus_hint_model.py:373-432).  ``differentiable``: renderer.shadow_hint_gradient (:379) - the final alpha evaluation
+    keeps its graph w.r.t. the network (second order through d sdf/dx); the sample positions are constants w.r.t. the network
+    either way (importance samples are detached, :313; the coarse ones depend on the light only)."""
     n = pls.shape[0]
     dvec = hit - pls
     L = torch.linalg.norm(dvec, dim=-1, keepdim=True)
@@ -276,14 +278,15 @@ def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=No
         upper = torch.cat([mids, z[:, -1:]], -1)
         lower = torch.cat([z[:, :1], mids], -1)
         z = lower + (upper - lower) * t_rand
-    z = hierarchical_z(p, pls, ds, z, full_forward=(mode == "as_written"))
+    with torch.no_grad():
+        z = hierarchical_z(p, pls, ds, z, full_forward=(mode == "as_written"))
     dists = torch.cat([z[:, 1:] - z[:, :-1], (L / 64.0).expand(n, 1)], dim=-1)
     mid = z + dists * 0.5
     pts = (pls[:, None, :] + ds[:, None, :] * mid[..., None]).reshape(-1, 3)
     dirs = ds[:, None, :].expand(n, 128, 3).reshape(-1, 3)
     if mode == "as_written":
         sdf, _ = sdf_forward(p, pts, True)
-        grad = sdf_gradient_autograd(p, pts)
+        grad = sdf_gradient_autograd(p, pts, create_graph=differentiable)
     else:
         sdf, _, grad = sdf_forward_grad_analytic(p, pts, False)
     alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s_of(p), cos_anneal).reshape(n, 128)
@@ -333,7 +336,8 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    global_step=0, anneal_end=50_000, t_rand_primary=None, t_rand_shadow=None,
                    mode="minimal", keep_intermediates=False, differentiable=False, hints=True,
                    analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0,
-                   depth_sphere_tracing=False, shadow_hint=None, specular_hint=None) -> Dict[str, torch.Tensor]:
+                   depth_sphere_tracing=False, shadow_hint=None, specular_hint=None, shadow_hint_gradient=False,
+                   specular_hint_gradient=False) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
@@ -379,17 +383,19 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
             hit = o + d * depth
         if shadow_hint and warmup:
             vis = torch.zeros(n, 1, dtype=dt)                  # :577-579 (shadow_map = zeros)
-        else:
+        elif not (shadow_hint and shadow_hint_gradient and differentiable):
             vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode) \
                 if shadow_hint else None                       # :546-551, :379
+    if shadow_hint and not warmup and shadow_hint_gradient and differentiable:
+        vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode, differentiable=True)
     n_hat = F.normalize(grad, dim=-1)                          # :584
     hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
     vis_s = cue_s = None
     if shadow_hint:
         vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
     if specular_hint:
-        with torch.no_grad():
-            cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :589-615 (no_grad), :617-619
+        with torch.enable_grad() if (specular_hint_gradient and differentiable) else torch.no_grad():   # :589
+            cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :590-615, :617-619
         cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
     col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :621-626
     rgb = (col * weights[..., None]).sum(1)

@@ -10,6 +10,8 @@ Variants, all on scene b's weights (nrhints_amd.synthetic.perturb_state of the r
   sho   shadow hint only   (shadow_hint=True,  specular_hint=False): evaluation render + one training step's loss and gradients
   spo   specular hint only (shadow_hint=False, specular_hint=True):  the same
   frc   force_shadow_map + force_specular_cue on top of both hints (a no-op: has_*_hint = hint or force, :239-240)
+  shg / spg / bhg   shadow_hint_gradient / specular_hint_gradient / both (:379, :589: the hints stay inside the autograd graph):
+        one training step's loss and gradients (the forward values equal the default model's)
 and the reference's own failure for force_* WITHOUT the hint (recorded as the exception's type name).
 """
 import os
@@ -73,6 +75,11 @@ def main():
         "spo": (R(shadow_hint=False, specular_hint=True), one_hint_state(state_b, shadow=False)),
         "frc": (R(force_shadow_map=True, force_specular_cue=True), state_b),
     }
+    grad_variants = {
+        "shg": (R(shadow_hint_gradient=True), state_b),
+        "spg": (R(specular_hint_gradient=True), state_b),
+        "bhg": (R(shadow_hint_gradient=True, specular_hint_gradient=True), state_b),
+    }
     N = 64
     rays = make_rays(N, seed=29, spread=0.12)
     rec = dict(zip(("o", "d", "pl", "near", "far"), rays))
@@ -98,8 +105,8 @@ def main():
     gt = torch.full((Nt, 3), 0.5)
     rec["t.rgb_gt"], rec["t.global_step"] = gt.numpy(), np.int64(20000)
     real_rand = torch.rand
-    for vt in ("sho", "spo"):
-        rcfg, st = variants[vt]
+    for vt in ("sho", "spo", "shg", "spg", "bhg"):
+        rcfg, st = variants[vt] if vt in variants else grad_variants[vt]
         drawn = []
 
         def rec_rand(*a, **k):
@@ -125,9 +132,9 @@ def main():
             loss.backward()
             if dt == torch.float32:
                 # shadow-only draws primary + shadow jitter; specular-only has no shadow march, hence one draw
-                assert len(drawn) == (2 if vt == "sho" else 1), len(drawn)
+                assert len(drawn) == (1 if vt == "spo" else 2), len(drawn)
                 rec[f"{vt}.t_rand_primary"] = drawn[0].numpy()
-                if vt == "sho":
+                if vt != "spo":
                     rec[f"{vt}.t_rand_shadow"] = drawn[1].numpy()
                 rec[f"{vt}.t.rgb"] = r.rgb.detach().numpy()
             rec[f"{vt}.loss{sfx}"] = loss.detach().numpy()

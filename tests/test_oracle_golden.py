@@ -269,17 +269,22 @@ def test_more_off_default_branches(scene_states):
     assert str(g["force_shadow_only.outcome"]).startswith("RuntimeError") and str(g["force_specular_only.outcome"]).startswith("RuntimeError")
 
 
-def test_one_hint_training_step_vs_reference(scene_states):
-    """One training step of the shadow-only and specular-only models: loss and the recorded gradient tensors."""
+@pytest.mark.parametrize("vt", ["sho", "spo", "shg", "spg", "bhg"])
+def test_one_hint_and_hint_gradient_training_step_vs_reference(scene_states, vt):
+    """One training step of the shadow-only / specular-only models and of the full model with shadow_hint_gradient /
+    specular_hint_gradient / both (:379, :589): loss and the recorded gradient tensors."""
     from nrhints_amd.synthetic import one_hint_state
     g = load_npz("render_branches_b.npz")
     rays = [T(g["t." + k]) for k in ("o", "d", "pl", "near", "far")]
-    for vt, shadow in (("sho", True), ("spo", False)):
-        st = {k: T(np.asarray(v)).clone().requires_grad_(True) for k, v in one_hint_state(scene_states["b"], shadow).items()}
+    shadow, specular = vt != "spo", vt != "sho"
+    base = one_hint_state(scene_states["b"], shadow) if vt in ("sho", "spo") else scene_states["b"]
+    for _ in (0,):
+        st = {k: T(np.asarray(v)).clone().requires_grad_(True) for k, v in base.items()}
         out = orc.render_forward(orc.params_from_state(st), *rays, background_rgb=torch.ones(1, 3), is_training=True,
                                  global_step=int(g["t.global_step"]), t_rand_primary=T(g[f"{vt}.t_rand_primary"]),
                                  t_rand_shadow=T(g[f"{vt}.t_rand_shadow"]) if shadow else None, mode="as_written",
-                                 differentiable=True, shadow_hint=shadow, specular_hint=not shadow)
+                                 differentiable=True, shadow_hint=shadow, specular_hint=specular,
+                                 shadow_hint_gradient=vt in ("shg", "bhg"), specular_hint_gradient=vt in ("spg", "bhg"))
         np.testing.assert_allclose(out["rgb"].detach().numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=5e-5)
         loss, _, _ = orc.train_loss(out, T(g["t.rgb_gt"]))
         np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)
