@@ -127,6 +127,11 @@ int nrh_weight_norm_fold_backward(int nlayers, const int* rows, const int* cols,
  *             -> zbar [4][P][256], fbar [P,256] (adjoint of feat), mbar [P][128 | 64] (adjoint of the non-feature input)
  *   weight gradients are GEMMs over these arrays on the caller's side:  dW_l = zbar[l]^T save_h[l-1], ... */
 long long nrh_color_transposed_floats(int hints);
+/* nrh_color_train_forward with the per-ray table indexed per GROUP of `samples_per_row` consecutive samples (a power of two
+ * <= 128; 128 = per ray): raymisc [nrays * 128 / samples_per_row, 100].  The partial visibility hint's training forward. */
+int nrh_color_train_forward_grouped(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                                    const float* pts, const float* normal, const float* raymisc, int samples_per_row, long long nrays,
+                                    float* color, float* save_h, float* save_misc, void* stream);
 int nrh_color_train_forward(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
                             const float* pts, const float* normal, const float* raymisc, long long nrays, float* color,
                             float* save_h, float* save_misc, void* stream);
@@ -212,6 +217,11 @@ typedef struct NrhNet {
   int shadow_jvp;           /* 1 (with sdf_w32): the shadow march's last evaluation uses nrh_sdf_eval mode 3 - value + derivative
                                ALONG the ray in forward mode, returned as rd * (d sdf / dt) / |rd|^2 in place of the gradient:
                                get_alpha only uses <dirs, gradients> (models/neus_hint_model.py:343) */
+  int shadow_clip;          /* renderer.n_shadow_importance_clip (models/neus_hint_model.py:553-575): -1 / 0 = one shadow ray per
+                               primary ray, aimed at the hit point; 1, 2, 4, 8 or 16 = the partial visibility hint - one shadow ray
+                               per group of 128 / clip consecutive samples, aimed at the group's first sample position; the
+                               `visibilities` output is then the group value at the maximal-weight sample, t_rand_shadow is
+                               [nrays * clip, 64] (row ray * clip + group) and NrhTrainSaves.raymisc [nrays * clip, 100] */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);
@@ -243,6 +253,8 @@ typedef struct NrhTrainSaves {
   float* shadow_mid_z;  /* optional [nrays,128]: section mid-points along the shadow ray light -> hit point ... */
   float* shadow_dists;  /* optional [nrays,128]: ... and section lengths (get_visibility :411-415), for callers that differentiate
                            the visibility hint (renderer.shadow_hint_gradient); NULL = kept in the workspace */
+  float* vis_groups;    /* optional [nrays, clip]: the partial visibility hint per sample group (NrhNet.shadow_clip > 0; the
+                           `visibilities` output is only the value at the maximal-weight sample); NULL = kept in the workspace */
 } NrhTrainSaves;
 int nrh_render_forward_train(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
                              const float* nears, const float* fars, long long nrays, float cos_anneal,

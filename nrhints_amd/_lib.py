@@ -20,7 +20,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
-            "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_backward",
+            "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_forward_grouped", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
             "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite", "nrh_sphere_trace", "nrh_sphere_trace_workspace_floats",
@@ -33,7 +33,7 @@ class NrhNet(Structure):
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
                 ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
-                ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int)]
+                ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int), ("shadow_clip", c_int)]
 
 
 class NrhAdamTensor(Structure):
@@ -44,7 +44,7 @@ class NrhAdamTensor(Structure):
 class NrhTrainSaves(Structure):
     _fields_ = [("sdf", c_void_p), ("feat_rows", c_void_p), ("save_h", c_void_p), ("save_s1", c_void_p),
                 ("save_t", c_void_p), ("save_ge", c_void_p), ("raymisc", c_void_p), ("shadow_mid_z", c_void_p),
-                ("shadow_dists", c_void_p)]
+                ("shadow_dists", c_void_p), ("vis_groups", c_void_p)]
 
 
 class HipExtensionMissing(RuntimeError):
@@ -82,6 +82,7 @@ def load():
     lib.nrh_color_transposed_floats.argtypes = [c_int]
     lib.nrh_color_transposed_floats.restype = c_longlong
     lib.nrh_color_train_forward.argtypes = [c_int, c_int, P, P, P, P, P, P, c_longlong, P, P, P, P]
+    lib.nrh_color_train_forward_grouped.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_longlong, P, P, P, P]
     lib.nrh_color_train_backward.argtypes = [c_int, c_int, P, P, P, c_longlong, P, P, P, P]
     PP = POINTER(c_void_p)
     lib.nrh_weight_norm_fold.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, P]
@@ -181,7 +182,8 @@ def stream_handle(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False):
+def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False,
+             shadow_clip=-1):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
     ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""
@@ -194,4 +196,4 @@ def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fu
                   hints, normal_type, depth_type, ptr(dyn_scalars),
                   ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
                   ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None,
-                  int(bool(shadow_jvp and w32 is not None)))
+                  int(bool(shadow_jvp and w32 is not None)), int(shadow_clip))

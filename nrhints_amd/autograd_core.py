@@ -96,22 +96,23 @@ class ColorNetHip(torch.autograd.Function):
         lib = _lib.load()
         hints = bool(packed["hints"])
         dev = feat.device
-        n = ray_enc.shape[0]
-        Pn = n * 128
+        Pn = feat.shape[0]
+        n = Pn // 128
+        rows = ray_enc.shape[0]       # one per ray, or one per group of 128 / clip samples (partial visibility hint)
         f32c = lambda t: t.detach().to(torch.float32).contiguous()
         feat_c, pts_c, nrm_c = f32c(feat), f32c(pts), f32c(normal)
-        raymisc = torch.zeros(n, packing.RAYMISC_STRIDE, dtype=torch.float32, device=dev)
+        raymisc = torch.zeros(rows, packing.RAYMISC_STRIDE, dtype=torch.float32, device=dev)
         raymisc[:, :ray_enc.shape[1]] = ray_enc.detach()
         mw = 128 if hints else 64
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         color, save_h, save_misc = new(Pn, 3), new(4, Pn, 256), new(Pn, mw)
         P = _lib.ptr
         cw = packed["col_w"]
-        _lib.check(lib.nrh_color_train_forward(packed["precision"], int(hints), P(cw, cw.dtype), P(packed["col_b"]), P(feat_c), P(pts_c),
-                                               P(nrm_c), P(raymisc), n, P(color), P(save_h), P(save_misc), _lib.stream_handle()),
-                   "nrh_color_train_forward")
+        _lib.check(lib.nrh_color_train_forward_grouped(packed["precision"], int(hints), P(cw, cw.dtype), P(packed["col_b"]), P(feat_c),
+                                                       P(pts_c), P(nrm_c), P(raymisc), Pn // rows, n, P(color), P(save_h), P(save_misc),
+                                                       _lib.stream_handle()), "nrh_color_train_forward")
         ctx.save_for_backward(feat_c, color, save_h, save_misc)
-        ctx.packed, ctx.n, ctx.enc_width = packed, n, ray_enc.shape[1]
+        ctx.packed, ctx.n, ctx.enc_width, ctx.rows = packed, n, ray_enc.shape[1], rows
         ctx.shapes = [tuple(t.shape) for t in params]
         return color
 
@@ -133,7 +134,7 @@ class ColorNetHip(torch.autograd.Function):
         _lib.check(lib.nrh_color_train_backward(packed["precision"], int(hints), P(cwt, cwt.dtype), P(zbar4), P(save_h), n, P(zbar),
                                                 P(fbar), P(mbar), _lib.stream_handle()), "nrh_color_train_backward")
         nm = 105 if hints else 60
-        grads_in = (fbar, mbar[:, 0:3], mbar[:, 3:6], mbar[:, 6:nm].reshape(n, 128, nm - 6).sum(1), None)
+        grads_in = (fbar, mbar[:, 0:3], mbar[:, 3:6], mbar[:, 6:nm].reshape(ctx.rows, Pn // ctx.rows, nm - 6).sum(1), None)
         if not any(ctx.needs_input_grad[5:]):
             return grads_in + (None,) * 10
         # weight gradients: one split-K bf16x3 MFMA launch (csrc/nrh_dw.hip), bias gradients = its column sums
@@ -217,6 +218,9 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     per_ray = [_enc(dirs, 4), _enc(pl, 4)]
     if vis is not None:  # vis / cue are None for the pl-naive model (no hints)
         per_ray += [_enc(vis, 4), _enc(cue, 4)]
+        clip = vis.shape[0] // n
+        if clip > 1:     # partial visibility hint: vis [N * clip, 1], one row per group of 128 / clip samples (:553-570)
+            per_ray = [t if t.shape[0] == n * clip else t.repeat_interleave(clip, dim=0) for t in per_ray]
     normal = grad if analytic_normal else n_hat
     # reflectance net: forward and adjoint sweep in the HIP register-chain kernels, dW as split-K GEMMs
     col = ColorNetHip.apply(feat, pts, normal, torch.cat(per_ray, dim=-1), packed,

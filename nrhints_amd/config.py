@@ -109,7 +109,8 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
          "n_samples/n_importance_samples/up_sample_steps must be 64/64/4"),
         (r.n_shadow_samples == 64 and r.n_shadow_importance_samples == 64,
          "n_shadow_samples/n_shadow_importance_samples must be 64/64"),
-        (r.n_shadow_importance_clip == -1, "only the hit-point shadow mode (n_shadow_importance_clip=-1) is implemented"),
+        (r.n_shadow_importance_clip in (-1, 1, 2, 4, 8, 16) or not r.shadow_hint,
+         "n_shadow_importance_clip must be -1 (hit point) or 1, 2, 4, 8, 16 (partial visibility hint: that many shadow rays per ray)"),
         # force_* only adds the hint to has_*_hint (models/neus_hint_model.py:239-240): a no-op when the hint is on; with the hint
         # off the reference itself cannot run - the reflectance net's first layer is sized for the hint (:246-250) but built
         # without it (:256-257), so ReflectanceNetwork.forward never appends it (fields/reflectance_network.py:82-86) and lin0

@@ -195,7 +195,7 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
 
 int color_eval_impl(int prec, int hints, const float* w, const float* b, const float* feat, const float* ro, const float* rd,
                     const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
-                    hipStream_t st, int fused = 0) {
+                    hipStream_t st, int fused = 0, int misc_shift = 7) {
   if (!w || !b || !feat || !ro || !rd || !tmid || !nhat || !raymisc || !color)
     return fail(NRH_E_INVALID, "nrh_color_eval: null pointer%s", "");
   if (nrays == 0) return NRH_OK;
@@ -203,7 +203,7 @@ int color_eval_impl(int prec, int hints, const float* w, const float* b, const f
   if (rc) return rc;
   nrh::ColorArgs a;
   a.w = w; a.b = b; a.feat = feat; a.ro = ro; a.rd = rd; a.tmid = tmid; a.nhat = nhat; a.raymisc = raymisc;
-  a.color = color;
+  a.color = color; a.misc_shift = misc_shift;
   a.npts = nrays * 128;
   const long long groups = (a.npts + 16 * nrh::WG_WAVES - 1) / (16 * nrh::WG_WAVES);
   if (groups > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_color_eval: too many points%s", "");
@@ -276,7 +276,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 129; }
+int nrh_version(void) { return 130; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -466,6 +466,17 @@ int nrh_sdf32_tables(const float* const* sdf_bias, const int* rows, const float*
 int nrh_color_train_forward(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
                             const float* pts, const float* normal, const float* raymisc, long long nrays, float* color,
                             float* save_h, float* save_misc, void* stream) {
+  return nrh_color_train_forward_grouped(precision, hints, col_w, col_b, feat_rows, pts, normal, raymisc, 128, nrays, color, save_h,
+                                         save_misc, stream);
+}
+
+int nrh_color_train_forward_grouped(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                                    const float* pts, const float* normal, const float* raymisc, int samples_per_row, long long nrays,
+                                    float* color, float* save_h, float* save_misc, void* stream) {
+  int misc_shift = 0;
+  while ((1 << misc_shift) < samples_per_row) ++misc_shift;
+  if (samples_per_row < 1 || samples_per_row > 128 || (1 << misc_shift) != samples_per_row)
+    return fail(NRH_E_INVALID, "nrh_color_train_forward: samples_per_row must be a power of two <= 128%s", "");
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_color_train_forward: precision must be 0 (f32) or 1 (f16x3)%s", "");
   if (!col_w || !col_b || !feat_rows || !pts || !normal || !raymisc || !color || !save_h || !save_misc)
     return fail(NRH_E_INVALID, "nrh_color_train_forward: null pointer%s", "");
@@ -477,7 +488,7 @@ int nrh_color_train_forward(int precision, int hints, const float* col_w, const 
   memset(&a, 0, sizeof(a));
   a.w = col_w; a.b = col_b; a.feat = feat_rows; a.pts = pts; a.nhat = normal; a.raymisc = raymisc; a.color = color;
   a.ro = pts; a.rd = pts; a.tmid = pts;  // unused in the training instantiation
-  a.save_h = save_h; a.save_misc = save_misc;
+  a.save_h = save_h; a.save_misc = save_misc; a.misc_shift = misc_shift;
   a.npts = nrays * 128;
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_color_train_forward");
@@ -715,7 +726,7 @@ int nrh_color_eval(int precision, int hints, const float* col_w, const float* co
   X(zbuf, 128) X(sbuf, 128) X(znew, 16) X(snew, 16) X(tmid, 128) X(dists, 128) X(sdf_c, 128) X(grad_c, 384)          \
   X(feat, 32768) X(weights, 128) X(inside, 128) X(nhat, 384) X(depth, 1) X(wsum, 1) X(cue, 4) X(srd, 3) X(slast, 1)  \
   X(tmid_s, 128) X(dists_s, 128) X(sdf_s, 128) X(grad_s, 384) X(vis, 1) X(raymisc, nrh::RAYMISC_STRIDE)              \
-  X(color, 384) X(cue_b, 512)
+  X(color, 384) X(cue_b, 512) X(raymisc_g, nrh::MAX_SHADOW_CLIP * nrh::RAYMISC_STRIDE)
 
 int nrh_generate_rays(const float* pose /* host, 12 */, const float* pl /* host, 3 */, float cx, float cy, float fx, float fy,
                       int width, int row0, int nrows, float* origins, float* directions, float* pl_positions,
@@ -856,6 +867,11 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
       net->depth_type < 0 || net->depth_type > 2)
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type must be 0 or 1, depth_type 0, 1 or 2%s", "");
   const int no_hints = zero_hints || !net->hints;  // no shadow march: geometry warm-up, or the pl-naive model
+  if (net->shadow_clip != 0 && net->shadow_clip != -1 &&
+      (net->shadow_clip < 1 || net->shadow_clip > nrh::MAX_SHADOW_CLIP || (net->shadow_clip & (net->shadow_clip - 1)) != 0))
+    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: shadow_clip (n_shadow_importance_clip) must be -1 / 0 (hit point) or a power of two <= 16%s", "");
+  // partial visibility hint (n_shadow_importance_clip > 0): one shadow ray per group of 128 / clip samples instead of one per ray
+  const int clip = (!no_hints && net->shadow_clip > 0) ? net->shadow_clip : 0;
   if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || (!rgb && !train) || !workspace)
     return fail(NRH_E_INVALID, "nrh_render_forward: null pointer%s", "");
   if (train && (!train->sdf || !train->feat_rows || !train->save_h || !train->save_s1 || !train->save_t || !train->save_ge))
@@ -897,6 +913,8 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   int rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f,
                        o_tmid, o_dists, n, st);
   if (rc) return rc;
+  if (clip && hipMemcpyAsync(ws_cue_b, ws_zbuf, sizeof(float) * 128 * n, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(NRH_E_LAUNCH, "nrh_render_forward: copy of the sample positions failed%s", "");   // z_vals for the group targets
   // ---- render_core: sdf + feature + gradient at the 128 section mid-points ----
   float* sdf_c = train ? train->sdf : ws_sdf_c;
   if (train) {
@@ -933,7 +951,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     if (rc) return rc;
   }
   // ---- shadow rays light -> hit point ----
-  if (!no_hints) {
+  if (!no_hints && !clip) {
     rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, o_tmid_s,
                      o_dists_s, n, st);
     if (rc) return rc;
@@ -948,17 +966,54 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = o_dists_s;
     c.cue = ws_cue; c.vis = o_vis; c.raymisc = (train && train->raymisc) ? train->raymisc : ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
     c.dyn = net->dyn_scalars;
-    c.nrays = (int)n; c.zero_hints = no_hints;
+    c.nrays = (int)n; c.zero_hints = no_hints || clip; c.row_mul = 0; c.row_off = 0;   // clip: rows rewritten per group below
     hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
     rc = check_launch("shadow_finish_kernel");
     if (rc) return rc;
+  }
+  // ---- partial visibility hint: one shadow ray per group of 128 / clip samples (n_shadow_importance_clip > 0, :553-575) ----
+  const float* raymisc_rows = ws_raymisc;   // what the reflectance kernel reads, and at how many samples per row
+  int misc_shift = 7;
+  if (clip) {
+    const int ratio = 128 / clip;
+    float* rows = (train && train->raymisc) ? train->raymisc : ws_raymisc_g;   // [n * clip, RAYMISC_STRIDE]
+    float* visg = (train && train->vis_groups) ? train->vis_groups : ws_cue_b + 128 * n;   // [n, clip]
+    for (int g = 0; g < clip; ++g) {
+      nrh::PartialSetupArgs ps;
+      ps.ro = origins; ps.rd = directions; ps.pl = pl_positions; ps.z = ws_cue_b /* the kept z_vals */; ps.lin64 = lin64;
+      ps.t_rand_shadow = t_rand_shadow; ps.srd = ws_srd; ps.slast = ws_slast; ps.zs = ws_zbuf; ps.shadow_offset = 1e-2f;
+      ps.z_index = g * ratio; ps.clip = clip; ps.group = g; ps.nrays = (int)n;
+      hipLaunchKernelGGL(nrh::partial_shadow_setup_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ps);
+      rc = check_launch("partial_shadow_setup_kernel");
+      if (rc) return rc;
+      rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s, ws_dists_s, n, st);
+      if (rc) return rc;
+      rc = sdf_eval_impl(net->precision, 1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
+                         128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
+      if (rc) return rc;
+      nrh::ShadowArgs c;
+      c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = ws_dists_s;
+      c.cue = ws_cue; c.vis = visg; c.raymisc = rows; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal; c.dyn = net->dyn_scalars;
+      c.nrays = (int)n; c.zero_hints = 0; c.row_mul = clip; c.row_off = g;
+      hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
+      rc = check_launch("shadow_finish_kernel");
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(nrh::partial_shadow_map_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const float*)o_weights,
+                       (const float*)visg, o_vis, clip, (int)n);
+    rc = check_launch("partial_shadow_map_kernel");
+    if (rc) return rc;
+    raymisc_rows = rows;
+    misc_shift = 0;
+    while ((1 << misc_shift) < ratio) ++misc_shift;
   }
   if (train) return NRH_OK;  // reflectance + composite are differentiated by the caller
   // ---- reflectance + composite ----
   // feat_fused: ws_feat holds W0feat * feature (the wide mode-2 stream was packed with the product matrix)
   const int fused = (net->precision == 1 && net->feat_fused && net->sdf_w32 && net->sdf_tab32) ? 1 : 0;
-  if (fused && net->hints && net->col_w32 && net->col_tab32) {
-    // the reflectance net on the wide machinery too (csrc/nrh_color32.hip)
+  if (fused && net->hints && net->col_w32 && net->col_tab32 && !clip) {
+    // the reflectance net on the wide machinery too (csrc/nrh_color32.hip; one raymisc row per workgroup pass = per ray, so
+    // the partial shadow mode with its row per sample group stays on the 16-point kernel)
     nrh32::WideColorCall c;
     c.stream = net->col_w32; c.tables = net->col_tab32; c.part = ws_feat; c.ro = origins; c.rd = directions; c.tmid = o_tmid;
     c.nhat = net->normal_type ? o_grad : o_nhat; c.raymisc = ws_raymisc; c.color = ws_color; c.nrays = n;
@@ -972,7 +1027,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     rc = check_launch("color32_kernel");
   } else {
     rc = color_eval_impl(net->precision, net->hints, net->col_w, net->col_b, ws_feat, origins, directions, o_tmid,
-                         net->normal_type ? o_grad : o_nhat, ws_raymisc, n, ws_color, st, fused);
+                         net->normal_type ? o_grad : o_nhat, raymisc_rows, n, ws_color, st, fused, misc_shift);
   }
   if (rc) return rc;
   {

@@ -28,6 +28,8 @@ struct ColorArgs {
   const float* pts;      // [npts,3]
   float* save_h;         // [4][npts][256]  ReLU outputs of layers 0..3
   float* save_misc;      // [npts][16*MKB]  the non-feature part of the layer-0 input in kernel order
+  int misc_shift;        // sample P reads row P >> misc_shift of raymisc: 7 = one row per ray; smaller for the partial shadow
+                         // mode (n_shadow_importance_clip: one row per group of 128 / clip consecutive samples)
 };
 // adjoint sweep of the reflectance net (csrc/nrh_color.hip color_adjoint_kernel)
 struct ColorAdjArgs {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
         pn[c] = TRAIN ? a.pts[Pc * 3 + c] : a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt;
         pn[3 + c] = a.nhat[Pc * 3 + c];
       }
-      const float* rm = a.raymisc + ray * RAYMISC_STRIDE;
+      const float* rm = a.raymisc + (Pc >> a.misc_shift) * RAYMISC_STRIDE;
 #pragma unroll
       for (int ch = 0; ch < MKB / 2; ++ch) {
         float o[8];

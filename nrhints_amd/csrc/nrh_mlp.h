@@ -285,5 +285,6 @@ constexpr int COL_PACKED_FLOATS = col_packed_floats(8);
 constexpr int COL_BIAS_FLOATS = 4 * 256 + 16;
 __host__ __device__ constexpr int col_misc(int mkb) { return mkb == 8 ? 105 : 60; }  // [p 3, n 3, enc4(view) 27, enc4(pl) 27 (, enc4(vis) 9, enc4(cue) 36)]
 constexpr int RAYMISC_STRIDE = 100;  // per-ray part of the above: 27 + 27 + 9 + 36 = 99 (+1 pad)
+constexpr int MAX_SHADOW_CLIP = 16;   // largest n_shadow_importance_clip the workspace carve-up provides rows for
 
 }  // namespace nrh

@@ -408,6 +408,8 @@ struct ShadowArgs {
   const float* dyn;     // optional device [inv_s, cos_anneal], see CoreArgs
   int nrays;
   int zero_hints;       // geometry warm-up: hints are zero (models/neus_hint_model.py:577-579, 617-619)
+  int row_mul, row_off; // vis / raymisc row of ray r: r * row_mul + row_off (0, 0 = r; the partial shadow mode writes group g of
+                        // clip groups per ray: row_mul = clip, row_off = g)
 };
 
 __device__ __forceinline__ float enc4_entry_dyn(const float* x, int D, int e) {
@@ -446,7 +448,8 @@ __global__ __launch_bounds__(256) void shadow_finish_kernel(const ShadowArgs a) 
   if (lane >= 7 && lane < 11) V[lane] = a.zero_hints ? 0.0f : a.cue[ray * 4 + lane - 7];
   __syncthreads();
   if (active) {
-    if (lane == 0) a.vis[ray] = vis;
+    const long long row = a.row_mul ? ray * a.row_mul + a.row_off : ray;
+    if (lane == 0) a.vis[row] = vis;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int i = lane + 64 * e;
@@ -456,10 +459,74 @@ __global__ __launch_bounds__(256) void shadow_finish_kernel(const ShadowArgs a) 
         else if (i < 54) v = enc4_entry_dyn(V + 3, 3, i - 27);  // enc4(light position, un-normalised)
         else if (i < 63) v = enc4_entry_dyn(V + 6, 1, i - 54);  // enc4(visibility)
         else v = enc4_entry_dyn(V + 7, 4, i - 63);              // enc4(specular cue)
-        a.raymisc[ray * RAYMISC_STRIDE + i] = v;
+        a.raymisc[row * RAYMISC_STRIDE + i] = v;
       }
     }
   }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Partial visibility hint (n_shadow_importance_clip > 0, models/neus_hint_model.py:553-575): a shadow ray per group of
+// 128 / clip consecutive samples, aimed at the group's first sample position z[ray, g * ratio] (z_vals, not the mid-points).
+// One wave per ray sets up group g's shadow ray exactly as core_alpha_kernel does for the hit point (get_visibility :380-395).
+// -------------------------------------------------------------------------------------------------
+struct PartialSetupArgs {
+  const float* ro;
+  const float* rd;
+  const float* pl;
+  const float* z;              // [N,128] sorted sample positions of the primary ray
+  const float* lin64;
+  const float* t_rand_shadow;  // [N*clip,64] or null; row ray * clip + g
+  float* srd;                  // [N,3]
+  float* slast;                // [N]
+  float* zs;                   // [N,128] (first 64: coarse shadow samples)
+  float shadow_offset;
+  int z_index;                 // g * ratio
+  int clip, group;
+  int nrays;
+};
+
+__global__ __launch_bounds__(256) void partial_shadow_setup_kernel(const PartialSetupArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long ray = (long long)blockIdx.x * RAYS_PER_BLOCK + wave;
+  if (ray >= a.nrays) return;
+  const float zt = a.z[ray * 128 + a.z_index];
+  const float hx = a.ro[ray * 3 + 0] + a.rd[ray * 3 + 0] * zt, hy = a.ro[ray * 3 + 1] + a.rd[ray * 3 + 1] * zt,
+              hz = a.ro[ray * 3 + 2] + a.rd[ray * 3 + 2] * zt;
+  const float svx = hx - a.pl[ray * 3 + 0], svy = hy - a.pl[ray * 3 + 1], svz = hz - a.pl[ray * 3 + 2];
+  const float L = sqrtf(svx * svx + svy * svy + svz * svz);
+  const float om = 1.0f - a.shadow_offset;
+  float zj = a.lin64[lane] * L * om;
+  if (a.t_rand_shadow) {
+    const float zp = (lane > 0) ? a.lin64[lane - 1] * L * om : zj;
+    const float zn = (lane < 63) ? a.lin64[lane + 1] * L * om : zj;
+    const float lower = (lane > 0) ? 0.5f * (zj + zp) : zj;
+    const float upper = (lane < 63) ? 0.5f * (zn + zj) : zj;
+    zj = lower + (upper - lower) * a.t_rand_shadow[(ray * a.clip + a.group) * 64 + lane];
+  }
+  a.zs[ray * 128 + lane] = zj;
+  if (lane == 0) {
+    a.srd[ray * 3 + 0] = svx / L;
+    a.srd[ray * 3 + 1] = svy / L;
+    a.srd[ray * 3 + 2] = svz / L;
+    a.slast[ray] = L / 64.0f;
+  }
+}
+
+// shadow_map = the group visibility at the maximal-weight sample (:573-574; first index on ties, torch.argmax)
+__global__ __launch_bounds__(256) void partial_shadow_map_kernel(const float* weights, const float* vis_groups, float* shadow_map,
+                                                                 int clip, int nrays) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long ray = (long long)blockIdx.x * RAYS_PER_BLOCK + wave;
+  if (ray >= nrays) return;
+  const float w0 = weights[ray * 128 + lane], w1 = weights[ray * 128 + lane + 64];
+  float wmax = fmaxf(w0, w1);
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o2, 64));
+  int idx = (w0 == wmax) ? lane : ((w1 == wmax) ? lane + 64 : 1 << 20);
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) idx = min(idx, __shfl_xor(idx, o2, 64));
+  if (lane == 0) shadow_map[ray] = vis_groups[ray * clip + idx / (128 / clip)];
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -133,6 +133,8 @@ class NeuSHintRenderer(nn.Module):
         # hint's columns of the reflectance net's first layer are zero (see _pad_hint_columns), its output is reported as None
         self._hints = 1 if (self.has_shadow_hint or self.has_specular_hint) else 0
         self._mixed_hints = self.has_shadow_hint != self.has_specular_hint
+        # partial visibility hint (:553-575): shadow rays per group of samples instead of per ray; -1 = the hit-point mode
+        self._shadow_clip = int(config.renderer.n_shadow_importance_clip) if self.has_shadow_hint else -1
         self._normal_type = 1 if config.renderer.normal_type == NormalComputationType.Analytic else 0
         self._depth_type = {DepthComputationType.AlphaBlend: 0, DepthComputationType.MaximalWeightPoint: 1,
                             DepthComputationType.SphereTracing: 2}[config.renderer.depth_type]
@@ -284,7 +286,12 @@ class NeuSHintRenderer(nn.Module):
             # same draw order as the reference: primary jitter [N,1] (:682), then shadow jitter [N,64] (:394)
             t_rand_p = f32(_t_rand_primary).reshape(-1) if _t_rand_primary is not None else torch.rand(n, device=device)
             if not zero_hints:
-                t_rand_s = f32(_t_rand_shadow) if _t_rand_shadow is not None else torch.rand(n, 64, device=device)
+                # one row of 64 per shadow ray: per primary ray (:394), or per sample group in the partial mode (same order as the
+                # reference's mini-batches over the flattened [ray, group] list, :560-568)
+                rows = n * max(1, self._shadow_clip)
+                t_rand_s = f32(_t_rand_shadow) if _t_rand_shadow is not None else torch.rand(rows, 64, device=device)
+                if t_rand_s.shape != (rows, 64):
+                    raise ValueError(f"_t_rand_shadow must be [{rows}, 64]")
         bg = None
         if background_rgb is not None:
             bg = f32(background_rgb.to(device)).reshape(-1)
@@ -302,6 +309,10 @@ class NeuSHintRenderer(nn.Module):
         rcfg = cfg.renderer
         shadow_grad = bool(needs_grad and rcfg.shadow_hint_gradient and self.has_shadow_hint and not zero_hints)
         specular_grad = bool(needs_grad and rcfg.specular_hint_gradient and self.has_specular_hint and not zero_hints)
+        if self._shadow_clip > 0 and needs_grad and not fused_train:
+            raise ValueError(f"training with n_shadow_importance_clip > 0 needs the batch in one call (at most max_fused_train_rays = {self.max_fused_train_rays} rays)")
+        if self._shadow_clip > 0 and shadow_grad:
+            raise NotImplementedError("shadow_hint_gradient together with n_shadow_importance_clip > 0 is not implemented")
         if (shadow_grad or specular_grad) and not fused_train:
             raise ValueError(f"hint gradients need the batch in one training call (at most max_fused_train_rays = {self.max_fused_train_rays} rays)")
         if shadow_grad and any(t.requires_grad for t in (o_g, d_g, pl_g)):
@@ -322,7 +333,7 @@ class NeuSHintRenderer(nn.Module):
             # differentiable part (render_core) over the HIP results; see autograd_core.py
             core = autograd_core.render_core(
                 dense, self.deviation_network.variance, o_g.to(torch.float32), d_g.to(torch.float32),
-                pl_g.to(torch.float32), mid_z, dists, vis if self._hints else None,
+                pl_g.to(torch.float32), mid_z, dists, (res.get("vis_groups", vis) if self._hints else None),
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
                 packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars if is_training else None,
@@ -361,7 +372,8 @@ class NeuSHintRenderer(nn.Module):
         n = o.shape[0]
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
-        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels)
+        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels,
+                            shadow_clip=self._shadow_clip)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
@@ -373,8 +385,10 @@ class NeuSHintRenderer(nn.Module):
         sv = pre["saves"]
         if want_shadow:       # shadow_hint_gradient: the shadow ray's sections, for the differentiable visibility of render_core
             out.update(shadow_mid_z=new(n, T), shadow_dists=new(n, T))
+        if self._shadow_clip > 0 and not zero_hints:
+            out.update(vis_groups=new(n * self._shadow_clip, 1))
         saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]), P(raymisc),
-                                   P(out.get("shadow_mid_z")), P(out.get("shadow_dists")))
+                                   P(out.get("shadow_mid_z")), P(out.get("shadow_dists")), P(out.get("vis_groups")))
         ws = self._workspace(device, n)
         rc = lib.nrh_render_forward_train(
             net, P(o), P(d), P(pl), P(near), P(far), n, cos_anneal, P(t_rand_p) if t_rand_p is not None else None,
@@ -409,7 +423,7 @@ class NeuSHintRenderer(nn.Module):
             pk = dict(pk, inv_s=self._host_inv_s(pk, device))
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
                             wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color,
-                            shadow_jvp=self.shadow_jvp)
+                            shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))
@@ -428,13 +442,14 @@ class NeuSHintRenderer(nn.Module):
         stream = _lib.stream_handle()
         P = _lib.ptr
         opt = lambda key, sl: P(out[key][sl]) if key in out else None
+        rows_per_ray = max(1, self._shadow_clip)      # rows of the shadow jitter per primary ray
         for i in range(0, n, chunk):
             m = min(chunk, n - i)
             sl = slice(i, i + m)
             rc = lib.nrh_render_forward(
                 net, P(o[sl]), P(d[sl]), P(pl[sl]), P(near[sl]), P(far[sl]), m, P(bg), cos_anneal,
                 P(t_rand_p[sl]) if t_rand_p is not None else None,
-                P(t_rand_s[sl]) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16),
+                P(t_rand_s[i * rows_per_ray:(i + m) * rows_per_ray]) if t_rand_s is not None else None, zero_hints, P(lin64), P(lin16),
                 P(out["rgb"][sl]), P(out["depth"][sl]), opt("weights", sl), opt("inside", sl), opt("normals", sl),
                 opt("nhat", sl), P(out["visibilities"][sl]), P(cue_scratch) if cue_scratch is not None else opt("cue", sl),
                 opt("mid_z", sl), opt("dists", sl),

@@ -33,6 +33,8 @@ def supported(renderer, ray_bundle) -> Optional[str]:
     rc = renderer.config.renderer
     if (rc.shadow_hint_gradient and renderer.has_shadow_hint) or (rc.specular_hint_gradient and renderer.has_specular_hint):
         return "hint gradients (differentiated by the autograd path)"
+    if getattr(renderer, "_shadow_clip", -1) > 0:
+        return "partial visibility hint (n_shadow_importance_clip > 0)"
     if getattr(renderer, "_mixed_hints", False):
         return "one hint without the other (zero-padded first reflectance layer)"
     if any(t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):

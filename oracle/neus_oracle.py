@@ -337,7 +337,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    mode="minimal", keep_intermediates=False, differentiable=False, hints=True,
                    analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0,
                    depth_sphere_tracing=False, shadow_hint=None, specular_hint=None, shadow_hint_gradient=False,
-                   specular_hint_gradient=False) -> Dict[str, torch.Tensor]:
+                   specular_hint_gradient=False, n_shadow_importance_clip=-1) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
@@ -381,8 +381,19 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
         else:
             depth = (mid * weights).sum(-1, keepdim=True)      # :531-533 (no_grad)
             hit = o + d * depth
+        vis_samples = None
         if shadow_hint and warmup:
             vis = torch.zeros(n, 1, dtype=dt)                  # :577-579 (shadow_map = zeros)
+        elif shadow_hint and n_shadow_importance_clip > 0:
+            # partial visibility hint (:553-575): one shadow ray per group of 128 / clip samples, aimed at z_vals[:, g * ratio]
+            clip = n_shadow_importance_clip
+            ratio = 128 // clip
+            zt = z[:, torch.arange(0, 128, ratio)]
+            tgt = (o[:, None, :] + d[:, None, :] * zt[..., None]).reshape(-1, 3)
+            pls_g = pl[:, None, :].repeat(1, clip, 1).reshape(-1, 3)
+            vg = visibility(p, pls_g, tgt, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode).reshape(n, clip, 1)
+            vis_samples = vg.repeat_interleave(ratio, dim=1)                               # [n,128,1]
+            vis = torch.gather(vis_samples[..., 0], 1, torch.argmax(weights, dim=1, keepdim=True))   # shadow_map (:573-574)
         elif not (shadow_hint and shadow_hint_gradient and differentiable):
             vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode) \
                 if shadow_hint else None                       # :546-551, :379
@@ -392,7 +403,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
     vis_s = cue_s = None
     if shadow_hint:
-        vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1)
+        vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1) if vis_samples is None else vis_samples.reshape(-1, 1)
     if specular_hint:
         with torch.enable_grad() if (specular_hint_gradient and differentiable) else torch.no_grad():   # :589
             cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :590-615, :617-619

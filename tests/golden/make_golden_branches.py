@@ -10,6 +10,7 @@ Variants, all on scene b's weights (nrhints_amd.synthetic.perturb_state of the r
   sho   shadow hint only   (shadow_hint=True,  specular_hint=False): evaluation render + one training step's loss and gradients
   spo   specular hint only (shadow_hint=False, specular_hint=True):  the same
   frc   force_shadow_map + force_specular_cue on top of both hints (a no-op: has_*_hint = hint or force, :239-240)
+  psh   n_shadow_importance_clip = 8 (:553-575: a shadow ray per group of 16 samples): evaluation render + one training step
   shg / spg / bhg   shadow_hint_gradient / specular_hint_gradient / both (:379, :589: the hints stay inside the autograd graph):
         one training step's loss and gradients (the forward values equal the default model's)
 and the reference's own failure for force_* WITHOUT the hint (recorded as the exception's type name).
@@ -74,6 +75,7 @@ def main():
         "sho": (R(shadow_hint=True, specular_hint=False), one_hint_state(state_b, shadow=True)),
         "spo": (R(shadow_hint=False, specular_hint=True), one_hint_state(state_b, shadow=False)),
         "frc": (R(force_shadow_map=True, force_specular_cue=True), state_b),
+        "psh": (R(n_shadow_importance_clip=8), state_b),
     }
     grad_variants = {
         "shg": (R(shadow_hint_gradient=True), state_b),
@@ -105,7 +107,7 @@ def main():
     gt = torch.full((Nt, 3), 0.5)
     rec["t.rgb_gt"], rec["t.global_step"] = gt.numpy(), np.int64(20000)
     real_rand = torch.rand
-    for vt in ("sho", "spo", "shg", "spg", "bhg"):
+    for vt in ("sho", "spo", "shg", "spg", "bhg", "psh"):
         rcfg, st = variants[vt] if vt in variants else grad_variants[vt]
         drawn = []
 

@@ -250,7 +250,7 @@ def test_more_off_default_branches(scene_states):
     hit = g["st.trace_depths"][:, 0] < 100.0
     assert 0.2 < hit.mean() < 1.0                                  # both outcomes are in the batch
     assert np.abs(g["st.trace_depths"] - g["st.trace_depths_f64"])[hit].max() < 2e-4   # the reference's own fp32 noise on hits
-    cases = {"st": (dict(depth_sphere_tracing=True), sb), "frc": (dict(), sb),
+    cases = {"st": (dict(depth_sphere_tracing=True), sb), "frc": (dict(), sb), "psh": (dict(n_shadow_importance_clip=8), sb),
              "sho": (dict(shadow_hint=True, specular_hint=False), one_hint_state(sb, True)),
              "spo": (dict(shadow_hint=False, specular_hint=True), one_hint_state(sb, False))}
     for vt, (opts, st) in cases.items():
@@ -269,7 +269,7 @@ def test_more_off_default_branches(scene_states):
     assert str(g["force_shadow_only.outcome"]).startswith("RuntimeError") and str(g["force_specular_only.outcome"]).startswith("RuntimeError")
 
 
-@pytest.mark.parametrize("vt", ["sho", "spo", "shg", "spg", "bhg"])
+@pytest.mark.parametrize("vt", ["sho", "spo", "shg", "spg", "bhg", "psh"])
 def test_one_hint_and_hint_gradient_training_step_vs_reference(scene_states, vt):
     """One training step of the shadow-only / specular-only models and of the full model with shadow_hint_gradient /
     specular_hint_gradient / both (:379, :589): loss and the recorded gradient tensors."""
@@ -284,7 +284,8 @@ def test_one_hint_and_hint_gradient_training_step_vs_reference(scene_states, vt)
                                  global_step=int(g["t.global_step"]), t_rand_primary=T(g[f"{vt}.t_rand_primary"]),
                                  t_rand_shadow=T(g[f"{vt}.t_rand_shadow"]) if shadow else None, mode="as_written",
                                  differentiable=True, shadow_hint=shadow, specular_hint=specular,
-                                 shadow_hint_gradient=vt in ("shg", "bhg"), specular_hint_gradient=vt in ("spg", "bhg"))
+                                 shadow_hint_gradient=vt in ("shg", "bhg"), specular_hint_gradient=vt in ("spg", "bhg"),
+                                 n_shadow_importance_clip=8 if vt == "psh" else -1)
         np.testing.assert_allclose(out["rgb"].detach().numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=5e-5)
         loss, _, _ = orc.train_loss(out, T(g["t.rgb_gt"]))
         np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)
