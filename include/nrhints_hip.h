@@ -420,6 +420,10 @@ int nrh_adam_step(const NrhAdamTensor* tensors_dev, int ntensors, const int* chu
  *   Same roundings as the torch expressions of the packers: the result is bit-identical to them.
  * nrh_sdf32_tables: packing32.sdf32_tables - the [11][256] bias / head tables of the wide SDF kernels from the eight bias vectors
  *   (HOST array of 8 device pointers + their lengths), b_feat [256], b_s [1], w_s [256]. */
+/* packing32.fuse_feature_head: out_w [256,256] = W0[:, 60:316] W_feat, out_b [256] = W0[:, 60:316] b_feat (float64 accumulation,
+ * one rounding): the feature head multiplied into the feature block of the reflectance net's first layer (col_w0 [256, ld0]
+ * row-major, ld0 = 316 or 361) - what NrhNet.feat_fused expects in the FEAT block of the wide streams. */
+int nrh_fuse_feature_head(const float* col_w0, int ld0, const float* feat_w, const float* feat_b, float* out_w, float* out_b, void* stream);
 int nrh_pack_gather(const float* flat, const int* index, const float* factor, long long n, int mode, void* out, void* stream);
 int nrh_sdf32_tables(const float* const* sdf_bias, const int* rows, const float* feat_b, const float* head_b, const float* head_w,
                      float* tables, void* stream);

@@ -25,7 +25,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
             "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite", "nrh_sphere_trace", "nrh_sphere_trace_workspace_floats",
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
-            "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step")
+            "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step", "nrh_fuse_feature_head")
 
 
 class NrhNet(Structure):
@@ -122,6 +122,7 @@ def load():
     lib.nrh_variance_grad.argtypes = [P, c_longlong, c_float, P, P, P]
     lib.nrh_adam_step.argtypes = [P, c_int, P, c_int, c_int, POINTER(ctypes.c_double), POINTER(c_void_p), POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double), POINTER(ctypes.c_double), P]
+    lib.nrh_fuse_feature_head.argtypes = [P, c_int, P, P, P, P, P]
     lib.nrh_pack_gather.argtypes = [P, P, P, c_longlong, c_int, P, P]
     lib.nrh_sdf32_tables.argtypes = [POINTER(c_void_p), POINTER(c_int), P, P, P, P, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]

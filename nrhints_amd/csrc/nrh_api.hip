@@ -276,7 +276,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 130; }
+int nrh_version(void) { return 131; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -1039,6 +1039,13 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     if (rc) return rc;
   }
   return NRH_OK;
+}
+
+int nrh_fuse_feature_head(const float* col_w0, int ld0, const float* feat_w, const float* feat_b, float* out_w, float* out_b, void* stream) {
+  if (!col_w0 || !feat_w || !feat_b || !out_w || !out_b) return fail(NRH_E_INVALID, "nrh_fuse_feature_head: null pointer%s", "");
+  if (ld0 < 316) return fail(NRH_E_INVALID, "nrh_fuse_feature_head: the first reflectance layer has at least 316 input columns%s", "");
+  hipLaunchKernelGGL(nrh::fuse_head_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, col_w0, ld0, feat_w, feat_b, out_w, out_b);
+  return check_launch("fuse_head_kernel");
 }
 
 // ---- Adam in one launch (csrc/nrh_adam.hip) ----

@@ -142,4 +142,24 @@ __global__ __launch_bounds__(256) void sdf32_tables_kernel(const TablesArgs a) {
   a.out[r * 256 + c] = v;
 }
 
+// -------------------------------------------------------------------------------------------------
+// packing32.fuse_feature_head on the device: (W0[:, 60:316] W_feat, W0[:, 60:316] b_feat) with float64 accumulation, rounded
+// to float32 once - the feature head of the SDF net multiplied into the feature block of the reflectance net's first layer
+// (fields/sdf_field.py:119-123 -> fields/reflectance_network.py:77-84).  One thread per output entry, a 256-long dot product
+// each (16.8 M FMAs in all: not worth a library GEMM call, and it keeps rocBLAS out of the process).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fuse_head_kernel(const float* w0, int ld0, const float* feat_w, const float* feat_b,
+                                                        float* out_w, float* out_b) {
+  const int r = blockIdx.x, c = threadIdx.x;        // out_w[r][c], 256 x 256
+  const float* wr = w0 + (long long)r * ld0 + 60;
+  double acc = 0.0;
+  for (int k = 0; k < 256; ++k) acc += (double)wr[k] * (double)feat_w[k * 256 + c];
+  out_w[r * 256 + c] = (float)acc;
+  if (c == 0) {
+    double b = 0.0;
+    for (int k = 0; k < 256; ++k) b += (double)wr[k] * (double)feat_b[k];
+    out_b[r] = (float)b;
+  }
+}
+
 }  // namespace nrh

@@ -167,8 +167,22 @@ def fuse_feature_head(d: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     row (fields/sdf_field.py:119-123 -> fields/reflectance_network.py:77-84, columns 60:316 of the 316 / 361-wide input):
     replace (W_feat, b_feat) by (W0[:, 60:316] W_feat, W0[:, 60:316] b_feat), evaluated in fp64.  The mode-2 kernel then
     returns that block's contribution to the first hidden layer and the reflectance kernel skips it (NrhNet.feat_fused)."""
-    w0f = d["col_w0"].detach().double()[:, 60:316]
     out = dict(d)
+    w0 = d["col_w0"].detach()
+    if w0.is_cuda:
+        # on the device: one small HIP launch (csrc/nrh_fold.hip fuse_head_kernel) instead of two float64 library GEMM calls
+        from . import _lib
+        lib = _lib.load()
+        f32c = lambda t: t.detach().to(torch.float32).contiguous()
+        w0c, fw, fb = f32c(w0), f32c(d["feat_w"]), f32c(d["feat_b"])
+        ow, ob = torch.empty(256, 256, dtype=torch.float32, device=w0.device), torch.empty(256, dtype=torch.float32, device=w0.device)
+        with torch.cuda.device(w0.device):
+            rc = lib.nrh_fuse_feature_head(_lib.ptr(w0c), int(w0c.shape[1]), _lib.ptr(fw), _lib.ptr(fb), _lib.ptr(ow), _lib.ptr(ob),
+                                           _lib.stream_handle())
+        _lib.check(rc, "nrh_fuse_feature_head")
+        out["feat_w"], out["feat_b"] = ow, ob
+        return out
+    w0f = w0.double()[:, 60:316]
     out["feat_w"] = (w0f @ d["feat_w"].detach().double()).float()
     out["feat_b"] = (w0f @ d["feat_b"].detach().double()).float()
     return out

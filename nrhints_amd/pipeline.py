@@ -66,8 +66,9 @@ def render_image(renderer, camera: CameraModel, pose: torch.Tensor, pl: torch.Te
     bg = torch.full((1, 3), 1.0 if white_background else 0.0, device=device)
     res = renderer.render_products(rays, bg, specular_cue=specular_hint)
     rows, W = row1 - row0, camera.W
-    rot = torch.linalg.inv(pose.to(device=device, dtype=torch.float32)[:3, :3])
-    to_cam = lambda m: (m @ rot.T).reshape(rows, W, 3)     # rot @ n per pixel
+    # rot = inverse of the view's rotation, on the host as the reference does (:122); applied per pixel as three multiply-adds
+    rot = torch.linalg.inv(pose.detach().to(device="cpu", dtype=torch.float32)[:3, :3]).to(device)
+    to_cam = lambda m: (m[:, None, :] * rot[None, :, :]).sum(-1).reshape(rows, W, 3)     # rot @ n per pixel
     out = {"rgb": res["rgb"].reshape(rows, W, 3), "depth": res["depth"].reshape(rows, W, 1),
            "shadow_map": res["visibilities"].reshape(rows, W, 1),
            "analytic_normals": to_cam(res["normal_map"]),

@@ -44,6 +44,12 @@ def _hat(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1], w[:, 0], z], dim=-1).reshape(-1, 3, 3)
 
 
+def _mm3(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Batched [B,3,3] x [B,3,k] as a broadcast product + sum over the inner index: a handful of 3 x 3 products per view do not
+    warrant a library GEMM call (and keep rocBLAS out of the training process)."""
+    return (a[:, :, :, None] * b[:, None, :, :]).sum(2)
+
+
 def exp_map_SO3xR3(tangent: torch.Tensor) -> torch.Tensor:
     """[B,6] (translation, rotation vector) -> [B,3,4] = [R | t] with R = I + sin(th)/th K + (1-cos th)/th^2 K^2,
     th = sqrt(max(|w|^2, 1e-4)) (the reference clamps the SQUARED norm, camera/lie_groups.py:39-43), t copied."""
@@ -53,7 +59,7 @@ def exp_map_SO3xR3(tangent: torch.Tensor) -> torch.Tensor:
     a = (th.sin() / th)[:, None, None]
     b = ((1.0 - th.cos()) / (th * th))[:, None, None]
     eye = torch.eye(3, dtype=w.dtype, device=w.device)[None]
-    R = eye + a * K + b * torch.bmm(K, K)
+    R = eye + a * K + b * _mm3(K, K)
     return torch.cat([R, tangent[:, :3, None]], dim=-1)
 
 
@@ -148,7 +154,7 @@ class RayGenerator(nn.Module):
     def _compose(delta: torch.Tensor, R: torch.Tensor, t: torch.Tensor):
         """Left-multiply the camera-to-world [R|t] by a [B,3,4] delta."""
         dR, dt = delta[:, :3, :3], delta[:, :3, 3:]
-        return dR @ R, dt + dR @ t
+        return _mm3(dR, R), dt + _mm3(dR, t)
 
     def view_deltas(self):
         """Per-view left deltas, composed in the reference's order - noise first, then the adjustment (:108-121), i.e.
