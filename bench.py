@@ -205,7 +205,10 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
     else:
         opt, sched = make_optimizer(student, warm_up_end=10)
         sync = FlatGradAllReduce(list(student.parameters()))
-        run = lambda i, rb, gt: train_step(student, rb, gt, bg, global_step=20000 + i, optimizer=opt, scheduler=sched, grad_sync=sync)
+        # eager steps without a per-step read-back: the host enqueues step i + 1 while step i runs (the losses are read after the
+        # timed region)
+        run = lambda i, rb, gt: train_step(student, rb, gt, bg, global_step=20000 + i, optimizer=opt, scheduler=sched, grad_sync=sync,
+                                           sync=False)
     losses = []
     t0 = None
     for i, (rb, gt) in enumerate(batches):
@@ -225,6 +228,10 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
         dt = float(t.item())
     if graphed is not None:
         graphed.release()
+    else:
+        from nrhints_amd.training import release_device_scalars
+        release_device_scalars(student)
+    losses = [float(x) for x in losses]
     value = world * batch * steps / dt
     peak = PEAK_TFLOPS[student.precision]
     return {"metric": "training ray-steps/s (forward + backward + Adam)", "value": round(value, 1), "unit": "ray-steps/s",

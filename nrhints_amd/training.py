@@ -121,14 +121,26 @@ class FlatGradAllReduce:
 
 
 def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, optimizer, scheduler=None,
-               grad_sync: Optional[FlatGradAllReduce] = None, fused: Optional[bool] = None) -> Dict[str, float]:
+               grad_sync: Optional[FlatGradAllReduce] = None, fused: Optional[bool] = None, sync: bool = True) -> Dict[str, float]:
     """One optimisation step (trainer/trainer.py:269-283): forward (training mode), loss, backward, gradient mean over
     ranks, Adam, schedule.  Returns python floats of the loss dict (one host sync, as the reference's psnr .item()).
     ``fused``: forward + loss + backward as one fixed sequence of HIP launches without autograd (train_fused.py); None = use it
-    whenever it applies (renderer parameters only, no ray gradients), False = the autograd path."""
+    whenever it applies (renderer parameters only, no ray gradients), False = the autograd path.  ``sync=False``: return the loss
+    dict as 0-dim DEVICE tensors instead of python floats - no host synchronisation, so the host can enqueue the next step while
+    this one runs (an eager step is ~70 launches: 1.1 ms of a 7.8 ms step at 1 024 rays is the host catching up after the
+    read-back, profiles/r03/train_bench_modes.log)."""
     from . import train_fused
     if fused is None:
         fused = train_fused.supported(renderer, ray_bundle) is None
+    if not sync and fused:
+        # 1/s and the cos-anneal ratio on the device (as in a captured step): the re-pack after every optimiser step then needs no
+        # host read of 1/s.  Evaluation renders in between read 1/s back themselves (renderer._host_inv_s); release_device_scalars()
+        # returns to host-side scalars.
+        if renderer.dyn_scalars is None:
+            renderer.dyn_scalars = torch.zeros(2, dtype=torch.float32, device=ray_bundle.origins.device)
+            renderer._packed_key = None
+        cfg = renderer.config
+        renderer.dyn_scalars[1:2].fill_(min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0)
     if fused:
         optimizer.zero_grad(set_to_none=True)
         loss8 = train_fused.train_step_backward(renderer, ray_bundle, rgb_gt, background_rgb, global_step)
@@ -145,7 +157,17 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
+    if not sync:
+        vec = vec.clone()                     # the fused step's loss vector is a persistent buffer
+        return {k: vec[i] for i, k in enumerate(keys)}
     return dict(zip(keys, vec.tolist()))      # one device-to-host copy
+
+
+def release_device_scalars(renderer) -> None:
+    """Undo what ``train_step(..., sync=False)`` switched on: 1/s and the cos-anneal ratio back on the host."""
+    renderer.dyn_scalars = None
+    renderer._packed_key = None
+    renderer._generation = getattr(renderer, "_generation", 0) + 1
 
 
 class GraphedTrainStep:

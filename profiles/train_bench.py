@@ -16,7 +16,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     torch.manual_seed(0)
     student = na.NeuSHintRenderer().cuda()
-    backend = sys.argv[3] if len(sys.argv) > 3 else "hip"          # hip | graph | manual | autograd (the last two: tests/torch_backends.py)
+    backend = sys.argv[3] if len(sys.argv) > 3 else "hip"          # hip | hip_nosync (no per-step loss read-back) | graph | manual | autograd (the last two: tests/torch_backends.py)
     teacher = na.NeuSHintRenderer()
     st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in student.state_dict().items()})
     teacher.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
@@ -48,10 +48,11 @@ def main():
         if graphed is not None:
             out = graphed(rb, gt, global_step=20000 + step)
         else:
-            out = train_step(student, rb, gt, bg, global_step=20000 + step, optimizer=opt, scheduler=sched)
+            out = train_step(student, rb, gt, bg, global_step=20000 + step, optimizer=opt, scheduler=sched, sync=backend != "hip_nosync")
         losses.append(out["loss"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    losses = [float(x) for x in losses]
     print(json.dumps({"metric": "training ray-steps/s (fwd+bwd+Adam)", "batch": batch, "steps": steps,
                       "value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2),
                       "loss_first3": [round(x, 5) for x in losses[:3]], "loss_last3": [round(x, 5) for x in losses[-3:]],
