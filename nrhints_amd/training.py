@@ -132,10 +132,11 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
     from . import train_fused
     if fused is None:
         fused = train_fused.supported(renderer, ray_bundle) is None
-    if not sync and fused:
+    if (not sync and fused) or renderer.dyn_scalars is not None:
         # 1/s and the cos-anneal ratio on the device (as in a captured step): the re-pack after every optimiser step then needs no
         # host read of 1/s.  Evaluation renders in between read 1/s back themselves (renderer._host_inv_s); release_device_scalars()
-        # returns to host-side scalars.
+        # returns to host-side scalars.  (Once the device scalars exist the kernels read THEM, so this step's ratio goes there
+        # whichever way the step was asked for.)
         if renderer.dyn_scalars is None:
             renderer.dyn_scalars = torch.zeros(2, dtype=torch.float32, device=ray_bundle.origins.device)
             renderer._packed_key = None

@@ -359,3 +359,34 @@ def test_hip_adam_equals_torch_adam():
     assert hip2._stage is not None
     for a, b in zip(pa, pb):
         assert float((a.detach() - b.detach()).abs().max()) <= 4e-7 * float(b.detach().abs().max()) + 1e-9
+
+
+def test_train_step_without_readback_equals_with(scene_states):
+    """training.train_step(sync=False) - no per-step loss read-back, 1/s and the cos-anneal ratio on the device - takes the same
+    steps as the default call: same losses, same parameters after four steps (fixed jitter through the seed), and a step WITH the
+    read-back afterwards still follows the anneal schedule (the kernels read the device scalars once they exist)."""
+    from nrhints_amd.training import make_optimizer, release_device_scalars, train_step
+    rb = _bundle(*make_rays(128, seed=9, spread=0.08))
+    bg = torch.ones(1, 3).cuda()
+    gt = cu(np.random.RandomState(3).rand(128, 3).astype(np.float32))
+    runs = []
+    for sync in (True, False):
+        model = _model(scene_states["b"])
+        opt, sched = make_optimizer(model, lr=5e-4, warm_up_end=2)
+        torch.manual_seed(11)
+        losses = [train_step(model, rb, gt, bg, 10_000 + 5_000 * i, opt, sched, sync=sync)["loss"] for i in range(4)]
+        if not sync:
+            assert model.dyn_scalars is not None and all(torch.is_tensor(x) for x in losses)
+            assert abs(float(model.dyn_scalars[1]) - 25_000 / 50_000) < 1e-7
+            more = train_step(model, rb, gt, bg, 40_000, opt, sched, sync=True)["loss"]       # read-back variant on device scalars
+            assert abs(float(model.dyn_scalars[1]) - 0.8) < 1e-7 and np.isfinite(more)
+            release_device_scalars(model)
+            assert model.dyn_scalars is None
+            with torch.no_grad():
+                assert bool(torch.isfinite(model(rb, background_rgb=bg).rgb).all())
+        runs.append(([float(x) for x in losses], {k: v.detach().clone() for k, v in model.named_parameters()}))
+    (la, pa), (lb, pb) = runs
+    np.testing.assert_allclose(la, lb, rtol=1e-4)
+    # (pb took one more step; compare what both did: the losses above, and that the fifth step moved the parameters only slightly)
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) < 2e-3, k
