@@ -320,6 +320,21 @@ def test_rccl_world1_render_sharded_grad_allreduce_and_graph(scene_states, nccl_
         a, b = step(rb, gt, global_step=30000 + i)["loss"], step2(rb, gt, global_step=30000 + i)["loss"]
         assert np.isfinite(a) and abs(a - b) < 2e-5 * max(1.0, abs(b)), (i, a, b)
     step.release(); step2.release()
+    # what bench.py's multi-rank training leg runs per rank: eager fused steps without a read-back, the flat all-reduce between
+    # backward and the one-launch Adam - against the same steps without the exchange
+    from nrhints_amd.training import make_optimizer, release_device_scalars, train_step
+    ma, mb = _model(scene_states["b"], train=True), _model(scene_states["b"], train=True)
+    (oa, sa), (ob, sb) = make_optimizer(ma, warm_up_end=2), make_optimizer(mb, warm_up_end=2)
+    sync_a = FlatGradAllReduce(list(ma.parameters()), always=True)
+    for i in range(3):
+        torch.manual_seed(100 + i)
+        la = train_step(ma, rb, gt, bg, 30000 + i, oa, sa, grad_sync=sync_a, sync=False)["loss"]
+        torch.manual_seed(100 + i)
+        lb = train_step(mb, rb, gt, bg, 30000 + i, ob, sb, sync=False)["loss"]
+        assert torch.is_tensor(la) and abs(float(la) - float(lb)) < 2e-5 * max(1.0, abs(float(lb))), (i, float(la), float(lb))
+    for (k, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert float((a.detach() - b.detach()).abs().max()) < 1e-5, k
+    release_device_scalars(ma); release_device_scalars(mb)
 
 
 # ---- unit entries of the evaluation render's per-ray stages against the reference's recorded intermediates ----------------
