@@ -386,6 +386,15 @@ int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const fl
                                    float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
                                    const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
                                    float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream);
+/* The same stage for a SHADOW ray (renderer.shadow_hint_gradient, models/neus_hint_model.py:379, :417-432): alpha from sdf /
+ * grad / dists at its 128 sections, visibilities [n] = transmittance in front of the last sample; the adjoint takes
+ * d loss / d visibility [n] and returns the adjoints of sdf [n,128], grad [n*128,3], the shadow ray's direction [n,3] and the
+ * per-ray partial of d loss / d inv_s [n] (feed nrh_variance_grad). */
+int nrh_shadow_alpha_forward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
+                             float cos_anneal, const float* dyn_scalars, long long nrays, float* visibilities, void* stream);
+int nrh_shadow_alpha_backward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
+                              float cos_anneal, const float* dyn_scalars, long long nrays, const float* visibilities_bar,
+                              float* sdf_bar, float* grad_bar, float* dirs_bar, float* invs_bar, void* stream);
 /* d loss / d variance from the per-ray partials of nrh_alpha_train_backward (inv_s = clip(exp(10 variance), 1e-6, 1e6),
  * models/neus_hint_model.py:104-110): variance_bar[0] = 10 inv_s sum(invs_bar) inside the clip range, else 0. */
 int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const float* dyn_scalars, float* variance_bar, void* stream);

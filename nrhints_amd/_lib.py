@@ -20,6 +20,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
+            "nrh_shadow_alpha_forward", "nrh_shadow_alpha_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_forward_grouped", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
@@ -79,6 +80,8 @@ def load():
     lib.nrh_sdf_train_backward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P, P]
     lib.nrh_alpha_train_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P]
     lib.nrh_alpha_train_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P]
+    lib.nrh_shadow_alpha_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P]
+    lib.nrh_shadow_alpha_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P]
     lib.nrh_color_transposed_floats.argtypes = [c_int]
     lib.nrh_color_transposed_floats.restype = c_longlong
     lib.nrh_color_train_forward.argtypes = [c_int, c_int, P, P, P, P, P, P, c_longlong, P, P, P, P]

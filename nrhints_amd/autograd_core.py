@@ -145,14 +145,47 @@ class ColorNetHip(torch.autograd.Function):
         return grads_in + tuple(out[f"w{l}"] for l in range(5)) + tuple(out[f"b{l}"] for l in range(5))
 
 
-def _alpha(sdf, grad, dirs, dists, inv_s, cos_anneal: float):
-    """NeuSHintRenderer.get_alpha (models/neus_hint_model.py:339-356) as differentiable torch expressions; [P,1] / [P,3] inputs."""
-    true_cos = (dirs * grad).sum(-1, keepdim=True)
-    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + F.relu(-true_cos) * cos_anneal)
-    est_next = sdf + iter_cos * dists * 0.5
-    est_prev = sdf - iter_cos * dists * 0.5
-    prev_cdf, next_cdf = torch.sigmoid(est_prev * inv_s), torch.sigmoid(est_next * inv_s)
-    return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+class ShadowVisibilityHip(torch.autograd.Function):
+    """(sdf [P,1], grad [P,3], shadow_dirs [N,3], dists [N,128], variance) -> visibility [N,1] = transmittance in front of the
+    shadow ray's last sample (get_alpha + the cumprod of models/neus_hint_model.py:339-356, :428-432), forward and adjoint in the
+    alpha-stage kernel pair (csrc/nrh_rays_train.hip, nrh_shadow_alpha_*).  For renderer.shadow_hint_gradient."""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float, dyn=None):
+        from . import _lib
+        lib = _lib.load()
+        n = dirs.shape[0]
+        f32c = lambda t: t.detach().to(torch.float32).contiguous()
+        sdf_c, grad_c, dirs_c, dists_c = f32c(sdf), f32c(grad), f32c(dirs), f32c(dists)
+        vis = torch.empty(n, 1, dtype=torch.float32, device=dirs.device)
+        P = _lib.ptr
+        _lib.check(lib.nrh_shadow_alpha_forward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), float(inv_s), float(cos_anneal), P(dyn), n,
+                                                P(vis), _lib.stream_handle()), "nrh_shadow_alpha_forward")
+        ctx.save_for_backward(sdf_c, grad_c, dirs_c, dists_c)
+        ctx.consts, ctx.dyn = (float(inv_s), float(cos_anneal)), dyn
+        return vis
+
+    @staticmethod
+    def backward(ctx, vbar):
+        from . import _lib
+        lib = _lib.load()
+        sdf_c, grad_c, dirs_c, dists_c = ctx.saved_tensors
+        inv_s, cos_anneal = ctx.consts
+        n = dirs_c.shape[0]
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dirs_c.device)
+        vbar = vbar.to(torch.float32).contiguous()
+        sdf_bar, grad_bar, rd_bar, invs_bar = new(n * 128, 1), new(n * 128, 3), new(n, 3), new(n)
+        P = _lib.ptr
+        dyn = ctx.dyn
+        _lib.check(lib.nrh_shadow_alpha_backward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, P(dyn), n, P(vbar),
+                                                 P(sdf_bar), P(grad_bar), P(rd_bar), P(invs_bar), _lib.stream_handle()),
+                   "nrh_shadow_alpha_backward")
+        if dyn is not None:
+            s_dev = dyn[0]
+            var_bar = invs_bar.sum() * torch.where((s_dev > 1e-6) & (s_dev < 1e6), 10.0 * s_dev, torch.zeros_like(s_dev))
+        else:
+            var_bar = invs_bar.sum() * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)
+        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None, None
 
 
 def _specular_cue(hit_normal, pl, hit, dirs, roughness) -> torch.Tensor:
@@ -177,19 +210,18 @@ def _specular_cue(hit_normal, pl, hit, dirs, roughness) -> torch.Tensor:
     return torch.stack(out, dim=-1)
 
 
-def _visibility(d, packed, variance, pl, hit, mid_z, dists, cos_anneal: float) -> torch.Tensor:
+def _visibility(d, packed, variance, pl, hit, mid_z, dists, cos_anneal: float, dyn=None) -> torch.Tensor:
     """The differentiable tail of get_visibility (models/neus_hint_model.py:411-432) for renderer.shadow_hint_gradient: alpha at
     the 128 section mid-points of the shadow ray light -> hit point (sections from the graph-less HIP sampler; the reference
     detaches its importance samples too, :313), transmittance in front of the last one.  The SDF network and d sdf/dx at the
-    shadow points run through the same HIP forward / backward sweeps as the primary samples (sdf_value_feat_grad)."""
+    shadow points run through the same HIP forward / backward sweeps as the primary samples (sdf_value_feat_grad), the alpha
+    stage through its kernel pair (ShadowVisibilityHip)."""
     n, T = mid_z.shape
     sd = hit - pl
     srd = sd / torch.linalg.norm(sd, ord=2, dim=-1, keepdim=True)
     pts = (pl[:, None, :] + srd[:, None, :] * mid_z[..., None]).reshape(-1, 3)
     sdf, _, grad = sdf_value_feat_grad(d, pts, packed=packed)
-    inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
-    alpha = _alpha(sdf, grad, srd[:, None, :].expand(n, T, 3).reshape(-1, 3), dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, T)
-    return torch.prod(1.0 - alpha[:, :-1] + 1e-7, dim=-1, keepdim=True)     # taus[..., -1:] of :428-432
+    return ShadowVisibilityHip.apply(sdf, grad, srd, dists, variance, packed["inv_s"], cos_anneal, dyn)
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
@@ -210,7 +242,8 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal, dyn)
     if hint_grad is not None:
         if hint_grad.get("shadow") is not None:
-            vis = _visibility(d, packed, variance, pl, hint_grad["hit"], hint_grad["shadow"]["mid_z"], hint_grad["shadow"]["dists"], cos_anneal)
+            vis = _visibility(d, packed, variance, pl, hint_grad["hit"], hint_grad["shadow"]["mid_z"], hint_grad["shadow"]["dists"],
+                              cos_anneal, dyn)
         if hint_grad.get("specular"):
             hit_n = F.normalize((n_hat.reshape(n, T, 3) * weights[..., None]).sum(1), dim=-1, p=2)      # :586-587
             cue = _specular_cue(hit_n, pl, hint_grad["hit"], dirs, hint_grad["roughness"])

@@ -276,7 +276,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 131; }
+int nrh_version(void) { return 132; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -542,6 +542,38 @@ int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("alpha_train_kernel<fwd>");
+}
+
+// the shadow ray's alpha stage for renderer.shadow_hint_gradient: visibility = transmittance in front of the last sample
+int nrh_shadow_alpha_forward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
+                             float cos_anneal, const float* dyn_scalars, long long nrays, float* visibilities, void* stream) {
+  if (!sdf || !grad || !shadow_dirs || !dists || !visibilities) return fail(NRH_E_INVALID, "nrh_shadow_alpha_forward: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_shadow_alpha_forward: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::AlphaTrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf; a.grad = grad; a.rd = shadow_dirs; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.dyn = dyn_scalars; a.tlast = visibilities;
+  const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
+  hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("alpha_train_kernel<fwd, shadow>");
+}
+
+int nrh_shadow_alpha_backward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
+                              float cos_anneal, const float* dyn_scalars, long long nrays, const float* visibilities_bar,
+                              float* sdf_bar, float* grad_bar, float* dirs_bar, float* invs_bar, void* stream) {
+  if (!sdf || !grad || !shadow_dirs || !dists || !visibilities_bar || !sdf_bar || !grad_bar || !dirs_bar || !invs_bar)
+    return fail(NRH_E_INVALID, "nrh_shadow_alpha_backward: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_shadow_alpha_backward: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::AlphaTrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf; a.grad = grad; a.rd = shadow_dirs; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.dyn = dyn_scalars; a.tlast_bar = visibilities_bar;
+  a.sdf_bar = sdf_bar; a.grad_bar = grad_bar; a.rd_bar = dirs_bar; a.invs_bar = invs_bar;
+  const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
+  hipLaunchKernelGGL(nrh::alpha_train_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("alpha_train_kernel<adjoint, shadow>");
 }
 
 int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,

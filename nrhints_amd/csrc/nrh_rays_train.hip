@@ -39,6 +39,10 @@ struct AlphaTrainArgs {
   int nbar_stride;       // floats between rows of nhat_bar (0 = 3)
   const float* inside;   // [N,128] or null
   const float* eik_coef; // device scalar igr_weight / (sum inside + 1e-5), or null
+  // shadow rays (renderer.shadow_hint_gradient): the visibility is the transmittance in front of the LAST sample,
+  // T_127 = prod_{k<127} (1 - alpha_k + 1e-7) (get_visibility :428-432), not a weight
+  float* tlast;            // forward: [N] T_127, or null
+  const float* tlast_bar;  // adjoint: [N] d loss / d T_127 (added to the transmittance adjoint of sample 127), or null
 };
 
 // inclusive SUFFIX sum over the 128-long per-ray sequence (j0 = lane, j1 = lane + 64)
@@ -87,13 +91,16 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
 
   if (!ADJOINT) {
     if (active) {
+      if (a.weights) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const long long P = ray * 128 + lane + 64 * e;
-        a.weights[P] = w[e];
+        for (int e = 0; e < 2; ++e) {
+          const long long P = ray * 128 + lane + 64 * e;
+          a.weights[P] = w[e];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.nhat[P * 3 + c] = g[e][c] / gn[e];
+          for (int c = 0; c < 3; ++c) a.nhat[P * 3 + c] = g[e][c] / gn[e];
+        }
       }
+      if (a.tlast && lane == 63) a.tlast[ray] = T[1];
     }
     return;
   }
@@ -102,9 +109,10 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
   float wb[2], x[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    wb[e] = a.weights_bar[ray * 128 + lane + 64 * e];
+    wb[e] = a.weights_bar ? a.weights_bar[ray * 128 + lane + 64 * e] : 0.0f;
     x[e] = wb[e] * w[e];   // = Tbar_i T_i
   }
+  if (a.tlast_bar && lane == 63) x[1] += a.tlast_bar[ray] * T[1];   // T_127 is an output itself: Tbar_127 += tlast_bar
   float suf[2];
   suffix_sum_128(x[0], x[1], suf[0], suf[1]);
   float rdb[3] = {0.f, 0.f, 0.f}, Sb = 0.0f;
