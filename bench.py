@@ -238,6 +238,9 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
             "batch_rays_per_gpu": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
             "dtype": student.precision, "mode": "hipGraph replay" if world == 1 else "eager + flat RCCL all-reduce",
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
+            "bound_note": "the step's five big kernels (dW, SDF training forward, tangent / value sweeps, reflectance adjoint) are HBM-bound: "
+                          "4.1-5.0 TB/s = 0.5-0.6 of the 8 TB/s peak by the committed counters (profiles/r03/pmc_train_summary.txt, DESIGN 7b); "
+                          "the MFMA fraction below is the SURVEY 8d convention",
             "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
                          "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(value * FLOP_PER_RAY_STEP / 1e12 / world / peak, 4)}}
