@@ -222,6 +222,9 @@ typedef struct NrhNet {
                                per group of 128 / clip consecutive samples, aimed at the group's first sample position; the
                                `visibilities` output is then the group value at the maximal-weight sample, t_rand_shadow is
                                [nrays * clip, 64] (row ray * clip + group) and NrhTrainSaves.raymisc [nrays * clip, 100] */
+  int samples;              /* 0 or 128: 64 stratified + 64 importance samples per ray; 64: renderer.n_importance_samples = 0
+                               (models/neus_hint_model.py:696 - no hierarchical sampling, the 64 coarse samples are final).  The
+                               per-sample arrays keep 128 entries per ray; entries 64..127 are padding with weight exactly 0 */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);
@@ -390,6 +393,14 @@ int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const fl
  * grad / dists at its 128 sections, visibilities [n] = transmittance in front of the last sample; the adjoint takes
  * d loss / d visibility [n] and returns the adjoints of sdf [n,128], grad [n*128,3], the shadow ray's direction [n,3] and the
  * per-ray partial of d loss / d inv_s [n] (feed nrh_variance_grad). */
+/* nrh_alpha_train_forward / _backward for rays with n_real = 64 or 128 existing samples of the 128 slots (NrhNet.samples):
+ * padded samples have alpha = 0 and receive zero adjoints. */
+int nrh_alpha_train_forward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                              float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, float* weights, float* nhat,
+                              void* stream);
+int nrh_alpha_train_backward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                               float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, const float* weights_bar,
+                               const float* nhat_bar, float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream);
 int nrh_shadow_alpha_forward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
                              float cos_anneal, const float* dyn_scalars, long long nrays, float* visibilities, void* stream);
 int nrh_shadow_alpha_backward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,

@@ -20,7 +20,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
-            "nrh_shadow_alpha_forward", "nrh_shadow_alpha_backward",
+            "nrh_shadow_alpha_forward", "nrh_shadow_alpha_backward", "nrh_alpha_train_forward_n", "nrh_alpha_train_backward_n",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_forward_grouped", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
@@ -34,7 +34,8 @@ class NrhNet(Structure):
                 ("col_b", c_void_p), ("inv_s", c_float), ("precision", c_int), ("hints", c_int),
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
                 ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
-                ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int), ("shadow_clip", c_int)]
+                ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int), ("shadow_clip", c_int),
+                ("samples", c_int)]
 
 
 class NrhAdamTensor(Structure):
@@ -80,6 +81,8 @@ def load():
     lib.nrh_sdf_train_backward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P, P]
     lib.nrh_alpha_train_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P]
     lib.nrh_alpha_train_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P]
+    lib.nrh_alpha_train_forward_n.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P, P]
+    lib.nrh_alpha_train_backward_n.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P, P, P, P, P, P]
     lib.nrh_shadow_alpha_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P]
     lib.nrh_shadow_alpha_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P]
     lib.nrh_color_transposed_floats.argtypes = [c_int]
@@ -187,7 +190,7 @@ def stream_handle(device=None):
 
 
 def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False,
-             shadow_clip=-1):
+             shadow_clip=-1, samples=128):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
     ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""
@@ -200,4 +203,4 @@ def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fu
                   hints, normal_type, depth_type, ptr(dyn_scalars),
                   ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
                   ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None,
-                  int(bool(shadow_jvp and w32 is not None)), int(shadow_clip))
+                  int(bool(shadow_jvp and w32 is not None)), int(shadow_clip), int(samples))

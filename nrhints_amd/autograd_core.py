@@ -42,7 +42,7 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
     and F.normalize of models/neus_hint_model.py:339-356, :521-525, :584 and what autograd derives from them."""
 
     @staticmethod
-    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float, dyn=None):
+    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float, dyn=None, n_real: int = 128):
         from . import _lib
         lib = _lib.load()
         n = dirs.shape[0]
@@ -51,10 +51,11 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
         weights = torch.empty(n, 128, dtype=torch.float32, device=dirs.device)
         nhat = torch.empty(n * 128, 3, dtype=torch.float32, device=dirs.device)
         P = _lib.ptr
-        _lib.check(lib.nrh_alpha_train_forward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), float(inv_s), float(cos_anneal), P(dyn), n,
-                                               P(weights), P(nhat), _lib.stream_handle()), "nrh_alpha_train_forward")
+        _lib.check(lib.nrh_alpha_train_forward_n(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), float(inv_s), float(cos_anneal), P(dyn), n,
+                                                 int(n_real), P(weights), P(nhat), _lib.stream_handle()), "nrh_alpha_train_forward")
         ctx.save_for_backward(sdf_c, grad_c, dirs_c, dists_c)
         ctx.consts = (float(inv_s), float(cos_anneal))
+        ctx.n_real = int(n_real)
         ctx.dyn = dyn
         return weights, nhat
 
@@ -71,8 +72,8 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
         sdf_bar, grad_bar, rd_bar, invs_bar = new(n * 128, 1), new(n * 128, 3), new(n, 3), new(n)
         P = _lib.ptr
         dyn = ctx.dyn
-        _lib.check(lib.nrh_alpha_train_backward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, P(dyn), n, P(wbar), P(nbar),
-                                                P(sdf_bar), P(grad_bar), P(rd_bar), P(invs_bar), _lib.stream_handle()),
+        _lib.check(lib.nrh_alpha_train_backward_n(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, P(dyn), n, ctx.n_real,
+                                                  P(wbar), P(nbar), P(sdf_bar), P(grad_bar), P(rd_bar), P(invs_bar), _lib.stream_handle()),
                    "nrh_alpha_train_backward")
         # inv_s = clip(exp(10 variance), 1e-6, 1e6): d inv_s / d variance = 10 inv_s inside the clip range
         if dyn is not None:       # device-side inv_s (hipGraph mode): same chain rule without a host value
@@ -80,7 +81,7 @@ class AlphaWeightsNormalsHip(torch.autograd.Function):
             var_bar = invs_bar.sum() * torch.where((s_dev > 1e-6) & (s_dev < 1e6), 10.0 * s_dev, torch.zeros_like(s_dev))
         else:
             var_bar = invs_bar.sum() * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)
-        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None, None
+        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None, None, None
 
 
 class ColorNetHip(torch.autograd.Function):
@@ -225,7 +226,8 @@ def _visibility(d, packed, variance, pl, hit, mid_z, dists, cos_anneal: float, d
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
-                background_rgb, analytic_normal: bool = False, packed=None, pre=None, dyn=None, hint_grad=None) -> Dict[str, torch.Tensor]:
+                background_rgb, analytic_normal: bool = False, packed=None, pre=None, dyn=None, hint_grad=None,
+                n_real: int = 128) -> Dict[str, torch.Tensor]:
     """``d``: weight-norm-folded dense parameters WITH autograd history (packing.dense_params* on the live nn.Parameters);
     mid_z / dists [N,128], vis [N,1], cue [N,4]: graph-less results of the HIP forward; ``packed``: the kernel buffers of the
     same parameters.  Every network evaluation and its adjoint is a HIP kernel (there is no torch formulation in here; the
@@ -239,7 +241,8 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     sdf, feat, grad = sdf_value_feat_grad(d, pts, packed=packed, pre=pre)
     inv_s = torch.exp(variance * 10.0).clip(1e-6, 1e6)
     # alpha, transmittance product, weights and unit normals: one HIP kernel forward, one for the adjoint
-    weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal, dyn)
+    # n_real = 64: renderer.n_importance_samples = 0 - slots 64..127 of every ray are padding with weight exactly 0
+    weights, n_hat = AlphaWeightsNormalsHip.apply(sdf, grad, dirs, dists, variance, packed["inv_s"], cos_anneal, dyn, n_real)
     if hint_grad is not None:
         if hint_grad.get("shadow") is not None:
             vis = _visibility(d, packed, variance, pl, hint_grad["hit"], hint_grad["shadow"]["mid_z"], hint_grad["shadow"]["dists"],

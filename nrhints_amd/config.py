@@ -105,8 +105,10 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
         (c.d_hidden == 256 and c.n_layers == 4 and c.multi_res == 4 and c.weight_norm and c.squeeze_out,
          "reflectance_network must be the default 4x256 / multi_res=4 / sigmoid MLP"),
         (not r.use_outside_nerf, "use_outside_nerf=True (outside NeRF background) is not implemented"),
-        (r.n_samples == 64 and r.n_importance_samples == 64 and r.up_sample_steps == 4,
-         "n_samples/n_importance_samples/up_sample_steps must be 64/64/4"),
+        (r.n_samples == 64 and ((r.n_importance_samples == 64 and r.up_sample_steps == 4) or r.n_importance_samples == 0),
+         "n_samples must be 64 and n_importance_samples / up_sample_steps 64 / 4, or n_importance_samples 0 (no hierarchical sampling)"),
+        (not (r.n_importance_samples == 0 and r.shadow_hint and r.n_shadow_importance_clip > 0),
+         "the partial visibility hint needs the 128-sample layout (n_importance_samples = 64)"),
         (r.n_shadow_samples == 64 and r.n_shadow_importance_samples == 64,
          "n_shadow_samples/n_shadow_importance_samples must be 64/64"),
         (r.n_shadow_importance_clip in (-1, 1, 2, 4, 8, 16) or not r.shadow_hint,

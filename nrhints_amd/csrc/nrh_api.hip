@@ -276,7 +276,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 132; }
+int nrh_version(void) { return 133; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -531,13 +531,20 @@ int nrh_color_train_backward(int precision, int hints, const float* col_wt, cons
 int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                             float cos_anneal, const float* dyn_scalars, long long nrays, float* weights, float* nhat,
                             void* stream) {
+  return nrh_alpha_train_forward_n(sdf, grad, rd, dists, inv_s, cos_anneal, dyn_scalars, nrays, 128, weights, nhat, stream);
+}
+
+int nrh_alpha_train_forward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                              float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, float* weights, float* nhat,
+                              void* stream) {
+  if (n_real != 64 && n_real != 128) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: n_real must be 64 or 128%s", "");
   if (!sdf || !grad || !rd || !dists || !weights || !nhat) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: null pointer%s", "");
   if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: nrays out of range%s", "");
   if (nrays == 0) return NRH_OK;
   nrh::AlphaTrainArgs a;
   memset(&a, 0, sizeof(a));
   a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
-  a.dyn = dyn_scalars;
+  a.dyn = dyn_scalars; a.nreal = n_real == 128 ? 0 : n_real;
   a.weights = weights; a.nhat = nhat;
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -583,10 +590,31 @@ int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* r
                                         nullptr, sdf_bar, grad_bar, rd_bar, invs_bar, stream);
 }
 
+static int alpha_backward_impl(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                               float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
+                               const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
+                               float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, int n_real, void* stream);
+
+int nrh_alpha_train_backward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                               float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, const float* weights_bar,
+                               const float* nhat_bar, float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
+  if (n_real != 64 && n_real != 128) return fail(NRH_E_INVALID, "nrh_alpha_train_backward: n_real must be 64 or 128%s", "");
+  return alpha_backward_impl(sdf, grad, rd, dists, inv_s, cos_anneal, dyn_scalars, nrays, weights_bar, nhat_bar, 3, nullptr, nullptr,
+                             sdf_bar, grad_bar, rd_bar, invs_bar, n_real, stream);
+}
+
 int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                                    float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
                                    const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
                                    float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
+  return alpha_backward_impl(sdf, grad, rd, dists, inv_s, cos_anneal, dyn_scalars, nrays, weights_bar, nhat_bar, nhat_bar_stride,
+                             inside_sphere, eikonal_coef, sdf_bar, grad_bar, rd_bar, invs_bar, 128, stream);
+}
+
+static int alpha_backward_impl(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
+                               float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
+                               const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
+                               float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, int n_real, void* stream) {
   if (!sdf || !grad || !rd || !dists || !weights_bar || !sdf_bar || !grad_bar || !rd_bar || !invs_bar)
     return fail(NRH_E_INVALID, "nrh_alpha_train_backward: null pointer%s", "");
   if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_train_backward: nrays out of range%s", "");
@@ -600,6 +628,7 @@ int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const fl
   a.dyn = dyn_scalars;
   a.weights_bar = weights_bar; a.nhat_bar = nhat_bar; a.sdf_bar = sdf_bar; a.grad_bar = grad_bar; a.rd_bar = rd_bar;
   a.invs_bar = invs_bar; a.nbar_stride = nhat_bar_stride; a.inside = inside_sphere; a.eik_coef = eikonal_coef;
+  a.nreal = n_real == 128 ? 0 : n_real;
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("alpha_train_kernel<bwd>");
@@ -898,6 +927,10 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   if ((net->hints != 0 && net->hints != 1) || (net->normal_type != 0 && net->normal_type != 1) ||
       net->depth_type < 0 || net->depth_type > 2)
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type must be 0 or 1, depth_type 0, 1 or 2%s", "");
+  if (net->samples != 0 && net->samples != 64 && net->samples != 128)
+    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: NrhNet.samples must be 0 / 128 (64 + 64 importance) or 64 (no importance samples)%s", "");
+  if (net->samples == 64 && net->shadow_clip > 0)
+    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: the partial visibility hint needs the 128-sample layout%s", "");
   const int no_hints = zero_hints || !net->hints;  // no shadow march: geometry warm-up, or the pl-naive model
   if (net->shadow_clip != 0 && net->shadow_clip != -1 &&
       (net->shadow_clip < 1 || net->shadow_clip > nrh::MAX_SHADOW_CLIP || (net->shadow_clip & (net->shadow_clip - 1)) != 0))
@@ -942,8 +975,15 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     int rc = check_launch("coarse_z_kernel");
     if (rc) return rc;
   }
-  int rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f,
-                       o_tmid, o_dists, n, st);
+  int rc = NRH_OK;
+  if (net->samples == 64) {
+    // renderer.n_importance_samples = 0: no hierarchical sampling, the 64 coarse samples are final (padded to 128 with alpha = 0)
+    hipLaunchKernelGGL(nrh::finalize64_kernel, dim3((unsigned)((n * 128 + 255) / 256)), dim3(256), 0, st, (const float*)ws_zbuf,
+                       2.0f / 64.0f, o_tmid, o_dists, (int)n);
+    rc = check_launch("finalize64_kernel");
+  } else {
+    rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f, o_tmid, o_dists, n, st);
+  }
   if (rc) return rc;
   if (clip && hipMemcpyAsync(ws_cue_b, ws_zbuf, sizeof(float) * 128 * n, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(NRH_E_LAUNCH, "nrh_render_forward: copy of the sample positions failed%s", "");   // z_vals for the group targets
@@ -977,6 +1017,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
       c.depth_in = st_depth; c.hit_in = st_pts;
     }
     c.zero_hints = no_hints;
+    c.nreal = net->samples == 64 ? 64 : 0;
     c.depth_max_weight = net->depth_type == 1;
     c.nrays = (int)n;
     rc = launch_core_alpha(c, st);

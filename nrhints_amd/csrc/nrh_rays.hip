@@ -63,6 +63,22 @@ __global__ void coarse_z_kernel(const CoarseArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// renderer.n_importance_samples = 0 (models/neus_hint_model.py:696: no hierarchical sampling): the 64 coarse samples are the
+// final ones.  Sections (:491-496) for them; entries 64..127 of the 128-wide per-ray arrays repeat the last mid-point with
+// length 0 - the alpha kernels give those padded samples alpha = 0 (CoreArgs.nreal), so they carry no weight anywhere.
+// -------------------------------------------------------------------------------------------------
+__global__ void finalize64_kernel(const float* z, float last_dist, float* tmid, float* dists, int nrays) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)nrays * 128) return;
+  const long long ray = i >> 7;
+  const int j = (int)(i & 127), jr = j < 64 ? j : 63;
+  const float zj = z[ray * 128 + jr];
+  const float d = (jr < 63) ? z[ray * 128 + jr + 1] - zj : last_dist;
+  tmid[i] = zj + d * 0.5f;
+  dists[i] = j < 64 ? d : 0.0f;
+}
+
+// -------------------------------------------------------------------------------------------------
 // one launch = [merge the 16 samples of the previous step] + [up-sample 16 new ones | finalise sections]
 // -------------------------------------------------------------------------------------------------
 struct StepArgs {
@@ -267,6 +283,7 @@ struct CoreArgs {
   float kk[4], omk[4], a2[4], a2m1[4];
   int zero_hints;  // geometry warm-up: cue = 0 (:617-619)
   int depth_max_weight;  // DepthComputationType.MaximalWeightPoint (:534-538) instead of alpha blending
+  int nreal;             // samples per ray that exist (0 = all 128; 64 for n_importance_samples = 0): the rest get alpha = 0
   int nrays;
 };
 
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
     al[e] = neus_alpha(a.sdf[P], gx, gy, gz, dx, dy, dz, a.dists[P], a.dyn ? a.dyn[0] : a.inv_s, a.dyn ? a.dyn[1] : a.cos_anneal);
     const float px = ox + dx * mid[e], py = oy + dy * mid[e], pz = oz + dz * mid[e];
     ins[e] = (sqrtf(px * px + py * py + pz * pz) < 1.0f) ? 1.0f : 0.0f;
+    if (a.nreal && lane + 64 * e >= a.nreal) { al[e] = 0.0f; ins[e] = 0.0f; }   // padded sample: no weight, not counted
     const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
     nh[e][0] = gx / gn;
     nh[e][1] = gy / gn;

@@ -41,6 +41,8 @@ struct AlphaTrainArgs {
   const float* eik_coef; // device scalar igr_weight / (sum inside + 1e-5), or null
   // shadow rays (renderer.shadow_hint_gradient): the visibility is the transmittance in front of the LAST sample,
   // T_127 = prod_{k<127} (1 - alpha_k + 1e-7) (get_visibility :428-432), not a weight
+  int nreal;               // samples per ray that exist (0 = all 128; 64 for n_importance_samples = 0): the rest have alpha = 0
+                           // and receive zero adjoints
   float* tlast;            // forward: [N] T_127, or null
   const float* tlast_bar;  // adjoint: [N] d loss / d T_127 (added to the transmittance adjoint of sample 127), or null
 };
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
     nc[e] = sigmoidf_(en[e] * S);
     q[e] = (pc[e] - nc[e] + 1e-5f) / (pc[e] + 1e-5f);
     al[e] = fminf(fmaxf(q[e], 0.0f), 1.0f);
+    if (a.nreal && lane + 64 * e >= a.nreal) al[e] = 0.0f;
     f[e] = 1.0f - al[e] + 1e-7f;
     gn[e] = fmaxf(sqrtf(g[e][0] * g[e][0] + g[e][1] * g[e][1] + g[e][2] * g[e][2]), 1e-12f);  // F.normalize eps
   }
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
     const long long P = ray * 128 + lane + 64 * e;
     const float fbar = (suf[e] - x[e]) / f[e];                 // sum_{i>k} Tbar_i T_i / f_k  (cumprod backward)
     const float abar = wb[e] * T[e] - fbar;
-    const float qbar = (q[e] >= 0.0f && q[e] <= 1.0f) ? abar : 0.0f;   // clamp passes the gradient on [min, max]
+    const bool pad = a.nreal && lane + 64 * e >= a.nreal;               // padded sample: alpha was forced to 0
+    const float qbar = (!pad && q[e] >= 0.0f && q[e] <= 1.0f) ? abar : 0.0f;   // clamp passes the gradient on [min, max]
     const float ipc = 1.0f / (pc[e] + 1e-5f);
     const float pcb = qbar * (1.0f - q[e]) * ipc;
     const float ncb = -qbar * ipc;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
     rdb[0] += tcb * g[e][0];
     rdb[1] += tcb * g[e][1];
     rdb[2] += tcb * g[e][2];
-    if (a.nhat_bar) {
+    if (a.nhat_bar && !pad) {
       // n = g / max(|g|, eps):  gbar += (nbar - n (n . nbar)) / |g|   (0 through the clamp when |g| < eps)
       const long long nbs = a.nbar_stride ? a.nbar_stride : 3;
       const float nb[3] = {a.nhat_bar[P * nbs + 0], a.nhat_bar[P * nbs + 1], a.nhat_bar[P * nbs + 2]};
@@ -149,13 +153,13 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
       gb[1] += (nb[1] - (clamped ? 0.0f : ny * dot)) / gn[e];
       gb[2] += (nb[2] - (clamped ? 0.0f : nz * dot)) / gn[e];
     }
-    if (a.eik_coef) {
+    if (a.eik_coef && !pad) {
       // (|g| - 1)^2 on relax_inside_sphere samples: d/dg = 2 (|g| - 1) g / |g|
       const float k = a.eik_coef[0] * a.inside[P] * 2.0f * (gn[e] - 1.0f) / gn[e];
       gb[0] += k * g[e][0]; gb[1] += k * g[e][1]; gb[2] += k * g[e][2];
     }
     if (active) {
-      a.sdf_bar[P] = enb + epb;
+      a.sdf_bar[P] = enb + epb;      // (0 for a padded sample: qbar = 0 above)
 #pragma unroll
       for (int c = 0; c < 3; ++c) a.grad_bar[P * 3 + c] = gb[c];
     }

@@ -135,6 +135,9 @@ class NeuSHintRenderer(nn.Module):
         self._mixed_hints = self.has_shadow_hint != self.has_specular_hint
         # partial visibility hint (:553-575): shadow rays per group of samples instead of per ray; -1 = the hit-point mode
         self._shadow_clip = int(config.renderer.n_shadow_importance_clip) if self.has_shadow_hint else -1
+        # n_importance_samples = 0 (:696): the 64 coarse samples are final; the kernels keep 128 slots per ray, the upper 64 as
+        # padding with weight exactly 0, and the outputs are cut back to 64 here
+        self._samples = 64 if config.renderer.n_importance_samples == 0 else N_SAMPLES_TOTAL
         self._normal_type = 1 if config.renderer.normal_type == NormalComputationType.Analytic else 0
         self._depth_type = {DepthComputationType.AlphaBlend: 0, DepthComputationType.MaximalWeightPoint: 1,
                             DepthComputationType.SphereTracing: 2}[config.renderer.depth_type]
@@ -328,7 +331,8 @@ class NeuSHintRenderer(nn.Module):
         weights, inside, normals, nhat, cue = (res[k] for k in ("weights", "inside", "normals", "nhat", "cue"))
         mid_z, dists = res.get("mid_z"), res.get("dists")
         pk = self.packed_params(device)
-        T = N_SAMPLES_TOTAL
+        T = self._samples
+        cut = (lambda t: t) if T == N_SAMPLES_TOTAL else (lambda t: None if t is None else t[:, :T])
         if needs_grad:
             # differentiable part (render_core) over the HIP results; see autograd_core.py
             core = autograd_core.render_core(
@@ -337,18 +341,18 @@ class NeuSHintRenderer(nn.Module):
                 cue[:, 0, :].contiguous() if self._hints else None, cos_anneal,
                 background_rgb.to(device) if background_rgb is not None else None, analytic_normal=bool(self._normal_type),
                 packed=pk, pre=res.get("pre"), dyn=self.dyn_scalars if is_training else None,
-                hint_grad=self._hint_grad_inputs(o, d, depth, res, shadow_grad, specular_grad))
-            return RenderOutput(rgb=core["rgb"], depth=depth, weights=core["weights"], s_val=core["s_val"],
-                                inside_sphere=inside, relax_inside_sphere=inside,
-                                analytic_normals=core["analytic_normals"],
-                                normalized_analytic_normals=core["normalized_analytic_normals"],
+                hint_grad=self._hint_grad_inputs(o, d, depth, res, shadow_grad, specular_grad), n_real=T)
+            return RenderOutput(rgb=core["rgb"], depth=depth, weights=cut(core["weights"]), s_val=cut(core["s_val"]),
+                                inside_sphere=cut(inside), relax_inside_sphere=cut(inside),
+                                analytic_normals=cut(core["analytic_normals"]),
+                                normalized_analytic_normals=cut(core["normalized_analytic_normals"]),
                                 visibilities=vis if self.has_shadow_hint else None,
-                                specular_cue=cue if self.has_specular_hint else None)
+                                specular_cue=cut(cue) if self.has_specular_hint else None)
         s_val = torch.full((1, 1), 1.0 / self._host_inv_s(pk, device), dtype=torch.float32, device=device).expand(n, T)
-        return RenderOutput(rgb=rgb, depth=depth, weights=weights, s_val=s_val, inside_sphere=inside,
-                            relax_inside_sphere=inside, analytic_normals=normals,
-                            normalized_analytic_normals=nhat, visibilities=vis if self.has_shadow_hint else None,
-                            specular_cue=cue if self.has_specular_hint else None)
+        return RenderOutput(rgb=rgb, depth=depth, weights=cut(weights), s_val=s_val, inside_sphere=cut(inside),
+                            relax_inside_sphere=cut(inside), analytic_normals=cut(normals),
+                            normalized_analytic_normals=cut(nhat), visibilities=vis if self.has_shadow_hint else None,
+                            specular_cue=cut(cue) if self.has_specular_hint else None)
 
     def _hint_grad_inputs(self, o, d, depth, res, shadow_grad: bool, specular_grad: bool):
         """What render_core needs to differentiate the hints (renderer.shadow_hint_gradient / specular_hint_gradient,
@@ -373,7 +377,7 @@ class NeuSHintRenderer(nn.Module):
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels,
-                            shadow_clip=self._shadow_clip)
+                            shadow_clip=self._shadow_clip, samples=self._samples)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
@@ -423,7 +427,7 @@ class NeuSHintRenderer(nn.Module):
             pk = dict(pk, inv_s=self._host_inv_s(pk, device))
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
                             wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color,
-                            shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip)
+                            shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip, samples=self._samples)
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))

@@ -337,7 +337,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    mode="minimal", keep_intermediates=False, differentiable=False, hints=True,
                    analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0,
                    depth_sphere_tracing=False, shadow_hint=None, specular_hint=None, shadow_hint_gradient=False,
-                   specular_hint_gradient=False, n_shadow_importance_clip=-1) -> Dict[str, torch.Tensor]:
+                   specular_hint_gradient=False, n_shadow_importance_clip=-1, n_importance_samples=64) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
@@ -354,21 +354,23 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     z = near + (far - near) * torch.linspace(0.0, 1.0, 64).to(dt)[None, :]
     if is_training:
         z = z + (t_rand_primary - 0.5) * 2.0 / 64              # :681-683
-    with torch.no_grad():
-        z = hierarchical_z(p, o, d, z, full_forward=(mode == "as_written"))  # :696-713
+    if n_importance_samples > 0:                              # :696 (n_importance_samples = 0: the coarse samples are final)
+        with torch.no_grad():
+            z = hierarchical_z(p, o, d, z, full_forward=(mode == "as_written"))  # :696-713
+    T = z.shape[1]
     # ---- render_core ----
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=dt)], dim=-1)
     mid = z + dists * 0.5
     pts = (o[:, None, :] + d[:, None, :] * mid[..., None]).reshape(-1, 3)
-    dirs = d[:, None, :].expand(n, 128, 3).reshape(-1, 3)
-    pls = pl[:, None, :].expand(n, 128, 3).reshape(-1, 3)
+    dirs = d[:, None, :].expand(n, T, 3).reshape(-1, 3)
+    pls = pl[:, None, :].expand(n, T, 3).reshape(-1, 3)
     # ``differentiable`` (training): the render_core graph is kept, incl. the double-backward path through d sdf/dx
     # (mode "as_written" only); sampling, depth / hit point, shadow hint and specular cue stay outside the graph as
     # in the reference (:697, :531, :379, :589).
     sdf, feat, grad = _sdf_and_grad(p, pts, mode, True, differentiable)
     inv_s = inv_s_of(p)
-    alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, 128)
-    radius = torch.linalg.norm(pts, dim=-1).reshape(n, 128)
+    alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, T)
+    radius = torch.linalg.norm(pts, dim=-1).reshape(n, T)
     inside = (radius < 1.0).to(dt)
     weights = alpha * excl_cumprod_one_minus(alpha)            # :521-523
     wsum = weights.sum(-1, keepdim=True)
@@ -387,8 +389,8 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
         elif shadow_hint and n_shadow_importance_clip > 0:
             # partial visibility hint (:553-575): one shadow ray per group of 128 / clip samples, aimed at z_vals[:, g * ratio]
             clip = n_shadow_importance_clip
-            ratio = 128 // clip
-            zt = z[:, torch.arange(0, 128, ratio)]
+            ratio = T // clip
+            zt = z[:, torch.arange(0, T, ratio)]
             tgt = (o[:, None, :] + d[:, None, :] * zt[..., None]).reshape(-1, 3)
             pls_g = pl[:, None, :].repeat(1, clip, 1).reshape(-1, 3)
             vg = visibility(p, pls_g, tgt, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode).reshape(n, clip, 1)
@@ -400,25 +402,25 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     if shadow_hint and not warmup and shadow_hint_gradient and differentiable:
         vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode, differentiable=True)
     n_hat = F.normalize(grad, dim=-1)                          # :584
-    hit_n = F.normalize((n_hat.reshape(n, 128, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
+    hit_n = F.normalize((n_hat.reshape(n, T, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
     vis_s = cue_s = None
     if shadow_hint:
-        vis_s = vis[:, None, :].expand(n, 128, 1).reshape(-1, 1) if vis_samples is None else vis_samples.reshape(-1, 1)
+        vis_s = vis[:, None, :].expand(n, T, 1).reshape(-1, 1) if vis_samples is None else vis_samples.reshape(-1, 1)
     if specular_hint:
         with torch.enable_grad() if (specular_hint_gradient and differentiable) else torch.no_grad():   # :589
             cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :590-615, :617-619
-        cue_s = cue[:, None, :].expand(n, 128, 4).reshape(-1, 4)
-    col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, 128, 3)  # :621-626
+        cue_s = cue[:, None, :].expand(n, T, 4).reshape(-1, 4)
+    col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, T, 3)  # :621-626
     rgb = (col * weights[..., None]).sum(1)
     if background_rgb is not None:
         rgb = rgb + background_rgb * (1.0 - wsum)              # :635-637
-    out = dict(rgb=rgb, depth=depth, weights=weights, s_val=(1.0 / inv_s).expand(n, 128),
+    out = dict(rgb=rgb, depth=depth, weights=weights, s_val=(1.0 / inv_s).expand(n, T),
                inside_sphere=inside, relax_inside_sphere=inside,            # :745 (quirk kept)
-               analytic_normals=grad.reshape(n, 128, 3),
-               normalized_analytic_normals=n_hat.reshape(n, 128, 3),
-               visibilities=vis, specular_cue=cue_s.reshape(n, 128, 4) if specular_hint else None)
+               analytic_normals=grad.reshape(n, T, 3),
+               normalized_analytic_normals=n_hat.reshape(n, T, 3),
+               visibilities=vis, specular_cue=cue_s.reshape(n, T, 4) if specular_hint else None)
     if keep_intermediates:
-        out.update(z_vals=z, mid_z=mid, sdf=sdf.reshape(n, 128), alpha=alpha, hit=hit, hit_normal=hit_n,
+        out.update(z_vals=z, mid_z=mid, sdf=sdf.reshape(n, T), alpha=alpha, hit=hit, hit_normal=hit_n,
                    sampled_color=col, feat=feat)
     return out
 

@@ -10,6 +10,8 @@ Variants, all on scene b's weights (nrhints_amd.synthetic.perturb_state of the r
   sho   shadow hint only   (shadow_hint=True,  specular_hint=False): evaluation render + one training step's loss and gradients
   spo   specular hint only (shadow_hint=False, specular_hint=True):  the same
   frc   force_shadow_map + force_specular_cue on top of both hints (a no-op: has_*_hint = hint or force, :239-240)
+  i0    n_importance_samples = 0 with both hints off (BASELINE configs[0]'s plumbing variant, SURVEY 8d C1: 64 samples per ray,
+        :696): evaluation render + one training step
   psh   n_shadow_importance_clip = 8 (:553-575: a shadow ray per group of 16 samples): evaluation render + one training step
   shg / spg / bhg   shadow_hint_gradient / specular_hint_gradient / both (:379, :589: the hints stay inside the autograd graph):
         one training step's loss and gradients (the forward values equal the default model's)
@@ -55,7 +57,7 @@ def main():
     from camera.ray_utils import RayBundle
     from models.neus_hint_model import DepthComputationType, NeuSHintRenderer, NeuSModelConfig, NeuSRendererConfig
 
-    from nrhints_amd.synthetic import make_rays, one_hint_state, perturb_state
+    from nrhints_amd.synthetic import make_rays, naive_state, one_hint_state, perturb_state
 
     state_b = perturb_state(dict(np.load(os.path.join(HERE, "scene_a_state.npz"))))
 
@@ -76,6 +78,7 @@ def main():
         "spo": (R(shadow_hint=False, specular_hint=True), one_hint_state(state_b, shadow=False)),
         "frc": (R(force_shadow_map=True, force_specular_cue=True), state_b),
         "psh": (R(n_shadow_importance_clip=8), state_b),
+        "i0": (R(n_importance_samples=0, shadow_hint=False, specular_hint=False), naive_state(state_b)),
     }
     grad_variants = {
         "shg": (R(shadow_hint_gradient=True), state_b),
@@ -95,7 +98,7 @@ def main():
                 rec["st.trace_pts"], rec["st.trace_depths"] = pts.numpy(), dep.numpy()
                 pts64, dep64 = build(rcfg, st, torch.float64).sphere_trace(rb.origins.double(), rb.directions.double(), 2000, 1e-4, 100)
                 rec["st.trace_pts_f64"], rec["st.trace_depths_f64"] = pts64.numpy(), dep64.numpy()
-        for name in ("rgb", "depth", "weights", "visibilities", "specular_cue"):
+        for name in ("rgb", "depth", "weights", "visibilities", "specular_cue") + (("inside_sphere", "normalized_analytic_normals", "s_val") if vt == "i0" else ()):
             v = getattr(r, name)
             rec[f"{vt}.{name}"] = v.detach().numpy() if v is not None else np.zeros(0, np.float32)
         print("variant", vt, "rgb mean", float(r.rgb.mean()), "depth mean", float(r.depth.mean()))
@@ -107,7 +110,7 @@ def main():
     gt = torch.full((Nt, 3), 0.5)
     rec["t.rgb_gt"], rec["t.global_step"] = gt.numpy(), np.int64(20000)
     real_rand = torch.rand
-    for vt in ("sho", "spo", "shg", "spg", "bhg", "psh"):
+    for vt in ("sho", "spo", "shg", "spg", "bhg", "psh", "i0"):
         rcfg, st = variants[vt] if vt in variants else grad_variants[vt]
         drawn = []
 
@@ -134,9 +137,9 @@ def main():
             loss.backward()
             if dt == torch.float32:
                 # shadow-only draws primary + shadow jitter; specular-only has no shadow march, hence one draw
-                assert len(drawn) == (1 if vt == "spo" else 2), len(drawn)
+                assert len(drawn) == (1 if vt in ("spo", "i0") else 2), len(drawn)
                 rec[f"{vt}.t_rand_primary"] = drawn[0].numpy()
-                if vt != "spo":
+                if vt not in ("spo", "i0"):
                     rec[f"{vt}.t_rand_shadow"] = drawn[1].numpy()
                 rec[f"{vt}.t.rgb"] = r.rgb.detach().numpy()
             rec[f"{vt}.loss{sfx}"] = loss.detach().numpy()

@@ -726,3 +726,56 @@ def test_partial_visibility_hint(scene_states, prec):
             assert cos > 0.995, (name, cos)
     with pytest.raises(ValueError):
         na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=3)))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_no_importance_samples_plumbing_variant(scene_states, prec):
+    """renderer.n_importance_samples = 0 with both hints off - BASELINE configs[0]'s plumbing variant (4096 rays x 64
+    samples; models/neus_hint_model.py:696 skips the hierarchical sampling).  The kernels keep 128 slots per ray and give the upper
+    64 weight exactly 0: every output has the reference's 64-sample shape and values, at the fixture's 64 rays and at the config's
+    4096 (properties), and one training step's loss and gradients match the reference's."""
+    from nrhints_amd.synthetic import naive_state
+    from nrhints_amd.training import train_loss_dict
+    g = load_npz("render_branches_b.npz")
+    cfg = na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_importance_samples=0, shadow_hint=False, specular_hint=False))
+    st = naive_state(scene_states["b"])
+    bg = torch.ones(1, 3).cuda()
+    model = _model(st, prec, cfg=cfg)
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    with torch.no_grad():
+        out = model(rb, background_rgb=bg)
+    assert out.weights.shape == (64, 64) and out.inside_sphere.shape == (64, 64) and out.s_val.shape == (64, 64)
+    assert out.analytic_normals.shape == (64, 64, 3) and out.visibilities is None and out.specular_cue is None
+    np.testing.assert_allclose(out.rgb.cpu().numpy(), g["i0.rgb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out.depth.cpu().numpy(), g["i0.depth"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(out.weights.cpu().numpy(), g["i0.weights"], rtol=0, atol=3e-4)
+    assert np.array_equal(out.inside_sphere.cpu().numpy(), g["i0.inside_sphere"])
+    dn = np.abs(out.normalized_analytic_normals.cpu().numpy() - g["i0.normalized_analytic_normals"])
+    assert dn.mean() < 2e-5 and dn.max() < 5e-3
+    np.testing.assert_allclose(out.s_val.cpu().numpy(), g["i0.s_val"], rtol=1e-5)
+    # the config's size: 4096 rays x 64 samples
+    big = _bundle(*make_rays(4096, seed=4, spread=0.12))
+    with torch.no_grad():
+        ob = model(big, background_rgb=bg)
+        prod = model.render_products(big, bg)
+    assert ob.weights.shape == (4096, 64) and bool(torch.isfinite(ob.rgb).all())
+    assert bool((ob.weights >= 0).all()) and bool((ob.weights.sum(-1) <= 1.0 + 1e-4).all())
+    assert torch.equal(prod["rgb"], ob.rgb)
+    # one training step
+    tb = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    model = _model(st, prec, cfg=cfg, train=True)
+    o = model(tb, is_training=True, background_rgb=bg, global_step=int(g["t.global_step"]), _t_rand_primary=cu(g["i0.t_rand_primary"]))
+    assert o.weights.shape == (32, 64) and o.analytic_normals.shape == (32, 64, 3)
+    np.testing.assert_allclose(o.rgb.detach().cpu().numpy(), g["i0.t.rgb"], rtol=0, atol=1e-4)
+    ld = train_loss_dict(o, cu(g["t.rgb_gt"]), 0.1)
+    np.testing.assert_allclose(float(ld["loss"]), float(g["i0.loss"]), rtol=2e-4)
+    ld["loss"].backward()
+    named = dict(model.named_parameters())
+    keys = [k for k in g if k.startswith("i0.grad.") and ".rays." not in k]
+    assert len(keys) == 11
+    for k in keys:
+        name = k[len("i0") + 6:]
+        want64 = g[k.replace(".grad.", ".grad64.")]
+        bound, scale = grad_bound(g[k], want64, factor=4.0, floor=5e-3)
+        err = float(np.abs(named[name].grad.detach().cpu().numpy().astype(np.float64) - want64).max())
+        assert err <= bound, (name, err, bound, scale)

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 132
+    assert lib.nrh_version() == 133
     lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
     from nrhints_amd import packing32 as pk32
     assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
@@ -77,6 +77,7 @@ def test_unsupported_configs_are_rejected():
     na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(depth_type=na.DepthComputationType.SphereTracing)))
     na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(force_shadow_map=True, force_specular_cue=True)))
     na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=8)))
+    na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_importance_samples=0, shadow_hint=False, specular_hint=False)))
     na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint_gradient=True, specular_hint_gradient=True)))
     # one hint without the other: the reference's layer shapes (fields/reflectance_network.py:44-52)
     sho = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=True, specular_hint=False)))

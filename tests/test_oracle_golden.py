@@ -238,10 +238,17 @@ def test_core_intermediates_vs_reference(tag):
 def test_more_off_default_branches(scene_states):
     """SphereTracing depth, one hint without the other, force_* flags - the oracle vs the reference's recorded outputs
     (tests/golden/render_branches_b.npz, make_golden_branches.py)."""
-    from nrhints_amd.synthetic import one_hint_state
+    from nrhints_amd.synthetic import naive_state, one_hint_state
     g = load_npz("render_branches_b.npz")
     rays = [T(g[k]) for k in ("o", "d", "pl", "near", "far")]
     sb = scene_states["b"]
+    # n_importance_samples = 0, hints off (BASELINE configs[0]'s plumbing variant): 64 samples per ray
+    out = orc.render_forward(orc.params_from_state(naive_state(sb)), *rays, background_rgb=torch.ones(1, 3), mode="as_written",
+                             hints=False, n_importance_samples=0)
+    assert out["weights"].shape == (64, 64) and g["i0.weights"].shape == (64, 64)
+    np.testing.assert_allclose(out["rgb"].numpy(), g["i0.rgb"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["depth"].numpy(), g["i0.depth"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out["weights"].numpy(), g["i0.weights"], rtol=0, atol=2e-4)
     # the tracer on its own: same trajectory in the same arithmetic
     pts, dep = orc.sphere_trace(orc.params_from_state(sb), rays[0], rays[1], 2000, 1e-4, 100.0)
     # rtol: rays that miss run on to depth > 100 (their last steps are ~50 long, so an fp32 ulp there is ~1e-5 of the depth)
@@ -269,15 +276,16 @@ def test_more_off_default_branches(scene_states):
     assert str(g["force_shadow_only.outcome"]).startswith("RuntimeError") and str(g["force_specular_only.outcome"]).startswith("RuntimeError")
 
 
-@pytest.mark.parametrize("vt", ["sho", "spo", "shg", "spg", "bhg", "psh"])
+@pytest.mark.parametrize("vt", ["sho", "spo", "shg", "spg", "bhg", "psh", "i0"])
 def test_one_hint_and_hint_gradient_training_step_vs_reference(scene_states, vt):
     """One training step of the shadow-only / specular-only models and of the full model with shadow_hint_gradient /
     specular_hint_gradient / both (:379, :589): loss and the recorded gradient tensors."""
     from nrhints_amd.synthetic import one_hint_state
     g = load_npz("render_branches_b.npz")
     rays = [T(g["t." + k]) for k in ("o", "d", "pl", "near", "far")]
-    shadow, specular = vt != "spo", vt != "sho"
-    base = one_hint_state(scene_states["b"], shadow) if vt in ("sho", "spo") else scene_states["b"]
+    from nrhints_amd.synthetic import naive_state
+    shadow, specular = vt not in ("spo", "i0"), vt not in ("sho", "i0")
+    base = one_hint_state(scene_states["b"], shadow) if vt in ("sho", "spo") else (naive_state(scene_states["b"]) if vt == "i0" else scene_states["b"])
     for _ in (0,):
         st = {k: T(np.asarray(v)).clone().requires_grad_(True) for k, v in base.items()}
         out = orc.render_forward(orc.params_from_state(st), *rays, background_rgb=torch.ones(1, 3), is_training=True,
@@ -285,7 +293,7 @@ def test_one_hint_and_hint_gradient_training_step_vs_reference(scene_states, vt)
                                  t_rand_shadow=T(g[f"{vt}.t_rand_shadow"]) if shadow else None, mode="as_written",
                                  differentiable=True, shadow_hint=shadow, specular_hint=specular,
                                  shadow_hint_gradient=vt in ("shg", "bhg"), specular_hint_gradient=vt in ("spg", "bhg"),
-                                 n_shadow_importance_clip=8 if vt == "psh" else -1)
+                                 n_shadow_importance_clip=8 if vt == "psh" else -1, n_importance_samples=0 if vt == "i0" else 64)
         np.testing.assert_allclose(out["rgb"].detach().numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=5e-5)
         loss, _, _ = orc.train_loss(out, T(g["t.rgb_gt"]))
         np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)

@@ -216,9 +216,9 @@ def _color_net_torch(d, feat, pts, normal, per_ray, n, T, hints):
 
 def render_core_torch(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
                       background_rgb, analytic_normal: bool = False, packed=None, pre=None, dyn=None, hint_grad=None,
-                      sdf_impl: str = "manual"):
+                      n_real: int = 128, sdf_impl: str = "manual"):
     """autograd_core.render_core in torch ops: ``sdf_impl`` "manual" (hand-derived sweeps) | "autograd" (second-order graph)."""
-    assert hint_grad is None, "the torch back-ends cover the default (hint-constant) training path"
+    assert hint_grad is None and n_real == 128, "the torch back-ends cover the default (hint-constant, 128-sample) training path"
     n, T = mid_z.shape
     pts = (o[:, None, :] + dirs[:, None, :] * mid_z[..., None]).reshape(-1, 3)
     if sdf_impl == "autograd":
