@@ -314,6 +314,48 @@ def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
     return torch.stack(out, dim=-1)
 
 
+def nerf_forward(nerf: Dict[str, torch.Tensor], pts4, views, pls):
+    """The outside NeRF (fields/nerf_density_field.py:66-89): 8 x 256 ReLU layers on enc10(pts4), the input re-attached after layer 4
+    (cat[input, h], so layer 5 is 340 wide), density head, feature -> cat[feature, enc4(cat[view, light])] -> 128 ReLU -> rgb.
+    ``nerf``: the module's state dict (pts_linears.N.weight ...).  Returns (density [P,1], rgb pre-sigmoid [P,3])."""
+    x = nerf_encode(pts4, 10)
+    v = nerf_encode(torch.cat([views, pls], dim=-1), 4)
+    h = x
+    for i in range(8):
+        h = torch.relu(F.linear(h, nerf[f"pts_linears.{i}.weight"], nerf[f"pts_linears.{i}.bias"]))
+        if i == 4:
+            h = torch.cat([x, h], dim=-1)
+    density = F.linear(h, nerf["alpha_linear.weight"], nerf["alpha_linear.bias"])
+    feat = F.linear(h, nerf["feature_linear.weight"], nerf["feature_linear.bias"])
+    h = torch.relu(F.linear(torch.cat([feat, v], dim=-1), nerf["views_linears.0.weight"], nerf["views_linears.0.bias"]))
+    return density, F.linear(h, nerf["rgb_linear.weight"], nerf["rgb_linear.bias"])
+
+
+def outside_z(far, n_outside: int = 32, n_samples: int = 64, t_rand=None):
+    """Sample positions of the background beyond the unit sphere (models/neus_hint_model.py:677-693): inverse-depth spacing,
+    stratified jitter in training, ``far / flip(u) + 1 / n_samples``.  far [N,1] -> [N, n_outside]."""
+    u = torch.linspace(1e-3, 1.0 - 1.0 / (n_outside + 1.0), n_outside).to(far.dtype)
+    if t_rand is not None:
+        mids = 0.5 * (u[1:] + u[:-1])
+        upper, lower = torch.cat([mids, u[-1:]]), torch.cat([u[:1], mids])
+        u = lower[None, :] + (upper - lower)[None, :] * t_rand
+    return far / torch.flip(u, dims=[-1]) + 1.0 / n_samples
+
+
+def render_outside(nerf, o, d, pl, z, sample_dist: float):
+    """``render_outside`` (models/neus_hint_model.py:434-473) at the sorted positions z [N,n]: inverted-sphere parameterisation
+    (p / |p|, 1 / |p|) with |p| clipped to >= 1, alpha = 1 - exp(-softplus(density) dist).  -> (alpha [N,n], colour [N,n,3])."""
+    n, m = z.shape
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=z.dtype)], dim=-1)
+    mid = z + dists * 0.5
+    pts = o[:, None, :] + d[:, None, :] * mid[..., None]
+    r = torch.linalg.norm(pts, ord=2, dim=-1, keepdim=True).clip(1.0, 1e10)
+    pts4 = torch.cat([pts / r, 1.0 / r], dim=-1).reshape(-1, 4)
+    density, col = nerf_forward(nerf, pts4, d[:, None, :].expand(n, m, 3).reshape(-1, 3), pl[:, None, :].expand(n, m, 3).reshape(-1, 3))
+    alpha = 1.0 - torch.exp(-F.softplus(density.reshape(n, m)) * dists)
+    return alpha, torch.sigmoid(col).reshape(n, m, 3)
+
+
 def sphere_trace(p: OracleParams, o, d, iterations: int = 2000, threshold: float = 1e-4, far: float = 100.0):
     """``NeuSHintRenderer.sphere_trace`` (models/neus_hint_model.py:359-372): from the ray origins, advance each ray by the SDF
     at its point until |sdf| < threshold or the travelled depth exceeds ``far``; -> (points [N,3], depths [N,1])."""
@@ -337,7 +379,8 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    mode="minimal", keep_intermediates=False, differentiable=False, hints=True,
                    analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0,
                    depth_sphere_tracing=False, shadow_hint=None, specular_hint=None, shadow_hint_gradient=False,
-                   specular_hint_gradient=False, n_shadow_importance_clip=-1, n_importance_samples=64) -> Dict[str, torch.Tensor]:
+                   specular_hint_gradient=False, n_shadow_importance_clip=-1, n_importance_samples=64, outside_nerf=None,
+                   t_rand_outside=None) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
@@ -358,6 +401,11 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
         with torch.no_grad():
             z = hierarchical_z(p, o, d, z, full_forward=(mode == "as_written"))  # :696-713
     T = z.shape[1]
+    bg_alpha = bg_col = None
+    if outside_nerf is not None:                              # renderer.use_outside_nerf (:715-724)
+        z_out = outside_z(far, 32, 64, t_rand_outside if is_training else None)
+        z_feed, _ = torch.sort(torch.cat([z, z_out], dim=-1), dim=-1)
+        bg_alpha, bg_col = render_outside(outside_nerf, o, d, pl, z_feed, sample_dist)
     # ---- render_core ----
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=dt)], dim=-1)
     mid = z + dists * 0.5
@@ -372,8 +420,11 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, T)
     radius = torch.linalg.norm(pts, dim=-1).reshape(n, T)
     inside = (radius < 1.0).to(dt)
-    weights = alpha * excl_cumprod_one_minus(alpha)            # :521-523
-    wsum = weights.sum(-1, keepdim=True)
+    if bg_alpha is not None:                                   # :516-519: NeuS inside the unit sphere, the NeRF outside and beyond
+        alpha = torch.cat([alpha * inside + bg_alpha[:, :T] * (1.0 - inside), bg_alpha[:, T:]], dim=-1)
+    weights_all = alpha * excl_cumprod_one_minus(alpha)        # :521-523
+    wsum = weights_all.sum(-1, keepdim=True)
+    weights = weights_all[:, :T]                               # neus_weights (:524): depth, hit normal
     with torch.no_grad():
         if depth_sphere_tracing:                               # DepthComputationType.SphereTracing (:527-528)
             hit, depth = sphere_trace(p, o, d, 2000, 1e-4, 100.0)
@@ -411,10 +462,14 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
             cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :590-615, :617-619
         cue_s = cue[:, None, :].expand(n, T, 4).reshape(-1, 4)
     col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, T, 3)  # :621-626
-    rgb = (col * weights[..., None]).sum(1)
+    if bg_col is not None:                                     # :630-633
+        col_all = torch.cat([col * inside[..., None] + bg_col[:, :T] * (1.0 - inside)[..., None], bg_col[:, T:]], dim=1)
+    else:
+        col_all = col
+    rgb = (col_all * weights_all[..., None]).sum(1)
     if background_rgb is not None:
         rgb = rgb + background_rgb * (1.0 - wsum)              # :635-637
-    out = dict(rgb=rgb, depth=depth, weights=weights, s_val=(1.0 / inv_s).expand(n, T),
+    out = dict(rgb=rgb, depth=depth, weights=weights_all, s_val=(1.0 / inv_s).expand(n, T),
                inside_sphere=inside, relax_inside_sphere=inside,            # :745 (quirk kept)
                analytic_normals=grad.reshape(n, T, 3),
                normalized_analytic_normals=n_hat.reshape(n, T, 3),

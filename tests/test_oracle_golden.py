@@ -303,3 +303,41 @@ def test_one_hint_and_hint_gradient_training_step_vs_reference(scene_states, vt)
             bound, scale = grad_bound(g[k], g[k.replace(".grad.", ".grad64.")])
             err = float(np.abs(st[name].grad.numpy() - g[k.replace(".grad.", ".grad64.")]).max())
             assert err <= bound, (vt, name, err, bound, scale)
+
+
+def test_outside_nerf_vs_reference(scene_states):
+    """renderer.use_outside_nerf (models/neus_hint_model.py:434-473, :516-519, :630-633, :677-724; fields/nerf_density_field.py):
+    the NeRF on its own, the evaluation render (160 weights per ray: 128 blended + 32 beyond the sphere) and one training step's
+    loss and recorded gradients, against tests/golden/outside_b.npz (make_golden_outside.py)."""
+    g = load_npz("outside_b.npz")
+    nerf = {k[5:]: T(v) for k, v in g.items() if k.startswith("nerf.")}
+    dens, col = orc.nerf_forward(nerf, T(g["unit.pts4"]), T(g["unit.views"]), T(g["unit.pls"]))
+    np.testing.assert_allclose(dens.numpy(), g["unit.density"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(col.numpy(), g["unit.rgb"], rtol=0, atol=2e-6)
+    rays = [T(g[k]) for k in ("o", "d", "pl", "near", "far")]
+    out = orc.render_forward(orc.params_from_state(scene_states["b"]), *rays, background_rgb=torch.ones(1, 3), mode="as_written",
+                             outside_nerf=nerf)
+    assert out["weights"].shape == (64, 160)
+    np.testing.assert_allclose(out["rgb"].numpy(), g["eval.rgb"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["depth"].numpy(), g["eval.depth"], rtol=0, atol=2e-4)
+    dw = np.abs(out["weights"].numpy() - g["eval.weights"])
+    assert dw.mean() < 3e-5 and dw.max() < 5e-3
+    assert float(g["eval.weights"][:, 128:].sum(-1).mean()) > 0.05           # the background is seen on these rays
+    np.testing.assert_allclose(out["visibilities"].numpy(), g["eval.visibilities"], rtol=0, atol=2e-3)
+    # one training step
+    st = {k: T(np.asarray(v)).clone().requires_grad_(True) for k, v in scene_states["b"].items()}
+    nerf_l = {k: v.clone().requires_grad_(True) for k, v in nerf.items()}
+    trays = [T(g["t." + k]) for k in ("o", "d", "pl", "near", "far")]
+    out = orc.render_forward(orc.params_from_state(st), *trays, background_rgb=torch.ones(1, 3), is_training=True,
+                             global_step=int(g["t.global_step"]), t_rand_primary=T(g["t.t_rand_primary"]), t_rand_shadow=T(g["t.t_rand_shadow"]),
+                             mode="as_written", differentiable=True, outside_nerf=nerf_l, t_rand_outside=T(g["t.t_rand_outside"]))
+    np.testing.assert_allclose(out["rgb"].detach().numpy(), g["t.rgb"], rtol=0, atol=5e-5)
+    loss, _, _ = orc.train_loss(out, T(g["t.rgb_gt"]))
+    np.testing.assert_allclose(loss.item(), g["t.loss"], rtol=1e-4)
+    loss.backward()
+    for k in (k for k in g if k.startswith("t.grad.") and ".rays." not in k):
+        name = k[len("t.grad."):]
+        got = (nerf_l[name[len("outside_nerf."):]] if name.startswith("outside_nerf.") else st[name]).grad.numpy()
+        bound, scale = grad_bound(g[k], g[k.replace("t.grad.", "t.grad64.")], factor=4.0, floor=5e-3)     # a 32-ray fixture (conftest)
+        err = float(np.abs(got - g[k.replace("t.grad.", "t.grad64.")]).max())
+        assert err <= bound, (name, err, bound, scale)
