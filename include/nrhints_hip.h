@@ -225,6 +225,14 @@ typedef struct NrhNet {
   int samples;              /* 0 or 128: 64 stratified + 64 importance samples per ray; 64: renderer.n_importance_samples = 0
                                (models/neus_hint_model.py:696 - no hierarchical sampling, the 64 coarse samples are final).  The
                                per-sample arrays keep 128 entries per ray; entries 64..127 are padding with weight exactly 0 */
+  /* renderer.use_outside_nerf (models/neus_hint_model.py:516-519, :630-633): the background network is the caller's; these carry its
+     results into the call and what the caller needs back out of it.  All NULL otherwise. */
+  const float* bg_alpha;    /* [nrays,160] alpha of render_outside at the merged sample positions (first 128 = this ray's samples):
+                               a sample outside the unit sphere takes it instead of the NeuS alpha - weights, depth, hit point,
+                               shadow march and cue follow */
+  float* tail_t;            /* out [nrays]: transmittance behind sample 127 (the 32 samples beyond the sphere start from it) */
+  float* sampled_color;     /* out [nrays,128,3]: the reflectance net's colour per sample (the caller blends and composites; the
+                               call's own `rgb` is then NOT the final colour) */
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);
@@ -393,6 +401,23 @@ int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const fl
  * grad / dists at its 128 sections, visibilities [n] = transmittance in front of the last sample; the adjoint takes
  * d loss / d visibility [n] and returns the adjoints of sdf [n,128], grad [n*128,3], the shadow ray's direction [n,3] and the
  * per-ray partial of d loss / d inv_s [n] (feed nrh_variance_grad). */
+/* ---- renderer.use_outside_nerf: what surrounds the caller's background network ------------------------------------------------
+ * nrh_sample_primary: coarse z + the four hierarchical sampling steps of NeuSHintRenderer.forward (:673-713) on their own:
+ *   z_vals [n,128] sorted sample positions, mid_z / dists [n,128] as nrh_render_forward computes them (the same call sequence,
+ *   so a later nrh_render_forward on the same inputs places the same samples).  workspace: >= 128 n + 32 n + 192 floats.
+ * nrh_alpha_blend_forward / _backward: nrh_alpha_train_* with alpha <- alpha inside_sphere + bg_alpha[:, :128] (1 - inside_sphere)
+ *   (bg_alpha row stride 160) and the transmittance behind the last sample as an extra output (tail_t [n]) / adjoint input; the
+ *   adjoint also returns d loss / d bg_alpha[:, :128] (bg_alpha_bar [n,128]). */
+int nrh_sample_primary(const NrhNet* net, const float* origins, const float* directions, const float* nears, const float* fars,
+                       long long nrays, const float* t_rand_primary, const float* lin64, const float* lin16, float* z_vals, float* mid_z,
+                       float* dists, float* workspace, long long workspace_floats, void* stream);
+int nrh_alpha_blend_forward(const float* sdf, const float* grad, const float* rd, const float* dists, const float* inside_sphere,
+                            const float* bg_alpha, float inv_s, float cos_anneal, const float* dyn_scalars, long long nrays,
+                            float* weights, float* nhat, float* tail_t, void* stream);
+int nrh_alpha_blend_backward(const float* sdf, const float* grad, const float* rd, const float* dists, const float* inside_sphere,
+                             const float* bg_alpha, float inv_s, float cos_anneal, const float* dyn_scalars, long long nrays,
+                             const float* weights_bar, const float* nhat_bar, const float* tail_t_bar, float* sdf_bar, float* grad_bar,
+                             float* rd_bar, float* invs_bar, float* bg_alpha_bar, void* stream);
 /* nrh_alpha_train_forward / _backward for rays with n_real = 64 or 128 existing samples of the 128 slots (NrhNet.samples):
  * padded samples have alpha = 0 and receive zero adjoints. */
 int nrh_alpha_train_forward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,

@@ -21,6 +21,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
             "nrh_shadow_alpha_forward", "nrh_shadow_alpha_backward", "nrh_alpha_train_forward_n", "nrh_alpha_train_backward_n",
+            "nrh_sample_primary", "nrh_alpha_blend_forward", "nrh_alpha_blend_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_forward_grouped", "nrh_color_train_backward",
             "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes",
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
@@ -35,7 +36,7 @@ class NrhNet(Structure):
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
                 ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
                 ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int), ("shadow_clip", c_int),
-                ("samples", c_int)]
+                ("samples", c_int), ("bg_alpha", c_void_p), ("tail_t", c_void_p), ("sampled_color", c_void_p)]
 
 
 class NrhAdamTensor(Structure):
@@ -83,6 +84,9 @@ def load():
     lib.nrh_alpha_train_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P]
     lib.nrh_alpha_train_forward_n.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P, P]
     lib.nrh_alpha_train_backward_n.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P, P, P, P, P, P]
+    lib.nrh_sample_primary.argtypes = [POINTER(NrhNet), P, P, P, P, c_longlong, P, P, P, P, P, P, P, c_longlong, P]
+    lib.nrh_alpha_blend_forward.argtypes = [P, P, P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P]
+    lib.nrh_alpha_blend_backward.argtypes = [P, P, P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P, P, P]
     lib.nrh_shadow_alpha_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P]
     lib.nrh_shadow_alpha_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P]
     lib.nrh_color_transposed_floats.argtypes = [c_int]
@@ -190,7 +194,7 @@ def stream_handle(device=None):
 
 
 def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False,
-             shadow_clip=-1, samples=128):
+             shadow_clip=-1, samples=128, bg_alpha=None, tail_t=None, sampled_color=None):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
     ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""
@@ -203,4 +207,4 @@ def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fu
                   hints, normal_type, depth_type, ptr(dyn_scalars),
                   ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
                   ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None,
-                  int(bool(shadow_jvp and w32 is not None)), int(shadow_clip), int(samples))
+                  int(bool(shadow_jvp and w32 is not None)), int(shadow_clip), int(samples), ptr(bg_alpha), ptr(tail_t), ptr(sampled_color))

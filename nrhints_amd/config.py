@@ -49,6 +49,16 @@ class ReflectanceNetConfig:
 
 
 @dataclass(frozen=True)
+class NeRFConfig:
+    """The outside-NeRF background network (fields/nerf_density_field.py:12-25)."""
+    d_hidden: int = 256
+    n_layers: int = 8
+    multi_res: int = 10
+    multi_res_view: int = 4
+    skips: List[int] = field(default_factory=lambda: [4])
+
+
+@dataclass(frozen=True)
 class SingleVarianceNetConfig:
     init_val: float = 0.3
 
@@ -79,6 +89,7 @@ class NeuSRendererConfig:
 @dataclass(frozen=True)
 class NeuSModelConfig:
     sdf_network: SDFNetConfig = field(default_factory=SDFNetConfig)
+    outside_nerf: NeRFConfig = field(default_factory=NeRFConfig)
     deviation_network: SingleVarianceNetConfig = field(default_factory=SingleVarianceNetConfig)
     reflectance_network: ReflectanceNetConfig = field(default_factory=ReflectanceNetConfig)
     renderer: NeuSRendererConfig = field(default_factory=NeuSRendererConfig)
@@ -98,13 +109,19 @@ class NeuSModelConfig:
 def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
     """None if ``cfg`` is the network/renderer shape the gfx950 kernels are compiled for, else why not."""
     s, c, r = cfg.sdf_network, cfg.reflectance_network, cfg.renderer
+    n = getattr(cfg, "outside_nerf", None) or NeRFConfig()
     checks = [
         (s.d_in == 3 and s.d_out_feat == 256 and s.d_hidden == 256 and s.n_layers == 8 and list(s.skip_in) == [4]
          and s.multi_res == 6 and s.weight_norm and not s.inside_outside and float(s.scale) == 3.0,
          "sdf_network must be the default 8x256 / skip_in=[4] / multi_res=6 / scale=3 MLP"),
         (c.d_hidden == 256 and c.n_layers == 4 and c.multi_res == 4 and c.weight_norm and c.squeeze_out,
          "reflectance_network must be the default 4x256 / multi_res=4 / sigmoid MLP"),
-        (not r.use_outside_nerf, "use_outside_nerf=True (outside NeRF background) is not implemented"),
+        (not r.use_outside_nerf or (r.n_outside_samples == 32 and r.n_importance_samples == 64 and r.n_shadow_importance_clip == -1
+                                    and not r.shadow_hint_gradient and not r.specular_hint_gradient),
+         "use_outside_nerf needs n_outside_samples = 32, the 128-sample layout, the hit-point shadow mode and no hint gradients"),
+        (not r.use_outside_nerf or (n.d_hidden == 256 and n.n_layers == 8 and n.multi_res == 10 and n.multi_res_view == 4
+                                    and list(n.skips) == [4]),
+         "outside_nerf must be the default 8x256 / multires 10 + 4 / skips=[4] network"),
         (r.n_samples == 64 and ((r.n_importance_samples == 64 and r.up_sample_steps == 4) or r.n_importance_samples == 0),
          "n_samples must be 64 and n_importance_samples / up_sample_steps 64 / 4, or n_importance_samples 0 (no hierarchical sampling)"),
         (not (r.n_importance_samples == 0 and r.shadow_hint and r.n_shadow_importance_clip > 0),

@@ -276,7 +276,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 133; }
+int nrh_version(void) { return 134; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -549,6 +549,65 @@ int nrh_alpha_train_forward_n(const float* sdf, const float* grad, const float* 
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("alpha_train_kernel<fwd>");
+}
+
+// ---- renderer.use_outside_nerf: the pieces around the caller's background network -------------------------------------------
+int nrh_sample_primary(const NrhNet* net, const float* origins, const float* directions, const float* nears, const float* fars,
+                       long long nrays, const float* t_rand_primary, const float* lin64, const float* lin16, float* z_vals, float* mid_z,
+                       float* dists, float* workspace, long long workspace_floats, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !origins || !directions || !nears || !fars || !lin64 || !lin16 || !z_vals ||
+      !mid_z || !dists || !workspace)
+    return fail(NRH_E_INVALID, "nrh_sample_primary: null pointer%s", "");
+  if (nrays < 0 || nrays > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_sample_primary: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  const long long n = nrays;
+  if (workspace_floats < round64(n * 128) + 2 * round64(n * 16)) return fail(NRH_E_WORKSPACE, "nrh_sample_primary: workspace too small%s", "");
+  float* sbuf = workspace;
+  float* znew = sbuf + round64(n * 128);
+  float* snew = znew + round64(n * 16);
+  nrh::CoarseArgs c;
+  c.near_ = nears; c.far_ = fars; c.lin64 = lin64; c.t_rand = t_rand_primary; c.z = z_vals; c.nrays = (int)n;
+  hipLaunchKernelGGL(nrh::coarse_z_kernel, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, c);
+  int rc = check_launch("coarse_z_kernel");
+  if (rc) return rc;
+  return run_sampler(net, origins, directions, z_vals, sbuf, znew, snew, lin16, nullptr, 2.0f / 64.0f, mid_z, dists, n, st);
+}
+
+int nrh_alpha_blend_forward(const float* sdf, const float* grad, const float* rd, const float* dists, const float* inside_sphere,
+                            const float* bg_alpha, float inv_s, float cos_anneal, const float* dyn_scalars, long long nrays,
+                            float* weights, float* nhat, float* tail_t, void* stream) {
+  if (!sdf || !grad || !rd || !dists || !inside_sphere || !bg_alpha || !weights || !nhat || !tail_t)
+    return fail(NRH_E_INVALID, "nrh_alpha_blend_forward: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_blend_forward: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::AlphaTrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.dyn = dyn_scalars; a.inside = inside_sphere; a.bg_alpha = bg_alpha; a.weights = weights; a.nhat = nhat; a.tail_t = tail_t;
+  const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
+  hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("alpha_train_kernel<fwd, blend>");
+}
+
+int nrh_alpha_blend_backward(const float* sdf, const float* grad, const float* rd, const float* dists, const float* inside_sphere,
+                             const float* bg_alpha, float inv_s, float cos_anneal, const float* dyn_scalars, long long nrays,
+                             const float* weights_bar, const float* nhat_bar, const float* tail_t_bar, float* sdf_bar, float* grad_bar,
+                             float* rd_bar, float* invs_bar, float* bg_alpha_bar, void* stream) {
+  if (!sdf || !grad || !rd || !dists || !inside_sphere || !bg_alpha || !weights_bar || !tail_t_bar || !sdf_bar || !grad_bar || !rd_bar ||
+      !invs_bar || !bg_alpha_bar)
+    return fail(NRH_E_INVALID, "nrh_alpha_blend_backward: null pointer%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_blend_backward: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::AlphaTrainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf; a.grad = grad; a.rd = rd; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
+  a.dyn = dyn_scalars; a.inside = inside_sphere; a.bg_alpha = bg_alpha; a.weights_bar = weights_bar; a.nhat_bar = nhat_bar;
+  a.tail_t_bar = tail_t_bar; a.sdf_bar = sdf_bar; a.grad_bar = grad_bar; a.rd_bar = rd_bar; a.invs_bar = invs_bar;
+  a.bg_alpha_bar = bg_alpha_bar;
+  const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
+  hipLaunchKernelGGL(nrh::alpha_train_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("alpha_train_kernel<adjoint, blend>");
 }
 
 // the shadow ray's alpha stage for renderer.shadow_hint_gradient: visibility = transmittance in front of the last sample
@@ -929,6 +988,8 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type must be 0 or 1, depth_type 0, 1 or 2%s", "");
   if (net->samples != 0 && net->samples != 64 && net->samples != 128)
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: NrhNet.samples must be 0 / 128 (64 + 64 importance) or 64 (no importance samples)%s", "");
+  if (net->bg_alpha && (net->samples == 64 || net->shadow_clip > 0))
+    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: the outside-NeRF blend needs the 128-sample layout and the hit-point shadow mode%s", "");
   if (net->samples == 64 && net->shadow_clip > 0)
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: the partial visibility hint needs the 128-sample layout%s", "");
   const int no_hints = zero_hints || !net->hints;  // no shadow march: geometry warm-up, or the pl-naive model
@@ -1017,6 +1078,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
       c.depth_in = st_depth; c.hit_in = st_pts;
     }
     c.zero_hints = no_hints;
+    c.bg_alpha = net->bg_alpha; c.tail_t = net->tail_t;
     c.nreal = net->samples == 64 ? 64 : 0;
     c.depth_max_weight = net->depth_type == 1;
     c.nrays = (int)n;
@@ -1082,6 +1144,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   }
   if (train) return NRH_OK;  // reflectance + composite are differentiated by the caller
   // ---- reflectance + composite ----
+  if (net->sampled_color) ws_color = net->sampled_color;      // outside NeRF: the caller blends the colours itself (:630-633)
   // feat_fused: ws_feat holds W0feat * feature (the wide mode-2 stream was packed with the product matrix)
   const int fused = (net->precision == 1 && net->feat_fused && net->sdf_w32 && net->sdf_tab32) ? 1 : 0;
   if (fused && net->hints && net->col_w32 && net->col_tab32 && !clip) {

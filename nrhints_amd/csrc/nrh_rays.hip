@@ -284,6 +284,11 @@ struct CoreArgs {
   int zero_hints;  // geometry warm-up: cue = 0 (:617-619)
   int depth_max_weight;  // DepthComputationType.MaximalWeightPoint (:534-538) instead of alpha blending
   int nreal;             // samples per ray that exist (0 = all 128; 64 for n_importance_samples = 0): the rest get alpha = 0
+  // renderer.use_outside_nerf (:516-519): outside the unit sphere a sample's alpha is the background NeRF's.  bg_alpha [N,160]
+  // (the caller's render_outside at the merged positions; the first 128 are this ray's samples), tail_t [N] out = transmittance
+  // behind sample 127, from which the caller composites the 32 samples beyond the sphere; both null otherwise
+  const float* bg_alpha;
+  float* tail_t;
   int nrays;
 };
 
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
     const float px = ox + dx * mid[e], py = oy + dy * mid[e], pz = oz + dz * mid[e];
     ins[e] = (sqrtf(px * px + py * py + pz * pz) < 1.0f) ? 1.0f : 0.0f;
     if (a.nreal && lane + 64 * e >= a.nreal) { al[e] = 0.0f; ins[e] = 0.0f; }   // padded sample: no weight, not counted
+    if (a.bg_alpha) al[e] = al[e] * ins[e] + a.bg_alpha[ray * 160 + lane + 64 * e] * (1.0f - ins[e]);
     const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps
     nh[e][0] = gx / gn;
     nh[e][1] = gy / gn;
@@ -394,6 +400,7 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
       zj = lower + (upper - lower) * a.t_rand_shadow[ray * 64 + lane];
     }
     a.zs[ray * 128 + lane] = zj;
+    if (a.tail_t && lane == 63) a.tail_t[ray] = T1 * (1.0f - al[1] + 1e-7f);
     if (lane == 0) {
       a.depth[ray] = depth;
       a.wsum[ray] = wsum;

@@ -43,6 +43,11 @@ struct AlphaTrainArgs {
   // T_127 = prod_{k<127} (1 - alpha_k + 1e-7) (get_visibility :428-432), not a weight
   int nreal;               // samples per ray that exist (0 = all 128; 64 for n_importance_samples = 0): the rest have alpha = 0
                            // and receive zero adjoints
+  // renderer.use_outside_nerf: alpha <- alpha inside + bg_alpha (1 - inside) (models/neus_hint_model.py:516-519), `inside` as above
+  const float* bg_alpha;   // [N,160] row stride 160 (first 128 used), or null
+  float* bg_alpha_bar;     // adjoint: [N,128] d loss / d bg_alpha[:, :128]
+  float* tail_t;           // forward: [N] transmittance behind sample 127 (the 32 samples beyond the sphere start from it)
+  const float* tail_t_bar; // adjoint: [N] d loss / d tail_t
   float* tlast;            // forward: [N] T_127, or null
   const float* tlast_bar;  // adjoint: [N] d loss / d T_127 (added to the transmittance adjoint of sample 127), or null
 };
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
     q[e] = (pc[e] - nc[e] + 1e-5f) / (pc[e] + 1e-5f);
     al[e] = fminf(fmaxf(q[e], 0.0f), 1.0f);
     if (a.nreal && lane + 64 * e >= a.nreal) al[e] = 0.0f;
+    if (a.bg_alpha) al[e] = al[e] * a.inside[P] + a.bg_alpha[ray * 160 + lane + 64 * e] * (1.0f - a.inside[P]);
     f[e] = 1.0f - al[e] + 1e-7f;
     gn[e] = fmaxf(sqrtf(g[e][0] * g[e][0] + g[e][1] * g[e][1] + g[e][2] * g[e][2]), 1e-12f);  // F.normalize eps
   }
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
         }
       }
       if (a.tlast && lane == 63) a.tlast[ray] = T[1];
+      if (a.tail_t && lane == 63) a.tail_t[ray] = T[1] * f[1];
     }
     return;
   }
@@ -118,12 +125,18 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
   if (a.tlast_bar && lane == 63) x[1] += a.tlast_bar[ray] * T[1];   // T_127 is an output itself: Tbar_127 += tlast_bar
   float suf[2];
   suffix_sum_128(x[0], x[1], suf[0], suf[1]);
+  // the transmittance behind the last sample is an output too (outside NeRF): a virtual 129th entry of the suffix sums
+  const float extra = a.tail_t_bar ? a.tail_t_bar[ray] * __shfl(T[1] * f[1], 63, 64) : 0.0f;
   float rdb[3] = {0.f, 0.f, 0.f}, Sb = 0.0f;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const long long P = ray * 128 + lane + 64 * e;
-    const float fbar = (suf[e] - x[e]) / f[e];                 // sum_{i>k} Tbar_i T_i / f_k  (cumprod backward)
-    const float abar = wb[e] * T[e] - fbar;
+    const float fbar = (suf[e] - x[e] + extra) / f[e];         // sum_{i>k} Tbar_i T_i / f_k  (cumprod backward)
+    float abar = wb[e] * T[e] - fbar;
+    if (a.bg_alpha) {                                          // alpha = alpha_neus inside + bg (1 - inside)
+      if (active) a.bg_alpha_bar[P] = abar * (1.0f - a.inside[P]);
+      abar *= a.inside[P];
+    }
     const bool pad = a.nreal && lane + 64 * e >= a.nreal;               // padded sample: alpha was forced to 0
     const float qbar = (!pad && q[e] >= 0.0f && q[e] <= 1.0f) ? abar : 0.0f;   // clamp passes the gradient on [min, max]
     const float ipc = 1.0f / (pc[e] + 1e-5f);

@@ -146,6 +146,11 @@ class NeuSHintRenderer(nn.Module):
         n_cue = len(config.renderer.specular_roughness) if self.has_specular_hint else 0
         self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + int(self.has_shadow_hint) + n_cue, 3,
                                                 config.reflectance_network, n_cue, self.has_shadow_hint)
+        self.has_outside_nerf = bool(config.renderer.use_outside_nerf)
+        if self.has_outside_nerf:      # constructed after the reflectance net, as the reference does (:260-266)
+            from .outside import OutsideNeRF
+            nc = config.outside_nerf
+            self.outside_nerf = OutsideNeRF(4, 6, nc.d_hidden, nc.n_layers, nc.multi_res, nc.multi_res_view, nc.skips)
         self._packed = None
         self._pack_plan = None
         self._pack_plan32 = None
@@ -247,8 +252,14 @@ class NeuSHintRenderer(nn.Module):
     # ---------------------------------------------------------------------------------------------
     def forward(self, ray_bundle: RayBundle, is_training: bool = False, background_rgb: Optional[torch.Tensor] = None,
                 global_step: int = 0, _t_rand_primary: Optional[torch.Tensor] = None,
-                _t_rand_shadow: Optional[torch.Tensor] = None) -> RenderOutput:
+                _t_rand_shadow: Optional[torch.Tensor] = None, _t_rand_outside: Optional[torch.Tensor] = None) -> RenderOutput:
         o = ray_bundle.origins
+        if self.has_outside_nerf:
+            if not (torch.is_tensor(o) and o.is_cuda):
+                raise RuntimeError("NeuSHintRenderer (MI355X) runs on the GPU only")
+            with torch.cuda.device(o.device):
+                return self._forward_outside(ray_bundle, is_training, background_rgb, global_step, _t_rand_primary, _t_rand_shadow,
+                                             _t_rand_outside)
         if torch.is_tensor(o) and o.is_cuda:
             # every C call below launches on "the current stream of the current device": make that the rays' device
             with torch.cuda.device(o.device):
@@ -354,6 +365,103 @@ class NeuSHintRenderer(nn.Module):
                             normalized_analytic_normals=cut(nhat), visibilities=vis if self.has_shadow_hint else None,
                             specular_cue=cut(cue) if self.has_specular_hint else None)
 
+    # ---------------------------------------------------------------------------------------------
+    max_outside_rays = 8192     # rays per pass of the outside-NeRF branch (its [N,160] network evaluation lives in torch)
+
+    def _forward_outside(self, ray_bundle, is_training, background_rgb, global_step, t_p, t_s, t_o) -> RenderOutput:
+        """``forward`` with the outside-NeRF background (renderer.use_outside_nerf; see outside.py for who computes what)."""
+        from . import outside
+        from .containers import td_concat
+        n = ray_bundle.origins.shape[0]
+        dev = ray_bundle.origins.device
+        if is_training:      # the reference's draw order: primary [N,1] (:682), outside [N,32] (:689), shadow [N,64] (:394)
+            t_p = torch.rand(n, 1, device=dev) if t_p is None else t_p.to(dev)
+            t_o = torch.rand(n, outside.N_OUTSIDE, device=dev) if t_o is None else t_o.to(dev)
+            warm = global_step < self.config.geometry_warmup_end
+            t_s = (None if warm else torch.rand(n, 64, device=dev)) if t_s is None else t_s.to(dev)
+        outs = []
+        for i in range(0, n, self.max_outside_rays):
+            sl = slice(i, i + self.max_outside_rays)
+            rb = RayBundle(origins=ray_bundle.origins[sl], directions=ray_bundle.directions[sl], pl_positions=ray_bundle.pl_positions[sl],
+                           nears=ray_bundle.nears[sl], fars=ray_bundle.fars[sl])
+            cut = lambda t: None if t is None else t[sl]
+            outs.append(self._outside_pass(rb, is_training, background_rgb, global_step, cut(t_p), cut(t_s), cut(t_o)))
+        return outs[0] if len(outs) == 1 else td_concat(outs)
+
+    def _outside_pass(self, ray_bundle, is_training, background_rgb, global_step, t_p, t_s, t_o) -> RenderOutput:
+        from . import outside
+        lib = _lib.load()
+        o_g, d_g, pl_g = ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions
+        device, n = o_g.device, o_g.shape[0]
+        needs_grad = torch.is_grad_enabled() and (
+            any(t.requires_grad for t in (o_g, d_g, pl_g)) or any(p.requires_grad for p in self.parameters()))
+        f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
+        o, d, pl = f32(o_g), f32(d_g), f32(pl_g)
+        near, far = f32(ray_bundle.nears).reshape(-1), f32(ray_bundle.fars).reshape(-1)
+        cfg = self.config
+        cos_anneal = min(1.0, global_step / cfg.anneal_end) if (is_training and cfg.anneal_end > 0) else 1.0
+        zero_hints = 1 if (is_training and global_step < cfg.geometry_warmup_end) else 0
+        t_rand_p = f32(t_p).reshape(-1) if is_training else None
+        t_rand_s = f32(t_s) if (is_training and not zero_hints and self._hints) else None
+        bgc = None if background_rgb is None else f32(background_rgb.to(device)).reshape(1, 3)
+        dense = None
+        if needs_grad:
+            named = dict(self.named_parameters())
+            dense = self._pad_hint_columns(packing.dense_params_hip({k: v for k, v in named.items() if not k.startswith("outside_nerf.")}))
+            self.packed_params(device, dense=dense)
+        pk = self.packed_params(device)
+        if self.dyn_scalars is not None:
+            raise RuntimeError("the outside-NeRF branch runs eagerly (release the GraphedTrainStep first)")
+        # 1. where the primary ray's samples are (the background network needs them before the alpha stage can blend)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
+        z, mid0, dists0 = new(n, 128), new(n, 128), new(n, 128)
+        lin64, lin16 = self._const(device)
+        net0 = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, None, wide=self.wide_kernels)
+        ws = self._workspace(device, n)
+        P = _lib.ptr
+        _lib.check(lib.nrh_sample_primary(net0, P(o), P(d), P(near), P(far), n, P(t_rand_p), P(lin64), P(lin16), P(z), P(mid0), P(dists0),
+                                          P(ws), ws.numel(), _lib.stream_handle()), "nrh_sample_primary")
+        # 2. the background at the merged positions (:715-724): library GEMMs, autograd when training
+        with torch.set_grad_enabled(needs_grad):
+            far_g = ray_bundle.fars.to(torch.float32).reshape(-1, 1)
+            z_out = outside.outside_z(far_g, cfg.renderer.n_samples, f32(t_o) if is_training else None)
+            z_feed, _ = torch.sort(torch.cat([z, z_out], dim=-1), dim=-1)
+            bg_alpha, bg_col = outside.render_outside(self.outside_nerf, o_g.to(torch.float32), d_g.to(torch.float32), pl_g.to(torch.float32),
+                                                      z_feed, 2.0 / cfg.renderer.n_samples)
+        bg_a = bg_alpha.detach().contiguous()
+        extra = dict(bg_alpha=bg_a, tail_t=new(n), sampled_color=None)
+        if not needs_grad:
+            extra["sampled_color"] = new(n, 128, 3)
+            res = self._render_chunks(o, d, pl, near, far, bgc.reshape(-1) if bgc is not None else None, cos_anneal, t_rand_p, t_rand_s, zero_hints,
+                                      want_samples=True, want_maps=False, want_mid=False, extra_net=extra)
+            comp = outside.composite(res["weights"], extra["tail_t"].reshape(n, 1), res["inside"], extra["sampled_color"], bg_a, bg_col, bgc)
+            s_val = torch.full((1, 1), 1.0 / self._host_inv_s(pk, device), dtype=torch.float32, device=device).expand(n, 128)
+            return RenderOutput(rgb=comp["rgb"], depth=res["depth"], weights=comp["weights"], s_val=s_val, inside_sphere=res["inside"],
+                                relax_inside_sphere=res["inside"], analytic_normals=res["normals"], normalized_analytic_normals=res["nhat"],
+                                visibilities=res["visibilities"] if self.has_shadow_hint else None,
+                                specular_cue=res["cue"] if self.has_specular_hint else None)
+        if n > self.max_fused_train_rays:
+            raise ValueError("training with use_outside_nerf needs at most max_fused_train_rays rays per call")
+        res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, extra_net=extra)
+        mid_z, dists, inside = res["mid_z"], res["dists"], res["inside"]
+        pts = (o_g.to(torch.float32)[:, None, :] + d_g.to(torch.float32)[:, None, :] * mid_z[..., None]).reshape(-1, 3)
+        sdf, feat, grad = autograd_core.sdf_value_feat_grad(dense, pts, packed=pk, pre=res.get("pre"))
+        weights128, n_hat, tail_t = outside.AlphaBlendHip.apply(sdf, grad, d_g.to(torch.float32), dists, inside, bg_alpha,
+                                                                self.deviation_network.variance, pk["inv_s"], cos_anneal, None)
+        per_ray = [autograd_core._enc(d_g.to(torch.float32), 4), autograd_core._enc(pl_g.to(torch.float32), 4)]
+        if self._hints:
+            per_ray += [autograd_core._enc(res["visibilities"], 4), autograd_core._enc(res["cue"][:, 0, :].contiguous(), 4)]
+        normal = grad if self._normal_type else n_hat
+        col = autograd_core.ColorNetHip.apply(feat, pts, normal, torch.cat(per_ray, dim=-1), pk,
+                                              *[dense[f"col_w{l}"] for l in range(5)], *[dense[f"col_b{l}"] for l in range(5)]).reshape(n, 128, 3)
+        comp = outside.composite(weights128, tail_t, inside, col, bg_alpha, bg_col, bgc)
+        inv_s = torch.exp(self.deviation_network.variance * 10.0).clip(1e-6, 1e6)
+        return RenderOutput(rgb=comp["rgb"], depth=res["depth"], weights=comp["weights"], s_val=(1.0 / inv_s).expand(n, 128),
+                            inside_sphere=inside, relax_inside_sphere=inside, analytic_normals=grad.reshape(n, 128, 3),
+                            normalized_analytic_normals=n_hat.reshape(n, 128, 3),
+                            visibilities=res["visibilities"] if self.has_shadow_hint else None,
+                            specular_cue=res["cue"] if self.has_specular_hint else None)
+
     def _hint_grad_inputs(self, o, d, depth, res, shadow_grad: bool, specular_grad: bool):
         """What render_core needs to differentiate the hints (renderer.shadow_hint_gradient / specular_hint_gradient,
         models/neus_hint_model.py:379, :589): the graph-less hit point and, for the visibility, the shadow ray's sections."""
@@ -367,7 +475,8 @@ class NeuSHintRenderer(nn.Module):
                     roughness=[float(r) for r in self.config.renderer.specular_roughness])
 
     # ---------------------------------------------------------------------------------------------
-    def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None, want_shadow=False):
+    def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None, want_shadow=False,
+                      extra_net=None):
         """One nrh_render_forward_train call over the whole batch: the no-grad stages (samplers, hit point, shadow march,
         cue) plus the training evaluation of the SDF network at the section mid-points, whose outputs and saved arrays
         feed the backward sweeps directly (no second evaluation)."""
@@ -377,7 +486,7 @@ class NeuSHintRenderer(nn.Module):
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels,
-                            shadow_clip=self._shadow_clip, samples=self._samples)
+                            shadow_clip=self._shadow_clip, samples=self._samples, **(extra_net or {}))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
@@ -411,7 +520,7 @@ class NeuSHintRenderer(nn.Module):
         return float(torch.exp(v * 10.0).clip(1e-6, 1e6).item())
 
     def _render_chunks(self, o, d, pl, near, far, bg, cos_anneal, t_rand_p, t_rand_s, zero_hints, want_samples: bool,
-                       want_maps: bool, want_mid: bool, use_dyn: bool = False, want_ray_cue: bool = False):
+                       want_maps: bool, want_mid: bool, use_dyn: bool = False, want_ray_cue: bool = False, extra_net=None):
         """Enqueue nrh_render_forward per chunk of rays; returns a dict of freshly allocated output tensors.
         want_samples: materialise the per-sample RenderOutput fields; want_maps: the per-pixel normal maps of the
         evaluation loop; want_mid: section mid-points / lengths (for the autograd training path); want_ray_cue: the
@@ -427,7 +536,7 @@ class NeuSHintRenderer(nn.Module):
             pk = dict(pk, inv_s=self._host_inv_s(pk, device))
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
                             wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color,
-                            shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip, samples=self._samples)
+                            shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip, samples=self._samples, **(extra_net or {}))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))
@@ -474,6 +583,16 @@ class NeuSHintRenderer(nn.Module):
         o, d, pl = ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions
         if not o.is_cuda:
             raise RuntimeError("NeuSHintRenderer (MI355X) runs on the GPU only")
+        if self.has_outside_nerf:
+            # with a background network the per-pixel products are reduced from the full output (the composite happens on the host
+            # side of this branch, outside.py); same keys as below
+            out = self(ray_bundle, is_training=False, background_rgb=background_rgb)
+            w = (out.weights[:, :N_SAMPLES_TOTAL] * out.inside_sphere)[..., None]
+            res = dict(rgb=out.rgb, depth=out.depth, visibilities=out.visibilities if out.visibilities is not None else torch.zeros_like(out.depth),
+                       normal_map=(out.analytic_normals * w).sum(1), normalized_normal_map=(out.normalized_analytic_normals * w).sum(1))
+            if specular_cue and out.specular_cue is not None:
+                res["cue_ray"] = out.specular_cue[:, 0, :]
+            return res
         f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
         bg = f32(background_rgb.to(o.device)).reshape(-1) if background_rgb is not None else None
         with torch.cuda.device(o.device):

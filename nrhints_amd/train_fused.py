@@ -33,6 +33,8 @@ def supported(renderer, ray_bundle) -> Optional[str]:
     rc = renderer.config.renderer
     if (rc.shadow_hint_gradient and renderer.has_shadow_hint) or (rc.specular_hint_gradient and renderer.has_specular_hint):
         return "hint gradients (differentiated by the autograd path)"
+    if getattr(renderer, "has_outside_nerf", False):
+        return "outside-NeRF background"
     if getattr(renderer, "_samples", 128) != 128:
         return "n_importance_samples = 0 (64 samples per ray)"
     if getattr(renderer, "_shadow_clip", -1) > 0:

@@ -779,3 +779,65 @@ def test_no_importance_samples_plumbing_variant(scene_states, prec):
         bound, scale = grad_bound(g[k], want64, factor=4.0, floor=5e-3)
         err = float(np.abs(named[name].grad.detach().cpu().numpy().astype(np.float64) - want64).max())
         assert err <= bound, (name, err, bound, scale)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_outside_nerf_background(scene_states, prec):
+    """renderer.use_outside_nerf (models/neus_hint_model.py:434-473, :516-519, :630-633, :677-724) against the reference's recorded
+    run: evaluation (rgb, depth, the 160 weights per ray - 128 blended + 32 beyond the sphere -, visibility; the per-pixel products
+    path) and one training step (loss; gradients of the renderer AND of the background network, float64 reference, bounds from its
+    float32 run).  NeuS side in the HIP kernels with the alpha blend inside the alpha stage, the NeRF MLP as library GEMMs."""
+    from nrhints_amd.training import train_loss_dict
+    g = load_npz("outside_b.npz")
+    cfg = na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True))
+    state = {k: T(np.asarray(v)) for k, v in scene_states["b"].items()}
+    state.update({"outside_nerf." + k[5:]: T(v) for k, v in g.items() if k.startswith("nerf.")})
+    bg = torch.ones(1, 3).cuda()
+
+    def build(train=False):
+        m = na.NeuSHintRenderer(cfg, precision=prec)
+        m.load_state_dict(state)
+        m = m.cuda()
+        return m if train else m.eval()
+
+    model = build()
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    with torch.no_grad():
+        out = model(rb, background_rgb=bg)
+        prod = model.render_products(rb, bg)
+    assert out.weights.shape == (64, 160) and out.inside_sphere.shape == (64, 128)
+    np.testing.assert_allclose(out.rgb.cpu().numpy(), g["eval.rgb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(prod["rgb"].cpu().numpy(), g["eval.rgb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out.depth.cpu().numpy(), g["eval.depth"], rtol=0, atol=3e-4)
+    dw = np.abs(out.weights.cpu().numpy() - g["eval.weights"])
+    assert dw.mean() < 3e-5 and dw.max() < 5e-3, (dw.mean(), dw.max())
+    assert float(out.weights[:, 128:].sum(-1).mean()) > 0.05                   # the background is visible on these rays
+    np.testing.assert_allclose(out.visibilities.cpu().numpy(), g["eval.visibilities"], rtol=0, atol=3e-3)
+    assert np.array_equal(out.inside_sphere.cpu().numpy(), g["eval.inside_sphere"])
+    # chunked == unchunked
+    model.max_outside_rays = 24
+    with torch.no_grad():
+        out2 = model(rb, background_rgb=bg)
+    assert float((out2.rgb - out.rgb).abs().max()) < 2e-6 and out2.weights.shape == (64, 160)
+    # one training step
+    model = build(train=True)
+    tb = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    o = model(tb, is_training=True, background_rgb=bg, global_step=int(g["t.global_step"]), _t_rand_primary=cu(g["t.t_rand_primary"]),
+              _t_rand_shadow=cu(g["t.t_rand_shadow"]), _t_rand_outside=cu(g["t.t_rand_outside"]))
+    np.testing.assert_allclose(o.rgb.detach().cpu().numpy(), g["t.rgb"], rtol=0, atol=1e-4)
+    dwt = np.abs(o.weights.detach().cpu().numpy() - g["t.weights"])
+    assert dwt.mean() < 3e-5 and dwt.max() < 5e-3
+    ld = train_loss_dict(o, cu(g["t.rgb_gt"]), 0.1)
+    np.testing.assert_allclose(float(ld["loss"]), float(g["t.loss"]), rtol=2e-4)
+    ld["loss"].backward()
+    named = dict(model.named_parameters())
+    keys = [k for k in g if k.startswith("t.grad.") and ".rays." not in k]
+    assert len(keys) == 14 and sum("outside_nerf" in k for k in keys) == 7
+    for k in keys:
+        name = k[len("t.grad."):]
+        want64 = g[k.replace("t.grad.", "t.grad64.")]
+        bound, scale = grad_bound(g[k], want64, factor=4.0, floor=5e-3)
+        got = named[name].grad.detach().cpu().numpy().astype(np.float64)
+        err = float(np.abs(got - want64).max())
+        assert err <= bound, (name, err, bound, scale)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
