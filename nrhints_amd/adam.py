@@ -14,7 +14,7 @@ gradients do move every step (the autograd path allocates them) they are copied 
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional
+from typing import List
 
 import torch
 

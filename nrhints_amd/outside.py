@@ -10,7 +10,6 @@ tail composite and the colour blend (elementwise work on [N,160] arrays).
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, Tuple
 
 import torch
