@@ -25,6 +25,9 @@ LU = "nrh32::LO_UNSCALE"
 MFMA = "v_mfma_f32_32x32x16_f16"
 
 
+TRANS_COST = float(os.environ.get("NRH32_TRANS_COST", "1"))
+
+
 class Op:
     """One epilogue micro-operation: C++ statement(s), the values it defines (pinned at slot end) and its inputs."""
 
@@ -145,7 +148,7 @@ def epi_feat(c, hp, cp, store="W32_FSTORE"):
     return ops
 
 
-def schedule(ops, nslots, per_slot):
+def schedule(ops, nslots, per_slot, trans_cost=1.0):
     """Greedy list schedule: an op may run in slot k if everything it uses was defined in a slot < k (or outside).
     Returns (slots, tail): ops per slot, and what did not fit."""
     defined_in = {}
@@ -159,10 +162,11 @@ def schedule(ops, nslots, per_slot):
         rest = []
         for o in todo:
             ready = all((u not in defined_in) or (defined_in[u].slot is not None and defined_in[u].slot < k) for u in o.uses)
-            if ready and budget >= o.cost:
+            cost = trans_cost if o.kind == "trans" else o.cost     # (experiment knob NRH32_TRANS_COST: a transcendental holds the
+            if ready and budget >= cost:                            # VALU issue port longer than a plain op)
                 o.slot = k
                 slots[k].append(o)
-                budget -= o.cost
+                budget -= cost
             else:
                 rest.append(o)
         todo = rest
@@ -393,10 +397,10 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
                 budget = lambda k: (budget0(k) if k < 41 else 0)
             if HEAD_SLOTS and not small:
                 b1 = budget
-                slots, tail = schedule(epi, HEAD_SLOTS + nslots, lambda k: HEAD_OPS if k < HEAD_SLOTS else b1(k - HEAD_SLOTS))
+                slots, tail = schedule(epi, HEAD_SLOTS + nslots, lambda k: HEAD_OPS if k < HEAD_SLOTS else b1(k - HEAD_SLOTS), TRANS_COST)
                 head, slots = slots[:HEAD_SLOTS], slots[HEAD_SLOTS:]
             else:
-                slots, tail = schedule(epi, nslots, budget)
+                slots, tail = schedule(epi, nslots, budget, TRANS_COST)
             assert not (c == 0 and not small and tail), "pending epilogue does not fit ahead of K step 14"
         else:
             slots, tail = None, []
