@@ -246,9 +246,15 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
                          "frac": round(value * FLOP_PER_RAY_STEP / 1e12 / world / peak, 4)}}
 
 
+# test-only: NRH_BENCH_SHARE_GPU=1 runs the N ranks of --gpus N on ONE GPU with gloo collectives, so that the self-spawn, the
+# barriers, the strong-scaling render and the gradient exchange of the training leg execute with N > 1 on a one-GPU box
+# (tests/test_gpu_fullsize.py); the line it prints carries "rehearsal": true
+SHARE_GPU = os.environ.get("NRH_BENCH_SHARE_GPU") == "1"
+
+
 def respawn(args):
     """--gpus N without a launcher: start N ranks ourselves (one process per GPU) and relay their output."""
-    if torch.cuda.device_count() < args.gpus:
+    if torch.cuda.device_count() < args.gpus and not SHARE_GPU:
         raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -281,12 +287,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    if SHARE_GPU:
+        local_rank = 0          # rehearsal of the N-rank code paths on a box with ONE GPU: every rank on cuda:0, collectives over gloo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm: barrier, max-over-ranks, pixel all-gather, gradient all-reduce
+        # RCCL on ROCm ("nccl"): barrier, max-over-ranks, pixel all-gather, gradient all-reduce.  RCCL refuses two ranks on one device,
+        # hence gloo (which stages device tensors through the host) for the one-GPU rehearsal - its numbers are not a benchmark
+        dist.init_process_group(backend="gloo" if SHARE_GPU else "nccl")
 
     model, state = build_scene(args.precision)
     peak = PEAK_TFLOPS[args.precision]
@@ -359,6 +369,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(state, rays_np, args.cpu_rays, rgb)
         else:
             line["cpu_baseline"] = None
+        if SHARE_GPU:
+            line["rehearsal"] = True
         line["secondary"] = secondary
         line["train"] = train if world == 1 or args.no_train else "second JSON line on stderr (multi-rank run)"
         print(json.dumps(line), flush=True)

@@ -1,5 +1,6 @@
 """Worker of tests/test_gpu_fullsize.py::test_two_rank_training_step: run under torch.distributed.run with 2 ranks, one GPU each
-(backend nccl = RCCL).  Not collected by pytest (no test_ prefix)."""
+(backend nccl = RCCL) - or, with NRH_WORKER_SHARE_GPU=1, both ranks on cuda:0 with gloo collectives (RCCL refuses two ranks on one
+device): the rehearsal of the same code on a one-GPU box.  Not collected by pytest (no test_ prefix)."""
 import os
 import sys
 
@@ -17,9 +18,11 @@ from nrhints_amd.training import FlatGradAllReduce, GraphedTrainStep, train_loss
 def main():
     rank, local, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
     assert world == 2
+    share = os.environ.get("NRH_WORKER_SHARE_GPU") == "1"
+    local = 0 if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group(backend="nccl")
+    dist.init_process_group(backend="gloo" if share else "nccl")
     a = dict(np.load(os.path.join(ROOT, "tests", "golden", "scene_a_state.npz")))
     model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision="f16x3")
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in perturb_state(a).items()})

@@ -159,3 +159,42 @@ def test_two_rank_training_step():
               "--master-port", "29517", os.path.join("tests", "multi_gpu_worker.py")])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "MULTI_GPU_WORKER_OK rank 0" in r.stdout and "MULTI_GPU_WORKER_OK rank 1" in r.stdout
+
+
+# ---- the same N-rank code paths on ONE GPU: both ranks on cuda:0, collectives over gloo (RCCL refuses two ranks on one device) ----
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_rehearsal_on_one_gpu(scaling):
+    """bench.py --gpus 2 with NRH_BENCH_SHARE_GPU=1: the self-spawn through torch.distributed.run, the barriers and the
+    max-over-ranks time, the row-sharded strong-scaling render with its all-gather, and (weak) the training leg's eager fused steps
+    around the flat gradient all-reduce - executed with two ranks.  Timing is meaningless here (one GPU, host-staged collectives);
+    the line's structure and the rays accounted for are checked."""
+    env_extra = {"NRH_BENCH_SHARE_GPU": "1"}
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-rays", "0", "--no-secondary", "--scaling", scaling]
+    if scaling == "strong":
+        cmd.append("--no-train")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1", **env_extra)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0 and line.get("rehearsal") is True
+    rays = 640000 * (2 if scaling == "weak" else 1)
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - rays) < 1e-3 * rays
+    if scaling == "weak":
+        train = [json.loads(l) for l in r.stderr.splitlines() if l.startswith('{"train"')]
+        assert len(train) == 1 and "error" not in train[0]["train"], train
+        t = train[0]["train"]
+        assert t["value"] > 0 and t["batch_rays_per_gpu"] == 1024 and t["loss_last"] < t["loss_first"]
+
+
+def test_two_rank_training_step_rehearsal_on_one_gpu():
+    """tests/multi_gpu_worker.py with two ranks on one GPU (gloo): the flat all-reduce against the mean of the two ranks' local
+    gradients, and the two-graph GraphedTrainStep (graph | eager all-reduce | graph) keeping both ranks' parameters identical."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1",
+               NRH_WORKER_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", os.path.join("tests", "multi_gpu_worker.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "MULTI_GPU_WORKER_OK rank 0" in r.stdout and "MULTI_GPU_WORKER_OK rank 1" in r.stdout
