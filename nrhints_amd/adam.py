@@ -35,6 +35,29 @@ class HipAdam(torch.optim.Adam):
         self._rebuilt_last = False
         self._stage = None           # gradients that move every step (autograd allocates them): staged through fixed buffers
 
+    def load_state_dict(self, state_dict):
+        """``torch.optim.Adam.load_state_dict`` + the state layout this class steps on.  A checkpoint written by the reference's
+        (non-capturable) Adam stores ``step`` as a CPU tensor and ``capturable: False`` in its groups (trainer/trainer.py:155,222);
+        torch leaves both as they are, and the kernel would then read a HOST pointer.  After loading, every ``step`` is a float32
+        0-dim tensor on its parameter's device and every group is capturable again; the descriptor table is rebuilt at the next
+        step."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            group["capturable"], group["foreach"], group["fused"] = True, False, None
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                step = st.get("step", 0.0)
+                step = step.detach().to(device=p.device, dtype=torch.float32).reshape(()) if torch.is_tensor(step) \
+                    else torch.tensor(float(step), dtype=torch.float32, device=p.device)
+                st["step"] = step.clone()
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st:
+                        st[k] = st[k].detach().to(device=p.device, dtype=p.dtype).contiguous()
+        self._key = None
+        self._rebuilt_last = False
+
     def _entries(self):
         ents, grads = [], []
         for gi, group in enumerate(self.param_groups):
@@ -53,6 +76,9 @@ class HipAdam(torch.optim.Adam):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not (torch.is_tensor(st["step"]) and st["step"].is_cuda and st["step"].dtype == torch.float32):
+                    raise ValueError("HipAdam: optimizer state 'step' must be a float32 CUDA scalar (load the state through "
+                                     "HipAdam.load_state_dict, which converts a default-Adam checkpoint)")
                 ents.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
                              p.numel(), gi))
                 grads.append(g)

@@ -60,7 +60,35 @@ def _rows(t: torch.Tensor):
     return t.data_ptr(), int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
 
 
+# Split-K workspace, one per device.  A captured training step (training.GraphedTrainStep) bakes its ADDRESS into the hipGraph,
+# and the size a call needs depends on its job table (768 slabs for the fused table at 256 CUs, 769 for the autograd SDF table,
+# far fewer for a small batch), so the buffer is sized ONCE per device to an upper bound that no job table of `run` can exceed -
+# (items + MAX_JOBS) slots: every job's share is rounded, at most one extra slab each - and is never replaced afterwards.  Should
+# a caller ask for more items than the default, a larger buffer is allocated and the old one stays referenced (a live graph may
+# still write to it).
+MAX_JOBS = 24                     # csrc/nrh_dw.hip
+SLOT_FLOATS = 256 * 256 + 512     # one item's partial product + its column sums
 _WS: Dict[str, torch.Tensor] = {}
+_WS_RETIRED: List[torch.Tensor] = []
+
+
+def _default_items(dev) -> int:
+    # three work items per CU: the jobs' per-step costs are only modelled roughly and short items level the tail, while
+    # every item costs 256 KiB of partial sums to write and reduce (measured on the 1024-ray job table: 1.70 / 2.05 / 1.56 /
+    # 1.58 ms with 1 / 2 / 3 / 4 items per CU; profiles/r03/dw_bench_items.log)
+    return 3 * max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
+
+
+def workspace(dev, need_floats: int = 0) -> torch.Tensor:
+    """The device's split-K workspace (see above): at least the fixed bound, grown (never freed) only for oversize requests."""
+    key = str(dev)
+    bound = max(int(need_floats), (_default_items(dev) + MAX_JOBS) * SLOT_FLOATS)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < bound:
+        if ws is not None:
+            _WS_RETIRED.append(ws)
+        _WS[key] = ws = torch.empty(bound, dtype=torch.float32, device=dev)
+    return ws
 
 
 def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
@@ -70,10 +98,7 @@ def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
     dev = jobs[0].a[0].device
     with torch.cuda.device(dev):
         if total_items is None:
-            # three work items per CU: the jobs' per-step costs are only modelled roughly and short items level the tail, while
-            # every item costs 256 KiB of partial sums to write and reduce (measured on the 1024-ray job table: 1.70 / 2.05 / 1.56 /
-            # 1.58 ms with 1 / 2 / 3 / 4 items per CU; profiles/r03/dw_bench_items.log)
-            total_items = 3 * max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
+            total_items = _default_items(dev)
         nsteps = npts // 32
         costs = [j.cost() for j in jobs]
         tot = sum(costs)
@@ -104,10 +129,7 @@ def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
         need = int(lib.nrh_dw_workspace_floats(arr, len(jobs)))
         if need < 0:
             raise ValueError("nrh_dw_workspace_floats: bad job table")
-        key = str(dev)
-        ws = _WS.get(key)
-        if ws is None or ws.numel() < need:
-            _WS[key] = ws = torch.empty(need, dtype=torch.float32, device=dev)
+        ws = workspace(dev, need)
         rc = lib.nrh_dw_gemm(arr, len(jobs), npts, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_handle())
         _lib.check(rc, "nrh_dw_gemm")
 

@@ -171,13 +171,39 @@ class RayGenerator(nn.Module):
             pl_delta = self.pl_adjustment if pl_delta is None else pl_delta + self.pl_adjustment
         return delta, pl_delta
 
+    def num_views(self) -> int:
+        """rows of the per-view delta tables (0: the generator refines nothing)"""
+        for name in ("cam_pose_adjustment", "pl_adjustment", "cam_pose_noise", "pl_noise"):
+            if hasattr(self, name):
+                return int(getattr(self, name).shape[0])
+        return 0
+
+    def validate_view_indices(self, img_indices: torch.Tensor) -> None:
+        """Raise ``IndexError`` - as the reference's table lookup does - if a view index lies outside the delta tables.  One host
+        sync: call it once per dataset (e.g. on the data loader's index tensor), not per batch."""
+        nv = self.num_views()
+        if nv == 0 or img_indices is None or img_indices.numel() == 0:
+            return
+        lo, hi = (int(v) for v in torch.stack([img_indices.min(), img_indices.max()]).tolist())
+        if lo < -nv or hi >= nv:
+            raise IndexError(f"view index out of range: the ray generator holds {nv} views, the bundle has indices in [{lo}, {hi}]")
+        if lo < 0:
+            raise IndexError(f"negative view index {lo}: the HIP ray generator takes indices in [0, {nv})")
+
     def _forward_hip(self, pb: RawPixelBundle) -> RayBundle:
         cam, cfg = self.camera, self.config
         f32 = lambda t: t.detach().contiguous().float()
         idx = None if pb.img_indices is None else pb.img_indices.detach().reshape(-1).contiguous().long()
         delta, pl_delta = self.view_deltas() if idx is not None else (None, None)
-        # (no host-side range check of idx: the kernels treat a view index outside [0, ncam) as "no refinement" and scatter
-        # nothing for it in the adjoint, so a bad index cannot read or write out of range - and a training batch costs no host sync)
+        # No per-batch host-side range check of idx (a training batch costs no host sync): the kernels treat a view index outside
+        # [0, ncam) as "no refinement" and scatter nothing for it in the adjoint, so a bad index cannot read or write out of range.
+        # The reference raises IndexError when it indexes the delta tables with such an index (camera/ray_generator.py:108-121) - a
+        # dataset / checkpoint view-count mismatch must not train silently with unrefined poses - so the FIRST bundle of every
+        # generator is validated (one sync, outside a graph capture), and validate_view_indices() is there for the data loader.
+        if idx is not None and (delta is not None or pl_delta is not None) and not self.__dict__.get("_idx_validated", False) \
+                and not torch.cuda.is_current_stream_capturing():
+            self.validate_view_indices(idx)
+            self.__dict__["_idx_validated"] = True
         cc = lambda t: None if t is None else t.contiguous().float()
         poses = f32(pb.poses)
         o, d, p, near, far = _RaysIndexedHip.apply(cc(delta), cc(pl_delta), idx, f32(pb.h_indices).reshape(-1),

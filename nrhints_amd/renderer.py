@@ -217,21 +217,69 @@ class NeuSHintRenderer(nn.Module):
                 if self.dyn_scalars is not None:      # no host sync: the kernels read inv_s from the device
                     self.dyn_scalars[0:1].copy_(torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(1))
                     inv_s = float("nan")
+                    # ... so the f16x3 range check of the branch below cannot raise here.  It still runs, without a sync: every
+                    # `range_check_every`-th pack enqueues the same test and copies its verdict to pinned memory; a later pack
+                    # (or check_weight_range(), _host_inv_s) reads it once its event has passed and raises THEN (a
+                    # diverging run in this mode must not render / train on inf weights silently)
+                    if prec == 1:
+                        self._range_guard_async(bufs, d, device)
                 else:
                     # one host read: 1/s, and for f16x3 whether every packed weight survived the fp16 split (|w| times the
                     # kernels' input scaling must stay below 65504 - true for any trained NeuS net by orders of magnitude; a
                     # checkpoint outside that range is refused instead of rendered wrong)
-                    ok = torch.ones((), device=device)
-                    if prec == 1:
-                        halves = [v for v in bufs.values() if torch.is_tensor(v) and v.dtype == torch.float16]
-                        ok = torch.stack([torch.isfinite(v).all() for v in halves] + [packing32.tables_in_f16_range(d)]).all().to(torch.float32)
+                    ok = self._range_ok(bufs, d) if prec == 1 else torch.ones((), device=device)
                     inv_s, ok = torch.stack([torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(()), ok.reshape(())]).tolist()
                     if not ok:
-                        raise ValueError("precision 'f16x3': a network weight is outside the fp16 range of the 3-term split "
-                                         "(|w| * 144.3 >= 65504); use precision='f32' for this checkpoint")
+                        raise ValueError(self._RANGE_MSG)
             self._packed = dict(bufs, inv_s=inv_s, precision=prec, hints=hints)
             self._packed_key = key
         return self._packed
+
+    range_check_every = 256    # dyn-scalar mode (sync-free training): packs between two asynchronous f16x3 weight-range checks
+
+    _RANGE_MSG = ("precision 'f16x3': a network weight is outside the fp16 range of the 3-term split "
+                  "(|w| * 144.3 >= 65504); use precision='f32' for this checkpoint")
+
+    @staticmethod
+    def _range_ok(bufs, d) -> torch.Tensor:
+        """0-dim float32 device tensor, 1 if every packed fp16 half is finite and every packed bias fits fp16"""
+        halves = [v for v in bufs.values() if torch.is_tensor(v) and v.dtype == torch.float16]
+        return torch.stack([torch.isfinite(v).all() for v in halves] + [packing32.tables_in_f16_range(d)]).all().to(torch.float32)
+
+    def _range_guard_poll(self, wait: bool = False) -> None:
+        g = self.__dict__.get("_range_guard")
+        if not g or g["pending"] is None:
+            return
+        host, ev = g["pending"]
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            g["pending"] = None
+            if float(host) == 0.0:
+                raise ValueError(self._RANGE_MSG)
+
+    def _range_guard_async(self, bufs, d, device) -> None:
+        g = self.__dict__.setdefault("_range_guard", {"n": 0, "pending": None})
+        self._range_guard_poll()
+        g["n"] += 1
+        if g["pending"] is not None or (g["n"] - 1) % max(1, int(self.range_check_every)) != 0 or torch.cuda.is_current_stream_capturing():
+            return      # (inside a capture nothing may be read back: GraphedTrainStep calls check_weight_range() between replays)
+        host = torch.ones((), dtype=torch.float32).pin_memory()
+        host.copy_(self._range_ok(bufs, d), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        g["pending"] = (host, ev)
+
+    def check_weight_range(self) -> None:
+        """Synchronous form of the f16x3 weight-range guard for the modes that keep 1/s on the device (``train_step(sync=False)``,
+        ``GraphedTrainStep``): raises the documented ``ValueError`` if the CURRENT packed weights left the fp16 range of the split."""
+        self._range_guard_poll(wait=True)
+        pk = self._packed
+        if pk is None or pk.get("precision") != 1:
+            return
+        halves = [v for v in pk.values() if torch.is_tensor(v) and v.dtype == torch.float16]
+        if halves and not bool(torch.stack([torch.isfinite(v).all() for v in halves]).all().item()):
+            raise ValueError(self._RANGE_MSG)
 
     def _const(self, device):
         k = str(device)
@@ -516,6 +564,7 @@ class NeuSHintRenderer(nn.Module):
         """1/s as a host float also while a captured training graph keeps it on the device (one sync; evaluation only)."""
         if pk["inv_s"] == pk["inv_s"]:      # not NaN
             return pk["inv_s"]
+        self._range_guard_poll()            # (this call synchronises anyway: surface a pending range verdict here)
         v = self.deviation_network.variance.detach().to(device=device, dtype=torch.float32)
         return float(torch.exp(v * 10.0).clip(1e-6, 1e6).item())
 

@@ -122,6 +122,12 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         cache = renderer.__dict__.setdefault("_fused_buffers", {})     # per renderer: .grad aliases these arrays
         B = cache.get(key)
         if B is None:
+            # one buffer set is ~1.3 GB per 1 024 rays: a loop with varying batch sizes (a last partial batch, a curriculum) must not
+            # accumulate one set per distinct n.  Only the most recent set stays, plus whatever a live captured step
+            # pinned (GraphedTrainStep bakes the addresses into its hipGraph; it unpins in release()).
+            pinned = renderer.__dict__.setdefault("_fused_pinned", set())
+            for k in [k for k in cache if k not in pinned]:
+                del cache[k]
             shapes = {k: tuple(v.shape) for k, v in dense.items()}
             shapes.update({"v:" + k: tuple(v.shape) for k, v in zip(packing._FOLD_LAYERS, vs)})
             shapes.update({"g:" + k: tuple(x.shape) for k, x in zip(packing._FOLD_LAYERS, gs)})

@@ -165,7 +165,9 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
 
 
 def release_device_scalars(renderer) -> None:
-    """Undo what ``train_step(..., sync=False)`` switched on: 1/s and the cos-anneal ratio back on the host."""
+    """Undo what ``train_step(..., sync=False)`` switched on: 1/s and the cos-anneal ratio back on the host.  Raises the f16x3
+    weight-range ``ValueError`` here if the sync-free steps drove a weight out of range (the guard is asynchronous in that mode)."""
+    renderer.check_weight_range()
     renderer.dyn_scalars = None
     renderer._packed_key = None
     renderer._generation = getattr(renderer, "_generation", 0) + 1
@@ -282,6 +284,10 @@ class GraphedTrainStep:
         if optimizer_state is not None:                 # resume: moments and step counts of a checkpointed Adam
             self.load_optimizer_state(optimizer_state)
         renderer._generation = getattr(renderer, "_generation", 0) + 1
+        # the fused step's buffer set of this batch size is part of the graph from here on: keep train_fused from evicting it
+        self._pin_key = (str(dev), n, bool(getattr(renderer, "_hints", False)))
+        if self._use_fused:
+            renderer.__dict__.setdefault("_fused_pinned", set()).add(self._pin_key)
         self.graph, self.graph_tail = torch.cuda.CUDAGraph(), None
         self.optimizer.zero_grad(set_to_none=True)
         # With a process group alive its watchdog thread polls events while we capture: legal only in thread-local capture mode
@@ -400,7 +406,14 @@ class GraphedTrainStep:
         # the replay updated the parameters in place without touching their version counters: tell the renderer, so that
         # an evaluation render between replays re-packs instead of reusing a stale pack
         self.renderer._generation = getattr(self.renderer, "_generation", 0) + 1
-        return dict(zip(self._keys, self._loss_vec.tolist()))
+        out = dict(zip(self._keys, self._loss_vec.tolist()))
+        # the re-pack runs inside the graph, where nothing can raise: the f16x3 weight-range guard of the eager pack
+        # (renderer.packed_params) is applied to the replayed pack every `range_check_every` steps (the read-back above already
+        # synchronised, so this costs one small reduction + copy)
+        self._replays = getattr(self, "_replays", 0) + 1
+        if self._replays % max(1, int(self.renderer.range_check_every)) == 0:
+            self.renderer.check_weight_range()
+        return out
 
     def load_optimizer_state(self, state: Dict) -> None:
         """Copy the per-parameter Adam state of ``state`` (an ``optimizer.state_dict()`` of the same parameter order) into
@@ -415,6 +428,7 @@ class GraphedTrainStep:
     def release(self) -> None:
         """Back to eager operation (drops the graph and the device-side scalars)."""
         self.graph = self.graph_tail = None
+        self.renderer.__dict__.setdefault("_fused_pinned", set()).discard(getattr(self, "_pin_key", None))
         self.renderer.dyn_scalars = None
         # the cached pack was made while 1/s lived on the device (its host copy is NaN): packs of the eager mode must not
         # reuse it - a render after release() would otherwise run with inv_s = NaN and no device scalars

@@ -29,6 +29,36 @@ def test_loss_matches_reference_record():
     np.testing.assert_allclose(d["eikonal_loss"].item(), g["eikonal_loss"], rtol=1e-6)
 
 
+def test_hip_adam_loads_a_default_adam_checkpoint_layout():
+    """a reference checkpoint holds the state of torch's DEFAULT Adam - ``step`` a CPU tensor, groups with
+    ``capturable: False`` (trainer/trainer.py:155, 222).  HipAdam.load_state_dict must turn that into the layout its kernel
+    reads (float32 0-dim ``step`` on the parameter's device, capturable groups) - checked here on CPU tensors (no step)."""
+    from nrhints_amd.adam import HipAdam
+    torch.manual_seed(0)
+    pa = [nn.Parameter(torch.randn(4, 3)), nn.Parameter(torch.randn(7))]
+    ref = torch.optim.Adam([{"params": pa[:1], "lr": 5e-4}, {"params": pa[1:], "lr": 1e-4}])
+    for _ in range(3):
+        for p in pa:
+            p.grad = torch.randn_like(p)
+        ref.step()
+    sd = ref.state_dict()
+    assert sd["param_groups"][0]["capturable"] is False
+    pb = [nn.Parameter(p.detach().clone()) for p in pa]
+    hip = HipAdam([{"params": pb[:1], "lr": 5e-4}, {"params": pb[1:], "lr": 1e-4}])
+    hip.load_state_dict(sd)
+    for g in hip.param_groups:
+        assert g["capturable"] is True and not g["foreach"]
+    for p, q in zip(pb, pa):
+        st = hip.state[p]
+        assert st["step"].dtype == torch.float32 and st["step"].dim() == 0 and st["step"].device == p.device
+        assert float(st["step"]) == 3.0
+        np.testing.assert_array_equal(st["exp_avg"].numpy(), ref.state[q]["exp_avg"].numpy())
+        np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), ref.state[q]["exp_avg_sq"].numpy())
+    # and the round trip back into torch's Adam (resume in the other direction)
+    back = torch.optim.Adam([{"params": pa[:1], "lr": 5e-4}, {"params": pa[1:], "lr": 1e-4}])
+    back.load_state_dict(hip.state_dict())
+
+
 def test_lr_schedule():
     assert lr_factor(0) == 0.0 and abs(lr_factor(2500) - 0.5) < 1e-12 and abs(lr_factor(5000) - 1.0) < 1e-12
     assert abs(lr_factor(1_000_000) - 0.05) < 1e-12
