@@ -233,6 +233,12 @@ typedef struct NrhNet {
   float* tail_t;            /* out [nrays]: transmittance behind sample 127 (the 32 samples beyond the sphere start from it) */
   float* sampled_color;     /* out [nrays,128,3]: the reflectance net's colour per sample (the caller blends and composites; the
                                call's own `rgb` is then NOT the final colour) */
+  /* the renderer's two free scalars (models/neus_hint_model.py:161, :163) - kernel constants, not compiled shapes.  custom_consts
+     0: the reference's defaults (roughness 0.02, 0.05, 0.13, 0.34; offset 1e-2); 1: the values below.  Doubles, because the
+     reference forms k = (rho + 1)^2 / 8, rho^2 and 1 - offset as Python scalars before they meet a float32 tensor (:387, :600-611) */
+  int custom_consts;
+  double specular_roughness[4];
+  double shadow_ray_offset;
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

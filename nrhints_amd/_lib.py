@@ -36,7 +36,8 @@ class NrhNet(Structure):
                 ("normal_type", c_int), ("depth_type", c_int), ("dyn_scalars", c_void_p),
                 ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
                 ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int), ("shadow_clip", c_int),
-                ("samples", c_int), ("bg_alpha", c_void_p), ("tail_t", c_void_p), ("sampled_color", c_void_p)]
+                ("samples", c_int), ("bg_alpha", c_void_p), ("tail_t", c_void_p), ("sampled_color", c_void_p),
+                ("custom_consts", c_int), ("specular_roughness", ctypes.c_double * 4), ("shadow_ray_offset", ctypes.c_double)]
 
 
 class NrhAdamTensor(Structure):
@@ -194,7 +195,7 @@ def stream_handle(device=None):
 
 
 def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False,
-             shadow_clip=-1, samples=128, bg_alpha=None, tail_t=None, sampled_color=None):
+             shadow_clip=-1, samples=128, bg_alpha=None, tail_t=None, sampled_color=None, consts=None):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
     ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""
@@ -202,9 +203,13 @@ def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fu
     w32 = (pk.get("sdf_w32f") if fused else pk.get("sdf_w32")) if wide else None
     tab = pk.get("sdf_tab32f") if fused else pk.get("sdf_tab32")
     c32 = pk.get("col_w32") if (fused and wide_color) else None
+    # ``consts``: (specular_roughness [4], shadow_ray_offset) when they differ from the reference's defaults
+    rough, offs = ((ctypes.c_double * 4)(*[float(x) for x in consts[0]]), float(consts[1])) if consts is not None \
+        else ((ctypes.c_double * 4)(), 0.0)
     return NrhNet(ptr(pk["sdf_w"], pk["sdf_w"].dtype), ptr(pk["sdf_b"]), ptr(pk["sdf_head"]),
                   ptr(pk["col_w"], pk["col_w"].dtype), ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
                   hints, normal_type, depth_type, ptr(dyn_scalars),
                   ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
                   ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None,
-                  int(bool(shadow_jvp and w32 is not None)), int(shadow_clip), int(samples), ptr(bg_alpha), ptr(tail_t), ptr(sampled_color))
+                  int(bool(shadow_jvp and w32 is not None)), int(shadow_clip), int(samples), ptr(bg_alpha), ptr(tail_t), ptr(sampled_color),
+                  int(consts is not None), rough, offs)

@@ -139,8 +139,11 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
          "that ReflectanceNetwork.forward never appends); enable shadow_hint"),
         (not (r.force_specular_cue and not r.specular_hint),
          "force_specular_cue without specular_hint fails in the reference itself (same lin0 shape mismatch); enable specular_hint"),
-        (list(r.specular_roughness) == [0.02, 0.05, 0.13, 0.34], "specular_roughness must be the default 4 values"),
-        (abs(r.shadow_ray_offset - 1e-2) < 1e-12, "shadow_ray_offset must be 1e-2"),
+        # the VALUES of these two are kernel constants (NrhNet.specular_roughness / shadow_ray_offset); only the NUMBER of roughness
+        # values is a shape: it sizes the reflectance net's first layer (models/neus_hint_model.py:246-250)
+        (len(list(r.specular_roughness)) == 4 or not r.specular_hint, "specular_roughness must hold 4 values (the cue input is 4 x 9 wide)"),
+        (all(float(x) > 0.0 for x in r.specular_roughness), "specular_roughness values must be positive"),
+        (0.0 <= float(r.shadow_ray_offset) < 1.0, "shadow_ray_offset must lie in [0, 1)"),
     ]
     for ok, why in checks:
         if not ok:

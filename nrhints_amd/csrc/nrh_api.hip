@@ -261,9 +261,15 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
 
 // core_alpha_kernel with the renderer's constants (shadow_ray_offset 1e-2, the four specular roughness values of
 // models/neus_hint_model.py:161 evaluated in double like Python's scalars)
-int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
-  c.shadow_offset = 1e-2f;
-  const double rough[4] = {0.02, 0.05, 0.13, 0.34};
+// 1 - shadow_ray_offset as the reference forms it: a Python double, rounded to float32 when it meets the tensor (:387)
+float shadow_one_minus_offset(const NrhNet* net) {
+  return (float)(1.0 - ((net && net->custom_consts) ? net->shadow_ray_offset : 1e-2));
+}
+
+int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
+  c.shadow_om = shadow_one_minus_offset(net);
+  const double def[4] = {0.02, 0.05, 0.13, 0.34};
+  const double* rough = (net && net->custom_consts) ? net->specular_roughness : def;
   for (int i = 0; i < 4; ++i) {
     const double k = (rough[i] + 1.0) * (rough[i] + 1.0) / 8.0, a2 = rough[i] * rough[i];
     c.kk[i] = (float)k; c.omk[i] = (float)(1.0 - k); c.a2[i] = (float)a2; c.a2m1[i] = (float)(a2 - 1.0);
@@ -276,7 +282,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st) {
 
 extern "C" {
 
-int nrh_version(void) { return 134; }
+int nrh_version(void) { return 135; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -1082,7 +1088,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     c.nreal = net->samples == 64 ? 64 : 0;
     c.depth_max_weight = net->depth_type == 1;
     c.nrays = (int)n;
-    rc = launch_core_alpha(c, st);
+    rc = launch_core_alpha(c, st, net);
     if (rc) return rc;
   }
   // ---- shadow rays light -> hit point ----
@@ -1116,7 +1122,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     for (int g = 0; g < clip; ++g) {
       nrh::PartialSetupArgs ps;
       ps.ro = origins; ps.rd = directions; ps.pl = pl_positions; ps.z = ws_cue_b /* the kept z_vals */; ps.lin64 = lin64;
-      ps.t_rand_shadow = t_rand_shadow; ps.srd = ws_srd; ps.slast = ws_slast; ps.zs = ws_zbuf; ps.shadow_offset = 1e-2f;
+      ps.t_rand_shadow = t_rand_shadow; ps.srd = ws_srd; ps.slast = ws_slast; ps.zs = ws_zbuf; ps.shadow_om = shadow_one_minus_offset(net);
       ps.z_index = g * ratio; ps.clip = clip; ps.group = g; ps.nrays = (int)n;
       hipLaunchKernelGGL(nrh::partial_shadow_setup_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ps);
       rc = check_launch("partial_shadow_setup_kernel");
@@ -1244,7 +1250,7 @@ int nrh_alpha_composite(const float* origins, const float* directions, const flo
   c.depth = depth; c.wsum = weight_sum; c.cue = specular_cue; c.cue_b = nullptr; c.hit = hit_points; c.hit_n = hit_normals;
   c.srd = shadow_dirs; c.slast = shadow_last_dist; c.zs = shadow_z; c.inv_s = inv_s; c.cos_anneal = cos_anneal; c.dyn = nullptr;
   c.zero_hints = zero_hints ? 1 : 0; c.depth_max_weight = depth_type; c.nrays = (int)nrays;
-  return launch_core_alpha(c, (hipStream_t)stream);
+  return launch_core_alpha(c, (hipStream_t)stream, nullptr);   // (unit entry: the reference's default constants)
 }
 
 int nrh_visibility(const float* directions, const float* pl_positions, const float* shadow_dirs, const float* sdf, const float* grad,

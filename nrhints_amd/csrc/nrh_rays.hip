@@ -276,7 +276,7 @@ struct CoreArgs {
   float* srd;           // [N,3] shadow ray direction
   float* slast;         // [N] light distance / 64
   float* zs;            // [N,128] coarse shadow z (first 64)
-  float inv_s, cos_anneal, shadow_offset;
+  float inv_s, cos_anneal, shadow_om;   // shadow_om = 1 - renderer.shadow_ray_offset (host double -> float)
   const float* dyn;     // optional device [inv_s, cos_anneal] overriding the two values above (hipGraph-captured training steps)
   // per-roughness constants evaluated in double on the host, as Python does for the reference's scalars
   // (models/neus_hint_model.py:604, 609): k, 1 - k, a^2, a^2 - 1
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
       reinterpret_cast<f32x4*>(a.cue_b)[ray * 128 + lane + 64] = cv;
     }
     // coarse shadow samples z_j = lin[j] * L * (1 - offset)  (+ stratified jitter in training, :388-395)
-    const float om = 1.0f - a.shadow_offset;
+    const float om = a.shadow_om;
     float zj = a.lin64[lane] * L * om;
     if (a.t_rand_shadow) {
       const float zp = (lane > 0) ? a.lin64[lane - 1] * L * om : zj;
@@ -505,7 +505,7 @@ struct PartialSetupArgs {
   float* srd;                  // [N,3]
   float* slast;                // [N]
   float* zs;                   // [N,128] (first 64: coarse shadow samples)
-  float shadow_offset;
+  float shadow_om;             // 1 - renderer.shadow_ray_offset
   int z_index;                 // g * ratio
   int clip, group;
   int nrays;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void partial_shadow_setup_kernel(const Partial
               hz = a.ro[ray * 3 + 2] + a.rd[ray * 3 + 2] * zt;
   const float svx = hx - a.pl[ray * 3 + 0], svy = hy - a.pl[ray * 3 + 1], svz = hz - a.pl[ray * 3 + 2];
   const float L = sqrtf(svx * svx + svy * svy + svz * svz);
-  const float om = 1.0f - a.shadow_offset;
+  const float om = a.shadow_om;
   float zj = a.lin64[lane] * L * om;
   if (a.t_rand_shadow) {
     const float zp = (lane > 0) ? a.lin64[lane - 1] * L * om : zj;

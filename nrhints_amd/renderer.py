@@ -141,6 +141,9 @@ class NeuSHintRenderer(nn.Module):
         self._normal_type = 1 if config.renderer.normal_type == NormalComputationType.Analytic else 0
         self._depth_type = {DepthComputationType.AlphaBlend: 0, DepthComputationType.MaximalWeightPoint: 1,
                             DepthComputationType.SphereTracing: 2}[config.renderer.depth_type]
+        # the two free scalars of the renderer config (:161, :163) travel to the kernels through NrhNet when they are not the defaults
+        rough, offs = [float(x) for x in config.renderer.specular_roughness], float(config.renderer.shadow_ray_offset)
+        self._net_consts = None if (rough == [0.02, 0.05, 0.13, 0.34] and offs == 1e-2) else (rough, offs)
         self.sdf_network = SDFNetwork(config.sdf_network)
         self.deviation_network = SingleVarianceNetwork(config.deviation_network.init_val)
         n_cue = len(config.renderer.specular_roughness) if self.has_specular_hint else 0
@@ -464,7 +467,7 @@ class NeuSHintRenderer(nn.Module):
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         z, mid0, dists0 = new(n, 128), new(n, 128), new(n, 128)
         lin64, lin16 = self._const(device)
-        net0 = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, None, wide=self.wide_kernels)
+        net0 = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, None, wide=self.wide_kernels, consts=self._net_consts)
         ws = self._workspace(device, n)
         P = _lib.ptr
         _lib.check(lib.nrh_sample_primary(net0, P(o), P(d), P(near), P(far), n, P(t_rand_p), P(lin64), P(lin16), P(z), P(mid0), P(dists0),
@@ -534,7 +537,7 @@ class NeuSHintRenderer(nn.Module):
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels,
-                            shadow_clip=self._shadow_clip, samples=self._samples, **(extra_net or {}))
+                            shadow_clip=self._shadow_clip, samples=self._samples, consts=self._net_consts, **(extra_net or {}))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
@@ -585,7 +588,8 @@ class NeuSHintRenderer(nn.Module):
             pk = dict(pk, inv_s=self._host_inv_s(pk, device))
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
                             wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color,
-                            shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip, samples=self._samples, **(extra_net or {}))
+                            shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip, samples=self._samples, consts=self._net_consts,
+                            **(extra_net or {}))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(rgb=new(n, 3), depth=new(n, 1), visibilities=new(n, 1))
@@ -664,7 +668,7 @@ class NeuSHintRenderer(nn.Module):
         pk = self.packed_params(dev)
         if self.dyn_scalars is not None:
             pk = dict(pk, inv_s=self._host_inv_s(pk, dev))
-        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, None, wide=self.wide_kernels)
+        net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, None, wide=self.wide_kernels, consts=self._net_consts)
         pts, depth = torch.empty(n, 3, dtype=torch.float32, device=dev), torch.empty(n, 1, dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.nrh_sphere_trace_workspace_floats(n)), dtype=torch.float32, device=dev)
         P = _lib.ptr

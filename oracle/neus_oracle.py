@@ -293,7 +293,7 @@ def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=No
     return excl_cumprod_one_minus(alpha)[:, -1:]
 
 
-def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
+def specular_cue(hit_normal, pls, hit, d, roughness=SPEC_ROUGHNESS) -> torch.Tensor:
     """Cook-Torrance cue for the 4 roughness values (models/neus_hint_model.py:590-615)."""
     l = F.normalize(pls - hit, dim=-1)
     v = F.normalize(-d, dim=-1)
@@ -304,7 +304,7 @@ def specular_cue(hit_normal, pls, hit, d) -> torch.Tensor:
     hdv = (h * v).sum(-1).clip(0.0, 1.0)
     ndh2 = torch.pow(ndh, 2)
     out = []
-    for rough in SPEC_ROUGHNESS:
+    for rough in roughness:       # config.renderer.specular_roughness (models/neus_hint_model.py:161, :600)
         k = (rough + 1.0) * (rough + 1.0) / 8.0
         g = ndv / (ndv * (1.0 - k) + k) * (ndl / (ndl * (1.0 - k) + k))
         a2 = rough * rough
@@ -380,7 +380,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0,
                    depth_sphere_tracing=False, shadow_hint=None, specular_hint=None, shadow_hint_gradient=False,
                    specular_hint_gradient=False, n_shadow_importance_clip=-1, n_importance_samples=64, outside_nerf=None,
-                   t_rand_outside=None) -> Dict[str, torch.Tensor]:
+                   t_rand_outside=None, specular_roughness=SPEC_ROUGHNESS, shadow_ray_offset=1e-2) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
@@ -444,14 +444,14 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
             zt = z[:, torch.arange(0, T, ratio)]
             tgt = (o[:, None, :] + d[:, None, :] * zt[..., None]).reshape(-1, 3)
             pls_g = pl[:, None, :].repeat(1, clip, 1).reshape(-1, 3)
-            vg = visibility(p, pls_g, tgt, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode).reshape(n, clip, 1)
+            vg = visibility(p, pls_g, tgt, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode).reshape(n, clip, 1)
             vis_samples = vg.repeat_interleave(ratio, dim=1)                               # [n,128,1]
             vis = torch.gather(vis_samples[..., 0], 1, torch.argmax(weights, dim=1, keepdim=True))   # shadow_map (:573-574)
         elif not (shadow_hint and shadow_hint_gradient and differentiable):
-            vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode) \
+            vis = visibility(p, pl, hit, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode) \
                 if shadow_hint else None                       # :546-551, :379
     if shadow_hint and not warmup and shadow_hint_gradient and differentiable:
-        vis = visibility(p, pl, hit, cos_anneal, 1e-2, t_rand_shadow if is_training else None, mode, differentiable=True)
+        vis = visibility(p, pl, hit, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode, differentiable=True)
     n_hat = F.normalize(grad, dim=-1)                          # :584
     hit_n = F.normalize((n_hat.reshape(n, T, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
     vis_s = cue_s = None
@@ -459,7 +459,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
         vis_s = vis[:, None, :].expand(n, T, 1).reshape(-1, 1) if vis_samples is None else vis_samples.reshape(-1, 1)
     if specular_hint:
         with torch.enable_grad() if (specular_hint_gradient and differentiable) else torch.no_grad():   # :589
-            cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d)   # :590-615, :617-619
+            cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d, specular_roughness)   # :590-615, :617-619
         cue_s = cue[:, None, :].expand(n, T, 4).reshape(-1, 4)
     col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, T, 3)  # :621-626
     if bg_col is not None:                                     # :630-633

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 134
+    assert lib.nrh_version() == 135
     lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
     from nrhints_amd import packing32 as pk32
     assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
@@ -298,14 +298,14 @@ def test_integration_md_matches_the_binding():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "INTEGRATION.md")).read()
     block = re.search(r"class NrhNet\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n", text, re.S).group(1)
-    fields = re.findall(r'\("(\w+)", ctypes\.(\w+)\)', block)
+    fields = [(n, t if not k else f"{t}_Array_{k}") for n, t, k in re.findall(r'\("(\w+)", ctypes\.(\w+)(?: \* (\d+))?\)', block)]
     want = [(n, t.__name__) for n, t in _lib.NrhNet._fields_]
     assert fields == want, (fields, want)
     # the header declares the struct with the same members in the same order
     hdr = open(os.path.join(root, "include", "nrhints_hip.h")).read()
     body = re.search(r"typedef struct NrhNet \{(.*?)\} NrhNet;", hdr, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    members = re.findall(r"(\w+)\s*;", body)
+    members = re.findall(r"(\w+)\s*(?:\[\d+\])?\s*;", body)
     assert members == [n for n, _ in want], members
     lib = _lib.load()
     assert int(re.search(r"lib\.nrh_version\(\) == (\d+)", text).group(1)) == lib.nrh_version()
