@@ -372,6 +372,28 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
   return check_launch("sdf_kernel<3>");
 }
 
+// The training forward on the wide one-wave-per-SIMD machinery (csrc/nrh_sdf32.hip MODE 4, precision f16x3): same outputs and
+// saved arrays as nrh_sdf_train_forward, evaluated by the mode-2 stream of packing32.pack_sdf32 (plain feature head).
+int nrh_sdf_train_forward_wide(const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
+                               int t_stride, int n_per_ray, long long nrays, float* sdf, float* grad, float* feat_rows, float* save_h,
+                               float* save_s1, float* save_t, float* save_ge, float* scratch, void* stream) {
+  if (!sdf_w32 || !sdf_tab32 || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_s1 || !save_t || !save_ge || !scratch)
+    return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: null pointer%s", "");
+  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: bad n_per_ray/stride%s", "");
+  if ((nrays * n_per_ray) % 32 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: the number of points must be a multiple of 32%s", "");
+  if (nrays * n_per_ray > (1LL << 22)) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: at most 4 194 304 points per call%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh32::WideSdfCall c;
+  c.mode = 4; c.streams = sdf_w32; c.tables = sdf_tab32; c.ro = ro; c.rd = rd; c.t = t; c.sdf = sdf; c.grad = grad; c.feat = feat_rows;
+  c.scratch = scratch; c.npts = nrays * n_per_ray; c.n_per_ray = n_per_ray; c.t_stride = t_stride; c.sdf_stride = n_per_ray;
+  c.max_grid = device_cus();
+  c.save_h = save_h; c.save_s1 = save_s1; c.save_t = save_t; c.save_ge = save_ge;
+  const int wrc = nrh32::wide_sdf_launch(c, (hipStream_t)stream);
+  if (wrc == -1) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: too many points%s", "");
+  if (wrc) return fail(NRH_E_LAUNCH, "wide sdf kernel: no HIP device / attribute error%s", "");
+  return check_launch("sdf32_kernel<4>");
+}
+
 int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
                            const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
                            const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
@@ -1058,8 +1080,13 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   float* sdf_c = train ? train->sdf : ws_sdf_c;
   if (train) {
     // training: the same evaluation with the feature row-major and the arrays the backward sweeps need
-    rc = nrh_sdf_train_forward(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
-                               sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, stream);
+    // (precision f16x3 with the wide streams at hand: the wide kernel, csrc/nrh_sdf32.hip MODE 4; n * 128 is a multiple of 32)
+    if (net->precision == 1 && net->sdf_w32 && net->sdf_tab32 && !net->feat_fused && n * 128 <= (1LL << 22))
+      rc = nrh_sdf_train_forward_wide(net->sdf_w32, net->sdf_tab32, origins, directions, o_tmid, 128, 128, n, sdf_c, o_grad,
+                                      train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, scratch, stream);
+    else
+      rc = nrh_sdf_train_forward(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
+                                 sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, stream);
   } else {
     rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n, sdf_c, 128,
                        o_grad, ws_feat, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
