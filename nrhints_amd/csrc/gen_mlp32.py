@@ -374,6 +374,12 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
     out = []
     out.append(f"// generated by gen_mlp32.py: stage kind={kind} pend={pend_kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv} in=a{in_base} out=a{out_base}")
     out.append("{")
+    # VMEM stores of the previous window's epilogue (training kinds, or NRH32_SYNCK=1 for every kind): vmcnt counts them like the
+    # LDS-DMA pieces, so the window's opening wait keeps that many more operations in flight - `s_waitcnt vmcnt(8)` would drain
+    # every row store of the previous window (HBM write latency exposed once per window: measured 1.62 ms against 1.27 ms for
+    # the 16-point training forward, profiles/r04/train_ab1.log).  Window 0 keeps 8: what ran before it is another stage.
+    sync_k = kind.endswith("_t") or bool(os.environ.get("NRH32_SYNCK"))
+    prev_stores = 0
     for c in range(7):
         out.append(f"  nrh32::f32x16 hh{c}, cc{c};")
     for c in range(7):
@@ -388,7 +394,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         has_epi = (c > 0 or pend_in) and not os.environ.get("NRH32_NOEPI")
         ekind = kind if c > 0 else pend_kind
         if not small or c % 4 == 0:
-            out.append("    W32_SYNC();")
+            out.append(f"    W32_SYNC_K({8 + prev_stores});" if (sync_k and not small and c > 0 and prev_stores) else "    W32_SYNC();")
             out.append("    W32_FETCH_SETUP();")
         pnames = []
         if c == 0 and has_epi:
@@ -445,6 +451,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             assert not (c == 0 and not small and tail), "pending epilogue does not fit ahead of K step 14"
         else:
             slots, tail = None, []
+        prev_stores = sum(1 for o in (epi or []) if o.kind == "vmem")
         win.emit(out, slots, "    ", dma=dma, head=head)
         if tail:
             out.append("    // epilogue work that did not fit the MFMA shadows")

@@ -18,6 +18,10 @@
 #include "../../include/nrhints_hip.h"
 #include "nrh_wide.h"
 
+#ifndef NRH_TRAIN_FWD_WIDE
+#define NRH_TRAIN_FWD_WIDE 1   // A/B knob (make variant DEFS=-DNRH_TRAIN_FWD_WIDE=0): nrh_render_forward_train keeps the 16-point training forward
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -1081,7 +1085,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   if (train) {
     // training: the same evaluation with the feature row-major and the arrays the backward sweeps need
     // (precision f16x3 with the wide streams at hand: the wide kernel, csrc/nrh_sdf32.hip MODE 4; n * 128 is a multiple of 32)
-    if (net->precision == 1 && net->sdf_w32 && net->sdf_tab32 && !net->feat_fused && n * 128 <= (1LL << 22))
+    if (NRH_TRAIN_FWD_WIDE && net->precision == 1 && net->sdf_w32 && net->sdf_tab32 && !net->feat_fused && n * 128 <= (1LL << 22))
       rc = nrh_sdf_train_forward_wide(net->sdf_w32, net->sdf_tab32, origins, directions, o_tmid, 128, 128, n, sdf_c, o_grad,
                                       train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, scratch, stream);
     else

@@ -94,10 +94,17 @@ __device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
-// stream-once global traffic (sigma' scratch, feature tiles)
+// stream-once global traffic (sigma' scratch, feature tiles, the training sweeps' saved arrays); loads and stores can be switched
+// separately for A/B runs (make variant DEFS=-DNRH_NT_LOAD=0)
+#ifndef NRH_NT_LOAD
+#define NRH_NT_LOAD NRH_NT_SCRATCH
+#endif
+#ifndef NRH_NT_STORE
+#define NRH_NT_STORE NRH_NT_SCRATCH
+#endif
 template <typename V>
 __device__ __forceinline__ void st_stream(V* p, V v) {
-#if NRH_NT_SCRATCH
+#if NRH_NT_STORE
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;
@@ -105,7 +112,7 @@ __device__ __forceinline__ void st_stream(V* p, V v) {
 }
 template <typename V>
 __device__ __forceinline__ V ld_stream(const V* p) {
-#if NRH_NT_SCRATCH
+#if NRH_NT_LOAD
   return __builtin_nontemporal_load(p);
 #else
   return *p;

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
 #define W32_SYNC() chunk_sync<8>()
 #endif
+#define W32_SYNC_K(k) chunk_sync<(k)>()      // windows whose predecessor issued k - 8 row stores behind its DMA pieces (gen_mlp32.py)
 #define W32_FETCH_SETUP() fetch_setup()
 #define W32_WADDR() (wlane + cur_off)
 #define W32_NEXT() (cur_off = (cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES)

@@ -242,7 +242,11 @@ def test_fused_step_equals_autograd_path(scene_states):
         np.testing.assert_allclose(lb[k], float(la[k]), rtol=5e-6, err_msg=k)
     for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         scale = float(pa.grad.abs().max()) + 1e-30
-        assert float((pa.grad - pb.grad).abs().max()) / scale < 1e-4, (name, float((pa.grad - pb.grad).abs().max()) / scale)
+        # 1e-4 of the tensor's scale, plus 1e-6 absolute: the bias gradients of the last reflectance layers are sums over 32 768
+        # samples that cancel to ~1e-3, so the fp32 round-off of the summands (5e-7 absolute between the two paths) is not small
+        # against the RESULT although it is against every term
+        err = float((pa.grad - pb.grad).abs().max())
+        assert err < 1e-4 * scale + 1e-6, (name, err, scale)
 
 
 def test_fused_training_descends_and_graph_replays(scene_states):

@@ -305,7 +305,7 @@ def test_wide_training_forward_vs_16pt_and_oracle(wscene, npts):
     np.testing.assert_allclose(grad.cpu().numpy(), o_grad.numpy(), rtol=0, atol=1e-4 if tag == "a" else 5e-4)
     c = lambda t: t.cpu().numpy()
     # activations O(0.01..1): fp32 round-off class
-    np.testing.assert_allclose(c(sv["h"]), c(sv_r["h"]), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(c(sv["h"]), c(sv_r["h"]), rtol=0, atol=4e-6)
     np.testing.assert_array_equal(c(sv["h"])[3][:, 217:] != 0, c(sv_r["h"])[3][:, 217:] != 0)          # the embedding sits there
     np.testing.assert_allclose(c(sv["s1"]), c(sv_r["s1"]), rtol=0, atol=3e-5)     # sigma' = sigmoid(100 z): 100 x the error of z
     assert float(sv["s1"][3][:, 217:].abs().max()) == 0.0
@@ -317,3 +317,7 @@ def test_wide_training_forward_vs_16pt_and_oracle(wscene, npts):
     # mean errors, which a misplaced row / column would blow up while a tolerance on the maximum might not
     assert float((sv["t"] - sv_r["t"]).abs().mean()) < 2e-6 * scale_t
     assert float((sv["h"] - sv_r["h"]).abs().mean()) < 2e-7
+    # determinism (row stores, the skip fix-up and the sigma' scratch all leave in a fixed order): a second run is bit-identical
+    sdf2, feat2, grad2, sv2 = ops.sdf_train_forward_wide(packed["sdf_w32"], packed["sdf_tab32"], pts)
+    for x, y in ((sdf, sdf2), (feat, feat2), (grad, grad2), (sv["h"], sv2["h"]), (sv["s1"], sv2["s1"]), (sv["t"], sv2["t"]), (sv["ge"], sv2["ge"])):
+        assert torch.equal(x, y)
