@@ -112,6 +112,25 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            void* stream);
 
+/* ---- the outside-NeRF background network (renderer.use_outside_nerf) -----------------------------------------------------
+ * fields/nerf_density_field.py:30-89 as called from models/neus_hint_model.py:434-473: per point of the inverted-sphere
+ * parameterisation pts4 = (p / |p|, 1 / |p|) [npts,4] with the ray's view direction and light position (views, pls [nrays,3];
+ * point P belongs to ray P / pts_per_ray):  density [npts] (alpha_linear, before the softplus) and rgb [npts,3] (rgb_linear,
+ * before the sigmoid).  on_w / on_b / on_wt: nrhints_amd.outside.pack_outside (sizes: nrh_outside_sizes -> packed floats,
+ * bias floats, transposed packed floats, row widths 96 / 64 of the two encodings; f16x3: the same numbers of fp16 pairs).
+ * Training: with the five save_* arrays (all or none; npts % 16 == 0) the forward also writes the operands of the weight
+ * gradients row-major - save_x [npts][96] enc10(pts4), save_v [npts][64] enc4(cat[view, light]), save_h [8][npts][256] (ReLU
+ * outputs), save_f [npts][256] (feature_linear), save_hv [npts][128] - and nrh_outside_backward turns the adjoints of the two
+ * outputs into zbar [8][npts][256], fbar [npts][256], zvbar [npts][128] (operands of nrh_dw_gemm jobs) and the adjoints of the
+ * two encodings xbar [npts][96], vbar [npts][64] (for the ray gradients; the caller applies the encodings' derivative). */
+int nrh_outside_sizes(int* out5);
+int nrh_outside_forward(int precision, const float* on_w, const float* on_b, const float* pts4, const float* views, const float* pls,
+                        int pts_per_ray, long long npts, float* density, float* rgb, float* save_x, float* save_v, float* save_h,
+                        float* save_f, float* save_hv, void* stream);
+int nrh_outside_backward(int precision, const float* on_wt, const float* alpha_w, const float* density_bar, const float* rgb_bar,
+                         const float* save_h, const float* save_hv, long long npts, float* zbar, float* fbar, float* zvbar, float* xbar,
+                         float* vbar, void* stream);
+
 /* ---- weight-norm fold ---------------------------------------------------------------------------------------
  * W = v * g / ||v||_row for up to 16 linears in one launch (old-style nn.utils.weight_norm, dim = 0:
  * fields/sdf_field.py:81-82, fields/reflectance_network.py:61-62) and its adjoint in one launch.  rows / cols and the

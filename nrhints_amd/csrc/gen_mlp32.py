@@ -26,6 +26,8 @@ MFMA = "v_mfma_f32_32x32x16_f16"
 
 
 TRANS_COST = float(os.environ.get("NRH32_TRANS_COST", "1"))
+ROW_STORE_MACROS = ("W32_HSAVE", "W32_SSAVE", "W32_TSAVE", "W32_FSAVE")
+ROW_STORE_FROM = int(os.environ.get("NRH32_ROW_STORE_FROM", "-1"))    # first MFMA slot that may carry a row store (-1: anywhere)
 
 
 class Op:
@@ -185,9 +187,12 @@ def epi_feat(c, hp, cp, store="W32_FSTORE", train=False):
     return ops
 
 
-def schedule(ops, nslots, per_slot, trans_cost=1.0):
+def schedule(ops, nslots, per_slot, trans_cost=1.0, vmem_from=None):
     """Greedy list schedule: an op may run in slot k if everything it uses was defined in a slot < k (or outside).
-    Returns (slots, tail): ops per slot, and what did not fit."""
+    Returns (slots, tail): ops per slot, and what did not fit.
+    vmem_from: row stores (kind "vmem" whose code starts with one of the W32_?SAVE macros) only from that slot on and at most one
+    per slot - the training forward writes 10 KiB per wave and window, which HBM drains in about a window: issued as one burst
+    right after the window's opening they fill the CU's memory queue and the in-order wave stalls behind them."""
     defined_in = {}
     for o in ops:
         for d in o.defs:
@@ -197,9 +202,15 @@ def schedule(ops, nslots, per_slot, trans_cost=1.0):
     for k in range(nslots):
         budget = per_slot(k) if callable(per_slot) else per_slot
         rest = []
+        row_stores = 0
         for o in todo:
             ready = all((u not in defined_in) or (defined_in[u].slot is not None and defined_in[u].slot < k) for u in o.uses)
             cost = trans_cost if o.kind == "trans" else o.cost     # (experiment knob NRH32_TRANS_COST: a transcendental holds the
+            if vmem_from is not None and o.kind == "vmem" and o.code.startswith(ROW_STORE_MACROS):
+                if k < vmem_from or row_stores >= 1:
+                    rest.append(o)
+                    continue
+                row_stores += 1
             if ready and budget >= cost:                            # VALU issue port longer than a plain op)
                 o.slot = k
                 slots[k].append(o)
@@ -394,7 +405,15 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         has_epi = (c > 0 or pend_in) and not os.environ.get("NRH32_NOEPI")
         ekind = kind if c > 0 else pend_kind
         if not small or c % 4 == 0:
-            out.append(f"    W32_SYNC_K({8 + prev_stores});" if (sync_k and not small and c > 0 and prev_stores) else "    W32_SYNC();")
+            if sync_k and not small and c > 0 and prev_stores:
+                out.append(f"    W32_SYNC_K({8 + prev_stores});")
+            elif sync_k and not small and c == 0 and pend_in:
+                # what ran before this window is another stage's last window: the kernel knows whether it was a stage of the same
+                # kind (then its stores count like ours: 8 + own_stores) or something else (then 8)
+                own = sum(1 for o in stage_epilogue(pend_kind, 0, "hp", "cp", want_d, out_base, "W32_QSTORE") if o.kind == "vmem")
+                out.append(f"    W32_SYNC_FIRST({8 + own});" if own else "    W32_SYNC();")
+            else:
+                out.append("    W32_SYNC();")
             out.append("    W32_FETCH_SETUP();")
         pnames = []
         if c == 0 and has_epi:
@@ -447,7 +466,10 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
                 slots, tail = schedule(epi, HEAD_SLOTS + nslots, lambda k: HEAD_OPS if k < HEAD_SLOTS else b1(k - HEAD_SLOTS), TRANS_COST)
                 head, slots = slots[:HEAD_SLOTS], slots[HEAD_SLOTS:]
             else:
-                slots, tail = schedule(epi, nslots, budget, TRANS_COST)
+                vf = ROW_STORE_FROM if (ROW_STORE_FROM >= 0 and not small) else None
+                if vf is not None and c == 0:
+                    vf = min(vf, 28)          # window 0: everything sits ahead of slot 41
+                slots, tail = schedule(epi, nslots, budget, TRANS_COST, vmem_from=vf)
             assert not (c == 0 and not small and tail), "pending epilogue does not fit ahead of K step 14"
         else:
             slots, tail = None, []
@@ -468,7 +490,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         # anything may touch their registers (hipcc shuffles loop-carried registers at the loop edges - measured: 1-3 % of
         # the tiles got stale words without this).  They are older than window 7's eight LDS-DMA pieces.
         regs = ", ".join(f'"+v"({nm})' for nm in ln(7, loads))
-        out.append(f'  asm volatile("s_waitcnt vmcnt(8)" : {regs});')
+        out.append(f'  asm volatile("s_waitcnt vmcnt({8 + (prev_stores if sync_k else 0)})" : {regs});')
     out.append("}")
     return "\n".join(out) + "\n"
 

@@ -3,6 +3,7 @@
 #include "nrh_sdf.hip"
 #include "nrh_sdf_train.hip"
 #include "nrh_color.hip"
+#include "nrh_outside.hip"
 #include "nrh_rays.hip"
 #include "nrh_rays_train.hip"
 #include "nrh_fold.hip"
@@ -19,7 +20,11 @@
 #include "nrh_wide.h"
 
 #ifndef NRH_TRAIN_FWD_WIDE
-#define NRH_TRAIN_FWD_WIDE 1   // A/B knob (make variant DEFS=-DNRH_TRAIN_FWD_WIDE=0): nrh_render_forward_train keeps the 16-point training forward
+// 1: nrh_render_forward_train evaluates the SDF network with the wide training forward (nrh_sdf_train_forward_wide) when NrhNet
+// carries the streams.  Off: measured SLOWER than the 16-point kernel (1.53 against 1.33 ms per 131 072 points; its 3.3 GB of row
+// stores run at the HBM write rate but do not overlap with the one wave per SIMD's MFMA stream: 0.89 ms with the stores
+// compiled out, profiles/r04/train_fwd_ab.log).  The entry stays, tested against the 16-point kernel.
+#define NRH_TRAIN_FWD_WIDE 0
 #endif
 
 namespace {
@@ -558,6 +563,82 @@ int nrh_color_train_backward(int precision, int hints, const float* col_wt, cons
   else if (precision == 0) hipLaunchKernelGGL((nrh::color_adjoint_kernel<0, 4>), g, blk, lds, st, a);
   else hipLaunchKernelGGL((nrh::color_adjoint_kernel<1, 4>), g, blk, lds, st, a);
   return check_launch("color_adjoint_kernel");
+}
+
+// ---- the outside-NeRF background network (csrc/nrh_outside.hip) ----
+int nrh_outside_sizes(int* out) {
+  if (!out) return fail(NRH_E_INVALID, "nrh_outside_sizes: null%s", "");
+  out[0] = nrh::ON_PACKED_FLOATS; out[1] = nrh::ON_BIAS_FLOATS; out[2] = nrh::ONT_PACKED_FLOATS; out[3] = nrh::ON_X; out[4] = nrh::ON_V;
+  return NRH_OK;
+}
+
+static int outside_attrs() {
+  const int dev = current_device();
+  if (dev < 0) return fail(NRH_E_LAUNCH, "no HIP device%s", "");
+  static bool done[MAX_DEVICES] = {};
+  if (done[dev]) return NRH_OK;
+  const void* fns[] = {(const void*)nrh::outside_kernel<0, false>, (const void*)nrh::outside_kernel<0, true>,
+                       (const void*)nrh::outside_kernel<1, false>, (const void*)nrh::outside_kernel<1, true>,
+                       (const void*)nrh::outside_adjoint_kernel<0>, (const void*)nrh::outside_adjoint_kernel<1>};
+  for (const void* f : fns)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES) != hipSuccess)
+      return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed%s", "");
+  done[dev] = true;
+  return NRH_OK;
+}
+
+int nrh_outside_forward(int precision, const float* on_w, const float* on_b, const float* pts4, const float* views, const float* pls,
+                        int pts_per_ray, long long npts, float* density, float* rgb, float* save_x, float* save_v, float* save_h,
+                        float* save_f, float* save_hv, void* stream) {
+  if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_outside_forward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!on_w || !on_b || !pts4 || !views || !pls || !density || !rgb) return fail(NRH_E_INVALID, "nrh_outside_forward: null pointer%s", "");
+  const bool train = save_x || save_v || save_h || save_f || save_hv;
+  if (train && (!save_x || !save_v || !save_h || !save_f || !save_hv))
+    return fail(NRH_E_INVALID, "nrh_outside_forward: the training saves come all or none%s", "");
+  if (pts_per_ray <= 0 || npts < 0 || npts % pts_per_ray != 0) return fail(NRH_E_INVALID, "nrh_outside_forward: npts must be a multiple of pts_per_ray%s", "");
+  if (train && npts % 16 != 0) return fail(NRH_E_INVALID, "nrh_outside_forward: training needs a multiple of 16 points%s", "");
+  if (npts == 0) return NRH_OK;
+  int rc = outside_attrs();
+  if (rc) return rc;
+  nrh::OutsideArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w = on_w; a.b = on_b; a.pts4 = pts4; a.views = views; a.pls = pls; a.density = density; a.rgb = rgb; a.npts = npts;
+  a.pts_per_ray = pts_per_ray; a.save_x = save_x; a.save_v = save_v; a.save_h = save_h; a.save_f = save_f; a.save_hv = save_hv;
+  int grid = 0;
+  rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_outside_forward");
+  if (rc) return rc;
+  const hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid), blk(nrh::MLP_THREADS);
+  const int lds = nrh::MLP_LDS_BYTES;
+  if (precision == 0 && train) hipLaunchKernelGGL((nrh::outside_kernel<0, true>), g, blk, lds, st, a);
+  else if (precision == 0) hipLaunchKernelGGL((nrh::outside_kernel<0, false>), g, blk, lds, st, a);
+  else if (train) hipLaunchKernelGGL((nrh::outside_kernel<1, true>), g, blk, lds, st, a);
+  else hipLaunchKernelGGL((nrh::outside_kernel<1, false>), g, blk, lds, st, a);
+  return check_launch("outside_kernel");
+}
+
+int nrh_outside_backward(int precision, const float* on_wt, const float* alpha_w, const float* density_bar, const float* rgb_bar,
+                         const float* save_h, const float* save_hv, long long npts, float* zbar, float* fbar, float* zvbar, float* xbar,
+                         float* vbar, void* stream) {
+  if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_outside_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!on_wt || !alpha_w || !density_bar || !rgb_bar || !save_h || !save_hv || !zbar || !fbar || !zvbar || !xbar || !vbar)
+    return fail(NRH_E_INVALID, "nrh_outside_backward: null pointer%s", "");
+  if (npts < 0 || npts % 16 != 0) return fail(NRH_E_INVALID, "nrh_outside_backward: the number of points must be a multiple of 16%s", "");
+  if (npts == 0) return NRH_OK;
+  int rc = outside_attrs();
+  if (rc) return rc;
+  nrh::OutsideAdjArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wt = on_wt; a.walpha = alpha_w; a.dbar = density_bar; a.cbar = rgb_bar; a.save_h = save_h; a.save_hv = save_hv; a.zbar = zbar;
+  a.fbar = fbar; a.zvbar = zvbar; a.xbar = xbar; a.vbar = vbar; a.npts = npts;
+  int grid = 0;
+  rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_outside_backward");
+  if (rc) return rc;
+  const hipStream_t st = (hipStream_t)stream;
+  const dim3 g(grid), blk(nrh::MLP_THREADS);
+  if (precision == 0) hipLaunchKernelGGL((nrh::outside_adjoint_kernel<0>), g, blk, nrh::MLP_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((nrh::outside_adjoint_kernel<1>), g, blk, nrh::MLP_LDS_BYTES, st, a);
+  return check_launch("outside_adjoint_kernel");
 }
 
 int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,

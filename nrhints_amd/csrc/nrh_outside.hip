@@ -39,7 +39,7 @@ constexpr int ON_OFF_RGB = ON_OFF_VB + ON_VB_FLOATS;
 constexpr int ON_PACKED_FLOATS = ON_OFF_RGB + ON_RGB_FLOATS;
 // biases: [8][256] pts layers | [256] feature | [16] density (1 used) | [128] views | [16] rgb (3 used)
 constexpr int ON_B_FEAT = 8 * 256, ON_B_ALPHA = ON_B_FEAT + 256, ON_B_VIEWS = ON_B_ALPHA + 16, ON_B_RGB = ON_B_VIEWS + 128;
-constexpr int ON_BIAS_FLOATS = ON_B_RGB + 16;
+constexpr int ON_BIAS_FLOATS = ON_B_RGB + 32;   // (the rgb stage reads both 16-float blocks of its single chunk)
 // transposed stream (adjoint sweep): TRGB | TVA | TVB | THF | T7 | T6 | T5x | T5h | T4 | T3 | T2 | T1 | T0
 constexpr int ONT_RGB_FLOATS = 4 * 2 * 2 * 256;      // 128 x 32 (3 used)
 constexpr int ONT_VA_FLOATS = 8 * 2 * 8 * 256;       // 256 x 128
@@ -121,11 +121,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_kernel(const OutsideAr
         st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
       }
     };
+    // (the bias pointer is made opaque once per tile: the loads are invariant over the persistent tile loop, and hipcc would
+    // otherwise hoist all of them - 9 stages x 16 floats per lane - out of it and spill them)
+    const float* bias = a.b;
+    asm volatile("" : "+s"(bias));
     auto bias_pre = [&](int off) {
       return [&, off](int ch) {
         OnBias p;
-        p.b0 = *reinterpret_cast<const f32x4*>(a.b + off + (2 * ch) * 16 + 4 * q);
-        p.b1 = *reinterpret_cast<const f32x4*>(a.b + off + (2 * ch + 1) * 16 + 4 * q);
+        p.b0 = *reinterpret_cast<const f32x4*>(bias + off + (2 * ch) * 16 + 4 * q);
+        p.b1 = *reinterpret_cast<const f32x4*>(bias + off + (2 * ch + 1) * 16 + 4 * q);
         return p;
       };
     };
@@ -136,28 +140,36 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_kernel(const OutsideAr
     for (int c = 0; c < 4; ++c) x4[c] = a.pts4[Pc * 4 + c];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { v6[c] = a.views[ray * 3 + c]; v6[3 + c] = a.pls[ray * 3 + c]; }
-    Act<PREC, 6> xe;
+    // (the encodings are rebuilt where they are used - layers 0 and 5, the views layer - instead of being kept in registers
+    // across the eight 256 x 256 stages in between: 24 + 16 sines against 40 live registers per lane)
+    auto make_xe = [&](Act<PREC, 6>& xe, bool save) {
+      float xx[4] = {x4[0], x4[1], x4[2], x4[3]};
+      asm volatile("" : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]), "+v"(xx[3]));   // not shared between the two call sites
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float o[8];
+      for (int ch = 0; ch < 3; ++ch) {
+        float o[8];
 #pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) o[r8] = nerf_enc_entry_q<4, 10>(x4, (2 * ch + (r8 >> 2)) * 16 + (r8 & 3), q);
-      xe.set_chunk(ch, o);
-      if constexpr (TRAIN) save_rows(a.save_x, 0, ON_X, ch, f32x4{o[0], o[1], o[2], o[3]}, f32x4{o[4], o[5], o[6], o[7]});
-    }
-    Act<PREC, 4> ve;
+        for (int r8 = 0; r8 < 8; ++r8) o[r8] = nerf_enc_entry_q<4, 10>(xx, (2 * ch + (r8 >> 2)) * 16 + (r8 & 3), q);
+        xe.set_chunk(ch, o);
+        if (TRAIN && save) save_rows(a.save_x, 0, ON_X, ch, f32x4{o[0], o[1], o[2], o[3]}, f32x4{o[4], o[5], o[6], o[7]});
+      }
+    };
+    auto make_ve = [&](Act<PREC, 4>& ve) {
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      float o[8];
+      for (int ch = 0; ch < 2; ++ch) {
+        float o[8];
 #pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) o[r8] = nerf_enc_entry_q<6, 4>(v6, (2 * ch + (r8 >> 2)) * 16 + (r8 & 3), q);
-      ve.set_chunk(ch, o);
-      if constexpr (TRAIN) save_rows(a.save_v, 0, ON_V, ch, f32x4{o[0], o[1], o[2], o[3]}, f32x4{o[4], o[5], o[6], o[7]});
-    }
+        for (int r8 = 0; r8 < 8; ++r8) o[r8] = nerf_enc_entry_q<6, 4>(v6, (2 * ch + (r8 >> 2)) * 16 + (r8 & 3), q);
+        ve.set_chunk(ch, o);
+        if constexpr (TRAIN) save_rows(a.save_v, 0, ON_V, ch, f32x4{o[0], o[1], o[2], o[3]}, f32x4{o[4], o[5], o[6], o[7]});
+      }
+    };
 
     // ---- N0 ----
     Act<PREC, 16> h;
     {
+      Act<PREC, 6> xe;
+      make_xe(xe, true);
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const OnBias& p) {
         const f32x4 h0 = on_relu4(acc0 + p.b0), h1 = on_relu4(acc1 + p.b1);
         h.set_chunk(ch, h0, h1);
@@ -186,6 +198,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_kernel(const OutsideAr
         for (int r = 0; r < 4; ++r) { part[ch * 8 + r] = acc0[r]; part[ch * 8 + 4 + r] = acc1[r]; }
       };
       run_stage<PREC, 16, 8, false>(a.w + ON_OFF_N5A, a.w + ON_OFF_N5B, 12, smem, par, h, nullptr, pre0, epi0, wave, lane);
+      Act<PREC, 6> xe;
+      make_xe(xe, false);
       Act<PREC, 16> ho;
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const OnBias& p) {
         const f32x4 h0 = on_relu4(acc0 + p.b0), h1 = on_relu4(acc1 + p.b1);
@@ -231,6 +245,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_kernel(const OutsideAr
         for (int r = 0; r < 4; ++r) { part[ch * 8 + r] = acc0[r]; part[ch * 8 + 4 + r] = acc1[r]; }
       };
       run_stage<PREC, 16, 4, false>(a.w + ON_OFF_VA, a.w + ON_OFF_VB, 8, smem, par, f, nullptr, pre0, epi0, wave, lane);
+      Act<PREC, 4> ve;
+      make_ve(ve);
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const OnBias& p) {
         const f32x4 h0 = on_relu4(acc0 + p.b0), h1 = on_relu4(acc1 + p.b1);
         hv.set_chunk(ch, h0, h1);
@@ -359,14 +375,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_adjoint_kernel(const O
       run_stage<PREC, 16, 8, false, true>(a.wt + (l == 7 ? ONT_OFF_T7 : ONT_OFF_T6), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
       h = ho;
     }
-    // ---- T5x: the skip's share of xbar (kept in registers until T0);  T5h: zbar_4 ----
-    float xs[24];
+    // ---- T5x: the skip's share of xbar (parked in the xbar rows until T0 adds its own);  T5h: zbar_4 ----
     {
       auto pre = [&](int) { return 0; };
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { xs[ch * 8 + r] = acc0[r]; xs[ch * 8 + 4 + r] = acc1[r]; }
-      };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) { store_rows(a.xbar, 0, ON_X, ch, acc0, acc1); };
       run_stage<PREC, 16, 3, false>(a.wt + ONT_OFF_T5X, a.wt + ONT_OFF_T5H, 32, smem, par, h, nullptr, pre, epi, wave, lane);
     }
     for (int l = 5; l >= 1; --l) {
@@ -389,14 +401,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_adjoint_kernel(const O
     }
     // ---- T0: xbar = W0^T zbar_0 + the skip's share ----
     {
-      auto pre = [&](int) { return 0; };
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, int) {
-        f32x4 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s0[r] = acc0[r] + xs[ch * 8 + r]; s1[r] = acc1[r] + xs[ch * 8 + 4 + r]; }
-        store_rows(a.xbar, 0, ON_X, ch, s0, s1);
+      // (this wave's own stores of T5x, five stages ago: plain loads, same lanes, same addresses)
+      auto pre = [&](int ch) {
+        HPre p;
+        p.h0 = *rows_ptr(a.xbar, 0, ON_X, 2 * ch);
+        p.h1 = *rows_ptr(a.xbar, 0, ON_X, 2 * ch + 1);
+        return p;
       };
-      run_stage<PREC, 16, 3, false>(a.wt + ONT_OFF_T0, a.wt + ONT_OFF_RGB, 4, smem, par, h, nullptr, pre, epi, wave, lane);
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const HPre& p) { store_rows(a.xbar, 0, ON_X, ch, acc0 + p.h0, acc1 + p.h1); };
+      run_stage<PREC, 16, 3, false, true>(a.wt + ONT_OFF_T0, a.wt + ONT_OFF_RGB, 4, smem, par, h, nullptr, pre, epi, wave, lane);
     }
   }
 }

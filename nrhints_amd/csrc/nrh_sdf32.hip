@@ -261,6 +261,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W32_SYNC() chunk_sync<8>()
 #endif
 #define W32_SYNC_K(k) chunk_sync<(k)>()      // windows whose predecessor issued k - 8 row stores behind its DMA pieces (gen_mlp32.py)
+// first window of a stage with row stores: k if the stage before it was of the same kind (same_kind_before), else 8
+#define W32_SYNC_FIRST(k) do { if (same_kind_before) chunk_sync<(k)>(); else chunk_sync<8>(); } while (0)
+#ifndef NRH32_TRAIN_ABL
+#define NRH32_TRAIN_ABL 0      // timing ablations of the training forward (WRONG RESULTS): 1 no row stores, 2 no sigma' rows
+#endif
 #define W32_FETCH_SETUP() fetch_setup()
 #define W32_WADDR() (wlane + cur_off)
 #define W32_NEXT() (cur_off = (cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES)
@@ -308,11 +313,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // pattern, profiles/r04/rowstore.log)
     typedef __attribute__((address_space(1))) f32x4* grow_p;
     const uint32_t rowoff = (uint32_t)Pc * 1024u + (uint32_t)hf * 32u;
-#define W32_ROWST_(base, layer, c, g2, part, val) do { if (valid) *(grow_p)(rows_at((base), (layer)) + rowoff + ((c) * 128 + (g2) * 64 + (part) * 16)) = (val); } while (0)
+#define W32_ROWST_(base, layer, c, g2, part, val) do { if (valid && !(NRH32_TRAIN_ABL & 1)) *(grow_p)(rows_at((base), (layer)) + rowoff + ((c) * 128 + (g2) * 64 + (part) * 16)) = (val); } while (0)
 #define W32_HSAVE(c, g2, part, val) W32_ROWST_(a.save_h, qlayer, c, g2, part, val)
 #define W32_HSAVE_P(c, g2, part, val) W32_ROWST_(a.save_h, qlayer - 1, c, g2, part, val)
+#if NRH32_TRAIN_ABL & 2
+#define W32_SSAVE(c, g2, part, val) do { } while (0)
+#define W32_SSAVE_P(c, g2, part, val) do { } while (0)
+#else
 #define W32_SSAVE(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer, c, g2, part, val)
 #define W32_SSAVE_P(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer - 1, c, g2, part, val)
+#endif
     // ---- L0 ----
     {
       const int qlayer = 0;
@@ -331,6 +341,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     for (int l = 1; l <= 7; l += 2) {
       {
         const int qlayer = l;
+        const bool same_kind_before = l > 1;     // (layer 1 follows L0's short windows)
+        (void)same_kind_before;
         if constexpr (JVP) {
 #include "gen32/fwd_j_p0.inc"
         } else if constexpr (TRAIN) {
@@ -344,6 +356,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       if (l == 7) break;
       {
         const int qlayer = l + 1;
+        const bool same_kind_before = true;
+        (void)same_kind_before;
         if constexpr (JVP) {
 #include "gen32/fwd_j_p1.inc"
         } else if constexpr (TRAIN) {
@@ -552,6 +566,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
         {
           const int l = 7 - 2 * k;
           const char* const qbase = uni(scr + (l - 1) * 16384);
+          const bool same_kind_before = (k == 1 || k == 3);    // R5 after R6, R1 after R2; R7 follows T7, R3 the R4e stage
+          (void)same_kind_before;
           if constexpr (TRAIN) {
 #include "gen32/rev_t_p0.inc"
           } else {
@@ -569,6 +585,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
         } else {
           const int l = 6 - 2 * k;
           const char* const qbase = uni(scr + (l - 1) * 16384);
+          const bool same_kind_before = true;
+          (void)same_kind_before;
           if constexpr (TRAIN) {
 #include "gen32/rev_t_p1.inc"
           } else {

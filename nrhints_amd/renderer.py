@@ -417,7 +417,7 @@ class NeuSHintRenderer(nn.Module):
                             specular_cue=cut(cue) if self.has_specular_hint else None)
 
     # ---------------------------------------------------------------------------------------------
-    max_outside_rays = 8192     # rays per pass of the outside-NeRF branch (its [N,160] network evaluation lives in torch)
+    max_outside_rays = 65536    # rays per pass of the outside-NeRF branch (evaluation; its [N,160] elementwise glue lives in torch)
 
     def _forward_outside(self, ray_bundle, is_training, background_rgb, global_step, t_p, t_s, t_o) -> RenderOutput:
         """``forward`` with the outside-NeRF background (renderer.use_outside_nerf; see outside.py for who computes what)."""
@@ -472,7 +472,8 @@ class NeuSHintRenderer(nn.Module):
         P = _lib.ptr
         _lib.check(lib.nrh_sample_primary(net0, P(o), P(d), P(near), P(far), n, P(t_rand_p), P(lin64), P(lin16), P(z), P(mid0), P(dists0),
                                           P(ws), ws.numel(), _lib.stream_handle()), "nrh_sample_primary")
-        # 2. the background at the merged positions (:715-724): library GEMMs, autograd when training
+        # 2. the background at the merged positions (:715-724): the network is csrc/nrh_outside.hip (outside.OutsideNetHip)
+        self.outside_nerf.precision = self.precision
         with torch.set_grad_enabled(needs_grad):
             far_g = ray_bundle.fars.to(torch.float32).reshape(-1, 1)
             z_out = outside.outside_z(far_g, cfg.renderer.n_samples, f32(t_o) if is_training else None)

@@ -835,11 +835,58 @@ def test_no_importance_samples_plumbing_variant(scene_states, prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_outside_network_kernels_vs_reference_unit(prec):
+    """The background network on its own (csrc/nrh_outside.hip through outside.OutsideNetHip): values against the unit I/O the
+    reference's NeRF module recorded (tests/golden/outside_b.npz: unit.*), and the whole backward - the adjoint sweep, the 13
+    weight-gradient jobs, the chain rule through both encodings - against float64 autograd of the oracle's restatement
+    (oracle.neus_oracle.nerf_forward, itself pinned on the same unit vectors) for all 24 parameter tensors and the three inputs."""
+    from nrhints_amd.outside import OutsideNeRF
+    g = load_npz("outside_b.npz")
+    ref = {k[5:]: T(v) for k, v in g.items() if k.startswith("nerf.")}
+    nerf = OutsideNeRF()
+    nerf.load_state_dict(ref)
+    nerf = nerf.cuda()
+    nerf.precision = prec
+    pts4, views, pls = cu(g["unit.pts4"]), cu(g["unit.views"]), cu(g["unit.pls"])
+    with torch.no_grad():
+        dens, col = nerf(pts4, views, pls)
+    # 10 ReLU layers of K <= 340 in fp32-equivalent arithmetic (the reference's own record is float32)
+    np.testing.assert_allclose(dens.cpu().numpy(), g["unit.density"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(col.cpu().numpy(), g["unit.rgb"], rtol=0, atol=1e-5)
+    # backward: 32 rays x 5 points (160 points, a multiple of 16), per-ray view / light rows
+    rs = np.random.RandomState(5)
+    P, ppr = 160, 5
+    x = rs.randn(P, 3).astype(np.float32)
+    r = np.maximum(np.linalg.norm(x, axis=-1, keepdims=True), 1.0) * (1.0 + rs.rand(P, 1).astype(np.float32))
+    p4 = np.concatenate([x / np.linalg.norm(x, axis=-1, keepdims=True), 1.0 / r], axis=-1).astype(np.float32)
+    vw = rs.randn(P // ppr, 3).astype(np.float32); vw /= np.linalg.norm(vw, axis=-1, keepdims=True)
+    lg = (4.0 * rs.randn(P // ppr, 3)).astype(np.float32)
+    wd, wc = rs.randn(P, 1).astype(np.float32), rs.randn(P, 3).astype(np.float32)
+    a, b, c = (cu(v).requires_grad_(True) for v in (p4, vw, lg))
+    dens, col = nerf(a, b, c, pts_per_ray=ppr)
+    ((dens * cu(wd)).sum() + (col * cu(wc)).sum()).backward()
+    ref64 = {k: v.double().clone().requires_grad_(True) for k, v in ref.items()}
+    a64, b64, c64 = (T(v).double().requires_grad_(True) for v in (p4, vw, lg))
+    d64, c_64 = orc.nerf_forward(ref64, a64, b64.repeat_interleave(ppr, 0), c64.repeat_interleave(ppr, 0))
+    ((d64 * T(wd).double()).sum() + (c_64 * T(wc).double()).sum()).backward()
+    np.testing.assert_allclose(dens.detach().cpu().numpy(), d64.detach().numpy(), rtol=0, atol=2e-5)
+    for name, p in nerf.named_parameters():
+        want = ref64[name].grad.numpy()
+        scale = max(float(np.abs(want).max()), 1e-12)
+        err = float(np.abs(p.grad.cpu().numpy() - want).max())
+        assert err <= 2e-5 * scale + 1e-7, (name, err, scale)      # bf16x3 split-K products: 4e-6 of an entry's magnitude (nrh_dw.hip)
+    for got, want in ((a.grad, a64.grad), (b.grad, b64.grad), (c.grad, c64.grad)):
+        scale = max(float(want.abs().max()), 1e-12)
+        assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_outside_nerf_background(scene_states, prec):
     """renderer.use_outside_nerf (models/neus_hint_model.py:434-473, :516-519, :630-633, :677-724) against the reference's recorded
     run: evaluation (rgb, depth, the 160 weights per ray - 128 blended + 32 beyond the sphere -, visibility; the per-pixel products
     path) and one training step (loss; gradients of the renderer AND of the background network, float64 reference, bounds from its
-    float32 run).  NeuS side in the HIP kernels with the alpha blend inside the alpha stage, the NeRF MLP as library GEMMs."""
+    float32 run).  NeuS side in the HIP kernels with the alpha blend inside the alpha stage, the NeRF MLP as its own kernel pair
+    (csrc/nrh_outside.hip) with its weight gradients through nrh_dw_gemm."""
     from nrhints_amd.training import train_loss_dict
     g = load_npz("outside_b.npz")
     cfg = na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True))

@@ -370,8 +370,10 @@ def test_uint8_image_products_match_reference_fixture():
 
 def test_outside_nerf_module_matches_reference_fixture():
     """The background network of renderer.use_outside_nerf: constructed under the same seed it has the reference's state-dict keys
-    and initial values (fixture: tests/golden/outside_b.npz, whose density bias was then raised by 1.5), and its forward
-    reproduces the reference's recorded unit I/O; the inverse-depth sample positions follow models/neus_hint_model.py:677-693."""
+    and initial values (fixture: tests/golden/outside_b.npz, whose density bias was then raised by 1.5) - the layers are plain
+    parameter containers with nn.Linear's init arithmetic, evaluated by csrc/nrh_outside.hip (unit I/O: tests/test_gpu_parity2.py);
+    the kernels' packed buffers have the sizes the library reports; the inverse-depth sample positions follow
+    models/neus_hint_model.py:677-693."""
     from nrhints_amd.outside import OutsideNeRF, outside_z
     T = torch.from_numpy
     g = load_npz("outside_b.npz")
@@ -385,12 +387,19 @@ def test_outside_nerf_module_matches_reference_fixture():
             assert abs(float(sd["outside_nerf." + k]) + 1.5 - float(v)) < 2e-7
         else:
             assert np.array_equal(sd["outside_nerf." + k].numpy(), v), k
+    import ctypes
+    from nrhints_amd.outside import pack_outside
     nerf = OutsideNeRF()
     nerf.load_state_dict({k: T(v) for k, v in ref.items()})
-    with torch.no_grad():
-        dens, col = nerf(T(g["unit.pts4"]), T(g["unit.views"]), T(g["unit.pls"]))
-    np.testing.assert_allclose(dens.numpy(), g["unit.density"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(col.numpy(), g["unit.rgb"], rtol=0, atol=2e-6)
+    assert not any(isinstance(mod, torch.nn.Linear) for mod in nerf.modules())      # containers only: no library GEMM behind them
+    with pytest.raises(RuntimeError, match="GPU only"):
+        nerf(T(g["unit.pts4"]), T(g["unit.views"]), T(g["unit.pls"]))
+    sizes = (ctypes.c_int * 5)()
+    assert _lib.load().nrh_outside_sizes(sizes) == 0
+    for prec in (0, 1):
+        w, b = pack_outside(nerf.ordered_parameters(), prec, transposed=False)
+        wt = pack_outside(nerf.ordered_parameters(), prec, transposed=True)
+        assert w.numel() == sizes[0] * (1 + prec) and b.numel() == sizes[1] and wt.numel() == sizes[2] * (1 + prec)
     zo = outside_z(torch.tensor([[2.0], [3.5]]), 64)
     assert zo.shape == (2, 32) and bool((zo[:, 1:] > zo[:, :-1]).all()) and bool((zo > torch.tensor([[2.0], [3.5]])).all())
     assert abs(float(zo[0, -1]) - (2.0 / 1e-3 + 1.0 / 64)) < 1e-2
