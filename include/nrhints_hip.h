@@ -420,6 +420,14 @@ int nrh_embedding_rows(const float* ro, const float* rd, const float* t, int t_s
 int nrh_composite_loss(const float* sampled_color, const float* weights, const float* rgb_gt, const float* background,
                        const float* analytic_normals, const float* inside_sphere, long long nrays, float* rgb, float* zbar_out,
                        float* weights_bar, float* partials, void* stream);
+/* Adjoints of the rays for pose / light refinement (ray_bundle.origins / directions / pl_positions of the reference's autograd,
+ * camera/ray_generator.py:75-150 downstream of pipelines/base_pipeline.py:41-69 and :80-85), from what the sweeps left behind:
+ * pbar [nrays*128,3] (nrh_sdf_train_backward), gbar [nrays*128,3] (the spatial gradient's adjoint: nrh_alpha_train_backward*),
+ * save_ge [nrays*128,128] (NrhTrainSaves), mbar [nrays*128,mbar_width] (nrh_color_train_backward) and rd_bar [nrays,3] (the
+ * alpha stage).  Feeds nrh_generate_rays_indexed_backward. */
+int nrh_ray_adjoint(const float* origins, const float* directions, const float* pl_positions, const float* mid_z, const float* pbar,
+                    const float* gbar, const float* save_ge, const float* mbar, int mbar_width, const float* rd_bar, long long nrays,
+                    float* origins_bar, float* directions_bar, float* pl_bar, void* stream);
 int nrh_loss_finish(const float* partials, long long nrays, float inv_s, const float* dyn_scalars, float igr_weight, float* out8,
                     void* stream);
 /* nrh_alpha_train_backward with (a) strided rows of nhat_bar (the normal's three columns inside the reflectance adjoint's output)

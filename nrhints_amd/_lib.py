@@ -20,7 +20,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_forward_wide", "nrh_sdf_train_backward", "nrh_outside_sizes", "nrh_outside_forward",
-            "nrh_outside_backward", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
+            "nrh_outside_backward", "nrh_ray_adjoint", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
             "nrh_shadow_alpha_forward", "nrh_shadow_alpha_backward", "nrh_alpha_train_forward_n", "nrh_alpha_train_backward_n",
             "nrh_sample_primary", "nrh_alpha_blend_forward", "nrh_alpha_blend_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_forward_grouped", "nrh_color_train_backward",
@@ -82,6 +82,7 @@ def load():
     lib.nrh_sdf_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
     lib.nrh_sdf_train_forward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P]
     lib.nrh_sdf_train_forward_wide.argtypes = [P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P]
+    lib.nrh_ray_adjoint.argtypes = [P, P, P, P, P, P, P, P, c_int, P, c_longlong, P, P, P, P]
     lib.nrh_outside_sizes.argtypes = [POINTER(c_int)]
     lib.nrh_outside_forward.argtypes = [c_int, P, P, P, P, P, c_int, c_longlong, P, P, P, P, P, P, P, P]
     lib.nrh_outside_backward.argtypes = [c_int, P, P, P, P, P, P, c_longlong, P, P, P, P, P, P]

@@ -909,6 +909,22 @@ int nrh_composite_loss(const float* sampled_color, const float* weights, const f
   return check_launch("composite_loss_kernel");
 }
 
+int nrh_ray_adjoint(const float* origins, const float* directions, const float* pl_positions, const float* mid_z, const float* pbar,
+                    const float* gbar, const float* save_ge, const float* mbar, int mbar_width, const float* rd_bar, long long nrays,
+                    float* origins_bar, float* directions_bar, float* pl_bar, void* stream) {
+  if (!origins || !directions || !pl_positions || !mid_z || !pbar || !gbar || !save_ge || !mbar || !rd_bar || !origins_bar ||
+      !directions_bar || !pl_bar)
+    return fail(NRH_E_INVALID, "nrh_ray_adjoint: null pointer%s", "");
+  if (mbar_width < 60) return fail(NRH_E_INVALID, "nrh_ray_adjoint: mbar rows hold at least the 60 columns [p, n, enc4(view), enc4(light)]%s", "");
+  if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_ray_adjoint: nrays out of range%s", "");
+  if (nrays == 0) return NRH_OK;
+  nrh::RayAdjArgs a;
+  a.ro = origins; a.rd = directions; a.pl = pl_positions; a.mid = mid_z; a.pbar = pbar; a.gbar = gbar; a.ge = save_ge; a.mbar = mbar;
+  a.rd_bar = rd_bar; a.obar = origins_bar; a.dbar = directions_bar; a.plbar = pl_bar; a.mw = mbar_width; a.nrays = (int)nrays;
+  hipLaunchKernelGGL(nrh::ray_adjoint_kernel, dim3((unsigned)((nrays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("ray_adjoint_kernel");
+}
+
 int nrh_loss_finish(const float* partials, long long nrays, float inv_s, const float* dyn_scalars, float igr_weight, float* out8,
                     void* stream) {
   if (!partials || !out8) return fail(NRH_E_INVALID, "nrh_loss_finish: null pointer%s", "");

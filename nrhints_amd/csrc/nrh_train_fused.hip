@@ -35,6 +35,102 @@ __global__ __launch_bounds__(256) void emb_rows_kernel(const EmbRowsArgs a) {
   a.out[i] = v;
 }
 
+// ---- adjoints of the rays (pose / light refinement: nr-hints-cam-opt, register_view) ------------------------------------------
+// What autograd derives for ray_bundle.origins / directions / pl_positions in the reference (the samplers, depth / hit point and
+// both hints are outside its graph: models/neus_hint_model.py:697, :531, :379, :589), collected from the adjoints the sweeps left:
+//   pbar_j = pbar_sdf_j                                  value path of the SDF network through the encoding (sdf_adjoint_kernel)
+//          + 9 gbar_j[dim] sum_e ge_j[e] enc''_e(3 p_j)  the spatial gradient's own dependence on the point (second derivative of
+//                                                        the positional encoding; ge = d sdf / d embedding via layer 0 and the skip)
+//          + mbar_j[0:3]                                 the reflectance net's point input
+//   obar = sum_j pbar_j;   dbar = sum_j mid_j pbar_j + rd_bar (alpha stage: cos = <d, g>) + enc4'(d)^T sum_j mbar_j[6:33]
+//   plbar = enc4'(pl)^T sum_j mbar_j[33:60]              (the reflectance net sees enc4 of the view direction and the light position)
+// One wavefront per ray; 128 samples = 2 per lane for the per-sample part, lanes 0..53 = the 54 encoding columns for the column sums.
+struct RayAdjArgs {
+  const float* ro; const float* rd; const float* pl;   // [N,3]
+  const float* mid;       // [N,128] section mid-points
+  const float* pbar;      // [N*128,3]
+  const float* gbar;      // [N*128,3]  adjoint of d sdf / dx (after the alpha adjoint incl. the eikonal seed)
+  const float* ge;        // [N*128,128] save_ge: columns e and 73 + e
+  const float* mbar;      // [N*128,mw]
+  const float* rd_bar;    // [N,3]
+  float* obar; float* dbar; float* plbar;   // [N,3]
+  int mw;
+  int nrays;
+};
+__global__ __launch_bounds__(256) void ray_adjoint_kernel(const RayAdjArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long ray = (long long)blockIdx.x * 4 + wave;
+  if (ray >= a.nrays) return;
+  float o[3], d[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { o[c] = a.ro[ray * 3 + c]; d[c] = a.rd[ray * 3 + c]; }
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // obar, sum mid pbar
+#pragma unroll
+  for (int e2 = 0; e2 < 2; ++e2) {
+    const long long P = ray * 128 + lane + 64 * e2;
+    const float t = a.mid[P];
+    const float* ge = a.ge + P * 128;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x3 = (o[c] + d[c] * t) * 3.0f;
+      float s2 = 0.0f;     // sum_e ge[e] enc''_e over the 12 sine entries of coordinate c (the raw entry has no second derivative)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float f = (float)(1 << k), arg = x3 * f;
+        const float g0 = ge[3 + 6 * c + k] + ge[73 + 3 + 6 * c + k], g1 = ge[21 + 6 * c + k] + ge[73 + 21 + 6 * c + k];
+        s2 -= (g0 * sin_cw(arg) + g1 * sin_cw(arg + NRH_HALF_PI)) * (f * f);
+      }
+      const float pb = a.pbar[P * 3 + c] + 9.0f * a.gbar[P * 3 + c] * s2 + a.mbar[P * a.mw + c];
+      acc[c] += pb;
+      acc[3 + c] += t * pb;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+  }
+  // column sums of the per-ray encodings' adjoints: lane L < 54 owns column 6 + L (27 of the view direction, 27 of the light)
+  float cs = 0.0f;
+  if (lane < 54) {
+    const float* mb = a.mbar + ray * 128 * a.mw + 6 + lane;
+    for (int j = 0; j < 128; ++j) cs += mb[(long long)j * a.mw];
+  }
+  // enc4(v) = [v (3) | sin(v_c 2^k), c-major (12) | sin(v_c 2^k + pi/2) (12)]: column m of it differentiates against v[dim(m)]
+  const int m = lane < 27 ? lane : lane - 27;
+  const int dim = m < 3 ? m : ((m - 3) % 12) / 4;
+  float coef = 0.0f;
+  if (lane < 54) {
+    const float v = lane < 27 ? d[dim] : a.pl[ray * 3 + dim];
+    if (m < 3) coef = 1.0f;
+    else {
+      const int k = (m - 3) % 4;
+      const float f = (float)(1 << k);
+      coef = cos_cw(v * f + ((m - 3) >= 12 ? NRH_HALF_PI : 0.0f)) * f;
+    }
+  }
+  const float contrib = cs * coef;
+  float vs[6];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    vs[c] = (lane < 27 && dim == c) ? contrib : 0.0f;
+    vs[3 + c] = (lane >= 27 && lane < 54 && dim == c) ? contrib : 0.0f;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vs[i] += __shfl_xor(vs[i], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a.obar[ray * 3 + c] = acc[c];
+      a.dbar[ray * 3 + c] = acc[3 + c] + a.rd_bar[ray * 3 + c] + vs[c];
+      a.plbar[ray * 3 + c] = vs[3 + c];
+    }
+  }
+}
+
 // ---- composite + loss terms + the adjoint seeds of both (one wavefront per ray) ----------------------------------------------
 //   rgb = sum_j c_j w_j + bg (1 - sum_j w_j)                                     (models/neus_hint_model.py:635-637)
 //   rgb_loss = sum |rgb - gt| / (N + 1e-5);  eik = sum inside (|g| - 1)^2 / (sum inside + 1e-5);  loss = rgb_loss + igr * eik

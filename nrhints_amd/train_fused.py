@@ -11,8 +11,12 @@ returns the loss dict AND leaves ``.grad`` on all 46 parameter tensors:
     seed) -> SDF tangent + value sweeps -> positional encoding rows -> ALL weight gradients in one split-K bf16x3 launch
     (csrc/nrh_dw.hip) + its reduction -> d variance -> weight-norm adjoint (1)
 
-Restrictions (the autograd path covers the rest): GPU float32 parameters, normal_type NormalizedAnalytic, gradients for the
-parameters only (pose refinement needs the ray gradients: autograd path), at most ``max_fused_train_rays`` rays per call.
+Ray gradients (pose / light refinement: the reference's default preset nr-hints-cam-opt, and register_view): when the ray tensors
+require grad, one more launch (nrh_ray_adjoint) reduces the sweeps' adjoints to d loss / d (origins, directions, pl_positions),
+which are handed to the ray generator's backward (nrh_generate_rays_indexed_backward through its autograd.Function).
+
+Restrictions (the autograd path covers the rest): GPU float32 parameters, normal_type NormalizedAnalytic, at most
+``max_fused_train_rays`` rays per call.
 """
 from __future__ import annotations
 
@@ -41,8 +45,6 @@ def supported(renderer, ray_bundle) -> Optional[str]:
         return "partial visibility hint (n_shadow_importance_clip > 0)"
     if getattr(renderer, "_mixed_hints", False):
         return "one hint without the other (zero-padded first reflectance layer)"
-    if any(t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
-        return "ray gradients requested (pose / light refinement)"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
         return "more rays than max_fused_train_rays"
     if ray_bundle.origins.shape[0] == 0:
@@ -50,8 +52,8 @@ def supported(renderer, ray_bundle) -> Optional[str]:
     ps = list(renderer.parameters())
     if not all(p.is_cuda and p.dtype == torch.float32 for p in ps):
         return "parameters must be float32 on the GPU"
-    if not all(p.requires_grad for p in ps):
-        return "frozen parameters"
+    if not (all(p.requires_grad for p in ps) or not any(p.requires_grad for p in ps)):
+        return "partly frozen parameters"
     return None
 
 
@@ -71,6 +73,7 @@ class _Buffers:
         self.sdf_bar, self.grad_bar, self.rd_bar, self.invs_bar = new(P), new(P, 3), new(n, 3), new(n)
         self.emb = new(P, 64)
         self.var_bar = new(1)
+        self.o_bar, self.d_bar, self.pl_bar = new(n, 3), new(n, 3), new(n, 3)      # ray adjoints (pose / light refinement)
         g = {}
         for l in range(8):
             g[f"dW{l}"], g[f"db{l}"] = new(*shapes[f"sdf_w{l}"]), new(*shapes[f"sdf_b{l}"])
@@ -85,9 +88,19 @@ class _Buffers:
 
 
 def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_rgb: Optional[torch.Tensor], global_step: int,
-                        igr_weight: Optional[float] = None, t_rand_primary=None, t_rand_shadow=None) -> torch.Tensor:
-    """Forward (training mode) + loss + backward of one batch.  Returns the loss vector [8] on the device
-    (``LOSS_KEYS`` = entries 0..4) and sets ``.grad`` of every renderer parameter (overwriting, like zero_grad + backward)."""
+                        igr_weight: Optional[float] = None, t_rand_primary=None, t_rand_shadow=None, is_training: bool = True,
+                        ray_grads: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """Forward + loss + backward of one batch.  Returns the loss vector [8] on the device (``LOSS_KEYS`` = entries 0..4) and sets
+    ``.grad`` of every renderer parameter (overwriting, like zero_grad + backward) - unless the renderer's parameters are frozen
+    (``requires_grad_(False)``, as in register_view), in which case the weight gradients, the weight-norm adjoint and the variance
+    gradient are skipped.
+
+    ``is_training=False``: the evaluation-mode forward of ``register_view`` (pipelines/base_pipeline.py:80-85): no jitter, cosine
+    ratio 1, no geometry warm-up; pass ``igr_weight=0`` for its plain L1 loss.
+    Ray gradients: if any of the bundle's origins / directions / pl_positions requires grad, their adjoints are computed
+    (nrh_ray_adjoint) and - ``ray_grads`` None - pushed into the autograd graph that produced the bundle (the ray generator's
+    backward), accumulating ``.grad`` on its parameters like ``loss.backward()``; with a dict ``ray_grads`` they are returned in it
+    (keys origins / directions / pl_positions; persistent buffers) and nothing is propagated."""
     why = supported(renderer, ray_bundle)
     if why is not None:
         raise ValueError(f"fused training step not applicable: {why}")
@@ -101,12 +114,15 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
     dev, n = o.device, o.shape[0]
     with torch.cuda.device(dev), torch.no_grad():
         stream = _lib.stream_handle()
-        cos_anneal = min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0
-        zero_hints = 1 if global_step < cfg.geometry_warmup_end else 0
-        t_p = f32(t_rand_primary).reshape(-1) if t_rand_primary is not None else torch.rand(n, device=dev)
-        t_s = None
-        if not zero_hints and renderer._hints:
-            t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(n, 64, device=dev)
+        cos_anneal = (min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0) if is_training else 1.0
+        zero_hints = 1 if (is_training and global_step < cfg.geometry_warmup_end) else 0
+        t_p = t_s = None
+        if is_training:
+            t_p = f32(t_rand_primary).reshape(-1) if t_rand_primary is not None else torch.rand(n, device=dev)
+            if not zero_hints and renderer._hints:
+                t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(n, 64, device=dev)
+        want_rays = any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions))
+        want_params = any(p.requires_grad for p in renderer.parameters())
         # ---- parameters: fold weight-norm (one launch), re-pack ----
         named = dict(renderer.named_parameters())
         gs = [named[k + ".weight_g"].detach() for k in packing._FOLD_LAYERS]
@@ -163,9 +179,18 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
                                                       float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, mw, P_(res["inside"]),
                                                       ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
                                                       P_(B.invs_bar), stream), "nrh_alpha_train_backward_fused")
-        _lib.check(lib.nrh_variance_grad(P_(B.invs_bar), n, float(inv_s), P_(dyn), P_(B.var_bar), stream), "nrh_variance_grad")
+        if want_params:
+            _lib.check(lib.nrh_variance_grad(P_(B.invs_bar), n, float(inv_s), P_(dyn), P_(B.var_bar), stream), "nrh_variance_grad")
         # ---- SDF network: tangent + value sweeps ----
         r = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], o, d, res["mid_z"], 128, sv, B.sdf_bar, B.fbar, B.grad_bar)
+        # ---- ray adjoints (pose / light refinement): one per-ray reduction of what the sweeps left ----
+        if want_rays:
+            _lib.check(lib.nrh_ray_adjoint(P_(o), P_(d), P_(pl), P_(res["mid_z"]), P_(r["pbar"]), P_(B.grad_bar), P_(sv["ge"]), P_(B.mbar), mw,
+                                           P_(B.rd_bar), n, P_(B.o_bar), P_(B.d_bar), P_(B.pl_bar), stream), "nrh_ray_adjoint")
+        if not want_params:
+            # frozen renderer (register_view, pipelines/base_pipeline.py:71-91: only the ray generator's deltas step): the reference
+            # computes and discards all 46 parameter gradients there; the results are the same without them
+            return _finish_rays(B, ray_bundle, want_rays, ray_grads)
         _lib.check(lib.nrh_embedding_rows(P_(o), P_(d), P_(res["mid_z"]), 128, 128, n, P_(B.emb), stream), "nrh_embedding_rows")
         # ---- every weight gradient: one split-K launch + its reduction ----
         shapes = [tuple(dense[f"sdf_w{l}"].shape) for l in range(8)]
@@ -184,7 +209,20 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             named[k + ".weight_v"].grad, named[k + ".weight_g"].grad = vb, gb
             named[k + ".bias"].grad = bb.view(named[k + ".bias"].shape)
         named["deviation_network.variance"].grad = B.var_bar.view(())
-        return B.loss8
+        return _finish_rays(B, ray_bundle, want_rays, ray_grads)
+
+
+def _finish_rays(B, ray_bundle, want_rays: bool, ray_grads) -> torch.Tensor:
+    """Hand the ray adjoints on: into ``ray_grads`` when given, else into the autograd graph behind the bundle's tensors (the ray
+    generator: one nrh_generate_rays_indexed_backward launch + the exponential map's tiny backward), as loss.backward() would."""
+    if want_rays:
+        pairs = [(t, g) for t, g in ((ray_bundle.origins, B.o_bar), (ray_bundle.directions, B.d_bar), (ray_bundle.pl_positions, B.pl_bar))
+                 if torch.is_tensor(t) and t.requires_grad]
+        if ray_grads is not None:
+            ray_grads.update(origins=B.o_bar, directions=B.d_bar, pl_positions=B.pl_bar)
+        elif pairs:
+            torch.autograd.backward([t for t, _ in pairs], [g.to(t.dtype).reshape(t.shape) for t, g in pairs])
+    return B.loss8
 
 
 def loss_dict(loss8: torch.Tensor) -> Dict[str, float]:

@@ -232,8 +232,8 @@ class GraphedTrainStep:
         # step's gradients live at fixed addresses; the autograd path's are staged through the optimiser's own buffers
         from . import train_fused
         from .adam import HipAdam
-        refines = ray_generator is not None and any(p.requires_grad for p in ray_generator.parameters())
-        self._use_fused = (train_fused.supported(renderer, self.rays) is None and not refines) if fused is None else bool(fused)
+        # (pose / light refinement no longer leaves the fused step: train_fused computes the ray adjoints, nrh_ray_adjoint)
+        self._use_fused = (train_fused.supported(renderer, self.rays) is None) if fused is None else bool(fused)
         self.optimizer = HipAdam(groups)
         self.bg = background_rgb.detach().to(dev, torch.float32).reshape(1, 3).clone()
         renderer.dyn_scalars = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -336,9 +336,18 @@ class GraphedTrainStep:
             rg_live = [(p, rg_alias[n]) for n, p in rg_named if p.requires_grad]
         use_fused = self._use_fused
         if upto != "tail" and use_fused:
+            rgr = {} if rg_live else None
             loss8 = train_fused.train_step_backward(
                 self.renderer, rays, self.gt, self.bg, self._capture_step,
-                t_rand_primary=None if self.jitter is None else self.jitter[0], t_rand_shadow=None if self.jitter is None else self.jitter[1])
+                t_rand_primary=None if self.jitter is None else self.jitter[0], t_rand_shadow=None if self.jitter is None else self.jitter[1],
+                ray_grads=rgr)
+            if rg_live:
+                # the ray adjoints through the ray generator's backward (nrh_generate_rays_indexed_backward + the exponential map)
+                outs = [(t_, rgr[k]) for k, t_ in (("origins", rays.origins), ("directions", rays.directions),
+                                                   ("pl_positions", rays.pl_positions)) if t_.requires_grad]
+                gs = torch.autograd.grad([t_ for t_, _ in outs], [a for _, a in rg_live], grad_outputs=[g for _, g in outs], allow_unused=True)
+                for (p, _), g in zip(rg_live, gs):
+                    p.grad = g
             self._keys = list(train_fused.LOSS_KEYS)
             vec = loss8[:5]
             if sync:
@@ -439,17 +448,52 @@ class GraphedTrainStep:
 # ---- checkpoints in the reference's layout (trainer/trainer.py:149-158, 173-236) ---------------------------------------
 def register_view(renderer, ray_generator, img_pixel_bundle, device, steps: int = 500, batch_size: int = 512,
                   white_background: bool = True, lr: Optional[float] = None, generator: Optional[torch.Generator] = None,
-                  log=None) -> List[float]:
+                  log=None, fused: Optional[bool] = None) -> List[float]:
     """Fit the ray generator's pose / light deltas of one view to its pixels with the renderer frozen in evaluation mode
     (pipelines/base_pipeline.py:71-91): ``steps`` Adam steps over random ``batch_size``-pixel batches of the [H,W]
     ``img_pixel_bundle`` with the summed L1 loss / (N + 1e-5).  The gradient reaches the deltas through the renderer's ray
-    gradients (origins / directions / pl_positions).  Returns the loss trajectory (one host sync per step, as upstream's
-    ``loss.item()`` print)."""
+    gradients (origins / directions / pl_positions).  Returns the loss trajectory.
+    ``fused`` (None = whenever it applies): every step is the autograd-free sequence of train_fused.train_step_backward with the
+    renderer frozen - evaluation-mode forward, loss, the sweeps, nrh_ray_adjoint, the ray generator's backward, HipAdam on its
+    deltas - without the weight-gradient launches the reference computes and discards here, and with ONE read-back of the loss
+    trajectory at the end (per step only when ``log`` is given, as upstream's print does)."""
     lr = ray_generator.config.opt_lr if lr is None else lr
-    optimizer = torch.optim.Adam(ray_generator.parameters(), lr=lr)
     H, W = img_pixel_bundle.shape[0], img_pixel_bundle.shape[1]
     bg = torch.full((1, 3), 1.0 if white_background else 0.0, device=device)
     losses: List[float] = []
+    from . import train_fused
+    rg_params = [p for p in ray_generator.parameters() if p.requires_grad]
+    if fused is not False and rg_params and torch.device(device).type == "cuda" and batch_size <= renderer.max_fused_train_rays:
+        from types import SimpleNamespace
+        z3 = torch.zeros(batch_size, 3, device=device, requires_grad=True)
+        probe = SimpleNamespace(origins=z3, directions=z3, pl_positions=z3)
+        frozen = [(p, p.requires_grad) for p in renderer.parameters()]
+        for p, _ in frozen:
+            p.requires_grad_(False)        # the reference computes and discards the renderer's gradients here; only the deltas step
+        try:
+            if train_fused.supported(renderer, probe) is None:
+                from .adam import HipAdam
+                optimizer = HipAdam(rg_params, lr=lr)
+                dev_losses = []
+                with torch.enable_grad():
+                    for i in range(steps):
+                        hi = torch.randint(0, H, (batch_size,), device="cpu", generator=generator)
+                        wi = torch.randint(0, W, (batch_size,), device="cpu", generator=generator)
+                        pb = img_pixel_bundle[hi, wi].to(device)
+                        optimizer.zero_grad(set_to_none=True)
+                        # evaluation-mode forward + L1 loss / (N + 1e-5) + the ray adjoints as one fixed sequence of HIP launches
+                        # (no weight gradients, no autograd inside the renderer); its backward continues into the ray generator
+                        loss8 = train_fused.train_step_backward(renderer, ray_generator(pb), pb.rgb_gt, bg, 0, igr_weight=0.0, is_training=False)
+                        optimizer.step()
+                        dev_losses.append(loss8[1:2].clone())
+                        if log is not None:
+                            log(f"register step: {i} loss: {float(dev_losses[-1])}")
+                # one read-back for the whole trajectory (upstream prints loss.item() per step: pass `log` to get that behaviour)
+                return torch.cat(dev_losses).tolist() if dev_losses else []
+        finally:
+            for p, rq in frozen:
+                p.requires_grad_(rq)
+    optimizer = torch.optim.Adam(ray_generator.parameters(), lr=lr)
     with torch.enable_grad():
         for i in range(steps):
             hi = torch.randint(0, H, (batch_size,), device="cpu", generator=generator)

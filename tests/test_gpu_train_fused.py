@@ -222,6 +222,68 @@ def test_fused_step_gradients_vs_reference(scene_states, tag, prec):
     assert not bad, "gradient outside its derived bound (ratio, tensor, err/scale, bound/scale): " + repr(sorted(bad, reverse=True)[:8])
 
 
+@pytest.mark.parametrize("tag,prec", [("a", "f16x3"), ("b", "f16x3"), ("b", "f32")])
+def test_fused_step_ray_gradients_vs_reference(scene_states, tag, prec):
+    """Pose / light refinement on the fused step (nr-hints-cam-opt): d loss / d (origins, directions,
+    pl_positions) from nrh_ray_adjoint against the reference's recorded float64 gradients of the same training step
+    (tests/golden/train_*.npz), bounds derived from its own float32 run - the same check the autograd path passes in
+    test_gpu_parity.py::test_training_step_gradients - and the parameter gradients unchanged by asking for them."""
+    g = load_npz(f"train_{tag}.npz")
+    model = _model(scene_states[tag], prec)
+    rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+    for t_ in (rb.origins, rb.directions, rb.pl_positions):
+        t_.requires_grad_(True)
+    assert train_fused.supported(model, rb) is None
+    grads = {}
+    loss8 = train_fused.train_step_backward(model, rb, cu(g["rgb_gt"]), torch.ones(1, 3).cuda(), int(g["global_step"]),
+                                            t_rand_primary=cu(g["t_rand_primary"]), t_rand_shadow=cu(g["t_rand_shadow"]), ray_grads=grads)
+    np.testing.assert_allclose(float(loss8[0]), float(g["loss"]), rtol=2e-4)
+    bad = []
+    for nm in ("origins", "directions", "pl_positions"):
+        tol, scale = grad_bound(g["grad.rays." + nm], g["grad64.rays." + nm])
+        err = float(np.abs(grads[nm].cpu().numpy().astype(np.float64) - g["grad64.rays." + nm]).max())
+        if err >= tol:
+            bad.append((nm, err / scale, tol / scale))
+    assert not bad, bad
+    assert rb.origins.grad is None                      # returned, not propagated
+    for name in ("sdf_network.lin4.weight_v", "color_network.lin0.weight_v", "deviation_network.variance"):
+        tol, scale = grad_bound(g["grad." + name], g["grad64." + name])
+        prm = dict(model.named_parameters())[name]
+        assert float(np.abs(prm.grad.detach().cpu().numpy().astype(np.float64) - g["grad64." + name]).max()) < tol, name
+    # without a dict the adjoints go into the graph behind the bundle: leaves receive .grad, as loss.backward() would give
+    train_fused.train_step_backward(model, rb, cu(g["rgb_gt"]), torch.ones(1, 3).cuda(), int(g["global_step"]),
+                                    t_rand_primary=cu(g["t_rand_primary"]), t_rand_shadow=cu(g["t_rand_shadow"]))
+    for nm, t_ in (("origins", rb.origins), ("directions", rb.directions), ("pl_positions", rb.pl_positions)):
+        assert torch.equal(t_.grad, grads[nm]), nm
+
+
+def test_fused_register_view_step_equals_autograd(scene_states):
+    """The step register_view takes (pipelines/base_pipeline.py:80-91): evaluation-mode forward, L1 / (N + 1e-5), gradients for
+    the rays only.  Fused with the renderer frozen (no weight-gradient launches) against the autograd path on the same rays."""
+    model = _model(scene_states["b"]).eval()
+    n = 256
+    rs = np.random.RandomState(9)
+    bg = torch.ones(1, 3).cuda()
+    gt = cu(rs.rand(n, 3).astype(np.float32))
+    rb = _bundle(*make_rays(n, seed=21, spread=0.1))
+    for t_ in (rb.origins, rb.directions, rb.pl_positions):
+        t_.requires_grad_(True)
+    out = model(rb, background_rgb=bg, is_training=False)
+    loss = torch.nn.functional.l1_loss(out.rgb, gt, reduction="sum") / (n + 1e-5)
+    loss.backward()
+    want = [t_.grad.clone() for t_ in (rb.origins, rb.directions, rb.pl_positions)]
+    for p in model.parameters():
+        p.requires_grad_(False)
+    grads = {}
+    loss8 = train_fused.train_step_backward(model, rb, gt, bg, 0, igr_weight=0.0, is_training=False, ray_grads=grads)
+    np.testing.assert_allclose(float(loss8[0]), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(float(loss8[1]), float(loss), rtol=1e-5)
+    for nm, w in zip(("origins", "directions", "pl_positions"), want):
+        scale = float(w.abs().max()) + 1e-30
+        assert float((grads[nm] - w).abs().max()) < 1e-4 * scale + 1e-7, (nm, float((grads[nm] - w).abs().max()), scale)
+    assert all(p.grad is None for p in model.parameters())
+
+
 def test_fused_step_equals_autograd_path(scene_states):
     """Same batch, same jitter through the autograd Functions (forward + train_loss_dict + backward) and through the fused
     sequence: same kernels for the sweeps and the weight gradients, so the results agree to fp32 round-off of the few
