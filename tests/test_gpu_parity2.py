@@ -462,11 +462,12 @@ def _orbit_pixels(n, ncam, seed, H=48, W=64):
 def test_graph_with_ray_generator_group(scene_states, refine):
     """GraphedTrainStep(ray_generator=...): the step starts at the RawPixelBundle, and Adam carries the reference's second parameter
     group (trainer/trainer.py:99-102).  With pose + light refinement on (cam_opt_mode SO3xR3, pl_opt) the replay must equal
-    the eager sequence ray generator -> renderer -> loss -> backward -> two-group capturable Adam on the same batches and jitter:
-    losses, the deltas' gradients and values, the renderer's parameters - to the last bits on the first step; the ray generator's
-    adjoint scatters into the per-view deltas with atomics, so from the second step on the two runs differ by summation order
-    in the deltas' last bit, which the renderer amplifies (see test_graph_replay_equals_eager_step).  With refinement off the group is empty, the fused
-    autograd-free step runs inside the graph, and the optimiser state still has the two-group layout."""
+    the eager sequence ray generator -> renderer -> loss -> backward (autograd path) -> two-group Adam on the same batches and
+    jitter: losses, the deltas' gradients and values, the renderer's parameters - to fp32 round-off on the first step (the graph
+    holds the fused autograd-free step incl. nrh_ray_adjoint and the ray generator's adjoint kernel); the ray generator's adjoint
+    scatters into the per-view deltas with atomics, so from the second step on the two runs also differ by summation order in the
+    deltas' last bit, which the renderer amplifies (see test_graph_replay_equals_eager_step).  With refinement off the group is
+    empty and the optimiser state still has the two-group layout."""
     from nrhints_amd import RayGenerator, RayGeneratorConfig
     from nrhints_amd.pipeline import CameraModel
     from nrhints_amd.training import GraphedTrainStep, lr_factor, train_loss_dict
@@ -506,16 +507,17 @@ def test_graph_with_ray_generator_group(scene_states, refine):
         step.jitter[0].copy_(tp); step.jitter[1].copy_(ts)
         loss = step(pb, pb.rgb_gt, global_step=gs + i)["loss"]
         want = float(ld["loss"].detach())
-        # refine: autograd path on both sides (bit-equal as test_graph_replay_equals_eager_step); off: fused step vs autograd
-        assert abs(loss - want) <= (1e-6 if refine and i == 0 else 2e-5) * abs(want), (i, loss, want)
+        # the graph replays the FUSED step in both cases (since round 4 also under refinement: train_fused + nrh_ray_adjoint), the
+        # eager side is the autograd path: equal up to fp32 round-off of the few expressions that differ between the two
+        assert abs(loss - want) <= 2e-5 * abs(want), (i, loss, want)
         assert abs(float(step.ray_lr_t) - rlr * f) < 1e-10
         for (k, a), (_, b) in zip(rg_g.named_parameters(), rg_e.named_parameters()):
             scale = float(b.grad.abs().max()) + 1e-30
-            assert float((a.grad - b.grad).abs().max()) <= (1e-6 if i == 0 else 5e-3) * scale, (i, k)
-            assert float((a.detach() - b.detach()).abs().max()) <= (2e-7 if i == 0 else 5e-6), (i, k)
+            assert float((a.grad - b.grad).abs().max()) <= (1e-4 if i == 0 else 5e-3) * scale, (i, k)
+            assert float((a.detach() - b.detach()).abs().max()) <= 5e-6, (i, k)
         if refine:
             for (k, a), (_, b) in zip(graphed.named_parameters(), eager.named_parameters()):
-                assert float((a.detach() - b.detach()).abs().max()) <= (2e-7 if i == 0 else 5e-6), (i, k)
+                assert float((a.detach() - b.detach()).abs().max()) <= 5e-6, (i, k)
     if refine:
         assert float(rg_g.cam_pose_adjustment.grad.abs().max()) > 0 and float(rg_g.pl_adjustment.grad.abs().max()) > 0
         moved = float((rg_g.pl_adjustment.detach() - T(np.random.RandomState(2).randn(ncam, 3).astype(np.float32)).cuda() * 0.02).abs().max())

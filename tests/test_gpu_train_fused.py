@@ -272,12 +272,13 @@ def test_fused_register_view_step_equals_autograd(scene_states):
     loss = torch.nn.functional.l1_loss(out.rgb, gt, reduction="sum") / (n + 1e-5)
     loss.backward()
     want = [t_.grad.clone() for t_ in (rb.origins, rb.directions, rb.pl_positions)]
+    model.zero_grad(set_to_none=True)
     for p in model.parameters():
         p.requires_grad_(False)
     grads = {}
     loss8 = train_fused.train_step_backward(model, rb, gt, bg, 0, igr_weight=0.0, is_training=False, ray_grads=grads)
-    np.testing.assert_allclose(float(loss8[0]), float(loss), rtol=1e-5)
-    np.testing.assert_allclose(float(loss8[1]), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(float(loss8[0]), float(loss.detach()), rtol=1e-5)
+    np.testing.assert_allclose(float(loss8[1]), float(loss.detach()), rtol=1e-5)
     for nm, w in zip(("origins", "directions", "pl_positions"), want):
         scale = float(w.abs().max()) + 1e-30
         assert float((grads[nm] - w).abs().max()) < 1e-4 * scale + 1e-7, (nm, float((grads[nm] - w).abs().max()), scale)
