@@ -86,23 +86,80 @@ def dominant_kernel(precision, wide):
     return "sdf_kernel<2, %s>" % {"f16x3": "1", "f32": "0"}[precision], "sdf_kernel<2> (sdf + feature + d sdf/dx, 128 pts/ray)"
 
 
+def kernel_source_hash():
+    """Hash of the sources the evaluation kernels are generated / compiled from: a committed counter summary is only quoted when
+    it was taken with the same kernels (profiles/pmc_run.sh records this value in its summary)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("gen_mlp32.py", "nrh_mlp32.h", "nrh_sdf32.hip", "nrh_color32.hip", "nrh_wide.hip", "nrh_mlp.h", "nrh_sdf.hip", "nrh_common.h"):
+        with open(os.path.join(ROOT, "nrhints_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _traffic_from_summary(txt, precision, wide):
+    import re
+    m = re.search(re.escape(dominant_kernel(precision, wide)[0]) + r"[^\n]*\n((?:   .*\n)+)", txt)
+    if not m:
+        return None
+    vals = dict(re.findall(r"(\w+)\s+n=\s*\d+ mean=([0-9.e+]+)", m.group(1)))
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        # FETCH_SIZE [KiB] x 2 (gfx950 counts wide coalesced reads at half their size, MI355X_MICROARCH.md) + WRITE_SIZE [KiB]
+        return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024)
+    return None
+
+
 def pmc_traffic(precision, wide):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/pmc_run.sh): FETCH_SIZE [KiB] x 2 (gfx950 counts wide coalesced reads at half their size) + WRITE_SIZE
-    [KiB].  None if no counter summary for this precision is committed."""
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc passes of this same command
+    (profiles/pmc_run.sh) - IF that summary was taken with today's kernel sources (its ``source_hash`` line); a summary of other
+    kernels is reported as stale and its number is not quoted.  -> (bytes or None, path or None, kind)."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{precision}_v*", "summary.txt")))
-    key = re.escape(dominant_kernel(precision, wide)[0])
     for path in reversed(files):
         txt = open(path).read()
-        m = re.search(key + r"[^\n]*\n((?:   .*\n)+)", txt)
-        if not m:
+        t = _traffic_from_summary(txt, precision, wide)
+        if t is None:
             continue
-        vals = dict(re.findall(r"(\w+)\s+n=\s*\d+ mean=([0-9.e+]+)", m.group(1)))
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            return int((2.0 * float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(path, ROOT)
-    return None, None
+        m = re.search(r"source_hash\s+(\w+)", txt)
+        rel = os.path.relpath(path, ROOT)
+        if m and m.group(1) == kernel_source_hash():
+            return t, rel, "committed rocprofv3 --pmc summary of this command taken with the same kernel sources (source_hash matches); --pmc collects it live"
+        return None, rel, ("stale: the newest committed counter summary was taken with other kernel sources (source_hash "
+                           f"{m.group(1) if m else 'absent'} != {kernel_source_hash()}); run bench.py --pmc or profiles/pmc_run.sh")
+    return None, None, "no committed counter summary for this precision; run bench.py --pmc"
+
+
+def pmc_live(precision, wide):
+    """--pmc: collect FETCH_SIZE and WRITE_SIZE of one frame live - two rocprofv3 passes (one counter each: they do not fit one
+    pass; --kernel-trace only, as the pool requires) of this script with --steps 1 --no-train --no-secondary --cpu-rays 0."""
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="nrh_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", NRH_BENCH_PMC_CHILD="1")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(out, ctr), "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-rays", "0", "--no-train", "--no-secondary", "--precision", precision]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=False)
+        except Exception as e:  # noqa: BLE001
+            return None, f"rocprofv3 failed: {e}"
+    key = dominant_kernel(precision, wide)[0]
+    import csv
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        v = []
+        for f in glob.glob(os.path.join(out, ctr, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                v += [float(r["Counter_Value"]) for r in csv.DictReader(fh) if key in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        if not v:
+            return None, f"no {ctr} rows for {key}"
+        vals[ctr] = sum(v) / len(v)
+    shutil.rmtree(out, ignore_errors=True)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "live: two rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE) of one frame of this command"
 
 
 def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
@@ -110,8 +167,9 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
     ``n_sample`` rays (4096) in 512-ray chunks, 1 warm-up + 3 timed repeats, median.
 
     Eager PyTorch on [512*128, 256] operands stops scaling long before a 256-core host is full (oversubscribed it
-    is 10x slower), so the thread count is calibrated on a 64-ray probe over {all, 64, 32, 16} cores and the best
-    one is used and reported as ``cores``.  The repeats stop early if the time budget runs out (said in ``sample``)."""
+    is 10x slower), so the thread count is calibrated on ONE 512-ray chunk - the size the timed repeats use - over
+    {all, 128, 64, 32, 16} cores and the best one is used and reported as ``cores`` (the chunk doubles as the warm-up).  The
+    repeats stop early if the time budget runs out (said in ``sample``)."""
     from oracle import neus_oracle as orc  # the checker; only this leg and the tests import it
     host = os.cpu_count() or 1
     p = orc.params_from_state(state)
@@ -119,17 +177,17 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
     sub = [torch.from_numpy(a[idx]) for a in rays_np]
     bg = torch.ones(1, 3)
     best, best_t = host, float("inf")
-    for th in sorted({host, min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
+    calib = {}
+    for th in sorted({host, min(host, 128), min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
         torch.set_num_threads(th)
         t0 = time.perf_counter()
-        orc.render_chunked(p, *(t[:64] for t in sub), chunk=512, background_rgb=bg, mode="as_written")
+        orc.render_chunked(p, *(t[:512] for t in sub), chunk=512, background_rgb=bg, mode="as_written")
         dt = time.perf_counter() - t0
+        calib[th] = round(dt, 2)
         if dt < best_t:
             best, best_t = th, dt
     torch.set_num_threads(best)
     t_start = time.perf_counter()
-    # warm-up on one chunk (the protocol's warm-up repeat would cost a quarter of the budget for nothing new)
-    orc.render_chunked(p, *(t[:512] for t in sub), chunk=512, background_rgb=bg, mode="as_written")
     times, out = [], None
     for rep in range(3):
         t0 = time.perf_counter()
@@ -142,7 +200,7 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
     return {"value": round(n_sample / med, 2), "unit": "rays/s", "cores": best, "host_cores": host, "kind": "port",
             "sample": f"{n_sample} rays strided over the benchmark frame in 512-ray chunks, oracle mode=as_written (reference "
                       f"call pattern), fp32 PyTorch eager, one-chunk warm-up + {len(times)} repeat(s), median {med:.1f} s",
-            "repeats_s": [round(t, 2) for t in times],
+            "repeats_s": [round(t, 2) for t in times], "thread_calibration_s_per_512_rays": calib,
             "psnr_gpu_vs_cpu_db": round(psnr(gpu_rgb[idx], ref), 2),
             "max_abs_rgb_diff": float(np.abs(gpu_rgb[idx] - ref).max())}
 
@@ -183,11 +241,112 @@ def timed_render(model, rb, bg, steps, warmup, dist, dev, sharded):
     return dt, out, k_ms.value, max(1, k_n.value)
 
 
-def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
-    """BASELINE.json configs[2] (and [4] for N > 1): 1024-ray training steps of the reference-initialised student against
-    pixels of scene b (rendered before the timed region: ground-truth pixels are data)."""
-    from nrhints_amd.training import FlatGradAllReduce, GraphedTrainStep, make_optimizer, train_step
+def orbit_views(ncam=12, radius=3.6, elevation=0.4):
+    """Poses [ncam,4,4] of cameras on an orbit looking at the origin and one light per view (the synthetic stand-in for a real
+    scene's calibrated views: BASELINE configs[3] / [4] name datasets that are not reachable offline)."""
+    poses = np.zeros((ncam, 4, 4), dtype=np.float32)
+    for i, a in enumerate(np.linspace(0.2, 5.9, ncam)):
+        pos = radius * np.array([np.cos(elevation) * np.cos(a), np.cos(elevation) * np.sin(a), np.sin(elevation)])
+        fwd = -pos / np.linalg.norm(pos)
+        right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+        poses[i, :3, :3] = np.stack([right, np.cross(right, fwd), -fwd], axis=1)
+        poses[i, :3, 3], poses[i, 3, 3] = pos, 1.0
+    pls = (poses[:, :3, 3] * 1.2 + np.array([0.3, -0.2, 0.5])).astype(np.float32)
+    return poses, pls
+
+
+def camopt_legs(dev, batch=1024, steps=30, warm=3, view_steps=500, view_batch=512):
+    """The reference's DEFAULT preset, nr-hints-cam-opt (configs/main_config.py:60-64: RayGeneratorConfig(cam_opt_mode="SO3xR3")):
+      train_camopt   1024-pixel training steps that start at the data loader's RawPixelBundle - ray generation with per-view pose
+                     deltas, the fused step incl. the ray adjoints, the ray generator's adjoint, Adam over both parameter groups
+                     (trainer/trainer.py:99-102) - replayed as one hipGraph
+      register_view  what evaluation does per view under that preset (pipelines/base_pipeline.py:71-91, :103-106): 500 Adam steps
+                     of 512 random pixels on the view's pose delta with the renderer frozen; seconds per view"""
+    from nrhints_amd import RawPixelBundle, RayGenerator, RayGeneratorConfig
+    from nrhints_amd.pipeline import CameraModel
+    from nrhints_amd.training import GraphedTrainStep, register_view
     torch.manual_seed(0)
+    ncam, Hc, Wc = 12, 200, 200
+    cam = CameraModel(H=Hc, W=Wc, cx=Wc / 2, cy=Hc / 2, fx=280.0, fy=280.0)
+    poses, pls = orbit_views(ncam)
+    student = na.NeuSHintRenderer(na.NeuSModelConfig()).to(dev)
+    teacher, _ = build_scene(student.precision)
+    teacher = teacher.to(dev).eval()
+    bg = torch.ones(1, 3, device=dev)
+    rg_true = RayGenerator(cam, ncam, RayGeneratorConfig()).to(dev)
+    rs = np.random.RandomState(7)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def pixels(n, seed_rs, view=None):
+        img = seed_rs.randint(0, ncam, size=n) if view is None else np.full(n, view)
+        kw = dict(img_indices=cu(img[:, None].astype(np.int64)), h_indices=cu(seed_rs.randint(0, Hc, size=(n, 1)).astype(np.float32)),
+                  w_indices=cu(seed_rs.randint(0, Wc, size=(n, 1)).astype(np.float32)), poses=cu(poses[img]), pls=cu(pls[img]))
+        with torch.no_grad():      # ground-truth pixels are data: rendered before the timed region
+            gt = teacher(rg_true(RawPixelBundle(rgb_gt=None, **kw)), background_rgb=bg).rgb
+        return RawPixelBundle(rgb_gt=gt, **kw)
+
+    out = {}
+    # ---- training under cam-opt ----
+    rg = RayGenerator(cam, ncam, RayGeneratorConfig(cam_opt_mode="SO3xR3")).to(dev)
+    batches = [pixels(batch, rs) for _ in range(steps + warm)]
+    step = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000, ray_generator=rg, ray_lr=rg.config.opt_lr)
+    losses, t0 = [], None
+    for i, pb in enumerate(batches):
+        if i == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        losses.append(step(pb, pb.rgb_gt, global_step=20000 + i)["loss"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fused = bool(step._use_fused)
+    step.release()
+    out["train_camopt"] = {"metric": "training ray-steps/s under nr-hints-cam-opt (ray generation with pose deltas + forward + backward + ray "
+                                     "adjoints + Adam over both groups)", "value": round(batch * steps / dt, 1), "unit": "ray-steps/s",
+                           "batch_rays": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3), "views": ncam,
+                           "mode": "hipGraph replay of the " + ("fused (autograd-free) step" if fused else "autograd path"),
+                           "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
+                           "pose_delta_moved": float(rg.cam_pose_adjustment.detach().abs().max())}
+    # ---- register_view: one view, its pose perturbed by a known shift, 500 steps ----
+    model = teacher
+    rg2 = RayGenerator(cam, ncam, RayGeneratorConfig(cam_opt_mode="SO3xR3")).to(dev)
+    hh, ww = np.meshgrid(np.arange(Hc, dtype=np.float32), np.arange(Wc, dtype=np.float32), indexing="ij")
+    view = 3
+    with torch.no_grad():
+        full_true = RawPixelBundle(img_indices=torch.full((Hc * Wc, 1), view, dtype=torch.long, device=dev), h_indices=cu(hh.reshape(-1, 1)),
+                                   w_indices=cu(ww.reshape(-1, 1)), poses=cu(poses[view]).expand(Hc * Wc, 4, 4).contiguous(),
+                                   pls=cu(pls[view]).expand(Hc * Wc, 3).contiguous(), rgb_gt=None)
+        gt = model(rg_true(full_true), background_rgb=bg).rgb.reshape(Hc, Wc, 3).cpu()
+    shifted = poses[view].copy()
+    shifted[:3, 3] += np.array([0.05, -0.03, 0.04], dtype=np.float32)
+    img = RawPixelBundle(img_indices=torch.full((Hc, Wc, 1), view, dtype=torch.long), h_indices=torch.from_numpy(hh)[..., None],
+                         w_indices=torch.from_numpy(ww)[..., None], poses=torch.from_numpy(shifted).expand(Hc, Wc, 4, 4),
+                         pls=torch.from_numpy(pls[view]).expand(Hc, Wc, 3), rgb_gt=gt)
+    gen = torch.Generator().manual_seed(11)
+    register_view(model, rg2, img, dev, steps=20, batch_size=view_batch, lr=1e-3, generator=gen)      # warm-up: caches, pack plans
+    with torch.no_grad():
+        rg2.cam_pose_adjustment.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr = register_view(model, rg2, img, dev, steps=view_steps, batch_size=view_batch, lr=1e-3, generator=gen)
+    torch.cuda.synchronize()
+    dtv = time.perf_counter() - t0
+    out["register_view"] = {"metric": "seconds per registered view (500 pose-refinement steps of 512 pixels, renderer frozen)",
+                            "value": round(dtv, 3), "unit": "s/view", "higher_is_better": False, "steps": view_steps, "batch_rays": view_batch,
+                            "ms_per_step": round(dtv / view_steps * 1e3, 3), "loss_first10": round(float(np.mean(tr[:10])), 5),
+                            "loss_last10": round(float(np.mean(tr[-10:])), 5),
+                            "note": "excluded from rays/s (SURVEY 8d, config C4); the reference also computes and discards all 46 parameter "
+                                    "gradients in these steps - skipped here, results identical"}
+    return out
+
+
+def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch=None):
+    """BASELINE.json configs[2] (and [4] for N > 1): 1024-ray training steps of the reference-initialised student against
+    pixels of scene b (rendered before the timed region: ground-truth pixels are data).  ``global_batch``: the reference's DDP
+    semantics - the batch is split, per-rank = global // world (trainer/trainer.py:116-123) - instead of a fixed per-rank batch."""
+    from nrhints_amd.training import FlatGradAllReduce, GraphedTrainStep
+    torch.manual_seed(0)
+    if global_batch:
+        batch = max(16, global_batch // world)
     student = na.NeuSHintRenderer(na.NeuSModelConfig()).to(dev)
     teacher, _ = build_scene(student.precision)
     teacher = teacher.to(dev).eval()
@@ -198,17 +357,14 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
         rb = na.RayBundle(origins=o, directions=d, pl_positions=pl, nears=near, fars=far)
         with torch.no_grad():
             batches.append((rb, teacher(rb, background_rgb=bg).rgb))
-    graphed = None
-    if world == 1:
-        graphed = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000)
-        run = lambda i, rb, gt: graphed(rb, gt, global_step=20000 + i)
-    else:
-        opt, sched = make_optimizer(student, warm_up_end=10)
+    # one hipGraph per step at one rank; with more ranks two graphs around ONE flat RCCL all-reduce of the gradients
+    # (training.GraphedTrainStep: forward + loss + backward + flattening | all-reduce | unflatten + Adam)
+    sync = None
+    if world > 1:
         sync = FlatGradAllReduce(list(student.parameters()))
-        # eager steps without a per-step read-back: the host enqueues step i + 1 while step i runs (the losses are read after the
-        # timed region)
-        run = lambda i, rb, gt: train_step(student, rb, gt, bg, global_step=20000 + i, optimizer=opt, scheduler=sched, grad_sync=sync,
-                                           sync=False)
+        sync.broadcast_parameters(0)
+    graphed = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000, grad_sync=sync)
+    run = lambda i, rb, gt: graphed(rb, gt, global_step=20000 + i)
     losses = []
     t0 = None
     for i, (rb, gt) in enumerate(batches):
@@ -226,21 +382,18 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if graphed is not None:
-        graphed.release()
-    else:
-        from nrhints_amd.training import release_device_scalars
-        release_device_scalars(student)
+    graphed.release()
     losses = [float(x) for x in losses]
     value = world * batch * steps / dt
     peak = PEAK_TFLOPS[student.precision]
     return {"metric": "training ray-steps/s (forward + backward + Adam)", "value": round(value, 1), "unit": "ray-steps/s",
             "batch_rays_per_gpu": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
-            "dtype": student.precision, "mode": "hipGraph replay" if world == 1 else "eager + flat RCCL all-reduce",
+            "dtype": student.precision, "global_batch": batch * world,
+            "mode": "hipGraph replay" if world == 1 else "two hipGraphs around one flat RCCL all-reduce per step",
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
-            "bound_note": "the step's five big kernels (dW, SDF training forward, tangent / value sweeps, reflectance adjoint) are HBM-bound: "
-                          "4.1-5.0 TB/s = 0.5-0.6 of the 8 TB/s peak by the committed counters (profiles/r03/pmc_train_summary.txt, DESIGN 7b); "
-                          "the MFMA fraction below is the SURVEY 8d convention",
+            "bound_note": "the step's five big kernels (dW, SDF training forward, tangent / value sweeps, reflectance adjoint) are HBM-bound on "
+                          "the saved activations (profiles/r03/pmc_train_summary.txt, DESIGN 7b / 7c); the MFMA fraction below is the "
+                          "SURVEY 8d convention",
             "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
                          "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(value * FLOP_PER_RAY_STEP / 1e12 / world / peak, 4)}}
@@ -276,6 +429,11 @@ def main():
     ap.add_argument("--precision", choices=sorted(PEAK_TFLOPS), default=na.NeuSHintRenderer.precision)
     ap.add_argument("--no-train", action="store_true", help="skip the training leg (configs[2])")
     ap.add_argument("--no-secondary", action="store_true", help="skip the render in the other precision")
+    ap.add_argument("--no-camopt", action="store_true", help="skip the nr-hints-cam-opt legs (training under pose refinement, register_view)")
+    ap.add_argument("--train-batch-global", type=int, default=0,
+                    help="training leg with the reference's DDP semantics: this GLOBAL batch split over the ranks (per-rank = global // N, "
+                         "trainer/trainer.py:116-123) instead of 1024 rays per rank")
+    ap.add_argument("--pmc", action="store_true", help="collect roofline.traffic live (two rocprofv3 --pmc passes of one frame; +1-2 min)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -326,7 +484,7 @@ def main():
 
     def run_train_leg():
         try:
-            return train_leg(dev, rank, world, dist)
+            return train_leg(dev, rank, world, dist, global_batch=args.train_batch_global or None)
         except Exception as e:  # the headline must survive a failure of the secondary leg
             return {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -335,6 +493,12 @@ def main():
     # the leg starts and the leg's result follows as a second JSON line on stderr ({"train": ...}); nothing after the
     # headline can keep it from being printed.
     train = run_train_leg() if (not args.no_train and world == 1) else None
+    camopt = None
+    if rank == 0 and world == 1 and not args.no_train and not args.no_camopt:
+        try:
+            camopt = camopt_legs(dev)
+        except Exception as e:  # noqa: BLE001
+            camopt = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         work = 1 if strong else world                       # strong: the job is ONE frame however many ranks render it
@@ -343,7 +507,13 @@ def main():
         avg_ms = k_ms / launches
         achieved = FLOP_PER_POINT_CORE * pts_per_launch / (avg_ms * 1e-3) / 1e12
         wide = bool(getattr(model, "wide_kernels", False)) and args.precision == "f16x3"
-        traffic, traffic_src = pmc_traffic(args.precision, wide)
+        traffic, traffic_src, traffic_kind = pmc_traffic(args.precision, wide)
+        if args.pmc and world == 1 and not os.environ.get("NRH_BENCH_PMC_CHILD"):
+            live, how = pmc_live(args.precision, wide)
+            if live is not None:
+                traffic, traffic_src, traffic_kind = live, None, how
+            else:
+                traffic_kind += f" (live collection failed: {how})"
         line = {
             "metric": "rendered rays/sec (128 samples/ray)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -361,7 +531,11 @@ def main():
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                          "traffic_source": traffic_src,
-                         "traffic_kind": "static: newest committed rocprofv3 --pmc summary of this command (profiles/pmc_run.sh), not collected in this run", "algorithmic_bytes_per_launch": int(pts_per_launch * 1044),
+                         "traffic_kind": traffic_kind, "kernel_source_hash": kernel_source_hash(),
+                         # bytes the kernel's contract moves (features + sdf + gradient out, 1 044 B per point) and SURVEY 8(d)'s
+                         # algorithmic figure for the whole path (44 B in + 6 676 B out = 6 720 B per ray)
+                         "algorithmic_bytes_per_launch": int(pts_per_launch * 1044),
+                         "survey_8d_bytes_per_launch": int(pts_per_launch / 128 * 6720),
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
                          "algorithmic_flop_per_point": FLOP_PER_POINT_CORE},
         }
@@ -373,6 +547,8 @@ def main():
             line["rehearsal"] = True
         line["secondary"] = secondary
         line["train"] = train if world == 1 or args.no_train else "second JSON line on stderr (multi-rank run)"
+        if camopt is not None:
+            line.update(camopt)
         print(json.dumps(line), flush=True)
     if world > 1 and not args.no_train:
         train = run_train_leg()

@@ -15,4 +15,6 @@ run tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 python $GRAFT_REPO_ROOT/profiles/pmc_summarize.py $OUT > $OUT/summary.txt 2>&1
+# which kernels these counters belong to (bench.py quotes the summary only while this matches its own hash of the kernel sources)
+( cd $GRAFT_REPO_ROOT && python -c "import bench; print('source_hash', bench.kernel_source_hash())" ) >> $OUT/summary.txt 2>/dev/null
 cat $OUT/summary.txt
