@@ -475,11 +475,14 @@ def register_view(renderer, ray_generator, img_pixel_bundle, device, steps: int 
                 from .adam import HipAdam
                 optimizer = HipAdam(rg_params, lr=lr)
                 dev_losses = []
+                # the view's pixels move to the device ONCE (27 floats per pixel); a batch is then a gather on the GPU.  The pixel
+                # indices keep upstream's host-side draws (same generator, same order: h then w)
+                img_dev = img_pixel_bundle.to(device)
                 with torch.enable_grad():
                     for i in range(steps):
                         hi = torch.randint(0, H, (batch_size,), device="cpu", generator=generator)
                         wi = torch.randint(0, W, (batch_size,), device="cpu", generator=generator)
-                        pb = img_pixel_bundle[hi, wi].to(device)
+                        pb = img_dev[hi.to(device, non_blocking=True), wi.to(device, non_blocking=True)]
                         optimizer.zero_grad(set_to_none=True)
                         # evaluation-mode forward + L1 loss / (N + 1e-5) + the ray adjoints as one fixed sequence of HIP launches
                         # (no weight gradients, no autograd inside the renderer); its backward continues into the ray generator
