@@ -60,7 +60,7 @@ def supported(renderer, ray_bundle) -> Optional[str]:
 class _Buffers:
     """Per-(device, rays) arrays of a step, allocated once and reused (a captured graph bakes their addresses in)."""
 
-    def __init__(self, dev, n: int, hints: bool, shapes: Dict[str, tuple]):
+    def __init__(self, dev, n: int, hints: bool, shapes: Dict[str, tuple], param_layout: Dict[str, tuple]):
         T, P = 128, n * 128
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.n, self.dev = n, dev
@@ -72,19 +72,30 @@ class _Buffers:
         self.czbar, self.fbar, self.mbar = new(4, P, 256), new(P, 256), new(P, mw)
         self.sdf_bar, self.grad_bar, self.rd_bar, self.invs_bar = new(P), new(P, 3), new(n, 3), new(n)
         self.emb = new(P, 64)
-        self.var_bar = new(1)
         self.o_bar, self.d_bar, self.pl_bar = new(n, 3), new(n, 3), new(n, 3)      # ray adjoints (pose / light refinement)
+        # What .grad of the 46 parameter tensors points at: views into ONE flat float32 buffer, laid out in the order of
+        # renderer.parameters() (``param_layout``: name -> (offset, shape)).  The kernels that produce parameter gradients write
+        # straight into it - the weight-norm adjoint (weight_v / weight_g), the weight-gradient reduction's column sums (biases),
+        # nrh_variance_grad - so a data-parallel step all-reduces this buffer IN PLACE (training.FlatGradAllReduce finds it through
+        # the views' ``_nrh_flat`` tag: no pack / unpack copies) and an optimiser working from a pointer table (adam.HipAdam) never
+        # sees a new address.
+        self.flat = torch.zeros(sum(int(torch.Size(shp).numel()) for _, (_, shp) in param_layout.items()), dtype=torch.float32, device=dev)
+        self.pgrad = {}
+        for name, (off, shp) in param_layout.items():
+            v = self.flat[off: off + int(torch.Size(shp).numel())].view(shp)
+            v._nrh_flat = (self.flat, off)
+            self.pgrad[name] = v
         g = {}
-        for l in range(8):
-            g[f"dW{l}"], g[f"db{l}"] = new(*shapes[f"sdf_w{l}"]), new(*shapes[f"sdf_b{l}"])
-        g["ws"], g["bs"], g["Wf"], g["bf"] = new(1, 256), new(1), new(256, 256), new(256)
+        for l in range(8):     # dense (folded) weight gradients are intermediates; the bias gradients are final
+            g[f"dW{l}"], g[f"db{l}"] = new(*shapes[f"sdf_w{l}"]), self.pgrad[f"sdf_network.lin{l}.bias"].view(-1)
+        g["ws"], g["bs"] = new(1, 256), self.pgrad["sdf_network.out_sdf.bias"].view(-1)
+        g["Wf"], g["bf"] = new(256, 256), self.pgrad["sdf_network.out_feat.bias"].view(-1)
         for l in range(5):
-            g[f"w{l}"], g[f"b{l}"] = new(*shapes[f"col_w{l}"]), new(*shapes[f"col_b{l}"])
+            g[f"w{l}"], g[f"b{l}"] = new(*shapes[f"col_w{l}"]), self.pgrad[f"color_network.lin{l}.bias"].view(-1)
         self.g = g
-        # weight-norm gradients (what .grad of weight_v / weight_g points at): persistent like the bias gradients above, so that
-        # an optimiser working from a pointer table (adam.HipAdam) never sees a new address
-        self.vbars = {k: new(*s) for k, s in shapes.items() if k.startswith("v:")}
-        self.gbars = {k: new(*s) for k, s in shapes.items() if k.startswith("g:")}
+        self.vbars = {"v:" + k: self.pgrad[k + ".weight_v"] for k in packing._FOLD_LAYERS}
+        self.gbars = {"g:" + k: self.pgrad[k + ".weight_g"] for k in packing._FOLD_LAYERS}
+        self.var_bar = self.pgrad["deviation_network.variance"].view(1)
 
 
 def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_rgb: Optional[torch.Tensor], global_step: int,
@@ -147,7 +158,11 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             shapes = {k: tuple(v.shape) for k, v in dense.items()}
             shapes.update({"v:" + k: tuple(v.shape) for k, v in zip(packing._FOLD_LAYERS, vs)})
             shapes.update({"g:" + k: tuple(x.shape) for k, x in zip(packing._FOLD_LAYERS, gs)})
-            B = cache[key] = _Buffers(dev, n, hints, shapes)
+            layout, off = {}, 0
+            for pname, prm in renderer.named_parameters():
+                layout[pname] = (off, tuple(prm.shape))
+                off += prm.numel()
+            B = cache[key] = _Buffers(dev, n, hints, shapes, layout)
         # ---- no-grad stages + SDF training forward (one C call) ----
         res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc)
         pre, sv = res["pre"], res["pre"]["saves"]
@@ -205,10 +220,8 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         gbars = [B.gbars["g:" + k] for k in packing._FOLD_LAYERS]
         packing.WeightNormFoldHip._call("nrh_weight_norm_fold_backward", vs, gs, wbars, vbars, gbars)
         # (the bias / variance gradients ARE the persistent buffers: like backward() after zero_grad(), every call overwrites them)
-        for k, vb, gb, bb in zip(packing._FOLD_LAYERS, vbars, gbars, bbars):
-            named[k + ".weight_v"].grad, named[k + ".weight_g"].grad = vb, gb
-            named[k + ".bias"].grad = bb.view(named[k + ".bias"].shape)
-        named["deviation_network.variance"].grad = B.var_bar.view(())
+        for pname, prm in named.items():
+            prm.grad = B.pgrad[pname]
         return _finish_rays(B, ray_bundle, want_rays, ray_grads)
 
 

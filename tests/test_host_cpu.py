@@ -70,6 +70,12 @@ def test_unsupported_configs_are_rejected():
         with pytest.raises(ValueError):
             na.NeuSHintRenderer(cfg)
     assert na.unsupported_reason(na.NeuSModelConfig()) is None
+    # the renderer's two free scalars are kernel constants (NrhNet.custom_consts), not shapes: any sane value is accepted ...
+    rc = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(specular_roughness=[0.03, 0.08, 0.2, 0.5], shadow_ray_offset=3e-2)))
+    assert rc._net_consts == ([0.03, 0.08, 0.2, 0.5], 3e-2) and na.NeuSHintRenderer()._net_consts is None
+    # ... but the NUMBER of roughness values sizes the reflectance net's first layer
+    assert na.unsupported_reason(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(specular_roughness=[0.1, 0.2])))
+    assert na.unsupported_reason(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_ray_offset=1.5)))
     # the pl-naive preset and the cheap off-default branches are supported
     naive = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False)))
     assert naive.color_network.lin0.weight_v.shape == (256, 316) and sum(p.numel() for p in naive.parameters()) == 820_923 - 256 * 45
@@ -288,6 +294,23 @@ def test_marching_tetrahedra_sphere_is_a_closed_oriented_manifold():
     assert abs(((a - c) * np.cross(b - c, d - c)).sum() / 6 - 4 / 3 * np.pi * rad ** 3) < 0.01 * 4 / 3 * np.pi * rad ** 3
     v0, f0 = marching_tetrahedra(u - 10.0, 0.0)
     assert v0.shape == (0, 3) and f0.shape == (0, 3)
+
+
+def test_ray_generator_validates_view_indices():
+    """the HIP ray generator no longer checks view indices per batch (no host sync in training); the reference raises
+    IndexError when it indexes its delta tables with a bad index, so the first bundle / the data loader's index tensor is checked."""
+    from nrhints_amd import RayGenerator, RayGeneratorConfig
+    from nrhints_amd.pipeline import CameraModel
+    cam = CameraModel(H=8, W=8, cx=4.0, cy=4.0, fx=10.0, fy=10.0)
+    rg = RayGenerator(cam, 5, RayGeneratorConfig(cam_opt_mode="SO3xR3", pl_opt=True))
+    assert rg.num_views() == 5
+    rg.validate_view_indices(torch.tensor([[0], [4], [2]]))
+    for bad in ([[0], [5]], [[-1], [2]]):
+        with pytest.raises(IndexError):
+            rg.validate_view_indices(torch.tensor(bad))
+    plain = RayGenerator(cam, 5, RayGeneratorConfig())
+    assert plain.num_views() == 0
+    plain.validate_view_indices(torch.tensor([[99]]))       # nothing to index: as the reference, which never touches a table then
 
 
 def test_integration_md_matches_the_binding():

@@ -115,6 +115,46 @@ def test_flat_grad_allreduce_two_ranks(tmp_path):
     np.testing.assert_allclose(g0, ref, rtol=1e-5, atol=1e-7)
 
 
+def _worker_zero_copy(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # gradients laid out as the fused training step leaves them: views of ONE flat buffer in parameter order, tagged
+        params = [nn.Parameter(torch.zeros(4, 3)), nn.Parameter(torch.zeros(5)), nn.Parameter(torch.zeros(()))]
+        flat = torch.arange(18, dtype=torch.float32) * (rank + 1)
+        off = 0
+        for p in params:
+            v = flat[off: off + p.numel()].view(p.shape)
+            v._nrh_flat = (flat, off)
+            p.grad = v
+            off += p.numel()
+        ptrs = [p.grad.data_ptr() for p in params]
+        sync = FlatGradAllReduce(params)
+        sync()
+        assert sync._in_place and sync._flat is flat                       # no staging buffer, no copies
+        assert [p.grad.data_ptr() for p in params] == ptrs
+        np.save(os.path.join(out_dir, f"z{rank}.npy"), flat.numpy())
+        # a gradient that is NOT part of the buffer falls back to the copying form
+        params[1].grad = params[1].grad.clone()
+        sync2 = FlatGradAllReduce(params)
+        sync2()
+        assert not sync2._in_place
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_zero_copy_two_ranks(tmp_path):
+    """when every .grad is a view of one flat buffer (train_fused._Buffers) the exchange is the all-reduce of
+    that buffer in place - pack() and unpack() copy nothing."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_zero_copy, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z0, z1 = np.load(tmp_path / "z0.npy"), np.load(tmp_path / "z1.npy")
+    np.testing.assert_array_equal(z0, z1)
+    np.testing.assert_allclose(z0, np.arange(18, dtype=np.float32) * 1.5)      # mean of x1 and x2
+
+
 def test_checkpoint_roundtrip_reference_layout(tmp_path, scene_states):
     from nrhints_amd.training import load_checkpoint, save_checkpoint
     m = na.NeuSHintRenderer()
