@@ -380,10 +380,15 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    analytic_normal=False, depth_max_weight=False, geometry_warmup_end=0,
                    depth_sphere_tracing=False, shadow_hint=None, specular_hint=None, shadow_hint_gradient=False,
                    specular_hint_gradient=False, n_shadow_importance_clip=-1, n_importance_samples=64, outside_nerf=None,
-                   t_rand_outside=None, specular_roughness=SPEC_ROUGHNESS, shadow_ray_offset=1e-2) -> Dict[str, torch.Tensor]:
+                   t_rand_outside=None, specular_roughness=SPEC_ROUGHNESS, shadow_ray_offset=1e-2, z_override=None,
+                   vis_groups_override=None, cue_override=None) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
-    both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619)."""
+    both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619).
+    ``z_override`` [N,128] / ``vis_groups_override`` [N,clip] / ``cue_override`` [N,4]: test hooks that replace the three
+    NON-differentiable products of the forward (sample positions :697, partial visibility hint :553-575, specular cue :589) by
+    values recorded elsewhere (the HIP path's own), so that a gradient comparison isolates the arithmetic of the differentiable
+    part from where the samplers happened to place their samples."""
     n = o.shape[0]
     dt = o.dtype
     cos_anneal = 1.0
@@ -397,7 +402,9 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     z = near + (far - near) * torch.linspace(0.0, 1.0, 64).to(dt)[None, :]
     if is_training:
         z = z + (t_rand_primary - 0.5) * 2.0 / 64              # :681-683
-    if n_importance_samples > 0:                              # :696 (n_importance_samples = 0: the coarse samples are final)
+    if z_override is not None:
+        z = z_override.to(dt)
+    elif n_importance_samples > 0:                            # :696 (n_importance_samples = 0: the coarse samples are final)
         with torch.no_grad():
             z = hierarchical_z(p, o, d, z, full_forward=(mode == "as_written"))  # :696-713
     T = z.shape[1]
@@ -444,7 +451,10 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
             zt = z[:, torch.arange(0, T, ratio)]
             tgt = (o[:, None, :] + d[:, None, :] * zt[..., None]).reshape(-1, 3)
             pls_g = pl[:, None, :].repeat(1, clip, 1).reshape(-1, 3)
-            vg = visibility(p, pls_g, tgt, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode).reshape(n, clip, 1)
+            if vis_groups_override is not None:
+                vg = vis_groups_override.to(dt).reshape(n, clip, 1)
+            else:
+                vg = visibility(p, pls_g, tgt, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode).reshape(n, clip, 1)
             vis_samples = vg.repeat_interleave(ratio, dim=1)                               # [n,128,1]
             vis = torch.gather(vis_samples[..., 0], 1, torch.argmax(weights, dim=1, keepdim=True))   # shadow_map (:573-574)
         elif not (shadow_hint and shadow_hint_gradient and differentiable):
@@ -460,6 +470,8 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     if specular_hint:
         with torch.enable_grad() if (specular_hint_gradient and differentiable) else torch.no_grad():   # :589
             cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d, specular_roughness)   # :590-615, :617-619
+            if cue_override is not None:
+                cue = cue_override.to(dt)
         cue_s = cue[:, None, :].expand(n, T, 4).reshape(-1, 4)
     col = color_forward(p, pts, grad if analytic_normal else n_hat, dirs, feat, pls, vis_s, cue_s).reshape(n, T, 3)  # :621-626
     if bg_col is not None:                                     # :630-633

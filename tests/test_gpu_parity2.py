@@ -516,8 +516,12 @@ def test_graph_with_ray_generator_group(scene_states, refine):
             assert float((a.grad - b.grad).abs().max()) <= (1e-4 if i == 0 else 5e-3) * scale, (i, k)
             assert float((a.detach() - b.detach()).abs().max()) <= 5e-6, (i, k)
         if refine:
+            # Adam normalises every entry's step to ~lr whatever its gradient's size, so where the gradient is at round-off level
+            # (|g| ~ eps) the fused and the autograd run may step differently by up to 2 lr; everywhere else they agree
             for (k, a), (_, b) in zip(graphed.named_parameters(), eager.named_parameters()):
-                assert float((a.detach() - b.detach()).abs().max()) <= 5e-6, (i, k)
+                dpar = (a.detach() - b.detach()).abs()
+                assert float(dpar.max()) <= 2.0 * lr * f + 1e-7, (i, k)
+                assert float((dpar > 5e-6).float().mean()) <= 2e-3, (i, k, float((dpar > 5e-6).float().mean()))
     if refine:
         assert float(rg_g.cam_pose_adjustment.grad.abs().max()) > 0 and float(rg_g.pl_adjustment.grad.abs().max()) > 0
         moved = float((rg_g.pl_adjustment.detach() - T(np.random.RandomState(2).randn(ncam, 3).astype(np.float32)).cuda() * 0.02).abs().max())
@@ -770,8 +774,8 @@ def test_partial_visibility_hint(scene_states, prec):
         # torch on the CPU) moves single group visibilities by 1e-3 (the evaluation check above allows that) and, through the
         # reflectance net, the parameter gradients by up to a few per cent of their scale - far more than the reference's own
         # float32-vs-float64 distance happens to be on this draw (measured: up to 3.4 % of the tensor's scale in f32 mode, 9.8 % in
-        # f16x3 mode on the first reflectance layer).  Hence a direction + magnitude check instead of grad_bound; the forward of the
-        # same step (rgb to 1e-4, loss to 2e-4 relative) is checked above.
+        # f16x3 mode on the first reflectance layer).  Hence a direction + magnitude check against the REFERENCE's record here; the
+        # arithmetic itself is held to a float32 bound right below, against the oracle evaluated on this path's own sample placement.
         got = named[name].grad.detach().cpu().numpy().astype(np.float64)
         scale = max(float(np.abs(want64).max()), 1e-30)
         err = float(np.abs(got - want64).max())
@@ -779,6 +783,31 @@ def test_partial_visibility_hint(scene_states, prec):
         if got.size > 1:
             cos = float((got * want64).sum() / (np.linalg.norm(got) * np.linalg.norm(want64) + 1e-300))
             assert cos > 0.995, (name, cos)
+    # ... and the same gradients with PLACEMENT taken out of the comparison: the oracle in float64 on the HIP
+    # path's own non-differentiable products - sample positions, group visibilities, cue (the reference keeps all three outside
+    # its graph, :697, :553-575, :589) - differentiates exactly what the HIP backward differentiated, so the bound goes back to a
+    # float32-arithmetic one: 3e-4 of the tensor's scale (the default model's training fixtures sit at 1e-4 ... 3e-4 by grad_bound)
+    f32 = lambda t: t.detach().float().contiguous()
+    res = model._render_train(f32(tb.origins), f32(tb.directions), f32(tb.pl_positions), f32(tb.nears).reshape(-1), f32(tb.fars).reshape(-1),
+                              min(1.0, int(g["t.global_step"]) / model.config.anneal_end), cu(g["psh.t_rand_primary"]).reshape(-1),
+                              cu(g["psh.t_rand_shadow"]), 0)
+    n = tb.origins.shape[0]
+    mid, dist = res["mid_z"].double().cpu(), res["dists"].double().cpu()
+    z_hip = mid - 0.5 * dist
+    leaves = {k: T(np.asarray(v)).double().clone().requires_grad_(True) for k, v in scene_states["b"].items()}
+    o64 = orc.render_forward(orc.params_from_state(leaves, torch.float64), *(T(g["t." + k]).double() for k in ("o", "d", "pl", "near", "far")),
+                             background_rgb=torch.ones(1, 3, dtype=torch.float64), is_training=True, global_step=int(g["t.global_step"]),
+                             t_rand_primary=T(g["psh.t_rand_primary"]).double(), t_rand_shadow=T(g["psh.t_rand_shadow"]).double(),
+                             mode="as_written", differentiable=True, n_shadow_importance_clip=8, z_override=z_hip,
+                             vis_groups_override=res["vis_groups"].double().cpu().reshape(n, 8), cue_override=res["cue"][:, 0, :].double().cpu())
+    np.testing.assert_allclose(o.rgb.detach().cpu().numpy(), o64["rgb"].detach().numpy(), rtol=0, atol=2e-5)
+    loss64, _, _ = orc.train_loss(o64, T(g["t.rgb_gt"]).double())
+    loss64.backward()
+    for name, prm in named.items():
+        want = leaves[name].grad.numpy()
+        scale = max(float(np.abs(want).max()), 1e-30)
+        err = float(np.abs(prm.grad.detach().cpu().numpy().astype(np.float64) - want).max())
+        assert err <= 3e-4 * scale, ("placement-free", name, err / scale)
     with pytest.raises(ValueError):
         na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=3)))
 
