@@ -39,7 +39,7 @@ struct Sdf32Args {
   // MODE 4 (training forward): `feat` is the row-major feature [npts][256]; what the hand-derived backward needs, row-major
   // float32 like the 16-point training kernel writes them (csrc/nrh_sdf.hip MODE 3: same contract, same consumers)
   float* save_h;        // [8][npts][256]  h_l = softplus(z_l) (layer 3: columns 217.. hold the embedding, i.e. x_4)
-  float* save_s1;       // [8][npts][256]  sigma'_l (0 on the substituted entries of layer 3)
+  float* save_s1;       // optional [8][npts][256]  sigma'_l (0 on the substituted entries of layer 3); null: not written
   float* save_t;        // [8][npts][256]  t_l = sigma'_l * a_{l+1}  (t_7 = sigma'_7 w_s / 3)
   float* save_ge;       // [npts][128]     columns e: a_0[e]; columns 73 + e: a_4[217 + e]  (e < 39)
 };
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W32_SSAVE(c, g2, part, val) do { } while (0)
 #define W32_SSAVE_P(c, g2, part, val) do { } while (0)
 #else
-#define W32_SSAVE(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer, c, g2, part, val)
-#define W32_SSAVE_P(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer - 1, c, g2, part, val)
+#define W32_SSAVE(c, g2, part, val) do { if (a.save_s1) W32_ROWST_(a.save_s1, qlayer, c, g2, part, val); } while (0)      // (optional array)
+#define W32_SSAVE_P(c, g2, part, val) do { if (a.save_s1) W32_ROWST_(a.save_s1, qlayer - 1, c, g2, part, val); } while (0)
 #endif
     // ---- L0 ----
     {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
               const float v = emb_entry(x3, 2 * m, 2 * m + 1, hf);
               if (2 * m + hf < 39) {
                 *(gf_p)(rows_at(a.save_h, 3) + r0 + (2 * m + hf) * 4) = v;
-                *(gf_p)(rows_at(a.save_s1, 3) + r0 + (2 * m + hf) * 4) = 0.0f;
+                if (a.save_s1) *(gf_p)(rows_at(a.save_s1, 3) + r0 + (2 * m + hf) * 4) = 0.0f;
               }
               if (m & 1) __builtin_amdgcn_sched_barrier(0);
             }
