@@ -12,8 +12,8 @@ g with ``autograd.grad(create_graph=True)`` and lets autograd differentiate that
       * two plain GEMMs per layer for the weights:   dW_l = zbar_l^T x_l + t_l^T abar_l        (t_l = s'_l * a_{l+1})
 
 with s' = sigmoid(100 z), s'' = 100 s'(1 - s'), a_l the reverse-chain values of the forward pass.  Forward and both sweeps
-are the HIP register-chain kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are rocBLAS
-GEMMs over the saved row-major arrays.  The same maths in plain torch ops - the reference the kernels are tested against -
+are the HIP register-chain kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are one split-K
+bf16x3 MFMA launch over the saved row-major arrays (csrc/nrh_dw.hip through nrhints_amd/dw.py; no library GEMM).  The same maths in plain torch ops - the reference the kernels are tested against -
 lives with the tests (tests/torch_backends.py), not in the product.
 """
 from __future__ import annotations
@@ -58,7 +58,7 @@ def _scatter_dims(v: torch.Tensor, dim: torch.Tensor = None) -> torch.Tensor:
 
 class SdfValueFeatGradHip(torch.autograd.Function):
     """Same contract as ``SdfValueFeatGrad`` with the forward and both backward sweeps in the HIP register-chain
-    kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are rocBLAS GEMMs over the saved
+    kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are jobs of nrh_dw_gemm over the saved
     row-major arrays.  ``packed``: dict(sdf_w, sdf_b, sdf_head, sdf_wt_feat) packed from the SAME dense weights."""
 
     @staticmethod
