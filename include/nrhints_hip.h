@@ -90,8 +90,7 @@ long long nrh_sdf_wide_stream_bytes(void);
  *
  * nrh_sdf_train_forward: as nrh_sdf_eval mode 2 (sdf [npts], grad [npts,3]) with the feature ROW-MAJOR feat_rows
  *   [npts,256], plus  save_h [8][npts][256] (softplus outputs; layer 3 already holds the skip concatenation),
- *   save_s1 [8][npts][256] (sigmoid(100 z); OPTIONAL since ABI 136, may be NULL: every consumer recovers sigma' = 1 - exp(-100 h)
- *   from save_h, which saves 1 KiB per point and layer), save_t [8][npts][256] (reverse-chain stage inputs),
+ *   save_s1 [8][npts][256] (sigmoid(100 z)), save_t [8][npts][256] (reverse-chain stage inputs),
  *   save_ge [npts][128] (cols 0..38: d sdf/d embedding via layer 0; cols 73..111: via the skip connection).
  * nrh_sdf_train_backward: given the adjoints  sbar [npts], fbar [npts,256], gbar [npts,3]  of the three outputs
  *   writes  abar, coup, zbar [8][npts][256], gebar [npts][64] and pbar [npts,3] (adjoint of the points through the
@@ -109,7 +108,7 @@ int nrh_sdf_train_forward_wide(const void* sdf_w32, const float* sdf_tab32, cons
                                float* save_s1, float* save_t, float* save_ge, float* scratch, void* stream);
 int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
                            const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
-                           const float* save_h, const float* save_t, const float* gbar, const float* fbar,
+                           const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            void* stream);
 
@@ -288,7 +287,7 @@ typedef struct NrhTrainSaves {
   float* sdf;        /* [nrays,128]        sdf at the section mid-points */
   float* feat_rows;  /* [nrays*128,256]    row-major feature */
   float* save_h;     /* [8][nrays*128][256] */
-  float* save_s1;    /* optional [8][nrays*128][256] (NULL: not written; unused by nrh_sdf_train_backward since ABI 136) */
+  float* save_s1;    /* [8][nrays*128][256] */
   float* save_t;     /* [8][nrays*128][256] */
   float* save_ge;    /* [nrays*128][128] */
   float* raymisc;    /* optional [nrays,100]: the reflectance net's per-ray encodings enc4(view) | enc4(pl) | enc4(vis) | enc4(cue)

@@ -291,7 +291,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 136; }
+int nrh_version(void) { return 137; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -359,8 +359,8 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
                           float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
                           void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: precision must be 0 (f32) or 1 (f16x3)%s", "");
-  if (!sdf_w || !sdf_b || !sdf_head || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_t || !save_ge)
-    return fail(NRH_E_INVALID, "nrh_sdf_train_forward: null pointer%s", "");      // (save_s1 is optional)
+  if (!sdf_w || !sdf_b || !sdf_head || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_s1 || !save_t || !save_ge)
+    return fail(NRH_E_INVALID, "nrh_sdf_train_forward: null pointer%s", "");
   if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: bad n_per_ray/stride%s", "");
   if ((nrays * n_per_ray) % 16 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: the number of points must be a multiple of 16%s", "");
   if (nrays == 0) return NRH_OK;
@@ -386,7 +386,7 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
 int nrh_sdf_train_forward_wide(const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
                                int t_stride, int n_per_ray, long long nrays, float* sdf, float* grad, float* feat_rows, float* save_h,
                                float* save_s1, float* save_t, float* save_ge, float* scratch, void* stream) {
-  if (!sdf_w32 || !sdf_tab32 || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_t || !save_ge || !scratch)
+  if (!sdf_w32 || !sdf_tab32 || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_s1 || !save_t || !save_ge || !scratch)
     return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: null pointer%s", "");
   if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: bad n_per_ray/stride%s", "");
   if ((nrays * n_per_ray) % 32 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: the number of points must be a multiple of 32%s", "");
@@ -405,11 +405,11 @@ int nrh_sdf_train_forward_wide(const void* sdf_w32, const float* sdf_tab32, cons
 
 int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
                            const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
-                           const float* save_h, const float* save_t, const float* gbar, const float* fbar,
+                           const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
-  if (!sdf_w || !wt_feat || !sdf_head || !ro || !rd || !t || !save_h || !save_t || !gbar || !fbar || !sbar || !abar || !coup ||
+  if (!sdf_w || !wt_feat || !sdf_head || !ro || !rd || !t || !save_s1 || !save_t || !gbar || !fbar || !sbar || !abar || !coup ||
       !gebar || !zbar || !pbar)
     return fail(NRH_E_INVALID, "nrh_sdf_train_backward: null pointer%s", "");
   if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: bad n_per_ray/stride%s", "");
@@ -419,7 +419,7 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   if (rc) return rc;
   nrh::SdfTrainArgs a;
   memset(&a, 0, sizeof(a));
-  a.w = sdf_w; a.wt_feat = wt_feat; a.head = sdf_head; a.ro = ro; a.rd = rd; a.t = t; a.hh = save_h; a.tt = save_t;
+  a.w = sdf_w; a.wt_feat = wt_feat; a.head = sdf_head; a.ro = ro; a.rd = rd; a.t = t; a.s1 = save_s1; a.tt = save_t;
   a.gbar = gbar; a.abar = abar; a.coup = coup; a.gebar = gebar; a.fbar = fbar; a.sbar = sbar; a.zbar = zbar; a.pbar = pbar;
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride;
@@ -1129,7 +1129,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   const int clip = (!no_hints && net->shadow_clip > 0) ? net->shadow_clip : 0;
   if (!origins || !directions || !pl_positions || !nears || !fars || !lin64 || !lin16 || (!rgb && !train) || !workspace)
     return fail(NRH_E_INVALID, "nrh_render_forward: null pointer%s", "");
-  if (train && (!train->sdf || !train->feat_rows || !train->save_h || !train->save_t || !train->save_ge))
+  if (train && (!train->sdf || !train->feat_rows || !train->save_h || !train->save_s1 || !train->save_t || !train->save_ge))
     return fail(NRH_E_INVALID, "nrh_render_forward_train: null pointer in NrhTrainSaves%s", "");
   if (nrays < 0 || nrays > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_render_forward: nrays out of range (chunk the call)%s", "");
   if (nrays == 0) return NRH_OK;

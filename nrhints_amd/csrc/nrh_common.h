@@ -112,19 +112,6 @@ __device__ __forceinline__ void softplus100_4(const f32x4 z, f32x4& h, f32x4& d)
 #endif
 }
 
-// sigma'(z) = sigmoid(100 z) recovered from h = softplus_100(z):  sigma' = 1 - exp(-100 h)  (1 + e^{100 z} = e^{100 h}).  The
-// training sweeps read h anyway (it is the weight gradients' operand), so sigma' is not stored a second time (1 KiB per point
-// and layer).  Four VALU operations: the subtraction cancels for tiny sigma', i.e. the ABSOLUTE error is one ulp of 1 (6e-8; the
-// forward's own e / (1 + e) has 1e-7 against float64, checked in numpy) - and only absolute accuracy matters for a factor that
-// multiplies O(1) adjoints (a series for small arguments was measured: +0.16 ms on the tangent sweep, no accuracy anyone can see).
-// Entries that do not come from a softplus (the embedding in columns 217.. of layer 3) are masked by the callers; h < 0 reads as 0.
-__device__ __forceinline__ float sigp_from_h(float h) {
-  return 1.0f - __builtin_amdgcn_exp2f(fmaxf(h, 0.0f) * -144.26950408889634074f);
-}
-__device__ __forceinline__ f32x4 sigp_from_h4(const f32x4 h) {
-  return f32x4{sigp_from_h(h[0]), sigp_from_h(h[1]), sigp_from_h(h[2]), sigp_from_h(h[3])};
-}
-
 // sin for |x| up to a few 1e3: 3-term Cody-Waite reduction by pi/2 (fma) + cephes minimax kernels on
 // [-pi/4, pi/4]; <= 2 ulp.  libm sinf drags a Payne-Hanek slow path (scratch memory, ~150 instructions
 // inlined per call site) into every encoding entry.

@@ -35,8 +35,7 @@ struct SdfArgs {
   float* scratch;      // gridDim.x * WG_WAVES * SDF_SCRATCH_FLOATS_PER_WAVE (MODE 1, 2)
   // MODE 3 (training forward): what the hand-derived backward needs, row-major so that library GEMMs can read it
   float* save_h;       // [8][npts][256]  h_l = softplus(z_l) (layer 3: after the skip substitution, i.e. x_4)
-  float* save_s1;      // optional [8][npts][256]  sigma'_l = sigmoid(100 z_l) (0 on substituted entries); null: not written - every
-                       // consumer (this kernel's reverse chain, the two sweeps) recovers it from save_h
+  float* save_s1;      // [8][npts][256]  sigma'_l = sigmoid(100 z_l) (0 on substituted entries); replaces the scratch
   float* save_t;       // [8][npts][256]  t_l = sigma'_l * a_{l+1}, the reverse-chain stage inputs (t_7 = sigma'_7 w_s/3)
   float* save_ge;      // [npts][128]     cols 0..63 a_0 (39 used), cols 64..111 = a_4[208..255] (skip part from col 73)
   long long npts;
@@ -131,8 +130,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     const long long row = tile_ok ? tile * TILE_PTS + j : j;
     auto ds_store = [&](int l, int ch, const f32x4 d0, const f32x4 d1) {
       if constexpr (TRAIN) {
-        // (optional since round 4: the sweeps recover sigma' from save_h - sigp_from_h - so the product path passes no save_s1)
-        if (tile_ok && a.save_s1) {
+        if (tile_ok) {
           st_stream(reinterpret_cast<f32x4*>(rm_ptr(a.save_s1, l, a.npts, row, 2 * ch, q)), d0);
           st_stream(reinterpret_cast<f32x4*>(rm_ptr(a.save_s1, l, a.npts, row, 2 * ch + 1, q)), d1);
         }
@@ -236,9 +234,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         } else if (MODE >= 1) {
           // sigma' of the layer this stage's output feeds
           if constexpr (TRAIN) {
-            // sigma' of layer 16 - s - 1 from this wave's own rows of h (written stages ago by the same lanes)
-            p.a0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_h, 16 - s - 1, a.npts, row, 2 * ch, q)));
-            p.a1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_h, 16 - s - 1, a.npts, row, 2 * ch + 1, q)));
+            p.a0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch, q)));
+            p.a1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch + 1, q)));
           } else {
             dsig_issue<PREC>(scr, 16 - s - 1, ch, lane, p);
           }
@@ -306,15 +303,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             }
             f32x4 d0, d1;
             if constexpr (TRAIN) {
-              d0 = sigp_from_h4(p.a0);
-              d1 = sigp_from_h4(p.a1);
-              if (l - 1 == 3 && ch >= 6) {     // the substituted entries of layer 3 hold the embedding: no softplus, sigma' = 0
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  if (ch == 7) d0[r] = 0.0f;
-                  if ((2 * ch + 1) * 16 + 4 * q + r - 217 >= 0) d1[r] = 0.0f;
-                }
-              }
+              d0 = p.a0;
+              d1 = p.a1;
               save_rows(a.save_t, l - 1, ch, acc0 * d0, acc1 * d1);
             } else {
               dsig_decode<PREC>(p, d0, d1);

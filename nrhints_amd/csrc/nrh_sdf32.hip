@@ -39,7 +39,7 @@ struct Sdf32Args {
   // MODE 4 (training forward): `feat` is the row-major feature [npts][256]; what the hand-derived backward needs, row-major
   // float32 like the 16-point training kernel writes them (csrc/nrh_sdf.hip MODE 3: same contract, same consumers)
   float* save_h;        // [8][npts][256]  h_l = softplus(z_l) (layer 3: columns 217.. hold the embedding, i.e. x_4)
-  float* save_s1;       // optional [8][npts][256]  sigma'_l (0 on the substituted entries of layer 3); null: not written
+  float* save_s1;       // [8][npts][256]  sigma'_l (0 on the substituted entries of layer 3)
   float* save_t;        // [8][npts][256]  t_l = sigma'_l * a_{l+1}  (t_7 = sigma'_7 w_s / 3)
   float* save_ge;       // [npts][128]     columns e: a_0[e]; columns 73 + e: a_4[217 + e]  (e < 39)
 };
@@ -320,8 +320,30 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W32_SSAVE(c, g2, part, val) do { } while (0)
 #define W32_SSAVE_P(c, g2, part, val) do { } while (0)
 #else
-#define W32_SSAVE(c, g2, part, val) do { if (a.save_s1) W32_ROWST_(a.save_s1, qlayer, c, g2, part, val); } while (0)      // (optional array)
-#define W32_SSAVE_P(c, g2, part, val) do { if (a.save_s1) W32_ROWST_(a.save_s1, qlayer - 1, c, g2, part, val); } while (0)
+#define W32_SSAVE(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer, c, g2, part, val)
+#define W32_SSAVE_P(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer - 1, c, g2, part, val)
+#endif
+#ifndef NRH32_Q7REG
+#define NRH32_Q7REG 0      // experiment: layer 7's sigma' words stay in registers from its epilogues to the T7 pass
+#endif
+#if NRH32_Q7REG
+    u32x4 q0a, q0b, q1a, q1b, q2a, q2b, q3a, q3b, q4a, q4b, q5a, q5b, q6a, q6b, qpa, qpb;
+#define W32_Q7_0_0 q0a
+#define W32_Q7_0_1 q0b
+#define W32_Q7_1_0 q1a
+#define W32_Q7_1_1 q1b
+#define W32_Q7_2_0 q2a
+#define W32_Q7_2_1 q2b
+#define W32_Q7_3_0 q3a
+#define W32_Q7_3_1 q3b
+#define W32_Q7_4_0 q4a
+#define W32_Q7_4_1 q4b
+#define W32_Q7_5_0 q5a
+#define W32_Q7_5_1 q5b
+#define W32_Q7_6_0 q6a
+#define W32_Q7_6_1 q6b
+#define W32_Q7_7_0 qpa
+#define W32_Q7_7_1 qpb
 #endif
     // ---- L0 ----
     {
@@ -338,7 +360,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
     NRH32_STAMP(1);   // L0
     // ---- L1..L7: odd layers read set 0 / write set 1, even layers the other way round ----
-    for (int l = 1; l <= 7; l += 2) {
+    constexpr bool Q7REG = NRH32_Q7REG && (MODE == 1 || MODE == 2);
+    for (int l = 1; l <= (Q7REG ? 5 : 7); l += 2) {
       {
         const int qlayer = l;
         const bool same_kind_before = l > 1;     // (layer 1 follows L0's short windows)
@@ -382,7 +405,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
               const float v = emb_entry(x3, 2 * m, 2 * m + 1, hf);
               if (2 * m + hf < 39) {
                 *(gf_p)(rows_at(a.save_h, 3) + r0 + (2 * m + hf) * 4) = v;
-                if (a.save_s1) *(gf_p)(rows_at(a.save_s1, 3) + r0 + (2 * m + hf) * 4) = 0.0f;
+                *(gf_p)(rows_at(a.save_s1, 3) + r0 + (2 * m + hf) * 4) = 0.0f;
               }
               if (m & 1) __builtin_amdgcn_sched_barrier(0);
             }
@@ -390,6 +413,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
         }
       }
     }
+#if NRH32_Q7REG
+    if constexpr (Q7REG) {
+      // layer 7 on its own: its sigma' words go to the registers the T7 pass reads instead of through the scratch
+      // (its first window still finishes layer 6's last chunk: W32_QSTORE_P stays the scratch store)
+      const int qlayer = 7;
+      const bool same_kind_before = true;
+      (void)same_kind_before;
+#pragma push_macro("W32_QSTORE")
+#undef W32_QSTORE
+#define W32_QSTORE(c, half, val) W32_Q7_##c##_##half = (val)
+#include "gen32/fwd_d1_p0.inc"
+#pragma pop_macro("W32_QSTORE")
+    }
+#endif
     {
       const int qlayer = 8;   // the pending chunk 7 of layer 7 -> set 1, where FEAT / HEAD read their input
       if constexpr (JVP) {
@@ -397,7 +434,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       } else if constexpr (TRAIN) {
 #include "gen32/fwd_fin_t.inc"
       } else if constexpr (WANT_D) {
+#if NRH32_Q7REG
+#pragma push_macro("W32_QSTORE_P")
+#undef W32_QSTORE_P
+#define W32_QSTORE_P(c, half, val) W32_Q7_##c##_##half = (val)
 #include "gen32/fwd_fin_d1.inc"
+#pragma pop_macro("W32_QSTORE_P")
+#else
+#include "gen32/fwd_fin_d1.inc"
+#endif
       } else {
 #include "gen32/fwd_fin_d0.inc"
       }
@@ -448,7 +493,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #undef W32_BCONST
     }
     // q_7 words for the T7 pass: requested inside the HEAD window, consumed after it (their L2 latency passes under HEAD's K loop)
+#if !NRH32_Q7REG
     u32x4 q0a, q0b, q1a, q1b, q2a, q2b, q3a, q3b, q4a, q4b, q5a, q5b, q6a, q6b, qpa, qpb;
+#endif
     const char* const q7base = uni(scr + 7 * 16384);
     // nt: served by L2; asm: the destination registers are written straight by the load (no compiler copy of a value still in
     // flight - checked in the build's ISA, csrc/check_wide_isa.py, run by the Makefile), the wait is in t7.inc
@@ -456,7 +503,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     {
       W32_SYNC();
       W32_FETCH_SETUP();
-      if constexpr (WANT_D) {
+      if constexpr (WANT_D && !Q7REG) {
 #include "gen32/t7_loads.inc"
         W32_QLOAD7_ASM(qpa, 7, 0);
         W32_QLOAD7_ASM(qpb, 7, 1);

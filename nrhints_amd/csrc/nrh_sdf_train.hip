@@ -14,10 +14,9 @@
 //       zbar_l = s'_l hbar_l + coup_l ;   hbar_{l-1} = W_l^T zbar_l
 //       pbar   = 3 * sum_e (xbar_0[e] + xbar_4[217 + e]) dc[e]   (value path only; the host adds the d2c term)
 //
-// and the weight gradients are products over the saved row-major arrays (csrc/nrh_dw.hip, one split-K launch):
+// and the weight gradients are plain GEMMs over the saved row-major arrays (host side, rocBLAS):
 //       dW_l = zbar_l^T x_l + t_l^T abar_l,   db_l = sum_P zbar_l,   ...
-// Both sweeps are the transposed register chain of nrh_mlp.h with different epilogues; h_l - from which s'_l = 1 - exp(-100 h_l)
-// is recovered (nrh_common.h sigp_from_h; no second 1 KiB per point and layer for sigma') - and t_l come from the training
+// Both sweeps are the transposed register chain of nrh_mlp.h with different epilogues; s'_l, t_l come from the training
 // forward (sdf_kernel<3>), abar / coup / zbar are written row-major [layer][npts][256].
 #include "nrh_mlp.h"
 
@@ -30,7 +29,7 @@ struct SdfTrainArgs {
   const float* ro;       // points as rays: p = ro[ray] + rd[ray] * t[ray * t_stride + j]
   const float* rd;
   const float* t;
-  const float* hh;       // [8][npts][256] save_h of the forward: sigma'_l = sigp_from_h(h_l) (0 on layer 3's substituted entries)
+  const float* s1;       // [8][npts][256] from the forward
   const float* tt;       // [8][npts][256] from the forward
   const float* gbar;     // [npts][3]   tangent sweep in
   float* abar;           // [8][npts][256] tangent sweep out: abar_{l+1} at index l (index 7: s'_7 tbar_7, for d w_s)
@@ -135,19 +134,17 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
     for (int s = 0; s <= 7; ++s) {
       auto pre = [&](int ch) {
         TrainPre p;
-        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.hh, s, a.npts, row, 2 * ch, q)));
-        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.hh, s, a.npts, row, 2 * ch + 1, q)));
+        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, s, a.npts, row, 2 * ch, q)));
+        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, s, a.npts, row, 2 * ch + 1, q)));
         p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, s, a.npts, row, 2 * ch, q)));
         p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, s, a.npts, row, 2 * ch + 1, q)));
         return p;
       };
       Act<PREC, 16> ho;
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const TrainPre& p) {
-        // sigma' from h (layer 3's substituted entries: t = 0 there, so coup = 0 whatever sigma' reads, and abar is replaced below)
-        const f32x4 sp0 = sigp_from_h4(p.s0), sp1 = sigp_from_h4(p.s1);
-        const f32x4 c0 = (1.0f - sp0) * p.t0 * acc0 * 100.0f;
-        const f32x4 c1 = (1.0f - sp1) * p.t1 * acc1 * 100.0f;
-        f32x4 n0 = sp0 * acc0, n1 = sp1 * acc1;
+        const f32x4 c0 = (1.0f - p.s0) * p.t0 * acc0 * 100.0f;
+        const f32x4 c1 = (1.0f - p.s1) * p.t1 * acc1 * 100.0f;
+        f32x4 n0 = p.s0 * acc0, n1 = p.s1 * acc1;
         if (ch >= 6 && s == 3) {
           // abar_4 = [abar_4h (217), abar_0 (39)]: the skip connection (fields/sdf_field.py:113-114)
 #pragma unroll
@@ -217,8 +214,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
       const int lz = s - 1;  // layer whose zbar this stage's epilogue produces
       auto pre = [&](int ch) {
         TrainPre p;
-        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.hh, lz, a.npts, row, 2 * ch, q)));
-        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.hh, lz, a.npts, row, 2 * ch + 1, q)));
+        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch, q)));
+        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
         p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch, q)));
         p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
         if (s == 8) {
@@ -241,15 +238,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
             skip[(2 * ch + 1 - 13) * 4 + r] = acc1[r];
           }
         }
-        f32x4 sp0 = sigp_from_h4(p.s0), sp1 = sigp_from_h4(p.s1);
-        if (lz == 3 && ch >= 6) {     // the substituted entries of layer 3 hold the embedding: sigma' = 0 (their adjoint left through `skip`)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (ch == 7) sp0[r] = 0.0f;
-            if ((2 * ch + 1) * 16 + 4 * q + r - 217 >= 0) sp1[r] = 0.0f;
-          }
-        }
-        const f32x4 z0 = sp0 * acc0 + p.t0, z1 = sp1 * acc1 + p.t1;
+        const f32x4 z0 = p.s0 * acc0 + p.t0, z1 = p.s1 * acc1 + p.t1;
         if (tile_ok) {
           st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch, q)), z0);
           st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1);

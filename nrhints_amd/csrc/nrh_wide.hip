@@ -23,7 +23,7 @@ int wide_sdf_launch(const WideSdfCall& c, hipStream_t st) {
   long long off = 0;
   // mode 3 (forward-mode derivative along the ray) consumes the forward-only stream, mode 4 (training forward) mode 2's
   const int smode = c.mode == 3 ? 0 : (c.mode == 4 ? 2 : c.mode);
-  if (c.mode == 4 && (c.npts > (1LL << 22) || !c.save_h || !c.save_t || !c.save_ge)) return -1;   // 32-bit row offsets
+  if (c.mode == 4 && (c.npts > (1LL << 22) || !c.save_h || !c.save_s1 || !c.save_t || !c.save_ge)) return -1;   // 32-bit row offsets
   for (int m = 0; m < smode; ++m) off += sdf32_stream_bytes(m);
   a.w = reinterpret_cast<const char*>(c.streams) + off;
   a.tab = c.tables; a.ro = c.ro; a.rd = c.rd; a.t = c.t; a.sdf = c.sdf; a.grad = c.grad; a.feat = c.feat;

@@ -82,10 +82,9 @@ def sdf_at_points(mode: int, sdf_w, sdf_b, sdf_head, pts):
 
 
 @_lib.on_tensor_device
-def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts, want_s1: bool = False):
+def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
     """Training forward at free points [P,3] (P % 16 == 0): -> (sdf [P,1], feat [P,256] row-major, grad [P,3], saves)
-    where ``saves`` holds what ``sdf_train_backward`` and the weight-gradient GEMMs need (include/nrhints_hip.h).
-    ``want_s1``: also the optional sigma' array (tests; the sweeps recover sigma' from ``h``)."""
+    where ``saves`` holds what ``sdf_train_backward`` and the weight-gradient GEMMs need (include/nrhints_hip.h)."""
     lib = _lib.load()
     n = pts.shape[0]
     dev = pts.device
@@ -95,7 +94,7 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts, want_s1: bool = False):
     sdf = torch.empty(n, 1, **f32)
     grad = torch.empty(n, 3, **f32)
     feat = torch.empty(n, 256, **f32)
-    saves = dict(h=torch.empty(8, n, 256, **f32), s1=torch.empty(8, n, 256, **f32) if want_s1 else None, t=torch.empty(8, n, 256, **f32),
+    saves = dict(h=torch.empty(8, n, 256, **f32), s1=torch.empty(8, n, 256, **f32), t=torch.empty(8, n, 256, **f32),
                  ge=torch.empty(n, 128, **f32), zeros3=zeros3, zeros1=zeros1)
     P = _lib.ptr
     wp, prec = _wptr(sdf_w)
@@ -106,7 +105,7 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts, want_s1: bool = False):
 
 
 @_lib.on_tensor_device
-def sdf_train_forward_wide(sdf_w32, sdf_tab32, pts, scratch: Optional[torch.Tensor] = None, want_s1: bool = False):
+def sdf_train_forward_wide(sdf_w32, sdf_tab32, pts, scratch: Optional[torch.Tensor] = None):
     """``sdf_train_forward`` on the wide f16x3 kernels (csrc/nrh_sdf32.hip MODE 4; P % 32 == 0): same outputs, same saves."""
     lib = _lib.load()
     n = pts.shape[0]
@@ -115,7 +114,7 @@ def sdf_train_forward_wide(sdf_w32, sdf_tab32, pts, scratch: Optional[torch.Tens
     zeros3 = torch.zeros(n, 3, **f32)
     zeros1 = torch.zeros(n, **f32)
     sdf, grad, feat = torch.empty(n, 1, **f32), torch.empty(n, 3, **f32), torch.empty(n, 256, **f32)
-    saves = dict(h=torch.empty(8, n, 256, **f32), s1=torch.empty(8, n, 256, **f32) if want_s1 else None, t=torch.empty(8, n, 256, **f32),
+    saves = dict(h=torch.empty(8, n, 256, **f32), s1=torch.empty(8, n, 256, **f32), t=torch.empty(8, n, 256, **f32),
                  ge=torch.zeros(n, 128, **f32), zeros3=zeros3, zeros1=zeros1)
     if scratch is None:
         scratch = _scratch(dev)
@@ -143,7 +142,7 @@ def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sb
     if prec != prec2:
         raise ValueError("sdf_w and wt_feat are packed for different precisions")
     rc = lib.nrh_sdf_train_backward(prec, wp, wtp, P(sdf_head), P(ro), P(rd), P(t), n_per_ray, n_per_ray, nrays,
-                                    P(saves["h"]), P(saves["t"]), P(gbar), P(fbar), P(sbar), P(out["abar"]), P(out["coup"]),
+                                    P(saves["s1"]), P(saves["t"]), P(gbar), P(fbar), P(sbar), P(out["abar"]), P(out["coup"]),
                                     P(out["gebar"]), P(out["zbar"]), P(out["pbar"]), _lib.stream_handle())
     _lib.check(rc, "nrh_sdf_train_backward")
     return out

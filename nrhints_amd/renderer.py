@@ -544,7 +544,7 @@ class NeuSHintRenderer(nn.Module):
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
                    nhat=new(n, T, 3), cue=new(n, T, 4), mid_z=new(n, T), dists=new(n, T))
         pre = dict(sdf=new(n * T, 1), feat=new(n * T, 256), grad=out["normals"].reshape(n * T, 3),
-                   saves=dict(h=new(8, n * T, 256), t=new(8, n * T, 256), ge=new(n * T, 128)),      # (no sigma' array: recovered from h)
+                   saves=dict(h=new(8, n * T, 256), s1=new(8, n * T, 256), t=new(8, n * T, 256), ge=new(n * T, 128)),
                    ro=o, rd=d, t=out["mid_z"], n_per_ray=T)
         P = _lib.ptr
         sv = pre["saves"]
@@ -552,7 +552,7 @@ class NeuSHintRenderer(nn.Module):
             out.update(shadow_mid_z=new(n, T), shadow_dists=new(n, T))
         if self._shadow_clip > 0 and not zero_hints:
             out.update(vis_groups=new(n * self._shadow_clip, 1))
-        saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), None, P(sv["t"]), P(sv["ge"]), P(raymisc),
+        saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]), P(raymisc),
                                    P(out.get("shadow_mid_z")), P(out.get("shadow_dists")), P(out.get("vis_groups")))
         ws = self._workspace(device, n)
         rc = lib.nrh_render_forward_train(

@@ -294,11 +294,11 @@ def test_wide_training_forward_vs_16pt_and_oracle(wscene, npts):
     tag, model, packed, p64 = wscene
     g = torch.Generator().manual_seed(7 + npts)
     pts = ((torch.rand(npts, 3, generator=g) * 2 - 1) * 0.95).cuda()
-    sdf, feat, grad, sv = ops.sdf_train_forward_wide(packed["sdf_w32"], packed["sdf_tab32"], pts, want_s1=True)
+    sdf, feat, grad, sv = ops.sdf_train_forward_wide(packed["sdf_w32"], packed["sdf_tab32"], pts)
     st = {k: v.detach() for k, v in model.state_dict().items()}
     d = pk.dense_params({k: v.float().cuda() for k, v in st.items()})
     w0, b0, h0 = pk.pack_sdf(d, 0)
-    sdf_r, feat_r, grad_r, sv_r = ops.sdf_train_forward(w0, b0, h0, pts, want_s1=True)
+    sdf_r, feat_r, grad_r, sv_r = ops.sdf_train_forward(w0, b0, h0, pts)
     o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, pts.cpu().double())
     np.testing.assert_allclose(sdf.cpu().numpy(), o_sdf.numpy(), rtol=0, atol=5e-6)
     np.testing.assert_allclose(feat.cpu().numpy(), o_feat.numpy(), rtol=0, atol=3e-5)
@@ -318,6 +318,6 @@ def test_wide_training_forward_vs_16pt_and_oracle(wscene, npts):
     assert float((sv["t"] - sv_r["t"]).abs().mean()) < 2e-6 * scale_t
     assert float((sv["h"] - sv_r["h"]).abs().mean()) < 2e-7
     # determinism (row stores, the skip fix-up and the sigma' scratch all leave in a fixed order): a second run is bit-identical
-    sdf2, feat2, grad2, sv2 = ops.sdf_train_forward_wide(packed["sdf_w32"], packed["sdf_tab32"], pts, want_s1=True)
+    sdf2, feat2, grad2, sv2 = ops.sdf_train_forward_wide(packed["sdf_w32"], packed["sdf_tab32"], pts)
     for x, y in ((sdf, sdf2), (feat, feat2), (grad, grad2), (sv["h"], sv2["h"]), (sv["s1"], sv2["s1"]), (sv["t"], sv2["t"]), (sv["ge"], sv2["ge"])):
         assert torch.equal(x, y)
