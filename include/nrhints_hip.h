@@ -79,6 +79,17 @@ int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, con
                       float* scratch, void* stream);
 long long nrh_sdf_wide_stream_bytes(void);
 
+/* SDF value (mode 0) of a SMALL point set, precision f16x3: one 16-point tile's 256 output channels are split over the four
+ * waves of a workgroup (csrc/nrh_sdf_split.hip), so a pass of a few thousand points costs a quarter of a tile's matrix time
+ * instead of all of it.  Replaces SDFNetwork.sdf (fields/sdf_field.py:125-126) as the hierarchical sampler calls it
+ * (models/neus_hint_model.py:175-246) when the batch is the reference's per-rank share (trainer/trainer.py:116-123).
+ * sdf_w / sdf_b / sdf_head are nrh_sdf_eval's PRECISION-1 parameters; every value is bit-identical to
+ * nrh_sdf_eval(precision 1, mode 0).  tiles = 16-point tiles per workgroup: 1, 2, or 0 (chosen from the point count).
+ * nrh_render_forward_train takes this kernel for sampler passes of at most 16 384 points. */
+int nrh_sdf_eval_split(const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro, const float* rd,
+                       const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, int tiles,
+                       void* stream);
+
 /* ---- SDF network, training --------------------------------------------------------------------------------
  * The reference differentiates d(sdf)/dp a second time with autograd (create_graph=True, fields/sdf_field.py:145;
  * loss.backward(), pipelines/base_pipeline.py:59-62).  Here that second-order backward is two more register-chain

@@ -2,6 +2,7 @@
 // are included here so one hipcc invocation builds the whole library for gfx950.
 #include "nrh_sdf.hip"
 #include "nrh_sdf_train.hip"
+#include "nrh_sdf_split.hip"
 #include "nrh_color.hip"
 #include "nrh_outside.hip"
 #include "nrh_rays.hip"
@@ -202,6 +203,41 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
   return check_launch("sampler_step_kernel");
 }
 
+// SDF values of a SMALL point set on the channel-split kernel (csrc/nrh_sdf_split.hip; f16x3 stages, bit-identical to sdf_kernel<0, 1>).
+// tiles: 16-point tiles per workgroup (1 or 2; 0 = 2 once the point set fills a quarter of the CUs with single tiles)
+#ifndef NRH_SPLIT_MAX_PTS
+#define NRH_SPLIT_MAX_PTS 16384     // the training sampler takes the split kernel for passes of at most this many points (0: never)
+#endif
+int sdf_split_impl(const float* w, const float* b, const float* head, const float* ro, const float* rd, const float* t, int t_stride,
+                   int n_per_ray, long long nrays, float* sdf, int sdf_stride, int tiles, hipStream_t st) {
+  if (!w || !b || !head || !ro || !rd || !t || !sdf) return fail(NRH_E_INVALID, "nrh_sdf_eval_split: null pointer%s", "");
+  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray || sdf_stride < n_per_ray)
+    return fail(NRH_E_INVALID, "nrh_sdf_eval_split: bad n_per_ray/stride%s", "");
+  if (tiles < 0 || tiles > 2) return fail(NRH_E_INVALID, "nrh_sdf_eval_split: tiles must be 0 (auto), 1 or 2%s", "");
+  if (nrays == 0) return NRH_OK;
+  const long long npts = nrays * n_per_ray;
+  if (npts > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_sdf_eval_split: at most 16 777 216 points per call%s", "");
+  static bool attrs = false;
+  if (!attrs) {
+    if (hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(1)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(2)) != hipSuccess)
+      return fail(NRH_E_LAUNCH, "nrh_sdf_eval_split: no HIP device / attribute error%s", "");
+    attrs = true;
+  }
+  if (tiles == 0) tiles = (npts > 16LL * (device_cus() / 4)) ? 2 : 1;
+  nrh::SdfSplitArgs a;
+  a.w = w; a.b = b; a.head = head; a.ro = ro; a.rd = rd; a.t = t; a.sdf = sdf; a.npts = npts; a.n_per_ray = n_per_ray;
+  a.t_stride = t_stride; a.sdf_stride = sdf_stride;
+  const unsigned grid = (unsigned)((npts + 16 * tiles - 1) / (16 * tiles));
+  TimedLaunch tl;
+  bool timed;
+  timing_begin(0, st, tl, timed);
+  if (tiles == 1) hipLaunchKernelGGL(nrh::sdf_split_kernel<1>, dim3(grid), dim3(256), nrh::split_lds_bytes(1), st, a);
+  else hipLaunchKernelGGL(nrh::sdf_split_kernel<2>, dim3(grid), dim3(256), nrh::split_lds_bytes(2), st, a);
+  timing_end(st, tl, timed);
+  return check_launch("sdf_split_kernel");
+}
+
 int color_eval_impl(int prec, int hints, const float* w, const float* b, const float* feat, const float* ro, const float* rd,
                     const float* tmid, const float* nhat, const float* raymisc, long long nrays, float* color,
                     hipStream_t st, int fused = 0, int misc_shift = 7) {
@@ -239,10 +275,18 @@ int color_eval_impl(int prec, int hints, const float* w, const float* b, const f
 // hierarchical sampling of one family of rays: coarse sdf, 4 x (up-sample 16, evaluate, merge), finalise sections
 int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, float* s, float* znew, float* snew,
                 const float* lin16, const float* last_dist_ray, float last_dist, float* tmid, float* dists,
-                long long n, hipStream_t st) {
+                long long n, hipStream_t st, bool latency = false) {
   const WideNet wide{net->sdf_w32, net->sdf_tab32};
-  int rc = sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, z, 128, 64, n, s, 128, nullptr, nullptr,
-                         nullptr, st, wide);
+  // a training step's passes are small and serial: below NRH_SPLIT_MAX_PTS points the channel-split kernel (a tile's MFMA work
+  // over the CU's four SIMDs) instead of the one-wave-per-tile evaluation kernels.  Training only: a frame's chunks must not
+  // change kernels with their size (bit-equal re-chunking, tests/test_gpu_fullsize.py)
+  auto sdf0 = [&](const float* t, int stride, int per_ray, float* out) {
+    if (latency && net->precision == 1 && n * per_ray <= (long long)NRH_SPLIT_MAX_PTS)
+      return sdf_split_impl(net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, t, stride, per_ray, n, out, stride, 0, st);
+    return sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, t, stride, per_ray, n, out, stride, nullptr,
+                         nullptr, nullptr, st, wide);
+  };
+  int rc = sdf0(z, 128, 64, s);
   if (rc) return rc;
   for (int i = 0; i < 4; ++i) {
     nrh::StepArgs a;
@@ -256,8 +300,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
     if (rc) return rc;
     const bool last = (i == 3);
     if (!last) {
-      rc = sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, znew, 16, 16, n, snew, 16, nullptr, nullptr,
-                         nullptr, st, wide);
+      rc = sdf0(znew, 16, 16, snew);
       if (rc) return rc;
     }
     // launch B: merge (with sdf unless last); finalise after the last merge
@@ -291,7 +334,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 137; }
+int nrh_version(void) { return 138; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -350,6 +393,11 @@ int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, con
   if (!sdf_w32 || !sdf_tab32) return fail(NRH_E_INVALID, "nrh_sdf_eval_wide: null pointer%s", "");
   return sdf_eval_impl(1, mode, nullptr, nullptr, nullptr, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat, scratch,
                        (hipStream_t)stream, WideNet{sdf_w32, sdf_tab32});
+}
+
+int nrh_sdf_eval_split(const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro, const float* rd, const float* t,
+                       int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, int tiles, void* stream) {
+  return sdf_split_impl(sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, tiles, (hipStream_t)stream);
 }
 
 long long nrh_sdf_wide_stream_bytes(void) { return nrh32::wide_sdf_stream_bytes_total(); }
@@ -1172,7 +1220,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
                        2.0f / 64.0f, o_tmid, o_dists, (int)n);
     rc = check_launch("finalize64_kernel");
   } else {
-    rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f, o_tmid, o_dists, n, st);
+    rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f, o_tmid, o_dists, n, st, train != nullptr);
   }
   if (rc) return rc;
   if (clip && hipMemcpyAsync(ws_cue_b, ws_zbuf, sizeof(float) * 128 * n, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -1222,7 +1270,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   // ---- shadow rays light -> hit point ----
   if (!no_hints && !clip) {
     rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, o_tmid_s,
-                     o_dists_s, n, st);
+                     o_dists_s, n, st, train != nullptr);
     if (rc) return rc;
     // the shadow ray's alpha only needs <direction, gradient>: with the wide kernels that is mode 3 (forward mode, no scratch)
     const int smode = (net->shadow_jvp && net->precision == 1 && net->sdf_w32 && net->sdf_tab32) ? 3 : 1;
@@ -1255,7 +1303,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
       hipLaunchKernelGGL(nrh::partial_shadow_setup_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ps);
       rc = check_launch("partial_shadow_setup_kernel");
       if (rc) return rc;
-      rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s, ws_dists_s, n, st);
+      rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s, ws_dists_s, n, st, train != nullptr);
       if (rc) return rc;
       rc = sdf_eval_impl(net->precision, 1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
                          128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});

@@ -1,0 +1,94 @@
+"""GPU parity of the channel-split SDF kernel for small point sets (csrc/nrh_sdf_split.hip, C entry nrh_sdf_eval_split): bit-identical
+to the 16-point f16x3 kernel nrh_sdf_eval(precision 1, mode 0) on the same packed parameters, within float32 tolerance of the
+float64 oracle and of the golden fixtures the imported reference produced, and taken by the training forward's sampler."""
+import numpy as np
+import pytest
+import torch
+
+import nrhints_amd as na
+from nrhints_amd import ops
+from nrhints_amd.synthetic import make_rays
+from oracle import neus_oracle as orc
+from tests.conftest import load_npz
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def cu(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).float().contiguous().cuda()
+
+
+@pytest.fixture(scope="module", params=["a", "b"])
+def sscene(request, scene_states):
+    st = scene_states[request.param]
+    model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision="f16x3")
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+    model = model.cuda().eval()
+    packed = model.packed_params(torch.device("cuda", torch.cuda.current_device()))
+    return request.param, model, packed, orc.params_from_state(st, torch.float64)
+
+
+# (rays, samples per ray, row stride): the sampler's two calling conventions, ragged tails (points not a multiple of 16 / 32),
+# one point, and a set larger than one round of workgroups
+SHAPES = [(64, 64, 128), (64, 16, 16), (37, 16, 16), (1, 1, 1), (3, 5, 8), (128, 64, 128), (1000, 16, 16), (300, 64, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("tiles", [0, 1, 2])
+def test_split_bit_identical_to_the_16_point_kernel(sscene, shape, tiles):
+    tag, model, packed, p64 = sscene
+    n, nper, stride = shape
+    o, d, pl, near, far = make_rays(n, seed=11 + n, spread=0.1)
+    z = np.zeros((n, stride), np.float32)
+    z[:, :nper] = near + (far - near) * np.linspace(0, 1, nper, dtype=np.float32)[None]
+    args = (packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], cu(o), cu(d), cu(z), nper)
+    ref, _, _ = ops.sdf_eval(0, *args, t_stride=stride)
+    got = ops.sdf_eval_split(*args, t_stride=stride, tiles=tiles)
+    assert got.shape == ref.shape == (n, nper)
+    assert torch.equal(got, ref), f"max |diff| {float((got - ref).abs().max()):.3e}"          # bit for bit
+    again = ops.sdf_eval_split(*args, t_stride=stride, tiles=tiles)
+    assert torch.equal(got, again)
+    pts = (T(o)[:, None] + T(d)[:, None] * T(z[:, :nper])[..., None]).reshape(-1, 3)
+    o_sdf = orc.sdf_forward(p64, pts.double(), False)[0].reshape(n, nper)
+    # fp16 hi/lo products, fp32 accumulation, 8 layers of K = 256: the float32 chain's class (the wide kernels' bound)
+    np.testing.assert_allclose(got.cpu().numpy(), o_sdf.numpy(), rtol=0, atol=5e-6)
+
+
+def test_split_golden_fixture(sscene):
+    """Directly against what the imported reference produced (tests/golden/unit_*.npz)."""
+    tag, model, packed, _ = sscene
+    u = load_npz(f"unit_{tag}.npz")
+    pts = cu(u["sdf_pts"])
+    t = torch.zeros(pts.shape[0], dtype=torch.float32, device=pts.device)
+    sdf = ops.sdf_eval_split(packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], pts, torch.zeros_like(pts), t, 1)
+    np.testing.assert_allclose(sdf.cpu().numpy()[:, 0], u["sdf_out_f64"][:, 0], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(sdf.cpu().numpy()[:, 0], u["sdf_out"][:, 0], rtol=0, atol=5e-6)
+
+
+def test_split_rejects_bad_arguments(sscene):
+    tag, model, packed, _ = sscene
+    o, d, pl, near, far = make_rays(4, seed=1, spread=0.1)
+    z = cu(np.zeros((4, 16), np.float32))
+    with pytest.raises(RuntimeError, match="tiles"):
+        ops.sdf_eval_split(packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], cu(o), cu(d), z, 16, tiles=3)
+    with pytest.raises(RuntimeError, match="stride"):
+        ops.sdf_eval_split(packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], cu(o), cu(d), z, 16, t_stride=8)
+
+
+def test_training_sampler_takes_the_split_kernel(sscene):
+    """nrh_render_forward_train with a 64-ray batch (the reference's per-rank share, trainer/trainer.py:116-123): its sampler
+    passes (4 096 and 1 024 points) run on the split kernel, the evaluation path's on the wide kernels - same arithmetic class,
+    so the two renderings of the same rays agree to the float32 noise of the sample placement."""
+    tag, model, packed, p64 = sscene
+    o, d, pl, near, far = make_rays(64, seed=77, spread=0.08)
+    rb = na.RayBundle(origins=cu(o), directions=cu(d), pl_positions=cu(pl), nears=cu(near), fars=cu(far))
+    bg = torch.ones(1, 3, device="cuda")
+    out_t = model(rb, False, bg)                      # grad mode on, parameters require grad: the training forward
+    assert out_t.rgb.requires_grad
+    with torch.no_grad():
+        out_e = model(rb, False, bg)
+    np.testing.assert_allclose(out_t.rgb.detach().cpu().numpy(), out_e.rgb.cpu().numpy(), rtol=0, atol=5e-3)
+    np.testing.assert_allclose(out_t.depth.detach().cpu().numpy(), out_e.depth.cpu().numpy(), rtol=0, atol=5e-3)
+    w_t, w_e = out_t.weights.detach().cpu().numpy(), out_e.weights.cpu().numpy()
+    assert np.mean(np.abs(w_t - w_e) < 1e-3) > 0.995
