@@ -13,6 +13,7 @@
 #include "nrh_adam.hip"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -224,7 +225,10 @@ int sdf_split_impl(const float* w, const float* b, const float* head, const floa
       return fail(NRH_E_LAUNCH, "nrh_sdf_eval_split: no HIP device / attribute error%s", "");
     attrs = true;
   }
-  if (tiles == 0) tiles = (npts > 16LL * (device_cus() / 4)) ? 2 : 1;
+  if (tiles == 0) {
+    static const int forced = getenv("NRH_SPLIT_TILES") ? atoi(getenv("NRH_SPLIT_TILES")) : 0;       // profiling override
+    tiles = (forced == 1 || forced == 2) ? forced : (npts > 16LL * device_cus()) ? 2 : 1;            // one tile per workgroup while that fills the CUs once
+  }
   nrh::SdfSplitArgs a;
   a.w = w; a.b = b; a.head = head; a.ro = ro; a.rd = rd; a.t = t; a.sdf = sdf; a.npts = npts; a.n_per_ray = n_per_ray;
   a.t_stride = t_stride; a.sdf_stride = sdf_stride;
@@ -280,8 +284,9 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
   // a training step's passes are small and serial: below NRH_SPLIT_MAX_PTS points the channel-split kernel (a tile's MFMA work
   // over the CU's four SIMDs) instead of the one-wave-per-tile evaluation kernels.  Training only: a frame's chunks must not
   // change kernels with their size (bit-equal re-chunking, tests/test_gpu_fullsize.py)
+  static const long long split_max = getenv("NRH_SPLIT_MAX_PTS") ? atoll(getenv("NRH_SPLIT_MAX_PTS")) : (long long)NRH_SPLIT_MAX_PTS;   // (env: profiling override)
   auto sdf0 = [&](const float* t, int stride, int per_ray, float* out) {
-    if (latency && net->precision == 1 && n * per_ray <= (long long)NRH_SPLIT_MAX_PTS)
+    if (latency && net->precision == 1 && n * per_ray <= split_max)
       return sdf_split_impl(net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, t, stride, per_ray, n, out, stride, 0, st);
     return sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, t, stride, per_ray, n, out, stride, nullptr,
                          nullptr, nullptr, st, wide);

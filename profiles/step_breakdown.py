@@ -41,7 +41,11 @@ for r in step:
     k = cat(r["Kernel_Name"])
     agg[k][0] += dur(r)
     agg[k][1] += 1
-print(f"one training step: {len(step)} kernel launches, {sum(dur(r) for r in step) / 1e6:.3f} ms of kernel time")
+span = int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])
+print(f"one training step: {len(step)} kernel launches, {sum(dur(r) for r in step) / 1e6:.3f} ms of kernel time, {span / 1e6:.3f} ms from the first kernel's start to the last one's end")
+gaps = sorted(((int(step[i + 1]["Start_Timestamp"]) - int(step[i]["End_Timestamp"])) / 1e3, cat(step[i]["Kernel_Name"]), cat(step[i + 1]["Kernel_Name"])) for i in range(len(step) - 1))
+if DETAIL:
+    print("largest gaps (us, after, before):", [(round(g, 1), a[:28], b[:28]) for g, a, b in gaps[-5:]])
 for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     if t > 5000 or DETAIL:
         print(f"{t / 1e6:8.3f} ms {n:5d}  {k}")
