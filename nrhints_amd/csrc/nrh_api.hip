@@ -95,6 +95,8 @@ int ensure_attrs() {
   e = hipSuccess;
   for (const void* f : fns)
     if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(1));
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(2));
   if (e != hipSuccess) return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   g_attr_done[dev] = true;
   return NRH_OK;
@@ -218,13 +220,8 @@ int sdf_split_impl(const float* w, const float* b, const float* head, const floa
   if (nrays == 0) return NRH_OK;
   const long long npts = nrays * n_per_ray;
   if (npts > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_sdf_eval_split: at most 16 777 216 points per call%s", "");
-  static bool attrs = false;
-  if (!attrs) {
-    if (hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(1)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(2)) != hipSuccess)
-      return fail(NRH_E_LAUNCH, "nrh_sdf_eval_split: no HIP device / attribute error%s", "");
-    attrs = true;
-  }
+  const int arc = ensure_attrs();
+  if (arc) return arc;
   if (tiles == 0) {
     static const int forced = getenv("NRH_SPLIT_TILES") ? atoi(getenv("NRH_SPLIT_TILES")) : 0;       // profiling override
     tiles = (forced == 1 || forced == 2) ? forced : (npts > 16LL * device_cus()) ? 2 : 1;            // one tile per workgroup while that fills the CUs once
@@ -293,23 +290,26 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
   };
   int rc = sdf0(z, 128, 64, s);
   if (rc) return rc;
+  // five launches of the per-ray step kernel: up-sample 0 | merge i + up-sample i + 1 (i = 0, 1, 2) | merge 3 + finalise, with the
+  // SDF pass of the 16 new samples between them (the last up-sample's samples are merged without their sdf, :328-329)
+  nrh::StepArgs a;
+  a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew; a.snew_in = snew; a.znew_out = znew; a.lin16 = lin16;
+  a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.last_dist = last_dist;
+  a.nrays = (int)n;
+  a.inv_s = 64.0f; a.n = 64; a.do_merge = 0; a.merge_sdf = 0; a.do_upsample = 1; a.do_finalize = 0;
+  rc = sampler_step_impl(a, st);
+  if (rc) return rc;
   for (int i = 0; i < 4; ++i) {
-    nrh::StepArgs a;
-    a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew; a.snew_in = snew; a.znew_out = znew; a.lin16 = lin16;
-    a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.last_dist = last_dist;
-    a.nrays = (int)n;
-    // launch A: up-sample step i from the current (merged) state
-    a.inv_s = 64.0f * (float)(1 << i);
-    a.n = 64 + 16 * i; a.do_merge = 0; a.merge_sdf = 0; a.do_upsample = 1; a.do_finalize = 0;
-    rc = sampler_step_impl(a, st);
-    if (rc) return rc;
     const bool last = (i == 3);
-    if (!last) {
+    if (i < 3) {
       rc = sdf0(znew, 16, 16, snew);
       if (rc) return rc;
     }
-    // launch B: merge (with sdf unless last); finalise after the last merge
-    a.do_merge = 1; a.merge_sdf = last ? 0 : 1; a.do_upsample = 0; a.do_finalize = last ? 1 : 0;
+    // merge the new samples of step i (with their sdf unless they are the last step's); then up-sample step i + 1 from the merged
+    // state (inv_s = 64 * 2^(i+1)), or finalise after the last merge.  The step-2 launch's up-sample (step 3) is merged by the
+    // next launch without an SDF pass in between.
+    a.n = 64 + 16 * i; a.do_merge = 1; a.merge_sdf = (i < 3) ? 1 : 0; a.do_upsample = last ? 0 : 1; a.do_finalize = last ? 1 : 0;
+    a.inv_s = 64.0f * (float)(1 << (i + 1));
     rc = sampler_step_impl(a, st);
     if (rc) return rc;
   }
