@@ -20,6 +20,7 @@
 
 #include "../../include/nrhints_hip.h"
 #include "nrh_wide.h"
+#include "nrh_small.h"
 
 #ifndef NRH_TRAIN_FWD_WIDE
 // 1: nrh_render_forward_train evaluates the SDF network with the wide training forward (nrh_sdf_train_forward_wide) when NrhNet
@@ -198,6 +199,13 @@ int mlp_launch_geometry(long long npts, int& groups_out, int& grid_out, const ch
   grid_out = (int)(groups < mlp_grid() ? groups : mlp_grid());
   if (grid_out <= 0) return fail(NRH_E_LAUNCH, "no HIP device%s", "");
   return NRH_OK;
+}
+
+// Small batches (at most 4 sixteen-point tiles per CU): the SDF training kernels' 4-wave builds (csrc/nrh_small.hip) put one wave on
+// every SIMD of twice as many CUs.  NRH_SMALL_WG=0 in the environment keeps the 8-wave builds (A/B runs).
+bool small_batch(long long npts) {
+  static const bool on = !(getenv("NRH_SMALL_WG") && atoi(getenv("NRH_SMALL_WG")) == 0);
+  return on && nrh::WG_WAVES == 8 && npts <= 16LL * 4 * device_cus();
 }
 
 int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
@@ -425,10 +433,15 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
   a.save_h = save_h; a.save_s1 = save_s1; a.save_t = save_t; a.save_ge = save_ge;
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride; a.sdf_stride = n_per_ray;
+  const hipStream_t st = (hipStream_t)stream;
+  if (small_batch(a.npts)) {
+    const int src = nrh4s::launch_sdf_train_forward(precision, &a, sizeof(a), device_cus() * 2, st);
+    if (src) return fail(src == -1 ? NRH_E_INVALID : NRH_E_LAUNCH, "nrh_sdf_train_forward: small-batch launch failed%s", "");
+    return check_launch("sdf_kernel<3> (4 waves)");
+  }
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_sdf_train_forward");
   if (rc) return rc;
-  const hipStream_t st = (hipStream_t)stream;
   if (precision == 0) hipLaunchKernelGGL((nrh::sdf_kernel<3, 0>), dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((nrh::sdf_kernel<3, 1>), dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
   return check_launch("sdf_kernel<3>");
@@ -476,10 +489,15 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   a.gbar = gbar; a.abar = abar; a.coup = coup; a.gebar = gebar; a.fbar = fbar; a.sbar = sbar; a.zbar = zbar; a.pbar = pbar;
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride;
+  const hipStream_t st = (hipStream_t)stream;
+  if (small_batch(a.npts)) {
+    const int src = nrh4s::launch_sdf_train_sweeps(precision, &a, sizeof(a), device_cus() * 2, st);
+    if (src) return fail(src == -1 ? NRH_E_INVALID : NRH_E_LAUNCH, "nrh_sdf_train_backward: small-batch launch failed%s", "");
+    return check_launch("sdf_tangent_kernel / sdf_adjoint_kernel (4 waves)");
+  }
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_sdf_train_backward");
   if (rc) return rc;
-  const hipStream_t st = (hipStream_t)stream;
   const dim3 g(grid), blk(nrh::MLP_THREADS);
   if (precision == 0) hipLaunchKernelGGL((nrh::sdf_tangent_kernel<0>), g, blk, nrh::MLP_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((nrh::sdf_tangent_kernel<1>), g, blk, nrh::MLP_LDS_BYTES, st, a);

@@ -72,11 +72,14 @@ _WS: Dict[str, torch.Tensor] = {}
 _WS_RETIRED: List[torch.Tensor] = []
 
 
-def _default_items(dev) -> int:
+def _default_items(dev, npts: Optional[int] = None) -> int:
     # three work items per CU: the jobs' per-step costs are only modelled roughly and short items level the tail, while
     # every item costs 256 KiB of partial sums to write and reduce (measured on the 1024-ray job table: 1.70 / 2.05 / 1.56 /
-    # 1.58 ms with 1 / 2 / 3 / 4 items per CU; profiles/r03/dw_bench_items.log)
-    return 3 * max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
+    # 1.58 ms with 1 / 2 / 3 / 4 items per CU; profiles/r03/dw_bench_items.log).  Up to 512 rays (65 536 points) an item is a
+    # few K steps long and its fixed cost dominates: ONE item per CU there (profiles/r04/dw_items.log: 0.131 against 0.195 ms at
+    # 64 rays, 0.222 / 0.272 at 128, 0.407 / 0.436 at 256, 0.792 / 0.801 at 512).  ``npts`` None: the upper bound (workspace size).
+    cus = max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
+    return cus if (npts is not None and npts <= 65536) else 3 * cus
 
 
 def workspace(dev, need_floats: int = 0) -> torch.Tensor:
@@ -98,7 +101,7 @@ def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
     dev = jobs[0].a[0].device
     with torch.cuda.device(dev):
         if total_items is None:
-            total_items = _default_items(dev)
+            total_items = _default_items(dev, npts)
         nsteps = npts // 32
         costs = [j.cost() for j in jobs]
         tot = sum(costs)

@@ -259,6 +259,18 @@ def _h3_layout(wp: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return wp.reshape(nch, 2, 16, ks, 2, 4, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1)
 
 
+_ZERO1: Dict[str, torch.Tensor] = {}
+
+
+def zero1(dev) -> torch.Tensor:
+    """The constant element 0 that heads a pack plan's flat source (index 0 = "no source"): one tensor per device instead of a fill
+    launch per re-pack (a training step re-packs twice)."""
+    key = str(dev)
+    if key not in _ZERO1:
+        _ZERO1[key] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return _ZERO1[key]
+
+
 class PackPlan:
     """Index form of pack_sdf / pack_color / pack_feat_transposed / pack_color_transposed for one (precision, hints)."""
 
@@ -319,8 +331,7 @@ class PackPlan:
         On the GPU: one concatenation + two launches of nrh_pack_gather (csrc/nrh_fold.hip); the torch expressions below are
         the host-side form of the same plan (CPU tests, and the definition the kernel is tested against)."""
         dev = self.w_index.device
-        flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=dev)] +
-                         [dense[k].detach().to(torch.float32).reshape(-1) for k in _W_KEYS + _B_KEYS])
+        flat = torch.cat([zero1(dev)] + [dense[k].detach().to(torch.float32).reshape(-1) for k in _W_KEYS + _B_KEYS])
         if dev.type == "cuda":
             from . import _lib
             lib = _lib.load()

@@ -268,8 +268,8 @@ class PackPlan32:
 
     def pack(self, d: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
         dev = self.index.device
-        flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=dev)] +
-                         [d[k].detach().to(torch.float32).reshape(-1) for k in _SDF32_KEYS])
+        from .packing import zero1
+        flat = torch.cat([zero1(dev)] + [d[k].detach().to(torch.float32).reshape(-1) for k in _SDF32_KEYS])
         if dev.type == "cuda":
             # one launch for the streams, one for the tables (csrc/nrh_fold.hip); below: the same plan in torch ops (host side)
             import ctypes

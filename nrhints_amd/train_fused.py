@@ -129,9 +129,15 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         zero_hints = 1 if (is_training and global_step < cfg.geometry_warmup_end) else 0
         t_p = t_s = None
         if is_training:
-            t_p = f32(t_rand_primary).reshape(-1) if t_rand_primary is not None else torch.rand(n, device=dev)
-            if not zero_hints and renderer._hints:
-                t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(n, 64, device=dev)
+            want_s = not zero_hints and renderer._hints
+            if t_rand_primary is None and t_rand_shadow is None and want_s:
+                n64 = (n + 63) // 64 * 64                        # (the shadow block stays 256-byte aligned)
+                r = torch.rand(n64 + n * 64, device=dev)        # one generator launch: primary jitter [n], then shadow jitter [n, 64]
+                t_p, t_s = r[:n], r[n64:].view(n, 64)
+            else:
+                t_p = f32(t_rand_primary).reshape(-1) if t_rand_primary is not None else torch.rand(n, device=dev)
+                if want_s:
+                    t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(n, 64, device=dev)
         want_rays = any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions))
         want_params = any(p.requires_grad for p in renderer.parameters())
         # ---- parameters: fold weight-norm (one launch), re-pack ----

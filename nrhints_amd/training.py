@@ -428,8 +428,12 @@ class GraphedTrainStep:
             pairs = ((self.rays.origins, ray_bundle.origins), (self.rays.directions, ray_bundle.directions),
                      (self.rays.pl_positions, ray_bundle.pl_positions), (self.rays.nears, ray_bundle.nears),
                      (self.rays.fars, ray_bundle.fars), (self.gt, rgb_gt))
-        for dst, src in pairs:
-            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        srcs = [src.reshape(dst.shape) for dst, src in pairs]
+        if all(s_.is_cuda and s_.device == d_.device and s_.dtype == d_.dtype == torch.float32 for (d_, _), s_ in zip(pairs, srcs)):
+            torch._foreach_copy_([d_ for d_, _ in pairs], srcs)          # one launch for the batch's six tensors
+        else:
+            for (dst, _), src in zip(pairs, srcs):
+                dst.copy_(src, non_blocking=True)
         self._set_host_scalars(global_step)
         self.graph.replay()
         if self.graph_tail is not None:

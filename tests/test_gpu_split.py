@@ -92,3 +92,33 @@ def test_training_sampler_takes_the_split_kernel(sscene):
     np.testing.assert_allclose(out_t.depth.detach().cpu().numpy(), out_e.depth.cpu().numpy(), rtol=0, atol=5e-3)
     w_t, w_e = out_t.weights.detach().cpu().numpy(), out_e.weights.cpu().numpy()
     assert np.mean(np.abs(w_t - w_e) < 1e-3) > 0.995
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_small_batch_builds_of_the_training_kernels_are_bit_identical(scene_states, prec):
+    """csrc/nrh_small.hip: the SDF training forward and its two backward sweeps compiled with 4 waves per workgroup, taken while the
+    batch has at most 4 tiles per CU (<= 16 384 points on 256 CUs).  A tile's arithmetic does not depend on how many tiles share a
+    workgroup: the same 8 192 points evaluated alone (4-wave builds) and as the head of a 32 768-point call (8-wave builds) give
+    the same bits in every output and saved array."""
+    st = scene_states["b"]
+    model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision=prec)
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+    pk = model.cuda().eval().packed_params(torch.device("cuda", torch.cuda.current_device()))
+    g = torch.Generator().manual_seed(3)
+    small, big = 8192, 32768
+    pts = ((torch.rand(big, 3, generator=g) * 2 - 1) * 0.9).cuda()
+    s_sdf, s_feat, s_grad, s_sv = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts[:small].contiguous())
+    b_sdf, b_feat, b_grad, b_sv = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts)
+    assert torch.equal(s_sdf, b_sdf[:small]) and torch.equal(s_feat, b_feat[:small]) and torch.equal(s_grad, b_grad[:small])
+    for k in ("h", "s1", "t"):
+        assert torch.equal(s_sv[k], b_sv[k][:, :small]), k
+    assert torch.equal(s_sv["ge"][:, :112], b_sv["ge"][:small, :112])
+    sbar, fbar, gbar = (torch.randn(big, generator=g).cuda(), torch.randn(big, 256, generator=g).cuda() * 0.1,
+                        torch.randn(big, 3, generator=g).cuda())
+    zeros3, t0 = torch.zeros(big, 3, device="cuda"), torch.zeros(big, 1, device="cuda")
+    rs = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], pts[:small].contiguous(), zeros3[:small].contiguous(),
+                                t0[:small].contiguous(), 1, s_sv, sbar[:small].contiguous(), fbar[:small].contiguous(), gbar[:small].contiguous())
+    rb = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], pts, zeros3, t0, 1, b_sv, sbar, fbar, gbar)
+    for k in ("abar", "coup", "zbar"):
+        assert torch.equal(rs[k], rb[k][:, :small]), k
+    assert torch.equal(rs["gebar"], rb["gebar"][:small]) and torch.equal(rs["pbar"], rb["pbar"][:small])
