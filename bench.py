@@ -493,6 +493,17 @@ def main():
     # the leg starts and the leg's result follows as a second JSON line on stderr ({"train": ...}); nothing after the
     # headline can keep it from being printed.
     train = run_train_leg() if (not args.no_train and world == 1) else None
+    train_small = None
+    if rank == 0 and world == 1 and not args.no_train and not args.no_camopt:
+        # the reference splits the global batch over the ranks (trainer/trainer.py:116-123: 512 / 8 = 64 rays per rank, 128 with
+        # configs[2]'s 1 024): what ONE such per-rank step costs here, as the graph replay a rank runs
+        try:
+            legs = {b: train_leg(dev, rank, 1, None, batch=b, steps=40) for b in (64, 128)}
+            train_small = {"metric": "graphed training step at the reference's per-rank DDP batch (one GPU, no exchange)", "unit": "ms per step",
+                           "ms_per_step": {str(b): l["ms_per_step"] for b, l in legs.items()},
+                           "ray_steps_per_s": {str(b): l["value"] for b, l in legs.items()}, "steps": 40, "dtype": legs[64]["dtype"]}
+        except Exception as e:  # noqa: BLE001
+            train_small = {"error": f"{type(e).__name__}: {e}"[:300]}
     camopt = None
     if rank == 0 and world == 1 and not args.no_train and not args.no_camopt:
         try:
@@ -547,6 +558,8 @@ def main():
             line["rehearsal"] = True
         line["secondary"] = secondary
         line["train"] = train if world == 1 or args.no_train else "second JSON line on stderr (multi-rank run)"
+        if train_small is not None:
+            line["train_small"] = train_small
         if camopt is not None:
             line.update(camopt)
         print(json.dumps(line), flush=True)

@@ -29,6 +29,9 @@ f=$(find $OUT/prof_train -name '*kernel_trace.csv' | head -1)
 [ -n "$f" ] && python $R/profiles/step_breakdown.py $f detail > $OUT/train_step_breakdown.txt 2>&1
 rm -rf $OUT/prof_train
 cd $R
+# small batches: graphed step at 64..1024 rays, the split kernel's per-pass latency, one 64-ray step's kernels
+bash profiles/r04_small.sh $TAG "64 128" > $OUT/small.log 2>&1
+timeout 300 python profiles/split_bench.py > $OUT/split_bench.log 2>&1
 bash profiles/pmc_run.sh r04_$TAG f16x3 > $OUT/pmc.log 2>&1
 mkdir -p $OUT/pmc_f16x3 && cp gpurun_out/pmc_r04_$TAG/summary.txt $OUT/pmc_f16x3/summary.txt 2>/dev/null
 rm -rf gpurun_out/pmc_r04_$TAG
