@@ -84,7 +84,7 @@ long long nrh_sdf_wide_stream_bytes(void);
  * instead of all of it.  Replaces SDFNetwork.sdf (fields/sdf_field.py:125-126) as the hierarchical sampler calls it
  * (models/neus_hint_model.py:175-246) when the batch is the reference's per-rank share (trainer/trainer.py:116-123).
  * sdf_w / sdf_b / sdf_head are nrh_sdf_eval's PRECISION-1 parameters; every value is bit-identical to
- * nrh_sdf_eval(precision 1, mode 0).  tiles = 16-point tiles per workgroup: 1, 2, or 0 (chosen from the point count).
+ * nrh_sdf_eval(precision 1, mode 0).  tiles = 16-point tiles per workgroup: 1, 2, or 0 (one while that fills the CUs at most once, else two).
  * nrh_render_forward_train takes this kernel for sampler passes of at most 16 384 points. */
 int nrh_sdf_eval_split(const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro, const float* rd,
                        const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, int tiles,

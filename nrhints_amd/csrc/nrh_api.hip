@@ -3,6 +3,7 @@
 #include "nrh_sdf.hip"
 #include "nrh_sdf_train.hip"
 #include "nrh_sdf_split.hip"
+#include "nrh_sdf_train_split.hip"
 #include "nrh_color.hip"
 #include "nrh_outside.hip"
 #include "nrh_rays.hip"
@@ -98,6 +99,7 @@ int ensure_attrs() {
     if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::MLP_LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(1));
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(2));
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_train_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::SPLT_LDS_BYTES);
   if (e != hipSuccess) return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   g_attr_done[dev] = true;
   return NRH_OK;
@@ -208,6 +210,13 @@ bool small_batch(long long npts) {
   return on && nrh::WG_WAVES == 8 && npts <= 16LL * 4 * device_cus();
 }
 
+// ... and below that, for precision f16x3, the channel-split training kernels (csrc/nrh_sdf_train_split.hip): one tile per workgroup,
+// its stages' output channels over the four waves.  NRH_SPLIT_TRAIN=0 in the environment keeps the 4-wave builds (A/B runs).
+bool split_train(int precision, long long npts) {
+  static const bool on = !(getenv("NRH_SPLIT_TRAIN") && atoi(getenv("NRH_SPLIT_TRAIN")) == 0);
+  return on && precision == 1 && npts <= 16LL * 4 * device_cus();
+}
+
 int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
   const int blocks = (a.nrays + nrh::RAYS_PER_BLOCK - 1) / nrh::RAYS_PER_BLOCK;
   hipLaunchKernelGGL(nrh::sampler_step_kernel, dim3(blocks), dim3(256), 0, st, a);
@@ -215,7 +224,7 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
 }
 
 // SDF values of a SMALL point set on the channel-split kernel (csrc/nrh_sdf_split.hip; f16x3 stages, bit-identical to sdf_kernel<0, 1>).
-// tiles: 16-point tiles per workgroup (1 or 2; 0 = 2 once the point set fills a quarter of the CUs with single tiles)
+// tiles: 16-point tiles per workgroup (1 or 2; 0 = one while single tiles fit the CUs once, two above)
 #ifndef NRH_SPLIT_MAX_PTS
 #define NRH_SPLIT_MAX_PTS 16384     // the training sampler takes the split kernel for passes of at most this many points (0: never)
 #endif
@@ -434,6 +443,10 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride; a.sdf_stride = n_per_ray;
   const hipStream_t st = (hipStream_t)stream;
+  if (split_train(precision, a.npts)) {
+    hipLaunchKernelGGL(nrh::sdf_train_split_kernel, dim3((unsigned)(a.npts / 16)), dim3(256), nrh::SPLT_LDS_BYTES, st, a);
+    return check_launch("sdf_train_split_kernel");
+  }
   if (small_batch(a.npts)) {
     const int src = nrh4s::launch_sdf_train_forward(precision, &a, sizeof(a), device_cus() * 2, st);
     if (src) return fail(src == -1 ? NRH_E_INVALID : NRH_E_LAUNCH, "nrh_sdf_train_forward: small-batch launch failed%s", "");
