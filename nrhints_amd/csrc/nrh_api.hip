@@ -214,7 +214,7 @@ bool small_batch(long long npts) {
 // its stages' output channels over the four waves.  NRH_SPLIT_TRAIN=0 in the environment keeps the 4-wave builds (A/B runs).
 bool split_train(int precision, long long npts) {
   static const bool on = !(getenv("NRH_SPLIT_TRAIN") && atoi(getenv("NRH_SPLIT_TRAIN")) == 0);
-  return on && precision == 1 && npts <= 16LL * 4 * device_cus();
+  return on && precision == 1 && npts <= 16LL * 2 * device_cus();      // (at 4 tiles per CU the 4-wave builds are as fast: profiles/r04/tsplit_ab.log)
 }
 
 int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
@@ -503,6 +503,14 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride;
   const hipStream_t st = (hipStream_t)stream;
+  if (split_train(precision, a.npts)) {
+    const dim3 gs((unsigned)(a.npts / 16)), bs(256);
+    hipLaunchKernelGGL(nrh::sdf_tangent_split_kernel, gs, bs, nrh::SPLB_LDS_BYTES, st, a);
+    rc = check_launch("sdf_tangent_split_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(nrh::sdf_adjoint_split_kernel, gs, bs, nrh::SPLB_LDS_BYTES, st, a);
+    return check_launch("sdf_adjoint_split_kernel");
+  }
   if (small_batch(a.npts)) {
     const int src = nrh4s::launch_sdf_train_sweeps(precision, &a, sizeof(a), device_cus() * 2, st);
     if (src) return fail(src == -1 ? NRH_E_INVALID : NRH_E_LAUNCH, "nrh_sdf_train_backward: small-batch launch failed%s", "");

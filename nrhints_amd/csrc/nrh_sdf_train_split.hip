@@ -292,4 +292,248 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// the two backward sweeps (sdf_tangent_kernel<1> / sdf_adjoint_kernel<1> of nrh_sdf_train.hip) in the same form
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int SPLB_OFF_G = 2 * SPL_BUF;
+constexpr int SPLB_LDS_BYTES = SPLB_OFF_G + 16 * 4 * SPLT_G_FLOATS * 4;
+
+// tangent sweep: FORWARD through L0..L7 on the tangent adjoints; coup_l and abar_{l+1} out
+__global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const char* const W = reinterpret_cast<const char*>(a.w);
+  char* const buf0 = smem;
+  char* const buf1 = smem + SPL_BUF;
+
+  const long long row = (long long)blockIdx.x * TILE_PTS + j;
+  const long long ray = row / a.n_per_ray;
+  const int jj = (int)(row - ray * a.n_per_ray);
+  const float tpar = a.t[ray * a.t_stride + jj];
+  float x3[3], g3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tpar) * 3.0f;
+    g3[c] = a.gbar[row * 3 + c] * 3.0f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  SplRing<4> ring;
+  const char* const l0c = W + (size_t)SDF_OFF_L0 * 4 + (size_t)(2 * wave) * 8192;
+  auto chunks = [&](int float_off) { return W + (size_t)float_off * 4 + (size_t)(2 * wave) * 32768; };
+  spl_prologue<2, 2, 8, 4>(ring, l0c, chunks(sdf_off_L(1)), lane);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // abar_0 (embedding layout of the forward's L0 input); wave 0 writes gebar
+  Act<1, 4> emb;
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2) {
+    float o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int b = 2 * c2 + (r >> 2);
+      o[r] = (b < 3) ? enc_dentry_dot_q(x3, g3, b * 16 + (r & 3), q) : 0.0f;
+    }
+    emb.set_chunk(c2, o);
+    if (wave == 0) {
+      float* gr = a.gebar + (size_t)row * 64 + 4 * q;
+      *reinterpret_cast<f32x4*>(gr + (2 * c2) * 16) = f32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(gr + (2 * c2 + 1) * 16) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+  }
+
+  auto stage = [&](auto SC, const char* cur, const char* nxt, char* out, const auto& bsrc, auto NCN) {
+    constexpr int S = decltype(SC)::value;
+    auto pre = [&](auto CIC) {
+      constexpr int CI = decltype(CIC)::value;
+      const int ch = 2 * wave + CI;
+      TrainPre p;
+      p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, S, a.npts, row, 2 * ch, q)));
+      p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, S, a.npts, row, 2 * ch + 1, q)));
+      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, S, a.npts, row, 2 * ch, q)));
+      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, S, a.npts, row, 2 * ch + 1, q)));
+      return p;
+    };
+    auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const TrainPre& p) {
+      constexpr int CI = decltype(CIC)::value;
+      const int ch = 2 * wave + CI;
+      const f32x4 c0 = (1.0f - p.s0) * p.t0 * acc0 * 100.0f;
+      const f32x4 c1 = (1.0f - p.s1) * p.t1 * acc1 * 100.0f;
+      f32x4 n0 = p.s0 * acc0, n1 = p.s1 * acc1;
+      if constexpr (S == 3) {
+        if (wave == 3) {
+          // abar_4 = [abar_4h (217), abar_0 (39)]: the skip connection (fields/sdf_field.py:113-114)
+          constexpr int chs = 6 + CI;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (chs == 7) n0[r] = enc_dentry_dot_q(x3, g3, (2 * chs) * 16 + r - 217, q);
+            if ((2 * chs + 1) * 16 + 4 * q + r - 217 >= 0) n1[r] = enc_dentry_dot_q(x3, g3, (2 * chs + 1) * 16 + r - 217, q);
+          }
+        }
+      }
+      st_stream(reinterpret_cast<f32x4*>(rmw(a.coup, S, a.npts, row, 2 * ch, q)), c0);
+      st_stream(reinterpret_cast<f32x4*>(rmw(a.coup, S, a.npts, row, 2 * ch + 1, q)), c1);
+      st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, S, a.npts, row, 2 * ch, q)), n0);
+      st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, S, a.npts, row, 2 * ch + 1, q)), n1);
+      if constexpr (S < 7) spl_store_act(out, j, q, ch, n0, n1);
+    };
+    if constexpr (S == 0) spl_stage<2, 2, 0, 8, 2, 4>(ring, cur, nxt, lane, bsrc, pre, epi);
+    else spl_stage<8, 2, 0, 8, decltype(NCN)::value, 4>(ring, cur, nxt, lane, bsrc, pre, epi);
+    if constexpr (S < 7) __syncthreads();
+  };
+  auto ldsb = [&](const char* in) { return SplLdsB{in + j * SPL_ROW + 16 * q}; };
+  stage(IC<0>(), l0c, chunks(sdf_off_L(1)), buf0, SplRegB{&emb}, IC<2>());
+  stage(IC<1>(), chunks(sdf_off_L(1)), chunks(sdf_off_L(2)), buf1, ldsb(buf0), IC<2>());
+  stage(IC<2>(), chunks(sdf_off_L(2)), chunks(sdf_off_L(3)), buf0, ldsb(buf1), IC<2>());
+  stage(IC<3>(), chunks(sdf_off_L(3)), chunks(sdf_off_L(4)), buf1, ldsb(buf0), IC<2>());
+  stage(IC<4>(), chunks(sdf_off_L(4)), chunks(sdf_off_L(5)), buf0, ldsb(buf1), IC<2>());
+  stage(IC<5>(), chunks(sdf_off_L(5)), chunks(sdf_off_L(6)), buf1, ldsb(buf0), IC<2>());
+  stage(IC<6>(), chunks(sdf_off_L(6)), chunks(sdf_off_L(7)), buf0, ldsb(buf1), IC<2>());
+  stage(IC<7>(), chunks(sdf_off_L(7)), nullptr, buf1, ldsb(buf0), IC<0>());
+}
+
+// value sweep: REVERSE through FEAT^T, R7..R1, R0 on the value adjoints; zbar_l and pbar out
+__global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const char* const W = reinterpret_cast<const char*>(a.w);
+  char* const buf0 = smem;
+  char* const buf1 = smem + SPL_BUF;
+  float* const G = reinterpret_cast<float*>(smem + SPLB_OFF_G);
+  float* const Gl = G + (j * 4 + q) * SPLT_G_FLOATS;
+
+  const long long row = (long long)blockIdx.x * TILE_PTS + j;
+  const long long ray = row / a.n_per_ray;
+  const int jj = (int)(row - ray * a.n_per_ray);
+  const float tpar = a.t[ray * a.t_stride + jj];
+  float x3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tpar) * 3.0f;
+  const float sb3 = a.sbar[row] / 3.0f;
+  // fbar of this wave's 64 channels -> B rows of the first stage
+  f32x4 fb[2][2];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int ch = 2 * wave + ci;
+    fb[ci][0] = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.fbar, 0, a.npts, row, 2 * ch, q)));
+    fb[ci][1] = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.fbar, 0, a.npts, row, 2 * ch + 1, q)));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  SplRing<4> ring;
+  auto chunks = [&](int float_off) { return W + (size_t)float_off * 4 + (size_t)(2 * wave) * 32768; };
+  const char* const ftc = reinterpret_cast<const char*>(a.wt_feat) + (size_t)(2 * wave) * 32768;
+  spl_prologue<8, 2, 8, 4>(ring, ftc, chunks(sdf_off_R(7)), lane);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) spl_store_act(buf0, j, q, 2 * wave + ci, fb[ci][0], fb[ci][1]);
+  __syncthreads();
+
+  // S = 8: FEAT^T (-> zbar_7);  S = 7..1: R_S = W_S^T (-> zbar_{S-1})
+  auto stage = [&](auto SC, const char* cur, const char* nxt, const char* in, char* out, auto NCN) {
+    constexpr int S = decltype(SC)::value;
+    constexpr int lz = S - 1;
+    auto pre = [&](auto CIC) {
+      constexpr int CI = decltype(CIC)::value;
+      const int ch = 2 * wave + CI;
+      TrainPre p;
+      p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch, q)));
+      p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
+      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch, q)));
+      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
+      if constexpr (S == 8) {
+        p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
+        p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
+      }
+      return p;
+    };
+    auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const TrainPre& p) {
+      constexpr int CI = decltype(CIC)::value;
+      const int ch = 2 * wave + CI;
+      if constexpr (S == 8) {
+        acc0 += p.w0 * sb3;  // hbar_7 = Wf^T fbar + sbar w_s / 3
+        acc1 += p.w1 * sb3;
+      }
+      if constexpr (S == 4) {
+        if (wave == 3) {
+          // adjoint of the embedding through the skip connection (inputs 217..255 of L4): parked for wave 0
+          constexpr int chs = 6 + CI;
+          if (2 * chs >= 13) *reinterpret_cast<f32x4*>(Gl + 16 + (2 * chs - 13) * 4) = acc0;
+          *reinterpret_cast<f32x4*>(Gl + 16 + (2 * chs + 1 - 13) * 4) = acc1;
+        }
+      }
+      const f32x4 z0 = p.s0 * acc0 + p.t0, z1 = p.s1 * acc1 + p.t1;
+      st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch, q)), z0);
+      st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1);
+      spl_store_act(out, j, q, ch, z0, z1);
+    };
+    spl_stage<8, 2, 0, 8, decltype(NCN)::value, 4>(ring, cur, nxt, lane, SplLdsB{in + j * SPL_ROW + 16 * q}, pre, epi);
+    __syncthreads();
+  };
+  stage(IC<8>(), ftc, chunks(sdf_off_R(7)), buf0, buf1, IC<2>());
+  stage(IC<7>(), chunks(sdf_off_R(7)), chunks(sdf_off_R(6)), buf1, buf0, IC<2>());
+  stage(IC<6>(), chunks(sdf_off_R(6)), chunks(sdf_off_R(5)), buf0, buf1, IC<2>());
+  stage(IC<5>(), chunks(sdf_off_R(5)), chunks(sdf_off_R(4)), buf1, buf0, IC<2>());
+  stage(IC<4>(), chunks(sdf_off_R(4)), chunks(sdf_off_R(3)), buf0, buf1, IC<2>());
+  stage(IC<3>(), chunks(sdf_off_R(3)), chunks(sdf_off_R(2)), buf1, buf0, IC<2>());
+  stage(IC<2>(), chunks(sdf_off_R(2)), chunks(sdf_off_R(1)), buf0, buf1, IC<2>());
+  const char* const r0c = (wave < 2) ? W + (size_t)SDF_OFF_R0 * 4 + (size_t)wave * 32768 : nullptr;
+  stage(IC<1>(), chunks(sdf_off_R(1)), r0c, buf1, buf0, IC<1>());
+
+  // R0: adjoint of the 39 embedding entries (waves 0, 1), then through the encoding on wave 0 (same tail as the forward's gradient)
+  if (wave < 2) {
+    auto pre = [&](auto) { return 0; };
+    auto epi = [&](auto, f32x4 acc0, f32x4 acc1, int) {
+      *reinterpret_cast<f32x4*>(Gl + wave * 8) = acc0;
+      *reinterpret_cast<f32x4*>(Gl + wave * 8 + 4) = acc1;
+    };
+    spl_stage<8, 1, 0, 0, 0, 4>(ring, r0c, nullptr, lane, SplLdsB{buf0 + j * SPL_ROW + 16 * q}, pre, epi);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float ge[16], sk[12];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Gl + b * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ge[b * 4 + r] = v[r];
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Gl + 16 + b * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sk[b * 4 + r] = v[r];
+    }
+    float dx[3] = {0.f, 0.f, 0.f};
+    {
+      float dc[39];
+      nerf_enc_dall<3, 6>(x3, dc);
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int e = b * 16 + 4 * qq + r;
+            if (e < 39) dx[nerf_enc_dim<3, 6>(e)] += (q == qq) ? ge[b * 4 + r] * dc[e] : 0.0f;
+            const int es = (b + 13) * 16 + 4 * qq + r - 217;
+            if (es >= 0 && es < 39) dx[nerf_enc_dim<3, 6>(es)] += (q == qq) ? sk[b * 4 + r] * dc[es] : 0.0f;
+          }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dx[c] += __shfl_xor(dx[c], 16, 64);
+      dx[c] += __shfl_xor(dx[c], 32, 64);
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.pbar[row * 3 + c] = dx[c] * 3.0f;
+    }
+  }
+}
+
 }  // namespace nrh

@@ -6,7 +6,7 @@ import collections, csv, sys
 DETAIL = len(sys.argv) > 2 and sys.argv[2] == "detail"
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "sdf_kernel<3" in r["Kernel_Name"] or "sdf32_kernel<4>" in r["Kernel_Name"]]   # the training forward marks a step
+idx = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("sdf_kernel<3", "sdf32_kernel<4>", "sdf_train_split_kernel"))]   # the training forward marks a step
 
 
 def step_start(i):
