@@ -24,7 +24,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_shadow_alpha_forward", "nrh_shadow_alpha_backward", "nrh_alpha_train_forward_n", "nrh_alpha_train_backward_n",
             "nrh_sample_primary", "nrh_alpha_blend_forward", "nrh_alpha_blend_backward",
             "nrh_color_transposed_floats", "nrh_color_train_forward", "nrh_color_train_forward_grouped", "nrh_color_train_backward",
-            "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes", "nrh_sdf_eval_split",
+            "nrh_weight_norm_fold", "nrh_weight_norm_fold_backward", "nrh_sdf_eval_wide", "nrh_sdf_wide_stream_bytes", "nrh_sdf_eval_split", "nrh_sdf_grad_split",
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
             "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite", "nrh_sphere_trace", "nrh_sphere_trace_workspace_floats",
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
@@ -107,6 +107,7 @@ def load():
     lib.nrh_sdf_eval_wide.argtypes = [c_int, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
     lib.nrh_sdf_wide_stream_bytes.restype = c_longlong
     lib.nrh_sdf_eval_split.argtypes = [P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, c_int, P]
+    lib.nrh_sdf_grad_split.argtypes = [P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P]
     lib.nrh_sampler_step.argtypes = [P, P, P, P, P, P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, c_int,
                                      c_int, c_int, P]
     lib.nrh_color_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, P, P, c_longlong, P, P]

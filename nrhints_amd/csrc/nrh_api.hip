@@ -100,6 +100,7 @@ int ensure_attrs() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(1));
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::split_lds_bytes(2));
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_train_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::SPLT_LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nrh::sdf_grad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nrh::SPLG_LDS_BYTES);
   if (e != hipSuccess) return fail(NRH_E_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   g_attr_done[dev] = true;
   return NRH_OK;
@@ -225,6 +226,9 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
 
 // SDF values of a SMALL point set on the channel-split kernel (csrc/nrh_sdf_split.hip; f16x3 stages, bit-identical to sdf_kernel<0, 1>).
 // tiles: 16-point tiles per workgroup (1 or 2; 0 = one while single tiles fit the CUs once, two above)
+#ifndef NRH_SPLIT_GRAD_MAX_PTS
+#define NRH_SPLIT_GRAD_MAX_PTS 16384    // ... and the shadow rays' sdf + gradient pass of a training batch of at most this many points
+#endif
 #ifndef NRH_SPLIT_MAX_PTS
 #define NRH_SPLIT_MAX_PTS 16384     // the training sampler takes the split kernel for passes of at most this many points (0: never)
 #endif
@@ -254,6 +258,30 @@ int sdf_split_impl(const float* w, const float* b, const float* head, const floa
   else hipLaunchKernelGGL(nrh::sdf_split_kernel<2>, dim3(grid), dim3(256), nrh::split_lds_bytes(2), st, a);
   timing_end(st, tl, timed);
   return check_launch("sdf_split_kernel");
+}
+
+// sdf + d sdf / dx of a SMALL point set on the channel-split kernel (csrc/nrh_sdf_train_split.hip sdf_grad_split_kernel; f16x3 stages,
+// bit-identical to sdf_kernel<1, 1>)
+int sdf_grad_split_impl(const float* w, const float* b, const float* head, const float* ro, const float* rd, const float* t, int t_stride,
+                        int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, hipStream_t st) {
+  if (!w || !b || !head || !ro || !rd || !t || !sdf || !grad) return fail(NRH_E_INVALID, "nrh_sdf_grad_split: null pointer%s", "");
+  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray || sdf_stride < n_per_ray)
+    return fail(NRH_E_INVALID, "nrh_sdf_grad_split: bad n_per_ray/stride%s", "");
+  if (nrays == 0) return NRH_OK;
+  const long long npts = nrays * n_per_ray;
+  if (npts > (1LL << 24)) return fail(NRH_E_INVALID, "nrh_sdf_grad_split: at most 16 777 216 points per call%s", "");
+  const int arc = ensure_attrs();
+  if (arc) return arc;
+  nrh::SdfArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w = w; a.b = b; a.head = head; a.ro = ro; a.rd = rd; a.t = t; a.sdf = sdf; a.grad = grad; a.npts = npts; a.n_per_ray = n_per_ray;
+  a.t_stride = t_stride; a.sdf_stride = sdf_stride;
+  TimedLaunch tl;
+  bool timed;
+  timing_begin(1, st, tl, timed);
+  hipLaunchKernelGGL(nrh::sdf_grad_split_kernel, dim3((unsigned)((npts + 15) / 16)), dim3(256), nrh::SPLG_LDS_BYTES, st, a);
+  timing_end(st, tl, timed);
+  return check_launch("sdf_grad_split_kernel");
 }
 
 int color_eval_impl(int prec, int hints, const float* w, const float* b, const float* feat, const float* ro, const float* rd,
@@ -356,7 +384,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 138; }
+int nrh_version(void) { return 139; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -420,6 +448,11 @@ int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, con
 int nrh_sdf_eval_split(const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro, const float* rd, const float* t,
                        int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, int tiles, void* stream) {
   return sdf_split_impl(sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, tiles, (hipStream_t)stream);
+}
+
+int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro, const float* rd, const float* t,
+                       int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, void* stream) {
+  return sdf_grad_split_impl(sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, (hipStream_t)stream);
 }
 
 long long nrh_sdf_wide_stream_bytes(void) { return nrh32::wide_sdf_stream_bytes_total(); }
@@ -1318,8 +1351,12 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     if (rc) return rc;
     // the shadow ray's alpha only needs <direction, gradient>: with the wide kernels that is mode 3 (forward mode, no scratch)
     const int smode = (net->shadow_jvp && net->precision == 1 && net->sdf_w32 && net->sdf_tab32) ? 3 : 1;
-    rc = sdf_eval_impl(net->precision, smode, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, o_tmid_s, 128, 128, n, ws_sdf_s,
-                       128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
+    static const long long gsplit_max = getenv("NRH_SPLIT_GRAD_MAX_PTS") ? atoll(getenv("NRH_SPLIT_GRAD_MAX_PTS")) : (long long)NRH_SPLIT_GRAD_MAX_PTS;
+    if (train && net->precision == 1 && n * 128 <= gsplit_max)     // small training batch: the channel-split kernel (as the sampler passes)
+      rc = sdf_grad_split_impl(net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, o_tmid_s, 128, 128, n, ws_sdf_s, 128, ws_grad_s, st);
+    else
+      rc = sdf_eval_impl(net->precision, smode, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, o_tmid_s, 128, 128, n, ws_sdf_s,
+                         128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
     if (rc) return rc;
   }
   {

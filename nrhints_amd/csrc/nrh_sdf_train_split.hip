@@ -536,4 +536,231 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// sdf + d sdf / dx without saves (sdf_kernel<1, 1>: what the shadow rays' alpha needs, models/neus_hint_model.py:335-336) in the
+// same form.  sigma' never leaves the wave that produced it: 8 layers x 2 chunks x 8 values as unorm16 pairs = 64 VGPRs (the
+// 16-point kernel parks the same words in a global scratch); t_7 goes straight into R7's B rows (no feature stage in between).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int SPLG_LDS_BYTES = SPLT_LDS_BYTES;
+
+__global__ __launch_bounds__(256, 2) void sdf_grad_split_kernel(const SdfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const char* const W = reinterpret_cast<const char*>(a.w);
+  char* const buf0 = smem;
+  char* const buf1 = smem + SPL_BUF;
+  float* const tab = reinterpret_cast<float*>(smem + SPLT_OFF_TAB);
+  char* const h7 = smem + SPLT_OFF_H7;
+  float* const G = reinterpret_cast<float*>(smem + SPLT_OFF_G);
+  float* const Gl = G + (j * 4 + q) * SPLT_G_FLOATS;
+
+  const long long P = (long long)blockIdx.x * TILE_PTS + j;
+  const bool valid = P < a.npts;
+  const long long Pc = valid ? P : a.npts - 1;
+  const long long ray = Pc / a.n_per_ray;
+  const int jj = (int)(Pc - ray * a.n_per_ray);
+  const float tt = a.t[ray * a.t_stride + jj];
+  float x3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tt) * 3.0f;  // inputs * scale
+  {
+    const f32x4* const bsrc = reinterpret_cast<const f32x4*>(a.b);
+    f32x4* const bdst = reinterpret_cast<f32x4*>(tab);
+    const f32x4 v0 = bsrc[threadIdx.x], v1 = bsrc[256 + threadIdx.x];
+    const f32x4 v2 = (threadIdx.x < 64) ? bsrc[512 + threadIdx.x] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float hv = a.head[threadIdx.x], hl = a.head[256];
+    bdst[threadIdx.x] = v0;
+    bdst[256 + threadIdx.x] = v1;
+    if (threadIdx.x < 64) bdst[512 + threadIdx.x] = v2;
+    tab[9 * 256 + threadIdx.x] = hv;
+    if (threadIdx.x == 0) tab[9 * 256 + 256] = hl;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  SplRing<4> ring;
+  const char* const l0c = W + (size_t)SDF_OFF_L0 * 4 + (size_t)(2 * wave) * 8192;
+  auto chunks = [&](int float_off) { return W + (size_t)float_off * 4 + (size_t)(2 * wave) * 32768; };
+  spl_prologue<2, 2, 8, 4>(ring, l0c, chunks(sdf_off_L(1)), lane);
+  __builtin_amdgcn_sched_barrier(0);
+
+  Act<1, 4> emb;
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2) {
+    float o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int b = 2 * c2 + (r >> 2);
+      o[r] = (b < 3) ? nerf_enc_entry_q<3, 6>(x3, b * 16 + (r & 3), q) : 0.0f;
+    }
+    emb.set_chunk(c2, o);
+  }
+  __syncthreads();     // the tables are in LDS
+
+  u32x4 sg[7][2];      // sigma' of layers 0..6, this wave's two chunks: unorm16 pairs exactly as dsig_store<1> packs them
+
+  auto fwd = [&](auto SC, const char* cur, const char* nxt, char* out, const auto& bsrc) {
+    constexpr int S = decltype(SC)::value;
+    auto pre = [&](auto CIC) {
+      constexpr int CI = decltype(CIC)::value;
+      const int ch = 2 * wave + CI;
+      SplPreF p;
+      p.a0 = *reinterpret_cast<const f32x4*>(tab + S * 256 + (2 * ch) * 16 + 4 * q);
+      p.a1 = *reinterpret_cast<const f32x4*>(tab + S * 256 + (2 * ch + 1) * 16 + 4 * q);
+      if constexpr (S == 7) {
+        p.b0 = *reinterpret_cast<const f32x4*>(tab + 9 * 256 + (2 * ch) * 16 + 4 * q);
+        p.b1 = *reinterpret_cast<const f32x4*>(tab + 9 * 256 + (2 * ch + 1) * 16 + 4 * q);
+      }
+      return p;
+    };
+    auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const SplPreF& p) {
+      constexpr int CI = decltype(CIC)::value;
+      const int ch = 2 * wave + CI;
+      f32x4 h0, h1, d0, d1;
+      softplus100_4<true>(acc0 + p.a0, h0, d0);
+      softplus100_4<true>(acc1 + p.a1, h1, d1);
+      if constexpr (S == 3) {
+        if (wave == 3) {
+          constexpr int chs = 6 + CI;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (chs == 7) {
+              h0[r] = nerf_enc_entry_q<3, 6>(x3, (2 * chs) * 16 + r - 217, q);
+              d0[r] = 0.0f;
+            }
+            if ((2 * chs + 1) * 16 + 4 * q + r - 217 >= 0) {
+              h1[r] = nerf_enc_entry_q<3, 6>(x3, (2 * chs + 1) * 16 + r - 217, q);
+              d1[r] = 0.0f;
+            }
+          }
+        }
+      }
+      if constexpr (S == 7) {
+        // head operand for wave 0; t_7 = sigma'_7 * w_s / 3 is the reverse chain's first B operand
+        char* const p7 = h7 + j * SPLT_ROW7 + ((2 * ch) * 16 + 4 * q) * 4;
+        *reinterpret_cast<f32x4*>(p7) = h0;
+        *reinterpret_cast<f32x4*>(p7 + 64) = h1;
+        spl_store_act(out, j, q, ch, d0 * (p.b0 * (1.0f / 3.0f)), d1 * (p.b1 * (1.0f / 3.0f)));
+      } else {
+        sg[S][CI] = u32x4{unorm16x2(d0[0], d0[1]), unorm16x2(d0[2], d0[3]), unorm16x2(d1[0], d1[1]), unorm16x2(d1[2], d1[3])};
+        spl_store_act(out, j, q, ch, h0, h1);
+      }
+    };
+    if constexpr (S == 0) spl_stage<2, 2, 0, 8, 2, 4>(ring, cur, nxt, lane, bsrc, pre, epi);
+    else spl_stage<8, 2, 0, 8, 2, 4>(ring, cur, nxt, lane, bsrc, pre, epi);
+    __syncthreads();
+  };
+  auto ldsb = [&](const char* in) { return SplLdsB{in + j * SPL_ROW + 16 * q}; };
+  fwd(IC<0>(), l0c, chunks(sdf_off_L(1)), buf0, SplRegB{&emb});
+  fwd(IC<1>(), chunks(sdf_off_L(1)), chunks(sdf_off_L(2)), buf1, ldsb(buf0));
+  fwd(IC<2>(), chunks(sdf_off_L(2)), chunks(sdf_off_L(3)), buf0, ldsb(buf1));
+  fwd(IC<3>(), chunks(sdf_off_L(3)), chunks(sdf_off_L(4)), buf1, ldsb(buf0));
+  fwd(IC<4>(), chunks(sdf_off_L(4)), chunks(sdf_off_L(5)), buf0, ldsb(buf1));
+  fwd(IC<5>(), chunks(sdf_off_L(5)), chunks(sdf_off_L(6)), buf1, ldsb(buf0));
+  fwd(IC<6>(), chunks(sdf_off_L(6)), chunks(sdf_off_L(7)), buf0, ldsb(buf1));
+  fwd(IC<7>(), chunks(sdf_off_L(7)), chunks(sdf_off_R(7)), buf1, ldsb(buf0));
+
+  // ---- reverse chain R7..R1: g <- W_l^T (sigma'_l * g) ----
+  auto rev = [&](auto LC, const char* cur, const char* nxt, const char* in, char* out, auto NCN) {
+    constexpr int L = decltype(LC)::value;
+    auto pre = [&](auto) { return 0; };
+    auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, int) {
+      constexpr int CI = decltype(CIC)::value;
+      const int ch = 2 * wave + CI;
+      if constexpr (L == 4) {
+        if (wave == 3) {
+          constexpr int chs = 6 + CI;
+          if (2 * chs >= 13) *reinterpret_cast<f32x4*>(Gl + 16 + (2 * chs - 13) * 4) = acc0;
+          *reinterpret_cast<f32x4*>(Gl + 16 + (2 * chs + 1 - 13) * 4) = acc1;
+        }
+      }
+      const u32x4 v = sg[L - 1][CI];          // dsig_decode<1>
+      const f32x4 d0 = f32x4{(float)(v[0] & 0xffffu), (float)(v[0] >> 16), (float)(v[1] & 0xffffu), (float)(v[1] >> 16)} * (1.0f / 65535.0f);
+      const f32x4 d1 = f32x4{(float)(v[2] & 0xffffu), (float)(v[2] >> 16), (float)(v[3] & 0xffffu), (float)(v[3] >> 16)} * (1.0f / 65535.0f);
+      spl_store_act(out, j, q, ch, acc0 * d0, acc1 * d1);
+    };
+    spl_stage<8, 2, 0, 8, decltype(NCN)::value, 4>(ring, cur, nxt, lane, ldsb(in), pre, epi);
+    __syncthreads();
+  };
+  rev(IC<7>(), chunks(sdf_off_R(7)), chunks(sdf_off_R(6)), buf1, buf0, IC<2>());
+  rev(IC<6>(), chunks(sdf_off_R(6)), chunks(sdf_off_R(5)), buf0, buf1, IC<2>());
+  rev(IC<5>(), chunks(sdf_off_R(5)), chunks(sdf_off_R(4)), buf1, buf0, IC<2>());
+  rev(IC<4>(), chunks(sdf_off_R(4)), chunks(sdf_off_R(3)), buf0, buf1, IC<2>());
+  rev(IC<3>(), chunks(sdf_off_R(3)), chunks(sdf_off_R(2)), buf1, buf0, IC<2>());
+  rev(IC<2>(), chunks(sdf_off_R(2)), chunks(sdf_off_R(1)), buf0, buf1, IC<2>());
+  const char* const r0c = (wave < 2) ? W + (size_t)SDF_OFF_R0 * 4 + (size_t)wave * 32768 : nullptr;
+  rev(IC<1>(), chunks(sdf_off_R(1)), r0c, buf1, buf0, IC<1>());
+
+  if (wave < 2) {
+    auto pre = [&](auto) { return 0; };
+    auto epi = [&](auto, f32x4 acc0, f32x4 acc1, int) {
+      *reinterpret_cast<f32x4*>(Gl + wave * 8) = acc0;
+      *reinterpret_cast<f32x4*>(Gl + wave * 8 + 4) = acc1;
+    };
+    spl_stage<8, 1, 0, 0, 0, 4>(ring, r0c, nullptr, lane, ldsb(buf0), pre, epi);
+  }
+  __syncthreads();
+
+  if (wave == 0) {
+    float head_part = 0.0f;
+    const char* const r7 = h7 + j * SPLT_ROW7;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(tab + 9 * 256 + (2 * ch) * 16 + 4 * q);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(tab + 9 * 256 + (2 * ch + 1) * 16 + 4 * q);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(r7 + ((2 * ch) * 16 + 4 * q) * 4);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(r7 + ((2 * ch + 1) * 16 + 4 * q) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        head_part += w0[r] * h0[r];
+        head_part += w1[r] * h1[r];
+      }
+    }
+    float part = head_part;
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (valid && q == 0) a.sdf[ray * a.sdf_stride + jj] = (part + tab[9 * 256 + 256]) / 3.0f;
+
+    float ge[16], sk[12];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Gl + b * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ge[b * 4 + r] = v[r];
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Gl + 16 + b * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sk[b * 4 + r] = v[r];
+    }
+    float dx[3] = {0.f, 0.f, 0.f};
+    {
+      float dc[39];
+      nerf_enc_dall<3, 6>(x3, dc);
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int e = b * 16 + 4 * qq + r;
+            if (e < 39) dx[nerf_enc_dim<3, 6>(e)] += (q == qq) ? ge[b * 4 + r] * dc[e] : 0.0f;
+            const int es = (b + 13) * 16 + 4 * qq + r - 217;
+            if (es >= 0 && es < 39) dx[nerf_enc_dim<3, 6>(es)] += (q == qq) ? sk[b * 4 + r] * dc[es] : 0.0f;
+          }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dx[c] += __shfl_xor(dx[c], 16, 64);
+      dx[c] += __shfl_xor(dx[c], 32, 64);
+    }
+    if (valid && q == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.grad[P * 3 + c] = dx[c] * 3.0f;  // d(3x)/dx
+    }
+  }
+}
+
 }  // namespace nrh

@@ -90,6 +90,23 @@ def sdf_eval_split(sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_stride: 
 
 
 @_lib.on_tensor_device
+def sdf_grad_split(sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_stride: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """sdf and d sdf / dx of a small point set on the channel-split kernel: ``sdf_eval`` mode 1 with the precision-1 (f16x3) packed
+    parameters, bit-identical values, no scratch.  -> (sdf [nrays, n_per_ray], grad [nrays * n_per_ray, 3])."""
+    lib = _lib.load()
+    nrays = ro.shape[0]
+    t_stride = n_per_ray if t_stride is None else t_stride
+    sdf = torch.empty(nrays, n_per_ray, dtype=torch.float32, device=ro.device)
+    grad = torch.empty(nrays * n_per_ray, 3, dtype=torch.float32, device=ro.device)
+    P = _lib.ptr
+    with torch.cuda.device(ro.device):
+        rc = lib.nrh_sdf_grad_split(P(sdf_w, sdf_w.dtype), P(sdf_b), P(sdf_head), P(ro), P(rd), P(t), t_stride, n_per_ray, nrays,
+                                    P(sdf), n_per_ray, P(grad), _lib.stream_handle(ro.device))
+    _lib.check(rc, "nrh_sdf_grad_split")
+    return sdf, grad
+
+
+@_lib.on_tensor_device
 def sdf_at_points(mode: int, sdf_w, sdf_b, sdf_head, pts):
     """Convenience: free points [P,3] (one 'ray' per point, t = 0)."""
     zeros = torch.zeros_like(pts)

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 138
+    assert lib.nrh_version() == 139
     lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
     from nrhints_amd import packing32 as pk32
     assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
@@ -240,6 +240,7 @@ def test_training_entry_points_validate_arguments_without_a_device():
     # the wide-kernel entry validates its pointers before touching a device
     assert lib.nrh_sdf_eval_wide(0, None, None, None, None, None, 1, 1, 1, None, 1, None, None, None, None) == -1 and "null" in err()
     assert lib.nrh_sdf_eval_split(None, None, None, None, None, None, 1, 1, 1, None, 1, 0, None) == -1 and "null" in err()
+    assert lib.nrh_sdf_grad_split(None, None, None, None, None, None, 1, 1, 1, None, 1, None, None) == -1 and "null" in err()
     assert lib.nrh_color_transposed_floats(1) == 303104 and lib.nrh_color_transposed_floats(0) == 286720
 
 
