@@ -92,7 +92,7 @@ int nrh_sdf_eval_split(const float* sdf_w, const float* sdf_b, const float* sdf_
 /* The same for sdf + d sdf / dx (mode 1: SDFNetwork.gradient, fields/sdf_field.py:136-148, as the shadow rays' get_alpha needs it,
  * models/neus_hint_model.py:335-336): one 16-point tile per workgroup, sigma' in the producing wave's registers.  grad [npts,3].
  * Bit-identical to nrh_sdf_eval(precision 1, mode 1).  nrh_render_forward_train takes it for the shadow pass of batches of at most
- * 16 384 points (128 rays). */
+ * 12 288 points (96 rays). */
 int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro, const float* rd,
                        const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad,
                        void* stream);
