@@ -227,7 +227,7 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
 // SDF values of a SMALL point set on the channel-split kernel (csrc/nrh_sdf_split.hip; f16x3 stages, bit-identical to sdf_kernel<0, 1>).
 // tiles: 16-point tiles per workgroup (1 or 2; 0 = one while single tiles fit the CUs once, two above)
 #ifndef NRH_SPLIT_GRAD_MAX_PTS
-XX
+#define NRH_SPLIT_GRAD_MAX_PTS 12288    // ... and the shadow rays' sdf + gradient pass of a training batch of at most this many points (96 rays; profiles/r04/grad_split_bench.log)
 #endif
 #ifndef NRH_SPLIT_MAX_PTS
 #define NRH_SPLIT_MAX_PTS 16384     // the training sampler takes the split kernel for passes of at most this many points (0: never)
