@@ -26,8 +26,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 rank 0, N = 1 only)
   secondary     the same render in the other matrix arithmetic (exact fp32 MFMA) - value and roofline fraction
   train         BASELINE.json configs[2]: 1024-ray training steps (forward + backward + Adam; N = 1: the whole step
-                replayed as one hipGraph, reported inside the headline line; N > 1: eager steps with one flat RCCL gradient
-                all-reduce per step, run AFTER the headline line is out and reported as a second JSON line on stderr)
+                replayed as one hipGraph, reported inside the headline line; N > 1: two hipGraphs around one flat RCCL gradient
+                all-reduce per step, run AFTER the headline line is out and reported as a second JSON line on stderr;
+                --train-batch-global G: the reference's split batch, per-rank = G // N)
+  train_small   (N = 1) the graphed step at the reference's per-rank DDP batches, 64 and 128 rays (trainer/trainer.py:116-123)
+  train_camopt, register_view   (N = 1) the reference's default preset nr-hints-cam-opt on the fused step; 500-step view registration
 """
 import argparse
 import ctypes
