@@ -94,18 +94,19 @@ def test_training_sampler_takes_the_split_kernel(sscene):
     assert np.mean(np.abs(w_t - w_e) < 1e-3) > 0.995
 
 
-@pytest.mark.parametrize("prec", ["f16x3", "f32"])
-def test_small_batch_builds_of_the_training_kernels_are_bit_identical(scene_states, prec):
-    """csrc/nrh_small.hip: the SDF training forward and its two backward sweeps compiled with 4 waves per workgroup, taken while the
-    batch has at most 4 tiles per CU (<= 16 384 points on 256 CUs).  A tile's arithmetic does not depend on how many tiles share a
-    workgroup: the same 8 192 points evaluated alone (4-wave builds) and as the head of a 32 768-point call (8-wave builds) give
-    the same bits in every output and saved array."""
+@pytest.mark.parametrize("prec,small", [("f16x3", 8192), ("f16x3", 16384), ("f32", 8192)])
+def test_small_batch_builds_of_the_training_kernels_are_bit_identical(scene_states, prec, small):
+    """The small-batch forms of the SDF training forward and its two backward sweeps: the channel-split kernels
+    (csrc/nrh_sdf_train_split.hip: f16x3, at most 2 tiles per CU = 8 192 points on 256 CUs) and the 4-wave builds
+    (csrc/nrh_small.hip: both precisions, at most 4 tiles per CU = 16 384 points).  A tile's arithmetic does not depend on how its
+    work is spread: the same points evaluated alone and as the head of a 4x larger call (8-wave builds) give the same bits in every
+    output and saved array."""
     st = scene_states["b"]
     model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision=prec)
     model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
     pk = model.cuda().eval().packed_params(torch.device("cuda", torch.cuda.current_device()))
     g = torch.Generator().manual_seed(3)
-    small, big = 8192, 32768
+    big = 4 * small
     pts = ((torch.rand(big, 3, generator=g) * 2 - 1) * 0.9).cuda()
     s_sdf, s_feat, s_grad, s_sv = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts[:small].contiguous())
     b_sdf, b_feat, b_grad, b_sv = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts)
