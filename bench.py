@@ -395,7 +395,7 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
             "mode": "hipGraph replay" if world == 1 else "two hipGraphs around one flat RCCL all-reduce per step",
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
             "bound_note": "the step's five big kernels (dW, SDF training forward, tangent / value sweeps, reflectance adjoint) are HBM-bound on "
-                          "the saved activations (profiles/r03/pmc_train_summary.txt, DESIGN 7b / 7c); the MFMA fraction below is the "
+                          "the saved activations (profiles/r04/pmc_train_summary.txt: 22.1 GB per step at ~5 TB/s, DESIGN 7b / 7c); the MFMA fraction below is the "
                           "SURVEY 8d convention",
             "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
                          "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
