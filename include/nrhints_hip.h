@@ -111,7 +111,8 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
  *   save_s1 [8][npts][256] (sigmoid(100 z)), save_t [8][npts][256] (reverse-chain stage inputs),
  *   save_ge [npts][128] (cols 0..38: d sdf/d embedding via layer 0; cols 73..111: via the skip connection).
  * nrh_sdf_train_backward: given the adjoints  sbar [npts], fbar [npts,256], gbar [npts,3]  of the three outputs
- *   writes  abar, coup, zbar [8][npts][256], gebar [npts][64] and pbar [npts,3] (adjoint of the points through the
+ *   writes  abar, zbar [8][npts][256] (row-major), coup (8 * npts * 256 floats of hand-off between the two sweeps, tile-native:
+ *   opaque to the caller), gebar [npts][64] and pbar [npts,3] (adjoint of the points through the
  *   value path; the caller adds the term through the encoding's second derivative, see sdf_function.py).
  *   wt_feat: the feature head transposed, packed as one 256x256 stage (packing.pack_feat_transposed). */
 int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,

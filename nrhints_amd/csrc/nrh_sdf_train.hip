@@ -33,7 +33,7 @@ struct SdfTrainArgs {
   const float* tt;       // [8][npts][256] from the forward
   const float* gbar;     // [npts][3]   tangent sweep in
   float* abar;           // [8][npts][256] tangent sweep out: abar_{l+1} at index l (index 7: s'_7 tbar_7, for d w_s)
-  float* coup;           // [8][npts][256] tangent sweep out / value sweep in
+  float* coup;           // [8][npts][256] floats, tangent sweep out / value sweep in: tile-native (coup_off), not row-major
   float* gebar;          // [npts][64]  tangent sweep out: abar_0 (39 used)
   const float* fbar;     // [npts][256] value sweep in
   const float* sbar;     // [npts]      value sweep in
@@ -77,6 +77,19 @@ __device__ __forceinline__ float enc_dentry_dot_q(const float (&x)[3], const flo
   return (kind == 2) ? c * mul : ((kind == 1) ? mul : 0.0f);
 }
 
+// `coup` is a hand-off between the two sweeps and nothing else reads it: TILE-NATIVE instead of row-major - layer l, tile, 16-channel
+// block, lane: every store / load instruction of a wave is one contiguous KiB (profiles/r04/rowstore.log: 6.3 TB/s stores and
+// 6.4-7.1 TB/s loads against 5.6 / 4.2 for the 16 x 64-byte pattern of the row-major arrays).  Same size, [8][npts][256] floats.
+#ifndef NRH_COUP_TILE
+#define NRH_COUP_TILE 1
+#endif
+__device__ __forceinline__ size_t coup_off(int l, long long npts, long long row, int blk, int lane) {
+#if NRH_COUP_TILE
+  return ((size_t)l * (size_t)npts + (size_t)(row >> 4) * 16) * 256 + (size_t)blk * 256 + lane * 4;
+#else
+  return ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * (lane >> 4);
+#endif
+}
 __device__ __forceinline__ const float* rmc(const float* base, int l, long long npts, long long row, int blk, int q) {
   return base + ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * q;
 }
@@ -154,8 +167,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
           }
         }
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>(rmw(a.coup, s, a.npts, row, 2 * ch, q)), c0);
-          st_stream(reinterpret_cast<f32x4*>(rmw(a.coup, s, a.npts, row, 2 * ch + 1, q)), c1);
+          st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(s, a.npts, row, 2 * ch, lane)), c0);
+          st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(s, a.npts, row, 2 * ch + 1, lane)), c1);
           st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, s, a.npts, row, 2 * ch, q)), n0);
           st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, s, a.npts, row, 2 * ch + 1, q)), n1);
         }
@@ -216,8 +229,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
         TrainPre p;
         p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch, q)));
         p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
-        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch, q)));
-        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
+        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch, lane)));
+        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch + 1, lane)));
         if (s == 8) {
           p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
           p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);

@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrai
           }
         }
       }
-      st_stream(reinterpret_cast<f32x4*>(rmw(a.coup, S, a.npts, row, 2 * ch, q)), c0);
-      st_stream(reinterpret_cast<f32x4*>(rmw(a.coup, S, a.npts, row, 2 * ch + 1, q)), c1);
+      st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(S, a.npts, row, 2 * ch, lane)), c0);
+      st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(S, a.npts, row, 2 * ch + 1, lane)), c1);
       st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, S, a.npts, row, 2 * ch, q)), n0);
       st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, S, a.npts, row, 2 * ch + 1, q)), n1);
       if constexpr (S < 7) spl_store_act(out, j, q, ch, n0, n1);
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
       TrainPre p;
       p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch, q)));
       p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
-      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch, q)));
-      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
+      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch, lane)));
+      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch + 1, lane)));
       if constexpr (S == 8) {
         p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
         p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
