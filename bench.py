@@ -171,7 +171,8 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
 
     Eager PyTorch on [512*128, 256] operands stops scaling long before a 256-core host is full (oversubscribed it
     is 10x slower), so the thread count is calibrated on ONE 512-ray chunk - the size the timed repeats use - over
-    {all, 128, 64, 32, 16} cores and the best one is used and reported as ``cores`` (the chunk doubles as the warm-up).  The
+    {16, 32, 64, 128, all} cores (stopping once past the optimum) and the best one is used and reported as ``cores`` (the chunk
+    doubles as the warm-up).  The
     repeats stop early if the time budget runs out (said in ``sample``)."""
     from oracle import neus_oracle as orc  # the checker; only this leg and the tests import it
     host = os.cpu_count() or 1
@@ -181,7 +182,10 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
     bg = torch.ones(1, 3)
     best, best_t = host, float("inf")
     calib = {}
-    for th in sorted({host, min(host, 128), min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
+    # ascending, and no further once a count is 1.5x slower than the best so far: past the optimum (16 - 32 threads on the 256-core
+    # boxes) the time only grows - 4.8 s at 64, 10.7 s at 128, 133 s at 256 threads (profiles/r04/bench_v2.json) - and measuring
+    # that tail again in every run cost 2.5 minutes of the bench's wall time
+    for th in sorted({min(host, 16), min(host, 32), min(host, 64), min(host, 128), host}):
         torch.set_num_threads(th)
         t0 = time.perf_counter()
         orc.render_chunked(p, *(t[:512] for t in sub), chunk=512, background_rgb=bg, mode="as_written")
@@ -189,6 +193,8 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
         calib[th] = round(dt, 2)
         if dt < best_t:
             best, best_t = th, dt
+        elif dt > 1.5 * best_t:
+            break
     torch.set_num_threads(best)
     t_start = time.perf_counter()
     times, out = [], None
