@@ -428,3 +428,31 @@ def test_outside_nerf_module_matches_reference_fixture():
     zo = outside_z(torch.tensor([[2.0], [3.5]]), 64)
     assert zo.shape == (2, 32) and bool((zo[:, 1:] > zo[:, :-1]).all()) and bool((zo > torch.tensor([[2.0], [3.5]])).all())
     assert abs(float(zo[0, -1]) - (2.0 / 1e-3 + 1.0 / 64)) < 1e-2
+
+
+def test_bench_cpu_thread_calibration_stops_past_the_optimum(monkeypatch):
+    """bench.cpu_baseline picks its thread count on one 512-ray chunk, climbing from 16 threads and stopping once a count is 1.5x
+    slower than the best so far (on the 256-core GPU boxes 64 threads take 4.8 s, 128 take 10.7 s and 256 take 133 s per chunk:
+    the tail is not measured again in every run).  Fake clock, fake oracle: the ladder visits 16, 32, 64 and keeps 32."""
+    import bench
+    from oracle import neus_oracle as orc
+    cost = {16: 3.1, 32: 3.0, 64: 4.8, 128: 10.7, 256: 133.0}
+    clock, threads, visited = [0.0], [1], []
+
+    def fake_render(p, *rays, chunk, background_rgb, mode):
+        n = rays[0].shape[0]
+        if n == 512:
+            visited.append(threads[0])
+        clock[0] += cost[threads[0]] * n / 512.0
+        return {"rgb": torch.zeros(n, 3)}
+
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(bench.torch, "set_num_threads", lambda n: threads.__setitem__(0, n))
+    monkeypatch.setattr(bench.time, "perf_counter", lambda: clock[0])
+    monkeypatch.setattr(orc, "render_chunked", fake_render)
+    monkeypatch.setattr(orc, "params_from_state", lambda state: None)
+    rays = [np.zeros((2048, 3), np.float32)] * 3 + [np.zeros((2048, 1), np.float32)] * 2
+    r = bench.cpu_baseline({}, rays, 1024, np.zeros((2048, 3), np.float32), budget_s=1e9)
+    assert visited == [16, 32, 64] and r["cores"] == 32 and r["host_cores"] == 256
+    assert r["thread_calibration_s_per_512_rays"] == {16: 3.1, 32: 3.0, 64: 4.8}
+    assert abs(r["value"] - 1024 / 6.0) < 0.01 and len(r["repeats_s"]) == 3
