@@ -119,12 +119,6 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                           float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
                           void* stream);
-/* nrh_sdf_train_forward for precision f16x3 on the wide (32-point tile, one wave per SIMD) kernels: sdf_w32 / sdf_tab32 as for
- * nrh_sdf_eval_wide (packing32.pack_sdf32, plain feature head), scratch as for its modes 1 / 2; same outputs and saved arrays
- * (npts a multiple of 32, at most 4 194 304).  nrh_render_forward_train takes this path whenever NrhNet carries the streams. */
-int nrh_sdf_train_forward_wide(const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
-                               int t_stride, int n_per_ray, long long nrays, float* sdf, float* grad, float* feat_rows, float* save_h,
-                               float* save_s1, float* save_t, float* save_ge, float* scratch, void* stream);
 int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
                            const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
                            const float* save_s1, const float* save_t, const float* gbar, const float* fbar,

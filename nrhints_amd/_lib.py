@@ -19,7 +19,7 @@ _ERRNAMES = {-1: "NRH_E_INVALID", -2: "NRH_E_LAUNCH", -3: "NRH_E_WORKSPACE", -4:
 EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param_sizes", "nrh_mlp_grid",
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
-            "nrh_sdf_train_forward", "nrh_sdf_train_forward_wide", "nrh_sdf_train_backward", "nrh_outside_sizes", "nrh_outside_forward",
+            "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_outside_sizes", "nrh_outside_forward",
             "nrh_outside_backward", "nrh_ray_adjoint", "nrh_render_forward_train", "nrh_alpha_train_forward", "nrh_alpha_train_backward",
             "nrh_shadow_alpha_forward", "nrh_shadow_alpha_backward", "nrh_alpha_train_forward_n", "nrh_alpha_train_backward_n",
             "nrh_sample_primary", "nrh_alpha_blend_forward", "nrh_alpha_blend_backward",
@@ -81,7 +81,6 @@ def load():
     lib.nrh_mlp_grid.restype = c_int
     lib.nrh_sdf_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
     lib.nrh_sdf_train_forward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P]
-    lib.nrh_sdf_train_forward_wide.argtypes = [P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P]
     lib.nrh_ray_adjoint.argtypes = [P, P, P, P, P, P, P, P, c_int, P, c_longlong, P, P, P, P]
     lib.nrh_outside_sizes.argtypes = [POINTER(c_int)]
     lib.nrh_outside_forward.argtypes = [c_int, P, P, P, P, P, c_int, c_longlong, P, P, P, P, P, P, P, P]

@@ -26,8 +26,6 @@ MFMA = "v_mfma_f32_32x32x16_f16"
 
 
 TRANS_COST = float(os.environ.get("NRH32_TRANS_COST", "1"))
-ROW_STORE_MACROS = ("W32_HSAVE", "W32_SSAVE", "W32_TSAVE", "W32_FSAVE")
-ROW_STORE_FROM = int(os.environ.get("NRH32_ROW_STORE_FROM", "-1"))    # first MFMA slot that may carry a row store (-1: anywhere)
 
 
 class Op:
@@ -70,26 +68,7 @@ def split_ops(i, v0, v1, out_hi, out_lo, pfx="", scaled=False):
     return ops
 
 
-def save_rows_ops(c, names, macro, pfx):
-    """Row-major save of one chunk of a [points, 256] training array: the 16 values `names` (D32 registers: register r <-> channel
-    32 c + 8 (r >> 2) + 4 hf + (r & 3)) leave as 32-byte runs - v_permlane32_swap trades the odd quad of the hf = 0 lane for the
-    even quad of its hf = 1 partner, after which lane hf owns channels 32 c + 16 g2 + 8 hf + 0..7 (two adjacent float4) - because
-    16-byte pieces at a 32-byte stride store at a third of the rate (profiles/r04/rowstore.log).  macro(c, g2, part, float4)."""
-    ops = []
-    for g2 in range(2):
-        outs = []
-        for k in range(4):
-            a, b = names[8 * g2 + k], names[8 * g2 + 4 + k]
-            oa, ob = f"{pfx}a{g2}{k}", f"{pfx}b{g2}{k}"
-            ops.append(Op(f"float {oa}, {ob}; nrh32::swap32({a}, {b}, {oa}, {ob});", defs=(oa, ob), uses=(a, b), cost=2))
-            outs.append((oa, ob))
-        for part in range(2):
-            w = [o[part] for o in outs]
-            ops.append(Op(f"{macro}({c}, {g2}, {part}, (f32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
-    return ops
-
-
-def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE", jvp=False, train=False, sfx=""):
+def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE", jvp=False):
     """Forward epilogue of chunk c: t (bias is in the accumulator) -> u = log2(1 + 2^t) -> hi/lo -> out; q = 1/(1+2^t).
     jvp: the tile holds 16 points (columns 0..15) and their 16 tangents (columns 16..31, the directional derivative along the
     ray): a tangent lane takes q from its point lane (16 lanes below: W32_SWAP = v_permlane16_swap) and writes (1 - q) t
@@ -120,22 +99,11 @@ def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE", jvp=False, tra
             if i % 4 == 3 and not os.environ.get("NRH32_NOQSTORE"):      # (timing ablation: WRONG RESULTS)
                 w = [f"qq{i - 3 + k}" for k in range(4)]
                 ops.append(Op(f"{qstore}({c}, {i // 4}, (nrh32::u32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
-        if train:
-            # training forward: h = u ln2 / 100 and sigma' = 1 - q of this chunk as rows of save_h / save_s1 (what the tangent and
-            # value sweeps and the weight-gradient kernel read; csrc/nrh_sdf_train.hip, nrh_dw.hip)
-            for r in (2 * i, 2 * i + 1):
-                ops += [Op(f"float hs{r} = u{r} * nrh32::KK;", defs=(f"hs{r}",), uses=(f"u{r}",)),
-                        Op(f"float sg{r} = 1.0f - q{r};", defs=(f"sg{r}",), uses=(f"q{r}",))]
-    if train:
-        ops += save_rows_ops(c, [f"hs{r}" for r in range(16)], "W32_HSAVE" + sfx, "hx")
-        ops += save_rows_ops(c, [f"sg{r}" for r in range(16)], "W32_SSAVE" + sfx, "sx")
     return ops
 
 
-def epi_rev(c, hp, cp, out_base=128, train=False, sfx=""):
-    """Reverse epilogue of chunk c: g = W^T t (accumulator) -> t' = g - g q, q = unorm16 from scratch -> hi/lo -> out.
-    train: t' also leaves as a row of save_t (the reverse-chain stage inputs t_l = sigma'_l a_{l+1} that the tangent sweep and
-    the weight-gradient kernel read)."""
+def epi_rev(c, hp, cp, out_base=128):
+    """Reverse epilogue of chunk c: g = W^T t (accumulator) -> t' = g - g q, q = unorm16 from scratch -> hi/lo -> out."""
     ops = []
     for i in range(8):
         for r in (2 * i, 2 * i + 1):
@@ -148,8 +116,6 @@ def epi_rev(c, hp, cp, out_base=128, train=False, sfx=""):
                 Op(f"float u{r} = __builtin_fmaf(n{r}, f{r}, g{r});", defs=(f"u{r}",), uses=(f"n{r}", f"f{r}", f"g{r}")),
             ]
         ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", out_base + 8 * c + i, out_base + 64 + 8 * c + i)
-    if train:
-        ops += save_rows_ops(c, [f"u{r}" for r in range(16)], "W32_TSAVE" + sfx, "tx")
     return ops
 
 
@@ -169,15 +135,10 @@ def epi_relu(c, hp, cp, out_base=128, part=False):
     return ops
 
 
-def epi_feat(c, hp, cp, store="W32_FSTORE", train=False):
+def epi_feat(c, hp, cp, store="W32_FSTORE"):
     """Feature-head epilogue of chunk c: v = hh + cc 2^-11, stored as four float4 (rows 32 c + 8 g + 4 hf + 0..3 of this lane's
-    point): W32_FSTORE(c, g, value).  No AGPR output - nothing reads the feature as a B operand.
-    train: row-major [points, 256] instead (W32_FSAVE(c, g2, part, value), 32-byte runs as save_rows_ops makes them)."""
+    point): W32_FSTORE(c, g, value).  No AGPR output - nothing reads the feature as a B operand."""
     ops = []
-    if train:
-        for r in range(16):
-            ops.append(Op(f"float v{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"v{r}",)))
-        return ops + save_rows_ops(c, [f"v{r}" for r in range(16)], "W32_FSAVE", "fx")
     for g in range(4):
         for k in range(4):
             r = 4 * g + k
@@ -187,12 +148,9 @@ def epi_feat(c, hp, cp, store="W32_FSTORE", train=False):
     return ops
 
 
-def schedule(ops, nslots, per_slot, trans_cost=1.0, vmem_from=None):
+def schedule(ops, nslots, per_slot, trans_cost=1.0):
     """Greedy list schedule: an op may run in slot k if everything it uses was defined in a slot < k (or outside).
-    Returns (slots, tail): ops per slot, and what did not fit.
-    vmem_from: row stores (kind "vmem" whose code starts with one of the W32_?SAVE macros) only from that slot on and at most one
-    per slot - the training forward writes 10 KiB per wave and window, which HBM drains in about a window: issued as one burst
-    right after the window's opening they fill the CU's memory queue and the in-order wave stalls behind them."""
+    Returns (slots, tail): ops per slot, and what did not fit."""
     defined_in = {}
     for o in ops:
         for d in o.defs:
@@ -202,15 +160,9 @@ def schedule(ops, nslots, per_slot, trans_cost=1.0, vmem_from=None):
     for k in range(nslots):
         budget = per_slot(k) if callable(per_slot) else per_slot
         rest = []
-        row_stores = 0
         for o in todo:
             ready = all((u not in defined_in) or (defined_in[u].slot is not None and defined_in[u].slot < k) for u in o.uses)
             cost = trans_cost if o.kind == "trans" else o.cost     # (experiment knob NRH32_TRANS_COST: a transcendental holds the
-            if vmem_from is not None and o.kind == "vmem" and o.code.startswith(ROW_STORE_MACROS):
-                if k < vmem_from or row_stores >= 1:
-                    rest.append(o)
-                    continue
-                row_stores += 1
             if ready and budget >= cost:                            # VALU issue port longer than a plain op)
                 o.slot = k
                 slots[k].append(o)
@@ -347,19 +299,16 @@ def acc_names(c):
 
 
 # asm loads a stage issues per window for the epilogue that runs one window later: (register stems, macro)
-STAGE_LOADS = {"rev": (("qa", "qb"), "W32_QLOAD_ASM"), "rev_t": (("qa", "qb"), "W32_QLOAD_ASM"),
+STAGE_LOADS = {"rev": (("qa", "qb"), "W32_QLOAD_ASM"),
                "relu_part": (("pa", "pb", "pc", "pd"), "W32_PLOAD_ASM")}
-LOAD_TYPE = {"rev": "nrh32::u32x4", "rev_t": "nrh32::u32x4", "relu_part": "f32x4"}
+LOAD_TYPE = {"rev": "nrh32::u32x4", "relu_part": "f32x4"}
 
 
 def stage_epilogue(kind, c, ph, pc, want_d, out_base, qstore):
-    sfx = "_P" if qstore.endswith("_P") else ""      # the pending chunk of the PREVIOUS stage: its layer's save macros
-    if kind in ("fwd", "fwd_jvp", "fwd_t"):
-        return epi_fwd(c, ph, pc, want_d, out_base=out_base, qstore=qstore, jvp=(kind == "fwd_jvp"), train=(kind == "fwd_t"), sfx=sfx)
-    if kind in ("rev", "rev_t"):
-        return epi_rev(c, ph, pc, out_base=out_base, train=(kind == "rev_t"), sfx=sfx)
-    if kind == "feat_t":
-        return epi_feat(c, ph, pc, train=True)
+    if kind in ("fwd", "fwd_jvp"):
+        return epi_fwd(c, ph, pc, want_d, out_base=out_base, qstore=qstore, jvp=(kind == "fwd_jvp"))
+    if kind == "rev":
+        return epi_rev(c, ph, pc, out_base=out_base)
     if kind in ("relu", "relu_part"):
         return epi_relu(c, ph, pc, out_base=out_base, part=(kind == "relu_part"))
     if kind == "feat":
@@ -381,15 +330,13 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
     pend_kind = kind if pend_kind is None else pend_kind
     loads, load_macro = STAGE_LOADS.get(kind, ((), None))            # what this stage's windows request
     ploads = STAGE_LOADS.get(pend_kind, ((), None))[0]               # what arrives pending from the previous stage
-    wname = {"rev": "qw", "rev_t": "qw", "relu_part": "pw"}
+    wname = {"rev": "qw", "relu_part": "pw"}
     out = []
     out.append(f"// generated by gen_mlp32.py: stage kind={kind} pend={pend_kind} want_d={want_d} ks={ks} b={b_src} valu/slot={nv} in=a{in_base} out=a{out_base}")
     out.append("{")
-    # VMEM stores of the previous window's epilogue (training kinds, or NRH32_SYNCK=1 for every kind): vmcnt counts them like the
-    # LDS-DMA pieces, so the window's opening wait keeps that many more operations in flight - `s_waitcnt vmcnt(8)` would drain
-    # every row store of the previous window (HBM write latency exposed once per window: measured 1.62 ms against 1.27 ms for
-    # the 16-point training forward, profiles/r04/train_ab1.log).  Window 0 keeps 8: what ran before it is another stage.
-    sync_k = kind.endswith("_t") or bool(os.environ.get("NRH32_SYNCK"))
+    # NRH32_SYNCK=1 (experiment): vmcnt counts the VMEM stores of the previous window's epilogue like the LDS-DMA pieces, so the
+    # window's opening wait keeps that many more operations in flight instead of draining them with `s_waitcnt vmcnt(8)`.
+    sync_k = bool(os.environ.get("NRH32_SYNCK"))
     prev_stores = 0
     for c in range(7):
         out.append(f"  nrh32::f32x16 hh{c}, cc{c};")
@@ -466,10 +413,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
                 slots, tail = schedule(epi, HEAD_SLOTS + nslots, lambda k: HEAD_OPS if k < HEAD_SLOTS else b1(k - HEAD_SLOTS), TRANS_COST)
                 head, slots = slots[:HEAD_SLOTS], slots[HEAD_SLOTS:]
             else:
-                vf = ROW_STORE_FROM if (ROW_STORE_FROM >= 0 and not small) else None
-                if vf is not None and c == 0:
-                    vf = min(vf, 28)          # window 0: everything sits ahead of slot 41
-                slots, tail = schedule(epi, nslots, budget, TRANS_COST, vmem_from=vf)
+                slots, tail = schedule(epi, nslots, budget, TRANS_COST)
             assert not (c == 0 and not small and tail), "pending epilogue does not fit ahead of K step 14"
         else:
             slots, tail = None, []
@@ -498,16 +442,16 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
 def gen_finish(kind, want_d, out_base):
     """The pending chunk 7 of the last stage of a chain, on its own (no K loop to hide under): outputs into set `out_base`."""
     out = [f"// generated by gen_mlp32.py: finish kind={kind} want_d={want_d} out=a{out_base}", "{"]
-    if kind in ("fwd", "fwd_jvp", "fwd_t"):
-        epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P", jvp=(kind == "fwd_jvp"), train=(kind == "fwd_t"), sfx="_P")
+    if kind in ("fwd", "fwd_jvp"):
+        epi = epi_fwd(7, "hp", "cp", want_d, out_base=out_base, qstore="W32_QSTORE_P", jvp=(kind == "fwd_jvp"))
     elif kind == "relu":
         epi = epi_relu(7, "hp", "cp", out_base=out_base)
-    elif kind in ("feat", "feat_t"):
-        epi = epi_feat(7, "hp", "cp", train=(kind == "feat_t"))
+    elif kind == "feat":
+        epi = epi_feat(7, "hp", "cp")
     else:
         out.append('  asm volatile("" : "+v"(qpa), "+v"(qpb));   // landed: the stage body ends with a wait for them')
         out.append("  const nrh32::u32x4 qw0 = qpa, qw1 = qpb;")
-        epi = epi_rev(7, "hp", "cp", out_base=out_base, train=(kind == "rev_t"), sfx="_P")
+        epi = epi_rev(7, "hp", "cp", out_base=out_base)
     slots, tail = schedule(epi, (len(epi) + 7) // 8 + 8, 8)
     for ops in slots:
         if ops:
@@ -545,11 +489,10 @@ def gen_t7_loads():
     return "\n".join(out) + "\n"
 
 
-def gen_t7(train=False):
+def gen_t7():
     """t_7 = (1 - q_7) * a8 written straight into AGPR set 0 (R7's input): W32_A8(c) -> f32x16 (w_s / 3 in D32 layout).  The q
-    words were requested in the HEAD window (gen_t7_loads); they are older than HEAD's eight LDS-DMA pieces.
-    train: chunks 0..6 of t_7 also leave as rows of save_t[7] (W32_TSAVE7; chunk 7 is R7's pending chunk: W32_TSAVE_P there)."""
-    out = [f"// generated by gen_mlp32.py: T7 pass train={train}", "{"]
+    words were requested in the HEAD window (gen_t7_loads); they are older than HEAD's eight LDS-DMA pieces."""
+    out = ["// generated by gen_mlp32.py: T7 pass train=False", "{"]
     regs = ", ".join(f'"+v"(q{c}{h})' for c in range(7) for h in "ab")
     out.append(f'  asm volatile("s_waitcnt vmcnt(8)" : {regs}, "+v"(qpa), "+v"(qpb) :: "memory");   // asm loads: the wait is ours')
     out.append("  __builtin_amdgcn_sched_barrier(0);")
@@ -566,8 +509,6 @@ def gen_t7(train=False):
                     Op(f"float u{r} = __builtin_fmaf(n{r}, f{r}, a8[{r}]);", defs=(f"u{r}",))]
         for i in range(8):
             ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", 8 * c + i, 64 + 8 * c + i)
-        if train:
-            ops += save_rows_ops(c, [f"u{r}" for r in range(16)], "W32_TSAVE7", "tx")
         for o in ops:
             out.append("    " + o.code)
         out.append("    __builtin_amdgcn_sched_barrier(0);")
@@ -588,7 +529,6 @@ def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen32")
     os.makedirs(outdir, exist_ok=True)
     nv = int(os.environ.get("NRH32_NV", "4"))
-    nvt = int(os.environ.get("NRH32_NVT", "7"))     # VALU budget per MFMA slot of the training forward's windows
     bm = True      # bias through one extra MFMA per window (see gen_stage); the older start-value form is gone from the kernel
     nohinit = bool(os.environ.get("NRH32_NOHINIT"))      # timing ablation (WRONG RESULTS): forward windows start from zero
     files = {
@@ -616,18 +556,6 @@ def main():
         "feat_fin.inc": gen_finish("feat", False, 128),
         "t7.inc": gen_t7(),
         "t7_loads.inc": gen_t7_loads(),
-        # training forward (sdf32_kernel<4>): the mode-2 chain whose epilogues also write the rows the backward sweeps and the
-        # weight-gradient kernel read - h_l and sigma'_l (forward), t_l (T7 and the reverse chain), the feature (FEAT)
-        "l0_t.inc": gen_stage("fwd_t", True, 3, "vgpr", 12, False, in_base=0, out_base=0, pend_in=False, bias_mfma=bm),
-        "fwd_t_p0.inc": gen_stage("fwd_t", True, 16, "agpr", nvt, nohinit, in_base=0, out_base=128, bias_mfma=bm),
-        "fwd_t_p1.inc": gen_stage("fwd_t", True, 16, "agpr", nvt, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
-        "fwd_fin_t.inc": gen_finish("fwd_t", True, 128),
-        "rev_t_p0.inc": gen_stage("rev_t", True, 16, "agpr", nv + 1, True, in_base=0, out_base=128),
-        "rev_t_p1.inc": gen_stage("rev_t", True, 16, "agpr", nv + 1, True, in_base=128, out_base=0),
-        "rev_t_fin.inc": gen_finish("rev_t", True, 128),
-        "feat_t.inc": gen_stage("feat_t", False, 16, "agpr", nv, True, in_base=128, out_base=128, pend_in=False, bias_mfma=True),
-        "feat_t_fin.inc": gen_finish("feat_t", False, 128),
-        "t7_t.inc": gen_t7(train=True),
         # reflectance net on the same machinery (csrc/nrh_color32.hip): C0 (misc inputs, + the feature block's share loaded per
         # window) -> C1 -> C2 -> C3 (ReLU), then the 3-row output chunk as a bare K loop
         "col_c0.inc": gen_stage("relu_part", False, 8, "agpr", 6, True, in_base=0, out_base=128, pend_in=False, bias_mfma=True, full_block=True),
@@ -637,7 +565,8 @@ def main():
         "col_fin.inc": gen_finish("relu", False, 0),
         "kloop16_a0.inc": gen_kloop(16, "agpr", False, in_base=0, b_lo_scaled=not COL_UNSCALED),
     }
-    for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc"):
+    for stale in ("fwd_d0.inc", "fwd_d1.inc", "rev.inc", "swap.inc", "dump_in.inc", "l0_t.inc", "fwd_t_p0.inc", "fwd_t_p1.inc", "fwd_fin_t.inc",
+                  "rev_t_p0.inc", "rev_t_p1.inc", "rev_t_fin.inc", "feat_t.inc", "feat_t_fin.inc", "t7_t.inc"):
         if os.path.exists(os.path.join(outdir, stale)):
             os.remove(os.path.join(outdir, stale))
     for name, text in files.items():

@@ -23,14 +23,6 @@
 #include "nrh_wide.h"
 #include "nrh_small.h"
 
-#ifndef NRH_TRAIN_FWD_WIDE
-// 1: nrh_render_forward_train evaluates the SDF network with the wide training forward (nrh_sdf_train_forward_wide) when NrhNet
-// carries the streams.  Off: measured SLOWER than the 16-point kernel (1.53 against 1.33 ms per 131 072 points; its 3.3 GB of row
-// stores run at the HBM write rate but do not overlap with the one wave per SIMD's MFMA stream: 0.89 ms with the stores
-// compiled out, profiles/r04/train_fwd_ab.log).  The entry stays, tested against the 16-point kernel.
-#define NRH_TRAIN_FWD_WIDE 0
-#endif
-
 namespace {
 
 thread_local char g_err[512] = "";
@@ -384,7 +376,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 139; }
+int nrh_version(void) { return 140; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -491,28 +483,6 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
   if (precision == 0) hipLaunchKernelGGL((nrh::sdf_kernel<3, 0>), dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((nrh::sdf_kernel<3, 1>), dim3(grid), dim3(nrh::MLP_THREADS), nrh::MLP_LDS_BYTES, st, a);
   return check_launch("sdf_kernel<3>");
-}
-
-// The training forward on the wide one-wave-per-SIMD machinery (csrc/nrh_sdf32.hip MODE 4, precision f16x3): same outputs and
-// saved arrays as nrh_sdf_train_forward, evaluated by the mode-2 stream of packing32.pack_sdf32 (plain feature head).
-int nrh_sdf_train_forward_wide(const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
-                               int t_stride, int n_per_ray, long long nrays, float* sdf, float* grad, float* feat_rows, float* save_h,
-                               float* save_s1, float* save_t, float* save_ge, float* scratch, void* stream) {
-  if (!sdf_w32 || !sdf_tab32 || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_s1 || !save_t || !save_ge || !scratch)
-    return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: null pointer%s", "");
-  if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: bad n_per_ray/stride%s", "");
-  if ((nrays * n_per_ray) % 32 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: the number of points must be a multiple of 32%s", "");
-  if (nrays * n_per_ray > (1LL << 22)) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: at most 4 194 304 points per call%s", "");
-  if (nrays == 0) return NRH_OK;
-  nrh32::WideSdfCall c;
-  c.mode = 4; c.streams = sdf_w32; c.tables = sdf_tab32; c.ro = ro; c.rd = rd; c.t = t; c.sdf = sdf; c.grad = grad; c.feat = feat_rows;
-  c.scratch = scratch; c.npts = nrays * n_per_ray; c.n_per_ray = n_per_ray; c.t_stride = t_stride; c.sdf_stride = n_per_ray;
-  c.max_grid = device_cus();
-  c.save_h = save_h; c.save_s1 = save_s1; c.save_t = save_t; c.save_ge = save_ge;
-  const int wrc = nrh32::wide_sdf_launch(c, (hipStream_t)stream);
-  if (wrc == -1) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_wide: too many points%s", "");
-  if (wrc) return fail(NRH_E_LAUNCH, "wide sdf kernel: no HIP device / attribute error%s", "");
-  return check_launch("sdf32_kernel<4>");
 }
 
 int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
@@ -1305,14 +1275,11 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   // ---- render_core: sdf + feature + gradient at the 128 section mid-points ----
   float* sdf_c = train ? train->sdf : ws_sdf_c;
   if (train) {
-    // training: the same evaluation with the feature row-major and the arrays the backward sweeps need
-    // (precision f16x3 with the wide streams at hand: the wide kernel, csrc/nrh_sdf32.hip MODE 4; n * 128 is a multiple of 32)
-    if (NRH_TRAIN_FWD_WIDE && net->precision == 1 && net->sdf_w32 && net->sdf_tab32 && !net->feat_fused && n * 128 <= (1LL << 22))
-      rc = nrh_sdf_train_forward_wide(net->sdf_w32, net->sdf_tab32, origins, directions, o_tmid, 128, 128, n, sdf_c, o_grad,
-                                      train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, scratch, stream);
-    else
-      rc = nrh_sdf_train_forward(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
-                                 sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, stream);
+    // training: the same evaluation with the feature row-major and the arrays the backward sweeps need (16-point kernels: a wide
+    // one-wave-per-SIMD form was built in round 4, measured slower - its row stores do not overlap a single wave's MFMA stream,
+    // DESIGN.md section 7c - and removed in round 5)
+    rc = nrh_sdf_train_forward(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
+                               sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, stream);
   } else {
     rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n, sdf_c, 128,
                        o_grad, ws_feat, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});

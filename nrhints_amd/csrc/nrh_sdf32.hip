@@ -36,12 +36,9 @@ struct Sdf32Args {
   int ngroups;          // ceil(npts / GROUP)
   uint32_t* dbg;        // diagnosis builds only (-DNRH32_TIMING): per-wave cycle totals, see profiles/ubench/sdf32_bench.hip
   int dbg_stage;        // unused
-  // MODE 4 (training forward): `feat` is the row-major feature [npts][256]; what the hand-derived backward needs, row-major
-  // float32 like the 16-point training kernel writes them (csrc/nrh_sdf.hip MODE 3: same contract, same consumers)
-  float* save_h;        // [8][npts][256]  h_l = softplus(z_l) (layer 3: columns 217.. hold the embedding, i.e. x_4)
-  float* save_s1;       // [8][npts][256]  sigma'_l (0 on the substituted entries of layer 3)
-  float* save_t;        // [8][npts][256]  t_l = sigma'_l * a_{l+1}  (t_7 = sigma'_7 w_s / 3)
-  float* save_ge;       // [npts][128]     columns e: a_0[e]; columns 73 + e: a_4[217 + e]  (e < 39)
+#if defined(NRH32_ARGPAD) && NRH32_ARGPAD
+  void* argpad[4];      // A/B aid: the kernarg size of rounds 3-4 (hipcc's scalar register allocation of modes 1 / 2 depends on it)
+#endif
 };
 
 constexpr int SCRATCH_WORDS_PER_WAVE = 8 * 8 * 2 * 64 * 4;   // [layer][chunk][half][lane] uint4
@@ -112,17 +109,6 @@ __device__ __forceinline__ float swap_rows16(float x) {
   return __builtin_bit_cast(float, v);
 }
 
-// lanes 32..63 of `a` trade places with lanes 0..31 of `b` (v_permlane32_swap_b32): afterwards oa = {a of this half's lower
-// partner, ...}: lane hf = 0 holds (its own a, its partner's a), lane hf = 1 (its partner's b, its own b) - gen_mlp32.py
-// save_rows_ops turns two 16-byte quads at a 32-byte stride into one 32-byte run per lane with it
-__device__ __forceinline__ void swap32(float a, float b, float& oa, float& ob) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-  const unsigned x = r[0], y = r[1];
-  oa = __builtin_bit_cast(float, x);
-  ob = __builtin_bit_cast(float, y);
-}
-
-// MODE 4: the training forward - MODE 2 (plain feature head) whose epilogues also write the saved arrays of Sdf32Args.
 // MODE 0: sdf | 1: sdf + gradient | 2: + feature tiles | 3: sdf + the derivative ALONG the ray, forward mode: a tile is 16 points
 // (columns 0..15) and their 16 tangents (columns 16..31) through the same forward chain - no sigma' scratch, no reverse chain.
 // `grad` receives rd * (d sdf / dt) / |rd|^2, so that <rd, grad> is the directional derivative the alpha formula of a shadow ray
@@ -135,9 +121,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const int j = lane & 31, hf = lane >> 5;
   const uint32_t lane16 = lane * 16;
   constexpr bool JVP = MODE == 3;
-  constexpr bool TRAIN = MODE == 4;
-  constexpr bool WANT_D = MODE == 1 || MODE == 2 || TRAIN;
-  constexpr int SMODE = JVP ? 0 : (TRAIN ? 2 : MODE);   // which stream this mode consumes (3: the forward-only one, 4: mode 2's)
+  constexpr bool WANT_D = MODE == 1 || MODE == 2;
+  constexpr int SMODE = JVP ? 0 : MODE;   // which stream this mode consumes (3: the forward-only one)
   constexpr long long STREAM = sdf32_stream_bytes(SMODE);
   constexpr int TPTS = JVP ? 16 : TILE;              // points per wave tile
   const bool is_pt = !JVP || j < 16;                 // JVP: point column (else: the tangent column of point j - 16)
@@ -154,15 +139,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     gchar_p b = (gchar_p)scr;
     asm volatile("" : "+s"(b));   // keeps the address arithmetic scalar and local (hipcc otherwise hoists 64-bit VGPR addresses)
     return (gvec_p)(b + ((layer * 8 + c) * 2 + half) * 1024 + lane16);
-  };
-
-  // training saves: row P of a [layer][npts][256] float32 array = wave-uniform base (SGPRs) + this lane's 32-bit byte offset
-  // (points * 1 KiB < 4 GiB: at most 4 M points per launch, checked by the host) + a compile-time column offset
-  auto rows_at = [&](float* base, int layer) {
-    typedef __attribute__((address_space(1))) char* gchar_p;
-    gchar_p b = (gchar_p)(base + (size_t)layer * (size_t)a.npts * 256);
-    asm volatile("" : "+s"(b));
-    return b;
   };
 
   // constant tables -> LDS (once per workgroup)
@@ -260,12 +236,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
 #define W32_SYNC() chunk_sync<8>()
 #endif
-#define W32_SYNC_K(k) chunk_sync<(k)>()      // windows whose predecessor issued k - 8 row stores behind its DMA pieces (gen_mlp32.py)
-// first window of a stage with row stores: k if the stage before it was of the same kind (same_kind_before), else 8
-#define W32_SYNC_FIRST(k) do { if (same_kind_before) chunk_sync<(k)>(); else chunk_sync<8>(); } while (0)
-#ifndef NRH32_TRAIN_ABL
-#define NRH32_TRAIN_ABL 0      // timing ablations of the training forward (WRONG RESULTS): 1 no row stores, 2 no sigma' rows
-#endif
 #define W32_FETCH_SETUP() fetch_setup()
 #define W32_WADDR() (wlane + cur_off)
 #define W32_NEXT() (cur_off = (cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES)
@@ -308,21 +278,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #endif
 #define W32_QSTORE(c, half, val) W32_QST_((val), scr_at(qlayer, c, half))
 #define W32_QSTORE_P(c, half, val) W32_QST_((val), scr_at(qlayer - 1, c, half))
-    // MODE 4: this lane's two adjacent float4 of chunk c, group pair g2 (channels 32 c + 16 g2 + 8 hf + 4 part + 0..3 after the
-    // permlane32 swap of gen_mlp32.save_rows_ops) of row P; PLAIN stores (non-temporal ones run at a sixth of the rate in this
-    // pattern, profiles/r04/rowstore.log)
-    typedef __attribute__((address_space(1))) f32x4* grow_p;
-    const uint32_t rowoff = (uint32_t)Pc * 1024u + (uint32_t)hf * 32u;
-#define W32_ROWST_(base, layer, c, g2, part, val) do { if (valid && !(NRH32_TRAIN_ABL & 1)) *(grow_p)(rows_at((base), (layer)) + rowoff + ((c) * 128 + (g2) * 64 + (part) * 16)) = (val); } while (0)
-#define W32_HSAVE(c, g2, part, val) W32_ROWST_(a.save_h, qlayer, c, g2, part, val)
-#define W32_HSAVE_P(c, g2, part, val) W32_ROWST_(a.save_h, qlayer - 1, c, g2, part, val)
-#if NRH32_TRAIN_ABL & 2
-#define W32_SSAVE(c, g2, part, val) do { } while (0)
-#define W32_SSAVE_P(c, g2, part, val) do { } while (0)
-#else
-#define W32_SSAVE(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer, c, g2, part, val)
-#define W32_SSAVE_P(c, g2, part, val) W32_ROWST_(a.save_s1, qlayer - 1, c, g2, part, val)
-#endif
 #ifndef NRH32_Q7REG
 #define NRH32_Q7REG 1      // layer 7's sigma' words stay in registers from its epilogues to the T7 pass: +0.6 % frame rate, 16 KiB of scratch round trip per tile less; 0 = the scratch path
 #endif
@@ -350,8 +305,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const int qlayer = 0;
       if constexpr (JVP) {
 #include "gen32/l0_j.inc"
-      } else if constexpr (TRAIN) {
-#include "gen32/l0_t.inc"
       } else if constexpr (WANT_D) {
 #include "gen32/l0_d1.inc"
       } else {
@@ -364,12 +317,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     for (int l = 1; l <= (Q7REG ? 5 : 7); l += 2) {
       {
         const int qlayer = l;
-        const bool same_kind_before = l > 1;     // (layer 1 follows L0's short windows)
-        (void)same_kind_before;
         if constexpr (JVP) {
 #include "gen32/fwd_j_p0.inc"
-        } else if constexpr (TRAIN) {
-#include "gen32/fwd_t_p0.inc"
         } else if constexpr (WANT_D) {
 #include "gen32/fwd_d1_p0.inc"
         } else {
@@ -379,37 +328,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       if (l == 7) break;
       {
         const int qlayer = l + 1;
-        const bool same_kind_before = true;
-        (void)same_kind_before;
         if constexpr (JVP) {
 #include "gen32/fwd_j_p1.inc"
-        } else if constexpr (TRAIN) {
-#include "gen32/fwd_t_p1.inc"
         } else if constexpr (WANT_D) {
 #include "gen32/fwd_d1_p1.inc"
         } else {
 #include "gen32/fwd_d0_p1.inc"
-        }
-      }
-      if constexpr (TRAIN) {
-        if (l == 3) {
-          // x_4 = [h_3 (217), embedding (39)]: columns 217..255 of save_h[3] are the embedding (the operand of layer 4's weight
-          // gradient) and sigma' there is 0 (fields/sdf_field.py:113-114; csrc/nrh_sdf.hip does the same substitution in its L3
-          // epilogue).  Layer 3's last chunk left this wave during layer 4's first window, so its rows are complete by now and
-          // these stores come later in the same wave's program order.  Lane hf takes entries e = 2 m + hf.
-          if (valid) {
-            typedef __attribute__((address_space(1))) float* gf_p;
-            const uint32_t r0 = (uint32_t)Pc * 1024u + 217u * 4u;
-#pragma unroll
-            for (int m = 0; m < 20; ++m) {
-              const float v = emb_entry(x3, 2 * m, 2 * m + 1, hf);
-              if (2 * m + hf < 39) {
-                *(gf_p)(rows_at(a.save_h, 3) + r0 + (2 * m + hf) * 4) = v;
-                *(gf_p)(rows_at(a.save_s1, 3) + r0 + (2 * m + hf) * 4) = 0.0f;
-              }
-              if (m & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-          }
         }
       }
     }
@@ -418,8 +342,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // layer 7 on its own: its sigma' words go to the registers the T7 pass reads instead of through the scratch
       // (its first window still finishes layer 6's last chunk: W32_QSTORE_P stays the scratch store)
       const int qlayer = 7;
-      const bool same_kind_before = true;
-      (void)same_kind_before;
 #pragma push_macro("W32_QSTORE")
 #undef W32_QSTORE
 #define W32_QSTORE(c, half, val) W32_Q7_##c##_##half = (val)
@@ -431,8 +353,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       const int qlayer = 8;   // the pending chunk 7 of layer 7 -> set 1, where FEAT / HEAD read their input
       if constexpr (JVP) {
 #include "gen32/fwd_fin_j.inc"
-      } else if constexpr (TRAIN) {
-#include "gen32/fwd_fin_t.inc"
       } else if constexpr (WANT_D) {
 #if NRH32_Q7REG
 #pragma push_macro("W32_QSTORE_P")
@@ -453,28 +373,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #undef W32_SKIP
 #undef W32_QSTORE
 #undef W32_QSTORE_P
-#undef W32_HSAVE
-#undef W32_HSAVE_P
-#undef W32_SSAVE
-#undef W32_SSAVE_P
 #undef W32_SWAP
 #undef W32_ISPT
 
     NRH32_STAMP(2);   // L1..L7
     // ---- FEAT (MODE 2) and HEAD ----
-    if constexpr (TRAIN) {
-      // the feature as rows of a [npts][256] array (what csrc/nrh_color.hip's training forward reads), same pipelined stage
-#define W32_FSAVE(c, g2, part, val) W32_ROWST_(a.feat, 0, c, g2, part, val)
-#define W32_BIAS(c) (*reinterpret_cast<const uint32_t*>(brow + 8 * 1024 + (c) * 128))
-#define W32_BCONST bconst
-      {
-#include "gen32/feat_t.inc"
-      }
-#include "gen32/feat_t_fin.inc"
-#undef W32_FSAVE
-#undef W32_BIAS
-#undef W32_BCONST
-    }
     if (MODE == 2) {
       const long long t16 = 2 * tile + (j >> 4);
       const bool t16_ok = t16 * 16 < a.npts;
@@ -536,13 +439,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if constexpr (WANT_D) {
       // ---- T7: t_7 = (1 - q_7) * w_s / 3: chunks 0..6 straight into set 0 (R7's input), chunk 7 as R7's pending pair ----
 #define W32_A8(c) tab_init(10, c)
-#define W32_TSAVE7(c, g2, part, val) W32_ROWST_(a.save_t, 7, c, g2, part, val)
-      if constexpr (TRAIN) {
-#include "gen32/t7_t.inc"
-      } else {
 #include "gen32/t7.inc"
-      }
-#undef W32_TSAVE7
       hp = W32_A8(7);
       cp = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #undef W32_A8
@@ -553,29 +450,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // recomputed for each of the two stages that need them (R4e, R0): keeping them live across R4..R1 costs more
       // registers than 20 cosines cost time.
       float dx[3] = {0.f, 0.f, 0.f};
-      auto epi_emb = [&](int c, const f32x16& hh, const f32x16& cc, int ge_col0) {
+      auto epi_emb = [&](int c, const f32x16& hh, const f32x16& cc) {
         float xx[3] = {x3[0], x3[1], x3[2]};
         asm volatile("" : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]));   // not hoisted, not shared between the two stages
-        typedef __attribute__((address_space(1))) char* gchar_p;
-        gchar_p ge_base = nullptr;
-        uint32_t ge_off = 0;
-        if constexpr (TRAIN) {
-          ge_base = (gchar_p)(a.save_ge + ge_col0);
-          ge_off = (uint32_t)Pc * 512u + (uint32_t)hf * 16u;
-          asm volatile("" : "+s"(ge_base), "+v"(ge_off));
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (c == 1 && r >= 4) continue;
           const int e0 = 32 * c + frow(r, 0), e1 = 32 * c + frow(r, 1);
           if (e0 >= 39) continue;
           const float ge = __builtin_fmaf(cc[r], LO_UNSCALE, hh[r]);
-          if constexpr (TRAIN) {   // a_0[e] (R0) / a_4[217 + e] (R4e): the embedding gradient itself, for the second-order term
-            // e = e0 + 4 hf: scalar base + one 32-bit lane offset + an immediate (64-bit lane addresses per entry would be
-            // loop invariants that hipcc keeps - and spills - across the whole tile)
-            typedef __attribute__((address_space(1))) float* gf_p;
-            if (valid && e0 + 4 * hf < 39) *(gf_p)(ge_base + ge_off + e0 * 4) = ge;
-          }
           const float v = ge * emb_dentry(xx, e0, e1, hf);
           const int d0 = emb_dim(e0), d1 = (e1 < 39) ? emb_dim(e1) : d0;
           if (d0 == d1) {
@@ -587,14 +470,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
           if (r & 1) __builtin_amdgcn_sched_barrier(0);
         }
       };
-      auto emb_stage = [&](int ge_col0) {   // two 32-row chunks (R4e or R0) over AGPR set 1
+      auto emb_stage = [&]() {   // two 32-row chunks (R4e or R0) over AGPR set 1
         for (int c = 0; c < 2; ++c) {
           W32_SYNC();
           W32_FETCH_SETUP();
           f32x16 hh, cc;
           const uint32_t wa = W32_WADDR();
 #include "gen32/kloop16z.inc"
-          if (c == 0) epi_emb(0, hh, cc, ge_col0); else epi_emb(1, hh, cc, ge_col0);
+          if (c == 0) epi_emb(0, hh, cc); else epi_emb(1, hh, cc);
           W32_NEXT();
         }
       };
@@ -604,46 +487,23 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W32_QLOAD_ASM(dst, c, half) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" W32_QLD_NT : "=v"(dst) : "v"(lane16), "s"(qbase + (c) * 2048), "n"((half) * 1024))
       // R7 R6 | R5 R4 R4e | R3 R2 | R1 finish R0: odd layers read set 0 / write set 1, even layers the other way round, so both
       // embedding-gradient stages (after R4: t_4 is R4's input; after R1: t_0) read set 1 - one copy of emb_stage in the code
-      // MODE 4: the stage that applies W_l^T produces t_{l-1} (chunks 0..6 in its own windows: W32_TSAVE); its first window
-      // finishes the previous stage's last chunk, which belongs to t_l (W32_TSAVE_P; for R7 that is T7's chunk 7, for the
-      // finish after R1 it is t_0)
-#define W32_TSAVE(c, g2, part, val) W32_ROWST_(a.save_t, l - 1, c, g2, part, val)
-#define W32_TSAVE_P(c, g2, part, val) W32_ROWST_(a.save_t, l, c, g2, part, val)
       for (int k = 0; k < 4; ++k) {
         {
           const int l = 7 - 2 * k;
           const char* const qbase = uni(scr + (l - 1) * 16384);
-          const bool same_kind_before = (k == 1 || k == 3);    // R5 after R6, R1 after R2; R7 follows T7, R3 the R4e stage
-          (void)same_kind_before;
-          if constexpr (TRAIN) {
-#include "gen32/rev_t_p0.inc"
-          } else {
 #include "gen32/rev_p0.inc"
-          }
         }
         if (k == 3) {
           const int l = 0;
           (void)l;
-          if constexpr (TRAIN) {
-#include "gen32/rev_t_fin.inc"
-          } else {
 #include "gen32/rev_fin.inc"
-          }
         } else {
           const int l = 6 - 2 * k;
           const char* const qbase = uni(scr + (l - 1) * 16384);
-          const bool same_kind_before = true;
-          (void)same_kind_before;
-          if constexpr (TRAIN) {
-#include "gen32/rev_t_p1.inc"
-          } else {
 #include "gen32/rev_p1.inc"
-          }
         }
-        if (k == 1 || k == 3) emb_stage(k == 1 ? 73 : 0);
+        if (k == 1 || k == 3) emb_stage();
       }
-#undef W32_TSAVE
-#undef W32_TSAVE_P
 #undef W32_QLOAD_ASM
 
       NRH32_STAMP(5);   // R7..R1 (+ R4e)

@@ -5,7 +5,7 @@
 namespace nrh32 {
 
 struct WideSdfCall {
-  int mode;                 // 0 sdf | 1 + gradient | 2 + feature tiles | 3 sdf + derivative along the ray | 4 training forward
+  int mode;                 // 0 sdf | 1 + gradient | 2 + feature tiles | 3 sdf + derivative along the ray
   const void* streams;      // packing32.pack_sdf32: the three mode streams back to back
   const float* tables;      // [11][256]
   const float *ro, *rd, *t;
@@ -14,8 +14,6 @@ struct WideSdfCall {
   long long npts;
   int n_per_ray, t_stride, sdf_stride;
   int max_grid;             // workgroups (one per CU)
-  // mode 4: `feat` is row-major [npts][256]; the arrays of the hand-derived backward (nrh_sdf32.hip Sdf32Args)
-  float *save_h = nullptr, *save_s1 = nullptr, *save_t = nullptr, *save_ge = nullptr;
 };
 int wide_sdf_launch(const WideSdfCall& c, hipStream_t st);   // 0 ok, -1 invalid, -2 launch/device error
 long long wide_sdf_stream_bytes_total();

@@ -13,17 +13,16 @@ int wide_sdf_launch(const WideSdfCall& c, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -2;
   if (dev >= 0 && dev < 16 && !g_attr[dev]) {
-    const void* fns[5] = {(const void*)sdf32_kernel<0>, (const void*)sdf32_kernel<1>, (const void*)sdf32_kernel<2>,
-                          (const void*)sdf32_kernel<3>, (const void*)sdf32_kernel<4>};
+    const void* fns[4] = {(const void*)sdf32_kernel<0>, (const void*)sdf32_kernel<1>, (const void*)sdf32_kernel<2>,
+                          (const void*)sdf32_kernel<3>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -2;
     g_attr[dev] = true;
   }
   Sdf32Args a;
   long long off = 0;
-  // mode 3 (forward-mode derivative along the ray) consumes the forward-only stream, mode 4 (training forward) mode 2's
-  const int smode = c.mode == 3 ? 0 : (c.mode == 4 ? 2 : c.mode);
-  if (c.mode == 4 && (c.npts > (1LL << 22) || !c.save_h || !c.save_s1 || !c.save_t || !c.save_ge)) return -1;   // 32-bit row offsets
+  if (c.mode < 0 || c.mode > 3) return -1;
+  const int smode = c.mode == 3 ? 0 : c.mode;     // mode 3 (forward-mode derivative along the ray) consumes the forward-only stream
   for (int m = 0; m < smode; ++m) off += sdf32_stream_bytes(m);
   a.w = reinterpret_cast<const char*>(c.streams) + off;
   a.tab = c.tables; a.ro = c.ro; a.rd = c.rd; a.t = c.t; a.sdf = c.sdf; a.grad = c.grad; a.feat = c.feat;
@@ -34,13 +33,11 @@ int wide_sdf_launch(const WideSdfCall& c, hipStream_t st) {
   if (groups > 0x7fffffffLL) return -1;
   a.ngroups = (int)groups;
   a.dbg = nullptr; a.dbg_stage = 99;
-  a.save_h = c.save_h; a.save_s1 = c.save_s1; a.save_t = c.save_t; a.save_ge = c.save_ge;
   const int grid = (int)(groups < c.max_grid ? groups : c.max_grid);
   if (grid <= 0) return -2;
   if (c.mode == 0) hipLaunchKernelGGL(sdf32_kernel<0>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
   else if (c.mode == 1) hipLaunchKernelGGL(sdf32_kernel<1>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
   else if (c.mode == 2) hipLaunchKernelGGL(sdf32_kernel<2>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
-  else if (c.mode == 4) hipLaunchKernelGGL(sdf32_kernel<4>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
   else hipLaunchKernelGGL(sdf32_kernel<3>, dim3(grid), dim3(THREADS), LDS_BYTES, st, a);
   return 0;
 }

@@ -138,28 +138,6 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
 
 
 @_lib.on_tensor_device
-def sdf_train_forward_wide(sdf_w32, sdf_tab32, pts, scratch: Optional[torch.Tensor] = None):
-    """``sdf_train_forward`` on the wide f16x3 kernels (csrc/nrh_sdf32.hip MODE 4; P % 32 == 0): same outputs, same saves."""
-    lib = _lib.load()
-    n = pts.shape[0]
-    dev = pts.device
-    f32 = dict(dtype=torch.float32, device=dev)
-    zeros3 = torch.zeros(n, 3, **f32)
-    zeros1 = torch.zeros(n, **f32)
-    sdf, grad, feat = torch.empty(n, 1, **f32), torch.empty(n, 3, **f32), torch.empty(n, 256, **f32)
-    saves = dict(h=torch.empty(8, n, 256, **f32), s1=torch.empty(8, n, 256, **f32), t=torch.empty(8, n, 256, **f32),
-                 ge=torch.zeros(n, 128, **f32), zeros3=zeros3, zeros1=zeros1)
-    if scratch is None:
-        scratch = _scratch(dev)
-    P = _lib.ptr
-    rc = lib.nrh_sdf_train_forward_wide(P(sdf_w32, sdf_w32.dtype), P(sdf_tab32), P(pts), P(zeros3), P(zeros1), 1, 1, n, P(sdf), P(grad),
-                                        P(feat), P(saves["h"]), P(saves["s1"]), P(saves["t"]), P(saves["ge"]), P(scratch),
-                                        _lib.stream_handle())
-    _lib.check(rc, "nrh_sdf_train_forward_wide")
-    return sdf, feat, grad, saves
-
-
-@_lib.on_tensor_device
 def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sbar, fbar, gbar):
     """The two backward sweeps at the points ro[ray] + rd[ray] * t[ray, j]
     -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3])."""

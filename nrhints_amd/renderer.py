@@ -143,6 +143,8 @@ class NeuSHintRenderer(nn.Module):
                             DepthComputationType.SphereTracing: 2}[config.renderer.depth_type]
         # the two free scalars of the renderer config (:161, :163) travel to the kernels through NrhNet when they are not the defaults
         rough, offs = [float(x) for x in config.renderer.specular_roughness], float(config.renderer.shadow_ray_offset)
+        if not self.has_specular_hint:
+            rough = [0.02, 0.05, 0.13, 0.34]      # no cue is computed: the values (any number of them) never reach a kernel
         self._net_consts = None if (rough == [0.02, 0.05, 0.13, 0.34] and offs == 1e-2) else (rough, offs)
         self.sdf_network = SDFNetwork(config.sdf_network)
         self.deviation_network = SingleVarianceNetwork(config.deviation_network.init_val)
@@ -263,10 +265,16 @@ class NeuSHintRenderer(nn.Module):
 
     def _range_guard_async(self, bufs, d, device) -> None:
         g = self.__dict__.setdefault("_range_guard", {"n": 0, "pending": None})
+        if torch.cuda.is_current_stream_capturing():
+            # inside a capture nothing may be read back and no event may be queried (hipEventQuery from the capturing thread
+            # invalidates a global / thread-local capture; a raise in the middle of one would leave it open): no poll, no new
+            # verdict.  GraphedTrainStep drains a pending verdict before it starts capturing and calls check_weight_range()
+            # between replays.
+            return
         self._range_guard_poll()
         g["n"] += 1
-        if g["pending"] is not None or (g["n"] - 1) % max(1, int(self.range_check_every)) != 0 or torch.cuda.is_current_stream_capturing():
-            return      # (inside a capture nothing may be read back: GraphedTrainStep calls check_weight_range() between replays)
+        if g["pending"] is not None or (g["n"] - 1) % max(1, int(self.range_check_every)) != 0:
+            return
         host = torch.ones((), dtype=torch.float32).pin_memory()
         host.copy_(self._range_ok(bufs, d), non_blocking=True)
         ev = torch.cuda.Event()
@@ -281,7 +289,14 @@ class NeuSHintRenderer(nn.Module):
         if pk is None or pk.get("precision") != 1:
             return
         halves = [v for v in pk.values() if torch.is_tensor(v) and v.dtype == torch.float16]
-        if halves and not bool(torch.stack([torch.isfinite(v).all() for v in halves]).all().item()):
+        tests = [torch.isfinite(v).all() for v in halves]
+        tab = pk.get("sdf_tab32")
+        if torch.is_tensor(tab):
+            # the bias rows of the wide kernels' table are packed fp16 pairs: what the eager pack tests on the dense parameters
+            # (packing32.tables_in_f16_range: |b * IK| < 65504) shows up here as an fp16 half at infinity / NaN
+            w = tab.reshape(-1, 256)[:9].view(torch.int32)           # rows 0..8: (b_hi | b_lo << 16) of packing32.sdf32_tables
+            tests += [((w & 0x7fff) < 0x7c00).all(), (((w >> 16) & 0x7fff) < 0x7c00).all(), torch.isfinite(tab.reshape(-1, 256)[9:]).all()]
+        if tests and not bool(torch.stack(tests).all().item()):
             raise ValueError(self._RANGE_MSG)
 
     def _const(self, device):

@@ -70,7 +70,8 @@ class FlatGradAllReduce:
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.always = always      # run the collective at world size 1 as well (tests of the RCCL path on one GPU)
-        self._flat: Optional[torch.Tensor] = None
+        self._flat: Optional[torch.Tensor] = None          # what reduce() operates on this step
+        self._own_flat: Optional[torch.Tensor] = None      # pack scratch of the copy path (never a zero-copy buffer)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Initial parameter sync from rank 0 (what DDP does at wrap time)."""
@@ -108,8 +109,9 @@ class FlatGradAllReduce:
             return
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         n = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
-            self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        if self._own_flat is None or self._own_flat.numel() != n or self._own_flat.device != grads[0].device:
+            self._own_flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        self._flat = self._own_flat      # (a zero-copy step's buffer is the live .grad storage of a fused buffer set: never scratch)
         off = 0
         for g in grads:
             self._flat[off: off + g.numel()].copy_(g.reshape(-1))
@@ -190,10 +192,14 @@ def train_step(renderer, ray_bundle, rgb_gt, background_rgb, global_step: int, o
 def release_device_scalars(renderer) -> None:
     """Undo what ``train_step(..., sync=False)`` switched on: 1/s and the cos-anneal ratio back on the host.  Raises the f16x3
     weight-range ``ValueError`` here if the sync-free steps drove a weight out of range (the guard is asynchronous in that mode)."""
-    renderer.check_weight_range()
-    renderer.dyn_scalars = None
-    renderer._packed_key = None
-    renderer._generation = getattr(renderer, "_generation", 0) + 1
+    try:
+        renderer.check_weight_range()
+    finally:
+        # also when the guard raises: the renderer must not stay in device-scalar mode with a NaN host 1/s (the caller may
+        # switch to precision "f32" and go on, ADVICE r4)
+        renderer.dyn_scalars = None
+        renderer._packed_key = None
+        renderer._generation = getattr(renderer, "_generation", 0) + 1
 
 
 class GraphedTrainStep:
@@ -317,6 +323,8 @@ class GraphedTrainStep:
         # (in the default global mode hipEventQuery from ANY thread invalidates the capture / kills the watchdog - measured).
         mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
         torch.cuda.synchronize(dev)
+        # a weight-range verdict the warm-up packs enqueued is read (and raised) NOW: no event query may happen inside the capture
+        renderer._range_guard_poll(wait=True)
         if self._sync_active():
             # The collective stays OUTSIDE the graphs: graph 1 = forward + loss + backward + gradient flattening, one eager
             # all-reduce on the same stream, graph 2 = unflatten + Adam - three launches per step instead of one.  (A captured

@@ -38,5 +38,11 @@ def grad_bound(ref32, ref64, factor=3.0, floor=1e-4):
     sample near the surface lands differently (its weight moves by 1.8e-3) - while the reference's float32 run happened to land
     within 5e-5 of its float64 run there.  Returns (absolute bound, scale); the comparison is made against the float64 gradient."""
     ref32, ref64 = np.asarray(ref32, dtype=np.float64), np.asarray(ref64, dtype=np.float64)
-    scale = max(float(np.abs(ref64).max()), 1e-12)
-    return max(factor * float(np.abs(ref32 - ref64).max()), floor * scale), scale
+    return grad_bound_from_noise(float(np.abs(ref32 - ref64).max()), ref64, factor, floor)
+
+
+def grad_bound_from_noise(noise, ref64, factor=3.0, floor=1e-4):
+    """``grad_bound`` for fixtures that record max |ref32 - ref64| of a tensor as one number (``noise.<name>`` in
+    tests/golden/train1024_b.npz) instead of the whole float32 gradient: same bound, same defaults."""
+    scale = max(float(np.abs(np.asarray(ref64, dtype=np.float64)).max()), 1e-12)
+    return max(factor * float(noise), floor * scale), scale

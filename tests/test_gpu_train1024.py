@@ -1,0 +1,135 @@
+"""Training parity at the size BASELINE configs[2] is quoted on: 1 024 rays = 131 072 sample points per
+step - the 8-wave `sdf_kernel<3>` / tangent / value sweeps and the 131 072-point table of `nrh_dw_gemm`, not the channel-split
+small-batch kernels the 40-ray fixtures run - at the three cos-anneal ratios SURVEY.md section 8d lists for C3: global_step 0
+(ratio 0), 25 000 (0.5) and 100 000 (saturated at 1; models/neus_hint_model.py:668-671).  The fixture
+(tests/golden/train1024_b.npz, written by tests/golden/make_golden_train1024.py from the imported reference) holds the reference's
+float64 gradients of all 46 parameter tensors and of the rays, and its own float32-vs-float64 distance per tensor, from which
+the tolerances are derived exactly as for the 40-ray fixtures (tests/conftest.py grad_bound: 3 x that distance, floor 1e-4 of the
+tensor's scale).  Three routes to the same numbers: the autograd-free fused step, the autograd Functions, and the captured
+hipGraph replay (one graph, the anneal ratio a device scalar) - each against the reference directly."""
+import numpy as np
+import pytest
+import torch
+
+import nrhints_amd as na
+from nrhints_amd import train_fused
+from tests.conftest import grad_bound_from_noise, load_npz
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+STEPS = (0, 25000, 100000)
+N = 1024
+
+
+def cu(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).float().contiguous().cuda()
+
+
+@pytest.fixture(scope="module")
+def fx():
+    g = load_npz("train1024_b.npz")
+    assert tuple(int(s) for s in g["steps"]) == STEPS and g["o"].shape == (N, 3)
+    return g
+
+
+def _model(state, prec="f16x3"):
+    m = na.NeuSHintRenderer(na.NeuSModelConfig(), precision=prec)
+    m.load_state_dict({k: T(np.asarray(v)) for k, v in state.items()})
+    return m.cuda()
+
+
+def _bundle(g, ray_grad=False):
+    rb = na.RayBundle(origins=cu(g["o"]), directions=cu(g["d"]), pl_positions=cu(g["pl"]), nears=cu(g["near"]), fars=cu(g["far"]))
+    if ray_grad:
+        for t_ in (rb.origins, rb.directions, rb.pl_positions):
+            t_.requires_grad_(True)
+    return rb
+
+
+def _check_losses(ld, g, p):
+    np.testing.assert_allclose(float(ld["loss"]), float(g[p + "loss_f64"]), rtol=2e-4)
+    np.testing.assert_allclose(float(ld["rgb_loss"]), float(g[p + "rgb_loss_f64"]), rtol=2e-4)
+    np.testing.assert_allclose(float(ld["eikonal_loss"]), float(g[p + "eikonal_loss_f64"]), rtol=2e-3)
+
+
+def _check_grads(g, p, param_grads, ray_grads=None):
+    """every tensor against the reference's float64 gradient, bound = 3 x the reference's own float32 noise on that tensor"""
+    report = []
+    assert len(param_grads) == 46
+    for name, got in param_grads.items():
+        want = g[p + "grad64." + name]
+        assert got is not None and tuple(got.shape) == tuple(want.shape), name
+        tol, scale = grad_bound_from_noise(g[p + "noise." + name], want)
+        err = float(np.abs(got.detach().cpu().numpy().astype(np.float64) - want).max())
+        report.append((err / tol, name, err / scale, tol / scale))
+    for nm, got in (ray_grads or {}).items():
+        want = g[p + "grad64.rays." + nm]
+        tol, scale = grad_bound_from_noise(g[p + "noise.rays." + nm], want)
+        err = float(np.abs(got.detach().cpu().numpy().astype(np.float64) - want).max())
+        report.append((err / tol, "rays." + nm, err / scale, tol / scale))
+    bad = sorted((r for r in report if not r[0] < 1.0), reverse=True)
+    assert not bad, "gradient outside its derived bound (ratio, tensor, err/scale, bound/scale): " + repr(bad[:8])
+    return max(r[0] for r in report)
+
+
+@pytest.mark.parametrize("gs", STEPS)
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_fused_step_1024_vs_reference(scene_states, fx, prec, gs):
+    """train_fused.train_step_backward (58 launches, the 8-wave training kernels, one 131 072-point nrh_dw_gemm table): loss dict,
+    rgb, 46 parameter gradients and the three ray gradients (nrh_ray_adjoint) against the reference's float64 step."""
+    g, p = fx, f"s{gs}."
+    model = _model(scene_states["b"], prec)
+    rb = _bundle(g, ray_grad=True)
+    assert train_fused.supported(model, rb) is None
+    rays = {}
+    loss8 = train_fused.train_step_backward(model, rb, cu(g["rgb_gt"]), torch.ones(1, 3).cuda(), gs, t_rand_primary=cu(g[p + "t_rand_primary"]),
+                                            t_rand_shadow=cu(g[p + "t_rand_shadow"]), ray_grads=rays)
+    _check_losses(train_fused.loss_dict(loss8), g, p)
+    B = next(iter(model._fused_buffers.values()))
+    rgb = B.rgb.cpu().numpy()
+    assert float(np.abs(rgb - g[p + "rgb_f64"]).max()) < max(1e-4, 3.0 * float(np.abs(g[p + "rgb"] - g[p + "rgb_f64"]).max()))
+    _check_grads(g, p, {k: v.grad for k, v in model.named_parameters()}, rays)
+
+
+@pytest.mark.parametrize("gs", STEPS)
+def test_autograd_path_1024_vs_reference(scene_states, fx, gs):
+    """forward(is_training=True) + the caller's loss + loss.backward() through the autograd Functions (what the reference's
+    trainer calls, pipelines/base_pipeline.py:41-69): same fixture, same bounds."""
+    from nrhints_amd.training import train_loss_dict
+    g, p = fx, f"s{gs}."
+    model = _model(scene_states["b"])
+    rb = _bundle(g, ray_grad=True)
+    out = model(rb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=gs,
+                _t_rand_primary=cu(g[p + "t_rand_primary"]), _t_rand_shadow=cu(g[p + "t_rand_shadow"]))
+    ld = train_loss_dict(out, cu(g["rgb_gt"]), model.config.igr_weight)
+    ld["loss"].backward()
+    _check_losses({k: float(v) for k, v in ld.items() if k in ("loss", "rgb_loss", "eikonal_loss")}, g, p)
+    _check_grads(g, p, {k: v.grad for k, v in model.named_parameters()},
+                 dict(origins=rb.origins.grad, directions=rb.directions.grad, pl_positions=rb.pl_positions.grad))
+
+
+def test_graphed_step_1024_vs_reference(scene_states, fx):
+    """training.GraphedTrainStep: ONE captured hipGraph of the fused step, replayed at the three global steps (the anneal ratio and
+    the learning rate are device scalars the replay reads; the jitter buffers are overwritten in place).  Learning rate 0: Adam
+    runs inside the graph and leaves the parameters where the fixture's gradients were taken."""
+    from nrhints_amd.training import GraphedTrainStep
+    g = fx
+    model = _model(scene_states["b"])
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    rb = _bundle(g)
+    gt, bg = cu(g["rgb_gt"]), torch.ones(1, 3).cuda()
+    tp, ts = cu(g["s0.t_rand_primary"]), cu(g["s0.t_rand_shadow"])
+    step = GraphedTrainStep(model, N, bg, lr=0.0, warm_up_end=0, global_step=STEPS[0], jitter=(tp, ts), fused=True)
+    assert step._use_fused
+    try:
+        for gs in STEPS:
+            p = f"s{gs}."
+            step.jitter[0].copy_(cu(g[p + "t_rand_primary"]).reshape(step.jitter[0].shape))
+            step.jitter[1].copy_(cu(g[p + "t_rand_shadow"]).reshape(step.jitter[1].shape))
+            got = step(rb, gt, global_step=gs)
+            _check_losses(got, g, p)
+            _check_grads(g, p, {k: v.grad for k, v in model.named_parameters()})
+            for k, v in model.named_parameters():
+                assert torch.equal(v.detach(), before[k]), (gs, k)        # lr = 0
+    finally:
+        step.release()

@@ -283,41 +283,3 @@ def test_wide_sdf_subnormal_activations(scene_states, level):
     s16, g16, f16 = ops.sdf_at_points(2, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], pts.cuda())
     np.testing.assert_allclose(s16.cpu().numpy()[:, 0], o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
     np.testing.assert_allclose(pk.feat_tiles_to_rows(f16.cpu(), pts.shape[0]).numpy(), o_feat.numpy(), rtol=0, atol=3e-5)
-
-
-@pytest.mark.parametrize("npts", [32, 2048, 4096 + 64])
-def test_wide_training_forward_vs_16pt_and_oracle(wscene, npts):
-    """The training forward on the wide machinery (nrh_sdf_train_forward_wide, csrc/nrh_sdf32.hip MODE 4) writes the SAME arrays as
-    the 16-point training kernel (nrh_sdf_train_forward): outputs against the fp64 oracle, every saved array against the 16-point
-    kernel in exact-fp32 arithmetic on the same points (row layout, layer indices, the skip substitution in save_h[3] / save_s1[3],
-    the embedding-gradient columns)."""
-    tag, model, packed, p64 = wscene
-    g = torch.Generator().manual_seed(7 + npts)
-    pts = ((torch.rand(npts, 3, generator=g) * 2 - 1) * 0.95).cuda()
-    sdf, feat, grad, sv = ops.sdf_train_forward_wide(packed["sdf_w32"], packed["sdf_tab32"], pts)
-    st = {k: v.detach() for k, v in model.state_dict().items()}
-    d = pk.dense_params({k: v.float().cuda() for k, v in st.items()})
-    w0, b0, h0 = pk.pack_sdf(d, 0)
-    sdf_r, feat_r, grad_r, sv_r = ops.sdf_train_forward(w0, b0, h0, pts)
-    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, pts.cpu().double())
-    np.testing.assert_allclose(sdf.cpu().numpy(), o_sdf.numpy(), rtol=0, atol=5e-6)
-    np.testing.assert_allclose(feat.cpu().numpy(), o_feat.numpy(), rtol=0, atol=3e-5)
-    np.testing.assert_allclose(grad.cpu().numpy(), o_grad.numpy(), rtol=0, atol=1e-4 if tag == "a" else 5e-4)
-    c = lambda t: t.cpu().numpy()
-    # activations O(0.01..1): fp32 round-off class
-    np.testing.assert_allclose(c(sv["h"]), c(sv_r["h"]), rtol=0, atol=4e-6)
-    np.testing.assert_array_equal(c(sv["h"])[3][:, 217:] != 0, c(sv_r["h"])[3][:, 217:] != 0)          # the embedding sits there
-    np.testing.assert_allclose(c(sv["s1"]), c(sv_r["s1"]), rtol=0, atol=3e-5)     # sigma' = sigmoid(100 z): 100 x the error of z
-    assert float(sv["s1"][3][:, 217:].abs().max()) == 0.0
-    # t_l = sigma'_l a_{l+1}: the reverse chain runs on the unorm16 sigma' of the evaluation kernels (7.6e-6 per layer)
-    scale_t = float(sv_r["t"].abs().max())
-    np.testing.assert_allclose(c(sv["t"]), c(sv_r["t"]), rtol=0, atol=2e-4 * scale_t)
-    for sl in (slice(0, 39), slice(73, 112)):
-        np.testing.assert_allclose(c(sv["ge"])[:, sl], c(sv_r["ge"])[:, sl], rtol=0, atol=2e-4 * float(sv_r["ge"][:, sl].abs().max()))
-    # mean errors, which a misplaced row / column would blow up while a tolerance on the maximum might not
-    assert float((sv["t"] - sv_r["t"]).abs().mean()) < 2e-6 * scale_t
-    assert float((sv["h"] - sv_r["h"]).abs().mean()) < 2e-7
-    # determinism (row stores, the skip fix-up and the sigma' scratch all leave in a fixed order): a second run is bit-identical
-    sdf2, feat2, grad2, sv2 = ops.sdf_train_forward_wide(packed["sdf_w32"], packed["sdf_tab32"], pts)
-    for x, y in ((sdf, sdf2), (feat, feat2), (grad, grad2), (sv["h"], sv2["h"]), (sv["s1"], sv2["s1"]), (sv["t"], sv2["t"]), (sv["ge"], sv2["ge"])):
-        assert torch.equal(x, y)
