@@ -114,7 +114,13 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
  *   writes  abar, zbar [8][npts][256] (row-major), coup (8 * npts * 256 floats of hand-off between the two sweeps, tile-native:
  *   opaque to the caller), gebar [npts][64] and pbar [npts,3] (adjoint of the points through the
  *   value path; the caller adds the term through the encoding's second derivative, see sdf_function.py).
- *   wt_feat: the feature head transposed, packed as one 256x256 stage (packing.pack_feat_transposed). */
+ *   wt_feat: the feature head transposed, packed as one 256x256 stage (packing.pack_feat_transposed).
+ * adj_scale (this entry, nrh_color_train_backward, nrh_outside_backward): a power of two S in [2^-60, 2^60], used by precision f16x3
+ *   only: the kernel carries S x (its input adjoints) through the chain and writes 1 / S x (the result) - same values, but the
+ *   fp16 halves of the 3-term split see adjoints of a magnitude that does not depend on the batch size.  The loss is normalised
+ *   by the ray count (pipelines/base_pipeline.py:57-62): at 1 024 rays per step unscaled adjoints are ~ 1e-3 of a single ray's
+ *   and the split's absolute floor (3e-11 below 6e-5) cost up to 6e-3 of a gradient tensor's scale against the reference's
+ *   float64 step (tests/test_gpu_train1024.py).  Pass 2^round(log2(rays in the batch)); 1 reproduces the unscaled chain. */
 int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                           float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
@@ -123,7 +129,7 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
                            const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
                            const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
-                           void* stream);
+                           float adj_scale, void* stream);
 
 /* ---- the outside-NeRF background network (renderer.use_outside_nerf) -----------------------------------------------------
  * fields/nerf_density_field.py:30-89 as called from models/neus_hint_model.py:434-473: per point of the inverted-sphere
@@ -142,7 +148,7 @@ int nrh_outside_forward(int precision, const float* on_w, const float* on_b, con
                         float* save_f, float* save_hv, void* stream);
 int nrh_outside_backward(int precision, const float* on_wt, const float* alpha_w, const float* density_bar, const float* rgb_bar,
                          const float* save_h, const float* save_hv, long long npts, float* zbar, float* fbar, float* zvbar, float* xbar,
-                         float* vbar, void* stream);
+                         float* vbar, float adj_scale, void* stream);
 
 /* ---- weight-norm fold ---------------------------------------------------------------------------------------
  * W = v * g / ||v||_row for up to 16 linears in one launch (old-style nn.utils.weight_norm, dim = 0:
@@ -174,7 +180,7 @@ int nrh_color_train_forward(int precision, int hints, const float* col_w, const 
                             const float* pts, const float* normal, const float* raymisc, long long nrays, float* color,
                             float* save_h, float* save_misc, void* stream);
 int nrh_color_train_backward(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
-                             long long nrays, float* zbar, float* fbar, float* mbar, void* stream);
+                             long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, void* stream);
 
 /* ---- alpha stage, training ---------------------------------------------------------------------------------
  * NeuSHintRenderer.get_alpha + compositing weights + unit normals (models/neus_hint_model.py:339-356, :521-525, :584)

@@ -52,6 +52,19 @@ class NrhTrainSaves(Structure):
                 ("shadow_dists", c_void_p), ("vis_groups", c_void_p)]
 
 
+def adjoint_scale(n_rays: int) -> float:
+    """``adj_scale`` of nrh_sdf_train_backward / nrh_color_train_backward / nrh_outside_backward for a batch of ``n_rays`` rays: the
+    power of two that brings the adjoints of a loss normalised by the ray count (pipelines/base_pipeline.py:57-62) to the magnitude
+    they have in a batch of about 8 rays, whatever the batch size.  The f16x3 kernels split every adjoint into fp16 halves with an
+    absolute floor of 3e-11 below 6e-5: unscaled, a 1 024-ray step lost up to 6e-3 of a gradient tensor's scale against the
+    reference's float64 step; the 40-ray fixtures (magnitudes of an unscaled 40-ray batch) and scales 64 .. 32 768 at 1 024 rays
+    were all inside the bounds (profiles/r05/train1024_diag2.log).  8 leaves three more octaves of head-room to fp16's 65 504
+    than a scale of n_rays would (the largest seed, d alpha / d sdf <= inv_s / 4 per unit of colour adjoint, grows with the
+    trained sharpness).  Ignored by precision f32."""
+    import math
+    return float(2.0 ** max(0, round(math.log2(max(1, int(n_rays)) / 8.0))))
+
+
 class HipExtensionMissing(RuntimeError):
     pass
 
@@ -84,8 +97,8 @@ def load():
     lib.nrh_ray_adjoint.argtypes = [P, P, P, P, P, P, P, P, c_int, P, c_longlong, P, P, P, P]
     lib.nrh_outside_sizes.argtypes = [POINTER(c_int)]
     lib.nrh_outside_forward.argtypes = [c_int, P, P, P, P, P, c_int, c_longlong, P, P, P, P, P, P, P, P]
-    lib.nrh_outside_backward.argtypes = [c_int, P, P, P, P, P, P, c_longlong, P, P, P, P, P, P]
-    lib.nrh_sdf_train_backward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P, P]
+    lib.nrh_outside_backward.argtypes = [c_int, P, P, P, P, P, P, c_longlong, P, P, P, P, P, c_float, P]
+    lib.nrh_sdf_train_backward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P, c_float, P]
     lib.nrh_alpha_train_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P]
     lib.nrh_alpha_train_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P]
     lib.nrh_alpha_train_forward_n.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P, P]
@@ -99,7 +112,7 @@ def load():
     lib.nrh_color_transposed_floats.restype = c_longlong
     lib.nrh_color_train_forward.argtypes = [c_int, c_int, P, P, P, P, P, P, c_longlong, P, P, P, P]
     lib.nrh_color_train_forward_grouped.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_longlong, P, P, P, P]
-    lib.nrh_color_train_backward.argtypes = [c_int, c_int, P, P, P, c_longlong, P, P, P, P]
+    lib.nrh_color_train_backward.argtypes = [c_int, c_int, P, P, P, c_longlong, P, P, P, c_float, P]
     PP = POINTER(c_void_p)
     lib.nrh_weight_norm_fold.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, P]
     lib.nrh_weight_norm_fold_backward.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, PP, PP, P]

@@ -376,7 +376,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 140; }
+int nrh_version(void) { return 141; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -485,12 +485,19 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
   return check_launch("sdf_kernel<3>");
 }
 
+// adj_scale of the three backward entries: a positive power of two (exact to apply and to undo)
+static bool adj_scale_ok(float s) {
+  int e = 0;
+  return s > 0.0f && s < 3.0e38f && frexpf(s, &e) == 0.5f && e >= -60 && e <= 60;
+}
+
 int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
                            const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
                            const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
-                           void* stream) {
+                           float adj_scale, void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!adj_scale_ok(adj_scale)) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: adj_scale must be a power of two in [2^-60, 2^60]%s", "");
   if (!sdf_w || !wt_feat || !sdf_head || !ro || !rd || !t || !save_s1 || !save_t || !gbar || !fbar || !sbar || !abar || !coup ||
       !gebar || !zbar || !pbar)
     return fail(NRH_E_INVALID, "nrh_sdf_train_backward: null pointer%s", "");
@@ -505,6 +512,7 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   a.gbar = gbar; a.abar = abar; a.coup = coup; a.gebar = gebar; a.fbar = fbar; a.sbar = sbar; a.zbar = zbar; a.pbar = pbar;
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride;
+  a.adj_scale = precision == 1 ? adj_scale : 1.0f;
   const hipStream_t st = (hipStream_t)stream;
   if (split_train(precision, a.npts)) {
     const dim3 gs((unsigned)(a.npts / 16)), bs(256);
@@ -636,8 +644,9 @@ int nrh_color_train_forward_grouped(int precision, int hints, const float* col_w
 }
 
 int nrh_color_train_backward(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
-                             long long nrays, float* zbar, float* fbar, float* mbar, void* stream) {
+                             long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_color_train_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!adj_scale_ok(adj_scale)) return fail(NRH_E_INVALID, "nrh_color_train_backward: adj_scale must be a power of two in [2^-60, 2^60]%s", "");
   if (!col_wt || !zbar4 || !save_h || !zbar || !fbar || !mbar) return fail(NRH_E_INVALID, "nrh_color_train_backward: null pointer%s", "");
   if (nrays < 0) return fail(NRH_E_INVALID, "nrh_color_train_backward: nrays < 0%s", "");
   if (nrays == 0) return NRH_OK;
@@ -647,6 +656,7 @@ int nrh_color_train_backward(int precision, int hints, const float* col_wt, cons
   memset(&a, 0, sizeof(a));
   a.wt = col_wt; a.zbar4 = zbar4; a.save_h = save_h; a.zbar = zbar; a.fbar = fbar; a.mbar = mbar;
   a.npts = nrays * 128;
+  a.adj_scale = precision == 1 ? adj_scale : 1.0f;
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_color_train_backward");
   if (rc) return rc;
@@ -714,8 +724,9 @@ int nrh_outside_forward(int precision, const float* on_w, const float* on_b, con
 
 int nrh_outside_backward(int precision, const float* on_wt, const float* alpha_w, const float* density_bar, const float* rgb_bar,
                          const float* save_h, const float* save_hv, long long npts, float* zbar, float* fbar, float* zvbar, float* xbar,
-                         float* vbar, void* stream) {
+                         float* vbar, float adj_scale, void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_outside_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (!adj_scale_ok(adj_scale)) return fail(NRH_E_INVALID, "nrh_outside_backward: adj_scale must be a power of two in [2^-60, 2^60]%s", "");
   if (!on_wt || !alpha_w || !density_bar || !rgb_bar || !save_h || !save_hv || !zbar || !fbar || !zvbar || !xbar || !vbar)
     return fail(NRH_E_INVALID, "nrh_outside_backward: null pointer%s", "");
   if (npts < 0 || npts % 16 != 0) return fail(NRH_E_INVALID, "nrh_outside_backward: the number of points must be a multiple of 16%s", "");
@@ -726,6 +737,7 @@ int nrh_outside_backward(int precision, const float* on_wt, const float* alpha_w
   memset(&a, 0, sizeof(a));
   a.wt = on_wt; a.walpha = alpha_w; a.dbar = density_bar; a.cbar = rgb_bar; a.save_h = save_h; a.save_hv = save_hv; a.zbar = zbar;
   a.fbar = fbar; a.zvbar = zvbar; a.xbar = xbar; a.vbar = vbar; a.npts = npts;
+  a.adj_scale = precision == 1 ? adj_scale : 1.0f;
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_outside_backward");
   if (rc) return rc;

@@ -41,6 +41,11 @@ struct ColorAdjArgs {
   float* mbar;           // [npts][16*MKB]  adjoint of the non-feature input part
   long long npts;
   int ntile_groups;
+  float adj_scale;       // f16x3 only: a power of two S.  The adjoint chain runs on S * (the seeds) and its outputs leave as 1 / S *
+                         // (the result): the loss is normalised by the ray count (pipelines/base_pipeline.py:57), so at 1 024 rays
+                         // per step the adjoints are ~ 1e-3 of a single ray's and their fp16 halves (absolute floor 3e-11 under
+                         // 6e-5) lose up to 6e-3 of a gradient tensor's scale - measured against the reference's 1 024-ray step,
+                         // profiles/r05/train1024_diag*.log.  The host passes 2^round(log2(rays)): batch-size independent ranges.
 };
 
 struct BiasV {
@@ -219,6 +224,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_adjoint_kernel(const Col
   int par = 0;
   dma_chunk(a.wt, smem, 4, wave, lane);
   __syncthreads();
+  // (ColorAdjArgs.adj_scale) everything between the seeds and the stores is linear in the seeds (ReLU masks come from save_h)
+  const float S = (PREC == 1) ? a.adj_scale : 1.0f, IS = 1.0f / S;
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -230,8 +237,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_adjoint_kernel(const Col
     auto store_rows = [&](float* base, int l, int width, int ch, const f32x4 v0, const f32x4 v1) {
       if (tile_ok) {
         float* p = base + ((size_t)l * (size_t)a.npts + (size_t)row) * width + 4 * q;
-        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0);
-        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
+        if constexpr (PREC == 1) {
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0 * IS);
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1 * IS);
+        } else {
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0);
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
+        }
       }
     };
     struct HPre { f32x4 h0, h1; };
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_adjoint_kernel(const Col
     {
       float o[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = (q == 0 && r < 3) ? a.zbar4[row * 3 + r] : 0.0f;
+      for (int r = 0; r < 8; ++r) o[r] = (q == 0 && r < 3) ? a.zbar4[row * 3 + r] * S : 0.0f;
       z4.set_chunk(0, o);
     }
     Act<PREC, 16> h;

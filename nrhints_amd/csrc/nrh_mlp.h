@@ -263,6 +263,43 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
   }
 }
 
+// ---------------- layout of the [layer][npts][256] float32 arrays of the training step ----------------
+// What the SDF training forward saves and the two backward sweeps hand on (csrc/nrh_sdf.hip MODE 3, nrh_sdf_train.hip, their
+// channel-split and 4-wave builds) - h, sigma', t, abar, coup, zbar - is written once and read once or twice, 1 KiB per point and
+// layer: the step's HBM traffic.  Two layouts, both with the 16 points of a tile in the same contiguous 16 KiB:
+//   ROWS   row-major [point][256]: a wave instruction (lane (j, q): 16 bytes of block blk of point j) touches 16 rows x 64 bytes;
+//          measured 5.6 TB/s for stores and 4.2 TB/s for loads (profiles/r04/rowstore.log);
+//   TILED  [tile][block 16][row (j + block) & 15][16 channels]: the same instruction is ONE contiguous KiB (6.3 / 6.4-7.1 TB/s).
+//          The rotation of the rows by the block index costs the kernels nothing and lets the weight-gradient kernel, which
+//          receives a tile's 16 KiB by LDS-DMA as they lie, read two adjacent channels of 16 points without a bank conflict
+//          (csrc/nrh_dw.hip convert: the eight lanes of a block read 64 contiguous bytes, four blocks sit four rows apart).
+// sigma' and coup are private to these kernels; h, t, abar, zbar are operands of nrh_dw_gemm, which is told (NrhDwJob.tiled).
+enum TrainArr { ARR_ROWS = 0, ARR_H, ARR_S1, ARR_T, ARR_ABAR, ARR_COUP, ARR_ZBAR };
+#ifndef NRH_TILE_S1
+#define NRH_TILE_S1 1         // sigma' tiled (round 5)
+#endif
+#ifndef NRH_COUP_TILE
+#define NRH_COUP_TILE 1       // coup tiled (round 4: profiles/r04/coup_ab.log)
+#endif
+#ifndef NRH_TILE_DW
+#define NRH_TILE_DW 0         // h, t, abar, zbar tiled (needs nrh_dw_gemm's tiled operand path)
+#endif
+__host__ __device__ constexpr bool arr_tiled(int arr) {
+  return arr == ARR_ROWS ? false : (arr == ARR_S1 ? (NRH_TILE_S1 != 0) : (arr == ARR_COUP ? (NRH_COUP_TILE != 0) : (NRH_TILE_DW != 0)));
+}
+// float offset of the lane's 4 consecutive channels (block blk, quarter q) of point `row` in layer l of such an array
+template <int ARR>
+__device__ __forceinline__ size_t arr_off(int l, long long npts, long long row, int blk, int q) {
+  if constexpr (arr_tiled(ARR)) {
+    const int j = (int)(row & 15);
+    return ((size_t)l * (size_t)npts + (size_t)(row - j)) * 256 + (size_t)blk * 256 + (size_t)((((j + blk) & 15) << 4) + 4 * q);
+  } else {
+    return ((size_t)l * (size_t)npts + (size_t)row) * 256 + (size_t)(blk * 16 + 4 * q);
+  }
+}
+template <int V>
+struct ArrTag { static constexpr int value = V; };
+
 // ---------------- packed-buffer geometry of the SDF net (floats) ----------------
 // execution order: L0 | L1..L7 | FEAT | R7..R1 | R0        (R_l = W_l^T, the reverse chain)
 constexpr int SDF_L0_FLOATS = 8 * 2 * 4 * 256;     // 8 chunks x (2 ob x 4 kb) KiB (39 inputs -> 64)

@@ -90,6 +90,7 @@ struct OutsideAdjArgs {
   float* vbar;           // [npts][64]      adjoint of enc4(cat[view, light])
   long long npts;
   int ntile_groups;
+  float adj_scale;       // f16x3 only: power of two S; the chain runs on S * seeds, outputs leave as 1 / S (see ColorAdjArgs, nrh_color.hip)
 };
 
 struct OnBias { f32x4 b0, b1; };
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_adjoint_kernel(const O
   int par = 0;
   dma_chunk(a.wt + ONT_OFF_RGB, smem, 4, wave, lane);
   __syncthreads();
+  const float S = (PREC == 1) ? a.adj_scale : 1.0f, IS = 1.0f / S;
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -292,22 +294,27 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_adjoint_kernel(const O
     auto store_rows = [&](float* base, int l, int width, int ch, const f32x4 v0, const f32x4 v1) {
       if (tile_ok) {
         float* p = base + ((size_t)l * (size_t)a.npts + (size_t)row) * width + 4 * q;
-        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0);
-        st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
+        if constexpr (PREC == 1) {
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0 * IS);
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1 * IS);
+        } else {
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0);
+          st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
+        }
       }
     };
     struct HPre { f32x4 h0, h1; };
     auto mask = [](const f32x4 h, const f32x4 g) {
       return f32x4{h[0] > 0.0f ? g[0] : 0.0f, h[1] > 0.0f ? g[1] : 0.0f, h[2] > 0.0f ? g[2] : 0.0f, h[3] > 0.0f ? g[3] : 0.0f};
     };
-    const float db = a.dbar[row];
+    const float db = a.dbar[row] * S;
 
     // ---- TRGB: 3 -> 128 (the adjoint of the 3 outputs sits in block 0, lanes q == 0, registers 0..2) ----
     Act<PREC, 2> c3;
     {
       float o[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = (q == 0 && r < 3) ? a.cbar[row * 3 + r] : 0.0f;
+      for (int r = 0; r < 8; ++r) o[r] = (q == 0 && r < 3) ? a.cbar[row * 3 + r] * S : 0.0f;
       c3.set_chunk(0, o);
     }
     Act<PREC, 8> zv;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void outside_adjoint_kernel(const O
         p.h1 = *rows_ptr(a.xbar, 0, ON_X, 2 * ch + 1);
         return p;
       };
-      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const HPre& p) { store_rows(a.xbar, 0, ON_X, ch, acc0 + p.h0, acc1 + p.h1); };
+      auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const HPre& p) { store_rows(a.xbar, 0, ON_X, ch, acc0 + p.h0 * S, acc1 + p.h1 * S); };
       run_stage<PREC, 16, 3, false, true>(a.wt + ONT_OFF_T0, a.wt + ONT_OFF_RGB, 4, smem, par, h, nullptr, pre, epi, wave, lane);
     }
   }

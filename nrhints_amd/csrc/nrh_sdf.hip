@@ -94,14 +94,6 @@ __device__ __forceinline__ float* t7_ptr(float* scr, int blk, int lane) {
   return scr + ((PREC == 0) ? 7 * 16 * 256 : 7 * 2048) + (blk * 64 + lane) * 4;
 }
 
-// the lane's 4 consecutive features (block blk) of its point in a row-major [layer][npts][256] training array
-__device__ __forceinline__ float* rm_ptr(float* base, int l, long long npts, long long row, int blk, int q) {
-  return base + ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * q;
-}
-__device__ __forceinline__ const float* rm_ptr(const float* base, int l, long long npts, long long row, int blk, int q) {
-  return base + ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * q;
-}
-
 // MODE 0: sdf | 1: sdf + gradient | 2: + feature tiles (inference render) | 3: training forward (= 2 with row-major saves)
 template <int MODE, int PREC>
 __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
@@ -131,17 +123,18 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     auto ds_store = [&](int l, int ch, const f32x4 d0, const f32x4 d1) {
       if constexpr (TRAIN) {
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>(rm_ptr(a.save_s1, l, a.npts, row, 2 * ch, q)), d0);
-          st_stream(reinterpret_cast<f32x4*>(rm_ptr(a.save_s1, l, a.npts, row, 2 * ch + 1, q)), d1);
+          st_stream(reinterpret_cast<f32x4*>((a.save_s1 + arr_off<ARR_S1>(l, a.npts, row, 2 * ch, q))), d0);
+          st_stream(reinterpret_cast<f32x4*>((a.save_s1 + arr_off<ARR_S1>(l, a.npts, row, 2 * ch + 1, q))), d1);
         }
       } else {
         dsig_store<PREC>(scr, l, ch, lane, d0, d1);
       }
     };
-    auto save_rows = [&](float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
+    auto save_rows = [&](auto AT, float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
+      constexpr int ARR = decltype(AT)::value;
       if (tile_ok) {
-        st_stream(reinterpret_cast<f32x4*>(rm_ptr(base, l, a.npts, row, 2 * ch, q)), v0);
-        st_stream(reinterpret_cast<f32x4*>(rm_ptr(base, l, a.npts, row, 2 * ch + 1, q)), v1);
+        st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch, q))), v0);
+        st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch + 1, q))), v1);
       }
     };
     float x3[3];
@@ -175,7 +168,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         softplus100_4<WANT_D>(acc1 + p.a1, h1, d1);
         h.set_chunk(ch, h0, h1);
         if (MODE >= 1) ds_store(0, ch, d0, d1);
-        if constexpr (TRAIN) save_rows(a.save_h, 0, ch, h0, h1);
+        if constexpr (TRAIN) save_rows(ArrTag<ARR_H>(), a.save_h, 0, ch, h0, h1);
       };
       run_stage<PREC, 4, 8, false, true>(a.w + SDF_OFF_L0, a.w + sdf_off_L(1), 32, smem, par, emb, nullptr, pre, epi, wave, lane);
     }
@@ -211,8 +204,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         for (int ch = 0; ch < 8; ++ch) {
           f32x4 v0, v1;
           if constexpr (TRAIN) {
-            v0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_t, 7, a.npts, row, 2 * ch, q)));
-            v1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_t, 7, a.npts, row, 2 * ch + 1, q)));
+            v0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch, q))));
+            v1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch + 1, q))));
           } else {
             v0 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)));
             v1 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)));
@@ -234,8 +227,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         } else if (MODE >= 1) {
           // sigma' of the layer this stage's output feeds
           if constexpr (TRAIN) {
-            p.a0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch, q)));
-            p.a1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch + 1, q)));
+            p.a0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(16 - s - 1, a.npts, row, 2 * ch, q))));
+            p.a1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(16 - s - 1, a.npts, row, 2 * ch + 1, q))));
           } else {
             dsig_issue<PREC>(scr, 16 - s - 1, ch, lane, p);
           }
@@ -270,7 +263,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             }
             if constexpr (TRAIN) {
               ds_store(7, ch, d0, d1);
-              save_rows(a.save_t, 7, ch, d0 * (p.b0 * (1.0f / 3.0f)), d1 * (p.b1 * (1.0f / 3.0f)));
+              save_rows(ArrTag<ARR_T>(), a.save_t, 7, ch, d0 * (p.b0 * (1.0f / 3.0f)), d1 * (p.b1 * (1.0f / 3.0f)));
             } else if (MODE >= 1) {
               st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)), d0 * (p.b0 * (1.0f / 3.0f)));
               st_stream(reinterpret_cast<f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)), d1 * (p.b1 * (1.0f / 3.0f)));
@@ -278,11 +271,11 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
           } else if (MODE >= 1) {
             ds_store(s, ch, d0, d1);
           }
-          if constexpr (TRAIN) save_rows(a.save_h, s, ch, h0, h1);
+          if constexpr (TRAIN) save_rows(ArrTag<ARR_H>(), a.save_h, s, ch, h0, h1);
           ho.set_chunk(ch, h0, h1);
         } else if (s == 8) {
           if constexpr (TRAIN) {
-            save_rows(a.feat, 0, ch, acc0 + p.a0, acc1 + p.a1);
+            save_rows(ArrTag<ARR_ROWS>(), a.feat, 0, ch, acc0 + p.a0, acc1 + p.a1);
           } else if (MODE == 2) {
             if (tile * TILE_PTS < a.npts) {
               float* ft = a.feat + (size_t)tile * (16 * 256);
@@ -305,7 +298,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
             if constexpr (TRAIN) {
               d0 = p.a0;
               d1 = p.a1;
-              save_rows(a.save_t, l - 1, ch, acc0 * d0, acc1 * d1);
+              save_rows(ArrTag<ARR_T>(), a.save_t, l - 1, ch, acc0 * d0, acc1 * d1);
             } else {
               dsig_decode<PREC>(p, d0, d1);
             }

@@ -33,7 +33,7 @@ struct SdfTrainArgs {
   const float* tt;       // [8][npts][256] from the forward
   const float* gbar;     // [npts][3]   tangent sweep in
   float* abar;           // [8][npts][256] tangent sweep out: abar_{l+1} at index l (index 7: s'_7 tbar_7, for d w_s)
-  float* coup;           // [8][npts][256] floats, tangent sweep out / value sweep in: tile-native (coup_off), not row-major
+  float* coup;           // [8][npts][256] floats, tangent sweep out / value sweep in: tiled (nrh_mlp.h arr_off<ARR_COUP>), not row-major
   float* gebar;          // [npts][64]  tangent sweep out: abar_0 (39 used)
   const float* fbar;     // [npts][256] value sweep in
   const float* sbar;     // [npts]      value sweep in
@@ -43,6 +43,11 @@ struct SdfTrainArgs {
   int n_per_ray;
   int t_stride;
   int ntile_groups;
+  float adj_scale;       // f16x3 only: a power of two S.  The adjoint chain runs on S * (the seeds) and its outputs leave as 1 / S *
+                         // (the result): the loss is normalised by the ray count (pipelines/base_pipeline.py:57), so at 1 024 rays
+                         // per step the adjoints are ~ 1e-3 of a single ray's and their fp16 halves (absolute floor 3e-11 under
+                         // 6e-5) lose up to 6e-3 of a gradient tensor's scale - measured against the reference's 1 024-ray step,
+                         // profiles/r05/train1024_diag*.log.  The host passes 2^round(log2(rays)): batch-size independent ranges.
 };
 
 struct TrainPre {
@@ -77,25 +82,7 @@ __device__ __forceinline__ float enc_dentry_dot_q(const float (&x)[3], const flo
   return (kind == 2) ? c * mul : ((kind == 1) ? mul : 0.0f);
 }
 
-// `coup` is a hand-off between the two sweeps and nothing else reads it: TILE-NATIVE instead of row-major - layer l, tile, 16-channel
-// block, lane: every store / load instruction of a wave is one contiguous KiB (profiles/r04/rowstore.log: 6.3 TB/s stores and
-// 6.4-7.1 TB/s loads against 5.6 / 4.2 for the 16 x 64-byte pattern of the row-major arrays).  Same size, [8][npts][256] floats.
-#ifndef NRH_COUP_TILE
-#define NRH_COUP_TILE 1
-#endif
-__device__ __forceinline__ size_t coup_off(int l, long long npts, long long row, int blk, int lane) {
-#if NRH_COUP_TILE
-  return ((size_t)l * (size_t)npts + (size_t)(row >> 4) * 16) * 256 + (size_t)blk * 256 + lane * 4;
-#else
-  return ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * (lane >> 4);
-#endif
-}
-__device__ __forceinline__ const float* rmc(const float* base, int l, long long npts, long long row, int blk, int q) {
-  return base + ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * q;
-}
-__device__ __forceinline__ float* rmw(float* base, int l, long long npts, long long row, int blk, int q) {
-  return base + ((size_t)l * (size_t)npts + (size_t)row) * 256 + blk * 16 + 4 * q;
-}
+// (layouts of s1 / t / abar / coup / zbar: nrh_mlp.h arr_off)
 
 // ------------------------------------------------------------------------------------------------------------------
 // tangent sweep
@@ -110,6 +97,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
 
   dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
   __syncthreads();
+  const float S = (PREC == 1) ? a.adj_scale : 1.0f, IS = 1.0f / S;   // SdfTrainArgs.adj_scale: the sweep is linear in gbar
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -122,7 +110,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tpar) * 3.0f;
-      g3[c] = a.gbar[row * 3 + c] * 3.0f;
+      g3[c] = a.gbar[row * 3 + c] * 3.0f * S;
     }
 
     // abar_0 (embedding layout of the forward's L0 input)
@@ -138,8 +126,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
       emb.set_chunk(c2, o);
       if (tile_ok) {
         float* gr = a.gebar + (size_t)row * 64 + 4 * q;
-        *reinterpret_cast<f32x4*>(gr + (2 * c2) * 16) = f32x4{o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<f32x4*>(gr + (2 * c2 + 1) * 16) = f32x4{o[4], o[5], o[6], o[7]};
+        *reinterpret_cast<f32x4*>(gr + (2 * c2) * 16) = f32x4{o[0], o[1], o[2], o[3]} * IS;
+        *reinterpret_cast<f32x4*>(gr + (2 * c2 + 1) * 16) = f32x4{o[4], o[5], o[6], o[7]} * IS;
       }
     }
 
@@ -147,10 +135,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
     for (int s = 0; s <= 7; ++s) {
       auto pre = [&](int ch) {
         TrainPre p;
-        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, s, a.npts, row, 2 * ch, q)));
-        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, s, a.npts, row, 2 * ch + 1, q)));
-        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, s, a.npts, row, 2 * ch, q)));
-        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, s, a.npts, row, 2 * ch + 1, q)));
+        p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(s, a.npts, row, 2 * ch, q))));
+        p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(s, a.npts, row, 2 * ch + 1, q))));
+        p.t0 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(s, a.npts, row, 2 * ch, q))));
+        p.t1 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(s, a.npts, row, 2 * ch + 1, q))));
         return p;
       };
       Act<PREC, 16> ho;
@@ -167,10 +155,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
           }
         }
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(s, a.npts, row, 2 * ch, lane)), c0);
-          st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(s, a.npts, row, 2 * ch + 1, lane)), c1);
-          st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, s, a.npts, row, 2 * ch, q)), n0);
-          st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, s, a.npts, row, 2 * ch + 1, q)), n1);
+          st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(s, a.npts, row, 2 * ch, q)), c0 * IS);
+          st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(s, a.npts, row, 2 * ch + 1, q)), c1 * IS);
+          st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(s, a.npts, row, 2 * ch, q))), n0 * IS);
+          st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(s, a.npts, row, 2 * ch + 1, q))), n1 * IS);
         }
         ho.set_chunk(ch, n0, n1);
       };
@@ -198,6 +186,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
 
   dma_chunk(a.wt_feat, smem, 32, wave, lane);
   __syncthreads();
+  const float S = (PREC == 1) ? a.adj_scale : 1.0f, IS = 1.0f / S;   // SdfTrainArgs.adj_scale: linear in (fbar, sbar, coup)
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -209,14 +198,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
     float x3[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tpar) * 3.0f;
-    const float sb3 = a.sbar[row] / 3.0f;
+    const float sb3 = a.sbar[row] / 3.0f * S;
 
     Act<PREC, 16> h;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
-      const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.fbar, 0, a.npts, row, 2 * ch, q)));
-      const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.fbar, 0, a.npts, row, 2 * ch + 1, q)));
-      h.set_chunk(ch, v0, v1);
+      const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch, q))));
+      const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch + 1, q))));
+      h.set_chunk(ch, v0 * S, v1 * S);
     }
 
     float skip[12];
@@ -227,10 +216,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
       const int lz = s - 1;  // layer whose zbar this stage's epilogue produces
       auto pre = [&](int ch) {
         TrainPre p;
-        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch, q)));
-        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
-        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch, lane)));
-        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch + 1, lane)));
+        p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch, q))));
+        p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch + 1, q))));
+        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch, q)));
+        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch + 1, q)));
         if (s == 8) {
           p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
           p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
@@ -251,10 +240,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
             skip[(2 * ch + 1 - 13) * 4 + r] = acc1[r];
           }
         }
-        const f32x4 z0 = p.s0 * acc0 + p.t0, z1 = p.s1 * acc1 + p.t1;
+        const f32x4 z0 = p.s0 * acc0 + p.t0 * S, z1 = p.s1 * acc1 + p.t1 * S;
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch, q)), z0);
-          st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1);
+          st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch, q))), z0 * IS);
+          st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch + 1, q))), z1 * IS);
         }
         ho.set_chunk(ch, z0, z1);
       };
@@ -296,7 +285,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
     }
     if (tile_ok && q == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a.pbar[row * 3 + c] = dx[c] * 3.0f;
+      for (int c = 0; c < 3; ++c) a.pbar[row * 3 + c] = dx[c] * 3.0f * IS;
     }
   }
 }

@@ -83,9 +83,10 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
   }
   __syncthreads();     // the tables are in LDS
 
-  auto save_rows = [&](float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
-    st_stream(reinterpret_cast<f32x4*>(rm_ptr(base, l, a.npts, row, 2 * ch, q)), v0);
-    st_stream(reinterpret_cast<f32x4*>(rm_ptr(base, l, a.npts, row, 2 * ch + 1, q)), v1);
+  auto save_rows = [&](auto AT, float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
+      constexpr int ARR = decltype(AT)::value;
+    st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch, q))), v0);
+    st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch + 1, q))), v1);
   };
   float* const Gl = G + (j * 4 + q) * SPLT_G_FLOATS;      // this lane's slots of the embedding-adjoint exchange
 
@@ -127,14 +128,14 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
           }
         }
       }
-      save_rows(a.save_s1, S, ch, d0, d1);
+      save_rows(ArrTag<ARR_S1>(), a.save_s1, S, ch, d0, d1);
       if constexpr (S == 7) {
-        save_rows(a.save_t, 7, ch, d0 * (p.b0 * (1.0f / 3.0f)), d1 * (p.b1 * (1.0f / 3.0f)));
+        save_rows(ArrTag<ARR_T>(), a.save_t, 7, ch, d0 * (p.b0 * (1.0f / 3.0f)), d1 * (p.b1 * (1.0f / 3.0f)));
         char* const p7 = h7 + j * SPLT_ROW7 + ((2 * ch) * 16 + 4 * q) * 4;
         *reinterpret_cast<f32x4*>(p7) = h0;
         *reinterpret_cast<f32x4*>(p7 + 64) = h1;
       }
-      save_rows(a.save_h, S, ch, h0, h1);
+      save_rows(ArrTag<ARR_H>(), a.save_h, S, ch, h0, h1);
       spl_store_act(out, j, q, ch, h0, h1);
     };
     if constexpr (S == 0) spl_stage<2, 2, 0, 8, 2, 4>(ring, cur, nxt, lane, bsrc, pre, epi);
@@ -162,14 +163,14 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
       SplPreF p;
       p.a0 = *reinterpret_cast<const f32x4*>(tab + 8 * 256 + (2 * ch) * 16 + 4 * q);
       p.a1 = *reinterpret_cast<const f32x4*>(tab + 8 * 256 + (2 * ch + 1) * 16 + 4 * q);
-      p.b0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_t, 7, a.npts, row, 2 * ch, q)));
-      p.b1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_t, 7, a.npts, row, 2 * ch + 1, q)));
+      p.b0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch, q))));
+      p.b1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch + 1, q))));
       return p;
     };
     auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const SplPreF& p) {
       constexpr int CI = decltype(CIC)::value;
       const int ch = 2 * wave + CI;
-      save_rows(a.feat, 0, ch, acc0 + p.a0, acc1 + p.a1);
+      save_rows(ArrTag<ARR_ROWS>(), a.feat, 0, ch, acc0 + p.a0, acc1 + p.a1);
       spl_store_act(buf0, j, q, ch, p.b0, p.b1);
     };
     spl_stage<8, 2, 0, 8, 2, 4>(ring, chunks(SDF_OFF_FEAT), chunks(sdf_off_R(7)), lane, ldsb(buf1), pre, epi);
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
       constexpr int CI = decltype(CIC)::value;
       const int ch = 2 * wave + CI;
       SplPreF p;
-      p.a0 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, L - 1, a.npts, row, 2 * ch, q)));
-      p.a1 = ld_stream(reinterpret_cast<const f32x4*>(rm_ptr(a.save_s1, L - 1, a.npts, row, 2 * ch + 1, q)));
+      p.a0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(L - 1, a.npts, row, 2 * ch, q))));
+      p.a1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(L - 1, a.npts, row, 2 * ch + 1, q))));
       return p;
     };
     auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const SplPreF& p) {
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
         }
       }
       const f32x4 o0 = acc0 * p.a0, o1 = acc1 * p.a1;
-      save_rows(a.save_t, L - 1, ch, o0, o1);
+      save_rows(ArrTag<ARR_T>(), a.save_t, L - 1, ch, o0, o1);
       spl_store_act(out, j, q, ch, o0, o1);
     };
     spl_stage<8, 2, 0, 8, decltype(NCN)::value, 4>(ring, cur, nxt, lane, ldsb(in), pre, epi);
@@ -316,8 +317,9 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrai
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tpar) * 3.0f;
-    g3[c] = a.gbar[row * 3 + c] * 3.0f;
+    g3[c] = a.gbar[row * 3 + c] * 3.0f * a.adj_scale;      // (SdfTrainArgs.adj_scale: scaled chain, outputs leave as 1 / S)
   }
+  const float IS = 1.0f / a.adj_scale;
   __builtin_amdgcn_sched_barrier(0);
 
   SplRing<4> ring;
@@ -339,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrai
     emb.set_chunk(c2, o);
     if (wave == 0) {
       float* gr = a.gebar + (size_t)row * 64 + 4 * q;
-      *reinterpret_cast<f32x4*>(gr + (2 * c2) * 16) = f32x4{o[0], o[1], o[2], o[3]};
-      *reinterpret_cast<f32x4*>(gr + (2 * c2 + 1) * 16) = f32x4{o[4], o[5], o[6], o[7]};
+      *reinterpret_cast<f32x4*>(gr + (2 * c2) * 16) = f32x4{o[0], o[1], o[2], o[3]} * IS;
+      *reinterpret_cast<f32x4*>(gr + (2 * c2 + 1) * 16) = f32x4{o[4], o[5], o[6], o[7]} * IS;
     }
   }
 
@@ -350,10 +352,10 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrai
       constexpr int CI = decltype(CIC)::value;
       const int ch = 2 * wave + CI;
       TrainPre p;
-      p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, S, a.npts, row, 2 * ch, q)));
-      p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, S, a.npts, row, 2 * ch + 1, q)));
-      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, S, a.npts, row, 2 * ch, q)));
-      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.tt, S, a.npts, row, 2 * ch + 1, q)));
+      p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(S, a.npts, row, 2 * ch, q))));
+      p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(S, a.npts, row, 2 * ch + 1, q))));
+      p.t0 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(S, a.npts, row, 2 * ch, q))));
+      p.t1 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(S, a.npts, row, 2 * ch + 1, q))));
       return p;
     };
     auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const TrainPre& p) {
@@ -373,10 +375,10 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrai
           }
         }
       }
-      st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(S, a.npts, row, 2 * ch, lane)), c0);
-      st_stream(reinterpret_cast<f32x4*>(a.coup + coup_off(S, a.npts, row, 2 * ch + 1, lane)), c1);
-      st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, S, a.npts, row, 2 * ch, q)), n0);
-      st_stream(reinterpret_cast<f32x4*>(rmw(a.abar, S, a.npts, row, 2 * ch + 1, q)), n1);
+      st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(S, a.npts, row, 2 * ch, q)), c0 * IS);
+      st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(S, a.npts, row, 2 * ch + 1, q)), c1 * IS);
+      st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(S, a.npts, row, 2 * ch, q))), n0 * IS);
+      st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(S, a.npts, row, 2 * ch + 1, q))), n1 * IS);
       if constexpr (S < 7) spl_store_act(out, j, q, ch, n0, n1);
     };
     if constexpr (S == 0) spl_stage<2, 2, 0, 8, 2, 4>(ring, cur, nxt, lane, bsrc, pre, epi);
@@ -413,14 +415,15 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
   float x3[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) x3[c] = (a.ro[ray * 3 + c] + a.rd[ray * 3 + c] * tpar) * 3.0f;
-  const float sb3 = a.sbar[row] / 3.0f;
+  const float AS = a.adj_scale, IS = 1.0f / AS;      // (SdfTrainArgs.adj_scale: scaled chain, outputs leave as 1 / S)
+  const float sb3 = a.sbar[row] / 3.0f * AS;
   // fbar of this wave's 64 channels -> B rows of the first stage
   f32x4 fb[2][2];
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci) {
     const int ch = 2 * wave + ci;
-    fb[ci][0] = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.fbar, 0, a.npts, row, 2 * ch, q)));
-    fb[ci][1] = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.fbar, 0, a.npts, row, 2 * ch + 1, q)));
+    fb[ci][0] = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch, q)))) * AS;
+    fb[ci][1] = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch + 1, q)))) * AS;
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -441,10 +444,10 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
       constexpr int CI = decltype(CIC)::value;
       const int ch = 2 * wave + CI;
       TrainPre p;
-      p.s0 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch, q)));
-      p.s1 = ld_stream(reinterpret_cast<const f32x4*>(rmc(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
-      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch, lane)));
-      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + coup_off(lz, a.npts, row, 2 * ch + 1, lane)));
+      p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch, q))));
+      p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch + 1, q))));
+      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch, q)));
+      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch + 1, q)));
       if constexpr (S == 8) {
         p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
         p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
@@ -466,9 +469,9 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
           *reinterpret_cast<f32x4*>(Gl + 16 + (2 * chs + 1 - 13) * 4) = acc1;
         }
       }
-      const f32x4 z0 = p.s0 * acc0 + p.t0, z1 = p.s1 * acc1 + p.t1;
-      st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch, q)), z0);
-      st_stream(reinterpret_cast<f32x4*>(rmw(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1);
+      const f32x4 z0 = p.s0 * acc0 + p.t0 * AS, z1 = p.s1 * acc1 + p.t1 * AS;
+      st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch, q))), z0 * IS);
+      st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch + 1, q))), z1 * IS);
       spl_store_act(out, j, q, ch, z0, z1);
     };
     spl_stage<8, 2, 0, 8, decltype(NCN)::value, 4>(ring, cur, nxt, lane, SplLdsB{in + j * SPL_ROW + 16 * q}, pre, epi);
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
     }
     if (q == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a.pbar[row * 3 + c] = dx[c] * 3.0f;
+      for (int c = 0; c < 3; ++c) a.pbar[row * 3 + c] = dx[c] * 3.0f * IS;
     }
   }
 }

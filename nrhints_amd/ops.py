@@ -138,9 +138,10 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
 
 
 @_lib.on_tensor_device
-def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sbar, fbar, gbar):
+def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sbar, fbar, gbar, adj_scale: float = 1.0):
     """The two backward sweeps at the points ro[ray] + rd[ray] * t[ray, j]
-    -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3])."""
+    -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3]).  ``adj_scale``: see _lib.adjoint_scale (a training step passes
+    it; 1 = the adjoints as they come, for callers whose adjoints are O(1))."""
     lib = _lib.load()
     nrays = ro.shape[0]
     n = nrays * n_per_ray
@@ -154,7 +155,7 @@ def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sb
         raise ValueError("sdf_w and wt_feat are packed for different precisions")
     rc = lib.nrh_sdf_train_backward(prec, wp, wtp, P(sdf_head), P(ro), P(rd), P(t), n_per_ray, n_per_ray, nrays,
                                     P(saves["s1"]), P(saves["t"]), P(gbar), P(fbar), P(sbar), P(out["abar"]), P(out["coup"]),
-                                    P(out["gebar"]), P(out["zbar"]), P(out["pbar"]), _lib.stream_handle())
+                                    P(out["gebar"]), P(out["zbar"]), P(out["pbar"]), float(adj_scale), _lib.stream_handle())
     _lib.check(rc, "nrh_sdf_train_backward")
     return out
 

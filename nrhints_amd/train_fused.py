@@ -192,7 +192,7 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         # ---- reflectance adjoint sweep ----
         cwt = pk["col_wt"]
         _lib.check(lib.nrh_color_train_backward(pk["precision"], int(hints), P_(cwt, cwt.dtype), P_(B.zbar4), P_(B.save_h), n, P_(B.czbar),
-                                                P_(B.fbar), P_(B.mbar), stream), "nrh_color_train_backward")
+                                                P_(B.fbar), P_(B.mbar), _lib.adjoint_scale(n), stream), "nrh_color_train_backward")
         # ---- alpha stage adjoint (+ the eikonal seed; the unit normal's adjoint are columns 3..5 of mbar) ----
         mw = B.mbar.shape[1]
         nbar = ctypes.c_void_p(B.mbar.data_ptr() + 12)
@@ -203,7 +203,8 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         if want_params:
             _lib.check(lib.nrh_variance_grad(P_(B.invs_bar), n, float(inv_s), P_(dyn), P_(B.var_bar), stream), "nrh_variance_grad")
         # ---- SDF network: tangent + value sweeps ----
-        r = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], o, d, res["mid_z"], 128, sv, B.sdf_bar, B.fbar, B.grad_bar)
+        r = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], o, d, res["mid_z"], 128, sv, B.sdf_bar, B.fbar, B.grad_bar,
+                                   adj_scale=_lib.adjoint_scale(n))
         # ---- ray adjoints (pose / light refinement): one per-ray reduction of what the sweeps left ----
         if want_rays:
             _lib.check(lib.nrh_ray_adjoint(P_(o), P_(d), P_(pl), P_(res["mid_z"]), P_(r["pbar"]), P_(B.grad_bar), P_(sv["ge"]), P_(B.mbar), mw,

@@ -15,7 +15,7 @@ Per step s in {0, 25000, 100000} (keys prefixed "s<step>."):
                                    is four orders below every bound) - 46 tensors; grad64.rays.<origins|directions|pl_positions>
   noise.<name>, noise.rays.<...>   max |grad32 - grad64| over the tensor: the reference's own float32 noise, which is
                                    what tests/conftest.grad_bound turns into the tolerance (full float32 gradients would
-                                   double the file for one number per tensor)
+                                   double the file for one number per tensor);  noise2.<...>: its L2 norm ||grad32 - grad64||_2
 Shared: o, d, pl, near, far (nrhints_amd.synthetic.make_rays(1024, seed=41, spread=0.1)), rgb_gt (seeded uniform colours).
 Weights: scene b = perturb_state(scene_a_state.npz) with variance 0.7, as every other *_b fixture.
 """
@@ -106,6 +106,7 @@ def main():
         for k in g64:
             rec[p + "grad64." + k] = g64[k].numpy().astype(np.float32)
             rec[p + "noise." + k] = np.float64((g32[k].double() - g64[k]).abs().max().item())
+            rec[p + "noise2." + k] = np.float64((g32[k].double() - g64[k]).pow(2).sum().sqrt().item())
         worst = max((float(rec[p + "noise." + k]) / max(float(g64[k].abs().max()), 1e-30), k) for k in g64)
         print(f"step {gs}: loss {float(l32[0]):.6f} (f64 {float(l64[0]):.6f}) eik {float(l32[2]):.5f}; worst f32 noise / scale "
               f"{worst[0]:.2e} on {worst[1]}; {time.time() - t0:.0f} s", flush=True)

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 140
+    assert lib.nrh_version() == 141
     lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
     from nrhints_amd import packing32 as pk32
     assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
@@ -218,11 +218,14 @@ def test_training_entry_points_validate_arguments_without_a_device():
     assert lib.nrh_sdf_train_forward(1, None, None, None, None, None, None, 1, 1, 16, None, None, None, None, None, None, None, None) == -1
     assert "null" in err()
     assert lib.nrh_sdf_train_backward(1, None, None, None, None, None, None, 1, 1, 16, None, None, None, None, None, None, None, None,
-                                      None, None, None) == -1 and "null" in err()
+                                      None, None, 1.0, None) == -1 and "null" in err()
+    assert lib.nrh_sdf_train_backward(1, one, one, one, one, one, one, 1, 1, 16, one, one, one, one, one, one, one, one, one, one, 3.0, None) == -1
+    assert "power of two" in err()
     assert lib.nrh_alpha_train_forward(None, None, None, None, 1.0, 1.0, None, 4, None, None, None) == -1 and "null" in err()
     assert lib.nrh_alpha_train_backward(None, None, None, None, 1.0, 1.0, None, 4, None, None, None, None, None, None, None) == -1
     assert lib.nrh_color_train_forward(1, 1, None, None, None, None, None, None, 4, None, None, None, None) == -1 and "null" in err()
-    assert lib.nrh_color_train_backward(1, 1, None, None, None, 4, None, None, None, None) == -1 and "null" in err()
+    assert lib.nrh_color_train_backward(1, 1, None, None, None, 4, None, None, None, 1.0, None) == -1 and "null" in err()
+    assert lib.nrh_color_train_backward(1, 1, one, one, one, 4, one, one, one, 0.0, None) == -1 and "power of two" in err()
     # bad precision / point count not a multiple of 16
     assert lib.nrh_sdf_train_forward(7, one, one, one, one, one, one, 1, 1, 16, one, one, one, one, one, one, one, None) == -1
     assert "precision" in err()
@@ -232,7 +235,7 @@ def test_training_entry_points_validate_arguments_without_a_device():
     # zero rays: nothing to do, success
     assert lib.nrh_sdf_train_forward(1, one, one, one, one, one, one, 1, 1, 0, one, one, one, one, one, one, one, None) == 0
     assert lib.nrh_alpha_train_forward(one, one, one, one, 1.0, 1.0, None, 0, one, one, None) == 0
-    assert lib.nrh_color_train_backward(1, 1, one, one, one, 0, one, one, one, None) == 0
+    assert lib.nrh_color_train_backward(1, 1, one, one, one, 0, one, one, one, 128.0, None) == 0
     # fold: layer count and shape limits
     IntArr, PtrArr = ctypes.c_int * 1, ctypes.c_void_p * 1
     assert lib.nrh_weight_norm_fold(0, IntArr(4), IntArr(4), PtrArr(16), PtrArr(16), PtrArr(16), None) == -1
