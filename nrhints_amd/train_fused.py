@@ -15,8 +15,12 @@ Ray gradients (pose / light refinement: the reference's default preset nr-hints-
 require grad, one more launch (nrh_ray_adjoint) reduces the sweeps' adjoints to d loss / d (origins, directions, pl_positions),
 which are handed to the ray generator's backward (nrh_generate_rays_indexed_backward through its autograd.Function).
 
-Restrictions (the autograd path covers the rest): GPU float32 parameters, normal_type NormalizedAnalytic, at most
-``max_fused_train_rays`` rays per call.
+Covered since round 5 (each differs from the default model only in what the alpha / colour stages are fed): ``normal_type``
+Analytic (the reflectance net reads the raw gradient, its adjoint goes straight into the gradient's), one hint without the other
+(the kernels of the full model on a first reflectance layer whose missing columns are zero; their gradient columns are dropped)
+and the partial visibility hint (``n_shadow_importance_clip``: one row of per-ray inputs per group of samples).
+Restrictions (the autograd path covers the rest): GPU float32 parameters, no hint gradients, no outside NeRF, 128 samples per
+ray, at most ``max_fused_train_rays`` rays per call.
 """
 from __future__ import annotations
 
@@ -32,8 +36,6 @@ LOSS_KEYS = ("loss", "rgb_loss", "eikonal_loss", "s_val", "psnr")
 
 def supported(renderer, ray_bundle) -> Optional[str]:
     """None if the fused step applies, else the reason it does not."""
-    if renderer._normal_type != 0:
-        return "normal_type Analytic"
     rc = renderer.config.renderer
     if (rc.shadow_hint_gradient and renderer.has_shadow_hint) or (rc.specular_hint_gradient and renderer.has_specular_hint):
         return "hint gradients (differentiated by the autograd path)"
@@ -41,10 +43,6 @@ def supported(renderer, ray_bundle) -> Optional[str]:
         return "outside-NeRF background"
     if getattr(renderer, "_samples", 128) != 128:
         return "n_importance_samples = 0 (64 samples per ray)"
-    if getattr(renderer, "_shadow_clip", -1) > 0:
-        return "partial visibility hint (n_shadow_importance_clip > 0)"
-    if getattr(renderer, "_mixed_hints", False):
-        return "one hint without the other (zero-padded first reflectance layer)"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
         return "more rays than max_fused_train_rays"
     if ray_bundle.origins.shape[0] == 0:
@@ -60,12 +58,13 @@ def supported(renderer, ray_bundle) -> Optional[str]:
 class _Buffers:
     """Per-(device, rays) arrays of a step, allocated once and reused (a captured graph bakes their addresses in)."""
 
-    def __init__(self, dev, n: int, hints: bool, shapes: Dict[str, tuple], param_layout: Dict[str, tuple]):
+    def __init__(self, dev, n: int, hints: bool, shapes: Dict[str, tuple], param_layout: Dict[str, tuple], clip: int = 1):
         T, P = 128, n * 128
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.n, self.dev = n, dev
         mw = 128 if hints else 64
-        self.raymisc = torch.zeros(n, packing.RAYMISC_STRIDE, dtype=torch.float32, device=dev)
+        # per-ray inputs of the reflectance net: one row per ray, or per group of 128 / clip samples (partial visibility hint)
+        self.raymisc = torch.zeros(n * max(1, clip), packing.RAYMISC_STRIDE, dtype=torch.float32, device=dev)
         self.pts = new(P, 3)
         self.color, self.save_h, self.save_misc = new(P, 3), new(4, P, 256), new(P, mw)
         self.rgb, self.zbar4, self.wbar, self.partial, self.loss8 = new(n, 3), new(P, 3), new(n, T), new(n, 4), new(8)
@@ -92,6 +91,9 @@ class _Buffers:
         g["Wf"], g["bf"] = new(256, 256), self.pgrad["sdf_network.out_feat.bias"].view(-1)
         for l in range(5):
             g[f"w{l}"], g[f"b{l}"] = new(*shapes[f"col_w{l}"]), self.pgrad[f"color_network.lin{l}.bias"].view(-1)
+        # one-hint models: the weight-gradient kernel fills the full model's [256, 361] first layer; ``w0_real`` receives the
+        # columns that exist in the parameter (``shapes["col_w0_real"]``)
+        self.w0_real = new(*shapes["col_w0_real"]) if tuple(shapes["col_w0_real"]) != tuple(shapes["col_w0"]) else None
         self.g = g
         self.vbars = {"v:" + k: self.pgrad[k + ".weight_v"] for k in packing._FOLD_LAYERS}
         self.gbars = {"g:" + k: self.pgrad[k + ".weight_g"] for k in packing._FOLD_LAYERS}
@@ -130,14 +132,17 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         t_p = t_s = None
         if is_training:
             want_s = not zero_hints and renderer._hints
+            srows = n * max(1, int(getattr(renderer, "_shadow_clip", -1)))      # one shadow ray per ray, or per group of samples (:560-568)
             if t_rand_primary is None and t_rand_shadow is None and want_s:
                 n64 = (n + 63) // 64 * 64                        # (the shadow block stays 256-byte aligned)
-                r = torch.rand(n64 + n * 64, device=dev)        # one generator launch: primary jitter [n], then shadow jitter [n, 64]
-                t_p, t_s = r[:n], r[n64:].view(n, 64)
+                r = torch.rand(n64 + srows * 64, device=dev)    # one generator launch: primary jitter [n], then shadow jitter [rows, 64]
+                t_p, t_s = r[:n], r[n64:].view(srows, 64)
             else:
                 t_p = f32(t_rand_primary).reshape(-1) if t_rand_primary is not None else torch.rand(n, device=dev)
                 if want_s:
-                    t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(n, 64, device=dev)
+                    t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(srows, 64, device=dev)
+                    if tuple(t_s.shape) != (srows, 64):
+                        raise ValueError(f"t_rand_shadow must be [{srows}, 64]")
         want_rays = any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions))
         want_params = any(p.requires_grad for p in renderer.parameters())
         # ---- parameters: fold weight-norm (one launch), re-pack ----
@@ -149,8 +154,12 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         dense = {}
         for (wk, bk), k, w in zip(packing._FOLD_KEYS, packing._FOLD_LAYERS, ws):
             dense[wk], dense[bk] = w, named[k + ".bias"].detach()
+        w0_real_shape = tuple(dense["col_w0"].shape)
+        dense = renderer._pad_hint_columns(dense)            # one-hint models: zero columns for the hint that is not there
         pk = renderer.packed_params(dev, dense=dense)
         hints = bool(renderer._hints)
+        clip = max(1, int(getattr(renderer, "_shadow_clip", -1)))
+        analytic = bool(renderer._normal_type)
         key = (str(dev), n, hints)
         cache = renderer.__dict__.setdefault("_fused_buffers", {})     # per renderer: .grad aliases these arrays
         B = cache.get(key)
@@ -162,13 +171,14 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             for k in [k for k in cache if k not in pinned]:
                 del cache[k]
             shapes = {k: tuple(v.shape) for k, v in dense.items()}
+            shapes["col_w0_real"] = w0_real_shape
             shapes.update({"v:" + k: tuple(v.shape) for k, v in zip(packing._FOLD_LAYERS, vs)})
             shapes.update({"g:" + k: tuple(x.shape) for k, x in zip(packing._FOLD_LAYERS, gs)})
             layout, off = {}, 0
             for pname, prm in renderer.named_parameters():
                 layout[pname] = (off, tuple(prm.shape))
                 off += prm.numel()
-            B = cache[key] = _Buffers(dev, n, hints, shapes, layout)
+            B = cache[key] = _Buffers(dev, n, hints, shapes, layout, clip)
         # ---- no-grad stages + SDF training forward (one C call) ----
         res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc)
         pre, sv = res["pre"], res["pre"]["saves"]
@@ -178,9 +188,13 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         torch.mul(d[:, None, :], res["mid_z"][..., None], out=pts3)
         pts3.add_(o[:, None, :])
         cw = pk["col_w"]
-        _lib.check(lib.nrh_color_train_forward(pk["precision"], int(hints), P_(cw, cw.dtype), P_(pk["col_b"]), P_(pre["feat"]), P_(B.pts),
-                                               P_(res["nhat"].view(Pn, 3)), P_(B.raymisc), n, P_(B.color), P_(B.save_h), P_(B.save_misc),
-                                               stream), "nrh_color_train_forward")
+        # the normal the reflectance net reads: normalised (default) or the raw gradient (normal_type Analytic, :622-623)
+        normal_in = (res["normals"] if analytic else res["nhat"]).view(Pn, 3)
+        # rows of per-ray inputs: one per ray, or - partial visibility hint outside the geometry warm-up - one per group of samples
+        per_row = 128 // clip if (clip > 1 and not zero_hints) else 128
+        _lib.check(lib.nrh_color_train_forward_grouped(pk["precision"], int(hints), P_(cw, cw.dtype), P_(pk["col_b"]), P_(pre["feat"]), P_(B.pts),
+                                                       P_(normal_in), P_(B.raymisc), per_row, n, P_(B.color), P_(B.save_h),
+                                                       P_(B.save_misc), stream), "nrh_color_train_forward")
         # ---- composite, loss, adjoint seeds ----
         bg = f32(background_rgb.to(dev)).reshape(-1) if background_rgb is not None else None
         gt = f32(rgb_gt)
@@ -195,11 +209,15 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
                                                 P_(B.fbar), P_(B.mbar), _lib.adjoint_scale(n), stream), "nrh_color_train_backward")
         # ---- alpha stage adjoint (+ the eikonal seed; the unit normal's adjoint are columns 3..5 of mbar) ----
         mw = B.mbar.shape[1]
-        nbar = ctypes.c_void_p(B.mbar.data_ptr() + 12)
+        # NormalizedAnalytic: the unit normal's adjoint goes through the normalisation inside the kernel; Analytic: the reflectance
+        # net read the gradient itself, its adjoint is added to the gradient's below
+        nbar = None if analytic else ctypes.c_void_p(B.mbar.data_ptr() + 12)
         _lib.check(lib.nrh_alpha_train_backward_fused(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), float(inv_s),
                                                       float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, mw, P_(res["inside"]),
                                                       ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
                                                       P_(B.invs_bar), stream), "nrh_alpha_train_backward_fused")
+        if analytic:
+            B.grad_bar.add_(B.mbar[:, 3:6])
         if want_params:
             _lib.check(lib.nrh_variance_grad(P_(B.invs_bar), n, float(inv_s), P_(dyn), P_(B.var_bar), stream), "nrh_variance_grad")
         # ---- SDF network: tangent + value sweeps ----
@@ -221,7 +239,15 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         dw.run(jobs, Pn)
         # ---- weight-norm adjoint -> .grad ----
         g = B.g
-        wbars = [g[f"dW{l}"] for l in range(8)] + [g["ws"], g["Wf"]] + [g[f"w{l}"] for l in range(5)]
+        w0bar = g["w0"]
+        if B.w0_real is not None:       # one-hint model: drop the gradient columns of the hint that does not exist (renderer._pad_hint_columns)
+            if renderer.has_shadow_hint:
+                B.w0_real.copy_(w0bar[:, :B.w0_real.shape[1]])
+            else:
+                B.w0_real[:, :316].copy_(w0bar[:, :316])
+                B.w0_real[:, 316:].copy_(w0bar[:, 325:])
+            w0bar = B.w0_real
+        wbars = [g[f"dW{l}"] for l in range(8)] + [g["ws"], g["Wf"], w0bar] + [g[f"w{l}"] for l in range(1, 5)]
         bbars = [g[f"db{l}"] for l in range(8)] + [g["bs"], g["bf"]] + [g[f"b{l}"] for l in range(5)]
         vbars = [B.vbars["v:" + k] for k in packing._FOLD_LAYERS]
         gbars = [B.gbars["g:" + k] for k in packing._FOLD_LAYERS]

@@ -179,6 +179,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(scaling):
     assert len(lines) == 1
     line = lines[0]
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0 and line.get("rehearsal") is True
+    # the line says what the process group was: backend, world size as the collective library sees it, one entry per rank
+    assert line["comm"]["backend"] == "gloo" and line["comm"]["world_size"] == 2 and line["comm"]["all_reduce_of_ones"] == 2.0
+    assert len(line["comm"]["devices"]) == 2 and line["comm"]["devices"][1].startswith("rank 1:")
     rays = 640000 * (2 if scaling == "weak" else 1)
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - rays) < 1e-3 * rays
     if scaling == "weak":
