@@ -283,6 +283,21 @@ typedef struct NrhNet {
   int custom_consts;
   double specular_roughness[4];
   double shadow_ray_offset;
+  /* Sample counts off the reference's defaults (models/neus_hint_model.py:139-171; n_coarse = 0: the defaults - 64 + 64 importance
+     samples in 4 steps on the primary ray, 64 + 64 on the shadow ray - and `samples` as described above).  Otherwise:
+       n_coarse  renderer.n_samples (2 .. 128)        n_steps  renderer.up_sample_steps (0 with n_importance_samples = 0)
+       n_new     n_importance_samples / up_sample_steps, at most 16;   samples = n_coarse + n_steps * n_new <= 128
+       s_coarse  n_shadow_samples (2 .. 64)           s_new    n_shadow_importance_samples / 4 (the shadow march always takes 4
+                 steps, :373; 0 = none), at most 16;  s_coarse + 4 s_new <= 128
+     lin_tables: DEVICE [4][128] float32, rows = torch.linspace(0, 1, k) for k = n_coarse, n_new, s_coarse, s_new (bit-exact
+     tables from the host, like lin64 / lin16; t_rand_shadow is then [nrays, s_coarse]).  The per-sample arrays keep 128 entries
+     per ray; entries past `samples` are padding with weight exactly 0.  Not with bg_alpha or shadow_clip > 0. */
+  int n_coarse;
+  int n_steps;
+  int n_new;
+  int s_coarse;
+  int s_new;
+  const float* lin_tables;
 } NrhNet;
 
 long long nrh_render_workspace_floats(long long nrays);

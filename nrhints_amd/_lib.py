@@ -38,7 +38,8 @@ class NrhNet(Structure):
                 ("sdf_w32", c_void_p), ("sdf_tab32", c_void_p), ("feat_fused", c_int),
                 ("col_w32", c_void_p), ("col_tab32", c_void_p), ("shadow_jvp", c_int), ("shadow_clip", c_int),
                 ("samples", c_int), ("bg_alpha", c_void_p), ("tail_t", c_void_p), ("sampled_color", c_void_p),
-                ("custom_consts", c_int), ("specular_roughness", ctypes.c_double * 4), ("shadow_ray_offset", ctypes.c_double)]
+                ("custom_consts", c_int), ("specular_roughness", ctypes.c_double * 4), ("shadow_ray_offset", ctypes.c_double),
+                ("n_coarse", c_int), ("n_steps", c_int), ("n_new", c_int), ("s_coarse", c_int), ("s_new", c_int), ("lin_tables", c_void_p)]
 
 
 class NrhAdamTensor(Structure):
@@ -215,10 +216,12 @@ def stream_handle(device=None):
 
 
 def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False,
-             shadow_clip=-1, samples=128, bg_alpha=None, tail_t=None, sampled_color=None, consts=None):
+             shadow_clip=-1, samples=128, bg_alpha=None, tail_t=None, sampled_color=None, consts=None, counts=None):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
-    ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32)."""
+    ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32).
+    ``counts``: None (the reference's default sample counts) or (n_coarse, n_steps, n_new, s_coarse, s_new, lin_tables [4,128] on
+    the device), see NrhNet in include/nrhints_hip.h."""
     fused = bool(fused and wide and pk.get("sdf_w32f") is not None)
     w32 = (pk.get("sdf_w32f") if fused else pk.get("sdf_w32")) if wide else None
     tab = pk.get("sdf_tab32f") if fused else pk.get("sdf_tab32")
@@ -232,4 +235,6 @@ def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fu
                   ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
                   ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None,
                   int(bool(shadow_jvp and w32 is not None)), int(shadow_clip), int(samples), ptr(bg_alpha), ptr(tail_t), ptr(sampled_color),
-                  int(consts is not None), rough, offs)
+                  int(consts is not None), rough, offs,
+                  *((0, 0, 0, 0, 0, None) if counts is None else (int(counts[0]), int(counts[1]), int(counts[2]), int(counts[3]), int(counts[4]),
+                                                                   ptr(counts[5]))))

@@ -106,6 +106,22 @@ class NeuSModelConfig:
     inference_chunk_size: int = 512
 
 
+def sample_counts(r: "NeuSRendererConfig"):
+    """(n_coarse, n_steps, n_new, s_coarse, s_new) the kernels run for this renderer config, or None if they cannot
+    (models/neus_hint_model.py:696-713: n_importance_samples // up_sample_steps new samples per step on the primary ray; :373-412: the
+    shadow march always takes 4 steps of n_shadow_importance_samples // 4)."""
+    nc, ni, st = int(r.n_samples), int(r.n_importance_samples), int(r.up_sample_steps)
+    snc, sni = int(r.n_shadow_samples), int(r.n_shadow_importance_samples)
+    if ni <= 0 or st <= 0:
+        st, nn = 0, 16
+    else:
+        nn = ni // st
+    sn = sni // 4 if sni > 0 else 0
+    ok = (2 <= nc <= 128 and 0 <= st <= 8 and 1 <= nn <= 16 and nc + st * nn <= 128 and 2 <= snc <= 64 and 0 <= sn <= 16
+          and (sni <= 0 or sn >= 1) and snc + 4 * sn <= 128)
+    return (nc, st, nn, snc, sn) if ok else None
+
+
 def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
     """None if ``cfg`` is the network/renderer shape the gfx950 kernels are compiled for, else why not."""
     s, c, r = cfg.sdf_network, cfg.reflectance_network, cfg.renderer
@@ -122,12 +138,13 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
         (not r.use_outside_nerf or (n.d_hidden == 256 and n.n_layers == 8 and n.multi_res == 10 and n.multi_res_view == 4
                                     and list(n.skips) == [4]),
          "outside_nerf must be the default 8x256 / multires 10 + 4 / skips=[4] network"),
-        (r.n_samples == 64 and ((r.n_importance_samples == 64 and r.up_sample_steps == 4) or r.n_importance_samples == 0),
-         "n_samples must be 64 and n_importance_samples / up_sample_steps 64 / 4, or n_importance_samples 0 (no hierarchical sampling)"),
-        (not (r.n_importance_samples == 0 and r.shadow_hint and r.n_shadow_importance_clip > 0),
-         "the partial visibility hint needs the 128-sample layout (n_importance_samples = 64)"),
-        (r.n_shadow_samples == 64 and r.n_shadow_importance_samples == 64,
-         "n_shadow_samples/n_shadow_importance_samples must be 64/64"),
+        (sample_counts(r) is not None,
+         "sample counts: 2 <= n_samples, n_importance_samples // up_sample_steps in 1..16 (or n_importance_samples = 0), up_sample_steps <= 8 "
+         "and n_samples + up_sample_steps * (n_importance_samples // up_sample_steps) <= 128; 2 <= n_shadow_samples <= 64, "
+         "n_shadow_importance_samples // 4 in 1..16 (or 0) and n_shadow_samples + 4 * (n_shadow_importance_samples // 4) <= 128 "
+         "(the kernels keep 128 slots per ray and draw at most 16 importance samples per step)"),
+        (not ((r.use_outside_nerf or (r.shadow_hint and r.n_shadow_importance_clip > 0)) and sample_counts(r) != (64, 4, 16, 64, 16)),
+         "the outside NeRF and the partial visibility hint need the default sample counts (64 + 64 / 4 steps, 64 + 64 on the shadow ray)"),
         (r.n_shadow_importance_clip in (-1, 1, 2, 4, 8, 16) or not r.shadow_hint,
          "n_shadow_importance_clip must be -1 (hit point) or 1, 2, 4, 8, 16 (partial visibility hint: that many shadow rays per ray)"),
         # force_* only adds the hint to has_*_hint (models/neus_hint_model.py:239-240): a no-op when the hint is on; with the hint

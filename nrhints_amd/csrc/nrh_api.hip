@@ -310,10 +310,46 @@ int color_eval_impl(int prec, int hints, const float* w, const float* b, const f
   return check_launch("color_kernel");
 }
 
-// hierarchical sampling of one family of rays: coarse sdf, 4 x (up-sample 16, evaluate, merge), finalise sections
+// Sample counts of one family of rays (models/neus_hint_model.py:139-171, :696-713, :373-412): nc coarse samples, `steps`
+// up-sampling steps of n_new samples each (lin_new = linspace(0, 1, n_new), at most 16), nc + steps * n_new <= 128 in all.  The
+// default {64, 4, 16} is the reference's 64 + 64 / 4.
+struct SamplerPlan {
+  int nc, steps, n_new;
+  const float* lin_new;
+  int total() const { return nc + steps * n_new; }
+};
+constexpr int LIN_TABLE_STRIDE = 128;     // NrhNet.lin_tables: [4][128] floats
+// the primary rays' / the shadow rays' plan of a net: NrhNet.n_coarse == 0 -> the defaults with the caller's lin16 table
+static SamplerPlan primary_plan(const NrhNet* net, const float* lin16) {
+  if (!net || net->n_coarse == 0) return SamplerPlan{64, (net && net->samples == 64) ? 0 : 4, 16, lin16};
+  return SamplerPlan{net->n_coarse, net->n_steps, net->n_new, net->lin_tables + 1 * LIN_TABLE_STRIDE};
+}
+static SamplerPlan shadow_plan(const NrhNet* net, const float* lin16) {
+  if (!net || net->n_coarse == 0) return SamplerPlan{64, 4, 16, lin16};
+  return SamplerPlan{net->s_coarse, net->s_new > 0 ? 4 : 0, net->s_new > 0 ? net->s_new : 16, net->lin_tables + 3 * LIN_TABLE_STRIDE};
+}
+static const char* plan_problem(const NrhNet* net) {
+  if (!net || net->n_coarse == 0) return nullptr;
+  if (!net->lin_tables) return "NrhNet.lin_tables is null";
+  if (net->n_coarse < 2 || net->n_coarse > 128 || net->n_steps < 0 || net->n_steps > 8 || net->n_new < 1 || net->n_new > 16 ||
+      net->n_coarse + net->n_steps * net->n_new > 128)
+    return "primary ray: 2 <= n_coarse, n_new <= 16, n_coarse + n_steps * n_new <= 128";
+  if (net->s_coarse < 2 || net->s_coarse > 64 || net->s_new < 0 || net->s_new > 16 || net->s_coarse + 4 * net->s_new > 128)
+    return "shadow ray: 2 <= s_coarse <= 64, s_new <= 16, s_coarse + 4 * s_new <= 128";
+  return nullptr;
+}
+
+// hierarchical sampling of one family of rays: coarse sdf, steps x (up-sample n_new, evaluate, merge), finalise sections
 int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, float* s, float* znew, float* snew,
-                const float* lin16, const float* last_dist_ray, float last_dist, float* tmid, float* dists,
+                const SamplerPlan plan, const float* last_dist_ray, float last_dist, float* tmid, float* dists,
                 long long n, hipStream_t st, bool latency = false) {
+  if (plan.steps == 0) {
+    // no hierarchical sampling (n_importance_samples = 0, :696): the coarse samples are final
+    if (last_dist_ray) return fail(NRH_E_UNSUPPORTED, "run_sampler: a shadow ray without importance samples is finalised by its caller%s", "");
+    hipLaunchKernelGGL(nrh::finalize64_kernel, dim3((unsigned)((n * 128 + 255) / 256)), dim3(256), 0, st, (const float*)z, last_dist, tmid,
+                       dists, (int)n, plan.nc);
+    return check_launch("finalize64_kernel");
+  }
   const WideNet wide{net->sdf_w32, net->sdf_tab32};
   // a training step's passes are small and serial: below NRH_SPLIT_MAX_PTS points the channel-split kernel (a tile's MFMA work
   // over the CU's four SIMDs) instead of the one-wave-per-tile evaluation kernels.  Training only: a frame's chunks must not
@@ -325,27 +361,27 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
     return sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, t, stride, per_ray, n, out, stride, nullptr,
                          nullptr, nullptr, st, wide);
   };
-  int rc = sdf0(z, 128, 64, s);
+  int rc = sdf0(z, 128, plan.nc, s);
   if (rc) return rc;
   // five launches of the per-ray step kernel: up-sample 0 | merge i + up-sample i + 1 (i = 0, 1, 2) | merge 3 + finalise, with the
   // SDF pass of the 16 new samples between them (the last up-sample's samples are merged without their sdf, :328-329)
   nrh::StepArgs a;
-  a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew; a.snew_in = snew; a.znew_out = znew; a.lin16 = lin16;
+  a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew; a.snew_in = snew; a.znew_out = znew; a.lin16 = plan.lin_new;
   a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.last_dist = last_dist;
-  a.nrays = (int)n;
-  a.inv_s = 64.0f; a.n = 64; a.do_merge = 0; a.merge_sdf = 0; a.do_upsample = 1; a.do_finalize = 0;
+  a.nrays = (int)n; a.n_new = plan.n_new;
+  a.inv_s = 64.0f; a.n = plan.nc; a.do_merge = 0; a.merge_sdf = 0; a.do_upsample = 1; a.do_finalize = 0;
   rc = sampler_step_impl(a, st);
   if (rc) return rc;
-  for (int i = 0; i < 4; ++i) {
-    const bool last = (i == 3);
-    if (i < 3) {
-      rc = sdf0(znew, 16, 16, snew);
+  for (int i = 0; i < plan.steps; ++i) {
+    const bool last = (i == plan.steps - 1);
+    if (!last) {
+      rc = sdf0(znew, 16, plan.n_new, snew);
       if (rc) return rc;
     }
     // merge the new samples of step i (with their sdf unless they are the last step's); then up-sample step i + 1 from the merged
     // state (inv_s = 64 * 2^(i+1)), or finalise after the last merge.  The step-2 launch's up-sample (step 3) is merged by the
     // next launch without an SDF pass in between.
-    a.n = 64 + 16 * i; a.do_merge = 1; a.merge_sdf = (i < 3) ? 1 : 0; a.do_upsample = last ? 0 : 1; a.do_finalize = last ? 1 : 0;
+    a.n = plan.nc + plan.n_new * i; a.do_merge = 1; a.merge_sdf = last ? 0 : 1; a.do_upsample = last ? 0 : 1; a.do_finalize = last ? 1 : 0;
     a.inv_s = 64.0f * (float)(1 << (i + 1));
     rc = sampler_step_impl(a, st);
     if (rc) return rc;
@@ -376,7 +412,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 141; }
+int nrh_version(void) { return 142; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -757,7 +793,7 @@ int nrh_alpha_train_forward(const float* sdf, const float* grad, const float* rd
 int nrh_alpha_train_forward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                               float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, float* weights, float* nhat,
                               void* stream) {
-  if (n_real != 64 && n_real != 128) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: n_real must be 64 or 128%s", "");
+  if (n_real < 2 || n_real > 128) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: n_real must lie in 2 .. 128%s", "");
   if (!sdf || !grad || !rd || !dists || !weights || !nhat) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: null pointer%s", "");
   if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_alpha_train_forward: nrays out of range%s", "");
   if (nrays == 0) return NRH_OK;
@@ -787,11 +823,11 @@ int nrh_sample_primary(const NrhNet* net, const float* origins, const float* dir
   float* znew = sbuf + round64(n * 128);
   float* snew = znew + round64(n * 16);
   nrh::CoarseArgs c;
-  c.near_ = nears; c.far_ = fars; c.lin64 = lin64; c.t_rand = t_rand_primary; c.z = z_vals; c.nrays = (int)n;
+  c.near_ = nears; c.far_ = fars; c.lin64 = lin64; c.t_rand = t_rand_primary; c.z = z_vals; c.nrays = (int)n; c.nc = 64;
   hipLaunchKernelGGL(nrh::coarse_z_kernel, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, c);
   int rc = check_launch("coarse_z_kernel");
   if (rc) return rc;
-  return run_sampler(net, origins, directions, z_vals, sbuf, znew, snew, lin16, nullptr, 2.0f / 64.0f, mid_z, dists, n, st);
+  return run_sampler(net, origins, directions, z_vals, sbuf, znew, snew, SamplerPlan{64, 4, 16, lin16}, nullptr, 2.0f / 64.0f, mid_z, dists, n, st);
 }
 
 int nrh_alpha_blend_forward(const float* sdf, const float* grad, const float* rd, const float* dists, const float* inside_sphere,
@@ -877,7 +913,7 @@ static int alpha_backward_impl(const float* sdf, const float* grad, const float*
 int nrh_alpha_train_backward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                                float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, const float* weights_bar,
                                const float* nhat_bar, float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
-  if (n_real != 64 && n_real != 128) return fail(NRH_E_INVALID, "nrh_alpha_train_backward: n_real must be 64 or 128%s", "");
+  if (n_real < 2 || n_real > 128) return fail(NRH_E_INVALID, "nrh_alpha_train_backward: n_real must lie in 2 .. 128%s", "");
   return alpha_backward_impl(sdf, grad, rd, dists, inv_s, cos_anneal, dyn_scalars, nrays, weights_bar, nhat_bar, 3, nullptr, nullptr,
                              sdf_bar, grad_bar, rd_bar, invs_bar, n_real, stream);
 }
@@ -1067,7 +1103,7 @@ int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const
   a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew_in; a.snew_in = snew_in; a.znew_out = znew_out;
   a.lin16 = lin16; a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.inv_s = inv_s;
   a.last_dist = last_dist; a.nrays = nrays; a.n = n; a.do_merge = do_merge; a.merge_sdf = merge_sdf;
-  a.do_upsample = do_upsample; a.do_finalize = do_finalize;
+  a.do_upsample = do_upsample; a.do_finalize = do_finalize; a.n_new = 16;
   return sampler_step_impl(a, (hipStream_t)stream);
 }
 
@@ -1222,8 +1258,15 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   if ((net->hints != 0 && net->hints != 1) || (net->normal_type != 0 && net->normal_type != 1) ||
       net->depth_type < 0 || net->depth_type > 2)
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type must be 0 or 1, depth_type 0, 1 or 2%s", "");
-  if (net->samples != 0 && net->samples != 64 && net->samples != 128)
+  if (net->n_coarse == 0 && net->samples != 0 && net->samples != 64 && net->samples != 128)
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: NrhNet.samples must be 0 / 128 (64 + 64 importance) or 64 (no importance samples)%s", "");
+  if (const char* why = plan_problem(net)) return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: sample counts: %s", why);
+  const SamplerPlan pplan = primary_plan(net, lin16), splan = shadow_plan(net, lin16);
+  const int T_primary = pplan.total(), T_shadow = splan.total();
+  if (net->n_coarse != 0 && net->samples != T_primary)
+    return fail(NRH_E_INVALID, "nrh_render_forward: NrhNet.samples must equal n_coarse + n_steps * n_new%s", "");
+  if ((net->bg_alpha || net->shadow_clip > 0) && (T_primary != 128 || T_shadow != 128 || pplan.nc != 64 || splan.nc != 64))
+    return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: the outside-NeRF blend and the partial visibility hint need the default sample counts%s", "");
   if (net->bg_alpha && (net->samples == 64 || net->shadow_clip > 0))
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: the outside-NeRF blend needs the 128-sample layout and the hit-point shadow mode%s", "");
   if (net->samples == 64 && net->shadow_clip > 0)
@@ -1266,21 +1309,18 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   // ---- primary rays: coarse z, hierarchical sampling ----
   {
     nrh::CoarseArgs c;
-    c.near_ = nears; c.far_ = fars; c.lin64 = lin64; c.t_rand = t_rand_primary; c.z = ws_zbuf; c.nrays = (int)n;
-    const long long tot = n * 64;
+    c.near_ = nears; c.far_ = fars; c.lin64 = net->n_coarse ? net->lin_tables : lin64; c.t_rand = t_rand_primary; c.z = ws_zbuf; c.nrays = (int)n;
+    c.nc = pplan.nc;
+    const long long tot = n * pplan.nc;
     hipLaunchKernelGGL(nrh::coarse_z_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c);
     int rc = check_launch("coarse_z_kernel");
     if (rc) return rc;
   }
   int rc = NRH_OK;
-  if (net->samples == 64) {
-    // renderer.n_importance_samples = 0: no hierarchical sampling, the 64 coarse samples are final (padded to 128 with alpha = 0)
-    hipLaunchKernelGGL(nrh::finalize64_kernel, dim3((unsigned)((n * 128 + 255) / 256)), dim3(256), 0, st, (const float*)ws_zbuf,
-                       2.0f / 64.0f, o_tmid, o_dists, (int)n);
-    rc = check_launch("finalize64_kernel");
-  } else {
-    rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, nullptr, 2.0f / 64.0f, o_tmid, o_dists, n, st, train != nullptr);
-  }
+  // (steps = 0, renderer.n_importance_samples = 0: the coarse samples are final, padded to 128 with alpha = 0; the last section's
+  // length is sample_dist = 2 / n_samples, :670)
+  rc = run_sampler(net, origins, directions, ws_zbuf, ws_sbuf, ws_znew, ws_snew, pplan, nullptr, 2.0f / (float)pplan.nc, o_tmid, o_dists, n, st,
+                   train != nullptr);
   if (rc) return rc;
   if (clip && hipMemcpyAsync(ws_cue_b, ws_zbuf, sizeof(float) * 128 * n, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(NRH_E_LAUNCH, "nrh_render_forward: copy of the sample positions failed%s", "");   // z_vals for the group targets
@@ -1300,7 +1340,8 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   {
     nrh::CoreArgs c;
     c.ro = origins; c.rd = directions; c.pl = pl_positions; c.sdf = sdf_c; c.grad = o_grad; c.dists = o_dists;
-    c.tmid = o_tmid; c.lin64 = lin64; c.t_rand_shadow = t_rand_shadow; c.weights = o_weights; c.inside = o_inside;
+    c.tmid = o_tmid; c.lin64 = net->n_coarse ? net->lin_tables + 2 * LIN_TABLE_STRIDE : lin64; c.t_rand_shadow = t_rand_shadow;
+    c.s_coarse = splan.nc; c.weights = o_weights; c.inside = o_inside;
     c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
     c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
     c.dyn = net->dyn_scalars; c.hit = nullptr; c.hit_n = nullptr; c.depth_in = nullptr; c.hit_in = nullptr;
@@ -1317,7 +1358,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     }
     c.zero_hints = no_hints;
     c.bg_alpha = net->bg_alpha; c.tail_t = net->tail_t;
-    c.nreal = net->samples == 64 ? 64 : 0;
+    c.nreal = T_primary == 128 ? 0 : T_primary;
     c.depth_max_weight = net->depth_type == 1;
     c.nrays = (int)n;
     rc = launch_core_alpha(c, st, net);
@@ -1325,8 +1366,18 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   }
   // ---- shadow rays light -> hit point ----
   if (!no_hints && !clip) {
-    rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, o_tmid_s,
-                     o_dists_s, n, st, train != nullptr);
+    if (splan.steps == 0) {
+      // n_shadow_importance_samples = 0 (:397): the coarse shadow samples are final; the last section is light distance / n_shadow_samples
+      // (:383, :417), which core_alpha_kernel left per ray in ws_slast - finalised per ray by the step kernel without merge / up-sample
+      nrh::StepArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.ro = pl_positions; fa.rd = ws_srd; fa.z = ws_zbuf; fa.s = ws_sbuf; fa.last_dist_ray = ws_slast; fa.tmid = o_tmid_s; fa.dists = o_dists_s;
+      fa.nrays = (int)n; fa.n = splan.nc; fa.n_new = 16; fa.do_finalize = 1;
+      rc = sampler_step_impl(fa, st);
+    } else {
+      rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, splan, ws_slast, 0.0f, o_tmid_s,
+                       o_dists_s, n, st, train != nullptr);
+    }
     if (rc) return rc;
     // the shadow ray's alpha only needs <direction, gradient>: with the wide kernels that is mode 3 (forward mode, no scratch)
     const int smode = (net->shadow_jvp && net->precision == 1 && net->sdf_w32 && net->sdf_tab32) ? 3 : 1;
@@ -1344,6 +1395,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     c.cue = ws_cue; c.vis = o_vis; c.raymisc = (train && train->raymisc) ? train->raymisc : ws_raymisc; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
     c.dyn = net->dyn_scalars;
     c.nrays = (int)n; c.zero_hints = no_hints || clip; c.row_mul = 0; c.row_off = 0;   // clip: rows rewritten per group below
+    c.nreal = T_shadow == 128 ? 0 : T_shadow;
     hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
     rc = check_launch("shadow_finish_kernel");
     if (rc) return rc;
@@ -1363,7 +1415,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
       hipLaunchKernelGGL(nrh::partial_shadow_setup_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ps);
       rc = check_launch("partial_shadow_setup_kernel");
       if (rc) return rc;
-      rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, lin16, ws_slast, 0.0f, ws_tmid_s, ws_dists_s, n, st, train != nullptr);
+      rc = run_sampler(net, pl_positions, ws_srd, ws_zbuf, ws_sbuf, ws_znew, ws_snew, splan, ws_slast, 0.0f, ws_tmid_s, ws_dists_s, n, st, train != nullptr);
       if (rc) return rc;
       rc = sdf_eval_impl(net->precision, 1, net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, ws_tmid_s, 128, 128, n, ws_sdf_s,
                          128, ws_grad_s, nullptr, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});
@@ -1371,7 +1423,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
       nrh::ShadowArgs c;
       c.rd = directions; c.pl = pl_positions; c.srd = ws_srd; c.sdf = ws_sdf_s; c.grad = ws_grad_s; c.dists = ws_dists_s;
       c.cue = ws_cue; c.vis = visg; c.raymisc = rows; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal; c.dyn = net->dyn_scalars;
-      c.nrays = (int)n; c.zero_hints = 0; c.row_mul = clip; c.row_off = g;
+      c.nrays = (int)n; c.zero_hints = 0; c.row_mul = clip; c.row_off = g; c.nreal = 0;
       hipLaunchKernelGGL(nrh::shadow_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, c);
       rc = check_launch("shadow_finish_kernel");
       if (rc) return rc;

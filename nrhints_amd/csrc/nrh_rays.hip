@@ -47,18 +47,19 @@ __global__ __launch_bounds__(256) void sphere_trace_step_kernel(const TraceArgs 
 struct CoarseArgs {
   const float* near_;
   const float* far_;
-  const float* lin64;   // torch.linspace(0,1,64) as float32 (bit-exact table from the host)
+  const float* lin64;   // torch.linspace(0,1,nc) as float32 (bit-exact table from the host; nc = 64 by default)
   const float* t_rand;  // [N] or null
-  float* z;             // [N,128], first 64 written
+  float* z;             // [N,128], first nc written
   int nrays;
+  int nc;               // renderer.n_samples (models/neus_hint_model.py:673-683)
 };
 __global__ void coarse_z_kernel(const CoarseArgs a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)a.nrays * 64) return;
-  const int ray = (int)(i >> 6), j = (int)(i & 63);
+  if (i >= (long long)a.nrays * a.nc) return;
+  const int ray = (int)(i / a.nc), j = (int)(i - (long long)ray * a.nc);
   const float nr = a.near_[ray], fr = a.far_[ray];
   float z = nr + (fr - nr) * a.lin64[j];
-  if (a.t_rand) z = z + (a.t_rand[ray] - 0.5f) * 2.0f / 64.0f;
+  if (a.t_rand) z = z + (a.t_rand[ray] - 0.5f) * 2.0f / (float)a.nc;
   a.z[(long long)ray * 128 + j] = z;
 }
 
@@ -67,15 +68,16 @@ __global__ void coarse_z_kernel(const CoarseArgs a) {
 // final ones.  Sections (:491-496) for them; entries 64..127 of the 128-wide per-ray arrays repeat the last mid-point with
 // length 0 - the alpha kernels give those padded samples alpha = 0 (CoreArgs.nreal), so they carry no weight anywhere.
 // -------------------------------------------------------------------------------------------------
-__global__ void finalize64_kernel(const float* z, float last_dist, float* tmid, float* dists, int nrays) {
+// (nt = the number of coarse samples: 64 by default, renderer.n_samples in general)
+__global__ void finalize64_kernel(const float* z, float last_dist, float* tmid, float* dists, int nrays, int nt) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)nrays * 128) return;
   const long long ray = i >> 7;
-  const int j = (int)(i & 127), jr = j < 64 ? j : 63;
+  const int j = (int)(i & 127), jr = j < nt ? j : nt - 1;
   const float zj = z[ray * 128 + jr];
-  const float d = (jr < 63) ? z[ray * 128 + jr + 1] - zj : last_dist;
+  const float d = (jr < nt - 1) ? z[ray * 128 + jr + 1] - zj : last_dist;
   tmid[i] = zj + d * 0.5f;
-  dists[i] = j < 64 ? d : 0.0f;
+  dists[i] = j < nt ? d : 0.0f;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -98,6 +100,9 @@ struct StepArgs {
   int nrays;
   int n;                  // valid entries before the merge
   int do_merge, merge_sdf, do_upsample, do_finalize;
+  int n_new;              // samples per up-sampling step (n_importance_samples / up_sample_steps; 16 by default, at most 16): what is
+                          // merged and what is drawn; lin16 holds linspace(0, 1, n_new).  A finalised ray with fewer than 128 samples
+                          // is padded as finalize64_kernel pads: the last mid-point repeated, length 0
 };
 
 __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
@@ -120,26 +125,29 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
   float s0 = (j0 < n) ? a.s[ray * 128 + j0] : 0.0f;
   float s1 = (j1 < n) ? a.s[ray * 128 + j1] : 0.0f;
 
+  const int nn = a.n_new;
   if (a.do_merge) {
     // stable merge of two sorted lists by rank counting (old entries win ties, as a stable sort of cat[z, z_new])
-    const float zn = (lane < 16) ? a.znew_in[ray * 16 + lane] : 0.0f;
-    const float sn = (lane < 16 && a.merge_sdf) ? a.snew_in[ray * 16 + lane] : 0.0f;
+    const float zn = (lane < nn) ? a.znew_in[ray * 16 + lane] : 0.0f;
+    const float sn = (lane < nn && a.merge_sdf) ? a.snew_in[ray * 16 + lane] : 0.0f;
     int c0 = 0, c1 = 0, cn = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const float zk = __shfl(zn, k, 64);
-      c0 += (zk < z0) ? 1 : 0;
-      c1 += (zk < z1) ? 1 : 0;
-      const unsigned long long b0 = __ballot(j0 < n && z0 <= zk);
-      const unsigned long long b1 = __ballot(j1 < n && z1 <= zk);
-      const int cnt = __popcll(b0) + __popcll(b1);
-      cn = (lane == k) ? cnt : cn;
+      if (k < nn) {       // (wave-uniform; the loop stays unrolled)
+        const float zk = __shfl(zn, k, 64);
+        c0 += (zk < z0) ? 1 : 0;
+        c1 += (zk < z1) ? 1 : 0;
+        const unsigned long long b0 = __ballot(j0 < n && z0 <= zk);
+        const unsigned long long b1 = __ballot(j1 < n && z1 <= zk);
+        const int cnt = __popcll(b0) + __popcll(b1);
+        cn = (lane == k) ? cnt : cn;
+      }
     }
     if (j0 < n) { Z[j0 + c0] = z0; S[j0 + c0] = s0; }
     if (j1 < n) { Z[j1 + c1] = z1; S[j1 + c1] = s1; }
-    if (lane < 16) { Z[lane + cn] = zn; S[lane + cn] = sn; }
+    if (lane < nn) { Z[lane + cn] = zn; S[lane + cn] = sn; }
     __syncthreads();
-    n += 16;
+    n += nn;
     z0 = (j0 < n) ? Z[j0] : 0.0f;
     z1 = (j1 < n) ? Z[j1] : 0.0f;
     s0 = (j0 < n) ? S[j0] : 0.0f;
@@ -207,13 +215,15 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
     float u = 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const float uk = a.lin16[k];
-      const unsigned long long b0 = __ballot(j0 < n && cd0 <= uk);  // searchsorted(right=True)
-      const unsigned long long b1 = __ballot(j1 < n && cd1 <= uk);
-      const int cnt = __popcll(b0) + __popcll(b1);
-      if (lane == k) { ind = cnt; u = uk; }
+      if (k < nn) {
+        const float uk = a.lin16[k];
+        const unsigned long long b0 = __ballot(j0 < n && cd0 <= uk);  // searchsorted(right=True)
+        const unsigned long long b1 = __ballot(j1 < n && cd1 <= uk);
+        const int cnt = __popcll(b0) + __popcll(b1);
+        if (lane == k) { ind = cnt; u = uk; }
+      }
     }
-    if (lane < 16) {
+    if (lane < nn) {
       const int below = max(ind - 1, 0), above = min(ind, n - 1);
       const float cb = X[below], ca = X[above];
       const float bb = Z[below], ba = Z[above];
@@ -225,15 +235,17 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
   }
 
   if (a.do_finalize) {
-    // section lengths and mid-points of the final 128 samples
+    // section lengths and mid-points of the final n samples (128 by default; fewer: padded, see StepArgs.n_new)
     const float last = a.last_dist_ray ? a.last_dist_ray[ray] : a.last_dist;
-    const float d0 = Z[j0 + 1] - z0;
-    const float d1 = (j1 < 127) ? (Z[j1 + 1] - z1) : last;
+    const int r0 = min(j0, n - 1), r1 = min(j1, n - 1);
+    const float y0 = Z[r0], y1 = Z[r1];
+    const float d0 = (r0 < n - 1) ? (Z[r0 + 1] - y0) : last;
+    const float d1 = (r1 < n - 1) ? (Z[r1 + 1] - y1) : last;
     if (active) {
-      a.dists[ray * 128 + j0] = d0;
-      a.dists[ray * 128 + j1] = d1;
-      a.tmid[ray * 128 + j0] = z0 + d0 * 0.5f;
-      a.tmid[ray * 128 + j1] = z1 + d1 * 0.5f;
+      a.dists[ray * 128 + j0] = (j0 < n) ? d0 : 0.0f;
+      a.dists[ray * 128 + j1] = (j1 < n) ? d1 : 0.0f;
+      a.tmid[ray * 128 + j0] = y0 + d0 * 0.5f;
+      a.tmid[ray * 128 + j1] = y1 + d1 * 0.5f;
     }
   }
 }
@@ -284,6 +296,8 @@ struct CoreArgs {
   int zero_hints;  // geometry warm-up: cue = 0 (:617-619)
   int depth_max_weight;  // DepthComputationType.MaximalWeightPoint (:534-538) instead of alpha blending
   int nreal;             // samples per ray that exist (0 = all 128; 64 for n_importance_samples = 0): the rest get alpha = 0
+  int s_coarse;          // coarse samples of the shadow ray (renderer.n_shadow_samples, :377; 0 = 64, at most 64); lin64 holds
+                         // linspace(0, 1, s_coarse) and t_rand_shadow is [N, s_coarse]
   // renderer.use_outside_nerf (:516-519): outside the unit sphere a sample's alpha is the background NeRF's.  bg_alpha [N,160]
   // (the caller's render_outside at the merged positions; the first 128 are this ray's samples), tail_t [N] out = transmittance
   // behind sample 127, from which the caller composites the 32 samples beyond the sphere; both null otherwise
@@ -391,15 +405,17 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
     }
     // coarse shadow samples z_j = lin[j] * L * (1 - offset)  (+ stratified jitter in training, :388-395)
     const float om = a.shadow_om;
-    float zj = a.lin64[lane] * L * om;
+    const int snc = a.s_coarse ? a.s_coarse : 64;
+    const int sl = min(lane, snc - 1);
+    float zj = a.lin64[sl] * L * om;
     if (a.t_rand_shadow) {
-      const float zp = (lane > 0) ? a.lin64[lane - 1] * L * om : zj;
-      const float zn = (lane < 63) ? a.lin64[lane + 1] * L * om : zj;
-      const float lower = (lane > 0) ? 0.5f * (zj + zp) : zj;
-      const float upper = (lane < 63) ? 0.5f * (zn + zj) : zj;
-      zj = lower + (upper - lower) * a.t_rand_shadow[ray * 64 + lane];
+      const float zp = (sl > 0) ? a.lin64[sl - 1] * L * om : zj;
+      const float zn = (sl < snc - 1) ? a.lin64[sl + 1] * L * om : zj;
+      const float lower = (sl > 0) ? 0.5f * (zj + zp) : zj;
+      const float upper = (sl < snc - 1) ? 0.5f * (zn + zj) : zj;
+      zj = lower + (upper - lower) * a.t_rand_shadow[ray * snc + sl];
     }
-    a.zs[ray * 128 + lane] = zj;
+    if (lane < snc) a.zs[ray * 128 + lane] = zj;
     if (a.tail_t && lane == 63) a.tail_t[ray] = T1 * (1.0f - al[1] + 1e-7f);
     if (lane == 0) {
       a.depth[ray] = depth;
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
       a.srd[ray * 3 + 0] = svx / L;
       a.srd[ray * 3 + 1] = svy / L;
       a.srd[ray * 3 + 2] = svz / L;
-      a.slast[ray] = L / 64.0f;
+      a.slast[ray] = L / (float)snc;
       if (a.hit) { a.hit[ray * 3 + 0] = hx; a.hit[ray * 3 + 1] = hy; a.hit[ray * 3 + 2] = hz; }
       if (a.hit_n) { a.hit_n[ray * 3 + 0] = nx; a.hit_n[ray * 3 + 1] = ny; a.hit_n[ray * 3 + 2] = nz; }
     }
@@ -435,6 +451,7 @@ struct ShadowArgs {
   int zero_hints;       // geometry warm-up: hints are zero (models/neus_hint_model.py:577-579, 617-619)
   int row_mul, row_off; // vis / raymisc row of ray r: r * row_mul + row_off (0, 0 = r; the partial shadow mode writes group g of
                         // clip groups per ray: row_mul = clip, row_off = g)
+  int nreal;            // samples of the shadow ray that exist (0 = 128): visibility = transmittance in front of sample nreal - 1
 };
 
 __device__ __forceinline__ float enc4_entry_dyn(const float* x, int D, int e) {
@@ -464,7 +481,8 @@ __global__ __launch_bounds__(256) void shadow_finish_kernel(const ShadowArgs a) 
     }
     float T0, T1;
     excl_prod_128(1.0f - al[0] + 1e-7f, 1.0f - al[1] + 1e-7f, T0, T1);
-    vis = __shfl(T1, 63, 64);  // exclusive product at j = 127 (models/neus_hint_model.py:429-432)
+    const int jl = (a.nreal ? a.nreal : 128) - 1;      // the last sample that exists; padded ones behind it do not enter
+    vis = __shfl(jl >= 64 ? T1 : T0, jl & 63, 64);  // exclusive product at j = 127 (models/neus_hint_model.py:429-432)
   }
   float* V = sv[wave];
   if (lane < 3) V[lane] = a.rd[ray * 3 + lane];

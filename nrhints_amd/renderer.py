@@ -137,7 +137,13 @@ class NeuSHintRenderer(nn.Module):
         self._shadow_clip = int(config.renderer.n_shadow_importance_clip) if self.has_shadow_hint else -1
         # n_importance_samples = 0 (:696): the 64 coarse samples are final; the kernels keep 128 slots per ray, the upper 64 as
         # padding with weight exactly 0, and the outputs are cut back to 64 here
-        self._samples = 64 if config.renderer.n_importance_samples == 0 else N_SAMPLES_TOTAL
+        from .config import sample_counts
+        cnt = sample_counts(config.renderer)
+        # sample counts off the defaults (:139-171): kernel parameters carried by NrhNet (n_coarse .. lin_tables); None = the defaults,
+        # which includes the n_importance_samples = 0 variant of the default 64 coarse samples (NrhNet.samples = 64)
+        self._counts = None if cnt in ((64, 4, 16, 64, 16), (64, 0, 16, 64, 16)) else cnt
+        self._samples = cnt[0] + cnt[1] * cnt[2]
+        self._shadow_coarse = cnt[3]
         self._normal_type = 1 if config.renderer.normal_type == NormalComputationType.Analytic else 0
         self._depth_type = {DepthComputationType.AlphaBlend: 0, DepthComputationType.MaximalWeightPoint: 1,
                             DepthComputationType.SphereTracing: 2}[config.renderer.depth_type]
@@ -299,6 +305,19 @@ class NeuSHintRenderer(nn.Module):
         if tests and not bool(torch.stack(tests).all().item()):
             raise ValueError(self._RANGE_MSG)
 
+    def _count_args(self, device):
+        """``counts`` of _lib.make_net: None for the default sample counts, else the five counts + the linspace tables"""
+        if self._counts is None:
+            return None
+        k = "counts:" + str(device)
+        if k not in self._consts:
+            tab = torch.zeros(4, 128, dtype=torch.float32)
+            for row, m in enumerate((self._counts[0], self._counts[2], self._counts[3], self._counts[4])):
+                if m > 0:
+                    tab[row, :m] = torch.linspace(0.0, 1.0, m)      # on the CPU, like lin64 / lin16: bit-identical to the reference's
+            self._consts[k] = tab.to(device)
+        return tuple(self._counts) + (self._consts[k],)
+
     def _const(self, device):
         k = str(device)
         if k not in self._consts:
@@ -369,9 +388,10 @@ class NeuSHintRenderer(nn.Module):
                 # one row of 64 per shadow ray: per primary ray (:394), or per sample group in the partial mode (same order as the
                 # reference's mini-batches over the flattened [ray, group] list, :560-568)
                 rows = n * max(1, self._shadow_clip)
-                t_rand_s = f32(_t_rand_shadow) if _t_rand_shadow is not None else torch.rand(rows, 64, device=device)
-                if t_rand_s.shape != (rows, 64):
-                    raise ValueError(f"_t_rand_shadow must be [{rows}, 64]")
+                sc = self._shadow_coarse           # (renderer.n_shadow_samples: the jitter has the shape of the coarse shadow z, :394)
+                t_rand_s = f32(_t_rand_shadow) if _t_rand_shadow is not None else torch.rand(rows, sc, device=device)
+                if t_rand_s.shape != (rows, sc):
+                    raise ValueError(f"_t_rand_shadow must be [{rows}, {sc}]")
         bg = None
         if background_rgb is not None:
             bg = f32(background_rgb.to(device)).reshape(-1)
@@ -553,7 +573,8 @@ class NeuSHintRenderer(nn.Module):
         pk = self.packed_params(device)
         lin64, lin16 = self._const(device)
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars, wide=self.wide_kernels,
-                            shadow_clip=self._shadow_clip, samples=self._samples, consts=self._net_consts, **(extra_net or {}))
+                            shadow_clip=self._shadow_clip, samples=self._samples, consts=self._net_consts, counts=self._count_args(device),
+                            **(extra_net or {}))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
         out = dict(depth=new(n, 1), visibilities=new(n, 1), weights=new(n, T), inside=new(n, T), normals=new(n, T, 3),
@@ -605,6 +626,7 @@ class NeuSHintRenderer(nn.Module):
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
                             wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color,
                             shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip, samples=self._samples, consts=self._net_consts,
+                            counts=self._count_args(device),
                             **(extra_net or {}))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)

@@ -42,7 +42,7 @@ def supported(renderer, ray_bundle) -> Optional[str]:
     if getattr(renderer, "has_outside_nerf", False):
         return "outside-NeRF background"
     if getattr(renderer, "_samples", 128) != 128:
-        return "n_importance_samples = 0 (64 samples per ray)"
+        return "fewer than 128 samples per ray (n_importance_samples = 0 or sample counts off the defaults)"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
         return "more rays than max_fused_train_rays"
     if ray_bundle.origins.shape[0] == 0:

@@ -263,7 +263,8 @@ def _sdf_and_grad(p, pts, mode, want_feat, differentiable=False):
     return sdf, feat, grad
 
 
-def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=None, mode="minimal", differentiable=False):
+def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=None, mode="minimal", differentiable=False,
+               n_samples=64, n_importance=64):
     """Shadow ray light -> hit point, transmittance before the last sample
     (models/neus_hint_model.py:373-432).  ``differentiable``: renderer.shadow_hint_gradient (:379) - the final alpha evaluation
     keeps its graph w.r.t. the network (second order through d sdf/dx); the sample positions are constants w.r.t. the network
@@ -272,24 +273,26 @@ def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=No
     dvec = hit - pls
     L = torch.linalg.norm(dvec, dim=-1, keepdim=True)
     ds = dvec / L
-    z = torch.linspace(0.0, 1.0, 64).to(pls.dtype)[None, :] * L * (1.0 - offset)
+    z = torch.linspace(0.0, 1.0, n_samples).to(pls.dtype)[None, :] * L * (1.0 - offset)
     if t_rand is not None:  # stratified jitter in training (:388-395)
         mids = 0.5 * (z[:, 1:] + z[:, :-1])
         upper = torch.cat([mids, z[:, -1:]], -1)
         lower = torch.cat([z[:, :1], mids], -1)
         z = lower + (upper - lower) * t_rand
-    with torch.no_grad():
-        z = hierarchical_z(p, pls, ds, z, full_forward=(mode == "as_written"))
-    dists = torch.cat([z[:, 1:] - z[:, :-1], (L / 64.0).expand(n, 1)], dim=-1)
+    if n_importance > 0:                                      # :397: four steps of n_importance // 4 (get_visibility's own default, :373)
+        with torch.no_grad():
+            z = hierarchical_z(p, pls, ds, z, n_steps=4, n_new=n_importance // 4, full_forward=(mode == "as_written"))
+    Ts = z.shape[1]
+    dists = torch.cat([z[:, 1:] - z[:, :-1], (L / float(n_samples)).expand(n, 1)], dim=-1)      # sample_dist = light_norms / n_samples (:383, :417)
     mid = z + dists * 0.5
     pts = (pls[:, None, :] + ds[:, None, :] * mid[..., None]).reshape(-1, 3)
-    dirs = ds[:, None, :].expand(n, 128, 3).reshape(-1, 3)
+    dirs = ds[:, None, :].expand(n, Ts, 3).reshape(-1, 3)
     if mode == "as_written":
         sdf, _ = sdf_forward(p, pts, True)
         grad = sdf_gradient_autograd(p, pts, create_graph=differentiable)
     else:
         sdf, _, grad = sdf_forward_grad_analytic(p, pts, False)
-    alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s_of(p), cos_anneal).reshape(n, 128)
+    alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s_of(p), cos_anneal).reshape(n, Ts)
     return excl_cumprod_one_minus(alpha)[:, -1:]
 
 
@@ -381,7 +384,8 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    depth_sphere_tracing=False, shadow_hint=None, specular_hint=None, shadow_hint_gradient=False,
                    specular_hint_gradient=False, n_shadow_importance_clip=-1, n_importance_samples=64, outside_nerf=None,
                    t_rand_outside=None, specular_roughness=SPEC_ROUGHNESS, shadow_ray_offset=1e-2, z_override=None,
-                   vis_groups_override=None, cue_override=None) -> Dict[str, torch.Tensor]:
+                   vis_groups_override=None, cue_override=None, n_samples=64, up_sample_steps=4, n_shadow_samples=64,
+                   n_shadow_importance_samples=64) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619).
@@ -398,19 +402,21 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     warmup = bool(is_training and global_step < geometry_warmup_end)   # :668
     if is_training and anneal_end > 0:
         cos_anneal = min(1.0, global_step / anneal_end)       # :669-671
-    sample_dist = 2.0 / 64                                     # :673
-    z = near + (far - near) * torch.linspace(0.0, 1.0, 64).to(dt)[None, :]
+    sample_dist = 2.0 / n_samples                              # :673
+    z = near + (far - near) * torch.linspace(0.0, 1.0, n_samples).to(dt)[None, :]
     if is_training:
-        z = z + (t_rand_primary - 0.5) * 2.0 / 64              # :681-683
+        z = z + (t_rand_primary - 0.5) * 2.0 / n_samples       # :681-683
     if z_override is not None:
         z = z_override.to(dt)
     elif n_importance_samples > 0:                            # :696 (n_importance_samples = 0: the coarse samples are final)
-        with torch.no_grad():
-            z = hierarchical_z(p, o, d, z, full_forward=(mode == "as_written"))  # :696-713
+        with torch.no_grad():                                 # :696-713: up_sample_steps x (n_importance // up_sample_steps) new samples
+            z = hierarchical_z(p, o, d, z, n_steps=up_sample_steps, n_new=(n_importance_samples // up_sample_steps if up_sample_steps else 0),
+                               full_forward=(mode == "as_written"))
+    shadow_counts = dict(n_samples=n_shadow_samples, n_importance=n_shadow_importance_samples)
     T = z.shape[1]
     bg_alpha = bg_col = None
     if outside_nerf is not None:                              # renderer.use_outside_nerf (:715-724)
-        z_out = outside_z(far, 32, 64, t_rand_outside if is_training else None)
+        z_out = outside_z(far, 32, n_samples, t_rand_outside if is_training else None)
         z_feed, _ = torch.sort(torch.cat([z, z_out], dim=-1), dim=-1)
         bg_alpha, bg_col = render_outside(outside_nerf, o, d, pl, z_feed, sample_dist)
     # ---- render_core ----
@@ -454,14 +460,16 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
             if vis_groups_override is not None:
                 vg = vis_groups_override.to(dt).reshape(n, clip, 1)
             else:
-                vg = visibility(p, pls_g, tgt, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode).reshape(n, clip, 1)
+                vg = visibility(p, pls_g, tgt, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode,
+                                **shadow_counts).reshape(n, clip, 1)
             vis_samples = vg.repeat_interleave(ratio, dim=1)                               # [n,128,1]
             vis = torch.gather(vis_samples[..., 0], 1, torch.argmax(weights, dim=1, keepdim=True))   # shadow_map (:573-574)
         elif not (shadow_hint and shadow_hint_gradient and differentiable):
-            vis = visibility(p, pl, hit, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode) \
+            vis = visibility(p, pl, hit, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode, **shadow_counts) \
                 if shadow_hint else None                       # :546-551, :379
     if shadow_hint and not warmup and shadow_hint_gradient and differentiable:
-        vis = visibility(p, pl, hit, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode, differentiable=True)
+        vis = visibility(p, pl, hit, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode, differentiable=True,
+                         **shadow_counts)
     n_hat = F.normalize(grad, dim=-1)                          # :584
     hit_n = F.normalize((n_hat.reshape(n, T, 3) * weights[..., None]).sum(1), dim=-1)  # :586-587
     vis_s = cue_s = None

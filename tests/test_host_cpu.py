@@ -22,7 +22,7 @@ def test_library_loads_and_exports_header_symbols():
     for name in declared:
         assert getattr(lib, name) is not None
     lib.nrh_version.restype = ctypes.c_int
-    assert lib.nrh_version() == 141
+    assert lib.nrh_version() == 142
     lib.nrh_sdf_wide_stream_bytes.restype = ctypes.c_longlong
     from nrhints_amd import packing32 as pk32
     assert lib.nrh_sdf_wide_stream_bytes() == sum(pk32.stream_bytes(m) for m in range(3))
@@ -63,7 +63,7 @@ def test_unsupported_configs_are_rejected():
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=True, specular_hint=False, force_specular_cue=True)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=3)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_shadow_importance_clip=32)),
-        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_importance_samples=32)),
+        na.NeuSModelConfig(renderer=na.NeuSRendererConfig(n_importance_samples=72)),      # 18 new samples per step (at most 16), 136 slots
     ]
     for cfg in bad:
         assert na.unsupported_reason(cfg)
@@ -459,3 +459,27 @@ def test_bench_cpu_thread_calibration_stops_past_the_optimum(monkeypatch):
     assert visited == [16, 32, 64] and r["cores"] == 32 and r["host_cores"] == 256
     assert r["thread_calibration_s_per_512_rays"] == {16: 3.1, 32: 3.0, 64: 4.8}
     assert abs(r["value"] - 1024 / 6.0) < 0.01 and len(r["repeats_s"]) == 3
+
+
+def test_sample_count_configs():
+    """config.sample_counts: which renderer sample counts the kernels take (128 slots per ray, at most 16 new samples per step; the
+    shadow march's four steps), and that the rest is refused at construction."""
+    import nrhints_amd as na
+    from nrhints_amd.config import sample_counts, unsupported_reason
+    R = na.NeuSRendererConfig
+    assert sample_counts(R()) == (64, 4, 16, 64, 16)
+    assert sample_counts(R(n_importance_samples=0)) == (64, 0, 16, 64, 16)
+    assert sample_counts(R(n_samples=32, n_importance_samples=32, up_sample_steps=2)) == (32, 2, 16, 64, 16)
+    assert sample_counts(R(n_samples=48, n_importance_samples=48, n_shadow_samples=32, n_shadow_importance_samples=32)) == (48, 4, 12, 32, 8)
+    assert sample_counts(R(n_samples=80, n_importance_samples=0, n_shadow_samples=48, n_shadow_importance_samples=0)) == (80, 0, 16, 48, 0)
+    assert sample_counts(R(n_samples=64, n_importance_samples=70, up_sample_steps=4)) is None          # 17 per step
+    assert sample_counts(R(n_samples=100, n_importance_samples=64)) is None                            # 164 slots
+    assert sample_counts(R(n_shadow_samples=96)) is None and sample_counts(R(n_shadow_importance_samples=2)) is None
+    for bad in (R(n_samples=100, n_importance_samples=64), R(n_samples=32, n_importance_samples=32, up_sample_steps=2, n_shadow_importance_clip=8),
+                R(n_samples=32, n_importance_samples=32, up_sample_steps=2, use_outside_nerf=True)):
+        assert unsupported_reason(na.NeuSModelConfig(renderer=bad)) is not None
+        with pytest.raises(ValueError):
+            na.NeuSHintRenderer(na.NeuSModelConfig(renderer=bad))
+    m = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=R(n_samples=48, n_importance_samples=48, n_shadow_samples=32, n_shadow_importance_samples=32)))
+    assert m._samples == 96 and m._counts == (48, 4, 12, 32, 8) and m._shadow_coarse == 32
+    assert na.NeuSHintRenderer(na.NeuSModelConfig())._counts is None

@@ -379,3 +379,37 @@ def test_outside_nerf_vs_reference(scene_states):
         bound, scale = grad_bound(g[k], g[k.replace("t.grad.", "t.grad64.")], factor=4.0, floor=5e-3)     # a 32-ray fixture (conftest)
         err = float(np.abs(got - g[k.replace("t.grad.", "t.grad64.")]).max())
         assert err <= bound, (name, err, bound, scale)
+
+
+COUNT_VARIANTS = {
+    "c3232": dict(n_samples=32, n_importance_samples=32, up_sample_steps=2),
+    "c6432": dict(n_samples=64, n_importance_samples=32, up_sample_steps=2),
+    "c4848": dict(n_samples=48, n_importance_samples=48, up_sample_steps=4, n_shadow_samples=32, n_shadow_importance_samples=32),
+    "c8000": dict(n_samples=80, n_importance_samples=0, n_shadow_samples=48, n_shadow_importance_samples=0),
+}
+
+
+@pytest.mark.parametrize("vt", sorted(COUNT_VARIANTS))
+def test_sample_counts_vs_reference(scene_states, vt):
+    """Sample counts off the defaults (models/neus_hint_model.py:139-171: n_samples, n_importance_samples / up_sample_steps,
+    n_shadow_samples, n_shadow_importance_samples; tests/golden/make_golden_counts.py): evaluation render and one training step's
+    loss of the restatement against the reference's record."""
+    g = load_npz("render_counts_b.npz")
+    kw = COUNT_VARIANTS[vt]
+    p = orc.params_from_state(scene_states["b"])
+    rays = [T(g[k]) for k in ("o", "d", "pl", "near", "far")]
+    out = orc.render_forward(p, *rays, background_rgb=torch.ones(1, 3), mode="as_written", **kw)
+    assert out["weights"].shape == g[f"{vt}.weights"].shape
+    np.testing.assert_allclose(out["rgb"].numpy(), g[f"{vt}.rgb"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(out["depth"].numpy(), g[f"{vt}.depth"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out["visibilities"].numpy(), g[f"{vt}.visibilities"], rtol=0, atol=2e-3)
+    p64 = orc.params_from_state(scene_states["b"], dtype=torch.float64)
+    o64 = orc.render_forward(p64, *(t.double() for t in rays), background_rgb=torch.ones(1, 3, dtype=torch.float64), mode="minimal", **kw)
+    np.testing.assert_allclose(o64["rgb"].numpy(), g[f"{vt}.rgb_f64"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(o64["visibilities"].numpy(), g[f"{vt}.visibilities_f64"], rtol=0, atol=1e-8)
+    trays = [T(g["t." + k]) for k in ("o", "d", "pl", "near", "far")]
+    tout = orc.render_forward(p, *trays, background_rgb=torch.ones(1, 3), is_training=True, global_step=int(g["t.global_step"]),
+                              t_rand_primary=T(g[f"{vt}.t_rand_primary"]), t_rand_shadow=T(g[f"{vt}.t_rand_shadow"]), mode="as_written", **kw)
+    np.testing.assert_allclose(tout["rgb"].numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=5e-5)
+    loss, _, _ = orc.train_loss(tout, T(g["t.rgb_gt"]))
+    np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)
