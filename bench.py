@@ -475,12 +475,17 @@ def main():
     # the collective library sees it, and every rank's device
     comm = {"backend": "none", "world_size": 1, "devices": [f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]}
     if dist is not None:
-        mine = f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)} pci {torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), 'pci_bus_id') else '?'} pid {os.getpid()}"
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        probe = torch.ones(1, device=dev)
-        dist.all_reduce(probe)                       # a device collective through the backend: sum of ones = ranks that took part
-        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "all_reduce_of_ones": float(probe.item()), "devices": gathered}
+        try:
+            props = torch.cuda.get_device_properties(local_rank)
+            mine = f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)} pci {getattr(props, 'pci_bus_id', '?')} pid {os.getpid()}"
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                       # a device collective through the backend: sum of ones = ranks that took part
+            comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "all_reduce_of_ones": float(probe.item()),
+                    "devices": gathered}
+        except Exception as e:  # noqa: BLE001 - a report, never a reason for the benchmark to stop
+            comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "error": f"{type(e).__name__}: {e}"[:200]}
 
     model, state = build_scene(args.precision)
     peak = PEAK_TFLOPS[args.precision]

@@ -504,7 +504,8 @@ def test_fused_step_off_default_branches(scene_states, vt, prec):
         assert pf.grad is not None and pf.grad.shape == pf.shape == pa.grad.shape, name
         scale = float(pa.grad.abs().max()) + 1e-30
         err = float((pa.grad - pf.grad).abs().max())
-        assert err < 1e-4 * scale + 1e-6, (vt, name, err, scale)
+        # (5e-6 absolute: out_sdf.bias is a sum of 4 096 adjoints of either sign that cancels to 4e-4 on these 32-ray batches)
+        assert err < 1e-4 * scale + 5e-6, (vt, name, err, scale)
     # the reference's recorded tensors (psh: its group visibilities sit on the surface, where single flips move the gradients by
     # per cents - the autograd path's own test of this fixture checks direction + magnitude only; the equality above carries it here)
     if vt != "psh":
