@@ -379,7 +379,9 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
     if world > 1:
         sync = FlatGradAllReduce(list(student.parameters()))
         sync.broadcast_parameters(0)
-    graphed = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000, grad_sync=sync)
+    # NRH_BENCH_COLLECTIVE_IN_GRAPH=1 (opt-in, RCCL only): the all-reduce captured inside the step's one hipGraph
+    in_graph = bool(sync is not None and os.environ.get("NRH_BENCH_COLLECTIVE_IN_GRAPH") == "1" and not SHARE_GPU)
+    graphed = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000, grad_sync=sync, collective_in_graph=in_graph)
     run = lambda i, rb, gt: graphed(rb, gt, global_step=20000 + i)
     losses = []
     t0 = None
@@ -405,10 +407,11 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
     return {"metric": "training ray-steps/s (forward + backward + Adam)", "value": round(value, 1), "unit": "ray-steps/s",
             "batch_rays_per_gpu": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
             "dtype": student.precision, "global_batch": batch * world,
-            "mode": "hipGraph replay" if world == 1 else "two hipGraphs around one flat RCCL all-reduce per step",
+            "mode": "hipGraph replay" if world == 1 else ("one hipGraph incl. the flat RCCL all-reduce" if in_graph else
+                                                            "two hipGraphs around one flat RCCL all-reduce per step"),
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
             "bound_note": "the step's five big kernels (dW, SDF training forward, tangent / value sweeps, reflectance adjoint) are HBM-bound on "
-                          "the saved activations (profiles/r04/pmc_train_summary.txt: 22.1 GB per step at ~5 TB/s, DESIGN 7b / 7c); the MFMA fraction below is the "
+                          "the saved activations (profiles/r05/pmc_train_summary.txt, DESIGN 7b / 7c / 7g); the MFMA fraction below is the "
                           "SURVEY 8d convention",
             "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
                          "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",

@@ -231,8 +231,12 @@ class GraphedTrainStep:
                  end_iter: int = 1_000_000, lr_alpha: float = 0.05, global_step: int = 0,
                  grad_sync: Optional["FlatGradAllReduce"] = None, warmup_steps: int = 3,
                  optimizer_state: Optional[Dict] = None, jitter: Optional[tuple] = None, fused: Optional[bool] = None,
-                 ray_generator: Optional[nn.Module] = None, ray_lr: float = 1e-4):
-        """``jitter``: optional static buffers ``(t_rand_primary [n,1], t_rand_shadow [n,64])`` read by every replay instead
+                 ray_generator: Optional[nn.Module] = None, ray_lr: float = 1e-4, collective_in_graph: bool = False):
+        """``collective_in_graph`` (with a gradient exchange): capture the flat all-reduce INSIDE the one hipGraph of the step -
+        one launch per step instead of graph | eager all-reduce | graph.  Opt-in: a captured collective ties the replay to the
+        communicator's lifetime and needs the backend's capture support (RCCL: yes, tested with one rank; gloo stages through
+        the host and cannot be captured); the two-graph form is the default because it is correct by construction.
+        ``jitter``: optional static buffers ``(t_rand_primary [n,1], t_rand_shadow [n,64])`` read by every replay instead
         of the device generator's draws (reproducible runs; the parity test against the eager step overwrites them)."""
         dev = next(renderer.parameters()).device
         if dev.type != "cuda":
@@ -325,7 +329,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         # a weight-range verdict the warm-up packs enqueued is read (and raised) NOW: no event query may happen inside the capture
         renderer._range_guard_poll(wait=True)
-        if self._sync_active():
+        self.collective_in_graph = bool(collective_in_graph and self._sync_active())
+        if self._sync_active() and not self.collective_in_graph:
             # The collective stays OUTSIDE the graphs: graph 1 = forward + loss + backward + gradient flattening, one eager
             # all-reduce on the same stream, graph 2 = unflatten + Adam - three launches per step instead of one.  (A captured
             # single-rank RCCL all-reduce does replay on this stack, profiles/r02/rccl_graph_probe.log, but a collective inside

@@ -316,10 +316,19 @@ def test_rccl_world1_render_sharded_grad_allreduce_and_graph(scene_states, nccl_
     step = GraphedTrainStep(model, n, bg, lr=5e-4, warm_up_end=20, global_step=30000, grad_sync=sync, jitter=(tp, ts))
     plain = _model(scene_states["b"], train=True)
     step2 = GraphedTrainStep(plain, n, bg, lr=5e-4, warm_up_end=20, global_step=30000, jitter=(tp, ts))
+    # the same step with the all-reduce captured INSIDE its one hipGraph (collective_in_graph): bit-equal to the two-graph form
+    single = _model(scene_states["b"], train=True)
+    sync1 = FlatGradAllReduce(single.parameters(), always=True)
+    step3 = GraphedTrainStep(single, n, bg, lr=5e-4, warm_up_end=20, global_step=30000, grad_sync=sync1, jitter=(tp, ts), collective_in_graph=True)
+    assert step.graph_tail is not None and step3.graph_tail is None and step3.collective_in_graph
     for i in range(3):
         a, b = step(rb, gt, global_step=30000 + i)["loss"], step2(rb, gt, global_step=30000 + i)["loss"]
+        c = step3(rb, gt, global_step=30000 + i)["loss"]
         assert np.isfinite(a) and abs(a - b) < 2e-5 * max(1.0, abs(b)), (i, a, b)
-    step.release(); step2.release()
+        assert c == a, (i, c, a)
+    for (k, pa), (_, pc) in zip(model.named_parameters(), single.named_parameters()):
+        assert torch.equal(pa.detach(), pc.detach()), k
+    step.release(); step2.release(); step3.release()
     # what bench.py's multi-rank training leg runs per rank: eager fused steps without a read-back, the flat all-reduce between
     # backward and the one-launch Adam - against the same steps without the exchange
     from nrhints_amd.training import make_optimizer, release_device_scalars, train_step
