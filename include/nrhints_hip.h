@@ -465,11 +465,12 @@ int nrh_ray_adjoint(const float* origins, const float* directions, const float* 
 int nrh_loss_finish(const float* partials, long long nrays, float inv_s, const float* dyn_scalars, float igr_weight, float* out8,
                     void* stream);
 /* nrh_alpha_train_backward with (a) strided rows of nhat_bar (the normal's three columns inside the reflectance adjoint's output)
- * and (b) the eikonal term's seed added to grad_bar: eikonal_coef[0] * inside * 2 (|g| - 1) g / |g| (both NULL = plain adjoint). */
+ * and (b) the eikonal term's seed added to grad_bar: eikonal_coef[0] * inside * 2 (|g| - 1) g / |g| (both NULL = plain adjoint).
+ * n_real: samples per ray that exist (2 .. 128, NrhNet.samples; the padded ones behind them carry and receive nothing). */
 int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                                    float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
                                    const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
-                                   float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream);
+                                   float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, int n_real, void* stream);
 /* The same stage for a SHADOW ray (renderer.shadow_hint_gradient, models/neus_hint_model.py:379, :417-432): alpha from sdf /
  * grad / dists at its 128 sections, visibilities [n] = transmittance in front of the last sample; the adjoint takes
  * d loss / d visibility [n] and returns the adjoints of sdf [n,128], grad [n*128,3], the shadow ray's direction [n,3] and the

@@ -150,7 +150,7 @@ def load():
     lib.nrh_embedding_rows.argtypes = [P, P, P, c_int, c_int, c_longlong, P, P]
     lib.nrh_composite_loss.argtypes = [P, P, P, P, P, P, c_longlong, P, P, P, P, P]
     lib.nrh_loss_finish.argtypes = [P, c_longlong, c_float, P, c_float, P, P]
-    lib.nrh_alpha_train_backward_fused.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, c_int, P, P, P, P, P, P, P]
+    lib.nrh_alpha_train_backward_fused.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, c_int, P, P, P, P, P, P, c_int, P]
     lib.nrh_variance_grad.argtypes = [P, c_longlong, c_float, P, P, P]
     lib.nrh_adam_step.argtypes = [P, c_int, P, c_int, c_int, POINTER(ctypes.c_double), POINTER(c_void_p), POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double), POINTER(ctypes.c_double), P]

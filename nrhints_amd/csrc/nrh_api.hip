@@ -412,7 +412,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 142; }
+int nrh_version(void) { return 143; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -902,7 +902,7 @@ int nrh_alpha_train_backward(const float* sdf, const float* grad, const float* r
                              float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar, const float* nhat_bar,
                              float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
   return nrh_alpha_train_backward_fused(sdf, grad, rd, dists, inv_s, cos_anneal, dyn_scalars, nrays, weights_bar, nhat_bar, 3, nullptr,
-                                        nullptr, sdf_bar, grad_bar, rd_bar, invs_bar, stream);
+                                        nullptr, sdf_bar, grad_bar, rd_bar, invs_bar, 128, stream);
 }
 
 static int alpha_backward_impl(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
@@ -921,9 +921,10 @@ int nrh_alpha_train_backward_n(const float* sdf, const float* grad, const float*
 int nrh_alpha_train_backward_fused(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                                    float cos_anneal, const float* dyn_scalars, long long nrays, const float* weights_bar,
                                    const float* nhat_bar, int nhat_bar_stride, const float* inside_sphere, const float* eikonal_coef,
-                                   float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream) {
+                                   float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, int n_real, void* stream) {
+  if (n_real < 2 || n_real > 128) return fail(NRH_E_INVALID, "nrh_alpha_train_backward_fused: n_real must lie in 2 .. 128%s", "");
   return alpha_backward_impl(sdf, grad, rd, dists, inv_s, cos_anneal, dyn_scalars, nrays, weights_bar, nhat_bar, nhat_bar_stride,
-                             inside_sphere, eikonal_coef, sdf_bar, grad_bar, rd_bar, invs_bar, 128, stream);
+                             inside_sphere, eikonal_coef, sdf_bar, grad_bar, rd_bar, invs_bar, n_real, stream);
 }
 
 static int alpha_backward_impl(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,

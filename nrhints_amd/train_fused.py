@@ -19,8 +19,10 @@ Covered since round 5 (each differs from the default model only in what the alph
 Analytic (the reflectance net reads the raw gradient, its adjoint goes straight into the gradient's), one hint without the other
 (the kernels of the full model on a first reflectance layer whose missing columns are zero; their gradient columns are dropped)
 and the partial visibility hint (``n_shadow_importance_clip``: one row of per-ray inputs per group of samples).
-Restrictions (the autograd path covers the rest): GPU float32 parameters, no hint gradients, no outside NeRF, 128 samples per
-ray, at most ``max_fused_train_rays`` rays per call.
+Fewer than 128 samples per ray (``n_importance_samples = 0``, sample counts off the defaults): the per-sample arrays keep 128
+slots, the padded ones have weight and adjoint exactly 0.
+Restrictions (the autograd path covers the rest): GPU float32 parameters, no hint gradients, no outside NeRF, at most
+``max_fused_train_rays`` rays per call.
 """
 from __future__ import annotations
 
@@ -41,8 +43,6 @@ def supported(renderer, ray_bundle) -> Optional[str]:
         return "hint gradients (differentiated by the autograd path)"
     if getattr(renderer, "has_outside_nerf", False):
         return "outside-NeRF background"
-    if getattr(renderer, "_samples", 128) != 128:
-        return "fewer than 128 samples per ray (n_importance_samples = 0 or sample counts off the defaults)"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
         return "more rays than max_fused_train_rays"
     if ray_bundle.origins.shape[0] == 0:
@@ -133,16 +133,17 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         if is_training:
             want_s = not zero_hints and renderer._hints
             srows = n * max(1, int(getattr(renderer, "_shadow_clip", -1)))      # one shadow ray per ray, or per group of samples (:560-568)
+            sc = int(getattr(renderer, "_shadow_coarse", 64))                    # renderer.n_shadow_samples: the jitter's row length (:394)
             if t_rand_primary is None and t_rand_shadow is None and want_s:
                 n64 = (n + 63) // 64 * 64                        # (the shadow block stays 256-byte aligned)
-                r = torch.rand(n64 + srows * 64, device=dev)    # one generator launch: primary jitter [n], then shadow jitter [rows, 64]
-                t_p, t_s = r[:n], r[n64:].view(srows, 64)
+                r = torch.rand(n64 + srows * sc, device=dev)    # one generator launch: primary jitter [n], then shadow jitter [rows, sc]
+                t_p, t_s = r[:n], r[n64:].view(srows, sc)
             else:
                 t_p = f32(t_rand_primary).reshape(-1) if t_rand_primary is not None else torch.rand(n, device=dev)
                 if want_s:
-                    t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(srows, 64, device=dev)
-                    if tuple(t_s.shape) != (srows, 64):
-                        raise ValueError(f"t_rand_shadow must be [{srows}, 64]")
+                    t_s = f32(t_rand_shadow) if t_rand_shadow is not None else torch.rand(srows, sc, device=dev)
+                    if tuple(t_s.shape) != (srows, sc):
+                        raise ValueError(f"t_rand_shadow must be [{srows}, {sc}]")
         want_rays = any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions))
         want_params = any(p.requires_grad for p in renderer.parameters())
         # ---- parameters: fold weight-norm (one launch), re-pack ----
@@ -215,7 +216,7 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         _lib.check(lib.nrh_alpha_train_backward_fused(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), float(inv_s),
                                                       float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, mw, P_(res["inside"]),
                                                       ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
-                                                      P_(B.invs_bar), stream), "nrh_alpha_train_backward_fused")
+                                                      P_(B.invs_bar), int(renderer._samples), stream), "nrh_alpha_train_backward_fused")
         if analytic:
             B.grad_bar.add_(B.mbar[:, 3:6])
         if want_params:

@@ -72,7 +72,7 @@ def test_sample_counts_training_step_vs_reference(scene_states, vt, prec):
     tb = _bundle(g, "t.")
     for t_ in (tb.origins, tb.directions, tb.pl_positions):
         t_.requires_grad_(True)
-    assert "samples per ray" in train_fused.supported(model, tb) or Tn == 128          # the autograd path takes these
+    assert train_fused.supported(model, tb) is None          # (the fused step takes them too: checked against this path below)
     out = model(tb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["t.global_step"]),
                 _t_rand_primary=cu(g[f"{vt}.t_rand_primary"]), _t_rand_shadow=cu(g[f"{vt}.t_rand_shadow"]))
     assert out.weights.shape == (32, Tn) and out.analytic_normals.shape == (32, Tn, 3) and out.relax_inside_sphere.shape == (32, Tn)
@@ -96,3 +96,12 @@ def test_sample_counts_training_step_vs_reference(scene_states, vt, prec):
         assert got.shape == want64.shape, (vt, name)
         err = float(np.abs(got - want64).max())
         assert err <= bound, (vt, name, err, bound, scale)
+
+    # the autograd-free step on the same batch and jitter: same kernels, same numbers to float32 round-off
+    fused = _model(scene_states["b"], prec, kw).train()
+    l8 = train_fused.train_step_backward(fused, _bundle(g, "t."), cu(g["t.rgb_gt"]), torch.ones(1, 3).cuda(), int(g["t.global_step"]),
+                                         t_rand_primary=cu(g[f"{vt}.t_rand_primary"]), t_rand_shadow=cu(g[f"{vt}.t_rand_shadow"]))
+    np.testing.assert_allclose(float(l8[0]), float(ld["loss"].detach()), rtol=5e-6)
+    for (name, pa), (_, pf) in zip(model.named_parameters(), fused.named_parameters()):
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, (vt, name)

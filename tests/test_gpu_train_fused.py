@@ -165,7 +165,7 @@ def test_composite_loss_kernels_vs_autograd(bg_on):
     import ctypes
     dirs_ = f(dirs)
     _lib.check(lib.nrh_alpha_train_backward_fused(P(sdf), P(nrm_), P(dirs_), P(dists), inv_s, 1.0, None, n, P(zeros), None, 3, P(ins_),
-                                                  ctypes.c_void_p(loss8.data_ptr() + 20), P(sb), P(gbar), P(rdb), P(ib), _lib.stream_handle()),
+                                                  ctypes.c_void_p(loss8.data_ptr() + 20), P(sb), P(gbar), P(rdb), P(ib), 128, _lib.stream_handle()),
                "alpha_fused")
     np.testing.assert_allclose(gbar.cpu().numpy(), gb.numpy(), rtol=2e-5, atol=1e-10)
     assert float(sb.abs().max()) == 0.0
@@ -190,7 +190,7 @@ def test_alpha_adjoint_strided_normal_bar():
     for ptr, stride in ((P(nb), 3), (ctypes.c_void_p(mbar.data_ptr() + 12), 128)):
         o = [new(n * 128), new(n * 128, 3), new(n, 3), new(n)]
         _lib.check(lib.nrh_alpha_train_backward_fused(P(sdf), P(grad), P(dirs_), P(dists), 300.0, 0.6, None, n, P(wb), ptr, stride, None, None,
-                                                      *(P(x) for x in o), _lib.stream_handle()), "alpha_fused")
+                                                      *(P(x) for x in o), 128, _lib.stream_handle()), "alpha_fused")
         outs.append(o)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
