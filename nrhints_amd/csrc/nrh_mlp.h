@@ -273,10 +273,17 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
 //          The rotation of the rows by the block index costs the kernels nothing and lets the weight-gradient kernel, which
 //          receives a tile's 16 KiB by LDS-DMA as they lie, read two adjacent channels of 16 points without a bank conflict
 //          (csrc/nrh_dw.hip convert: the eight lanes of a block read 64 contiguous bytes, four blocks sit four rows apart).
-// sigma' and coup are private to these kernels; h, t, abar, zbar are operands of nrh_dw_gemm, which is told (NrhDwJob.tiled).
+// sigma' and coup are private to these kernels; h, t, abar, zbar are operands of nrh_dw_gemm (row-major today: NRH_TILE_DW 0).
+// What round 5 measured: written as one 64-bit sum per access, a tiled address needs its own register pair
+// per 16-channel block (the blocks lie 1 KiB apart, beyond the instruction's immediate offset, where row-major blocks are 64 bytes
+// apart), which the 8-wave kernels - already at 256 registers - paid in 40-90 spilled registers, and the gain was gone; split
+// into a wave-uniform and a 32-bit lane part (arr_ptr below) nothing spills in the sweeps and sigma' tiled is worth +3 %.
 enum TrainArr { ARR_ROWS = 0, ARR_H, ARR_S1, ARR_T, ARR_ABAR, ARR_COUP, ARR_ZBAR };
 #ifndef NRH_TILE_S1
-#define NRH_TILE_S1 1         // sigma' tiled (round 5)
+#define NRH_TILE_S1 1         // sigma' tiled (round 5): +3 % on the 1 024-ray step once its addressing stopped spilling
+#endif                        // (profiles/r05/train_layout_ab2.log; as first built: no gain, profiles/r05/train_s1_tiled_ab.log)
+#ifndef NRH_TILE_ROT
+#define NRH_TILE_ROT 0        // A/B aid: the rotated form of the tiled offset without tiled nrh_dw_gemm operands
 #endif
 #ifndef NRH_COUP_TILE
 #define NRH_COUP_TILE 1       // coup tiled (round 4: profiles/r04/coup_ab.log)
@@ -287,14 +294,52 @@ enum TrainArr { ARR_ROWS = 0, ARR_H, ARR_S1, ARR_T, ARR_ABAR, ARR_COUP, ARR_ZBAR
 __host__ __device__ constexpr bool arr_tiled(int arr) {
   return arr == ARR_ROWS ? false : (arr == ARR_S1 ? (NRH_TILE_S1 != 0) : (arr == ARR_COUP ? (NRH_COUP_TILE != 0) : (NRH_TILE_DW != 0)));
 }
-// float offset of the lane's 4 consecutive channels (block blk, quarter q) of point `row` in layer l of such an array
-template <int ARR>
-__device__ __forceinline__ size_t arr_off(int l, long long npts, long long row, int blk, int q) {
+// Address of the lane's 4 consecutive channels (block blk, quarter q) of point `row` in layer l of such an array, written as
+//   (array + WAVE-UNIFORM part: layer, block)  +  (32-bit LANE part: the point's row / tile slot)
+// so that hipcc keeps the first in SGPRs and the second in ONE register per tile for every array, layer and block
+// (global_load / global_store with a scalar base and a 32-bit vector offset).  As one 64-bit sum per access the tiled form cost an
+// address register pair per block and 40-90 spilled registers in the 8-wave kernels (profiles/r05/spill_counts.log).
+// (npts * 1 KiB < 4 GiB: at most 4 194 303 points per launch, checked by the host entry points.)
+#ifndef NRH_ARR_SGPR
+#define NRH_ARR_SGPR 1        // pin the wave-uniform part of a training-array address in SGPRs (scalar-base addressing)
+#endif
+template <bool PIN, typename F>
+__device__ __forceinline__ F* arr_join(F* u, uint32_t v) {
+  if constexpr (!PIN) return u + v;
+#if NRH_ARR_SGPR
+  // wave-uniform by construction (kernel arguments, layer and block indices): said so to hipcc with readfirstlane on the
+  // address as an integer, re-typed as a GLOBAL pointer afterwards (through an opaque generic pointer the accesses became flat_load /
+  // flat_store).  (An `asm("" : "+s"(address))` constraint did the same for the f16x3 kernels but broke the 4-wave float32 builds -
+  // wrong gradients at 40 rays, profiles/r05/run7_tests.log - readfirstlane is the defined way to say it.)
+  unsigned long long ub = (unsigned long long)u;
+  ub = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ub >> 32)) << 32) |
+       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ub);
+  typedef __attribute__((address_space(1))) F* gptr;
+  return (F*)((gptr)ub + v);
+#else
+  return u + v;
+#endif
+}
+// PIN: the f16x3 kernels only.  With it the 4-WAVE FLOAT32 builds (csrc/nrh_small.hip, batches of 8 193 .. 16 384 points) computed
+// wrong gradients (tests at 40 rays, profiles/r05/run7_tests.log / run8_tests.log: both with an SGPR asm constraint and with
+// readfirstlane) while the same source as 8-wave float32, 4-wave f16x3 and channel-split builds is bit-identical to the unpinned
+// form - not understood (the address IS uniform); the exact-fp32 mode keeps the plain 64-bit sum.
+template <int ARR, bool PIN = true, typename F>
+__device__ __forceinline__ F* arr_ptr(F* base, int l, long long npts, long long row, int blk, int q) {
   if constexpr (arr_tiled(ARR)) {
     const int j = (int)(row & 15);
-    return ((size_t)l * (size_t)npts + (size_t)(row - j)) * 256 + (size_t)blk * 256 + (size_t)((((j + blk) & 15) << 4) + 4 * q);
+#if NRH_TILE_DW || NRH_TILE_ROT
+    F* const u = base + ((size_t)l * (size_t)npts * 256 + (size_t)blk * 256);
+    const uint32_t v = (uint32_t)(row - j) * 256u + (uint32_t)((((j + blk) & 15) << 4) + 4 * q);
+#else
+    F* const u = base + ((size_t)l * (size_t)npts * 256 + (size_t)blk * 256);
+    const uint32_t v = (uint32_t)(row - j) * 256u + (uint32_t)(4 * (j + 16 * q));
+#endif
+    return arr_join<PIN>(u, v);
   } else {
-    return ((size_t)l * (size_t)npts + (size_t)row) * 256 + (size_t)(blk * 16 + 4 * q);
+    F* const u = base + ((size_t)l * (size_t)npts * 256 + (size_t)blk * 16);
+    const uint32_t v = (uint32_t)row * 256u + (uint32_t)(4 * q);
+    return arr_join<PIN>(u, v);
   }
 }
 template <int V>

@@ -123,8 +123,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     auto ds_store = [&](int l, int ch, const f32x4 d0, const f32x4 d1) {
       if constexpr (TRAIN) {
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>((a.save_s1 + arr_off<ARR_S1>(l, a.npts, row, 2 * ch, q))), d0);
-          st_stream(reinterpret_cast<f32x4*>((a.save_s1 + arr_off<ARR_S1>(l, a.npts, row, 2 * ch + 1, q))), d1);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.save_s1, l, a.npts, row, 2 * ch, q)), d0);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.save_s1, l, a.npts, row, 2 * ch + 1, q)), d1);
         }
       } else {
         dsig_store<PREC>(scr, l, ch, lane, d0, d1);
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     auto save_rows = [&](auto AT, float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
       constexpr int ARR = decltype(AT)::value;
       if (tile_ok) {
-        st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch, q))), v0);
-        st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch + 1, q))), v1);
+        st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR, PREC == 1>(base, l, a.npts, row, 2 * ch, q)), v0);
+        st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR, PREC == 1>(base, l, a.npts, row, 2 * ch + 1, q)), v1);
       }
     };
     float x3[3];
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         for (int ch = 0; ch < 8; ++ch) {
           f32x4 v0, v1;
           if constexpr (TRAIN) {
-            v0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch, q))));
-            v1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch + 1, q))));
+            v0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T, PREC == 1>(a.save_t, 7, a.npts, row, 2 * ch, q)));
+            v1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T, PREC == 1>(a.save_t, 7, a.npts, row, 2 * ch + 1, q)));
           } else {
             v0 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch, lane)));
             v1 = ld_stream(reinterpret_cast<const f32x4*>(t7_ptr<PREC>(scr, 2 * ch + 1, lane)));
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
         } else if (MODE >= 1) {
           // sigma' of the layer this stage's output feeds
           if constexpr (TRAIN) {
-            p.a0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(16 - s - 1, a.npts, row, 2 * ch, q))));
-            p.a1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(16 - s - 1, a.npts, row, 2 * ch + 1, q))));
+            p.a0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch, q)));
+            p.a1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.save_s1, 16 - s - 1, a.npts, row, 2 * ch + 1, q)));
           } else {
             dsig_issue<PREC>(scr, 16 - s - 1, ch, lane, p);
           }

@@ -33,7 +33,7 @@ struct SdfTrainArgs {
   const float* tt;       // [8][npts][256] from the forward
   const float* gbar;     // [npts][3]   tangent sweep in
   float* abar;           // [8][npts][256] tangent sweep out: abar_{l+1} at index l (index 7: s'_7 tbar_7, for d w_s)
-  float* coup;           // [8][npts][256] floats, tangent sweep out / value sweep in: tiled (nrh_mlp.h arr_off<ARR_COUP>), not row-major
+  float* coup;           // [8][npts][256] floats, tangent sweep out / value sweep in: tiled (nrh_mlp.h arr_ptr<ARR_COUP>), not row-major
   float* gebar;          // [npts][64]  tangent sweep out: abar_0 (39 used)
   const float* fbar;     // [npts][256] value sweep in
   const float* sbar;     // [npts]      value sweep in
@@ -82,7 +82,7 @@ __device__ __forceinline__ float enc_dentry_dot_q(const float (&x)[3], const flo
   return (kind == 2) ? c * mul : ((kind == 1) ? mul : 0.0f);
 }
 
-// (layouts of s1 / t / abar / coup / zbar: nrh_mlp.h arr_off)
+// (layouts of s1 / t / abar / coup / zbar: nrh_mlp.h arr_ptr)
 
 // ------------------------------------------------------------------------------------------------------------------
 // tangent sweep
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
     for (int s = 0; s <= 7; ++s) {
       auto pre = [&](int ch) {
         TrainPre p;
-        p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(s, a.npts, row, 2 * ch, q))));
-        p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(s, a.npts, row, 2 * ch + 1, q))));
-        p.t0 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(s, a.npts, row, 2 * ch, q))));
-        p.t1 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(s, a.npts, row, 2 * ch + 1, q))));
+        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, s, a.npts, row, 2 * ch, q)));
+        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, s, a.npts, row, 2 * ch + 1, q)));
+        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T, PREC == 1>(a.tt, s, a.npts, row, 2 * ch, q)));
+        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T, PREC == 1>(a.tt, s, a.npts, row, 2 * ch + 1, q)));
         return p;
       };
       Act<PREC, 16> ho;
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
           }
         }
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(s, a.npts, row, 2 * ch, q)), c0 * IS);
-          st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(s, a.npts, row, 2 * ch + 1, q)), c1 * IS);
-          st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(s, a.npts, row, 2 * ch, q))), n0 * IS);
-          st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(s, a.npts, row, 2 * ch + 1, q))), n1 * IS);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch, q)), c0 * IS);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch + 1, q)), c1 * IS);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR, PREC == 1>(a.abar, s, a.npts, row, 2 * ch, q)), n0 * IS);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR, PREC == 1>(a.abar, s, a.npts, row, 2 * ch + 1, q)), n1 * IS);
         }
         ho.set_chunk(ch, n0, n1);
       };
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
     Act<PREC, 16> h;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
-      const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch, q))));
-      const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch + 1, q))));
+      const f32x4 v0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_ROWS, PREC == 1>(a.fbar, 0, a.npts, row, 2 * ch, q)));
+      const f32x4 v1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_ROWS, PREC == 1>(a.fbar, 0, a.npts, row, 2 * ch + 1, q)));
       h.set_chunk(ch, v0 * S, v1 * S);
     }
 
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
       const int lz = s - 1;  // layer whose zbar this stage's epilogue produces
       auto pre = [&](int ch) {
         TrainPre p;
-        p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch, q))));
-        p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch + 1, q))));
-        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch, q)));
-        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch + 1, q)));
+        p.s0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, lz, a.npts, row, 2 * ch, q)));
+        p.s1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
+        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, lz, a.npts, row, 2 * ch, q)));
+        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
         if (s == 8) {
           p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
           p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
         }
         const f32x4 z0 = p.s0 * acc0 + p.t0 * S, z1 = p.s1 * acc1 + p.t1 * S;
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch, q))), z0 * IS);
-          st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch + 1, q))), z1 * IS);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR, PREC == 1>(a.zbar, lz, a.npts, row, 2 * ch, q)), z0 * IS);
+          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR, PREC == 1>(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1 * IS);
         }
         ho.set_chunk(ch, z0, z1);
       };

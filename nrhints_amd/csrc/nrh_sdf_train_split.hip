@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
 
   auto save_rows = [&](auto AT, float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
       constexpr int ARR = decltype(AT)::value;
-    st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch, q))), v0);
-    st_stream(reinterpret_cast<f32x4*>((base + arr_off<ARR>(l, a.npts, row, 2 * ch + 1, q))), v1);
+    st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR>(base, l, a.npts, row, 2 * ch, q)), v0);
+    st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR>(base, l, a.npts, row, 2 * ch + 1, q)), v1);
   };
   float* const Gl = G + (j * 4 + q) * SPLT_G_FLOATS;      // this lane's slots of the embedding-adjoint exchange
 
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
       SplPreF p;
       p.a0 = *reinterpret_cast<const f32x4*>(tab + 8 * 256 + (2 * ch) * 16 + 4 * q);
       p.a1 = *reinterpret_cast<const f32x4*>(tab + 8 * 256 + (2 * ch + 1) * 16 + 4 * q);
-      p.b0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch, q))));
-      p.b1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_t + arr_off<ARR_T>(7, a.npts, row, 2 * ch + 1, q))));
+      p.b0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T>(a.save_t, 7, a.npts, row, 2 * ch, q)));
+      p.b1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T>(a.save_t, 7, a.npts, row, 2 * ch + 1, q)));
       return p;
     };
     auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const SplPreF& p) {
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void sdf_train_split_kernel(const SdfArgs a
       constexpr int CI = decltype(CIC)::value;
       const int ch = 2 * wave + CI;
       SplPreF p;
-      p.a0 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(L - 1, a.npts, row, 2 * ch, q))));
-      p.a1 = ld_stream(reinterpret_cast<const f32x4*>((a.save_s1 + arr_off<ARR_S1>(L - 1, a.npts, row, 2 * ch + 1, q))));
+      p.a0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1>(a.save_s1, L - 1, a.npts, row, 2 * ch, q)));
+      p.a1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1>(a.save_s1, L - 1, a.npts, row, 2 * ch + 1, q)));
       return p;
     };
     auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const SplPreF& p) {
@@ -352,10 +352,10 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrai
       constexpr int CI = decltype(CIC)::value;
       const int ch = 2 * wave + CI;
       TrainPre p;
-      p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(S, a.npts, row, 2 * ch, q))));
-      p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(S, a.npts, row, 2 * ch + 1, q))));
-      p.t0 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(S, a.npts, row, 2 * ch, q))));
-      p.t1 = ld_stream(reinterpret_cast<const f32x4*>((a.tt + arr_off<ARR_T>(S, a.npts, row, 2 * ch + 1, q))));
+      p.s0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1>(a.s1, S, a.npts, row, 2 * ch, q)));
+      p.s1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1>(a.s1, S, a.npts, row, 2 * ch + 1, q)));
+      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T>(a.tt, S, a.npts, row, 2 * ch, q)));
+      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T>(a.tt, S, a.npts, row, 2 * ch + 1, q)));
       return p;
     };
     auto epi = [&](auto CIC, f32x4 acc0, f32x4 acc1, const TrainPre& p) {
@@ -375,10 +375,10 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_split_kernel(const SdfTrai
           }
         }
       }
-      st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(S, a.npts, row, 2 * ch, q)), c0 * IS);
-      st_stream(reinterpret_cast<f32x4*>(a.coup + arr_off<ARR_COUP>(S, a.npts, row, 2 * ch + 1, q)), c1 * IS);
-      st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(S, a.npts, row, 2 * ch, q))), n0 * IS);
-      st_stream(reinterpret_cast<f32x4*>((a.abar + arr_off<ARR_ABAR>(S, a.npts, row, 2 * ch + 1, q))), n1 * IS);
+      st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP>(a.coup, S, a.npts, row, 2 * ch, q)), c0 * IS);
+      st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP>(a.coup, S, a.npts, row, 2 * ch + 1, q)), c1 * IS);
+      st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR>(a.abar, S, a.npts, row, 2 * ch, q)), n0 * IS);
+      st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR>(a.abar, S, a.npts, row, 2 * ch + 1, q)), n1 * IS);
       if constexpr (S < 7) spl_store_act(out, j, q, ch, n0, n1);
     };
     if constexpr (S == 0) spl_stage<2, 2, 0, 8, 2, 4>(ring, cur, nxt, lane, bsrc, pre, epi);
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci) {
     const int ch = 2 * wave + ci;
-    fb[ci][0] = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch, q)))) * AS;
-    fb[ci][1] = ld_stream(reinterpret_cast<const f32x4*>((a.fbar + arr_off<ARR_ROWS>(0, a.npts, row, 2 * ch + 1, q)))) * AS;
+    fb[ci][0] = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_ROWS>(a.fbar, 0, a.npts, row, 2 * ch, q))) * AS;
+    fb[ci][1] = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_ROWS>(a.fbar, 0, a.npts, row, 2 * ch + 1, q))) * AS;
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -444,10 +444,10 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
       constexpr int CI = decltype(CIC)::value;
       const int ch = 2 * wave + CI;
       TrainPre p;
-      p.s0 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch, q))));
-      p.s1 = ld_stream(reinterpret_cast<const f32x4*>((a.s1 + arr_off<ARR_S1>(lz, a.npts, row, 2 * ch + 1, q))));
-      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch, q)));
-      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(a.coup + arr_off<ARR_COUP>(lz, a.npts, row, 2 * ch + 1, q)));
+      p.s0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1>(a.s1, lz, a.npts, row, 2 * ch, q)));
+      p.s1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1>(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
+      p.t0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP>(a.coup, lz, a.npts, row, 2 * ch, q)));
+      p.t1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP>(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
       if constexpr (S == 8) {
         p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
         p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256, 2) void sdf_adjoint_split_kernel(const SdfTrai
         }
       }
       const f32x4 z0 = p.s0 * acc0 + p.t0 * AS, z1 = p.s1 * acc1 + p.t1 * AS;
-      st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch, q))), z0 * IS);
-      st_stream(reinterpret_cast<f32x4*>((a.zbar + arr_off<ARR_ZBAR>(lz, a.npts, row, 2 * ch + 1, q))), z1 * IS);
+      st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR>(a.zbar, lz, a.npts, row, 2 * ch, q)), z0 * IS);
+      st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR>(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1 * IS);
       spl_store_act(out, j, q, ch, z0, z1);
     };
     spl_stage<8, 2, 0, 8, decltype(NCN)::value, 4>(ring, cur, nxt, lane, SplLdsB{in + j * SPL_ROW + 16 * q}, pre, epi);
