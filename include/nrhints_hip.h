@@ -439,7 +439,14 @@ typedef struct NrhDwJob {
   float scale_a;
   float* colsum_b;
   float scale_b;
+  int tiled_a[2];   /* pair k: the operand is in the TILED layout of the training arrays instead of row-major (256 channels only): */
+  int tiled_b[2];   /* [tile of 16 points][block of 16 channels][point 16][16 channels] - what nrh_sdf_train_forward / _backward    */
+                    /* write save_h, save_t, abar, zbar in when nrh_train_arrays_tiled() says so                                  */
 } NrhDwJob;
+/* 1 if save_h, save_t (nrh_sdf_train_forward), abar and zbar (nrh_sdf_train_backward) are tiled - opaque hand-offs between those
+ * kernels and nrh_dw_gemm, which a caller passes on with tiled_a / tiled_b set - 0 if they are row-major [layer][npts][256].
+ * (save_s1 and coup are private to the kernels either way.) */
+int nrh_train_arrays_tiled(void);
 long long nrh_dw_workspace_floats(const NrhDwJob* jobs, int njobs);
 int nrh_dw_gemm(const NrhDwJob* jobs, int njobs, long long npts, float* workspace, long long workspace_floats, void* stream);
 /* enc_6(3 p) of the points p = ro[ray] + rd[ray] * t[ray * t_stride + j] as rows [npts][64] (39 used, fields/encodings.py:168-174):

@@ -28,7 +28,8 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_generate_rays_indexed", "nrh_generate_rays_indexed_backward", "nrh_color_wide_stream_bytes", "nrh_color_eval_wide",
             "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite", "nrh_sphere_trace", "nrh_sphere_trace_workspace_floats",
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
-            "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step", "nrh_fuse_feature_head")
+            "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step", "nrh_fuse_feature_head",
+            "nrh_train_arrays_tiled")
 
 
 class NrhNet(Structure):
@@ -89,6 +90,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     P = c_void_p
     lib.nrh_version.restype = c_int
+    lib.nrh_train_arrays_tiled.restype = c_int
     lib.nrh_build_info.restype = c_char_p
     lib.nrh_last_error_string.restype = c_char_p
     lib.nrh_param_sizes.argtypes = [POINTER(c_int)]

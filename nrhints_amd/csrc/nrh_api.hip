@@ -412,7 +412,8 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 143; }
+int nrh_version(void) { return 144; }
+int nrh_train_arrays_tiled(void) { return nrh::arr_tiled(nrh::ARR_H) ? 1 : 0; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
 
@@ -985,6 +986,10 @@ int nrh_dw_gemm(const NrhDwJob* jobs, int njobs, long long npts, float* workspac
     for (int k = 0; k < q.npairs; ++k) {
       if (!q.a[k] || !q.b[k] || q.lda[k] < q.m || q.ldb[k] < q.n) return fail(NRH_E_INVALID, "nrh_dw_gemm: bad operand%s (job %lld)", "", (long long)j);
       a.job[j].a[k] = q.a[k]; a.job[j].b[k] = q.b[k]; a.job[j].lda[k] = q.lda[k]; a.job[j].ldb[k] = q.ldb[k];
+      // tiled operands (the layout of h, t, abar, zbar: csrc/nrh_mlp.h): 256-channel arrays only
+      if ((q.tiled_a[k] && (q.lda[k] != 256 || q.m != 256)) || (q.tiled_b[k] && (q.ldb[k] != 256 || q.n != 256)))
+        return fail(NRH_E_INVALID, "nrh_dw_gemm: a tiled operand has 256 channels%s (job %lld)", "", (long long)j);
+      a.job[j].ta[k] = q.tiled_a[k] ? 1 : 0; a.job[j].tb[k] = q.tiled_b[k] ? 1 : 0;
     }
     if (q.out && (q.rows < 1 || q.rows > q.m || q.cols < 1 || q.cols > q.n || q.ldo < 1))
       return fail(NRH_E_INVALID, "nrh_dw_gemm: bad output shape%s (job %lld)", "", (long long)j);

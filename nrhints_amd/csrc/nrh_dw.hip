@@ -64,6 +64,8 @@ struct JobDev {
   int m, n;              // channels of A / B that exist (<= 256); the rest reads as zero
   int slab0, slabs;      // this job's work items: [slab0, slab0 + slabs)
   int colsum;            // bit 0: column sums of A_0, bit 1: of B_0
+  int ta[2], tb[2];      // pair k: operand is TILED - [tile of 16 points][block 16][point 16][16 channels] (csrc/nrh_mlp.h, the layout
+                         // the sweep kernels write h, t, abar, zbar in) instead of row-major; 256 channels only
 };
 
 struct DwArgs {
@@ -91,6 +93,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ---- LDS-DMA of the operand rows (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave instruction, no VGPR in between) ----
 // Global address = gp + 16 * lane, LDS address = m0 + 16 * lane (csrc/nrh_mlp32.h dma_piece measured the addressing).  M0 cannot be
 // named as a clobber (reserved register for hipcc); it is rewritten in front of every piece.
+// lane16: the lane's byte offset in the SOURCE KiB (16 * lane for a row-major operand; for a tiled operand the lanes of block b
+// fetch 16 * ((lane - 4 b) & 63), which lands point i of the block in LDS row (i + b) & 15 - see tiled_lane16)
 __device__ __forceinline__ void dma_piece(const char* gp, uint32_t m0v, uint32_t lane16, uint64_t lanes) {
   // `lanes`: which lanes take part (the last piece of a narrow operand is partial, pieces past its end are empty).  EXEC is set
   // inside the statement - no branch for hipcc to build, so a piece can sit between two MFMAs of a straight-line block - and every
@@ -99,6 +103,10 @@ __device__ __forceinline__ void dma_piece(const char* gp, uint32_t m0v, uint32_t
   asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4 nt\n\ts_mov_b64 exec, %0"
                : "=&s"(save) : "s"(lanes), "s"(m0v), "v"(lane16), "s"(gp) : "memory");
 }
+// Tiled operand, block b (= piece b of the tile's 16 KiB): global slot of LDS slot `lane` (slots are 16 bytes: [point 16][quarter 4])
+// with the block's rows rotated by b - the conversion then reads channel pair (b, cc) of point i at row (i + b) & 15, and the four
+// blocks a 32-lane LDS pass touches sit in four different 64-byte bank groups (conflict-free ds_read_b64)
+__device__ __forceinline__ uint32_t tiled_lane16(int lane, int b) { return (uint32_t)((lane - 4 * b) & 63) * 16u; }
 __device__ __forceinline__ uint32_t lds_off(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -155,6 +163,7 @@ __device__ __forceinline__ void dw_item(const JobDev& J, const int slab, const i
   const char* pg[8];
   uint32_t pm[8];
   uint64_t pl[8];
+  uint32_t pv[8];        // per-lane source offsets (tiled operands: rotated per block)
   auto issue_setup = [&](int idx_raw) {
     // past the end of the item the eight pieces are still issued, with no lane taking part: one code path, one vmcnt pattern.
     // Everything here is wave-uniform integer arithmetic on kernel arguments and loop counters (SALU): lane masks included.
@@ -174,9 +183,10 @@ __device__ __forceinline__ void dw_item(const JobDev& J, const int slab, const i
       pl[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mk >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mk);
       pg[k] = uni(g + (left > 0 ? p * 1024 : 0));
       pm[k] = __builtin_amdgcn_readfirstlane(stage + op * 16384 + p * 1024);
+      pv[k] = (op ? J.tb[pair] : J.ta[pair]) ? tiled_lane16(lane, p) : lane16;
     }
   };
-  auto piece = [&](int k) { dma_piece(pg[k], pm[k], lane16, pl[k]); };
+  auto piece = [&](int k) { dma_piece(pg[k], pm[k], pv[k], pl[k]); };
   auto issue = [&](int idx) {     // all eight at once (prologue)
     issue_setup(idx);
 #pragma unroll
@@ -193,11 +203,15 @@ __device__ __forceinline__ void dw_item(const JobDev& J, const int slab, const i
     const char* raw = smem + LDS_RAW + (idx & 1) * RAW_STAGE + (is_b ? 16384 : 0) + (ok0 ? c0 : 0) * 4;
     char* base = smem + (idx & 1) * FRAG_STAGE + frag0;
     const bool first = want_sum && idx < nst;
+    const bool tiled = (is_b ? J.tb[pair] : J.ta[pair]) != 0;       // (256-channel operands only: wide is true)
+    const int tb_ = c0 >> 4;
+    const char* rawt = smem + LDS_RAW + (idx & 1) * RAW_STAGE + (is_b ? 16384 : 0) + tb_ * 1024 + (c0 & 15) * 4;
     float x[KSTEP], y[KSTEP];
 #pragma unroll
     for (int i = 0; i < KSTEP; ++i) {
       if (wide) {
-        const f32x2 t = *reinterpret_cast<const f32x2*>(raw + i * ld * 4);
+        const f32x2 t = tiled ? *reinterpret_cast<const f32x2*>(rawt + (((i + tb_) & 15) << 6))
+                              : *reinterpret_cast<const f32x2*>(raw + i * ld * 4);
         x[i] = t[0];
         y[i] = t[1];
       } else {
@@ -359,6 +373,8 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
   const int c0 = 2 * (tid & 127);
   const int frag0 = is_b * 16384 + (c0 >> 5) * 1024 + (c0 & 31) * 16;
   const int raw0 = LDS_RAW + is_b * 16384 + c0 * 4;
+  const int cb = c0 >> 4;                                           // the thread's channel block
+  const int raw0t = LDS_RAW + is_b * 16384 + cb * 1024 + (c0 & 15) * 4;   // ... and its column in a TILED operand's block
   const uint32_t raw_lds = lds_off(smem) + LDS_RAW;
   const float sum_flag = (J.colsum & (is_b ? 2 : 1)) ? 1.0f : 0.0f;
 
@@ -377,6 +393,16 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
   int fstage = 0;                    // its raw stage (fidx % 3)
   const char* ga = nullptr;
   const char* gb = nullptr;
+  // per-lane source offsets of this wave's pieces (blocks wave, wave + 4, wave + 8, wave + 12): rotated for a tiled operand.  The
+  // layout of an operand may differ between the two pairs of a job (it does not in the training step's table), hence per pair.
+  auto lane_off = [&](int tiled, int kk) { return tiled ? tiled_lane16(lane, wave + 4 * kk) : lane16; };
+  uint32_t va[4], vb[4];
+  auto set_offsets = [&](int pair) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { va[kk] = lane_off(J.ta[pair], kk); vb[kk] = lane_off(J.tb[pair], kk); }
+  };
+  set_offsets(0);
+  const bool same_layout = J.npairs == 1 || (J.ta[0] == J.ta[1] && J.tb[0] == J.tb[1]);
   auto point_at = [&](int idx) {
     const int pair = (idx >= nst) ? 1 : 0;
     const int s = s0 + (pair ? idx - nst : idx);
@@ -388,7 +414,7 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
     const uint32_t m = __builtin_amdgcn_readfirstlane(fidx < total ? 0xffffffffu : 0u);     // (wave-uniform, said so to hipcc)
     const uint64_t lanes = ((uint64_t)m << 32) | m;
     const uint32_t m0v = __builtin_amdgcn_readfirstlane(raw_lds + fstage * RAW_STAGE + (k >> 2) * 16384 + (wave + 4 * (k & 3)) * 1024);
-    dma_piece_fast(uni(((k >> 2) ? gb : ga) + (k & 3) * 4096), m0v, lane16, lanes);
+    dma_piece_fast(uni(((k >> 2) ? gb : ga) + (k & 3) * 4096), m0v, (k >> 2) ? vb[k & 3] : va[k & 3], lanes);
   };
   // where the second pair starts (branch-free advance: the block below must stay one basic block)
   const char* const ga1 = reinterpret_cast<const char*>(J.a[J.npairs - 1]) + (long long)s0 * 16384 + wave * 1024;
@@ -399,6 +425,7 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
     const bool second = fidx == nst;
     ga = second ? ga1 : ga + 16384;
     gb = second ? gb1 : gb + 16384;
+    if (second && !same_layout) set_offsets(1);       // (wave-uniform, rare: a job whose pairs differ in layout)
   };
   auto issue_all = [&]() {
 #pragma unroll
@@ -414,15 +441,21 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
   float xv[4][8];                    // the 32 raw values, group-major
   float rs_[8];                      // residuals of the group in flight
   bf16x8 hi_;
-  auto raw_read = [&](int rs) {
-    const char* raw = smem + raw0 + rs * RAW_STAGE;
+  // raw_read(stage, tiled): the thread's two channels of the 16 points.  Row-major: point i at i KiB + 4 c0; tiled: block cb, LDS row
+  // (i + cb) & 15 (64 bytes each).  One form for both: offset_i = ((i * stride + rot) & mask), base chosen per layout - a few SALU /
+  // VALU operations per step instead of a second code path in the scheduled block.
+  auto raw_read = [&](int rs, int tiled) {
+    const char* raw = smem + (tiled ? raw0t : raw0) + rs * RAW_STAGE;
+    const int sh = tiled ? 6 : 10, rot = tiled ? cb * 64 : 0, mask = tiled ? 1023 : 16383;
 #pragma unroll
     for (int i = 0; i < KSTEP; ++i) {
-      const f32x2 t = *reinterpret_cast<const f32x2*>(raw + i * 1024);
+      const f32x2 t = *reinterpret_cast<const f32x2*>(raw + (((i << sh) + rot) & mask));
       xv[i >> 3][i & 7] = t[0];
       xv[2 + (i >> 3)][i & 7] = t[1];
     }
   };
+  // layout of this thread's operand in the step that is converted next (the pair changes at idx = nst)
+  auto tiled_at = [&](int idx) { const int pair = (idx >= nst) ? 1 : 0; return is_b ? J.tb[pair] : J.ta[pair]; };
   auto convert_part = [&](int part, int fs, float flag) {
     const int g = part >> 1;
     // home of group g: channel (g >> 1), k half (g & 1)
@@ -455,7 +488,7 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
     issue_all();                       // step 1 -> raw 1   (empty pieces past the end of the item)
     issue_all();                       // step 2 -> raw 2
     asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // step 0 landed
-    raw_read(0);
+    raw_read(0, tiled_at(0));
 #pragma unroll
     for (int part = 0; part < 8; ++part) convert_part(part, 0, sum_flag);
     int rs_next = 1;                   // raw stage of step idx + 1
@@ -471,7 +504,7 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
       const int fs = (idx + 1) & 1;
       // (past the end of the item this converts stale rows into a stage nobody reads, with flag 0)
       const float flag = (idx + 1 < nst) ? sum_flag : 0.0f;
-      raw_read(rs_next);
+      raw_read(rs_next, tiled_at(idx + 1));
       bf16x8 ah[2], al[2];
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
@@ -541,12 +574,14 @@ __device__ __forceinline__ void dw_item_thin(const JobDev& J, const int slab, co
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, sa = 0.0f, sb[4] = {0.f, 0.f, 0.f, 0.f};
   for (int pair = 0; pair < J.npairs; ++pair) {
     const int lda = J.lda[pair], ldb = J.ldb[pair], n = J.n;
-    const float* A = J.a[pair] + (size_t)s0 * KSTEP * lda + c;
+    // channel c of point i of the step: row-major i * lda + c; tiled (256 channels): block c >> 4, row i, column c & 15
+    const int astride = J.ta[pair] ? 16 : lda;
+    const float* A = J.a[pair] + (size_t)s0 * KSTEP * lda + (J.ta[pair] ? (c >> 4) * 256 + (c & 15) : c);
     const float* B = J.b[pair] + (size_t)s0 * KSTEP * ldb;
     for (int s = s0; s < s1; ++s) {
       float a[KSTEP];
 #pragma unroll
-      for (int i = 0; i < KSTEP; ++i) a[i] = __builtin_nontemporal_load(A + (size_t)i * lda);
+      for (int i = 0; i < KSTEP; ++i) a[i] = __builtin_nontemporal_load(A + (size_t)i * astride);
 #pragma unroll
       for (int i = 0; i < KSTEP; ++i) {
 #pragma unroll

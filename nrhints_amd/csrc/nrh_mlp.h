@@ -269,11 +269,11 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
 // layer: the step's HBM traffic.  Two layouts, both with the 16 points of a tile in the same contiguous 16 KiB:
 //   ROWS   row-major [point][256]: a wave instruction (lane (j, q): 16 bytes of block blk of point j) touches 16 rows x 64 bytes;
 //          measured 5.6 TB/s for stores and 4.2 TB/s for loads (profiles/r04/rowstore.log);
-//   TILED  [tile][block 16][row (j + block) & 15][16 channels]: the same instruction is ONE contiguous KiB (6.3 / 6.4-7.1 TB/s).
-//          The rotation of the rows by the block index costs the kernels nothing and lets the weight-gradient kernel, which
-//          receives a tile's 16 KiB by LDS-DMA as they lie, read two adjacent channels of 16 points without a bank conflict
-//          (csrc/nrh_dw.hip convert: the eight lanes of a block read 64 contiguous bytes, four blocks sit four rows apart).
-// sigma' and coup are private to these kernels; h, t, abar, zbar are operands of nrh_dw_gemm (row-major today: NRH_TILE_DW 0).
+//   TILED  [tile][block 16][point 16][16 channels]: the same instruction is ONE contiguous KiB (6.3 / 6.4-7.1 TB/s); a block is
+//          a 16 x 16 sub-matrix, row-major.
+// sigma' and coup are private to these kernels; h, t, abar, zbar are operands of nrh_dw_gemm, which is told per operand
+// (NrhDwJob.tiled_a / tiled_b) and rotates a block's rows by the block index on their way into LDS (the lanes of its LDS-DMA
+// fetch permuted addresses), so that its conversion reads two adjacent channels of 16 points without a bank conflict.
 // What round 5 measured: written as one 64-bit sum per access, a tiled address needs its own register pair
 // per 16-channel block (the blocks lie 1 KiB apart, beyond the instruction's immediate offset, where row-major blocks are 64 bytes
 // apart), which the 8-wave kernels - already at 256 registers - paid in 40-90 spilled registers, and the gain was gone; split
@@ -282,14 +282,11 @@ enum TrainArr { ARR_ROWS = 0, ARR_H, ARR_S1, ARR_T, ARR_ABAR, ARR_COUP, ARR_ZBAR
 #ifndef NRH_TILE_S1
 #define NRH_TILE_S1 1         // sigma' tiled (round 5): +3 % on the 1 024-ray step once its addressing stopped spilling
 #endif                        // (profiles/r05/train_layout_ab2.log; as first built: no gain, profiles/r05/train_s1_tiled_ab.log)
-#ifndef NRH_TILE_ROT
-#define NRH_TILE_ROT 0        // A/B aid: the rotated form of the tiled offset without tiled nrh_dw_gemm operands
-#endif
 #ifndef NRH_COUP_TILE
 #define NRH_COUP_TILE 1       // coup tiled (round 4: profiles/r04/coup_ab.log)
 #endif
 #ifndef NRH_TILE_DW
-#define NRH_TILE_DW 0         // h, t, abar, zbar tiled (needs nrh_dw_gemm's tiled operand path)
+#define NRH_TILE_DW 1         // h, t, abar, zbar tiled: nrh_dw_gemm takes them through NrhDwJob.tiled_a / tiled_b (csrc/nrh_dw.hip)
 #endif
 __host__ __device__ constexpr bool arr_tiled(int arr) {
   return arr == ARR_ROWS ? false : (arr == ARR_S1 ? (NRH_TILE_S1 != 0) : (arr == ARR_COUP ? (NRH_COUP_TILE != 0) : (NRH_TILE_DW != 0)));
@@ -328,13 +325,8 @@ template <int ARR, bool PIN = true, typename F>
 __device__ __forceinline__ F* arr_ptr(F* base, int l, long long npts, long long row, int blk, int q) {
   if constexpr (arr_tiled(ARR)) {
     const int j = (int)(row & 15);
-#if NRH_TILE_DW || NRH_TILE_ROT
     F* const u = base + ((size_t)l * (size_t)npts * 256 + (size_t)blk * 256);
-    const uint32_t v = (uint32_t)(row - j) * 256u + (uint32_t)((((j + blk) & 15) << 4) + 4 * q);
-#else
-    F* const u = base + ((size_t)l * (size_t)npts * 256 + (size_t)blk * 256);
-    const uint32_t v = (uint32_t)(row - j) * 256u + (uint32_t)(4 * (j + 16 * q));
-#endif
+    const uint32_t v = (uint32_t)(row - j) * 256u + (uint32_t)(16 * j + 4 * q);       // block = a 16 x 16 sub-matrix, row-major
     return arr_join<PIN>(u, v);
   } else {
     F* const u = base + ((size_t)l * (size_t)npts * 256 + (size_t)blk * 16);

@@ -22,7 +22,8 @@ class NrhDwJob(ctypes.Structure):
                 ("npairs", ctypes.c_int), ("m", ctypes.c_int), ("n", ctypes.c_int), ("slabs", ctypes.c_int),
                 ("out", ctypes.c_void_p), ("col_map", ctypes.c_void_p), ("ldo", ctypes.c_int), ("transpose", ctypes.c_int),
                 ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("scale", ctypes.c_float),
-                ("colsum_a", ctypes.c_void_p), ("scale_a", ctypes.c_float), ("colsum_b", ctypes.c_void_p), ("scale_b", ctypes.c_float)]
+                ("colsum_a", ctypes.c_void_p), ("scale_a", ctypes.c_float), ("colsum_b", ctypes.c_void_p), ("scale_b", ctypes.c_float),
+                ("tiled_a", ctypes.c_int * 2), ("tiled_b", ctypes.c_int * 2)]
 
 
 class Job:
@@ -31,12 +32,16 @@ class Job:
     def __init__(self, a: Sequence[torch.Tensor], b: Sequence[torch.Tensor], m: int, n: int, out: Optional[torch.Tensor] = None,
                  rows: Optional[int] = None, cols: Optional[int] = None, transpose: bool = False, scale: float = 1.0,
                  col_map: Optional[torch.Tensor] = None, colsum_a: Optional[torch.Tensor] = None, scale_a: float = 1.0,
-                 colsum_b: Optional[torch.Tensor] = None, scale_b: float = 1.0):
+                 colsum_b: Optional[torch.Tensor] = None, scale_b: float = 1.0, tiled_a: Sequence[bool] = (), tiled_b: Sequence[bool] = ()):
+        """``tiled_a`` / ``tiled_b``: per pair, the operand is in the tiled layout of the training arrays (csrc/nrh_mlp.h: what the
+        sweep kernels write h, t, abar, zbar in when ``arrays_tiled()``) instead of row-major; 256 channels only."""
         assert len(a) == len(b) and 1 <= len(a) <= 2
         self.a, self.b, self.m, self.n, self.out = list(a), list(b), m, n, out
         self.rows, self.cols = (m if rows is None else rows), (n if cols is None else cols)
         self.transpose, self.scale, self.col_map = transpose, scale, col_map
         self.colsum_a, self.scale_a, self.colsum_b, self.scale_b = colsum_a, scale_a, colsum_b, scale_b
+        self.tiled_a = [bool(t) for t in tiled_a] + [False] * (len(self.a) - len(tiled_a))
+        self.tiled_b = [bool(t) for t in tiled_b] + [False] * (len(self.b) - len(tiled_b))
 
     def cost(self) -> float:
         """relative time of one K step: 6 MFMAs per 32 output columns per wave + the load / split / LDS overhead of both operands"""
@@ -113,6 +118,7 @@ def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
                     raise ValueError("dw operands must have one row per point")
                 q.a[k], q.lda[k] = _rows(a)
                 q.b[k], q.ldb[k] = _rows(b)
+                q.tiled_a[k], q.tiled_b[k] = int(j.tiled_a[k]), int(j.tiled_b[k])
             q.npairs, q.m, q.n = len(j.a), j.m, j.n
             q.slabs = max(1, min(nsteps, int(round(total_items * c / tot))))
             if j.out is not None:
@@ -160,19 +166,39 @@ def color_col_maps(device, hints: bool):
     return _MAPS[key]
 
 
+def arrays_tiled() -> bool:
+    """nrh_train_arrays_tiled(): whether the SDF sweeps' h / t / abar / zbar are in the tiled layout (a build constant of the library)"""
+    return bool(_lib.load().nrh_train_arrays_tiled())
+
+
+def to_tiled(x: torch.Tensor) -> torch.Tensor:
+    """Row-major [..., P, 256] -> the tiled layout of the training arrays, same shape and storage size: per tile of 16 points,
+    [block 16][point 16][16 channels] (tests; the kernels write this layout themselves)."""
+    P = x.shape[-2]
+    assert P % 16 == 0 and x.shape[-1] == 256
+    lead = x.shape[:-2]
+    return x.reshape(*lead, P // 16, 16, 16, 16).transpose(-3, -2).contiguous().reshape(*lead, P, 256)
+
+
+def from_tiled(x: torch.Tensor) -> torch.Tensor:
+    """inverse of ``to_tiled`` (the permutation is an involution on the [point, block] axes)"""
+    return to_tiled(x)
+
+
 def sdf_jobs(shapes, h, t, zbar, abar, gebar, emb, sbar, fbar, out) -> List[Job]:
     """Jobs for the SDF network's 8 layers and 2 heads (the maths: nrhints_amd/sdf_function.py).  h, t, zbar, abar [8,P,256];
     gebar, emb [P,64]; sbar [P]; fbar [P,256]; ``out``: dict of preallocated gradient tensors dW0..7, db0..7, ws, bs, Wf, bf;
     ``shapes``: the dense weights' shapes (layer 3 has 217 rows)."""
     P = h.shape[1]
-    jobs = [Job([zbar[0], t[0]], [emb, gebar], 256, 39, out["dW0"], rows=shapes[0][0], colsum_a=out["db0"])]
+    T_ = arrays_tiled()       # h, t, zbar, abar as the sweep kernels wrote them; emb, gebar, fbar, sbar are row-major
+    jobs = [Job([zbar[0], t[0]], [emb, gebar], 256, 39, out["dW0"], rows=shapes[0][0], colsum_a=out["db0"], tiled_a=(T_, T_))]
     for l in range(1, 8):
         jobs.append(Job([zbar[l], t[l]], [h[l - 1], abar[l - 1]], 256, 256, out[f"dW{l}"], rows=shapes[l][0],
-                        scale=(1.0 / math.sqrt(2.0) if l == 4 else 1.0), colsum_a=out[f"db{l}"]))
-    jobs.append(Job([fbar], [h[7]], 256, 256, out["Wf"], colsum_a=out["bf"]))
+                        scale=(1.0 / math.sqrt(2.0) if l == 4 else 1.0), colsum_a=out[f"db{l}"], tiled_a=(T_, T_), tiled_b=(T_, T_)))
+    jobs.append(Job([fbar], [h[7]], 256, 256, out["Wf"], colsum_a=out["bf"], tiled_b=(T_,)))
     # d w_s = (h_7^T sbar + sum_p abar_7) / 3,  d b_s = sum(sbar) / 3   (sdf = (w_s . h_7 + b_s) / 3)
     jobs.append(Job([h[7], abar[7]], [sbar.reshape(P, 1), ones(P, h.device).reshape(P, 1)], 256, 1, out["ws"], transpose=True,
-                    scale=1.0 / 3.0, colsum_b=out["bs"], scale_b=1.0 / 3.0))
+                    scale=1.0 / 3.0, colsum_b=out["bs"], scale_b=1.0 / 3.0, tiled_a=(T_, T_)))
     return jobs
 
 

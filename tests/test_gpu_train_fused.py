@@ -35,13 +35,16 @@ def _wide_range(rs, P, C, scale):
     return (rs.randn(P, C) * np.exp(rs.randn(P, 1) * 2.0) * np.exp(rs.randn(1, C) * 1.5) * scale).astype(np.float32)
 
 
+@pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("P", [32, 2048, 131072 + 32 * 7])
-def test_dw_gemm_vs_float64(P):
+def test_dw_gemm_vs_float64(P, tiled):
     """Every job shape of the training step in one nrh_dw_gemm call: two-pair full products, the 39-column layer-0 product, a
     one-column product with a column sum, a row-limited and scaled product, column maps, the transposed 3-column product; against
     float64 products of the same float32 data.  Error model of the bf16x3 split: operands rounded to 16 mantissa bits, products
     exact, fp32 accumulation: |err| <= 2^-16 sum_p |a b| worst case, a few 1e-6 of the entry in practice (asserted: 3e-5 of
-    sum |a b|, and 3e-5 of the matrix scale)."""
+    sum |a b|, and 3e-5 of the matrix scale).  ``tiled``: the 256-channel operands in the tiled layout of the training arrays
+    (NrhDwJob.tiled_a / tiled_b: the weight-gradient kernel rotates each block's rows on their way into LDS), in every path of the
+    kernel - full products, narrow ones, the thin matrix-vector path - and one job whose two pairs differ in layout; same results."""
     rs = np.random.RandomState(P % 1000)
     A1, A2 = cu(_wide_range(rs, P, 256, 1e-6)), cu(_wide_range(rs, P, 256, 1e-3))
     B1 = cu(np.log1p(np.exp(rs.randn(P, 256).astype(np.float32) * 3)) * 0.1)          # activation-like
@@ -54,14 +57,20 @@ def test_dw_gemm_vs_float64(P):
     out = dict(full=new(256, 256), bfull=new(256), l0=new(256, 39), bl0=new(256), rows=new(217, 256), brows=new(217), ws=new(1, 256), bs=new(1),
                w0=new(256, 361), b0=new(256), w4=new(3, 256), b4=new(3))
     fi, mi = dw.color_col_maps(torch.device("cuda"), True)
-    jobs = [dw.Job([A1, A2], [B1, B2], 256, 256, out["full"], colsum_a=out["bfull"]),
-            dw.Job([A1, A2], [E, GE], 256, 39, out["l0"], colsum_a=out["bl0"]),
-            dw.Job([A2], [B1], 256, 256, out["rows"], rows=217, scale=2.0 ** -0.5, colsum_a=out["brows"]),
-            dw.Job([B1, A2], [sb.reshape(P, 1), dw.ones(P, "cuda").reshape(P, 1)], 256, 1, out["ws"], transpose=True, scale=1.0 / 3.0,
-                   colsum_b=out["bs"], scale_b=1.0 / 3.0),
-            dw.Job([A1], [B1], 256, 256, out["w0"], col_map=fi, colsum_a=out["b0"]),
+    out["mixed"] = new(256, 256)
+    tl = (lambda x: dw.to_tiled(x)) if tiled else (lambda x: x)
+    A1t, A2t, B1t, B2t = tl(A1), tl(A2), tl(B1), tl(B2)
+    assert not tiled or (torch.equal(dw.from_tiled(A1t), A1) and not torch.equal(A1t, A1))
+    t_ = bool(tiled)
+    jobs = [dw.Job([A1t, A2t], [B1t, B2t], 256, 256, out["full"], colsum_a=out["bfull"], tiled_a=(t_, t_), tiled_b=(t_, t_)),
+            dw.Job([A1t, A2t], [E, GE], 256, 39, out["l0"], colsum_a=out["bl0"], tiled_a=(t_, t_)),
+            dw.Job([A2t], [B1t], 256, 256, out["rows"], rows=217, scale=2.0 ** -0.5, colsum_a=out["brows"], tiled_a=(t_,), tiled_b=(t_,)),
+            dw.Job([B1t, A2t], [sb.reshape(P, 1), dw.ones(P, "cuda").reshape(P, 1)], 256, 1, out["ws"], transpose=True, scale=1.0 / 3.0,
+                   colsum_b=out["bs"], scale_b=1.0 / 3.0, tiled_a=(t_, t_)),
+            dw.Job([A1], [B1t], 256, 256, out["w0"], col_map=fi, colsum_a=out["b0"], tiled_b=(t_,)),
             dw.Job([A1], [misc], 256, 105, out["w0"], col_map=mi),
-            dw.Job([B1], [M3], 256, 3, out["w4"], transpose=True, colsum_b=out["b4"])]
+            dw.Job([B1t], [M3], 256, 3, out["w4"], transpose=True, colsum_b=out["b4"], tiled_a=(t_,)),
+            dw.Job([A1t, A2], [B1, B2t], 256, 256, out["mixed"], tiled_a=(t_, False), tiled_b=(False, t_))]      # pairs of different layout
     dw.run(jobs, P)
     torch.cuda.synchronize()
     d = lambda t: t.double().cpu()
@@ -74,6 +83,7 @@ def test_dw_gemm_vs_float64(P):
         assert float(err.max()) < 3e-5 * float(ref.abs().max()), (what, float(err.max()), float(ref.abs().max()))
 
     check(out["full"], a1.t() @ b1 + a2.t() @ b2, a1.abs().t() @ b1.abs() + a2.abs().t() @ b2.abs(), "two-pair product")
+    check(out["mixed"], a1.t() @ b1 + a2.t() @ b2, a1.abs().t() @ b1.abs() + a2.abs().t() @ b2.abs(), "two-pair product, pairs of different layout")
     check(out["l0"], a1.t() @ e[:, :39] + a2.t() @ ge[:, :39], a1.abs().t() @ e[:, :39].abs() + a2.abs().t() @ ge[:, :39].abs(), "39 columns")
     check(out["rows"], (a2.t() @ b1)[:217] * 2.0 ** -0.5, (a2.abs().t() @ b1.abs())[:217], "217 rows, scaled")
     check(out["ws"], ((b1.t() @ s_[:, None] + a2.sum(0)[:, None]) / 3.0).t(), ((b1.abs().t() @ s_.abs()[:, None] + a2.abs().sum(0)[:, None]) / 3).t(), "head")
