@@ -413,3 +413,23 @@ def test_sample_counts_vs_reference(scene_states, vt):
     np.testing.assert_allclose(tout["rgb"].numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=5e-5)
     loss, _, _ = orc.train_loss(tout, T(g["t.rgb_gt"]))
     np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("gs", [0, 25000, 100000])
+def test_training_forward_at_three_anneal_ratios_vs_reference(scene_states, gs):
+    """The restatement's training-mode forward at cos-anneal ratio 0, 0.5 and 1 (models/neus_hint_model.py:668-671)
+    against the reference's 1 024-ray record (tests/golden/train1024_b.npz): rgb is per ray, so the first 96 rays with their rows
+    of the recorded jitter reproduce the reference's pixels - float32 within its own noise, float64 to 1e-9."""
+    g = load_npz("train1024_b.npz")
+    n, p_ = 96, f"s{gs}."
+    rays = [T(g[k][:n]) for k in ("o", "d", "pl", "near", "far")]
+    tp, ts = T(g[p_ + "t_rand_primary"][:n]), T(g[p_ + "t_rand_shadow"][:n])
+    out = orc.render_forward(orc.params_from_state(scene_states["b"]), *rays, background_rgb=torch.ones(1, 3), is_training=True,
+                             global_step=gs, t_rand_primary=tp, t_rand_shadow=ts, mode="as_written")
+    noise = float(np.abs(g[p_ + "rgb"] - g[p_ + "rgb_f64"]).max())
+    assert float(np.abs(out["rgb"].numpy() - g[p_ + "rgb_f64"][:n]).max()) < max(5e-5, 3.0 * noise)
+    o64 = orc.render_forward(orc.params_from_state(scene_states["b"], dtype=torch.float64), *(t.double() for t in rays),
+                             background_rgb=torch.ones(1, 3, dtype=torch.float64), is_training=True, global_step=gs,
+                             t_rand_primary=tp.double(), t_rand_shadow=ts.double(), mode="minimal")
+    # (rgb_f64 is stored as float32: 6e-8)
+    np.testing.assert_allclose(o64["rgb"].numpy(), g[p_ + "rgb_f64"][:n], rtol=0, atol=2e-7)
