@@ -77,6 +77,10 @@ int nrh_sdf_eval(int precision, int mode, const float* sdf_w, const float* sdf_b
 int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
                       int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, float* feat,
                       float* scratch, void* stream);
+/* the same on the one-term builds (NrhNet.precision 2, "f16"): one v_mfma_f32_32x32x16_f16 per K step instead of three */
+int nrh_sdf_eval_wide_f16(int mode, const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
+                          int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, float* feat,
+                          float* scratch, void* stream);
 long long nrh_sdf_wide_stream_bytes(void);
 
 /* SDF value (mode 0) of a SMALL point set, precision f16x3: one 16-point tile's 256 output channels are split over the four
@@ -241,7 +245,10 @@ typedef struct NrhNet {
   const float* col_w;
   const float* col_b;
   float inv_s;
-  int precision; /* 0 = f32 MFMA (exact fp32), 1 = f16x3 split MFMA (fp32-equivalent accuracy, 16/3 the rate) */
+  int precision; /* 0 = f32 MFMA (exact fp32), 1 = f16x3 split MFMA (fp32-equivalent accuracy, 16/3 the rate), 2 = f16: precision 1's
+                    buffers with the wide SDF kernels in their ONE-TERM builds (a single fp16 MFMA pass per K step: weights and
+                    activations of the SDF network at 11 bits; evaluation only, needs sdf_w32 / sdf_tab32) - a reduced-precision
+                    mode, narrower than the reference's float32 */
   int hints;       /* 1 = shadow + specular hints (nr-hints presets); 0 = none (pl-naive preset, configs/main_config.py:67-76):
                       no shadow march, reflectance input 316 wide, col_w packed accordingly */
   int normal_type; /* 0 = NormalizedAnalytic, 1 = Analytic normal fed to the reflectance net (models/neus_hint_model.py:621-625) */

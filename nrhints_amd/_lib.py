@@ -29,7 +29,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite", "nrh_sphere_trace", "nrh_sphere_trace_workspace_floats",
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
             "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step", "nrh_fuse_feature_head",
-            "nrh_train_arrays_tiled")
+            "nrh_train_arrays_tiled", "nrh_sdf_eval_wide_f16")
 
 
 class NrhNet(Structure):
@@ -120,6 +120,7 @@ def load():
     lib.nrh_weight_norm_fold.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, P]
     lib.nrh_weight_norm_fold_backward.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, PP, PP, P]
     lib.nrh_sdf_eval_wide.argtypes = [c_int, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
+    lib.nrh_sdf_eval_wide_f16.argtypes = lib.nrh_sdf_eval_wide.argtypes
     lib.nrh_sdf_wide_stream_bytes.restype = c_longlong
     lib.nrh_sdf_eval_split.argtypes = [P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, c_int, P]
     lib.nrh_sdf_grad_split.argtypes = [P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P]
@@ -179,7 +180,8 @@ def param_sizes():
     return list(out)
 
 
-PRECISIONS = {"f32": 0, "f16x3": 1}
+# precision name -> how the parameters are PACKED (NrhNet.precision of every call but the evaluation render of "f16": see make_net)
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 1}
 
 
 def ptr(t, dtype=None):
@@ -218,12 +220,13 @@ def stream_handle(device=None):
 
 
 def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fused=False, wide_color=True, shadow_jvp=False,
-             shadow_clip=-1, samples=128, bg_alpha=None, tail_t=None, sampled_color=None, consts=None, counts=None):
+             shadow_clip=-1, samples=128, bg_alpha=None, tail_t=None, sampled_color=None, consts=None, counts=None, single_pass=False):
     """NrhNet from a renderer's packed-parameter dict (nrhints_amd/renderer.py: packed_params).  ``fused``: use the wide streams
     whose feature head is multiplied into the reflectance net's first layer (evaluation renders), if the dict has them;
     ``wide_color``: with them, also the reflectance net's block stream for the wide kernel (col_w32 / col_tab32).
     ``counts``: None (the reference's default sample counts) or (n_coarse, n_steps, n_new, s_coarse, s_new, lin_tables [4,128] on
-    the device), see NrhNet in include/nrhints_hip.h."""
+    the device), see NrhNet in include/nrhints_hip.h.  ``single_pass``: NrhNet.precision 2 - the evaluation render of precision
+    "f16": the f16x3 buffers with the wide SDF kernels in their one-term builds."""
     fused = bool(fused and wide and pk.get("sdf_w32f") is not None)
     w32 = (pk.get("sdf_w32f") if fused else pk.get("sdf_w32")) if wide else None
     tab = pk.get("sdf_tab32f") if fused else pk.get("sdf_tab32")
@@ -232,7 +235,7 @@ def make_net(pk, hints, normal_type, depth_type, dyn_scalars=None, wide=True, fu
     rough, offs = ((ctypes.c_double * 4)(*[float(x) for x in consts[0]]), float(consts[1])) if consts is not None \
         else ((ctypes.c_double * 4)(), 0.0)
     return NrhNet(ptr(pk["sdf_w"], pk["sdf_w"].dtype), ptr(pk["sdf_b"]), ptr(pk["sdf_head"]),
-                  ptr(pk["col_w"], pk["col_w"].dtype), ptr(pk["col_b"]), pk["inv_s"], pk["precision"],
+                  ptr(pk["col_w"], pk["col_w"].dtype), ptr(pk["col_b"]), pk["inv_s"], (2 if (single_pass and w32 is not None) else pk["precision"]),
                   hints, normal_type, depth_type, ptr(dyn_scalars),
                   ptr(w32, w32.dtype) if w32 is not None else None, ptr(tab) if w32 is not None else None, int(fused),
                   ptr(c32, c32.dtype) if c32 is not None else None, ptr(pk.get("col_tab32")) if c32 is not None else None,

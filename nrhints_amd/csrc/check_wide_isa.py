@@ -19,7 +19,7 @@ def main():
     kern, bad, inflight = None, [], {}
     nload = 0
     for ln, line in enumerate(open(path), 1):
-        m = re.match(r"^(_ZN5nrh32(?:12sdf32_kernelILi\dE|14color32_kernelE)\w+):", line)
+        m = re.match(r"^(_ZN\d+nrh32t?(?:12sdf32_kernelILi\dE|14color32_kernelE)\w+):", line)       # nrh32: three-term builds, nrh32t: one-term
         if m: kern, inflight = m.group(1), {}; continue
         if kern is None: continue
         if line.startswith(".Lfunc_end"): kern = None; continue

@@ -26,6 +26,24 @@ MFMA = "v_mfma_f32_32x32x16_f16"
 
 
 TRANS_COST = float(os.environ.get("NRH32_TRANS_COST", "1"))
+# NRH32_ONE_TERM=1: the SINGLE-PASS variant of every schedule (precision "f16": one v_mfma per K step - A_hi * B_hi, weights and
+# activations at fp16's 11 bits, fp32 accumulation): the two cross-term MFMAs of a K step are left out (their slots keep the
+# epilogue work and the DMA pieces), the low fragments are not read from LDS, the accumulator of the scaled cross terms (cc) does not
+# exist for the epilogues (t = hh), and the activations' low halves are neither computed nor written.  Generated into another
+# directory (Makefile: gen32_1t) and compiled as its own translation unit (nrh_wide1.hip, namespace nrh32t).
+ONE_TERM = bool(os.environ.get("NRH32_ONE_TERM"))
+
+
+def joined(cp, hp, r):
+    """the value of accumulator entry r: hh + cc 2^-11, or hh alone in the one-term variant"""
+    return f"{hp}[{r}]" if ONE_TERM else f"__builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}])"
+
+
+def pin(*names):
+    """`asm volatile("" : "+v"(a), "+v"(b))` over the accumulator pair - the cross-term accumulator is not pinned in the one-term variant"""
+    names = [n for n in names if not (ONE_TERM and (n == "cp" or n.startswith("cc") or n.startswith("pc")))]
+    return 'asm volatile("" : ' + ", ".join(f'"+v"({n})' for n in names) + ");"
+
 
 
 class Op:
@@ -60,6 +78,9 @@ def split_ops(i, v0, v1, out_hi, out_lo, pfx="", scaled=False):
             Op(f"float R{n}a = __builtin_fmaf((float)hi{n}.x, -1.0f, {v0});", defs=(f"R{n}a",), uses=(f"hi{n}", v0)),
             Op(f"float R{n}b = __builtin_fmaf((float)hi{n}.y, -1.0f, {v1});", defs=(f"R{n}b",), uses=(f"hi{n}", v1)),
         ]
+    if ONE_TERM:
+        # (round to nearest: the high half is all there is - nrh_mlp32.h cvt_rn2)
+        return [Op(f"nrh32::h16x2 hi{n} = nrh32::cvt_rn2({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1)), aput(out_hi, f"hi{n}")]
     ops = [Op(f"nrh32::h16x2 hi{n} = __builtin_amdgcn_cvt_pkrtz({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1))] + mid + [
         Op(f"nrh32::h16x2 lo{n} = __builtin_amdgcn_cvt_pkrtz(R{n}a, R{n}b);", defs=(f"lo{n}",), uses=(f"R{n}a", f"R{n}b")),
         aput(out_hi, f"hi{n}"),
@@ -77,7 +98,7 @@ def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE", jvp=False):
     for i in range(8):
         for r in (2 * i, 2 * i + 1):
             ops += [
-                Op(f"float t{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"t{r}",)),
+                Op(f"float t{r} = {joined(cp, hp, r)};", defs=(f"t{r}",)),
                 Op(f"float m{r} = __builtin_amdgcn_fmed3f(t{r}, 64.0f, -3.0e38f);", defs=(f"m{r}",), uses=(f"t{r}",)),
                 Op(f"float e{r} = __builtin_amdgcn_exp2f(m{r});", defs=(f"e{r}",), uses=(f"m{r}",), kind="trans"),
                 Op(f"float p{r} = 1.0f + e{r};", defs=(f"p{r}",), uses=(f"e{r}",)),
@@ -110,7 +131,7 @@ def epi_rev(c, hp, cp, out_base=128):
             w = f"qw{r // 8}[{(r % 8) // 2}]"
             ext = f"({w} >> 16)" if r & 1 else f"({w} & 0xffffu)"
             ops += [
-                Op(f"float g{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"g{r}",)),
+                Op(f"float g{r} = {joined(cp, hp, r)};", defs=(f"g{r}",)),
                 Op(f"float f{r} = (float){ext};", defs=(f"f{r}",), cost=2),
                 Op(f"float n{r} = g{r} * (-1.0f / 65535.0f);", defs=(f"n{r}",), uses=(f"g{r}",)),
                 Op(f"float u{r} = __builtin_fmaf(n{r}, f{r}, g{r});", defs=(f"u{r}",), uses=(f"n{r}", f"f{r}", f"g{r}")),
@@ -125,7 +146,7 @@ def epi_relu(c, hp, cp, out_base=128, part=False):
     ops = []
     for i in range(8):
         for r in (2 * i, 2 * i + 1):
-            ops.append(Op(f"float t{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"t{r}",)))
+            ops.append(Op(f"float t{r} = {joined(cp, hp, r)};", defs=(f"t{r}",)))
             src = f"t{r}"
             if part:
                 ops.append(Op(f"float s{r} = t{r} + pw{r // 4}[{r % 4}];", defs=(f"s{r}",), uses=(f"t{r}",)))
@@ -142,7 +163,7 @@ def epi_feat(c, hp, cp, store="W32_FSTORE"):
     for g in range(4):
         for k in range(4):
             r = 4 * g + k
-            ops.append(Op(f"float v{r} = __builtin_fmaf({cp}[{r}], {LU}, {hp}[{r}]);", defs=(f"v{r}",)))
+            ops.append(Op(f"float v{r} = {joined(cp, hp, r)};", defs=(f"v{r}",)))
         w = [f"v{4 * g + k}" for k in range(4)]
         ops.append(Op(f"{store}({c}, {g}, (f32x4{{{', '.join(w)}}}));", uses=w, kind="vmem"))
     return ops
@@ -227,7 +248,8 @@ class Window:
 
         for s in range(min(pf, ks)):
             ds(s, 0)
-            ds(s, 1)
+            if not ONE_TERM:
+                ds(s, 1)
         for ops in (head or []):
             if ops:
                 emit_ops(out, ops, ind)
@@ -245,7 +267,7 @@ class Window:
             for j in range(3):
                 # weight fragments of K step s + pf go out in the first two slots of step s (their buffer was last read by
                 # the MFMAs of step s - 1, all issued by now)
-                if s + pf < ks and j < 2:
+                if s + pf < ks and j < (1 if ONE_TERM else 2):
                     ds(s + pf, j)
                 # j = 0: A_hi * B_hi -> hh;  j = MID: A_lo * B_hi (A_lo is scaled by 2^11) -> cc;  the other: A_hi * B_lo (B_lo is
                 # unscaled) -> hh.  MID = 1 keeps the two hh updates of a K step apart (no back-to-back dependent MFMAs).
@@ -255,7 +277,7 @@ class Window:
                 acc = (self.cd if self.cd else self.cc) if to_cc else self.hh
                 first_cc = 1 if self.b_lo_scaled else MID              # the first MFMA of the window that writes cc
                 first = (s == 0 and ((to_cc and j == first_cc) or (j == 0 and self.hh_zero))) and not self.acc_all
-                w = wait_for(s, 1)           # one wait per K step: both fragments (hi was issued first) before the first MFMA
+                w = wait_for(s, 0 if ONE_TERM else 1)           # one wait per K step: both fragments (hi was issued first) before the first MFMA
                 bpart = 1 if (j > 0 and not lo_a) else 0
                 pre = f"s_waitcnt lgkmcnt({w})\\n\\t" if (j == 0 and self.use_ds) else ""
                 if self.b_src == "agpr":
@@ -263,7 +285,9 @@ class Window:
                     bop, bcons = f"a[{base}:{base + 3}]", ""
                 else:
                     bop, bcons = "%2", f', "v"({self.bvar[bpart]}{s})'
-                if first:
+                if ONE_TERM and j > 0:
+                    pass                      # the cross terms do not exist; the slot keeps its epilogue work and DMA piece
+                elif first:
                     out.append(ind + f'asm volatile("{pre}{MFMA} %0, %1, {bop}, 0" : "=&v"({acc}) : "v"({self.frag(s, part)}){bcons});')
                 else:
                     out.append(ind + f'asm volatile("{pre}{MFMA} %0, %1, {bop}, %0" : "+v"({acc}) : "v"({self.frag(s, part)}){bcons});')
@@ -366,8 +390,8 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         if c == 0 and has_epi:
             # window 0 consumes the pending pair (and loaded words) of the previous stage; window 7 redefines those names
             # (the empty asm orders any copy hipcc makes of these registers behind W32_SYNC: the words were still in flight)
-            out.append('    asm volatile("" : "+v"(hp), "+v"(cp));')
-            out.append("    nrh32::f32x16 ph0 = hp, pc0 = cp;")
+            out.append("    " + pin("hp", "cp"))
+            out.append("    nrh32::f32x16 ph0 = hp, pc0 = cp;" if not ONE_TERM else "    nrh32::f32x16 ph0 = hp;")
             ph, pc = "ph0", "pc0"
             for nm in ln(7, ploads):
                 out.append(f'    asm volatile("" : "+v"({nm}));')
@@ -388,7 +412,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         out.append("    const uint32_t wa = W32_WADDR()" + (f" + {(c % 4) * 8192};" if small else ";"))
         if epi is not None:
             # the previous chunk's accumulators are read by VALU only from here on: >= 11 wait states after its last MFMA
-            out.append(f'    asm volatile("" : "+v"({ph}), "+v"({pc}));')
+            out.append("    " + pin(ph, pc))
             estems = STAGE_LOADS.get(ekind, ((), None))[0]
             if estems:
                 names = pnames if c == 0 else ln(prev, estems)
@@ -428,7 +452,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             out.append("    W32_NEXT();")
         out.append("  }")
     # whoever comes next may copy the pending registers: only after the last MFMAs have landed
-    out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hp), "+v"(cp));')
+    out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hp)' + ('' if ONE_TERM else ', "+v"(cp)') + ');')
     if loads:
         # same for the pending loaded words (asm loads of window 7, in flight, invisible to hipcc): they have landed before
         # anything may touch their registers (hipcc shuffles loop-carried registers at the loop edges - measured: 1-3 % of
@@ -468,7 +492,7 @@ def gen_kloop(ks, b_src, hh_zero, in_base=128, acc_all=False, b_lo_scaled=False)
     out = [f"// generated by gen_mlp32.py: bare K loop ks={ks} b={b_src}", "{"]
     Window(ks, "hh", "cc", b_src=b_src, hh_zero=hh_zero, in_base=in_base, acc_all=acc_all, b_lo_scaled=b_lo_scaled).emit(out, None, "  ", dma=(DMA_SLOTS16 if ks == 16 else None))
     if not acc_all:
-        out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh), "+v"(cc));   // MFMA results -> VALU reads: 11 wait states')
+        out.append('  asm volatile("s_nop 7\\n\\ts_nop 7" : "+v"(hh)' + ('' if ONE_TERM else ', "+v"(cc)') + ');   // MFMA results -> VALU reads: 11 wait states')
     out.append("}")
     return "\n".join(out) + "\n"
 

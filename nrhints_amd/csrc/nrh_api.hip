@@ -122,6 +122,14 @@ struct WideNet {
   const void* streams = nullptr;
   const float* tables = nullptr;
 };
+// NrhNet.precision 2 ("f16": the single-pass, one-term builds of the wide SDF kernels, nrh_wide1.hip): set for the duration of one
+// render call by render_forward_impl / nrh_sdf_eval_wide_f16 (a call runs on the caller's thread from entry to return)
+static thread_local int t_wide_one_term = 0;
+struct OneTermScope {
+  int saved;
+  explicit OneTermScope(int on) : saved(t_wide_one_term) { t_wide_one_term = on; }
+  ~OneTermScope() { t_wide_one_term = saved; }
+};
 
 int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const float* head, const float* ro, const float* rd,
                   const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad,
@@ -142,7 +150,7 @@ int sdf_eval_impl(int prec, int mode, const float* w, const float* b, const floa
     TimedLaunch tl;
     bool timed;
     timing_begin(mode == 3 ? 1 : mode, st, tl, timed);
-    const int wrc = nrh32::wide_sdf_launch(c, st);
+    const int wrc = t_wide_one_term ? nrh32t::wide_sdf_launch(c, st) : nrh32::wide_sdf_launch(c, st);
     timing_end(st, tl, timed);
     if (wrc == -1) return fail(NRH_E_INVALID, "nrh_sdf_eval: too many points%s", "");
     if (wrc) return fail(NRH_E_LAUNCH, "wide sdf kernel: no HIP device / attribute error%s", "");
@@ -412,7 +420,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 144; }
+int nrh_version(void) { return 145; }
 int nrh_train_arrays_tiled(void) { return nrh::arr_tiled(nrh::ARR_H) ? 1 : 0; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
@@ -472,6 +480,14 @@ int nrh_sdf_eval_wide(int mode, const void* sdf_w32, const float* sdf_tab32, con
   if (!sdf_w32 || !sdf_tab32) return fail(NRH_E_INVALID, "nrh_sdf_eval_wide: null pointer%s", "");
   return sdf_eval_impl(1, mode, nullptr, nullptr, nullptr, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat, scratch,
                        (hipStream_t)stream, WideNet{sdf_w32, sdf_tab32});
+}
+
+// nrh_sdf_eval_wide on the ONE-TERM builds of the wide kernels (precision "f16": one fp16 MFMA pass per K step; same streams / tables)
+int nrh_sdf_eval_wide_f16(int mode, const void* sdf_w32, const float* sdf_tab32, const float* ro, const float* rd, const float* t,
+                          int t_stride, int n_per_ray, long long nrays, float* sdf, int sdf_stride, float* grad, float* feat,
+                          float* scratch, void* stream) {
+  OneTermScope scope(1);
+  return nrh_sdf_eval_wide(mode, sdf_w32, sdf_tab32, ro, rd, t, t_stride, n_per_ray, nrays, sdf, sdf_stride, grad, feat, scratch, stream);
 }
 
 int nrh_sdf_eval_split(const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro, const float* rd, const float* t,
@@ -1259,8 +1275,19 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   hipStream_t st = (hipStream_t)stream;
   if (!net || !net->sdf_w || !net->sdf_b || !net->sdf_head || !net->col_w || !net->col_b)
     return fail(NRH_E_INVALID, "nrh_render_forward: null network pointer%s", "");
-  if (net->precision < 0 || net->precision > 1)
-    return fail(NRH_E_INVALID, "nrh_render_forward: net->precision must be 0 (f32) or 1 (f16x3)%s", "");
+  if (net->precision < 0 || net->precision > 2)
+    return fail(NRH_E_INVALID, "nrh_render_forward: net->precision must be 0 (f32), 1 (f16x3) or 2 (f16, evaluation only)%s", "");
+  // precision 2: everything as precision 1 (same packed buffers), with the wide SDF kernels in their one-term builds
+  NrhNet eff;
+  const int one_term = net->precision == 2;
+  if (one_term) {
+    if (!net->sdf_w32 || !net->sdf_tab32) return fail(NRH_E_INVALID, "nrh_render_forward: precision 2 (f16) needs the wide streams sdf_w32 / sdf_tab32%s", "");
+    if (train) return fail(NRH_E_UNSUPPORTED, "nrh_render_forward_train: precision 2 (f16, single pass) is an evaluation mode%s", "");
+    eff = *net;
+    eff.precision = 1;
+    net = &eff;
+  }
+  OneTermScope one_term_scope(one_term);
   if ((net->hints != 0 && net->hints != 1) || (net->normal_type != 0 && net->normal_type != 1) ||
       net->depth_type < 0 || net->depth_type > 2)
     return fail(NRH_E_UNSUPPORTED, "nrh_render_forward: hints / normal_type must be 0 or 1, depth_type 0, 1 or 2%s", "");

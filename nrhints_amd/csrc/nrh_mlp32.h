@@ -61,7 +61,22 @@ __host__ __device__ constexpr int col32(int s, int hf, int i) { return 16 * s + 
 // gfx950 and so does v_cvt_pkrtz_f16_f32: profiles/r02/denorm32.log, ubench/denorm32.hip; |x - hi - lo| <= max(2^-22 |x|, 2^-25)), two values per register.  Weights (A operands)
 // keep lo scaled by 2^11 in the packed stream, so a product is hh += A_hi B_hi + A_hi B_lo and cc += A_lo B_hi with cc in
 // units of 2^-11 (one fused multiply-add joins them in the epilogue).
+// two floats -> packed fp16, ROUND TO NEAREST EVEN (one v_cvt_pk_f16_f32 on gfx950).  The one-term builds (W32_ONE_TERM: the high half
+// is all there is) need it: v_cvt_pkrtz truncates, a bias of half an ulp per operand that 256-term dot products and eight layers
+// add up coherently - measured 4e-3 on the sdf and 42-57 dB PSNR with truncation against 2-6e-4 / 73-85 dB emulated with rounding.
+// (In the three-term split the low half carries whatever the high half dropped, truncated or rounded.)
+__device__ __forceinline__ h16x2 cvt_rn2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(h16x2, __builtin_convertvector((f32x2_{a, b}), f16x2_));
+}
+
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+#if defined(W32_ONE_TERM) && W32_ONE_TERM
+  hi = __builtin_bit_cast(uint32_t, cvt_rn2(a, b));
+  lo = 0u;
+  return;
+#endif
   const h16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
   const float ra = __builtin_fmaf((float)h.x, -1.0f, a);   // v_fma_mix_f32 on the packed fp16; exact
   const float rb = __builtin_fmaf((float)h.y, -1.0f, b);

@@ -17,6 +17,19 @@
 // (128 KiB per wave, L2 / Infinity-Cache resident).
 #include "nrh_mlp32.h"
 
+// The generated schedules (gen_mlp32.py) come from W32_GENDIR: gen32 (three product terms per K step: precision f16x3) or, in the
+// one-term translation unit (nrh_wide1.hip: W32_ONE_TERM 1, namespace nrh32t), gen32_1t - precision "f16", a single fp16 MFMA pass.
+#ifndef W32_GENDIR
+#define W32_GENDIR gen32
+#endif
+#ifndef W32_ONE_TERM
+#define W32_ONE_TERM 0
+#endif
+#define W32_STR2(x) #x
+#define W32_STR(x) W32_STR2(x)
+#define W32_INC(name) W32_STR(W32_GENDIR/name.inc)
+#define W32_ZERO16 (f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f})
+
 namespace nrh32 {
 
 struct Sdf32Args {
@@ -245,6 +258,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // ... no copies.  The last chunk of every stage stays PENDING in (hp, cp): its epilogue runs in the MFMA shadows of the
     // next stage's first window (its outputs are that stage's K steps 14 and 15, needed last).
     f32x16 hp, cp;
+#if W32_ONE_TERM
+    cp = W32_ZERO16;      // (one-term build: no cross-term accumulator; the generated epilogues do not read it)
+#endif
     // Every layer's windows start from zero and take their bias through one extra MFMA (gen_mlp32.py gen_stage, bias_mfma):
     // table rows 0..7 hold one packed fp16 pair per output row, (b_hi | b_lo * 2^11 << 16), and the B operand is the constant
     // [1, 2^-11, 0, ...] of the hf = 0 lanes.
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // layer 4's skip part: E4 * emb on top of the window's sums, 9 MFMAs over the resident block (B operands in VGPRs)
     auto skip_e4 = [&](int c, f32x16& hh, f32x16& cc) {
       const uint32_t wa = ring_lds + LDS_RESIDENT + c * 6144 + lane16;   // resident E4 chunk c: 3 K steps
-#include "gen32/kloop3v_acc.inc"
+#include W32_INC(kloop3v_acc)
     };
 #define W32_BIAS(c) (*reinterpret_cast<const uint32_t*>(brow + qlayer * 1024 + (c) * 128))
 #define W32_BCONST bconst
@@ -304,11 +320,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     {
       const int qlayer = 0;
       if constexpr (JVP) {
-#include "gen32/l0_j.inc"
+#include W32_INC(l0_j)
       } else if constexpr (WANT_D) {
-#include "gen32/l0_d1.inc"
+#include W32_INC(l0_d1)
       } else {
-#include "gen32/l0_d0.inc"
+#include W32_INC(l0_d0)
       }
     }
     NRH32_STAMP(1);   // L0
@@ -318,22 +334,22 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       {
         const int qlayer = l;
         if constexpr (JVP) {
-#include "gen32/fwd_j_p0.inc"
+#include W32_INC(fwd_j_p0)
         } else if constexpr (WANT_D) {
-#include "gen32/fwd_d1_p0.inc"
+#include W32_INC(fwd_d1_p0)
         } else {
-#include "gen32/fwd_d0_p0.inc"
+#include W32_INC(fwd_d0_p0)
         }
       }
       if (l == 7) break;
       {
         const int qlayer = l + 1;
         if constexpr (JVP) {
-#include "gen32/fwd_j_p1.inc"
+#include W32_INC(fwd_j_p1)
         } else if constexpr (WANT_D) {
-#include "gen32/fwd_d1_p1.inc"
+#include W32_INC(fwd_d1_p1)
         } else {
-#include "gen32/fwd_d0_p1.inc"
+#include W32_INC(fwd_d0_p1)
         }
       }
     }
@@ -345,26 +361,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma push_macro("W32_QSTORE")
 #undef W32_QSTORE
 #define W32_QSTORE(c, half, val) W32_Q7_##c##_##half = (val)
-#include "gen32/fwd_d1_p0.inc"
+#include W32_INC(fwd_d1_p0)
 #pragma pop_macro("W32_QSTORE")
     }
 #endif
     {
       const int qlayer = 8;   // the pending chunk 7 of layer 7 -> set 1, where FEAT / HEAD read their input
       if constexpr (JVP) {
-#include "gen32/fwd_fin_j.inc"
+#include W32_INC(fwd_fin_j)
       } else if constexpr (WANT_D) {
 #if NRH32_Q7REG
 #pragma push_macro("W32_QSTORE_P")
 #undef W32_QSTORE_P
 #define W32_QSTORE_P(c, half, val) W32_Q7_##c##_##half = (val)
-#include "gen32/fwd_fin_d1.inc"
+#include W32_INC(fwd_fin_d1)
 #pragma pop_macro("W32_QSTORE_P")
 #else
-#include "gen32/fwd_fin_d1.inc"
+#include W32_INC(fwd_fin_d1)
 #endif
       } else {
-#include "gen32/fwd_fin_d0.inc"
+#include W32_INC(fwd_fin_d0)
       }
       (void)qlayer;
     }
@@ -388,9 +404,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W32_BIAS(c) (*reinterpret_cast<const uint32_t*>(brow + 8 * 1024 + (c) * 128))
 #define W32_BCONST bconst
       {
-#include "gen32/feat.inc"
+#include W32_INC(feat)
       }
-#include "gen32/feat_fin.inc"
+#include W32_INC(feat_fin)
 #undef W32_FSTORE
 #undef W32_BIAS
 #undef W32_BCONST
@@ -407,17 +423,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
       W32_SYNC();
       W32_FETCH_SETUP();
       if constexpr (WANT_D && !Q7REG) {
-#include "gen32/t7_loads.inc"
+#include W32_INC(t7_loads)
         W32_QLOAD7_ASM(qpa, 7, 0);
         W32_QLOAD7_ASM(qpb, 7, 1);
       }
       f32x16 hh = tab_init(9, 0), cc;
+#if W32_ONE_TERM
+      cc = W32_ZERO16;
+#endif
       if constexpr (JVP) {     // tangent columns: the head is linear, its bias does not differentiate
 #pragma unroll
         for (int r = 0; r < 16; ++r) hh[r] = is_pt ? hh[r] : 0.0f;
       }
       const uint32_t wa = W32_WADDR();
-#include "gen32/kloop16.inc"
+#include W32_INC(kloop16)
       const float head = __builtin_fmaf(cc[0], LO_UNSCALE, hh[0]);
       if constexpr (JVP) {
         if (valid && hf == 0) {
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if constexpr (WANT_D) {
       // ---- T7: t_7 = (1 - q_7) * w_s / 3: chunks 0..6 straight into set 0 (R7's input), chunk 7 as R7's pending pair ----
 #define W32_A8(c) tab_init(10, c)
-#include "gen32/t7.inc"
+#include W32_INC(t7)
       hp = W32_A8(7);
       cp = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #undef W32_A8
@@ -475,8 +494,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
           W32_SYNC();
           W32_FETCH_SETUP();
           f32x16 hh, cc;
+#if W32_ONE_TERM
+          cc = W32_ZERO16;
+#endif
           const uint32_t wa = W32_WADDR();
-#include "gen32/kloop16z.inc"
+#include W32_INC(kloop16z)
           if (c == 0) epi_emb(0, hh, cc); else epi_emb(1, hh, cc);
           W32_NEXT();
         }
@@ -491,16 +513,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
         {
           const int l = 7 - 2 * k;
           const char* const qbase = uni(scr + (l - 1) * 16384);
-#include "gen32/rev_p0.inc"
+#include W32_INC(rev_p0)
         }
         if (k == 3) {
           const int l = 0;
           (void)l;
-#include "gen32/rev_fin.inc"
+#include W32_INC(rev_fin)
         } else {
           const int l = 6 - 2 * k;
           const char* const qbase = uni(scr + (l - 1) * 16384);
-#include "gen32/rev_p1.inc"
+#include W32_INC(rev_p1)
         }
         if (k == 1 || k == 3) emb_stage();
       }

@@ -32,3 +32,8 @@ int wide_color_launch(const WideColorCall& c, hipStream_t st);   // 0 ok, -1 inv
 long long wide_color_stream_bytes();
 
 }  // namespace nrh32
+
+// the one-term builds of the wide SDF kernels (nrh_wide1.hip: precision "f16", a single fp16 MFMA pass per K step)
+namespace nrh32t {
+int wide_sdf_launch(const nrh32::WideSdfCall& c, hipStream_t st);
+}

@@ -50,9 +50,10 @@ def sdf_eval(mode: int, sdf_w, sdf_b, sdf_head, ro, rd, t, n_per_ray: int, t_str
 
 @_lib.on_tensor_device
 def sdf_eval_wide(mode: int, sdf_w32, sdf_tab32, ro, rd, t, n_per_ray: int, t_stride: Optional[int] = None,
-                  scratch: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
+                  scratch: Optional[torch.Tensor] = None, one_term: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
     """``sdf_eval`` through the wide f16x3 kernels (csrc/nrh_sdf32.hip); sdf_w32 / sdf_tab32 from packing32.pack_sdf32.
-    mode 3 (wide only): sdf + the derivative along the ray in forward mode; ``grad`` = rd * (d sdf / dt) / |rd|^2."""
+    mode 3 (wide only): sdf + the derivative along the ray in forward mode; ``grad`` = rd * (d sdf / dt) / |rd|^2.
+    ``one_term``: their single-pass builds (precision "f16": one fp16 MFMA per K step, csrc/nrh_wide1.hip), same buffers."""
     lib = _lib.load()
     nrays = ro.shape[0]
     t_stride = n_per_ray if t_stride is None else t_stride
@@ -67,8 +68,9 @@ def sdf_eval_wide(mode: int, sdf_w32, sdf_tab32, ro, rd, t, n_per_ray: int, t_st
         raise ValueError("sdf_w32 has the wrong size for this library build")
     P = _lib.ptr
     with torch.cuda.device(dev):
-        rc = lib.nrh_sdf_eval_wide(mode, P(sdf_w32, sdf_w32.dtype), P(sdf_tab32), P(ro), P(rd), P(t), t_stride, n_per_ray, nrays,
-                                   P(sdf), n_per_ray, P(grad), P(feat), P(scratch) if mode in (1, 2) else None, _lib.stream_handle(dev))
+        fn = lib.nrh_sdf_eval_wide_f16 if one_term else lib.nrh_sdf_eval_wide
+        rc = fn(mode, P(sdf_w32, sdf_w32.dtype), P(sdf_tab32), P(ro), P(rd), P(t), t_stride, n_per_ray, nrays,
+                P(sdf), n_per_ray, P(grad), P(feat), P(scratch) if mode in (1, 2) else None, _lib.stream_handle(dev))
     _lib.check(rc, "nrh_sdf_eval_wide")
     return sdf, grad, feat
 

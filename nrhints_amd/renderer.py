@@ -103,7 +103,10 @@ class NeuSHintRenderer(nn.Module):
     #: rays per C call; bounds the workspace (about 145 KB per ray + 268 MB of gradient scratch)
     max_chunk_rays = 131072    # rays per nrh_render_forward call: 18 GB of workspace (HBM is 288 GB); +1.3 % over 32 768 (profiles/r02/chunk_rays_ab.log)
     #: matrix arithmetic of the MLP kernels: "f32" (v_mfma_f32_16x16x4_f32, exact fp32) or "f16x3" (three
-    #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate)
+    #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate), or - a
+    #: REDUCED-precision evaluation mode, never the default - "f16": f16x3 in everything (packing, training, the reflectance net)
+    #: except that an evaluation render runs the wide SDF kernels in their single-pass builds (one fp16 MFMA per K step: weights
+    #: and activations of the SDF network at 11 bits; PSNR against the reference 73-85 dB on the test scenes)
     precision = "f16x3"
     wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
     shadow_jvp = False         # the shadow march's last SDF evaluation in forward mode (mode 3: derivative along the ray only, no
@@ -626,7 +629,7 @@ class NeuSHintRenderer(nn.Module):
         net = _lib.make_net(pk, self._hints, self._normal_type, self._depth_type, self.dyn_scalars if use_dyn else None,
                             wide=self.wide_kernels, fused=self.fuse_feature_head and not want_mid, wide_color=self.wide_color,
                             shadow_jvp=self.shadow_jvp, shadow_clip=self._shadow_clip, samples=self._samples, consts=self._net_consts,
-                            counts=self._count_args(device),
+                            counts=self._count_args(device), single_pass=(self.precision == "f16" and not want_mid),
                             **(extra_net or {}))
         T = N_SAMPLES_TOTAL
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)

@@ -283,3 +283,62 @@ def test_wide_sdf_subnormal_activations(scene_states, level):
     s16, g16, f16 = ops.sdf_at_points(2, packed["sdf_w"], packed["sdf_b"], packed["sdf_head"], pts.cuda())
     np.testing.assert_allclose(s16.cpu().numpy()[:, 0], o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
     np.testing.assert_allclose(pk.feat_tiles_to_rows(f16.cpu(), pts.shape[0]).numpy(), o_feat.numpy(), rtol=0, atol=3e-5)
+
+
+# ---- precision "f16": the one-term (single-pass) builds of the wide SDF kernels (csrc/nrh_wide1.hip) -------------------------------
+@pytest.mark.parametrize("npts", [33, 1000, 40000])
+def test_one_term_sdf_modes_vs_oracle(wscene, npts):
+    """nrh_sdf_eval_wide_f16: the same packed streams through ONE fp16 MFMA per K step (weights and activations of the SDF network
+    at 11 bits).  A reduced-precision mode: against the float64 oracle the sdf is good to a few 1e-4 (emulated before it was built:
+    2-6e-4, profiles/r05/one_term_emulation.log) where the three-term kernels hold 5e-6 - and it must NOT be the three-term result
+    (the test tells the two builds apart); deterministic; modes 0 / 1 / 2 / 3 agree on the sdf."""
+    tag, model, packed, p64 = wscene
+    g = torch.Generator().manual_seed(1000 + npts)
+    pts = (torch.rand(npts, 3, generator=g) * 2 - 1) * 0.95
+    o_sdf, o_feat, o_grad = orc.sdf_forward_grad_analytic(p64, pts.double())
+    zeros = torch.zeros_like(pts).cuda()
+    t = torch.zeros(npts, dtype=torch.float32, device="cuda")
+    run = lambda mode, one: ops.sdf_eval_wide(mode, packed["sdf_w32"], packed["sdf_tab32"], pts.cuda().contiguous(), zeros, t, 1, one_term=one)
+    ref3 = run(0, False)[0]
+    outs = {}
+    for mode in (0, 1, 2):
+        sdf, grad, feat = run(mode, True)
+        outs[mode] = sdf
+        err = float(np.abs(sdf.cpu().numpy()[:, 0] - o_sdf.numpy()[:, 0]).max())
+        assert err < 2e-3, (mode, err)
+        if mode >= 1:
+            assert float(np.abs(grad.cpu().numpy() - o_grad.numpy()).max()) < (3e-2 if tag == "a" else 1e-1)
+        if mode == 2:
+            assert float(np.abs(pk.feat_tiles_to_rows(feat.cpu(), npts).numpy() - o_feat.numpy()).max()) < 5e-3
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(run(0, True)[0], outs[0])                                    # deterministic
+    d3 = float((outs[0] - ref3).abs().max())
+    assert d3 > 1e-6, d3                                                          # really the one-term arithmetic
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_one_term_render_vs_reference(scene_states, tag):
+    """precision "f16" end to end (evaluation render: both samplers, render_core and the shadow march on the one-term kernels, the
+    reflectance net and everything else as f16x3) against the reference's recorded render: PSNR(ours, reference) far above the
+    50 dB SURVEY 8c / 8d require of a reduced-precision mode (|delta PSNR vs ground truth| < 0.05 dB at 30 dB), rgb within 5e-3; the
+    default precision on the same rays is 30+ dB closer (so the mode is what it says); training with this precision runs the f16x3
+    kernels (same gradients)."""
+    from nrhints_amd.synthetic import psnr
+    g = load_npz(f"render_{tag}.npz")
+    mk = lambda prec: na.NeuSHintRenderer(na.NeuSModelConfig(), precision=prec)
+    rb = na.RayBundle(origins=T(g["o"]).cuda(), directions=T(g["d"]).cuda(), pl_positions=T(g["pl"]).cuda(), nears=T(g["near"]).cuda(),
+                      fars=T(g["far"]).cuda())
+    outs = {}
+    for prec in ("f16", "f16x3"):
+        m = mk(prec)
+        m.load_state_dict({k: T(np.asarray(v)) for k, v in scene_states[tag].items()})
+        m = m.cuda().eval()
+        with torch.no_grad():
+            outs[prec] = m(rb, background_rgb=torch.ones(1, 3).cuda())
+    ref = g["rgb_f64"]
+    p1, p3 = psnr(outs["f16"].rgb.cpu().numpy(), ref), psnr(outs["f16x3"].rgb.cpu().numpy(), ref)
+    assert p1 > 60.0 and p3 > p1 + 20.0, (p1, p3)
+    assert float(np.abs(outs["f16"].rgb.cpu().numpy() - ref).max()) < 5e-3
+    assert float(np.abs(outs["f16"].depth.cpu().numpy() - g["depth_f64"]).max()) < 3e-2
+    assert float(np.abs(outs["f16"].visibilities.cpu().numpy() - g["visibilities_f64"]).max()) < 1e-2
+    assert outs["f16"].weights.shape == (96, 128) and bool(torch.isfinite(outs["f16"].rgb).all())
