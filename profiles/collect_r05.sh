@@ -29,6 +29,7 @@ f=$(find $OUT/prof_train -name '*kernel_trace.csv' | head -1)
 [ -n "$f" ] && python $R/profiles/step_breakdown.py $f detail > $OUT/train_step_breakdown.txt 2>&1
 rm -rf $OUT/prof_train
 cd $R
+timeout 300 python profiles/one_term_gpu_check.py > $OUT/one_term_gpu_check.log 2>&1
 for b in 64 128 512 1024; do
   timeout 200 python profiles/train_bench.py $b 40 graph 2>/dev/null | tail -1 >> $OUT/train_bench_modes.log
 done

@@ -483,3 +483,14 @@ def test_sample_count_configs():
     m = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=R(n_samples=48, n_importance_samples=48, n_shadow_samples=32, n_shadow_importance_samples=32)))
     assert m._samples == 96 and m._counts == (48, 4, 12, 32, 8) and m._shadow_coarse == 32
     assert na.NeuSHintRenderer(na.NeuSModelConfig())._counts is None
+
+
+def test_reduced_precision_option():
+    """precision "f16" (DESIGN 7h): packed exactly like f16x3 (the one-term kernels read the same streams), accepted by the module,
+    the default stays f16x3, anything else is refused."""
+    import nrhints_amd as na
+    assert _lib.PRECISIONS["f16"] == _lib.PRECISIONS["f16x3"] == 1 and _lib.PRECISIONS["f32"] == 0
+    assert na.NeuSHintRenderer.precision == "f16x3"
+    assert na.NeuSHintRenderer(precision="f16").precision == "f16"
+    with pytest.raises(ValueError):
+        na.NeuSHintRenderer(precision="bf16")
