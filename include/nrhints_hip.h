@@ -134,6 +134,30 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
                            const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            float adj_scale, void* stream);
+/* 16-BIT HAND-OFFS of the weight-gradient operands (precision f16x3, batches the 8-wave kernels run: nrh_train_half_supported).
+ * h, abar and zbar are read by nothing but nrh_dw_gemm, which spends most of its time fetching them; these variants write them as
+ * fp16 in the HALF-TILED layout (per tile of 16 points: [block pair 8][point 16][quarter 4][block of the pair 2][4 channels], 8 KiB;
+ * arrays [8][npts][256] fp16, 16-byte aligned), which NrhDwJob.half_ops consumes with one fp16 MFMA pass and no conversion:
+ *   save_h16  layers 0..6 of h (they are NOT written to save_h; layer 7 is, in float32: the heads' jobs read it)
+ *   save_t16  a copy of layers 1..7 of t (save_t keeps all 8 in float32: the tangent sweep reads them)
+ *   abar16    layers 0..6 of abar, zbar16 layers 1..7 of zbar, both as S x the value (NOT written to abar / zbar; abar layer 7 and
+ *             zbar layer 0 are, in float32 and unscaled)
+ *   dyn       float32 [4], zero before the first call: {S, 1 / S, 2 work words}.  S is the step's adjoint scale, a power of two
+ *             taken from the range of the seeds (max |sbar|, |gbar|, |fbar| -> [8, 16] after scaling) by a small kernel ahead of the
+ *             sweeps: it replaces adj_scale (the adjoints' range moves by 2^16 between batches - one sample next to the surface at
+ *             inv_s ~ 1000 - which a constant cannot follow inside fp16's range); pass it on as NrhDwJob.dyn_scale.
+ * Accuracy: operands of the products carry 11 bits instead of 16; measured against the reference's float64 gradients every tensor of
+ * the 1 024-ray step stays inside the bound of tests/test_gpu_train1024.py (profiles/r05/dw16_emulation.log; bf16 would not). */
+int nrh_train_half_supported(int precision, long long npts);
+int nrh_sdf_train_forward_half(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                               const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                               float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
+                               void* save_h16, void* save_t16, void* stream);
+int nrh_sdf_train_backward_half(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
+                                const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
+                                const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
+                                const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
+                                void* abar16, void* zbar16, float* dyn, const void* save_t16, void* stream);
 
 /* ---- the outside-NeRF background network (renderer.use_outside_nerf) -----------------------------------------------------
  * fields/nerf_density_field.py:30-89 as called from models/neus_hint_model.py:434-473: per point of the inverted-sphere
@@ -185,6 +209,17 @@ int nrh_color_train_forward(int precision, int hints, const float* col_w, const 
                             float* save_h, float* save_misc, void* stream);
 int nrh_color_train_backward(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
                              long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, void* stream);
+/* The same with 16-BIT HAND-OFFS to nrh_dw_gemm (precision f16x3; see nrh_sdf_train_forward_half for the layout): save_h16 = fp16
+ * [4][nrays*128][256] half-tiled, layers 0..2 of the ReLU outputs (NOT written to save_h; layer 3 is) - the adjoint sweep reads them
+ * as masks; zbar16 = layers 1..3 of zbar as S x half_gain x the value (NOT written to zbar; layer 0 is, unscaled).  The seeds of
+ * this chain are bounded (|zbar4| <= 1 / (12 rays): a sigmoid's derivative times a weight <= 1 times the loss normalisation), so
+ * half_gain is a constant power of two: with adj_scale = rays / 8, 1 024 puts the arrays' maxima at 2^-6 .. 2^2. */
+int nrh_color_train_forward_half(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                                 const float* pts, const float* normal, const float* raymisc, int samples_per_row, long long nrays,
+                                 float* color, float* save_h, float* save_misc, void* save_h16, void* stream);
+int nrh_color_train_backward_half(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
+                                  long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, const void* save_h16,
+                                  void* zbar16, float half_gain, void* stream);
 
 /* ---- alpha stage, training ---------------------------------------------------------------------------------
  * NeuSHintRenderer.get_alpha + compositing weights + unit normals (models/neus_hint_model.py:339-356, :521-525, :584)
@@ -338,6 +373,8 @@ typedef struct NrhTrainSaves {
                            the visibility hint (renderer.shadow_hint_gradient); NULL = kept in the workspace */
   float* vis_groups;    /* optional [nrays, clip]: the partial visibility hint per sample group (NrhNet.shadow_clip > 0; the
                            `visibilities` output is only the value at the maximal-weight sample); NULL = kept in the workspace */
+  void* save_h16;       /* optional, both or neither (nrh_sdf_train_forward_half below): 16-bit hand-offs of h ...             */
+  void* save_t16;       /* ... and t to nrh_dw_gemm, fp16 [8][nrays*128][256] in the half-tiled layout                          */
 } NrhTrainSaves;
 int nrh_render_forward_train(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
                              const float* nears, const float* fars, long long nrays, float cos_anneal,
@@ -449,6 +486,10 @@ typedef struct NrhDwJob {
   int tiled_a[2];   /* pair k: the operand is in the TILED layout of the training arrays instead of row-major (256 channels only): */
   int tiled_b[2];   /* [tile of 16 points][block of 16 channels][point 16][16 channels] - what nrh_sdf_train_forward / _backward    */
                     /* write save_h, save_t, abar, zbar in when nrh_train_arrays_tiled() says so                                  */
+  int half_ops;     /* 1: all operands of the job are fp16 arrays in the HALF-TILED layout ([tile of 16 points][block pair 8][point 16] */
+                    /* [quarter 4][block of the pair 2][4 channels], 8 KiB per tile; NrhTrainHalf) - full 256 x 256 products only;     */
+                    /* one fp16 MFMA per K step instead of three bf16 ones (the a / b pointers are cast, lda = ldb = 256)              */
+  const float* dyn_scale;   /* optional DEVICE pointer {S, 1 / S} (nrh_adjoint_range): out and colsum_a are multiplied by dyn_scale[1] */
 } NrhDwJob;
 /* 1 if save_h, save_t (nrh_sdf_train_forward), abar and zbar (nrh_sdf_train_backward) are tiled - opaque hand-offs between those
  * kernels and nrh_dw_gemm, which a caller passes on with tiled_a / tiled_b set - 0 if they are row-major [layer][npts][256].

@@ -29,7 +29,8 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param
             "nrh_alpha_composite", "nrh_visibility", "nrh_color_composite", "nrh_sphere_trace", "nrh_sphere_trace_workspace_floats",
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
             "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step", "nrh_fuse_feature_head",
-            "nrh_train_arrays_tiled", "nrh_sdf_eval_wide_f16")
+            "nrh_train_arrays_tiled", "nrh_sdf_eval_wide_f16", "nrh_train_half_supported", "nrh_sdf_train_forward_half",
+            "nrh_sdf_train_backward_half", "nrh_color_train_forward_half", "nrh_color_train_backward_half")
 
 
 class NrhNet(Structure):
@@ -51,7 +52,7 @@ class NrhAdamTensor(Structure):
 class NrhTrainSaves(Structure):
     _fields_ = [("sdf", c_void_p), ("feat_rows", c_void_p), ("save_h", c_void_p), ("save_s1", c_void_p),
                 ("save_t", c_void_p), ("save_ge", c_void_p), ("raymisc", c_void_p), ("shadow_mid_z", c_void_p),
-                ("shadow_dists", c_void_p), ("vis_groups", c_void_p)]
+                ("shadow_dists", c_void_p), ("vis_groups", c_void_p), ("save_h16", c_void_p), ("save_t16", c_void_p)]
 
 
 def adjoint_scale(n_rays: int) -> float:
@@ -91,17 +92,21 @@ def load():
     P = c_void_p
     lib.nrh_version.restype = c_int
     lib.nrh_train_arrays_tiled.restype = c_int
+    lib.nrh_train_half_supported.argtypes = [c_int, c_longlong]
+    lib.nrh_train_half_supported.restype = c_int
     lib.nrh_build_info.restype = c_char_p
     lib.nrh_last_error_string.restype = c_char_p
     lib.nrh_param_sizes.argtypes = [POINTER(c_int)]
     lib.nrh_mlp_grid.restype = c_int
     lib.nrh_sdf_eval.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, c_int, P, P, P, P]
     lib.nrh_sdf_train_forward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P]
+    lib.nrh_sdf_train_forward_half.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P]
     lib.nrh_ray_adjoint.argtypes = [P, P, P, P, P, P, P, P, c_int, P, c_longlong, P, P, P, P]
     lib.nrh_outside_sizes.argtypes = [POINTER(c_int)]
     lib.nrh_outside_forward.argtypes = [c_int, P, P, P, P, P, c_int, c_longlong, P, P, P, P, P, P, P, P]
     lib.nrh_outside_backward.argtypes = [c_int, P, P, P, P, P, P, c_longlong, P, P, P, P, P, c_float, P]
     lib.nrh_sdf_train_backward.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P, c_float, P]
+    lib.nrh_sdf_train_backward_half.argtypes = [c_int, P, P, P, P, P, P, c_int, c_int, c_longlong, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]
     lib.nrh_alpha_train_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P]
     lib.nrh_alpha_train_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P]
     lib.nrh_alpha_train_forward_n.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P, P]
@@ -116,6 +121,8 @@ def load():
     lib.nrh_color_train_forward.argtypes = [c_int, c_int, P, P, P, P, P, P, c_longlong, P, P, P, P]
     lib.nrh_color_train_forward_grouped.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_longlong, P, P, P, P]
     lib.nrh_color_train_backward.argtypes = [c_int, c_int, P, P, P, c_longlong, P, P, P, c_float, P]
+    lib.nrh_color_train_forward_half.argtypes = [c_int, c_int, P, P, P, P, P, P, c_int, c_longlong, P, P, P, P, P]
+    lib.nrh_color_train_backward_half.argtypes = [c_int, c_int, P, P, P, c_longlong, P, P, P, c_float, P, P, c_float, P]
     PP = POINTER(c_void_p)
     lib.nrh_weight_norm_fold.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, P]
     lib.nrh_weight_norm_fold_backward.argtypes = [c_int, POINTER(c_int), POINTER(c_int), PP, PP, PP, PP, PP, P]

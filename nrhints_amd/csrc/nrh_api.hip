@@ -420,7 +420,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 145; }
+int nrh_version(void) { return 146; }
 int nrh_train_arrays_tiled(void) { return nrh::arr_tiled(nrh::ARR_H) ? 1 : 0; }
 const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
 const char* nrh_last_error_string(void) { return g_err; }
@@ -502,10 +502,38 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
 
 long long nrh_sdf_wide_stream_bytes(void) { return nrh32::wide_sdf_stream_bytes_total(); }
 
+// 16-bit hand-offs (NrhTrainSaves.save_h16 / save_t16, nrh_sdf_train_backward_half): the 8-wave f16x3 kernels only
+static int t16_only_mode() {      // experiment switch: layers 1..6 of t exist as fp16 only (the tangent sweep reads save_t16)
+  static const int on = (getenv("NRH_T16_ONLY") && atoi(getenv("NRH_T16_ONLY")) != 0) ? 1 : 0;
+  return on;
+}
+int nrh_train_half_supported(int precision, long long npts) {
+  return (precision == 1 && npts > 0 && npts % 32 == 0 && !split_train(precision, npts) && !small_batch(npts)) ? 1 : 0;
+}
+
+static int sdf_train_forward_impl(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                                  const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                                  float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
+                                  void* save_h16, void* save_t16, void* stream);
 int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                           float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
                           void* stream) {
+  return sdf_train_forward_impl(precision, sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, grad, feat_rows, save_h,
+                                save_s1, save_t, save_ge, nullptr, nullptr, stream);
+}
+int nrh_sdf_train_forward_half(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                               const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                               float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
+                               void* save_h16, void* save_t16, void* stream) {
+  if (!save_h16 || !save_t16) return fail(NRH_E_INVALID, "nrh_sdf_train_forward_half: null pointer%s", "");
+  return sdf_train_forward_impl(precision, sdf_w, sdf_b, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, sdf, grad, feat_rows, save_h,
+                                save_s1, save_t, save_ge, save_h16, save_t16, stream);
+}
+static int sdf_train_forward_impl(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
+                                  const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
+                                  float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
+                                  void* save_h16, void* save_t16, void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: precision must be 0 (f32) or 1 (f16x3)%s", "");
   if (!sdf_w || !sdf_b || !sdf_head || !ro || !rd || !t || !sdf || !grad || !feat_rows || !save_h || !save_s1 || !save_t || !save_ge)
     return fail(NRH_E_INVALID, "nrh_sdf_train_forward: null pointer%s", "");
@@ -520,6 +548,13 @@ int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b,
   a.save_h = save_h; a.save_s1 = save_s1; a.save_t = save_t; a.save_ge = save_ge;
   a.npts = nrays * n_per_ray;
   a.n_per_ray = n_per_ray; a.t_stride = t_stride; a.sdf_stride = n_per_ray;
+  if (save_h16 || save_t16) {
+    if (!save_h16 || !save_t16 || !nrh_train_half_supported(precision, a.npts) || (((uintptr_t)save_h16 | (uintptr_t)save_t16) & 15))
+      return fail(NRH_E_INVALID, "nrh_sdf_train_forward: 16-bit hand-offs need precision f16x3, a batch the 8-wave kernels run "
+                  "(nrh_train_half_supported) and 16-byte aligned arrays%s", "");
+    a.save_h16 = save_h16; a.save_t16 = save_t16;
+    a.t16_only = t16_only_mode();
+  }
   const hipStream_t st = (hipStream_t)stream;
   if (split_train(precision, a.npts)) {
     hipLaunchKernelGGL(nrh::sdf_train_split_kernel, dim3((unsigned)(a.npts / 16)), dim3(256), nrh::SPLT_LDS_BYTES, st, a);
@@ -544,11 +579,33 @@ static bool adj_scale_ok(float s) {
   return s > 0.0f && s < 3.0e38f && frexpf(s, &e) == 0.5f && e >= -60 && e <= 60;
 }
 
+static int sdf_train_backward_impl(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
+                                   const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
+                                   const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
+                                   const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
+                                   float adj_scale, void* abar16, void* zbar16, float* dyn, const void* save_t16, void* stream);
 int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
                            const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
                            const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            float adj_scale, void* stream) {
+  return sdf_train_backward_impl(precision, sdf_w, wt_feat, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, save_s1, save_t, gbar, fbar,
+                                 sbar, abar, coup, gebar, zbar, pbar, adj_scale, nullptr, nullptr, nullptr, nullptr, stream);
+}
+int nrh_sdf_train_backward_half(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
+                                const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
+                                const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
+                                const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
+                                void* abar16, void* zbar16, float* dyn, const void* save_t16, void* stream) {
+  if (!abar16 || !zbar16 || !dyn) return fail(NRH_E_INVALID, "nrh_sdf_train_backward_half: null pointer%s", "");
+  return sdf_train_backward_impl(precision, sdf_w, wt_feat, sdf_head, ro, rd, t, t_stride, n_per_ray, nrays, save_s1, save_t, gbar, fbar,
+                                 sbar, abar, coup, gebar, zbar, pbar, 1.0f, abar16, zbar16, dyn, save_t16, stream);
+}
+static int sdf_train_backward_impl(int precision, const float* sdf_w, const float* wt_feat, const float* sdf_head, const float* ro,
+                                   const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays,
+                                   const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
+                                   const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
+                                   float adj_scale, void* abar16, void* zbar16, float* dyn, const void* save_t16, void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
   if (!adj_scale_ok(adj_scale)) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: adj_scale must be a power of two in [2^-60, 2^60]%s", "");
   if (!sdf_w || !wt_feat || !sdf_head || !ro || !rd || !t || !save_s1 || !save_t || !gbar || !fbar || !sbar || !abar || !coup ||
@@ -567,6 +624,20 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
   a.n_per_ray = n_per_ray; a.t_stride = t_stride;
   a.adj_scale = precision == 1 ? adj_scale : 1.0f;
   const hipStream_t st = (hipStream_t)stream;
+  if (abar16) {
+    // 16-bit hand-offs: the adjoint scale follows the seeds (adjoint_range_kernel), abar / zbar leave as fp16 x S
+    if (!nrh_train_half_supported(precision, a.npts) || (((uintptr_t)abar16 | (uintptr_t)zbar16 | (uintptr_t)dyn) & 15))
+      return fail(NRH_E_INVALID, "nrh_sdf_train_backward_half: needs precision f16x3, a batch the 8-wave kernels run "
+                  "(nrh_train_half_supported) and 16-byte aligned arrays%s", "");
+    nrh::AdjRangeArgs ra;
+    ra.sbar = sbar; ra.gbar = gbar; ra.fbar = fbar; ra.dyn = dyn; ra.npts = a.npts;
+    const long long want = (a.npts * 64 / 8 + 255) / 256;
+    hipLaunchKernelGGL(nrh::adjoint_range_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want))), dim3(256), 0, st, ra);
+    rc = check_launch("adjoint_range_kernel");
+    if (rc) return rc;
+    a.abar16 = abar16; a.zbar16 = zbar16; a.dyn = dyn;
+    a.t16 = (t16_only_mode() && save_t16) ? save_t16 : nullptr;
+  }
   if (split_train(precision, a.npts)) {
     const dim3 gs((unsigned)(a.npts / 16)), bs(256);
     hipLaunchKernelGGL(nrh::sdf_tangent_split_kernel, gs, bs, nrh::SPLB_LDS_BYTES, st, a);
@@ -663,9 +734,26 @@ int nrh_color_train_forward(int precision, int hints, const float* col_w, const 
                                          save_misc, stream);
 }
 
+static int color_train_forward_impl(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                                    const float* pts, const float* normal, const float* raymisc, int samples_per_row, long long nrays,
+                                    float* color, float* save_h, float* save_misc, void* save_h16, void* stream);
 int nrh_color_train_forward_grouped(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
                                     const float* pts, const float* normal, const float* raymisc, int samples_per_row, long long nrays,
                                     float* color, float* save_h, float* save_misc, void* stream) {
+  return color_train_forward_impl(precision, hints, col_w, col_b, feat_rows, pts, normal, raymisc, samples_per_row, nrays, color, save_h,
+                                  save_misc, nullptr, stream);
+}
+int nrh_color_train_forward_half(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                                 const float* pts, const float* normal, const float* raymisc, int samples_per_row, long long nrays,
+                                 float* color, float* save_h, float* save_misc, void* save_h16, void* stream) {
+  if (!save_h16 || precision != 1 || ((uintptr_t)save_h16 & 15))
+    return fail(NRH_E_INVALID, "nrh_color_train_forward_half: precision f16x3 and a 16-byte aligned fp16 array%s", "");
+  return color_train_forward_impl(precision, hints, col_w, col_b, feat_rows, pts, normal, raymisc, samples_per_row, nrays, color, save_h,
+                                  save_misc, save_h16, stream);
+}
+static int color_train_forward_impl(int precision, int hints, const float* col_w, const float* col_b, const float* feat_rows,
+                                    const float* pts, const float* normal, const float* raymisc, int samples_per_row, long long nrays,
+                                    float* color, float* save_h, float* save_misc, void* save_h16, void* stream) {
   int misc_shift = 0;
   while ((1 << misc_shift) < samples_per_row) ++misc_shift;
   if (samples_per_row < 1 || samples_per_row > 128 || (1 << misc_shift) != samples_per_row)
@@ -681,7 +769,7 @@ int nrh_color_train_forward_grouped(int precision, int hints, const float* col_w
   memset(&a, 0, sizeof(a));
   a.w = col_w; a.b = col_b; a.feat = feat_rows; a.pts = pts; a.nhat = normal; a.raymisc = raymisc; a.color = color;
   a.ro = pts; a.rd = pts; a.tmid = pts;  // unused in the training instantiation
-  a.save_h = save_h; a.save_misc = save_misc; a.misc_shift = misc_shift;
+  a.save_h = save_h; a.save_misc = save_misc; a.misc_shift = misc_shift; a.save_h16 = save_h16;
   a.npts = nrays * 128;
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_color_train_forward");
@@ -696,8 +784,24 @@ int nrh_color_train_forward_grouped(int precision, int hints, const float* col_w
   return check_launch("color_kernel<train>");
 }
 
+static int color_train_backward_impl(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
+                                     long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, const void* save_h16,
+                                     void* zbar16, float half_gain, void* stream);
 int nrh_color_train_backward(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
                              long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, void* stream) {
+  return color_train_backward_impl(precision, hints, col_wt, zbar4, save_h, nrays, zbar, fbar, mbar, adj_scale, nullptr, nullptr, 1.0f, stream);
+}
+int nrh_color_train_backward_half(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
+                                  long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, const void* save_h16,
+                                  void* zbar16, float half_gain, void* stream) {
+  if (!save_h16 || !zbar16 || precision != 1 || !adj_scale_ok(half_gain) || (((uintptr_t)save_h16 | (uintptr_t)zbar16) & 15))
+    return fail(NRH_E_INVALID, "nrh_color_train_backward_half: precision f16x3, 16-byte aligned fp16 arrays, half_gain a power of two%s", "");
+  return color_train_backward_impl(precision, hints, col_wt, zbar4, save_h, nrays, zbar, fbar, mbar, adj_scale, save_h16, zbar16, half_gain,
+                                   stream);
+}
+static int color_train_backward_impl(int precision, int hints, const float* col_wt, const float* zbar4, const float* save_h,
+                                     long long nrays, float* zbar, float* fbar, float* mbar, float adj_scale, const void* save_h16,
+                                     void* zbar16, float half_gain, void* stream) {
   if (precision < 0 || precision > 1) return fail(NRH_E_INVALID, "nrh_color_train_backward: precision must be 0 (f32) or 1 (f16x3)%s", "");
   if (!adj_scale_ok(adj_scale)) return fail(NRH_E_INVALID, "nrh_color_train_backward: adj_scale must be a power of two in [2^-60, 2^60]%s", "");
   if (!col_wt || !zbar4 || !save_h || !zbar || !fbar || !mbar) return fail(NRH_E_INVALID, "nrh_color_train_backward: null pointer%s", "");
@@ -708,6 +812,7 @@ int nrh_color_train_backward(int precision, int hints, const float* col_wt, cons
   nrh::ColorAdjArgs a;
   memset(&a, 0, sizeof(a));
   a.wt = col_wt; a.zbar4 = zbar4; a.save_h = save_h; a.zbar = zbar; a.fbar = fbar; a.mbar = mbar;
+  a.save_h16 = save_h16; a.zbar16 = zbar16; a.half_gain = half_gain;
   a.npts = nrays * 128;
   a.adj_scale = precision == 1 ? adj_scale : 1.0f;
   int grid = 0;
@@ -1006,7 +1111,12 @@ int nrh_dw_gemm(const NrhDwJob* jobs, int njobs, long long npts, float* workspac
       if ((q.tiled_a[k] && (q.lda[k] != 256 || q.m != 256)) || (q.tiled_b[k] && (q.ldb[k] != 256 || q.n != 256)))
         return fail(NRH_E_INVALID, "nrh_dw_gemm: a tiled operand has 256 channels%s (job %lld)", "", (long long)j);
       a.job[j].ta[k] = q.tiled_a[k] ? 1 : 0; a.job[j].tb[k] = q.tiled_b[k] ? 1 : 0;
+      if (q.half_ops && (q.lda[k] != 256 || q.ldb[k] != 256 || q.m != 256 || q.n != 256 || (((uintptr_t)q.a[k] | (uintptr_t)q.b[k]) & 15)))
+        return fail(NRH_E_INVALID, "nrh_dw_gemm: half operands are full 256-channel arrays, 16-byte aligned%s (job %lld)", "", (long long)j);
     }
+    if (q.half_ops && (q.colsum_b || npts % 32 != 0 || q.slabs > nsteps / 2))
+      return fail(NRH_E_INVALID, "nrh_dw_gemm: a half-operand job has no column sums of B, 32-point stages%s (job %lld)", "", (long long)j);
+    a.job[j].half = q.half_ops ? 1 : 0;
     if (q.out && (q.rows < 1 || q.rows > q.m || q.cols < 1 || q.cols > q.n || q.ldo < 1))
       return fail(NRH_E_INVALID, "nrh_dw_gemm: bad output shape%s (job %lld)", "", (long long)j);
     if (q.col_map && q.transpose) return fail(NRH_E_INVALID, "nrh_dw_gemm: col_map with transpose%s", "");
@@ -1015,7 +1125,7 @@ int nrh_dw_gemm(const NrhDwJob* jobs, int njobs, long long npts, float* workspac
     nrhdw::OutDev& o = r.job[j];
     o.out = q.out; o.col_map = q.col_map; o.colsum_a = q.colsum_a; o.colsum_b = q.colsum_b; o.ldo = q.ldo; o.transpose = q.transpose;
     o.rows = q.out ? q.rows : q.m; o.cols = q.out ? q.cols : q.n; o.scale = q.scale; o.scale_a = q.scale_a; o.scale_b = q.scale_b;
-    o.slab0 = slab0; o.slabs = q.slabs;
+    o.slab0 = slab0; o.slabs = q.slabs; o.dyn = q.dyn_scale;
     slab0 += q.slabs;
   }
   a.njobs = njobs; a.nsteps = nsteps;
@@ -1363,8 +1473,8 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     // training: the same evaluation with the feature row-major and the arrays the backward sweeps need (16-point kernels: a wide
     // one-wave-per-SIMD form was built in round 4, measured slower - its row stores do not overlap a single wave's MFMA stream,
     // DESIGN.md section 7c - and removed in round 5)
-    rc = nrh_sdf_train_forward(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
-                               sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, stream);
+    rc = sdf_train_forward_impl(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
+                               sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, train->save_h16, train->save_t16, stream);
   } else {
     rc = sdf_eval_impl(net->precision, 2, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n, sdf_c, 128,
                        o_grad, ws_feat, scratch, st, WideNet{net->sdf_w32, net->sdf_tab32});

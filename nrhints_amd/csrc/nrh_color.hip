@@ -28,6 +28,8 @@ struct ColorArgs {
   const float* pts;      // [npts,3]
   float* save_h;         // [4][npts][256]  ReLU outputs of layers 0..3
   float* save_misc;      // [npts][16*MKB]  the non-feature part of the layer-0 input in kernel order
+  void* save_h16;        // optional (PREC 1, TRAIN): fp16 half-tiled [4][npts][256] (csrc/nrh_mlp.h half_ptr) - layers 0..2 of the ReLU
+                         // outputs go HERE INSTEAD of save_h: the adjoint sweep reads them as masks, nrh_dw_gemm as half operands
   int misc_shift;        // sample P reads row P >> misc_shift of raymisc: 7 = one row per ray; smaller for the partial shadow
                          // mode (n_shadow_importance_clip: one row per group of 128 / clip consecutive samples)
 };
@@ -39,6 +41,9 @@ struct ColorAdjArgs {
   float* zbar;           // [4][npts][256]  adjoints of the pre-ReLU outputs of layers 0..3
   float* fbar;           // [npts][256]     adjoint of the feature input (feeds the SDF value sweep)
   float* mbar;           // [npts][16*MKB]  adjoint of the non-feature input part
+  const void* save_h16;  // optional (f16x3): layers 0..2 of the ReLU outputs as fp16 half-tiled (ColorArgs.save_h16) - read instead of save_h
+  void* zbar16;          // optional (f16x3): layers 1..3 of zbar leave as fp16 half-tiled, times S * half_gain, INSTEAD of zbar
+  float half_gain;       // a power of two: the seeds are bounded (|zbar4| <= 1 / (12 rays)), so the stored range needs no measurement
   long long npts;
   int ntile_groups;
   float adj_scale;       // f16x3 only: a power of two S.  The adjoint chain runs on S * (the seeds) and its outputs leave as 1 / S *
@@ -83,6 +88,16 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
         st_stream(reinterpret_cast<f32x4*>(p + (2 * ch) * 16), v0);
         st_stream(reinterpret_cast<f32x4*>(p + (2 * ch + 1) * 16), v1);
       }
+    };
+
+    auto save_h_rows = [&](int l, int ch, const f32x4 v0, const f32x4 v1) {
+      if constexpr (PREC == 1) {
+        if (a.save_h16 && l < 3) {          // (wave-uniform: a kernel argument and the layer)
+          if (tile_ok) st_stream(half_ptr<true>(a.save_h16, l, a.npts, Pc, ch, q), pack_half8(v0, v1));
+          return;
+        }
+      }
+      save_rows(a.save_h, l, 256, ch, v0, v1);
     };
 
     // ---- C0a: feature part ----
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
         const f32x4 h0 = relu4(acc0 + p.b0), h1 = relu4(acc1 + p.b1);
         h.set_chunk(ch, h0, h1);
-        if constexpr (TRAIN) save_rows(a.save_h, 0, 256, ch, h0, h1);
+        if constexpr (TRAIN) save_h_rows(0, ch, h0, h1);
       };
       run_stage<PREC, MKB, 8, true, true>(a.w + COL_OFF_C0B, a.w + col_off_C(1, MKB), 32, smem, par, misc, part, pre, epi, wave, lane);
     }
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_kernel(const ColorArgs a
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const BiasV& p) {
         const f32x4 h0 = relu4(acc0 + p.b0), h1 = relu4(acc1 + p.b1);
         ho.set_chunk(ch, h0, h1);
-        if constexpr (TRAIN) save_rows(a.save_h, l, 256, ch, h0, h1);
+        if constexpr (TRAIN) save_h_rows(l, ch, h0, h1);
       };
       const float* wn = (l < 3) ? a.w + col_off_C(l + 1, MKB) : a.w + col_off_C4(MKB);
       run_stage<PREC, 16, 8, false, true>(a.w + col_off_C(l, MKB), wn, 32, smem, par, h, nullptr, pre, epi, wave, lane);
@@ -247,6 +262,30 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_adjoint_kernel(const Col
       }
     };
     struct HPre { f32x4 h0, h1; };
+    // ReLU outputs of layer l as masks: float32 rows, or (16-bit hand-offs, layers 0..2) the fp16 array - only the sign is used
+    auto load_h = [&](int l, int ch) {
+      HPre p;
+      if constexpr (PREC == 1) {
+        if (a.save_h16 && l < 3) {
+          const f16x8_t hv = ld_stream(half_ptr<true>(const_cast<void*>(a.save_h16), l, a.npts, row, ch, q));
+          p.h0 = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+          p.h1 = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+          return p;
+        }
+      }
+      p.h0 = ld_stream(rows_ptr(a.save_h, l, 2 * ch));
+      p.h1 = ld_stream(rows_ptr(a.save_h, l, 2 * ch + 1));
+      return p;
+    };
+    auto store_zbar = [&](int l, int ch, const f32x4 z0, const f32x4 z1) {
+      if constexpr (PREC == 1) {
+        if (a.zbar16 && l >= 1) {
+          if (tile_ok) st_stream(half_ptr<true>(a.zbar16, l, a.npts, row, ch, q), pack_half8(z0 * a.half_gain, z1 * a.half_gain));
+          return;
+        }
+      }
+      store_rows(a.zbar, l, 256, ch, z0, z1);
+    };
 
     // ---- T4: 3 -> 256 (the adjoint of the 3 outputs sits in block 0, lanes q == 0, registers 0..2) ----
     Act<PREC, 2> z4;
@@ -258,17 +297,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_adjoint_kernel(const Col
     }
     Act<PREC, 16> h;
     {
-      auto pre = [&](int ch) {
-        HPre p;
-        p.h0 = ld_stream(rows_ptr(a.save_h, 3, 2 * ch));
-        p.h1 = ld_stream(rows_ptr(a.save_h, 3, 2 * ch + 1));
-        return p;
-      };
+      auto pre = [&](int ch) { return load_h(3, ch); };
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const HPre& p) {
         f32x4 z0, z1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { z0[r] = p.h0[r] > 0.0f ? acc0[r] : 0.0f; z1[r] = p.h1[r] > 0.0f ? acc1[r] : 0.0f; }
-        store_rows(a.zbar, 3, 256, ch, z0, z1);
+        store_zbar(3, ch, z0, z1);
         h.set_chunk(ch, z0, z1);
       };
       run_stage<PREC, 2, 8, false, true>(a.wt, a.wt + colt_off_T(3), 32, smem, par, z4, nullptr, pre, epi, wave, lane);
@@ -276,17 +310,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void color_adjoint_kernel(const Col
     // ---- T3, T2, T1 ----
     for (int l = 3; l >= 1; --l) {
       Act<PREC, 16> ho;
-      auto pre = [&](int ch) {
-        HPre p;
-        p.h0 = ld_stream(rows_ptr(a.save_h, l - 1, 2 * ch));
-        p.h1 = ld_stream(rows_ptr(a.save_h, l - 1, 2 * ch + 1));
-        return p;
-      };
+      auto pre = [&](int ch) { return load_h(l - 1, ch); };
       auto epi = [&](int ch, f32x4 acc0, f32x4 acc1, const HPre& p) {
         f32x4 z0, z1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { z0[r] = p.h0[r] > 0.0f ? acc0[r] : 0.0f; z1[r] = p.h1[r] > 0.0f ? acc1[r] : 0.0f; }
-        store_rows(a.zbar, l - 1, 256, ch, z0, z1);
+        store_zbar(l - 1, ch, z0, z1);
         ho.set_chunk(ch, z0, z1);
       };
       const float* wn = (l > 1) ? a.wt + colt_off_T(l - 1) : a.wt + COLT_OFF_T0A;

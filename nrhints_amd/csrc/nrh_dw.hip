@@ -64,6 +64,7 @@ struct JobDev {
   int m, n;              // channels of A / B that exist (<= 256); the rest reads as zero
   int slab0, slabs;      // this job's work items: [slab0, slab0 + slabs)
   int colsum;            // bit 0: column sums of A_0, bit 1: of B_0
+  int half;              // all four operands are fp16 in the half-tiled layout (dw_item_half); full 256 x 256 products only
   int ta[2], tb[2];      // pair k: operand is TILED - [tile of 16 points][block 16][point 16][16 channels] (csrc/nrh_mlp.h, the layout
                          // the sweep kernels write h, t, abar, zbar in) instead of row-major; 256 channels only
 };
@@ -563,6 +564,132 @@ __device__ __forceinline__ void dw_item_fast(const JobDev& J, const int slab, co
   cs[c0 + 1] = sum1;
 }
 
+// ---- 16-bit operands (round 5): full 256 x 256 products whose four arrays are fp16 in the HALF-TILED layout -----------------------
+// The sweep kernels of the f16x3 training step can write h, t, abar, zbar - arrays nothing but this kernel reads - as fp16
+// (csrc/nrh_mlp.h, half_ptr: [tile of 16 points][block pair 8][point 16][quarter 4][block of the pair 2][4 channels], 8 KiB per
+// tile, one contiguous KiB per wave instruction), the adjoints multiplied by the step's power-of-two adjoint scale so that they sit in
+// fp16's range.  Then a product is ONE v_mfma_f32_32x32x16_f16 per K step instead of three bf16 ones, the operand bytes halve, and
+// nothing is converted: the LDS-DMA image of a KiB piece IS a [16 points][32 channels] block (64 bytes per point), and
+// ds_read_b64_tr_b16 - gfx950's transpose read: a 16-lane group fetches a 4 points x 16 channels matrix, lane c receives the four
+// points of channel c - turns it into MFMA fragments (K = points contiguous per lane) directly.  Lane l (group G = l >> 4, i = l & 15)
+// supplies point 8 (G >> 1) + (i >> 2), quarter i & 3, block G & 1 of the pair; the 32 lanes of a half-wave cover 256 contiguous
+// bytes: no bank conflict.  Accuracy: operands carry 11 bits, products are exact in the fp32 accumulator; priced against the
+// reference's float64 gradients before it was built (profiles/dw16_emulation.py -> profiles/r05/dw16_emulation.log: every tensor
+// inside the 1 024-ray test's bounds at the three anneal steps; bf16 operands are not - 4-5x outside on the reflectance net).
+// Pipeline: a stage = 32 points of both operands (32 KiB), five stages, four in flight (128 KiB per CU), one barrier per stage.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+constexpr int H16_STAGE = 32768;         // A: 2 tiles x 8 KiB | B: 2 tiles x 8 KiB
+constexpr int H16_STAGES = 5;
+constexpr int H16_DIST = 4;
+static_assert(H16_STAGES * H16_STAGE <= FAST_LDS_BYTES, "LDS per workgroup");
+
+__device__ __forceinline__ f16x8 tr_frag(const char* lds) {
+  typedef __attribute__((address_space(3))) i16x4 lds_v;
+  const lds_v* p = (const lds_v*)(const __attribute__((address_space(3))) char*)lds;
+  const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_v*>(p));            // points +0..3 of the lane's k group
+  const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_v*>(p + 32));       // points +4..7 (256 bytes further)
+  const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+  return f16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+
+__device__ __forceinline__ void dw_item_half(const JobDev& J, const int slab, const int nsteps_all, float* __restrict__ part,
+                                             float* __restrict__ csum, char* smem) {
+  constexpr int NF = 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane16 = lane * 16;
+  const int n32 = nsteps_all >> 1;                      // stages of 32 points
+  const int s0 = (int)((long long)n32 * slab / J.slabs), s1 = (int)((long long)n32 * (slab + 1) / J.slabs);
+  const int nst = s1 - s0;
+  const int total = nst * J.npairs;
+  const uint32_t lds0 = lds_off(smem);
+  const bool want_sum = (J.colsum & 1) != 0;
+
+  f32x16 acc[2][NF];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.0f;
+  float sum[2] = {0.0f, 0.0f};
+
+  // this wave's 4 + 4 pieces of a stage: piece p = wave + 4 k of the operand's 16 KiB (a stage is contiguous in both operands)
+  int fidx = 0, fstage = 0;
+  auto issue = [&]() {
+    const bool live = fidx < total;
+    const int pair = (fidx >= nst) ? 1 : 0;
+    const long long s = s0 + (pair ? fidx - nst : fidx);
+    const char* ga = reinterpret_cast<const char*>(J.a[pair]) + s * 16384 + wave * 1024;
+    const char* gb = reinterpret_cast<const char*>(J.b[pair]) + s * 16384 + wave * 1024;
+    const uint32_t m = __builtin_amdgcn_readfirstlane(live ? 0xffffffffu : 0u);
+    const uint64_t lanes = ((uint64_t)m << 32) | m;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + fstage * H16_STAGE + (k >> 2) * 16384 + (wave + 4 * (k & 3)) * 1024);
+      dma_piece_fast(uni(((k >> 2) ? gb : ga) + (k & 3) * 4096), m0v, lane16, lanes);
+    }
+    ++fidx;
+    fstage = (fstage == H16_STAGES - 1) ? 0 : fstage + 1;
+  };
+  // the lane's corner of a [16 points][32 channels] piece for the transpose read
+  const int lb = (((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64) + (lane & 3) * 16 + ((lane >> 4) & 1) * 8;
+
+  if (total > 0) {
+#pragma unroll
+    for (int d = 0; d < H16_DIST; ++d) issue();
+    int cstage = 0;
+    for (int idx = 0; idx < total; ++idx) {
+      // stage idx landed (this wave's 8 oldest pieces; everybody's after the barrier); everybody is done reading stage idx - 1
+      asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue();                            // stage idx + 4 -> the buffer stage idx - 1 was read from
+      const char* st = smem + cstage * H16_STAGE + lb;
+      const bool sum_now = want_sum && idx < nst;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {    // the stage's two tiles of 16 points
+        f16x8 af[2];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) af[mf] = tr_frag(st + (ss * 8 + 2 * wave + mf) * 1024);
+        if (sum_now) {
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              sum[mf] = __builtin_amdgcn_fdot2(f16x2{af[mf][2 * i], af[mf][2 * i + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, sum[mf], false);
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const f16x8 bf = tr_frag(st + 16384 + (ss * 8 + nf) * 1024);
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mf], bf, acc[mf][nf], 0, 0, 0);
+        }
+      }
+      cstage = (cstage == H16_STAGES - 1) ? 0 : cstage + 1;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // nothing of this item is in flight into LDS any more
+
+  const int col = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_nontemporal_store(acc[mf][nf][r], part + (size_t)(64 * wave + 32 * mf + frow(r, hf)) * 256 + 32 * nf + col);
+  // column sums of A_0: lane l and l ^ 32 hold the two K halves of channel 64 wave + 32 mf + (l & 31)
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    const float other = __shfl_xor(sum[mf], 32);
+    if (hf == 0) csum[64 * wave + 32 * mf + col] = sum[mf] + other;
+  }
+  if (tid < 256) csum[256 + tid] = 0.0f;
+}
+
 // ---- the thin path: products with at most four columns (the SDF head: h_7^T sbar + abar_7^T 1; the reflectance net's output layer
 // transposed: save_h_3^T zbar4) are matrix-VECTOR work - 256 x n multiply-adds per point against 1 KiB of A to read - so they run as
 // plain float32 FMAs straight from global memory, thread t = channel t of A, no LDS, no conversion (exact fp32 products).
@@ -623,7 +750,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
   float* part = a.partial + (size_t)item * SLOT_FLOATS;
   float* cs = a.csum + (size_t)item * CSUM_FLOATS;
   const bool full = J.m == 256 && J.n == 256 && J.lda[0] == 256 && J.ldb[0] == 256 && (J.npairs == 1 || (J.lda[1] == 256 && J.ldb[1] == 256));
-  if (full) dw_item_fast(J, slab, a.nsteps, part, cs, smem);
+  if (J.half) dw_item_half(J, slab, a.nsteps, part, cs, smem);
+  else if (full) dw_item_fast(J, slab, a.nsteps, part, cs, smem);
   else if (J.n <= 4) dw_item_thin(J, slab, a.nsteps, part, cs);
   else if (J.n <= 32) dw_item<1>(J, slab, a.nsteps, part, cs, smem);
   else if (J.n <= 64) dw_item<2>(J, slab, a.nsteps, part, cs, smem);
@@ -641,6 +769,7 @@ struct OutDev {
   int rows, cols;        // only i < rows, j < cols are written
   float scale, scale_a, scale_b;
   int slab0, slabs;
+  const float* dyn;      // optional device pointer {S, 1 / S}: the product and the column sums of A are multiplied by dyn[1]
 };
 struct ReduceArgs {
   OutDev job[MAX_JOBS];
@@ -653,18 +782,19 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const ReduceArgs a) {
   const OutDev& J = a.job[blockIdx.y];
   const int e = blockIdx.x * 256 + threadIdx.x;     // element of the [256][256] product
   const int i = e >> 8, j = e & 255;
+  const float dyn = J.dyn ? J.dyn[1] : 1.0f;
   if (J.out && i < J.rows && j < J.cols) {
     float s = 0.0f;
     for (int k = 0; k < J.slabs; ++k) s += a.partial[(size_t)(J.slab0 + k) * SLOT_FLOATS + e];
     const int jj = J.col_map ? J.col_map[j] : j;
-    J.out[J.transpose ? (size_t)jj * J.ldo + i : (size_t)i * J.ldo + jj] = s * J.scale;
+    J.out[J.transpose ? (size_t)jj * J.ldo + i : (size_t)i * J.ldo + jj] = s * J.scale * dyn;
   }
   if (blockIdx.x == 0) {
     const int c = threadIdx.x;
     if (J.colsum_a && c < J.rows) {
       float s = 0.0f;
       for (int k = 0; k < J.slabs; ++k) s += a.csum[(size_t)(J.slab0 + k) * CSUM_FLOATS + c];
-      J.colsum_a[c] = s * J.scale_a;
+      J.colsum_a[c] = s * J.scale_a * dyn;
     }
     if (J.colsum_b && c < J.cols) {
       float s = 0.0f;

@@ -337,6 +337,27 @@ __device__ __forceinline__ F* arr_ptr(F* base, int l, long long npts, long long 
 template <int V>
 struct ArrTag { static constexpr int value = V; };
 
+// ---- 16-bit hand-offs to nrh_dw_gemm (round 5, f16x3 step only) -----------------------------------------------------------------
+// h, abar, zbar (and a copy of t) are read by nothing but the weight-gradient kernel, so the sweeps can write them as fp16 in the
+// HALF-TILED layout [tile of 16 points][block pair 8][point 16][quarter 4][block of the pair 2][4 channels] (8 KiB per tile): a
+// chunk's two blocks of a lane (8 values) become ONE 16-byte store, a wave instruction one contiguous KiB, and the KiB is, as it
+// lands in LDS, the [16 points][32 channels] image ds_read_b64_tr_b16 turns into MFMA fragments (csrc/nrh_dw.hip, dw_item_half).
+// Adjoints are written as the chain carries them (S x the true value, S = the step's power-of-two adjoint scale); round to nearest.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <bool PIN = true>
+__device__ __forceinline__ f16x8_t* half_ptr(void* base, int l, long long npts, long long row, int ch, int q) {
+  const int j = (int)(row & 15);
+  _Float16* const u = reinterpret_cast<_Float16*>(base) + ((size_t)l * (size_t)npts * 256 + (size_t)ch * 512);
+  const uint32_t v = (uint32_t)(row - j) * 256u + (uint32_t)(32 * j + 8 * q);
+  return reinterpret_cast<f16x8_t*>(arr_join<PIN>(u, v));
+}
+__device__ __forceinline__ f16x8_t pack_half8(const f32x4 v0, const f32x4 v1) {
+  typedef float f32x8_t __attribute__((ext_vector_type(8)));
+  const f32x8_t v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  return __builtin_convertvector(v, f16x8_t);           // v_cvt_pk_f16_f32 x 4 (round to nearest even)
+}
+
+
 // ---------------- packed-buffer geometry of the SDF net (floats) ----------------
 // execution order: L0 | L1..L7 | FEAT | R7..R1 | R0        (R_l = W_l^T, the reverse chain)
 constexpr int SDF_L0_FLOATS = 8 * 2 * 4 * 256;     // 8 chunks x (2 ob x 4 kb) KiB (39 inputs -> 64)

@@ -38,6 +38,9 @@ struct SdfArgs {
   float* save_s1;      // [8][npts][256]  sigma'_l = sigmoid(100 z_l) (0 on substituted entries); replaces the scratch
   float* save_t;       // [8][npts][256]  t_l = sigma'_l * a_{l+1}, the reverse-chain stage inputs (t_7 = sigma'_7 w_s/3)
   float* save_ge;      // [npts][128]     cols 0..63 a_0 (39 used), cols 64..111 = a_4[208..255] (skip part from col 73)
+  void* save_h16;      // optional (PREC 1): fp16 half-tiled [8][npts][256] - layers 0..6 of h go HERE INSTEAD of save_h (nrh_mlp.h half_ptr)
+  void* save_t16;      // optional (PREC 1): fp16 half-tiled copy of layers 1..7 of t (save_t keeps all 8: the tangent sweep reads them)
+  int t16_only;        // with save_t16: layers 1..6 of t go to save_t16 ONLY (the tangent sweep is told to read them there)
   long long npts;
   int n_per_ray;
   int t_stride;
@@ -132,6 +135,17 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_kernel(const SdfArgs a) {
     };
     auto save_rows = [&](auto AT, float* base, int l, int ch, const f32x4 v0, const f32x4 v1) {
       constexpr int ARR = decltype(AT)::value;
+      if constexpr (PREC == 1 && (ARR == ARR_H || ARR == ARR_T)) {
+        // 16-bit hand-offs of the weight-gradient operands (wave-uniform branches on kernel arguments)
+        if (ARR == ARR_H && a.save_h16 && l < 7) {
+          if (tile_ok) st_stream(half_ptr<true>(a.save_h16, l, a.npts, row, ch, q), pack_half8(v0, v1));
+          return;
+        }
+        if (ARR == ARR_T && a.save_t16 && l >= 1) {
+          if (tile_ok) st_stream(half_ptr<true>(a.save_t16, l, a.npts, row, ch, q), pack_half8(v0, v1));
+          if (a.t16_only && l < 7) return;
+        }
+      }
       if (tile_ok) {
         st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR, PREC == 1>(base, l, a.npts, row, 2 * ch, q)), v0);
         st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR, PREC == 1>(base, l, a.npts, row, 2 * ch + 1, q)), v1);

@@ -43,6 +43,10 @@ struct SdfTrainArgs {
   int n_per_ray;
   int t_stride;
   int ntile_groups;
+  void* abar16;          // optional (f16x3): fp16 half-tiled [8][npts][256]; layers 0..6 of abar go HERE, as S x the value, INSTEAD of abar
+  void* zbar16;          // optional (f16x3): the same for layers 1..7 of zbar
+  const void* t16;       // optional (f16x3): layers 1..6 of t are read from this fp16 half-tiled array instead of tt (SdfArgs.t16_only)
+  const float* dyn;      // optional (f16x3) device {S, 1 / S}: the step's adjoint scale from the seeds' range (adjoint_range_kernel)
   float adj_scale;       // f16x3 only: a power of two S.  The adjoint chain runs on S * (the seeds) and its outputs leave as 1 / S *
                          // (the result): the loss is normalised by the ray count (pipelines/base_pipeline.py:57), so at 1 024 rays
                          // per step the adjoints are ~ 1e-3 of a single ray's and their fp16 halves (absolute floor 3e-11 under
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
 
   dma_chunk(a.w + SDF_OFF_L0, smem, 8, wave, lane);
   __syncthreads();
-  const float S = (PREC == 1) ? a.adj_scale : 1.0f, IS = 1.0f / S;   // SdfTrainArgs.adj_scale: the sweep is linear in gbar
+  const float S = (PREC == 1) ? (a.dyn ? a.dyn[0] : a.adj_scale) : 1.0f, IS = 1.0f / S;   // SdfTrainArgs.adj_scale: the sweep is linear in gbar
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -137,6 +141,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
         TrainPre p;
         p.s0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, s, a.npts, row, 2 * ch, q)));
         p.s1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, s, a.npts, row, 2 * ch + 1, q)));
+        if (PREC == 1 && a.t16 && s >= 1 && s < 7) {
+          const f16x8_t tv = ld_stream(half_ptr<true>(const_cast<void*>(a.t16), s, a.npts, row, ch, q));
+          p.t0 = f32x4{(float)tv[0], (float)tv[1], (float)tv[2], (float)tv[3]};
+          p.t1 = f32x4{(float)tv[4], (float)tv[5], (float)tv[6], (float)tv[7]};
+          return p;
+        }
         p.t0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T, PREC == 1>(a.tt, s, a.npts, row, 2 * ch, q)));
         p.t1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_T, PREC == 1>(a.tt, s, a.npts, row, 2 * ch + 1, q)));
         return p;
@@ -157,8 +167,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
         if (tile_ok) {
           st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch, q)), c0 * IS);
           st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch + 1, q)), c1 * IS);
-          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR, PREC == 1>(a.abar, s, a.npts, row, 2 * ch, q)), n0 * IS);
-          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR, PREC == 1>(a.abar, s, a.npts, row, 2 * ch + 1, q)), n1 * IS);
+          if (PREC == 1 && a.abar16 && s < 7) {
+            st_stream(half_ptr<true>(a.abar16, s, a.npts, row, ch, q), pack_half8(n0, n1));
+          } else {
+            st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR, PREC == 1>(a.abar, s, a.npts, row, 2 * ch, q)), n0 * IS);
+            st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ABAR, PREC == 1>(a.abar, s, a.npts, row, 2 * ch + 1, q)), n1 * IS);
+          }
         }
         ho.set_chunk(ch, n0, n1);
       };
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
 
   dma_chunk(a.wt_feat, smem, 32, wave, lane);
   __syncthreads();
-  const float S = (PREC == 1) ? a.adj_scale : 1.0f, IS = 1.0f / S;   // SdfTrainArgs.adj_scale: linear in (fbar, sbar, coup)
+  const float S = (PREC == 1) ? (a.dyn ? a.dyn[0] : a.adj_scale) : 1.0f, IS = 1.0f / S;   // SdfTrainArgs.adj_scale: linear in (fbar, sbar, coup)
 
   for (int tg = blockIdx.x; tg < a.ntile_groups; tg += gridDim.x) {
     const long long tile = (long long)tg * WG_WAVES + wave;
@@ -242,8 +256,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
         }
         const f32x4 z0 = p.s0 * acc0 + p.t0 * S, z1 = p.s1 * acc1 + p.t1 * S;
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR, PREC == 1>(a.zbar, lz, a.npts, row, 2 * ch, q)), z0 * IS);
-          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR, PREC == 1>(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1 * IS);
+          if (PREC == 1 && a.zbar16 && lz >= 1) {
+            st_stream(half_ptr<true>(a.zbar16, lz, a.npts, row, ch, q), pack_half8(z0, z1));
+          } else {
+            st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR, PREC == 1>(a.zbar, lz, a.npts, row, 2 * ch, q)), z0 * IS);
+            st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_ZBAR, PREC == 1>(a.zbar, lz, a.npts, row, 2 * ch + 1, q)), z1 * IS);
+          }
         }
         ho.set_chunk(ch, z0, z1);
       };

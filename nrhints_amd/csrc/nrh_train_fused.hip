@@ -242,6 +242,59 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const LossFinishArgs a
 
 // d loss / d variance = sum_rays invs_bar * d inv_s / d variance, inv_s = clip(exp(10 variance), 1e-6, 1e6)
 // (models/neus_hint_model.py:104-110, :337): 10 inv_s inside the clip range, 0 outside.  One block.
+// ---- the step's adjoint scale from the range of the seeds ------------------------------------------------------------------------
+// The f16x3 sweeps of the SDF net are linear in their seeds (sbar, gbar, fbar) and run on S x the seeds, S a power of two
+// (SdfTrainArgs.adj_scale).  With 16-bit hand-offs to nrh_dw_gemm the chain's S-scaled adjoints are also what is STORED (fp16:
+// abar, zbar), so S has to follow the data: over scenes, anneal steps and batch sizes the seeds' maximum times the ray count spans
+// 2^-8 .. 2^8 (events: one sample next to the surface at inv_s ~ 1000; profiles/r05/dw16_ranges.log), the ratio of the stored
+// arrays' maxima to the seeds' maximum only 2^-7 .. 2^-2.  S = 2^(4 - ceil(log2 max|seed|)) puts the seeds' maximum in [8, 16]:
+// stored maxima around 2^-3 .. 2^2 with 2^14 of head-room to fp16's largest number and 2^10 .. 2^15 above the level (2^-13)
+// where the format's absolute floor would start to cost accuracy relative to the array's largest entries.
+// dyn = {S, 1 / S, max bits (uint), block counter}: the last block to arrive writes S and resets the two work words - no memset
+// between steps, so the kernel is a plain node of the captured step; max is order-independent: deterministic.
+struct AdjRangeArgs {
+  const float* sbar;     // [npts]
+  const float* gbar;     // [npts][3]
+  const float* fbar;     // [npts][256] (every 8th row is looked at: its share of the range is small and it is 64x the bytes)
+  float* dyn;            // [4]
+  long long npts;
+};
+__global__ __launch_bounds__(256) void adjoint_range_kernel(const AdjRangeArgs a) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
+  float m = 0.0f;
+  for (long long i = tid; i < a.npts; i += nth) m = fmaxf(m, fabsf(a.sbar[i]));
+  for (long long i = tid; i < a.npts * 3; i += nth) m = fmaxf(m, fabsf(a.gbar[i]));
+  const long long nf = (a.npts + 7) / 8 * 64;          // float4 words of the sampled rows
+  for (long long i = tid; i < nf; i += nth) {
+    const long long row = (i >> 6) * 8;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.fbar + row * 256 + (i & 63) * 4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  unsigned int* const w = reinterpret_cast<unsigned int*>(a.dyn);
+  if ((threadIdx.x & 63) == 0) {
+    // non-negative floats order like their bit patterns; NaN seeds (bits above +inf) are caught below
+    atomicMax(w + 2, __float_as_uint(m));
+    __threadfence();
+    if (atomicAdd(w + 3, 1u) == gridDim.x * 4 - 1) {
+      const float mx = __uint_as_float(atomicMax(w + 2, 0u));
+      float S = 1.0f;
+      if (mx > 0.0f && mx < 3.0e38f) {
+        int e;
+        (void)frexpf(mx, &e);                              // mx = f 2^e, f in [0.5, 1): ceil(log2 mx) <= e
+        e = 4 - e;
+        e = e < -60 ? -60 : (e > 60 ? 60 : e);
+        S = ldexpf(1.0f, e);
+      }
+      a.dyn[0] = S;
+      a.dyn[1] = 1.0f / S;
+      w[2] = 0u;
+      w[3] = 0u;
+    }
+  }
+}
+
 struct VarGradArgs {
   const float* invs_bar;  // [N]
   const float* dyn;

@@ -23,7 +23,7 @@ class NrhDwJob(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("col_map", ctypes.c_void_p), ("ldo", ctypes.c_int), ("transpose", ctypes.c_int),
                 ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("scale", ctypes.c_float),
                 ("colsum_a", ctypes.c_void_p), ("scale_a", ctypes.c_float), ("colsum_b", ctypes.c_void_p), ("scale_b", ctypes.c_float),
-                ("tiled_a", ctypes.c_int * 2), ("tiled_b", ctypes.c_int * 2)]
+                ("tiled_a", ctypes.c_int * 2), ("tiled_b", ctypes.c_int * 2), ("half_ops", ctypes.c_int), ("dyn_scale", ctypes.c_void_p)]
 
 
 class Job:
@@ -32,9 +32,13 @@ class Job:
     def __init__(self, a: Sequence[torch.Tensor], b: Sequence[torch.Tensor], m: int, n: int, out: Optional[torch.Tensor] = None,
                  rows: Optional[int] = None, cols: Optional[int] = None, transpose: bool = False, scale: float = 1.0,
                  col_map: Optional[torch.Tensor] = None, colsum_a: Optional[torch.Tensor] = None, scale_a: float = 1.0,
-                 colsum_b: Optional[torch.Tensor] = None, scale_b: float = 1.0, tiled_a: Sequence[bool] = (), tiled_b: Sequence[bool] = ()):
+                 colsum_b: Optional[torch.Tensor] = None, scale_b: float = 1.0, tiled_a: Sequence[bool] = (), tiled_b: Sequence[bool] = (),
+                 half: bool = False, dyn_scale: Optional[torch.Tensor] = None):
         """``tiled_a`` / ``tiled_b``: per pair, the operand is in the tiled layout of the training arrays (csrc/nrh_mlp.h: what the
-        sweep kernels write h, t, abar, zbar in when ``arrays_tiled()``) instead of row-major; 256 channels only."""
+        sweep kernels write h, t, abar, zbar in when ``arrays_tiled()``) instead of row-major; 256 channels only.
+        ``half``: every operand is a float16 [P, 256] array in the HALF-TILED layout (``to_half_tiled``; what the f16x3 sweeps write
+        when asked for 16-bit hand-offs) - full 256 x 256 products only, one fp16 MFMA pass.  ``dyn_scale``: device float32 [2]
+        {S, 1 / S} (nrh_adjoint_range): the product and colsum_a are multiplied by its second entry."""
         assert len(a) == len(b) and 1 <= len(a) <= 2
         self.a, self.b, self.m, self.n, self.out = list(a), list(b), m, n, out
         self.rows, self.cols = (m if rows is None else rows), (n if cols is None else cols)
@@ -42,6 +46,9 @@ class Job:
         self.colsum_a, self.scale_a, self.colsum_b, self.scale_b = colsum_a, scale_a, colsum_b, scale_b
         self.tiled_a = [bool(t) for t in tiled_a] + [False] * (len(self.a) - len(tiled_a))
         self.tiled_b = [bool(t) for t in tiled_b] + [False] * (len(self.b) - len(tiled_b))
+        self.half, self.dyn_scale = bool(half), dyn_scale
+        if self.half:
+            assert m == 256 and n == 256 and colsum_b is None and all(x.dtype == torch.float16 for x in self.a + self.b)
 
     def cost(self) -> float:
         """relative time of one K step: 6 MFMAs per 32 output columns per wave + the load / split / LDS overhead of both operands"""
@@ -53,11 +60,17 @@ class Job:
         if self.n <= 4:
             return len(self.a) * 1.0       # (latency-bound per workgroup: it needs as many items as an MFMA job to fill the chip)
         full = self.m == 256 and self.n == 256
+        if self.half:                      # half the bytes, a third of the MFMAs, no conversion
+            return len(self.a) * 0.45
         return len(self.a) * (1.0 if full else 1.5)
 
 
-def _rows(t: torch.Tensor):
-    """(pointer, leading dimension) of a [P, C] float32 view whose rows are contiguous"""
+def _rows(t: torch.Tensor, half: bool = False):
+    """(pointer, leading dimension) of a [P, C] float32 view whose rows are contiguous (``half``: a contiguous float16 [P, 256])"""
+    if half:
+        if not (t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.shape[1] == 256 and t.is_contiguous()):
+            raise ValueError("half dw operands must be contiguous float16 [P, 256] GPU arrays")
+        return t.data_ptr(), 256
     if t.dim() == 1:
         t = t[:, None]
     if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
@@ -116,10 +129,15 @@ def run(jobs: List[Job], npts: int, total_items: Optional[int] = None) -> None:
             for k, (a, b) in enumerate(zip(j.a, j.b)):
                 if a.shape[0] != npts or b.shape[0] != npts:
                     raise ValueError("dw operands must have one row per point")
-                q.a[k], q.lda[k] = _rows(a)
-                q.b[k], q.ldb[k] = _rows(b)
+                q.a[k], q.lda[k] = _rows(a, j.half)
+                q.b[k], q.ldb[k] = _rows(b, j.half)
                 q.tiled_a[k], q.tiled_b[k] = int(j.tiled_a[k]), int(j.tiled_b[k])
             q.npairs, q.m, q.n = len(j.a), j.m, j.n
+            q.half_ops = int(j.half)
+            if j.dyn_scale is not None:
+                if not (j.dyn_scale.is_cuda and j.dyn_scale.dtype == torch.float32 and j.dyn_scale.numel() >= 2):
+                    raise ValueError("dyn_scale must be a float32 GPU tensor {S, 1 / S}")
+                q.dyn_scale = j.dyn_scale.data_ptr()
             q.slabs = max(1, min(nsteps, int(round(total_items * c / tot))))
             if j.out is not None:
                 if not (j.out.is_cuda and j.out.dtype == torch.float32 and j.out.is_contiguous()):
@@ -180,19 +198,47 @@ def to_tiled(x: torch.Tensor) -> torch.Tensor:
     return x.reshape(*lead, P // 16, 16, 16, 16).transpose(-3, -2).contiguous().reshape(*lead, P, 256)
 
 
+def to_half_tiled(x: torch.Tensor) -> torch.Tensor:
+    """Row-major [..., P, 256] -> float16 in the half-tiled layout of the 16-bit hand-offs: per tile of 16 points,
+    [block pair 8][point 16][quarter 4][block of the pair 2][4 channels] (8 KiB; tests - the kernels write it themselves)."""
+    P = x.shape[-2]
+    assert P % 16 == 0 and x.shape[-1] == 256
+    lead = x.shape[:-2]
+    v = x.to(torch.float16).reshape(*lead, P // 16, 16, 8, 2, 4, 4)          # tile, point, pair, e, quarter, r
+    nd = len(lead)
+    v = v.permute(*range(nd), nd, nd + 2, nd + 1, nd + 4, nd + 3, nd + 5)    # tile, pair, point, quarter, e, r
+    return v.contiguous().reshape(*lead, P, 256)
+
+
+def from_half_tiled(x: torch.Tensor) -> torch.Tensor:
+    """inverse of ``to_half_tiled`` (float16 row-major)"""
+    P = x.shape[-2]
+    lead = x.shape[:-2]
+    nd = len(lead)
+    v = x.reshape(*lead, P // 16, 8, 16, 4, 2, 4).permute(*range(nd), nd, nd + 2, nd + 1, nd + 4, nd + 3, nd + 5)
+    return v.contiguous().reshape(*lead, P, 256)
+
+
 def from_tiled(x: torch.Tensor) -> torch.Tensor:
     """inverse of ``to_tiled`` (the permutation is an involution on the [point, block] axes)"""
     return to_tiled(x)
 
 
-def sdf_jobs(shapes, h, t, zbar, abar, gebar, emb, sbar, fbar, out) -> List[Job]:
+def sdf_jobs(shapes, h, t, zbar, abar, gebar, emb, sbar, fbar, out, half=None) -> List[Job]:
     """Jobs for the SDF network's 8 layers and 2 heads (the maths: nrhints_amd/sdf_function.py).  h, t, zbar, abar [8,P,256];
     gebar, emb [P,64]; sbar [P]; fbar [P,256]; ``out``: dict of preallocated gradient tensors dW0..7, db0..7, ws, bs, Wf, bf;
-    ``shapes``: the dense weights' shapes (layer 3 has 217 rows)."""
+    ``shapes``: the dense weights' shapes (layer 3 has 217 rows).
+    ``half``: dict(h16, t16, zbar16, abar16 float16 [8,P,256] half-tiled, dyn) - the 16-bit hand-offs of the f16x3 step: the seven
+    256 x 256 two-pair products (layers 1..7) read those instead; of the float32 arrays only h[7], t[0], zbar[0], abar[7] hold data."""
     P = h.shape[1]
     T_ = arrays_tiled()       # h, t, zbar, abar as the sweep kernels wrote them; emb, gebar, fbar, sbar are row-major
     jobs = [Job([zbar[0], t[0]], [emb, gebar], 256, 39, out["dW0"], rows=shapes[0][0], colsum_a=out["db0"], tiled_a=(T_, T_))]
     for l in range(1, 8):
+        if half is not None:
+            jobs.append(Job([half["zbar16"][l], half["t16"][l]], [half["h16"][l - 1], half["abar16"][l - 1]], 256, 256, out[f"dW{l}"],
+                            rows=shapes[l][0], scale=(1.0 / math.sqrt(2.0) if l == 4 else 1.0), colsum_a=out[f"db{l}"], half=True,
+                            dyn_scale=half["dyn"]))
+            continue
         jobs.append(Job([zbar[l], t[l]], [h[l - 1], abar[l - 1]], 256, 256, out[f"dW{l}"], rows=shapes[l][0],
                         scale=(1.0 / math.sqrt(2.0) if l == 4 else 1.0), colsum_a=out[f"db{l}"], tiled_a=(T_, T_), tiled_b=(T_, T_)))
     jobs.append(Job([fbar], [h[7]], 256, 256, out["Wf"], colsum_a=out["bf"], tiled_b=(T_,)))
@@ -202,14 +248,20 @@ def sdf_jobs(shapes, h, t, zbar, abar, gebar, emb, sbar, fbar, out) -> List[Job]
     return jobs
 
 
-def color_jobs(hints: bool, zbar, zbar4, save_h, feat, save_misc, out) -> List[Job]:
+def color_jobs(hints: bool, zbar, zbar4, save_h, feat, save_misc, out, half=None) -> List[Job]:
     """Jobs for the reflectance network's 5 layers.  zbar, save_h [4,P,256]; zbar4 [P,3]; feat [P,256]; save_misc [P,128|64];
-    ``out``: w0 [256,361|316], w1..w3 [256,256], w4 [3,256], b0..b3 [256], b4 [3]."""
+    ``out``: w0 [256,361|316], w1..w3 [256,256], w4 [3,256], b0..b3 [256], b4 [3].
+    ``half``: dict(zbar16, h16 float16 [4,P,256] half-tiled, inv_scale) - the 16-bit hand-offs: layers 1..3 read zbar16[l] (stored as
+    1 / inv_scale x the value) and h16[l - 1]; of the float32 arrays only zbar[0] and save_h[3] hold data."""
     fi, mi = color_col_maps(zbar.device, hints)
     nm = 105 if hints else 60
     jobs = [Job([zbar[0]], [feat], 256, 256, out["w0"], col_map=fi, colsum_a=out["b0"]),
             Job([zbar[0]], [save_misc], 256, nm, out["w0"], col_map=mi)]
     for l in (1, 2, 3):
+        if half is not None:
+            jobs.append(Job([half["zbar16"][l]], [half["h16"][l - 1]], 256, 256, out[f"w{l}"], colsum_a=out[f"b{l}"], half=True,
+                            scale=half["inv_scale"], scale_a=half["inv_scale"]))
+            continue
         jobs.append(Job([zbar[l]], [save_h[l - 1]], 256, 256, out[f"w{l}"], colsum_a=out[f"b{l}"]))
     jobs.append(Job([save_h[3]], [zbar4], 256, 3, out["w4"], transpose=True, colsum_b=out["b4"]))
     return jobs

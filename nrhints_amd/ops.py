@@ -140,10 +140,14 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
 
 
 @_lib.on_tensor_device
-def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sbar, fbar, gbar, adj_scale: float = 1.0):
+def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sbar, fbar, gbar, adj_scale: float = 1.0,
+                       half_handoffs: bool = False, dyn: Optional[torch.Tensor] = None):
     """The two backward sweeps at the points ro[ray] + rd[ray] * t[ray, j]
     -> dict(abar, coup, zbar [8,P,256], gebar [P,64], pbar [P,3]).  ``adj_scale``: see _lib.adjoint_scale (a training step passes
-    it; 1 = the adjoints as they come, for callers whose adjoints are O(1))."""
+    it; 1 = the adjoints as they come, for callers whose adjoints are O(1)).
+    ``half_handoffs`` (f16x3, batches with nrh_train_half_supported): layers 0..6 of abar and 1..7 of zbar leave as float16 arrays
+    ``abar16`` / ``zbar16`` (half-tiled, times the step's adjoint scale, which the library takes from the seeds' range and writes to
+    ``dyn`` = float32 [4], zero before its first use) INSTEAD of the float32 arrays; adj_scale is not used."""
     lib = _lib.load()
     nrays = ro.shape[0]
     n = nrays * n_per_ray
@@ -155,6 +159,17 @@ def sdf_train_backward(sdf_w, wt_feat, sdf_head, ro, rd, t, n_per_ray, saves, sb
     wtp, prec2 = _wptr(wt_feat)
     if prec != prec2:
         raise ValueError("sdf_w and wt_feat are packed for different precisions")
+    if half_handoffs:
+        out["abar16"] = torch.empty(8, n, 256, dtype=torch.float16, device=ro.device)
+        out["zbar16"] = torch.empty(8, n, 256, dtype=torch.float16, device=ro.device)
+        out["dyn"] = dyn if dyn is not None else torch.zeros(4, **f32)
+        rc = lib.nrh_sdf_train_backward_half(prec, wp, wtp, P(sdf_head), P(ro), P(rd), P(t), n_per_ray, n_per_ray, nrays,
+                                             P(saves["s1"]), P(saves["t"]), P(gbar), P(fbar), P(sbar), P(out["abar"]), P(out["coup"]),
+                                             P(out["gebar"]), P(out["zbar"]), P(out["pbar"]), P(out["abar16"], torch.float16),
+                                             P(out["zbar16"], torch.float16), P(out["dyn"]), P(saves.get("t16"), torch.float16),
+                                             _lib.stream_handle())
+        _lib.check(rc, "nrh_sdf_train_backward_half")
+        return out
     rc = lib.nrh_sdf_train_backward(prec, wp, wtp, P(sdf_head), P(ro), P(rd), P(t), n_per_ray, n_per_ray, nrays,
                                     P(saves["s1"]), P(saves["t"]), P(gbar), P(fbar), P(sbar), P(out["abar"]), P(out["coup"]),
                                     P(out["gebar"]), P(out["zbar"]), P(out["pbar"]), float(adj_scale), _lib.stream_handle())

@@ -566,10 +566,12 @@ class NeuSHintRenderer(nn.Module):
 
     # ---------------------------------------------------------------------------------------------
     def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None, want_shadow=False,
-                      extra_net=None):
+                      extra_net=None, half_handoffs=False):
         """One nrh_render_forward_train call over the whole batch: the no-grad stages (samplers, hit point, shadow march,
         cue) plus the training evaluation of the SDF network at the section mid-points, whose outputs and saved arrays
-        feed the backward sweeps directly (no second evaluation)."""
+        feed the backward sweeps directly (no second evaluation).  ``half_handoffs`` (the fused step, f16x3, batches the 8-wave
+        kernels run): layers 0..6 of h and a copy of layers 1..7 of t go to float16 arrays ``saves["h16"]`` / ``saves["t16"]`` in the
+        half-tiled layout nrh_dw_gemm reads with one fp16 MFMA pass (include/nrhints_hip.h, nrh_sdf_train_forward_half)."""
         lib = _lib.load()
         device = o.device
         n = o.shape[0]
@@ -591,8 +593,12 @@ class NeuSHintRenderer(nn.Module):
             out.update(shadow_mid_z=new(n, T), shadow_dists=new(n, T))
         if self._shadow_clip > 0 and not zero_hints:
             out.update(vis_groups=new(n * self._shadow_clip, 1))
+        if half_handoffs:
+            sv["h16"] = torch.empty(8, n * T, 256, dtype=torch.float16, device=device)
+            sv["t16"] = torch.empty(8, n * T, 256, dtype=torch.float16, device=device)
         saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]), P(raymisc),
-                                   P(out.get("shadow_mid_z")), P(out.get("shadow_dists")), P(out.get("vis_groups")))
+                                   P(out.get("shadow_mid_z")), P(out.get("shadow_dists")), P(out.get("vis_groups")),
+                                   P(sv.get("h16"), torch.float16), P(sv.get("t16"), torch.float16))
         ws = self._workspace(device, n)
         rc = lib.nrh_render_forward_train(
             net, P(o), P(d), P(pl), P(near), P(far), n, cos_anneal, P(t_rand_p) if t_rand_p is not None else None,

@@ -27,6 +27,7 @@ Restrictions (the autograd path covers the rest): GPU float32 parameters, no hin
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -34,6 +35,13 @@ import torch
 from . import _lib, dw, ops, packing
 
 LOSS_KEYS = ("loss", "rgb_loss", "eikonal_loss", "s_val", "psnr")
+
+
+# 16-bit hand-offs of the reflectance net's adjoints (nrh_color_train_backward_half): stored as adjoint_scale(rays) x this x the value.
+# |zbar4| <= 1 / (12 rays) whatever the scene, and the measured maxima of the layers' adjoints x rays span 2^-12.6 .. 2^-5.3
+# (profiles/r05/dw16_ranges.log): with rays / 8 x 1 024 they land at 2^-5.6 .. 2^1.7 - 13 binades under fp16's largest number,
+# 7 above the level (2^-13) where its absolute floor would cost accuracy relative to an array's largest entries.
+COLOR_HALF_GAIN = 1024.0
 
 
 def supported(renderer, ray_bundle) -> Optional[str]:
@@ -71,6 +79,8 @@ class _Buffers:
         self.czbar, self.fbar, self.mbar = new(4, P, 256), new(P, 256), new(P, mw)
         self.sdf_bar, self.grad_bar, self.rd_bar, self.invs_bar = new(P), new(P, 3), new(n, 3), new(n)
         self.emb = new(P, 64)
+        self.save_h16 = self.czbar16 = None      # the reflectance net's 16-bit hand-offs (allocated when the step uses them)
+        self.dyn = torch.zeros(4, dtype=torch.float32, device=dev)      # {S, 1 / S, work words} of the 16-bit hand-offs (ops.sdf_train_backward)
         self.o_bar, self.d_bar, self.pl_bar = new(n, 3), new(n, 3), new(n, 3)      # ray adjoints (pose / light refinement)
         # What .grad of the 46 parameter tensors points at: views into ONE flat float32 buffer, laid out in the order of
         # renderer.parameters() (``param_layout``: name -> (offset, shape)).  The kernels that produce parameter gradients write
@@ -181,9 +191,12 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
                 off += prm.numel()
             B = cache[key] = _Buffers(dev, n, hints, shapes, layout, clip)
         # ---- no-grad stages + SDF training forward (one C call) ----
-        res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc)
-        pre, sv = res["pre"], res["pre"]["saves"]
         Pn = n * 128
+        # 16-bit hand-offs of the SDF net's weight-gradient operands (f16x3, batches the 8-wave kernels run; NRH_DW_HALF=0: float32)
+        half = (pk["precision"] == 1 and getattr(renderer, "dw_half", True) and os.environ.get("NRH_DW_HALF", "1") != "0"
+                and bool(lib.nrh_train_half_supported(1, Pn)))
+        res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half)
+        pre, sv = res["pre"], res["pre"]["saves"]
         # ---- reflectance forward ----
         pts3 = B.pts.view(n, 128, 3)                       # p = o + d * t with separate roundings, as the SDF kernels form it
         torch.mul(d[:, None, :], res["mid_z"][..., None], out=pts3)
@@ -193,9 +206,19 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         normal_in = (res["normals"] if analytic else res["nhat"]).view(Pn, 3)
         # rows of per-ray inputs: one per ray, or - partial visibility hint outside the geometry warm-up - one per group of samples
         per_row = 128 // clip if (clip > 1 and not zero_hints) else 128
-        _lib.check(lib.nrh_color_train_forward_grouped(pk["precision"], int(hints), P_(cw, cw.dtype), P_(pk["col_b"]), P_(pre["feat"]), P_(B.pts),
-                                                       P_(normal_in), P_(B.raymisc), per_row, n, P_(B.color), P_(B.save_h),
-                                                       P_(B.save_misc), stream), "nrh_color_train_forward")
+        # (the reflectance net's 16-bit hand-offs: every batch size - its kernels have one build)
+        half_c = pk["precision"] == 1 and getattr(renderer, "dw_half", True) and os.environ.get("NRH_DW_HALF", "1") != "0"
+        if half_c:
+            if B.save_h16 is None:
+                B.save_h16 = torch.empty(4, Pn, 256, dtype=torch.float16, device=dev)
+                B.czbar16 = torch.empty(4, Pn, 256, dtype=torch.float16, device=dev)
+            _lib.check(lib.nrh_color_train_forward_half(1, int(hints), P_(cw, cw.dtype), P_(pk["col_b"]), P_(pre["feat"]), P_(B.pts),
+                                                        P_(normal_in), P_(B.raymisc), per_row, n, P_(B.color), P_(B.save_h),
+                                                        P_(B.save_misc), P_(B.save_h16, torch.float16), stream), "nrh_color_train_forward_half")
+        else:
+            _lib.check(lib.nrh_color_train_forward_grouped(pk["precision"], int(hints), P_(cw, cw.dtype), P_(pk["col_b"]), P_(pre["feat"]), P_(B.pts),
+                                                           P_(normal_in), P_(B.raymisc), per_row, n, P_(B.color), P_(B.save_h),
+                                                           P_(B.save_misc), stream), "nrh_color_train_forward")
         # ---- composite, loss, adjoint seeds ----
         bg = f32(background_rgb.to(dev)).reshape(-1) if background_rgb is not None else None
         gt = f32(rgb_gt)
@@ -206,8 +229,13 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         _lib.check(lib.nrh_loss_finish(P_(B.partial), n, float(inv_s), P_(dyn), igr, P_(B.loss8), stream), "nrh_loss_finish")
         # ---- reflectance adjoint sweep ----
         cwt = pk["col_wt"]
-        _lib.check(lib.nrh_color_train_backward(pk["precision"], int(hints), P_(cwt, cwt.dtype), P_(B.zbar4), P_(B.save_h), n, P_(B.czbar),
-                                                P_(B.fbar), P_(B.mbar), _lib.adjoint_scale(n), stream), "nrh_color_train_backward")
+        if half_c:
+            _lib.check(lib.nrh_color_train_backward_half(1, int(hints), P_(cwt, cwt.dtype), P_(B.zbar4), P_(B.save_h), n, P_(B.czbar), P_(B.fbar),
+                                                         P_(B.mbar), _lib.adjoint_scale(n), P_(B.save_h16, torch.float16),
+                                                         P_(B.czbar16, torch.float16), COLOR_HALF_GAIN, stream), "nrh_color_train_backward_half")
+        else:
+            _lib.check(lib.nrh_color_train_backward(pk["precision"], int(hints), P_(cwt, cwt.dtype), P_(B.zbar4), P_(B.save_h), n, P_(B.czbar),
+                                                    P_(B.fbar), P_(B.mbar), _lib.adjoint_scale(n), stream), "nrh_color_train_backward")
         # ---- alpha stage adjoint (+ the eikonal seed; the unit normal's adjoint are columns 3..5 of mbar) ----
         mw = B.mbar.shape[1]
         # NormalizedAnalytic: the unit normal's adjoint goes through the normalisation inside the kernel; Analytic: the reflectance
@@ -223,7 +251,7 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             _lib.check(lib.nrh_variance_grad(P_(B.invs_bar), n, float(inv_s), P_(dyn), P_(B.var_bar), stream), "nrh_variance_grad")
         # ---- SDF network: tangent + value sweeps ----
         r = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], o, d, res["mid_z"], 128, sv, B.sdf_bar, B.fbar, B.grad_bar,
-                                   adj_scale=_lib.adjoint_scale(n))
+                                   adj_scale=_lib.adjoint_scale(n), half_handoffs=half, dyn=B.dyn)
         # ---- ray adjoints (pose / light refinement): one per-ray reduction of what the sweeps left ----
         if want_rays:
             _lib.check(lib.nrh_ray_adjoint(P_(o), P_(d), P_(pl), P_(res["mid_z"]), P_(r["pbar"]), P_(B.grad_bar), P_(sv["ge"]), P_(B.mbar), mw,
@@ -235,8 +263,10 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         _lib.check(lib.nrh_embedding_rows(P_(o), P_(d), P_(res["mid_z"]), 128, 128, n, P_(B.emb), stream), "nrh_embedding_rows")
         # ---- every weight gradient: one split-K launch + its reduction ----
         shapes = [tuple(dense[f"sdf_w{l}"].shape) for l in range(8)]
-        jobs = dw.sdf_jobs(shapes, sv["h"], sv["t"], r["zbar"], r["abar"], r["gebar"], B.emb, B.sdf_bar, B.fbar, B.g) + \
-            dw.color_jobs(hints, B.czbar, B.zbar4, B.save_h, pre["feat"], B.save_misc, B.g)
+        h16 = dict(h16=sv["h16"], t16=sv["t16"], zbar16=r["zbar16"], abar16=r["abar16"], dyn=B.dyn) if half else None
+        jobs = dw.sdf_jobs(shapes, sv["h"], sv["t"], r["zbar"], r["abar"], r["gebar"], B.emb, B.sdf_bar, B.fbar, B.g, half=h16) + \
+            dw.color_jobs(hints, B.czbar, B.zbar4, B.save_h, pre["feat"], B.save_misc, B.g,
+                          half=dict(zbar16=B.czbar16, h16=B.save_h16, inv_scale=1.0 / (_lib.adjoint_scale(n) * COLOR_HALF_GAIN)) if half_c else None)
         dw.run(jobs, Pn)
         # ---- weight-norm adjoint -> .grad ----
         g = B.g

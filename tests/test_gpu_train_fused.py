@@ -106,6 +106,50 @@ def test_dw_gemm_vs_float64(P, tiled):
         assert torch.equal(first[k], out[k]), k
 
 
+@pytest.mark.parametrize("P", [32, 96, 2048 + 32, 131072 + 32 * 7])
+def test_dw_gemm_half_operands(P):
+    """NrhDwJob.half_ops: the four operands of a full product as float16 arrays in the half-tiled layout (what the f16x3 sweeps hand
+    over in 16-bit mode), one fp16 MFMA pass, fragments by ds_read_b64_tr_b16 straight out of the LDS-DMA image.  Against float64
+    products of the SAME float16 data (the operand rounding is the caller's, priced in profiles/dw16_emulation.py): products of
+    fp16 values are exact in fp32, so what is left is fp32 accumulation - 2e-6 of sum |a b|.  With a dynamic scale {S, 1 / S}, a
+    row limit, in one launch with float32 jobs, and bit-identical when repeated."""
+    rs = np.random.RandomState(P % 977)
+    # adjoint-like operands pre-scaled into fp16's range (what nrh_adjoint_range arranges), activation-like ones as they are
+    A1 = cu(_wide_range(rs, P, 256, 1.0)).clamp_(-6e4, 6e4)
+    A2 = cu(rs.randn(P, 256).astype(np.float32) * 0.2)
+    B1 = cu(np.log1p(np.exp(rs.randn(P, 256).astype(np.float32) * 3)) * 0.1)
+    B2 = cu(_wide_range(rs, P, 256, 0.1)).clamp_(-6e4, 6e4)
+    F1, G1 = cu(rs.randn(P, 256).astype(np.float32)), cu(rs.randn(P, 256).astype(np.float32))
+    h = dw.to_half_tiled
+    A1h, A2h, B1h, B2h = h(A1), h(A2), h(B1), h(B2)
+    assert torch.equal(dw.from_half_tiled(A1h), A1.half())
+    new = lambda *s: torch.full(s, float("nan"), dtype=torch.float32, device="cuda")
+    out = dict(two=new(256, 256), btwo=new(256), one=new(217, 256), bone=new(217), f32=new(256, 256))
+    dyn = torch.tensor([64.0, 1.0 / 64.0], device="cuda")
+    jobs = [dw.Job([A1h, A2h], [B1h, B2h], 256, 256, out["two"], colsum_a=out["btwo"], half=True, dyn_scale=dyn),
+            dw.Job([F1], [G1], 256, 256, out["f32"]),
+            dw.Job([A2h], [B1h], 256, 256, out["one"], rows=217, scale=2.0 ** -0.5, colsum_a=out["bone"], half=True)]
+    dw.run(jobs, P)
+    torch.cuda.synchronize()
+    d = lambda t: t.double().cpu()
+    a1, a2, b1, b2 = (d(x.half()) for x in (A1, A2, B1, B2))
+
+    def check(got, ref, absref, what, rel=2e-6):
+        assert bool(torch.isfinite(d(got)).all()), what
+        err = (d(got) - ref).abs()
+        assert float((err / (absref + 1e-300)).max()) < rel, (what, float((err / (absref + 1e-300)).max()))
+
+    check(out["two"], (a1.t() @ b1 + a2.t() @ b2) / 64, (a1.abs().t() @ b1.abs() + a2.abs().t() @ b2.abs()) / 64, "two pairs, dynamic scale")
+    check(out["btwo"], a1.sum(0) / 64, a1.abs().sum(0) / 64, "column sums of A_0")
+    check(out["one"], (a2.t() @ b1)[:217] * 2.0 ** -0.5, (a2.abs().t() @ b1.abs())[:217], "one pair, 217 rows")
+    check(out["bone"], a2.sum(0)[:217], a2.abs().sum(0)[:217], "column sums, row limit")
+    check(out["f32"], d(F1).t() @ d(G1), d(F1).abs().t() @ d(G1).abs(), "float32 job of the same launch", rel=3e-5)
+    first = {k: v.clone() for k, v in out.items()}
+    dw.run(jobs, P)
+    for k in out:
+        assert torch.equal(first[k], out[k]), k
+
+
 def test_embedding_rows_vs_oracle():
     lib = _lib.load()
     n, npr = 37, 128
@@ -295,10 +339,14 @@ def test_fused_register_view_step_equals_autograd(scene_states):
     assert all(p.grad is None for p in model.parameters())
 
 
-def test_fused_step_equals_autograd_path(scene_states):
+@pytest.mark.parametrize("half", [False, True])
+def test_fused_step_equals_autograd_path(scene_states, half):
     """Same batch, same jitter through the autograd Functions (forward + train_loss_dict + backward) and through the fused
     sequence: same kernels for the sweeps and the weight gradients, so the results agree to fp32 round-off of the few
-    elementwise expressions that moved from torch into the composite / loss kernels."""
+    elementwise expressions that moved from torch into the composite / loss kernels.  ``half``: the fused step with its default
+    16-bit hand-offs of the SDF net's weight-gradient operands (renderer.dw_half; the autograd path keeps float32 arrays and the
+    bf16x3 products): the operands' 11-bit rounding shows as up to 1.5e-4 of a tensor's scale - the price measured against the
+    reference in tests/test_gpu_train1024.py and profiles/r05/dw16_emulation.log."""
     from nrhints_amd.training import train_loss_dict
     n = 256
     rs = np.random.RandomState(3)
@@ -306,6 +354,7 @@ def test_fused_step_equals_autograd_path(scene_states):
     gt, tp, ts = (cu(rs.rand(n, k).astype(np.float32)) for k in (3, 1, 64))
     bg = torch.ones(1, 3).cuda()
     a, b = _model(scene_states["b"]), _model(scene_states["b"])
+    b.dw_half = half
     out = a(rb, is_training=True, background_rgb=bg, global_step=30000, _t_rand_primary=tp, _t_rand_shadow=ts)
     la = train_loss_dict(out, gt, a.config.igr_weight)
     la["loss"].backward()
@@ -319,7 +368,7 @@ def test_fused_step_equals_autograd_path(scene_states):
         # samples that cancel to ~1e-3, so the fp32 round-off of the summands (5e-7 absolute between the two paths) is not small
         # against the RESULT although it is against every term
         err = float((pa.grad - pb.grad).abs().max())
-        assert err < 1e-4 * scale + 1e-6, (name, err, scale)
+        assert err < (5e-4 if half else 1e-4) * scale + 1e-6, (name, err, scale)
 
 
 def test_fused_training_descends_and_graph_replays(scene_states):
