@@ -632,7 +632,7 @@ static int sdf_train_backward_impl(int precision, const float* sdf_w, const floa
     nrh::AdjRangeArgs ra;
     ra.sbar = sbar; ra.gbar = gbar; ra.fbar = fbar; ra.dyn = dyn; ra.npts = a.npts;
     const long long want = (a.npts * 64 / 8 + 255) / 256;
-    hipLaunchKernelGGL(nrh::adjoint_range_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want))), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL(nrh::adjoint_range_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want))), dim3(256), 0, st, ra);
     rc = check_launch("adjoint_range_kernel");
     if (rc) return rc;
     a.abar16 = abar16; a.zbar16 = zbar16; a.dyn = dyn;

@@ -784,8 +784,17 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const ReduceArgs a) {
   const int i = e >> 8, j = e & 255;
   const float dyn = J.dyn ? J.dyn[1] : 1.0f;
   if (J.out && i < J.rows && j < J.cols) {
+    // fixed summation order; the loads of eight slabs go out together (the adds alone serialised them: 96 us for 67 MB)
     float s = 0.0f;
-    for (int k = 0; k < J.slabs; ++k) s += a.partial[(size_t)(J.slab0 + k) * SLOT_FLOATS + e];
+    int k = 0;
+    for (; k + 8 <= J.slabs; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(a.partial + (size_t)(J.slab0 + k + u) * SLOT_FLOATS + e);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < J.slabs; ++k) s += a.partial[(size_t)(J.slab0 + k) * SLOT_FLOATS + e];
     const int jj = J.col_map ? J.col_map[j] : j;
     J.out[J.transpose ? (size_t)jj * J.ldo + i : (size_t)i * J.ldo + jj] = s * J.scale * dyn;
   }

@@ -117,9 +117,11 @@ def sdf_at_points(mode: int, sdf_w, sdf_b, sdf_head, pts):
 
 
 @_lib.on_tensor_device
-def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
+def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts, half_handoffs: bool = False):
     """Training forward at free points [P,3] (P % 16 == 0): -> (sdf [P,1], feat [P,256] row-major, grad [P,3], saves)
-    where ``saves`` holds what ``sdf_train_backward`` and the weight-gradient GEMMs need (include/nrhints_hip.h)."""
+    where ``saves`` holds what ``sdf_train_backward`` and the weight-gradient GEMMs need (include/nrhints_hip.h).
+    ``half_handoffs`` (f16x3, nrh_train_half_supported): saves also has ``h16`` (layers 0..6; saves["h"] then only holds layer 7) and
+    ``t16`` (layers 1..7), float16 [8,P,256] in the half-tiled layout (nrh_sdf_train_forward_half)."""
     lib = _lib.load()
     n = pts.shape[0]
     dev = pts.device
@@ -133,6 +135,14 @@ def sdf_train_forward(sdf_w, sdf_b, sdf_head, pts):
                  ge=torch.empty(n, 128, **f32), zeros3=zeros3, zeros1=zeros1)
     P = _lib.ptr
     wp, prec = _wptr(sdf_w)
+    if half_handoffs:
+        saves["h16"] = torch.empty(8, n, 256, dtype=torch.float16, device=dev)
+        saves["t16"] = torch.empty(8, n, 256, dtype=torch.float16, device=dev)
+        rc = lib.nrh_sdf_train_forward_half(prec, wp, P(sdf_b), P(sdf_head), P(pts), P(zeros3), P(zeros1), 1, 1, n, P(sdf), P(grad),
+                                            P(feat), P(saves["h"]), P(saves["s1"]), P(saves["t"]), P(saves["ge"]),
+                                            P(saves["h16"], torch.float16), P(saves["t16"], torch.float16), _lib.stream_handle())
+        _lib.check(rc, "nrh_sdf_train_forward_half")
+        return sdf, feat, grad, saves
     rc = lib.nrh_sdf_train_forward(prec, wp, P(sdf_b), P(sdf_head), P(pts), P(zeros3), P(zeros1), 1, 1, n, P(sdf), P(grad),
                                    P(feat), P(saves["h"]), P(saves["s1"]), P(saves["t"]), P(saves["ge"]), _lib.stream_handle())
     _lib.check(rc, "nrh_sdf_train_forward")
