@@ -503,7 +503,15 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
 long long nrh_sdf_wide_stream_bytes(void) { return nrh32::wide_sdf_stream_bytes_total(); }
 
 // 16-bit hand-offs (NrhTrainSaves.save_h16 / save_t16, nrh_sdf_train_backward_half): the 8-wave f16x3 kernels only
-static int t16_only_mode() {      // experiment switch: layers 1..6 of t exist as fp16 only (the tangent sweep reads save_t16)
+// Two further 16-bit candidates, built, measured and left OFF (profiles/r05/train_coup16_ab.log, train_t16only_ab.log): coup - the
+// sweeps' private hand-off - as fp16 (NRH_COUP16=1: -1.07 GB per 1 024-ray step, +0.6 %) and layers 1..6 of t as fp16 only
+// (NRH_T16_ONLY=1: -0.9 GB, +0.9 %).  Both pass the 1 024-ray parity tests, but unlike h / abar / zbar these arrays feed the adjoint
+// CHAIN (11-bit roundings inside it, not at its outputs), and the sweeps are no longer bound by their bytes.
+static int coup16_mode() {
+  static const int on = (getenv("NRH_COUP16") && atoi(getenv("NRH_COUP16")) != 0) ? 1 : 0;
+  return on;
+}
+static int t16_only_mode() {
   static const int on = (getenv("NRH_T16_ONLY") && atoi(getenv("NRH_T16_ONLY")) != 0) ? 1 : 0;
   return on;
 }
@@ -637,6 +645,7 @@ static int sdf_train_backward_impl(int precision, const float* sdf_w, const floa
     if (rc) return rc;
     a.abar16 = abar16; a.zbar16 = zbar16; a.dyn = dyn;
     a.t16 = (t16_only_mode() && save_t16) ? save_t16 : nullptr;
+    a.coup16 = coup16_mode();
   }
   if (split_train(precision, a.npts)) {
     const dim3 gs((unsigned)(a.npts / 16)), bs(256);

@@ -649,24 +649,39 @@ __device__ __forceinline__ void dw_item_half(const JobDev& J, const int slab, co
       issue();                            // stage idx + 4 -> the buffer stage idx - 1 was read from
       const char* st = smem + cstage * H16_STAGE + lb;
       const bool sum_now = want_sum && idx < nst;
+      // The stage's two tiles of 16 points = 16 B fragments, each feeding two MFMAs.  Fragment reads run TWO fragments (128 MFMA
+      // cycles ~ one LDS round trip) ahead of the MFMAs that consume them - a SIMD has one wave, an LDS wait that is not under
+      // MFMAs is lost time - and the A fragments of the second tile are fetched under the first tile's last MFMAs.  hipcc sinks
+      // loads to their uses; sched_group_barrier pins the order read, read, MFMA, MFMA per fragment.
+      f16x8 af[2], an[2], b0 = tr_frag(st + 16384), b1 = tr_frag(st + 16384 + 1024);
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {    // the stage's two tiles of 16 points
-        f16x8 af[2];
+      for (int mf = 0; mf < 2; ++mf) an[mf] = af[mf] = tr_frag(st + (2 * wave + mf) * 1024);
+      if (sum_now) {
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) af[mf] = tr_frag(st + (ss * 8 + 2 * wave + mf) * 1024);
-        if (sum_now) {
+        for (int ss = 0; ss < 2; ++ss) {
+          // (the second tile's A fragments are read once more for the column sums: two more of 42 reads, off the MFMA path)
+          const f16x8 a0 = ss ? tr_frag(st + (8 + 2 * wave) * 1024) : af[0], a1 = ss ? tr_frag(st + (8 + 2 * wave + 1) * 1024) : af[1];
 #pragma unroll
-          for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              sum[mf] = __builtin_amdgcn_fdot2(f16x2{af[mf][2 * i], af[mf][2 * i + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, sum[mf], false);
+          for (int i = 0; i < 4; ++i) {
+            sum[0] = __builtin_amdgcn_fdot2(f16x2{a0[2 * i], a0[2 * i + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, sum[0], false);
+            sum[1] = __builtin_amdgcn_fdot2(f16x2{a1[2 * i], a1[2 * i + 1]}, f16x2{(_Float16)1.0f, (_Float16)1.0f}, sum[1], false);
+          }
         }
+      }
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-          const f16x8 bf = tr_frag(st + 16384 + (ss * 8 + nf) * 1024);
+      for (int f = 0; f < 16; ++f) {           // fragment f = tile f >> 3, column block f & 7
+        f16x8 b2 = b1;
+        if (f + 2 < 16) b2 = tr_frag(st + 16384 + (f + 2) * 1024);
+        if (f == 5) an[0] = tr_frag(st + (8 + 2 * wave) * 1024);
+        if (f == 6) an[1] = tr_frag(st + (8 + 2 * wave + 1) * 1024);
+        if (f == 8) { af[0] = an[0]; af[1] = an[1]; }
 #pragma unroll
-          for (int mf = 0; mf < 2; ++mf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mf], bf, acc[mf][nf], 0, 0, 0);
-        }
+        for (int mf = 0; mf < 2; ++mf) acc[mf][f & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mf], b0, acc[mf][f & 7], 0, 0, 0);
+        b0 = b1;
+        b1 = b2;
+        if (f == 5 || f == 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        else if (f + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       }
       cstage = (cstage == H16_STAGES - 1) ? 0 : cstage + 1;
     }

@@ -45,6 +45,7 @@ struct SdfTrainArgs {
   int ntile_groups;
   void* abar16;          // optional (f16x3): fp16 half-tiled [8][npts][256]; layers 0..6 of abar go HERE, as S x the value, INSTEAD of abar
   void* zbar16;          // optional (f16x3): the same for layers 1..7 of zbar
+  int coup16;            // with abar16: coup - private to the two sweeps - is fp16 half-tiled as well (S x the value, in the same buffer)
   const void* t16;       // optional (f16x3): layers 1..6 of t are read from this fp16 half-tiled array instead of tt (SdfArgs.t16_only)
   const float* dyn;      // optional (f16x3) device {S, 1 / S}: the step's adjoint scale from the seeds' range (adjoint_range_kernel)
   float adj_scale;       // f16x3 only: a power of two S.  The adjoint chain runs on S * (the seeds) and its outputs leave as 1 / S *
@@ -165,8 +166,12 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_tangent_kernel(const SdfTr
           }
         }
         if (tile_ok) {
-          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch, q)), c0 * IS);
-          st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch + 1, q)), c1 * IS);
+          if (PREC == 1 && a.coup16) {
+            st_stream(half_ptr<true>(a.coup, s, a.npts, row, ch, q), pack_half8(c0, c1));
+          } else {
+            st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch, q)), c0 * IS);
+            st_stream(reinterpret_cast<f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, s, a.npts, row, 2 * ch + 1, q)), c1 * IS);
+          }
           if (PREC == 1 && a.abar16 && s < 7) {
             st_stream(half_ptr<true>(a.abar16, s, a.npts, row, ch, q), pack_half8(n0, n1));
           } else {
@@ -232,8 +237,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void sdf_adjoint_kernel(const SdfTr
         TrainPre p;
         p.s0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, lz, a.npts, row, 2 * ch, q)));
         p.s1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_S1, PREC == 1>(a.s1, lz, a.npts, row, 2 * ch + 1, q)));
-        p.t0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, lz, a.npts, row, 2 * ch, q)));
-        p.t1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
+        if (PREC == 1 && a.coup16) {
+          // (stored as S x the value: IS here cancels the S of the epilogue - exact, powers of two)
+          const f16x8_t cv = ld_stream(half_ptr<true>(a.coup, lz, a.npts, row, ch, q));
+          p.t0 = f32x4{(float)cv[0], (float)cv[1], (float)cv[2], (float)cv[3]} * IS;
+          p.t1 = f32x4{(float)cv[4], (float)cv[5], (float)cv[6], (float)cv[7]} * IS;
+        } else {
+          p.t0 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, lz, a.npts, row, 2 * ch, q)));
+          p.t1 = ld_stream(reinterpret_cast<const f32x4*>(arr_ptr<ARR_COUP, PREC == 1>(a.coup, lz, a.npts, row, 2 * ch + 1, q)));
+        }
         if (s == 8) {
           p.w0 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch) * 16 + 4 * q);
           p.w1 = *reinterpret_cast<const f32x4*>(a.head + (2 * ch + 1) * 16 + 4 * q);
