@@ -134,7 +134,8 @@ int nrh_sdf_train_backward(int precision, const float* sdf_w, const float* wt_fe
                            const float* save_s1, const float* save_t, const float* gbar, const float* fbar,
                            const float* sbar, float* abar, float* coup, float* gebar, float* zbar, float* pbar,
                            float adj_scale, void* stream);
-/* 16-BIT HAND-OFFS of the weight-gradient operands (precision f16x3, batches the 8-wave kernels run: nrh_train_half_supported).
+/* 16-BIT HAND-OFFS of the weight-gradient operands (precision f16x3, batches above the channel-split kernels' range - more than 32
+ * points per CU: nrh_train_half_supported).
  * h, abar and zbar are read by nothing but nrh_dw_gemm, which spends most of its time fetching them; these variants write them as
  * fp16 in the HALF-TILED layout (per tile of 16 points: [block pair 8][point 16][quarter 4][block of the pair 2][4 channels], 8 KiB;
  * arrays [8][npts][256] fp16, 16-byte aligned), which NrhDwJob.half_ops consumes with one fp16 MFMA pass and no conversion:

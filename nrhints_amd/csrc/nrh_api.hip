@@ -502,7 +502,7 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
 
 long long nrh_sdf_wide_stream_bytes(void) { return nrh32::wide_sdf_stream_bytes_total(); }
 
-// 16-bit hand-offs (NrhTrainSaves.save_h16 / save_t16, nrh_sdf_train_backward_half): the 8-wave f16x3 kernels only
+// 16-bit hand-offs (NrhTrainSaves.save_h16 / save_t16, nrh_sdf_train_backward_half): the 8- and 4-wave f16x3 kernels
 // Two further 16-bit candidates, built, measured and left OFF (profiles/r05/train_coup16_ab.log, train_t16only_ab.log): coup - the
 // sweeps' private hand-off - as fp16 (NRH_COUP16=1: -1.07 GB per 1 024-ray step, +0.6 %) and layers 1..6 of t as fp16 only
 // (NRH_T16_ONLY=1: -0.9 GB, +0.9 %).  Both pass the 1 024-ray parity tests, but unlike h / abar / zbar these arrays feed the adjoint
@@ -516,7 +516,8 @@ static int t16_only_mode() {
   return on;
 }
 int nrh_train_half_supported(int precision, long long npts) {
-  return (precision == 1 && npts > 0 && npts % 32 == 0 && !split_train(precision, npts) && !small_batch(npts)) ? 1 : 0;
+  // (the 4-wave builds of csrc/nrh_small.hip are the same source as the 8-wave kernels; the channel-split kernels are not)
+  return (precision == 1 && npts > 0 && npts % 32 == 0 && !split_train(precision, npts)) ? 1 : 0;
 }
 
 static int sdf_train_forward_impl(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
@@ -558,7 +559,7 @@ static int sdf_train_forward_impl(int precision, const float* sdf_w, const float
   a.n_per_ray = n_per_ray; a.t_stride = t_stride; a.sdf_stride = n_per_ray;
   if (save_h16 || save_t16) {
     if (!save_h16 || !save_t16 || !nrh_train_half_supported(precision, a.npts) || (((uintptr_t)save_h16 | (uintptr_t)save_t16) & 15))
-      return fail(NRH_E_INVALID, "nrh_sdf_train_forward: 16-bit hand-offs need precision f16x3, a batch the 8-wave kernels run "
+      return fail(NRH_E_INVALID, "nrh_sdf_train_forward: 16-bit hand-offs need precision f16x3, a batch above the channel-split kernels' range "
                   "(nrh_train_half_supported) and 16-byte aligned arrays%s", "");
     a.save_h16 = save_h16; a.save_t16 = save_t16;
     a.t16_only = t16_only_mode();
@@ -635,7 +636,7 @@ static int sdf_train_backward_impl(int precision, const float* sdf_w, const floa
   if (abar16) {
     // 16-bit hand-offs: the adjoint scale follows the seeds (adjoint_range_kernel), abar / zbar leave as fp16 x S
     if (!nrh_train_half_supported(precision, a.npts) || (((uintptr_t)abar16 | (uintptr_t)zbar16 | (uintptr_t)dyn) & 15))
-      return fail(NRH_E_INVALID, "nrh_sdf_train_backward_half: needs precision f16x3, a batch the 8-wave kernels run "
+      return fail(NRH_E_INVALID, "nrh_sdf_train_backward_half: needs precision f16x3, a batch above the channel-split kernels' range "
                   "(nrh_train_half_supported) and 16-byte aligned arrays%s", "");
     nrh::AdjRangeArgs ra;
     ra.sbar = sbar; ra.gbar = gbar; ra.fbar = fbar; ra.dyn = dyn; ra.npts = a.npts;

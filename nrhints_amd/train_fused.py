@@ -206,8 +206,11 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         normal_in = (res["normals"] if analytic else res["nhat"]).view(Pn, 3)
         # rows of per-ray inputs: one per ray, or - partial visibility hint outside the geometry warm-up - one per group of samples
         per_row = 128 // clip if (clip > 1 and not zero_hints) else 128
-        # (the reflectance net's 16-bit hand-offs: every batch size - its kernels have one build)
-        half_c = pk["precision"] == 1 and getattr(renderer, "dw_half", True) and os.environ.get("NRH_DW_HALF", "1") != "0"
+        # the reflectance net's 16-bit hand-offs: with the SDF net's (its kernels have one build and would take them at any size, but
+        # at 64 rays - where the SDF net runs on the channel-split kernels - the step was 7 % SLOWER with them: 1.04 against 0.97 ms,
+        # profiles/r05/train_half_small_ab.log; the weight-gradient launch is latency-bound there and the half path's deeper pipeline
+        # has the longer prologue)
+        half_c = half
         if half_c:
             if B.save_h16 is None:
                 B.save_h16 = torch.empty(4, Pn, 256, dtype=torch.float16, device=dev)

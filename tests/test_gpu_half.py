@@ -15,11 +15,12 @@ from nrhints_amd import _lib, dw, ops
 pytestmark = pytest.mark.gpu
 COUP16 = os.environ.get("NRH_COUP16", "0") != "0"      # experiment switch of the library (csrc/nrh_api.hip coup16_mode): off by default
 T = torch.from_numpy
-NPTS = 32768          # above the 4-wave builds' range on 256 CUs (16 384 points): the 8-wave kernels
+NPTS = 32768          # the 8-wave kernels; 16 384 points = the 4-wave builds of the same source (csrc/nrh_small.hip) on 256 CUs
 
 
-@pytest.fixture(scope="module")
-def net(scene_states):
+@pytest.fixture(scope="module", params=[NPTS, 16384])
+def net(scene_states, request):
+    NPTS = request.param
     model = na.NeuSHintRenderer(na.NeuSModelConfig(), precision="f16x3")
     model.load_state_dict({k: T(np.asarray(v)) for k, v in scene_states["b"].items()})
     pk = model.cuda().eval().packed_params(torch.device("cuda", torch.cuda.current_device()))
@@ -42,7 +43,8 @@ def test_half_supported_predicate():
     lib = _lib.load()
     assert lib.nrh_train_half_supported(1, NPTS) == 1 and lib.nrh_train_half_supported(1, 131072) == 1
     assert lib.nrh_train_half_supported(0, NPTS) == 0          # exact-fp32 mode keeps float32 hand-offs
-    assert lib.nrh_train_half_supported(1, 8192) == 0          # channel-split / 4-wave builds: not there
+    assert lib.nrh_train_half_supported(1, 16384) == 1         # the 4-wave builds (csrc/nrh_small.hip): the same source
+    assert lib.nrh_train_half_supported(1, 8192) == 0          # the channel-split kernels: not there
     assert lib.nrh_train_half_supported(1, NPTS + 16) == 0     # 32-point stages
 
 
@@ -64,6 +66,7 @@ def test_backward_half_arrays_scale_and_invariance(net):
     writes exactly those values into the float32 arrays; seeds 2^-9 times smaller give the same fp16 bits and S 2^9 times larger;
     zero seeds give S = 1 and zeros."""
     pk, pts, sbar, fbar, gbar = net
+    NPTS = pts.shape[0]
     _, _, _, sv = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts, half_handoffs=True)
     dyn = torch.zeros(4, device="cuda")
     r = _backward(pk, pts, sv, sbar, fbar, gbar, half_handoffs=True, dyn=dyn)
@@ -99,7 +102,7 @@ def test_backward_half_arrays_scale_and_invariance(net):
     k = 2.0 ** -9
     r2 = _backward(pk, pts, sv, sbar * k, fbar * k, gbar * k, half_handoffs=True, dyn=dyn)
     assert float(dyn[0]) == S / k
-    assert torch.equal(r2["abar16"], r["abar16"]) and torch.equal(r2["zbar16"], r["zbar16"])
+    assert torch.equal(r2["abar16"][:7], r["abar16"][:7]) and torch.equal(r2["zbar16"][1:], r["zbar16"][1:])      # (the written layers)
     for key, x2, x1 in (("pbar", r2["pbar"], r["pbar"]), ("zbar0", r2["zbar"][0], r["zbar"][0]), ("gebar", r2["gebar"], r["gebar"])):
         bad = (x2 != x1 * k) & ((x1 * k).abs() > 1e-36)          # (float32 subnormals round differently under the second scaling)
         assert not bool(bad.any()), (key, int(bad.sum()), x2[bad][:4].tolist(), (x1 * k)[bad][:4].tolist())
@@ -110,9 +113,10 @@ def test_backward_half_arrays_scale_and_invariance(net):
 def test_weight_gradients_from_half_handoffs(net):
     """nrh_dw_gemm on the SDF net's job table with the 16-bit hand-offs against the same table on the float32 arrays (bf16 x 3
     products): the difference is the operands' rounding to 11 bits - random, so ~2^-12 of sqrt(sum (a b)^2) per entry; asserted:
-    5e-4 of the tensor's scale (seeds this heavy-tailed leave few effective terms per entry: 2.8e-4 measured; the 1 024-ray step
-    shows 1.5e-4)."""
+    1e-3 of the tensor's scale (seeds this heavy-tailed leave few effective terms per entry: 2.8e-4 measured at 32 768 points, 5.2e-4
+    at 16 384; the 1 024-ray step shows 1.5e-4)."""
     pk, pts, sbar, fbar, gbar = net
+    NPTS = pts.shape[0]
     _, _, _, sv = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts, half_handoffs=True)
     _, _, _, sv32 = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts)
     dyn = torch.zeros(4, device="cuda")
@@ -145,8 +149,8 @@ def test_weight_gradients_from_half_handoffs(net):
             continue
         # (relative to the TENSOR's scale: entries of channels whose adjoints sit below fp16's absolute floor - 2^-24 / S - come
         # out as zero; they are < 1e-6 of the scale)
-        assert float(err.max()) < 5e-4 * scale, (l, float(err.max()), scale)
+        assert float(err.max()) < 1e-3 * scale, (l, float(err.max()), scale)
         dberr = float((a[f"db{l}"] - b[f"db{l}"]).abs().max())
-        assert dberr < 5e-4 * float(b[f"db{l}"].abs().max()) + 1e-30, (l, dberr)
+        assert dberr < 1e-3 * float(b[f"db{l}"].abs().max()) + 1e-30, (l, dberr)
     for k in ("ws", "bs", "Wf", "bf"):
         assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(b[k].abs().max()), k
