@@ -311,19 +311,24 @@ def camopt_legs(dev, batch=1024, steps=30, warm=3, view_steps=500, view_batch=51
     rg = RayGenerator(cam, ncam, RayGeneratorConfig(cam_opt_mode="SO3xR3")).to(dev)
     batches = [pixels(batch, rs) for _ in range(steps + warm)]
     step = GraphedTrainStep(student, batch, bg, warm_up_end=10, global_step=20000, ray_generator=rg, ray_lr=rg.config.opt_lr)
-    losses, t0 = [], None
-    for i, pb in enumerate(batches):
-        if i == warm:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        losses.append(step(pb, pb.rgb_gt, global_step=20000 + i)["loss"])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    losses, t0, block_s = [], None, []
+    for blk in range(3):                   # three consecutive blocks of `steps` steps, the median one is the value (train_leg: repeats)
+        for i, pb in enumerate(batches):
+            if blk and i < warm:
+                continue
+            if i == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            losses.append(step(pb, pb.rgb_gt, global_step=20000 + blk * len(batches) + i)["loss"])
+        torch.cuda.synchronize()
+        block_s.append(time.perf_counter() - t0)
+    dt = sorted(block_s)[1]
     fused = bool(step._use_fused)
     step.release()
     out["train_camopt"] = {"metric": "training ray-steps/s under nr-hints-cam-opt (ray generation with pose deltas + forward + backward + ray "
                                      "adjoints + Adam over both groups)", "value": round(batch * steps / dt, 1), "unit": "ray-steps/s",
-                           "batch_rays": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3), "views": ncam,
+                           "batch_rays": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
+                           "repeats_ms": [round(b / steps * 1e3, 3) for b in block_s], "views": ncam,
                            "mode": "hipGraph replay of the " + ("fused (autograd-free) step" if fused else "autograd path"),
                            "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
                            "pose_delta_moved": float(rg.cam_pose_adjustment.detach().abs().max())}
@@ -360,10 +365,14 @@ def camopt_legs(dev, batch=1024, steps=30, warm=3, view_steps=500, view_batch=51
     return out
 
 
-def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch=None):
+def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch=None, repeats=1):
     """BASELINE.json configs[2] (and [4] for N > 1): 1024-ray training steps of the reference-initialised student against
     pixels of scene b (rendered before the timed region: ground-truth pixels are data).  ``global_batch``: the reference's DDP
-    semantics - the batch is split, per-rank = global // world (trainer/trainer.py:116-123) - instead of a fixed per-rank batch."""
+    semantics - the batch is split, per-rank = global // world (trainer/trainer.py:116-123) - instead of a fixed per-rank batch.
+    ``repeats`` > 1 (the millisecond-scale small-batch legs, whose 40 steps are a 40 ms sample): that many consecutive blocks of
+    ``steps`` steps are timed, every block's ms per step is reported (``repeats_ms``) and the MEDIAN block is the value - inside the
+    full bench run one block of a leg was seen 25 % slow (1.22 against 0.97 ms at 64 rays, profiles/r05/bench_v4.json against
+    bench_legs_half_ab.log of the same tree) where the leg alone, or after the 1 024-ray leg only, was not."""
     from nrhints_amd.training import FlatGradAllReduce, GraphedTrainStep
     torch.manual_seed(0)
     if global_batch:
@@ -373,6 +382,7 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
     teacher = teacher.to(dev).eval()
     bg = torch.ones(1, 3, device=dev)
     batches = []
+    nblocks = max(1, int(repeats)) if world == 1 else 1
     for s in range(steps + warm):
         o, d, pl, near, far = (torch.from_numpy(a).to(dev) for a in make_rays(batch, seed=1000 + 97 * rank + s, spread=0.08))
         rb = na.RayBundle(origins=o, directions=d, pl_positions=pl, nears=near, fars=far)
@@ -390,17 +400,22 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
     run = lambda i, rb, gt: graphed(rb, gt, global_step=20000 + i)
     losses = []
     t0 = None
-    for i, (rb, gt) in enumerate(batches):
-        if i == warm:
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        losses.append(run(i, rb, gt)["loss"])
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    block_s = []
+    for blk in range(nblocks):
+        for i, (rb, gt) in enumerate(batches):
+            if blk and i < warm:
+                continue                       # (later blocks replay the timed batches only)
+            if i == warm:
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            losses.append(run(blk * len(batches) + i, rb, gt)["loss"])
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        block_s.append(time.perf_counter() - t0)
+    dt = sorted(block_s)[len(block_s) // 2]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -415,8 +430,10 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
             "mode": "hipGraph replay" if world == 1 else ("one hipGraph incl. the flat RCCL all-reduce" if in_graph else
                                                             "two hipGraphs around one flat RCCL all-reduce per step"),
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
-            "bound_note": "the step's five big kernels (dW, SDF training forward, tangent / value sweeps, reflectance adjoint) are HBM-bound on "
-                          "the saved activations (profiles/r05/pmc_train_summary.txt, DESIGN 7b / 7c / 7g); the MFMA fraction below is the "
+            **({"repeats_ms": [round(b / steps * 1e3, 3) for b in block_s]} if nblocks > 1 else {}),
+            "bound_note": "the step's big kernels (SDF training forward, dW, tangent / value sweeps, reflectance adjoint) move the saved "
+                          "activations through HBM at 4-5.5 TB/s; since the 16-bit hand-offs (DESIGN 7i) the sweeps are no longer bound by "
+                          "their bytes (profiles/r05/pmc_train_summary.txt, DESIGN 7b / 7c / 7g / 7i); the MFMA fraction below is the "
                           "SURVEY 8d convention",
             "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
                          "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
@@ -557,9 +574,11 @@ def main():
         # the reference splits the global batch over the ranks (trainer/trainer.py:116-123: 512 / 8 = 64 rays per rank, 128 with
         # configs[2]'s 1 024): what ONE such per-rank step costs here, as the graph replay a rank runs
         try:
-            legs = {b: train_leg(dev, rank, 1, None, batch=b, steps=40) for b in (64, 128)}
-            train_small = {"metric": "graphed training step at the reference's per-rank DDP batch (one GPU, no exchange)", "unit": "ms per step",
+            legs = {b: train_leg(dev, rank, 1, None, batch=b, steps=40, repeats=3) for b in (64, 128)}
+            train_small = {"metric": "graphed training step at the reference's per-rank DDP batch (one GPU, no exchange); median of 3 blocks "
+                                     "of 40 steps", "unit": "ms per step",
                            "ms_per_step": {str(b): l["ms_per_step"] for b, l in legs.items()},
+                           "repeats_ms": {str(b): l["repeats_ms"] for b, l in legs.items()},
                            "ray_steps_per_s": {str(b): l["value"] for b, l in legs.items()}, "steps": 40, "dtype": legs[64]["dtype"]}
         except Exception as e:  # noqa: BLE001
             train_small = {"error": f"{type(e).__name__}: {e}"[:300]}

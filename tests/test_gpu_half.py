@@ -144,8 +144,8 @@ def test_weight_gradients_from_half_handoffs(net):
         err = (a[f"dW{l}"] - b[f"dW{l}"]).abs()
         if l == 0:
             # float32 hand-offs either way (another split of the points over the work items: fp32 summation order only)
-            assert float(err.max()) < (1e-4 if COUP16 else 2e-6) * scale
-            assert float((a["db0"] - b["db0"]).abs().max()) < (1e-4 if COUP16 else 2e-6) * float(b["db0"].abs().max())
+            assert float(err.max()) < (1e-4 if COUP16 else 1e-5) * scale
+            assert float((a["db0"] - b["db0"]).abs().max()) < (1e-4 if COUP16 else 1e-5) * float(b["db0"].abs().max())
             continue
         # (relative to the TENSOR's scale: entries of channels whose adjoints sit below fp16's absolute floor - 2^-24 / S - come
         # out as zero; they are < 1e-6 of the scale)
@@ -153,4 +153,4 @@ def test_weight_gradients_from_half_handoffs(net):
         dberr = float((a[f"db{l}"] - b[f"db{l}"]).abs().max())
         assert dberr < 1e-3 * float(b[f"db{l}"].abs().max()) + 1e-30, (l, dberr)
     for k in ("ws", "bs", "Wf", "bf"):
-        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * float(b[k].abs().max()), k
+        assert float((a[k] - b[k]).abs().max()) <= 1e-5 * float(b[k].abs().max()), k       # (summation order: another split of the points)
