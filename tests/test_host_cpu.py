@@ -226,6 +226,22 @@ def test_training_entry_points_validate_arguments_without_a_device():
     assert lib.nrh_color_train_forward(1, 1, None, None, None, None, None, None, 4, None, None, None, None) == -1 and "null" in err()
     assert lib.nrh_color_train_backward(1, 1, None, None, None, 4, None, None, None, 1.0, None) == -1 and "null" in err()
     assert lib.nrh_color_train_backward(1, 1, one, one, one, 4, one, one, one, 0.0, None) == -1 and "power of two" in err()
+    # the 16-bit hand-off forms: their extra arrays are mandatory, f16x3 only, the reflectance net's gain a power of two
+    assert lib.nrh_sdf_train_forward_half(1, one, one, one, one, one, one, 1, 1, 16, one, one, one, one, one, one, one, None, None, None) == -1
+    assert "null" in err()
+    assert lib.nrh_sdf_train_backward_half(1, one, one, one, one, one, one, 1, 1, 16, one, one, one, one, one, one, one, one, one, one,
+                                           None, None, None, None, None) == -1 and "null" in err()
+    assert lib.nrh_color_train_forward_half(0, 1, one, one, one, one, one, one, 128, 4, one, one, one, one, None) == -1 and "f16x3" in err()
+    assert lib.nrh_color_train_backward_half(1, 1, one, one, one, 4, one, one, one, 128.0, one, one, 3.0, None) == -1 and "power of two" in err()
+    assert lib.nrh_color_train_backward_half(1, 1, one, one, one, 0, one, one, one, 128.0, one, one, 1024.0, None) == 0
+    from nrhints_amd.dw import NrhDwJob
+    job = (NrhDwJob * 1)()
+    job[0].a[0], job[0].b[0], job[0].lda[0], job[0].ldb[0] = 16, 16, 256, 256
+    job[0].npairs, job[0].m, job[0].n, job[0].slabs, job[0].half_ops = 1, 100, 256, 1, 1
+    assert lib.nrh_dw_gemm(job, 1, 64, one, 1 << 20, None) == -1 and "half operands" in err()
+    job[0].m, job[0].lda[0] = 256, 256
+    job[0].colsum_b = 16
+    assert lib.nrh_dw_gemm(job, 1, 64, one, 1 << 20, None) == -1 and "half-operand job" in err()
     # bad precision / point count not a multiple of 16
     assert lib.nrh_sdf_train_forward(7, one, one, one, one, one, one, 1, 1, 16, one, one, one, one, one, one, one, None) == -1
     assert "precision" in err()
