@@ -334,6 +334,42 @@ def test_ray_generator_validates_view_indices():
     plain.validate_view_indices(torch.tensor([[99]]))       # nothing to index: as the reference, which never touches a table then
 
 
+def test_struct_bindings_match_the_header():
+    """NrhTrainSaves and NrhDwJob as ctypes (nrhints_amd/_lib.py, nrhints_amd/dw.py) carry the header's members in the header's order
+    (the 16-bit hand-offs appended fields to both in ABI 146)."""
+    import re
+    from nrhints_amd.dw import NrhDwJob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "nrhints_hip.h")).read()
+    for name, struct in (("NrhTrainSaves", _lib.NrhTrainSaves), ("NrhDwJob", NrhDwJob)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        members = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                members.append(re.search(r"(\w+)\s*(?:\[\d+\])?\s*$", part.strip()).group(1))
+        assert members == [n for n, _ in struct._fields_], (name, members)
+
+
+def test_half_tiled_layout_helpers():
+    """dw.to_half_tiled / from_half_tiled (what the GPU tests compare the kernels' fp16 hand-offs with): element (point p, channel c)
+    of a tile sits at [pair c >> 5][point][quarter (c >> 2) & 3][block (c >> 4) & 1][c & 3] - the order a lane's 16-byte store of a
+    chunk's two blocks produces (csrc/nrh_mlp.h half_ptr) and nrh_dw_gemm's transpose reads expect."""
+    from nrhints_amd import dw
+    x = torch.arange(2 * 48 * 256, dtype=torch.float32).reshape(2, 48, 256) % 2039.0      # exact in fp16
+    y = dw.to_half_tiled(x)
+    assert y.dtype == torch.float16 and y.shape == x.shape
+    assert torch.equal(dw.from_half_tiled(y), x.half())
+    flat = y.reshape(2, 3, 16 * 256)
+    for (l, p, c) in ((0, 0, 0), (1, 17, 3), (0, 47, 255), (1, 31, 100), (0, 5, 16), (1, 40, 47)):
+        t, j = divmod(p, 16)
+        off = (c >> 5) * 512 + j * 32 + ((c >> 2) & 3) * 8 + ((c >> 4) & 1) * 4 + (c & 3)
+        assert float(flat[l, t, off]) == float(x[l, p, c]), (l, p, c)
+
+
 def test_integration_md_matches_the_binding():
     """INTEGRATION.md §2 is the stub a maintainer copies: its NrhNet field list, the ABI revision, the argument count of its
     nrh_render_forward call and its symbol table must agree with nrhints_amd/_lib.py (which the other tests check against
