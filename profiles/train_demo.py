@@ -3,7 +3,11 @@
 from a teacher scene (synthetic scene b: perturbed geometry, sharper variance) with the reference's loss / Adam / schedule,
 and PSNR is tracked on a held-out 128x128 view.  Prints one JSON line per evaluation and a final summary line.
 
-    python profiles/train_demo.py [steps=1500] [batch=1024]
+    python profiles/train_demo.py [steps=1500] [batch=1024] [late_eval_every=0] [seed=0]
+
+late_eval_every > 0: from step steps - 500 on, the held-out view is also evaluated every that many steps, and the summary carries the
+MEAN of those PSNRs and of the last 200 training losses - single evaluations of this fit swing by 3-4 dB from one to the next (in
+every run of every round), which is too coarse to compare two arithmetic variants by.
 """
 import json, os, sys, time
 import numpy as np, torch
@@ -17,6 +21,9 @@ from nrhints_amd.training import make_optimizer, train_step
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    late = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0            # another stream of training rays and jitter (same scene, same view)
+    late_psnr, losses = [], []
     torch.manual_seed(0)
     student = na.NeuSHintRenderer().cuda()
     teacher = na.NeuSHintRenderer()
@@ -41,21 +48,29 @@ def main():
         return line["eval_psnr_db"]
 
     first = evaluate(0, 0.0)
+    torch.manual_seed(seed)
     t_train, last_loss = 0.0, None
     for step in range(steps):
-        rb = bundle(make_rays(batch, seed=5000 + step, spread=0.08))
+        rb = bundle(make_rays(batch, seed=5000 + step + 100000 * seed, spread=0.08))
         with torch.no_grad():
             gt = teacher(rb, background_rgb=bg).rgb           # "dataset" pixels
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = train_step(student, rb, gt, bg, global_step=60000 + step, optimizer=opt, scheduler=sched)
         torch.cuda.synchronize(); t_train += time.perf_counter() - t0
         last_loss = out["loss"]
+        losses.append(float(last_loss))
         if (step + 1) % 250 == 0:
             last = evaluate(step + 1, t_train)
+            if late and step + 1 > steps - 500:
+                late_psnr.append(last)
+        elif late and step + 1 > steps - 500 and (step + 1) % late == 0:
+            late_psnr.append(evaluate(step + 1, t_train))
     print(json.dumps({"summary": "student fitted to teacher pixels through the HIP training kernels", "steps": steps, "batch": batch,
                       "eval_psnr_first_db": first, "eval_psnr_last_db": last, "final_loss": round(last_loss, 5),
                       "ray_steps_per_s": round(steps * batch / t_train, 1), "precision": student.precision,
-                      "sdf_backward": "hip"}), flush=True)
+                      "sdf_backward": "hip", "seed": seed,
+                      **({"late_eval_psnr_mean_db": round(float(np.mean(late_psnr)), 2), "late_eval_psnr_min_max_db": [min(late_psnr), max(late_psnr)],
+                          "late_evals": len(late_psnr), "mean_loss_last_200": round(float(np.mean(losses[-200:])), 5)} if late_psnr else {})}), flush=True)
 
 
 if __name__ == "__main__":
