@@ -6,6 +6,9 @@ points) and at the three cos-anneal ratios SURVEY.md §8d lists for C3: global_s
 Runs ONLY in the build container (imports /root/reference); writes data, never reference source:
 
     python tests/golden/make_golden_train1024.py          ->  tests/golden/train1024_b.npz
+    NRH_GOLDEN_RAYS=128 NRH_GOLDEN_STEPS=0,25000,100000 NRH_GOLDEN_FULL_STEPS=25000 python tests/golden/make_golden_train1024.py
+                                                          ->  tests/golden/train128_b.npz
+        (the reference's per-rank batch under 8-way DDP with configs[2]'s 1 024 rays: here the 4-wave builds with the 16-bit hand-offs)
 
 Per step s in {0, 25000, 100000} (keys prefixed "s<step>."):
   t_rand_primary / t_rand_shadow   the two torch.rand draws of forward(is_training=True)  (:682, :394)
@@ -32,6 +35,13 @@ from make_golden import REF, _install_stubs  # noqa: E402
 
 STEPS = (0, 25000, 100000)
 N = 1024
+if os.environ.get("NRH_GOLDEN_RAYS"):          # e.g. NRH_GOLDEN_RAYS=128 NRH_GOLDEN_STEPS=25000 -> train128_b.npz (the 4-wave builds' batch class)
+    N = int(os.environ["NRH_GOLDEN_RAYS"])
+    STEPS = tuple(int(x) for x in os.environ.get("NRH_GOLDEN_STEPS", "0,25000,100000").split(","))
+OUT = "train1024_b.npz" if N == 1024 else f"train{N}_b.npz"
+# steps whose gradients / draws are stored in full; the others only leave their per-tensor noise and scale (one number each: what
+# the pooled yardstick of tests/test_gpu_train1024.py::_tol needs from them)
+FULL = tuple(int(x) for x in os.environ["NRH_GOLDEN_FULL_STEPS"].split(",")) if os.environ.get("NRH_GOLDEN_FULL_STEPS") else STEPS
 
 
 def main():
@@ -98,20 +108,24 @@ def main():
         r64, l64, g64 = step(m64, torch.float64, gs, lambda *a, **k: replay.pop(0))
         assert not replay
         p = f"s{gs}."
-        rec[p + "t_rand_primary"], rec[p + "t_rand_shadow"] = drawn[0].numpy(), drawn[1].numpy()
-        rec[p + "loss"], rec[p + "rgb_loss"], rec[p + "eikonal_loss"] = (x.numpy() for x in l32)
-        rec[p + "loss_f64"], rec[p + "rgb_loss_f64"], rec[p + "eikonal_loss_f64"] = (x.numpy() for x in l64)
-        rec[p + "rgb"] = r32.rgb.detach().numpy()
-        rec[p + "rgb_f64"] = r64.rgb.detach().numpy().astype(np.float32)
+        full = gs in FULL
+        if full:
+            rec[p + "t_rand_primary"], rec[p + "t_rand_shadow"] = drawn[0].numpy(), drawn[1].numpy()
+            rec[p + "loss"], rec[p + "rgb_loss"], rec[p + "eikonal_loss"] = (x.numpy() for x in l32)
+            rec[p + "loss_f64"], rec[p + "rgb_loss_f64"], rec[p + "eikonal_loss_f64"] = (x.numpy() for x in l64)
+            rec[p + "rgb"] = r32.rgb.detach().numpy()
+            rec[p + "rgb_f64"] = r64.rgb.detach().numpy().astype(np.float32)
         for k in g64:
-            rec[p + "grad64." + k] = g64[k].numpy().astype(np.float32)
+            if full:
+                rec[p + "grad64." + k] = g64[k].numpy().astype(np.float32)
+            rec[p + "gscale." + k] = np.float64(g64[k].abs().max().item())
             rec[p + "noise." + k] = np.float64((g32[k].double() - g64[k]).abs().max().item())
             rec[p + "noise2." + k] = np.float64((g32[k].double() - g64[k]).pow(2).sum().sqrt().item())
         worst = max((float(rec[p + "noise." + k]) / max(float(g64[k].abs().max()), 1e-30), k) for k in g64)
         print(f"step {gs}: loss {float(l32[0]):.6f} (f64 {float(l64[0]):.6f}) eik {float(l32[2]):.5f}; worst f32 noise / scale "
               f"{worst[0]:.2e} on {worst[1]}; {time.time() - t0:.0f} s", flush=True)
-    np.savez_compressed(os.path.join(HERE, "train1024_b.npz"), **rec)
-    print("wrote train1024_b.npz", os.path.getsize(os.path.join(HERE, "train1024_b.npz")) / 1e6, "MB")
+    np.savez_compressed(os.path.join(HERE, OUT), **rec)
+    print("wrote", OUT, os.path.getsize(os.path.join(HERE, OUT)) / 1e6, "MB")
 
 
 if __name__ == "__main__":
