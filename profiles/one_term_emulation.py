@@ -6,7 +6,8 @@ reduced-precision mode is PSNR(ours, reference) >= 50 dB (keeps |delta PSNR vs g
 Float64 oracle in the reference's call pattern (mode "as_written": autograd gradient, so d sdf / dx is the derivative of the QUANTISED
 network, as a one-term reverse chain would compute it), every SDF-network evaluation of the render quantised - both samplers, render_core,
 the shadow march - with the operand roundings where the wide kernels would apply them (scaled softplus domain u = 100 h / ln 2 for
-activations); the reflectance net stays exact (it is the benign one).  Scenes a (1/s ~ 20) and b (1/s ~ 1 100, trained-like) on
+activations); the reflectance net stays exact (it is the benign one) - and, last block (round 5, after the SDF kernels were
+built: what the NEXT step of the mode would cost), ALSO at one term: weights and layer inputs of the reflectance net at fp16.  Scenes a (1/s ~ 20) and b (1/s ~ 1 100, trained-like) on
 the reference's recorded rays (tests/golden/render_*.npz).
 
     python profiles/one_term_emulation.py  >  profiles/r05/one_term_emulation.log
@@ -40,6 +41,22 @@ def make_forward(q):
     return fwd
 
 
+def make_color(q):
+    def col(p, pts, normals, view, feat, pls, vis=None, cue=None):
+        parts = [pts, orc.nerf_encode(view, 4), normals, orc.nerf_encode(pls, 4), feat]
+        if vis is not None:
+            parts.append(orc.nerf_encode(vis, 4))
+        if cue is not None:
+            parts.append(orc.nerf_encode(cue, 4))
+        x = torch.cat(parts, dim=-1)
+        for l in range(5):
+            x = torch.nn.functional.linear(q(x), q(p.col_w[l]), p.col_b[l])
+            if l < 4:
+                x = torch.relu(x)
+        return torch.sigmoid(x)
+    return col
+
+
 def main():
     a = dict(np.load(os.path.join(ROOT, "tests", "golden", "scene_a_state.npz")))
     real = orc.sdf_forward
@@ -59,6 +76,17 @@ def main():
             print(f"scene {tag} (1/s = {float(orc.inv_s_of(p)):.0f}), {name}: rgb max {d.max():.2e} mean {d.mean():.2e}  PSNR(ours, reference) {ps:.1f} dB  "
                   f"depth max {np.abs(out['depth'].numpy() - g['depth_f64']).max():.2e}  visibility max {np.abs(out['visibilities'].numpy() - g['visibilities_f64']).max():.2e}"
                   f"  -> gate >= 50 dB: {'PASS' if ps >= 50.0 else 'FAIL'}")
+        # ... and with the reflectance net at one term as well
+        real_c = orc.color_forward
+        orc.sdf_forward, orc.color_forward = make_forward(f16), make_color(f16)
+        try:
+            out = orc.render_forward(p, *rays, background_rgb=torch.ones(1, 3, dtype=torch.float64), mode="as_written")
+        finally:
+            orc.sdf_forward, orc.color_forward = real, real_c
+        d = np.abs(out["rgb"].numpy() - ref)
+        ps = psnr(out["rgb"].numpy(), ref)
+        print(f"scene {tag}, fp16 one-term SDF net AND reflectance net: rgb max {d.max():.2e} mean {d.mean():.2e}  PSNR(ours, reference) {ps:.1f} dB"
+              f"  -> gate >= 50 dB: {'PASS' if ps >= 50.0 else 'FAIL'}", flush=True)
 
 
 if __name__ == "__main__":
