@@ -226,15 +226,21 @@ def cpu_baseline(state, rays_np, n_sample, gpu_rgb, budget_s=150.0):
             "max_abs_rgb_diff": float(np.abs(gpu_rgb[idx] - ref).max())}
 
 
-def timed_render(model, rb, bg, steps, warmup, dist, dev, sharded):
-    """W untimed + K timed render steps bracketed by barrier + synchronize; -> (seconds, last output, kernel ms, launches)."""
+def timed_render(model, rb, bg, steps, warmup, dist, dev, sharded, n_total=None):
+    """W untimed + K timed render steps bracketed by barrier + synchronize; -> (seconds, last output, kernel ms, launches, host
+    seconds of THIS rank inside the timed steps: wall time its Python spent enqueueing, nothing in a step synchronises the device).
+    ``sharded``: ``rb`` is this rank's SLAB of a frame of ``n_total`` rays (parallel.render_slab: one all_gather_into_tensor)."""
     from nrhints_amd import parallel
+    stats = {}
 
     def step():
         with torch.no_grad():
             if sharded:
-                return parallel.render_sharded(lambda r: model(r, is_training=False, background_rgb=bg), rb, fields=("rgb",))
-            return model(rb, is_training=False, background_rgb=bg)
+                return parallel.render_slab(lambda r: model(r, is_training=False, background_rgb=bg), rb, n_total, fields=("rgb",), stats=stats)
+            t0 = time.perf_counter()
+            out = model(rb, is_training=False, background_rgb=bg)
+            stats["host_s"] = stats.get("host_s", 0.0) + time.perf_counter() - t0
+            return out
 
     def fence():
         if dist is not None:
@@ -247,6 +253,7 @@ def timed_render(model, rb, bg, steps, warmup, dist, dev, sharded):
     lib = _lib.load()
     _lib.check(lib.nrh_kernel_timing_select(2), "timing_select")
     fence()
+    stats.clear()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
@@ -259,7 +266,7 @@ def timed_render(model, rb, bg, steps, warmup, dist, dev, sharded):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, out, k_ms.value, max(1, k_n.value)
+    return dt, out, k_ms.value, max(1, k_n.value), float(stats.get("host_s", 0.0))
 
 
 def orbit_views(ncam=12, radius=3.6, elevation=0.4):
@@ -365,7 +372,12 @@ def camopt_legs(dev, batch=1024, steps=30, warm=3, view_steps=500, view_batch=51
     return out
 
 
-def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch=None, repeats=1):
+HANDOFF_LABEL = {False: "f16x3 (float32 dW hand-offs: three-term products throughout - the precision-matched form)",
+                 True: "f16x3 + fp16 dW hand-offs (weight-gradient products: ONE fp16 MFMA pass on operands rounded to 11 bits, range-scaled; "
+                       "narrower than the reference's float32 in those products - labelled option NeuSHintRenderer.dw_half)"}
+
+
+def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch=None, repeats=1, dw_half=False):
     """BASELINE.json configs[2] (and [4] for N > 1): 1024-ray training steps of the reference-initialised student against
     pixels of scene b (rendered before the timed region: ground-truth pixels are data).  ``global_batch``: the reference's DDP
     semantics - the batch is split, per-rank = global // world (trainer/trainer.py:116-123) - instead of a fixed per-rank batch.
@@ -378,6 +390,7 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
     if global_batch:
         batch = max(16, global_batch // world)
     student = na.NeuSHintRenderer(na.NeuSModelConfig()).to(dev)
+    student.dw_half = bool(dw_half)          # numerics option of the fused step (renderer attribute, never the environment)
     teacher, _ = build_scene(student.precision)
     teacher = teacher.to(dev).eval()
     bg = torch.ones(1, 3, device=dev)
@@ -426,15 +439,15 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
     peak = PEAK_TFLOPS[student.precision]
     return {"metric": "training ray-steps/s (forward + backward + Adam)", "value": round(value, 1), "unit": "ray-steps/s",
             "batch_rays_per_gpu": batch, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
-            "dtype": student.precision, "global_batch": batch * world,
+            "dtype": HANDOFF_LABEL[bool(dw_half)] if student.precision == "f16x3" else student.precision, "dw_half": bool(dw_half),
+            "global_batch": batch * world,
             "mode": "hipGraph replay" if world == 1 else ("one hipGraph incl. the flat RCCL all-reduce" if in_graph else
                                                             "two hipGraphs around one flat RCCL all-reduce per step"),
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
             **({"repeats_ms": [round(b / steps * 1e3, 3) for b in block_s]} if nblocks > 1 else {}),
             "bound_note": "the step's big kernels (SDF training forward, dW, tangent / value sweeps, reflectance adjoint) move the saved "
-                          "activations through HBM at 4-5.5 TB/s; since the 16-bit hand-offs (DESIGN 7i) the sweeps are no longer bound by "
-                          "their bytes (profiles/r05/pmc_train_summary.txt, DESIGN 7b / 7c / 7g / 7i); the MFMA fraction below is the "
-                          "SURVEY 8d convention",
+                          "activations through HBM at 4-5.5 TB/s (profiles/r05/pmc_train_summary.txt, DESIGN.md 'training step'); the MFMA "
+                          "fraction below is the SURVEY 8d convention",
             "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
                          "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(value * FLOP_PER_RAY_STEP / 1e12 / world / peak, 4)}}
@@ -518,12 +531,28 @@ def main():
     strong = args.scaling == "strong"
     # weak: each rank renders its own view of the same scene (different azimuth / light); strong: everyone holds view 0
     rays_np = make_image_rays(H, W, azimuth=0.6 + (0.0 if strong else 0.7 * rank), elevation=0.5)
-    rb = na.RayBundle(**{k: torch.from_numpy(v).to(dev) for k, v in
+    nrays = H * W + int(os.environ.get("NRH_BENCH_EXTRA_RAYS", "0"))      # (test hook: a frame that does not divide over the ranks)
+    if nrays != H * W:
+        rays_np = tuple(np.concatenate([a, a[: nrays - H * W]], axis=0) for a in rays_np)
+    sharded = strong and world > 1
+    # strong scaling: a rank uploads and holds ONLY its slab of the frame (parallel.slab_bounds: contiguous row blocks)
+    from nrhints_amd.parallel import slab_bounds
+    lo, hi = slab_bounds(nrays, rank, world) if sharded else (0, nrays)
+    rb = na.RayBundle(**{k: torch.from_numpy(np.ascontiguousarray(v[lo:hi])).to(dev) for k, v in
                          zip(("origins", "directions", "pl_positions", "nears", "fars"), rays_np)})
     bg = torch.ones(1, 3, device=dev)
-    nrays = H * W
-    dt, out, k_ms, launches = timed_render(model, rb, bg, args.steps, args.warmup, dist, dev, sharded=strong and world > 1)
+    dt, out, k_ms, launches, host_s = timed_render(model, rb, bg, args.steps, args.warmup, dist, dev, sharded=sharded, n_total=nrays)
     rgb = (out["rgb"] if isinstance(out, dict) else out.rgb).cpu().numpy()
+    # per-rank host time outside kernels (the >= 6x risk at 8 GPUs is host overhead, not bandwidth): every rank's
+    # enqueue time per step beside the step's wall time
+    host_ms = round(host_s / max(1, args.steps) * 1e3, 3)
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, host_ms)
+        comm["host_enqueue_ms_per_step_by_rank"] = per_rank
+    else:
+        comm["host_enqueue_ms_per_step_by_rank"] = [host_ms]
+    comm["step_ms"] = round(dt / max(1, args.steps) * 1e3, 3)
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
@@ -531,7 +560,7 @@ def main():
         m2, _ = build_scene(other)
         m2 = m2.to(dev).eval()
         sec_steps = 3                              # (one frame in exact fp32 takes ~4 s; VERDICT r4: more than a single sample)
-        dt2, out2, k2_ms, l2 = timed_render(m2, rb, bg, sec_steps, 1, None, dev, sharded=False)
+        dt2, out2, k2_ms, l2, _ = timed_render(m2, rb, bg, sec_steps, 1, None, dev, sharded=False)
         ach2 = FLOP_PER_POINT_CORE * (nrays * 128 * sec_steps / l2) / (k2_ms / l2 * 1e-3) / 1e12
         secondary = {"dtype": other, "value": round(nrays * sec_steps / dt2, 1), "unit": "rays/s", "steps": sec_steps, "warmup": 1,
                      "roofline_achieved_tflops": round(ach2, 2), "roofline_frac": round(ach2 / PEAK_TFLOPS[other], 4),
@@ -544,7 +573,7 @@ def main():
             m3, _ = build_scene("f16")
             m3 = m3.to(dev).eval()
             red_steps = 3
-            dt3, out3, k3_ms, l3 = timed_render(m3, rb, bg, red_steps, 1, None, dev, sharded=False)
+            dt3, out3, k3_ms, l3, _ = timed_render(m3, rb, bg, red_steps, 1, None, dev, sharded=False)
             ach3 = FLOP_PER_POINT_CORE * (nrays * 128 * red_steps / l3) / (k3_ms / l3 * 1e-3) / 1e12
             rgb3 = out3.rgb.cpu().numpy()
             reduced = {"dtype": "f16 (one fp16 MFMA pass in the SDF kernels; reflectance net and per-ray stages as f16x3)",
@@ -559,10 +588,19 @@ def main():
             reduced = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     def run_train_leg():
+        """configs[2]'s step twice: ``train`` itself at float32 hand-offs (the precision-matched number; the default of the
+        library), and beside it, labelled, the same step with the fp16 dW hand-offs (``train["handoff16"]``)."""
         try:
-            return train_leg(dev, rank, world, dist, global_batch=args.train_batch_global or None)
+            leg = train_leg(dev, rank, world, dist, global_batch=args.train_batch_global or None, dw_half=False)
         except Exception as e:  # the headline must survive a failure of the secondary leg
             return {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            h = train_leg(dev, rank, world, dist, global_batch=args.train_batch_global or None, dw_half=True)
+            leg["handoff16"] = {k: h[k] for k in ("value", "unit", "ms_per_step", "dtype", "dw_half", "loss_first", "loss_last")}
+            leg["handoff16"]["roofline_frac"] = h["roofline"]["frac"]
+        except Exception as e:  # noqa: BLE001
+            leg["handoff16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        return leg
 
     # One rank: the training leg runs first and rides in the headline line.  Several ranks: a failure on ONE rank inside the
     # leg (OOM, RCCL error) would leave the others blocked in its gradient all-reduce, so the headline line is printed BEFORE
@@ -580,6 +618,9 @@ def main():
                            "ms_per_step": {str(b): l["ms_per_step"] for b, l in legs.items()},
                            "repeats_ms": {str(b): l["repeats_ms"] for b, l in legs.items()},
                            "ray_steps_per_s": {str(b): l["value"] for b, l in legs.items()}, "steps": 40, "dtype": legs[64]["dtype"]}
+            # ... and the 128-ray step with the fp16 hand-offs, labelled (64 rays runs on the channel-split kernels, which have no such form)
+            h128 = train_leg(dev, rank, 1, None, batch=128, steps=40, repeats=3, dw_half=True)
+            train_small["handoff16_128"] = {"ms_per_step": h128["ms_per_step"], "repeats_ms": h128["repeats_ms"], "dtype": h128["dtype"]}
         except Exception as e:  # noqa: BLE001
             train_small = {"error": f"{type(e).__name__}: {e}"[:300]}
     camopt = None
@@ -610,7 +651,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "800x800 eval render (640000 primary rays/step" + ("" if strong else "/GPU") + "), 64+64 samples/ray, "
                                    "shadow + specular hints, synthetic random-weight scene b (BASELINE configs[1])",
-                       "rays_per_step_per_gpu": nrays // (world if strong else 1), "samples_per_ray": 128,
+                       "rays_per_step_per_gpu": (hi - lo), "samples_per_ray": 128,
                        "chunk_rays": int(model.max_chunk_rays),
                        "parallelism": (f"one view in {world} row blocks + RCCL all-gather of rgb" if strong else f"view-sharded x{world}"),
                        "algorithmic_gflop_per_ray": round(FLOP_PER_RAY / 1e9, 4),
@@ -621,6 +662,9 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                          "traffic_source": traffic_src,
                          "traffic_kind": traffic_kind, "kernel_source_hash": kernel_source_hash(),
+                         # the loaded binary's embedded source hash against the tree's (nrhints_amd/build_id.py): _lib.load() has
+                         # already refused a stale default library; a variant named through NRHINTS_HIP_LIB shows up here
+                         "library": _lib.library_identity(),
                          # bytes the kernel's contract moves (features + sdf + gradient out, 1 044 B per point) and SURVEY 8(d)'s
                          # algorithmic figure for the whole path (44 B in + 6 676 B out = 6 720 B per ray)
                          "algorithmic_bytes_per_launch": int(pts_per_launch * 1044),

@@ -30,9 +30,13 @@ extern "C" {
 #define NRH_E_WORKSPACE (-3)   /* workspace too small */
 #define NRH_E_UNSUPPORTED (-4) /* configuration outside the compiled network shape */
 
-/* ABI version (major * 100 + minor) and a human-readable build string. */
+/* ABI version (major * 100 + minor) and a human-readable build string (names the source hash and the -D variant flags).
+ * nrh_source_hash: the 16-hex-digit hash of the sources this binary was built from (nrhints_amd/build_id.py, embedded by
+ * csrc/Makefile); the Python binding refuses a library whose hash differs from the tree's - a stale binary cannot pass for
+ * the sources beside it.  "unknown" for a build that bypassed the Makefile. */
 int nrh_version(void);
 const char* nrh_build_info(void);
+const char* nrh_source_hash(void);
 const char* nrh_last_error_string(void);
 
 /* Sizes (in floats) of the packed parameter buffers and of the per-wave scratch the gradient kernels need.
@@ -105,18 +109,27 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
  * The reference differentiates d(sdf)/dp a second time with autograd (create_graph=True, fields/sdf_field.py:145;
  * loss.backward(), pipelines/base_pipeline.py:59-62).  Here that second-order backward is two more register-chain
  * sweeps over arrays the training forward saves (maths: nrhints_amd/sdf_function.py), and the weight gradients are
- * plain GEMMs over the saved row-major arrays, done by the caller (rocBLAS):
+ * products over the saved arrays:
  *     dW_l = zbar[l]^T x_l + save_t[l]^T abar_in_l ,  db_l = colsum zbar[l]
  *     x_0 = embedding, x_l = save_h[l-1];   abar_in_0 = gebar, abar_in_l = abar[l-1];   d w_s += colsum abar[7] / 3
- * All [.][npts][256] arrays are row-major fp32; npts = nrays * n_per_ray must be a multiple of 16.
+ * LAYOUT OF THE [8][npts][256] ARRAYS (save_h, save_s1, save_t, abar, zbar; float32): NOT row-major.  When nrh_train_arrays_tiled()
+ * returns 1 (every build since ABI 146) they are TILED - per layer, per tile of 16 consecutive points one contiguous 16 KiB block
+ * [channel block 16][point 16][channel 16]: element (point p, channel c) of a layer lives at float offset
+ *     (p / 16) * 4096 + (c / 16) * 256 + (p % 16) * 16 + (c % 16)
+ * (one contiguous KiB per wave instruction in the kernels that write and read them).  They are opaque hand-offs between
+ * nrh_sdf_train_forward, nrh_sdf_train_backward and nrh_dw_gemm: nrh_dw_gemm (NrhDwJob.tiled_a / tiled_b) is the ONLY supported
+ * consumer of the weight-gradient operands - a caller that ran its own GEMMs over them as if they were row-major would get wrong
+ * gradients silently.  (nrhints_amd/dw.py: from_tiled is the de-tiling used by the tests.)  ROW-MAJOR are only: feat_rows
+ * [npts,256], save_ge [npts][128], gebar [npts][64], pbar [npts,3], and every array of the reflectance network's training entries.
+ * npts = nrays * n_per_ray must be a multiple of 16 and < 2^24 (32-bit element offsets inside a layer).
  *
  * nrh_sdf_train_forward: as nrh_sdf_eval mode 2 (sdf [npts], grad [npts,3]) with the feature ROW-MAJOR feat_rows
  *   [npts,256], plus  save_h [8][npts][256] (softplus outputs; layer 3 already holds the skip concatenation),
  *   save_s1 [8][npts][256] (sigmoid(100 z)), save_t [8][npts][256] (reverse-chain stage inputs),
  *   save_ge [npts][128] (cols 0..38: d sdf/d embedding via layer 0; cols 73..111: via the skip connection).
  * nrh_sdf_train_backward: given the adjoints  sbar [npts], fbar [npts,256], gbar [npts,3]  of the three outputs
- *   writes  abar, zbar [8][npts][256] (row-major), coup (8 * npts * 256 floats of hand-off between the two sweeps, tile-native:
- *   opaque to the caller), gebar [npts][64] and pbar [npts,3] (adjoint of the points through the
+ *   writes  abar, zbar [8][npts][256] (tiled, see above), coup (8 * npts * 256 floats of hand-off between the two sweeps,
+ *   tile-native: opaque to the caller), gebar [npts][64] and pbar [npts,3] (row-major) (adjoint of the points through the
  *   value path; the caller adds the term through the encoding's second derivative, see sdf_function.py).
  *   wt_feat: the feature head transposed, packed as one 256x256 stage (packing.pack_feat_transposed).
  * adj_scale (this entry, nrh_color_train_backward, nrh_outside_backward): a power of two S in [2^-60, 2^60], used by precision f16x3
@@ -124,7 +137,12 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
  *   fp16 halves of the 3-term split see adjoints of a magnitude that does not depend on the batch size.  The loss is normalised
  *   by the ray count (pipelines/base_pipeline.py:57-62): at 1 024 rays per step unscaled adjoints are ~ 1e-3 of a single ray's
  *   and the split's absolute floor (3e-11 below 6e-5) cost up to 6e-3 of a gradient tensor's scale against the reference's
- *   float64 step (tests/test_gpu_train1024.py).  Pass 2^round(log2(rays in the batch)); 1 reproduces the unscaled chain. */
+ *   float64 step (tests/test_gpu_train1024.py).  Pass 2^round(log2(rays in the batch / 8)) (at least 1) for a loss normalised by
+ *   the ray count - nrhints_amd._lib.adjoint_scale: the adjoints then have the magnitude of an 8-ray batch whatever the batch
+ *   size, which leaves three more octaves of head-room below fp16's 65 504 than 2^round(log2(rays)) would (the largest seed,
+ *   d alpha / d sdf <= inv_s / 4 per unit of colour adjoint, grows with the trained sharpness); 1 reproduces the unscaled chain.
+ *   For losses that are NOT ~1 / rays (sum-reduced, custom weights) derive S from the seeds' range instead, as the _half entries
+ *   do on the device (`dyn`). */
 int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                           float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,
@@ -198,7 +216,8 @@ int nrh_weight_norm_fold_backward(int nlayers, const int* rows, const int* cols,
  *   backward: zbar4 [P,3] = adjoint of the pre-sigmoid output, col_wt = transposed stages
  *             (packing.pack_color_transposed, nrh_color_transposed_floats(hints) floats or fp16 pairs)
  *             -> zbar [4][P][256], fbar [P,256] (adjoint of feat), mbar [P][128 | 64] (adjoint of the non-feature input)
- *   weight gradients are GEMMs over these arrays on the caller's side:  dW_l = zbar[l]^T save_h[l-1], ... */
+ *   weight gradients are products over these (row-major) arrays:  dW_l = zbar[l]^T save_h[l-1], ... - nrh_dw_gemm jobs in this
+ *   package; being row-major, any GEMM would do */
 long long nrh_color_transposed_floats(int hints);
 /* nrh_color_train_forward with the per-ray table indexed per GROUP of `samples_per_row` consecutive samples (a power of two
  * <= 128; 128 = per ray): raymisc [nrays * 128 / samples_per_row, 100].  The partial visibility hint's training forward. */
@@ -556,10 +575,14 @@ int nrh_alpha_train_forward_n(const float* sdf, const float* grad, const float* 
 int nrh_alpha_train_backward_n(const float* sdf, const float* grad, const float* rd, const float* dists, float inv_s,
                                float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, const float* weights_bar,
                                const float* nhat_bar, float* sdf_bar, float* grad_bar, float* rd_bar, float* invs_bar, void* stream);
+/* The shadow ray's alpha stage for renderer.shadow_hint_gradient (models/neus_hint_model.py:379, :411-432): visibility =
+ * transmittance in front of the LAST sample that exists, taus[..., -1].  n_real = n_shadow_samples + 4 * (n_shadow_importance_samples
+ * // 4) of the 128 slots (128 with the reference's defaults); padded slots behind it have alpha = 0, do not enter the product
+ * and receive zero adjoints (ABI 147: the argument is new; before it the product always ran to slot 127). */
 int nrh_shadow_alpha_forward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
-                             float cos_anneal, const float* dyn_scalars, long long nrays, float* visibilities, void* stream);
+                             float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, float* visibilities, void* stream);
 int nrh_shadow_alpha_backward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
-                              float cos_anneal, const float* dyn_scalars, long long nrays, const float* visibilities_bar,
+                              float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, const float* visibilities_bar,
                               float* sdf_bar, float* grad_bar, float* dirs_bar, float* invs_bar, void* stream);
 /* d loss / d variance from the per-ray partials of nrh_alpha_train_backward (inv_s = clip(exp(10 variance), 1e-6, 1e6),
  * models/neus_hint_model.py:104-110): variance_bar[0] = 10 inv_s sum(invs_bar) inside the clip range, else 0. */

@@ -16,7 +16,7 @@ NRH_OK = 0
 _ERRNAMES = {-1: "NRH_E_INVALID", -2: "NRH_E_LAUNCH", -3: "NRH_E_WORKSPACE", -4: "NRH_E_UNSUPPORTED"}
 
 # every symbol include/nrhints_hip.h declares (tests check the .so exports exactly these)
-EXPORTED = ("nrh_version", "nrh_build_info", "nrh_last_error_string", "nrh_param_sizes", "nrh_mlp_grid",
+EXPORTED = ("nrh_version", "nrh_build_info", "nrh_source_hash", "nrh_last_error_string", "nrh_param_sizes", "nrh_mlp_grid",
             "nrh_sdf_eval", "nrh_sampler_step", "nrh_color_eval", "nrh_render_workspace_floats",
             "nrh_render_forward", "nrh_kernel_timing_select", "nrh_kernel_timing_read", "nrh_generate_rays",
             "nrh_sdf_train_forward", "nrh_sdf_train_backward", "nrh_outside_sizes", "nrh_outside_forward",
@@ -79,6 +79,35 @@ class NrhError(RuntimeError):
 _lib = None
 
 
+class StaleLibrary(RuntimeError):
+    pass
+
+
+def _check_provenance(lib) -> None:
+    """The binary must have been built from the sources beside it: ``nrh_source_hash()`` (embedded by csrc/Makefile) against
+    build_id.source_hash() of the tree.  The .so is git-ignored and reaches the GPU box as a prebuilt file; this is what ties it
+    to the tree.  A library named explicitly through NRHINTS_HIP_LIB (the -D experiment variants of ``make variant``) is exempt
+    from the comparison - its identity is reported by bench.py - but must still carry a hash."""
+    from . import build_id
+    try:
+        fn = lib.nrh_source_hash
+    except AttributeError:
+        raise StaleLibrary(f"{LIB_PATH} predates nrh_source_hash(): rebuild (make -C nrhints_amd/csrc)") from None
+    fn.restype = c_char_p
+    have, want = fn().decode(), build_id.source_hash()
+    if have != want and not os.environ.get("NRHINTS_HIP_LIB"):
+        raise StaleLibrary(f"{LIB_PATH} was built from other sources (embedded hash {have}, this tree {want}): "
+                           "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+
+
+def library_identity() -> dict:
+    """{'embedded': hash in the loaded binary, 'tree': hash of the sources beside it, 'build_info': ...} for reports."""
+    from . import build_id
+    lib = load()
+    return {"embedded": lib.nrh_source_hash().decode(), "tree": build_id.source_hash(), "build_info": lib.nrh_build_info().decode(),
+            "path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE))}
+
+
 def load():
     """Load (once) and return the ctypes handle.  Raises HipExtensionMissing if the .so is not built."""
     global _lib
@@ -89,12 +118,14 @@ def load():
             f"{LIB_PATH} not found: the HIP hot path is not built (run __graft_entry__.build()). "
             "nrhints_amd has no CPU/PyTorch fallback for rendering.")
     lib = ctypes.CDLL(LIB_PATH)
+    _check_provenance(lib)
     P = c_void_p
     lib.nrh_version.restype = c_int
     lib.nrh_train_arrays_tiled.restype = c_int
     lib.nrh_train_half_supported.argtypes = [c_int, c_longlong]
     lib.nrh_train_half_supported.restype = c_int
     lib.nrh_build_info.restype = c_char_p
+    lib.nrh_source_hash.restype = c_char_p
     lib.nrh_last_error_string.restype = c_char_p
     lib.nrh_param_sizes.argtypes = [POINTER(c_int)]
     lib.nrh_mlp_grid.restype = c_int
@@ -114,8 +145,8 @@ def load():
     lib.nrh_sample_primary.argtypes = [POINTER(NrhNet), P, P, P, P, c_longlong, P, P, P, P, P, P, P, c_longlong, P]
     lib.nrh_alpha_blend_forward.argtypes = [P, P, P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P]
     lib.nrh_alpha_blend_backward.argtypes = [P, P, P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P, P, P, P]
-    lib.nrh_shadow_alpha_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P]
-    lib.nrh_shadow_alpha_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, P, P, P, P]
+    lib.nrh_shadow_alpha_forward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P]
+    lib.nrh_shadow_alpha_backward.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, c_int, P, P, P, P, P, P]
     lib.nrh_color_transposed_floats.argtypes = [c_int]
     lib.nrh_color_transposed_floats.restype = c_longlong
     lib.nrh_color_train_forward.argtypes = [c_int, c_int, P, P, P, P, P, P, c_longlong, P, P, P, P]

@@ -152,7 +152,7 @@ class ShadowVisibilityHip(torch.autograd.Function):
     alpha-stage kernel pair (csrc/nrh_rays_train.hip, nrh_shadow_alpha_*).  For renderer.shadow_hint_gradient."""
 
     @staticmethod
-    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float, dyn=None):
+    def forward(ctx, sdf, grad, dirs, dists, variance, inv_s: float, cos_anneal: float, dyn=None, n_real: int = 128):
         from . import _lib
         lib = _lib.load()
         n = dirs.shape[0]
@@ -161,9 +161,9 @@ class ShadowVisibilityHip(torch.autograd.Function):
         vis = torch.empty(n, 1, dtype=torch.float32, device=dirs.device)
         P = _lib.ptr
         _lib.check(lib.nrh_shadow_alpha_forward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), float(inv_s), float(cos_anneal), P(dyn), n,
-                                                P(vis), _lib.stream_handle()), "nrh_shadow_alpha_forward")
+                                                int(n_real), P(vis), _lib.stream_handle()), "nrh_shadow_alpha_forward")
         ctx.save_for_backward(sdf_c, grad_c, dirs_c, dists_c)
-        ctx.consts, ctx.dyn = (float(inv_s), float(cos_anneal)), dyn
+        ctx.consts, ctx.dyn, ctx.n_real = (float(inv_s), float(cos_anneal)), dyn, int(n_real)
         return vis
 
     @staticmethod
@@ -178,15 +178,15 @@ class ShadowVisibilityHip(torch.autograd.Function):
         sdf_bar, grad_bar, rd_bar, invs_bar = new(n * 128, 1), new(n * 128, 3), new(n, 3), new(n)
         P = _lib.ptr
         dyn = ctx.dyn
-        _lib.check(lib.nrh_shadow_alpha_backward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, P(dyn), n, P(vbar),
-                                                 P(sdf_bar), P(grad_bar), P(rd_bar), P(invs_bar), _lib.stream_handle()),
+        _lib.check(lib.nrh_shadow_alpha_backward(P(sdf_c), P(grad_c), P(dirs_c), P(dists_c), inv_s, cos_anneal, P(dyn), n, ctx.n_real,
+                                                 P(vbar), P(sdf_bar), P(grad_bar), P(rd_bar), P(invs_bar), _lib.stream_handle()),
                    "nrh_shadow_alpha_backward")
         if dyn is not None:
             s_dev = dyn[0]
             var_bar = invs_bar.sum() * torch.where((s_dev > 1e-6) & (s_dev < 1e6), 10.0 * s_dev, torch.zeros_like(s_dev))
         else:
             var_bar = invs_bar.sum() * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)
-        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None, None
+        return sdf_bar, grad_bar, rd_bar, None, var_bar, None, None, None, None
 
 
 def _specular_cue(hit_normal, pl, hit, dirs, roughness) -> torch.Tensor:
@@ -211,7 +211,7 @@ def _specular_cue(hit_normal, pl, hit, dirs, roughness) -> torch.Tensor:
     return torch.stack(out, dim=-1)
 
 
-def _visibility(d, packed, variance, pl, hit, mid_z, dists, cos_anneal: float, dyn=None) -> torch.Tensor:
+def _visibility(d, packed, variance, pl, hit, mid_z, dists, cos_anneal: float, dyn=None, n_real: int = 128) -> torch.Tensor:
     """The differentiable tail of get_visibility (models/neus_hint_model.py:411-432) for renderer.shadow_hint_gradient: alpha at
     the 128 section mid-points of the shadow ray light -> hit point (sections from the graph-less HIP sampler; the reference
     detaches its importance samples too, :313), transmittance in front of the last one.  The SDF network and d sdf/dx at the
@@ -222,7 +222,9 @@ def _visibility(d, packed, variance, pl, hit, mid_z, dists, cos_anneal: float, d
     srd = sd / torch.linalg.norm(sd, ord=2, dim=-1, keepdim=True)
     pts = (pl[:, None, :] + srd[:, None, :] * mid_z[..., None]).reshape(-1, 3)
     sdf, _, grad = sdf_value_feat_grad(d, pts, packed=packed)
-    return ShadowVisibilityHip.apply(sdf, grad, srd, dists, variance, packed["inv_s"], cos_anneal, dyn)
+    # n_real: the shadow ray's samples that exist (n_shadow_samples + its importance samples; 128 with the defaults): the visibility
+    # is the transmittance in front of the last of THOSE, padded slots carry nothing
+    return ShadowVisibilityHip.apply(sdf, grad, srd, dists, variance, packed["inv_s"], cos_anneal, dyn, n_real)
 
 
 def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl, mid_z, dists, vis, cue, cos_anneal: float,
@@ -246,7 +248,7 @@ def render_core(d: Dict[str, torch.Tensor], variance: torch.Tensor, o, dirs, pl,
     if hint_grad is not None:
         if hint_grad.get("shadow") is not None:
             vis = _visibility(d, packed, variance, pl, hint_grad["hit"], hint_grad["shadow"]["mid_z"], hint_grad["shadow"]["dists"],
-                              cos_anneal, dyn)
+                              cos_anneal, dyn, int(hint_grad["shadow"].get("n_real", 128)))
         if hint_grad.get("specular"):
             hit_n = F.normalize((n_hat.reshape(n, T, 3) * weights[..., None]).sum(1), dim=-1, p=2)      # :586-587
             cue = _specular_cue(hit_n, pl, hint_grad["hit"], dirs, hint_grad["roughness"])

@@ -204,17 +204,24 @@ int mlp_launch_geometry(long long npts, int& groups_out, int& grid_out, const ch
   return NRH_OK;
 }
 
+// Kernel selection is a function of the call's arguments, not of the process environment: the A/B overrides below are read ONLY
+// when NRH_PROFILING=1 is set as well (profiles/*.sh set it); without it a stray variable changes nothing.
+static const char* prof_env(const char* name) {
+  static const bool profiling = getenv("NRH_PROFILING") && atoi(getenv("NRH_PROFILING")) != 0;
+  return profiling ? getenv(name) : nullptr;
+}
+
 // Small batches (at most 4 sixteen-point tiles per CU): the SDF training kernels' 4-wave builds (csrc/nrh_small.hip) put one wave on
-// every SIMD of twice as many CUs.  NRH_SMALL_WG=0 in the environment keeps the 8-wave builds (A/B runs).
+// every SIMD of twice as many CUs.  NRH_PROFILING=1 NRH_SMALL_WG=0 in the environment keeps the 8-wave builds (A/B runs).
 bool small_batch(long long npts) {
-  static const bool on = !(getenv("NRH_SMALL_WG") && atoi(getenv("NRH_SMALL_WG")) == 0);
+  static const bool on = !(prof_env("NRH_SMALL_WG") && atoi(prof_env("NRH_SMALL_WG")) == 0);
   return on && nrh::WG_WAVES == 8 && npts <= 16LL * 4 * device_cus();
 }
 
 // ... and below that, for precision f16x3, the channel-split training kernels (csrc/nrh_sdf_train_split.hip): one tile per workgroup,
-// its stages' output channels over the four waves.  NRH_SPLIT_TRAIN=0 in the environment keeps the 4-wave builds (A/B runs).
+// its stages' output channels over the four waves.  NRH_PROFILING=1 NRH_SPLIT_TRAIN=0 in the environment keeps the 4-wave builds (A/B runs).
 bool split_train(int precision, long long npts) {
-  static const bool on = !(getenv("NRH_SPLIT_TRAIN") && atoi(getenv("NRH_SPLIT_TRAIN")) == 0);
+  static const bool on = !(prof_env("NRH_SPLIT_TRAIN") && atoi(prof_env("NRH_SPLIT_TRAIN")) == 0);
   return on && precision == 1 && npts <= 16LL * 2 * device_cus();      // (at 4 tiles per CU the 4-wave builds are as fast: profiles/r04/tsplit_ab.log)
 }
 
@@ -244,7 +251,7 @@ int sdf_split_impl(const float* w, const float* b, const float* head, const floa
   const int arc = ensure_attrs();
   if (arc) return arc;
   if (tiles == 0) {
-    static const int forced = getenv("NRH_SPLIT_TILES") ? atoi(getenv("NRH_SPLIT_TILES")) : 0;       // profiling override
+    static const int forced = prof_env("NRH_SPLIT_TILES") ? atoi(prof_env("NRH_SPLIT_TILES")) : 0;       // profiling override
     tiles = (forced == 1 || forced == 2) ? forced : (npts > 16LL * device_cus()) ? 2 : 1;            // one tile per workgroup while that fills the CUs once
   }
   nrh::SdfSplitArgs a;
@@ -362,7 +369,7 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
   // a training step's passes are small and serial: below NRH_SPLIT_MAX_PTS points the channel-split kernel (a tile's MFMA work
   // over the CU's four SIMDs) instead of the one-wave-per-tile evaluation kernels.  Training only: a frame's chunks must not
   // change kernels with their size (bit-equal re-chunking, tests/test_gpu_fullsize.py)
-  static const long long split_max = getenv("NRH_SPLIT_MAX_PTS") ? atoll(getenv("NRH_SPLIT_MAX_PTS")) : (long long)NRH_SPLIT_MAX_PTS;   // (env: profiling override)
+  static const long long split_max = prof_env("NRH_SPLIT_MAX_PTS") ? atoll(prof_env("NRH_SPLIT_MAX_PTS")) : (long long)NRH_SPLIT_MAX_PTS;   // (env: profiling override)
   auto sdf0 = [&](const float* t, int stride, int per_ray, float* out) {
     if (latency && net->precision == 1 && n * per_ray <= split_max)
       return sdf_split_impl(net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, t, stride, per_ray, n, out, stride, 0, st);
@@ -420,9 +427,18 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 146; }
+int nrh_version(void) { return 147; }
 int nrh_train_arrays_tiled(void) { return nrh::arr_tiled(nrh::ARR_H) ? 1 : 0; }
-const char* nrh_build_info(void) { return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 " __DATE__ " " __TIME__; }
+#ifndef NRH_SOURCE_HASH
+#define NRH_SOURCE_HASH "unknown"      // (a build outside csrc/Makefile: _lib.load() refuses it)
+#endif
+#ifndef NRH_BUILD_DEFS
+#define NRH_BUILD_DEFS ""
+#endif
+const char* nrh_source_hash(void) { return NRH_SOURCE_HASH; }
+const char* nrh_build_info(void) {
+  return "nrhints_hip gfx950 mfma f32 16x16x4 | f16x3 16x16x32 | sources " NRH_SOURCE_HASH " | defs [" NRH_BUILD_DEFS "] | " __DATE__ " " __TIME__;
+}
 const char* nrh_last_error_string(void) { return g_err; }
 
 int nrh_param_sizes(int* out) {
@@ -504,17 +520,19 @@ long long nrh_sdf_wide_stream_bytes(void) { return nrh32::wide_sdf_stream_bytes_
 
 // 16-bit hand-offs (NrhTrainSaves.save_h16 / save_t16, nrh_sdf_train_backward_half): the 8- and 4-wave f16x3 kernels
 // Two further 16-bit candidates, built, measured and left OFF (profiles/r05/train_coup16_ab.log, train_t16only_ab.log): coup - the
-// sweeps' private hand-off - as fp16 (NRH_COUP16=1: -1.07 GB per 1 024-ray step, +0.6 %) and layers 1..6 of t as fp16 only
-// (NRH_T16_ONLY=1: -0.9 GB, +0.9 %).  Both pass the 1 024-ray parity tests, but unlike h / abar / zbar these arrays feed the adjoint
-// CHAIN (11-bit roundings inside it, not at its outputs), and the sweeps are no longer bound by their bytes.
-static int coup16_mode() {
-  static const int on = (getenv("NRH_COUP16") && atoi(getenv("NRH_COUP16")) != 0) ? 1 : 0;
-  return on;
-}
-static int t16_only_mode() {
-  static const int on = (getenv("NRH_T16_ONLY") && atoi(getenv("NRH_T16_ONLY")) != 0) ? 1 : 0;
-  return on;
-}
+// sweeps' private hand-off - as fp16 (-DNRH_COUP16=1: -1.07 GB per 1 024-ray step, +0.6 %) and layers 1..6 of t as fp16 only
+// (-DNRH_T16_ONLY=1: -0.9 GB, +0.9 %).  Both pass the 1 024-ray parity tests, but unlike h / abar / zbar these arrays feed the adjoint
+// CHAIN (11-bit roundings inside it, not at its outputs), and the sweeps are no longer bound by their bytes.  They change numerics,
+// so they are BUILD-TIME variants (make variant NAME=coup16 DEFS=-DNRH_COUP16=1; reported by nrh_build_info), never a process
+// environment switch.
+#ifndef NRH_COUP16
+#define NRH_COUP16 0
+#endif
+#ifndef NRH_T16_ONLY
+#define NRH_T16_ONLY 0
+#endif
+static constexpr int coup16_mode() { return NRH_COUP16 ? 1 : 0; }
+static constexpr int t16_only_mode() { return NRH_T16_ONLY ? 1 : 0; }
 int nrh_train_half_supported(int precision, long long npts) {
   // (the 4-wave builds of csrc/nrh_small.hip are the same source as the 8-wave kernels; the channel-split kernels are not)
   return (precision == 1 && npts > 0 && npts % 32 == 0 && !split_train(precision, npts)) ? 1 : 0;
@@ -1000,30 +1018,32 @@ int nrh_alpha_blend_backward(const float* sdf, const float* grad, const float* r
 
 // the shadow ray's alpha stage for renderer.shadow_hint_gradient: visibility = transmittance in front of the last sample
 int nrh_shadow_alpha_forward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
-                             float cos_anneal, const float* dyn_scalars, long long nrays, float* visibilities, void* stream) {
+                             float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, float* visibilities, void* stream) {
   if (!sdf || !grad || !shadow_dirs || !dists || !visibilities) return fail(NRH_E_INVALID, "nrh_shadow_alpha_forward: null pointer%s", "");
   if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_shadow_alpha_forward: nrays out of range%s", "");
+  if (n_real < 2 || n_real > 128) return fail(NRH_E_INVALID, "nrh_shadow_alpha_forward: n_real must be 2..128%s", "");
   if (nrays == 0) return NRH_OK;
   nrh::AlphaTrainArgs a;
   memset(&a, 0, sizeof(a));
   a.sdf = sdf; a.grad = grad; a.rd = shadow_dirs; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
-  a.dyn = dyn_scalars; a.tlast = visibilities;
+  a.dyn = dyn_scalars; a.tlast = visibilities; a.nreal = n_real == 128 ? 0 : n_real;
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("alpha_train_kernel<fwd, shadow>");
 }
 
 int nrh_shadow_alpha_backward(const float* sdf, const float* grad, const float* shadow_dirs, const float* dists, float inv_s,
-                              float cos_anneal, const float* dyn_scalars, long long nrays, const float* visibilities_bar,
+                              float cos_anneal, const float* dyn_scalars, long long nrays, int n_real, const float* visibilities_bar,
                               float* sdf_bar, float* grad_bar, float* dirs_bar, float* invs_bar, void* stream) {
   if (!sdf || !grad || !shadow_dirs || !dists || !visibilities_bar || !sdf_bar || !grad_bar || !dirs_bar || !invs_bar)
     return fail(NRH_E_INVALID, "nrh_shadow_alpha_backward: null pointer%s", "");
   if (nrays < 0 || nrays > 0x7fffffffLL) return fail(NRH_E_INVALID, "nrh_shadow_alpha_backward: nrays out of range%s", "");
+  if (n_real < 2 || n_real > 128) return fail(NRH_E_INVALID, "nrh_shadow_alpha_backward: n_real must be 2..128%s", "");
   if (nrays == 0) return NRH_OK;
   nrh::AlphaTrainArgs a;
   memset(&a, 0, sizeof(a));
   a.sdf = sdf; a.grad = grad; a.rd = shadow_dirs; a.dists = dists; a.inv_s = inv_s; a.cos_anneal = cos_anneal; a.nrays = (int)nrays;
-  a.dyn = dyn_scalars; a.tlast_bar = visibilities_bar;
+  a.dyn = dyn_scalars; a.tlast_bar = visibilities_bar; a.nreal = n_real == 128 ? 0 : n_real;
   a.sdf_bar = sdf_bar; a.grad_bar = grad_bar; a.rd_bar = dirs_bar; a.invs_bar = invs_bar;
   const unsigned blocks = (unsigned)((nrays + nrh::TRAIN_RAYS_PER_BLOCK - 1) / nrh::TRAIN_RAYS_PER_BLOCK);
   hipLaunchKernelGGL(nrh::alpha_train_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1534,7 +1554,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     if (rc) return rc;
     // the shadow ray's alpha only needs <direction, gradient>: with the wide kernels that is mode 3 (forward mode, no scratch)
     const int smode = (net->shadow_jvp && net->precision == 1 && net->sdf_w32 && net->sdf_tab32) ? 3 : 1;
-    static const long long gsplit_max = getenv("NRH_SPLIT_GRAD_MAX_PTS") ? atoll(getenv("NRH_SPLIT_GRAD_MAX_PTS")) : (long long)NRH_SPLIT_GRAD_MAX_PTS;
+    static const long long gsplit_max = prof_env("NRH_SPLIT_GRAD_MAX_PTS") ? atoll(prof_env("NRH_SPLIT_GRAD_MAX_PTS")) : (long long)NRH_SPLIT_GRAD_MAX_PTS;
     if (train && net->precision == 1 && n * 128 <= gsplit_max)     // small training batch: the channel-split kernel (as the sampler passes)
       rc = sdf_grad_split_impl(net->sdf_w, net->sdf_b, net->sdf_head, pl_positions, ws_srd, o_tmid_s, 128, 128, n, ws_sdf_s, 128, ws_grad_s, st);
     else

@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
           for (int c = 0; c < 3; ++c) a.nhat[P * 3 + c] = g[e][c] / gn[e];
         }
       }
-      if (a.tlast && lane == 63) a.tlast[ray] = T[1];
+      // the shadow ray's visibility: transmittance in front of the LAST sample THAT EXISTS (taus[..., -1], :428-432); padded
+      // slots behind it (shadow counts off the defaults) do not enter
+      const int jl = (a.nreal ? a.nreal : 128) - 1;
+      if (a.tlast && lane == (jl & 63)) a.tlast[ray] = T[jl >> 6];
       if (a.tail_t && lane == 63) a.tail_t[ray] = T[1] * f[1];
     }
     return;
@@ -122,7 +125,10 @@ __global__ __launch_bounds__(256) void alpha_train_kernel(const AlphaTrainArgs a
     wb[e] = a.weights_bar ? a.weights_bar[ray * 128 + lane + 64 * e] : 0.0f;
     x[e] = wb[e] * w[e];   // = Tbar_i T_i
   }
-  if (a.tlast_bar && lane == 63) x[1] += a.tlast_bar[ray] * T[1];   // T_127 is an output itself: Tbar_127 += tlast_bar
+  if (a.tlast_bar) {        // T of the last existing sample is an output itself: Tbar_jl += tlast_bar
+    const int jl = (a.nreal ? a.nreal : 128) - 1;
+    if (lane == (jl & 63)) x[jl >> 6] += a.tlast_bar[ray] * T[jl >> 6];
+  }
   float suf[2];
   suffix_sum_128(x[0], x[1], suf[0], suf[1]);
   // the transmittance behind the last sample is an output too (outside NeRF): a virtual 129th entry of the suffix sums

@@ -98,7 +98,8 @@ def _default_items(dev, npts: Optional[int] = None) -> int:
     # few K steps long and its fixed cost dominates: ONE item per CU there (profiles/r04/dw_items.log: 0.131 against 0.195 ms at
     # 64 rays, 0.222 / 0.272 at 128, 0.407 / 0.436 at 256, 0.792 / 0.801 at 512).  ``npts`` None: the upper bound (workspace size).
     cus = max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
-    per_cu = os.environ.get("NRH_DW_ITEMS_PER_CU")           # A/B runs only (1 .. 3: the workspace is sized for 3)
+    # A/B runs only (1 .. 3: the workspace is sized for 3); honoured only together with NRH_PROFILING=1, like the library's overrides
+    per_cu = os.environ.get("NRH_DW_ITEMS_PER_CU") if os.environ.get("NRH_PROFILING") == "1" else None
     if per_cu and npts is not None:
         return cus * max(1, min(3, int(per_cu)))
     return cus if (npts is not None and npts <= 65536) else 3 * cus

@@ -115,6 +115,15 @@ class NeuSHintRenderer(nn.Module):
     max_eval_rays_while_graphed = 32768   # training.GraphedTrainStep pins the workspace: evaluation chunks while a graph is alive
     fuse_feature_head = True   # evaluation renders with the wide kernels: W0feat * W_feat multiplied at pack time (NrhNet.feat_fused)
     max_fused_train_rays = 8192
+    #: OPTION of the fused f16x3 training step (train_fused.py; batches the 8- / 4-wave kernels run): hand the weight-gradient operands
+    #: (h, t, abar, zbar, the reflectance net's ReLU outputs / adjoints) to nrh_dw_gemm as fp16 - ONE fp16 MFMA pass on operands
+    #: rounded to 11 bits, range-scaled per step - instead of float32 arrays and three-term products.  False (the default) is the
+    #: precision-matched form: every product of the step then carries float32-equivalent operands, as the reference's float32 does.
+    #: True is ~10 % faster per step and meets the same gradient bounds against the reference's float64 step
+    #: (tests/test_gpu_train1024.py incl. the same-forward tests at the unwidened bound; a three-seed fit A/B shows no difference),
+    #: but its dW PRODUCTS are narrower than float32, so it is opt-in and every number measured with it is labelled (bench.py:
+    #: ``train.handoff16``).  An attribute of the renderer, never an environment switch.
+    dw_half = False
     # hipGraph mode (training.GraphedTrainStep): a device tensor [inv_s, cos_anneal] that the kernels read at run time
     # instead of the host floats baked into a captured launch; None = normal (eager) operation
     dyn_scalars = None
@@ -147,6 +156,7 @@ class NeuSHintRenderer(nn.Module):
         self._counts = None if cnt in ((64, 4, 16, 64, 16), (64, 0, 16, 64, 16)) else cnt
         self._samples = cnt[0] + cnt[1] * cnt[2]
         self._shadow_coarse = cnt[3]
+        self._shadow_total = cnt[3] + 4 * cnt[4]      # samples of a shadow ray that exist (the shadow march always takes four steps, :373)
         self._normal_type = 1 if config.renderer.normal_type == NormalComputationType.Analytic else 0
         self._depth_type = {DepthComputationType.AlphaBlend: 0, DepthComputationType.MaximalWeightPoint: 1,
                             DepthComputationType.SphereTracing: 2}[config.renderer.depth_type]
@@ -561,7 +571,7 @@ class NeuSHintRenderer(nn.Module):
             hit = self.sphere_trace(o, d, 2000, 1e-4, 100.0)[0]
         else:
             hit = o + d * depth.reshape(-1, 1)     # :533, :538 (under no_grad there too)
-        return dict(hit=hit, specular=specular_grad, shadow=dict(mid_z=res["shadow_mid_z"], dists=res["shadow_dists"]) if shadow_grad else None,
+        return dict(hit=hit, specular=specular_grad, shadow=dict(mid_z=res["shadow_mid_z"], dists=res["shadow_dists"], n_real=self._shadow_total) if shadow_grad else None,
                     roughness=[float(r) for r in self.config.renderer.specular_roughness])
 
     # ---------------------------------------------------------------------------------------------

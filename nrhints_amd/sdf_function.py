@@ -13,7 +13,8 @@ g with ``autograd.grad(create_graph=True)`` and lets autograd differentiate that
 
 with s' = sigmoid(100 z), s'' = 100 s'(1 - s'), a_l the reverse-chain values of the forward pass.  Forward and both sweeps
 are the HIP register-chain kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are one split-K
-bf16x3 MFMA launch over the saved row-major arrays (csrc/nrh_dw.hip through nrhints_amd/dw.py; no library GEMM).  The same maths in plain torch ops - the reference the kernels are tested against -
+bf16x3 MFMA launch over the saved arrays - in the sweeps' TILED layout (include/nrhints_hip.h, "LAYOUT OF THE [8][npts][256] ARRAYS"), which
+nrh_dw_gemm reads natively - (csrc/nrh_dw.hip through nrhints_amd/dw.py; no library GEMM).  The same maths in plain torch ops - the reference the kernels are tested against -
 lives with the tests (tests/torch_backends.py), not in the product.
 """
 from __future__ import annotations
@@ -59,7 +60,7 @@ def _scatter_dims(v: torch.Tensor, dim: torch.Tensor = None) -> torch.Tensor:
 class SdfValueFeatGradHip(torch.autograd.Function):
     """Same contract as ``SdfValueFeatGrad`` with the forward and both backward sweeps in the HIP register-chain
     kernels (csrc/nrh_sdf.hip MODE 3, csrc/nrh_sdf_train.hip); the weight gradients are jobs of nrh_dw_gemm over the saved
-    row-major arrays.  ``packed``: dict(sdf_w, sdf_b, sdf_head, sdf_wt_feat) packed from the SAME dense weights."""
+    (tiled) arrays.  ``packed``: dict(sdf_w, sdf_b, sdf_head, sdf_wt_feat) packed from the SAME dense weights."""
 
     @staticmethod
     def forward(ctx, pts, packed, pre, *params):

@@ -192,9 +192,10 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             B = cache[key] = _Buffers(dev, n, hints, shapes, layout, clip)
         # ---- no-grad stages + SDF training forward (one C call) ----
         Pn = n * 128
-        # 16-bit hand-offs of the SDF net's weight-gradient operands (f16x3, batches the 8-wave kernels run; NRH_DW_HALF=0: float32)
-        half = (pk["precision"] == 1 and getattr(renderer, "dw_half", True) and os.environ.get("NRH_DW_HALF", "1") != "0"
-                and bool(lib.nrh_train_half_supported(1, Pn)))
+        # 16-bit hand-offs of the SDF net's weight-gradient operands (f16x3, batches the 8-wave kernels run): the renderer's option
+        # ``dw_half`` (NeuSHintRenderer.dw_half; False = float32 hand-offs, the precision-matched form).  Not an environment switch:
+        # it changes numerics (11-bit operands of the weight-gradient products).
+        half = (pk["precision"] == 1 and bool(getattr(renderer, "dw_half", False)) and bool(lib.nrh_train_half_supported(1, Pn)))
         res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half)
         pre, sv = res["pre"], res["pre"]["saves"]
         # ---- reflectance forward ----

@@ -385,14 +385,22 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                    specular_hint_gradient=False, n_shadow_importance_clip=-1, n_importance_samples=64, outside_nerf=None,
                    t_rand_outside=None, specular_roughness=SPEC_ROUGHNESS, shadow_ray_offset=1e-2, z_override=None,
                    vis_groups_override=None, cue_override=None, n_samples=64, up_sample_steps=4, n_shadow_samples=64,
-                   n_shadow_importance_samples=64) -> Dict[str, torch.Tensor]:
+                   n_shadow_importance_samples=64, vis_override=None, net_override=None, sections_override=None) -> Dict[str, torch.Tensor]:
     """``NeuSHintRenderer.forward`` with the default nr-hints config
     (models/neus_hint_model.py:653-751 -> render_core :475-651).  ``geometry_warmup_end``: while training below that step
     both hints are fed as zeros and neither the shadow march nor the cue is evaluated (:668, :577-579, :617-619).
-    ``z_override`` [N,128] / ``vis_groups_override`` [N,clip] / ``cue_override`` [N,4]: test hooks that replace the three
+    ``z_override`` [N,128] / ``vis_override`` [N,1] (``vis_groups_override`` [N,clip] with the partial hint) / ``cue_override`` [N,4]: test hooks that replace the three
     NON-differentiable products of the forward (sample positions :697, partial visibility hint :553-575, specular cue :589) by
     values recorded elsewhere (the HIP path's own), so that a gradient comparison isolates the arithmetic of the differentiable
-    part from where the samplers happened to place their samples."""
+    part from where the samplers happened to place their samples.
+    ``sections_override`` (mid [N,T], dists [N,T]): with ``z_override``, the section mid-points and lengths themselves instead of
+    re-deriving them from z - importance samples cluster to sections of 1e-5 at the surface while z ~ 3 carries a float32 ulp of
+    2.4e-7, so lengths re-derived from rounded positions would be off by per cents where it matters most.
+    ``net_override`` dict(sdf [P,1], grad [P,3], feat [P,256]; any subset): a further test hook - the SDF network's outputs at the
+    composite samples take these VALUES while keeping their own derivatives (x <- x + stop_gradient(x_given - x)).  With the HIP
+    forward's own outputs this puts the oracle's linearisation point exactly where the HIP backward linearised: at NeuS sharpness
+    ~1e3 the alpha stage amplifies float32 round-off of the SDF by three orders, so two correct float32 forwards differ by 1e-4 in
+    single pixels - and in the gradients that pass through them - however the samples are placed."""
     n = o.shape[0]
     dt = o.dtype
     cos_anneal = 1.0
@@ -422,6 +430,8 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     # ---- render_core ----
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=dt)], dim=-1)
     mid = z + dists * 0.5
+    if sections_override is not None:
+        mid, dists = sections_override[0].to(dt), sections_override[1].to(dt)
     pts = (o[:, None, :] + d[:, None, :] * mid[..., None]).reshape(-1, 3)
     dirs = d[:, None, :].expand(n, T, 3).reshape(-1, 3)
     pls = pl[:, None, :].expand(n, T, 3).reshape(-1, 3)
@@ -429,6 +439,9 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     # (mode "as_written" only); sampling, depth / hit point, shadow hint and specular cue stay outside the graph as
     # in the reference (:697, :531, :379, :589).
     sdf, feat, grad = _sdf_and_grad(p, pts, mode, True, differentiable)
+    if net_override is not None:
+        given = lambda x, k: x + (net_override[k].to(dt).reshape(x.shape) - x).detach() if k in net_override else x
+        sdf, feat, grad = given(sdf, "sdf"), given(feat, "feat"), given(grad, "grad")
     inv_s = inv_s_of(p)
     alpha = alpha_from(sdf, grad, dirs, dists.reshape(-1, 1), inv_s, cos_anneal).reshape(n, T)
     radius = torch.linalg.norm(pts, dim=-1).reshape(n, T)
@@ -464,6 +477,8 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
                                 **shadow_counts).reshape(n, clip, 1)
             vis_samples = vg.repeat_interleave(ratio, dim=1)                               # [n,128,1]
             vis = torch.gather(vis_samples[..., 0], 1, torch.argmax(weights, dim=1, keepdim=True))   # shadow_map (:573-574)
+        elif shadow_hint and vis_override is not None:
+            vis = vis_override.to(dt).reshape(n, 1)
         elif not (shadow_hint and shadow_hint_gradient and differentiable):
             vis = visibility(p, pl, hit, cos_anneal, shadow_ray_offset, t_rand_shadow if is_training else None, mode, **shadow_counts) \
                 if shadow_hint else None                       # :546-551, :379

@@ -16,6 +16,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     torch.manual_seed(0)
     student = na.NeuSHintRenderer().cuda()
+    student.dw_half = "half" in sys.argv[4:]       # 4th argument "half": the fp16 dW hand-offs (NeuSHintRenderer.dw_half); default float32
     backend = sys.argv[3] if len(sys.argv) > 3 else "hip"          # hip | hip_nosync (no per-step loss read-back) | graph | manual | autograd (the last two: tests/torch_backends.py)
     teacher = na.NeuSHintRenderer()
     st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in student.state_dict().items()})
@@ -56,7 +57,7 @@ def main():
     print(json.dumps({"metric": "training ray-steps/s (fwd+bwd+Adam)", "batch": batch, "steps": steps,
                       "value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2),
                       "loss_first3": [round(x, 5) for x in losses[:3]], "loss_last3": [round(x, 5) for x in losses[-3:]],
-                      "precision": student.precision, "sdf_backward": backend, "hip_graph": graphed is not None}))
+                      "precision": student.precision, "dw_half": bool(student.dw_half), "sdf_backward": backend, "hip_graph": graphed is not None}))
 
 if __name__ == "__main__":
     main()

@@ -105,3 +105,43 @@ def test_sample_counts_training_step_vs_reference(scene_states, vt, prec):
     for (name, pa), (_, pf) in zip(model.named_parameters(), fused.named_parameters()):
         scale = float(pa.grad.abs().max()) + 1e-30
         assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, (vt, name)
+
+
+HG_COUNTS = {
+    "c4848g": dict(n_samples=48, n_importance_samples=48, up_sample_steps=4, n_shadow_samples=32, n_shadow_importance_samples=32),
+    "c8000g": dict(n_samples=80, n_importance_samples=0, n_shadow_samples=48, n_shadow_importance_samples=0),
+    "c6464g": dict(n_shadow_samples=64, n_shadow_importance_samples=32),
+}
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+@pytest.mark.parametrize("vt", sorted(HG_COUNTS))
+def test_shadow_hint_gradient_with_sample_counts_vs_reference(scene_states, vt, prec):
+    """renderer.shadow_hint_gradient with shadow-ray counts off the defaults (models/neus_hint_model.py:379, :411-432):
+    the differentiable visibility (ShadowVisibilityHip -> nrh_shadow_alpha_forward / _backward, n_real = the shadow ray's
+    existing samples) is the transmittance in front of the LAST EXISTING sample - before ABI 147 the product ran to slot 127,
+    through the last real sample and the padded slots (alpha = 1e-5 / (cdf + 1e-5) there, not 0).  One training step against
+    the reference's recorded run (tests/golden/make_golden_counts_hintgrad.py): rgb, visibilities, loss, 11 gradient tensors -
+    d loss / d variance exists only through the visibility's gradient path here."""
+    from nrhints_amd.training import train_loss_dict
+    g = load_npz("render_counts_hintgrad_b.npz")
+    model = _model(scene_states["b"], prec, dict(shadow_hint_gradient=True, **HG_COUNTS[vt])).train()
+    tb = _bundle(g, "t.")
+    out = model(tb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["t.global_step"]),
+                _t_rand_primary=cu(g[f"{vt}.t_rand_primary"]), _t_rand_shadow=cu(g[f"{vt}.t_rand_shadow"]))
+    np.testing.assert_allclose(out.rgb.detach().cpu().numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out.visibilities.detach().cpu().numpy(), g[f"{vt}.t.visibilities"], rtol=0, atol=3e-3)
+    ld = train_loss_dict(out, cu(g["t.rgb_gt"]), 0.1)
+    np.testing.assert_allclose(float(ld["loss"].detach()), float(g[f"{vt}.loss"]), rtol=2e-4)
+    ld["loss"].backward()
+    named = dict(model.named_parameters())
+    keys = [k for k in g if k.startswith(f"{vt}.grad.")]
+    assert len(keys) == 11
+    for k in keys:
+        name = k[len(vt) + 6:]
+        want64 = g[k.replace(".grad.", ".grad64.")]
+        bound, scale = grad_bound(g[k], want64, factor=4.0, floor=1e-2)
+        if np.size(want64) == 1:
+            bound = max(bound, 3e-7)
+        err = float(np.abs(named[name].grad.detach().cpu().numpy().astype(np.float64) - want64).max())
+        assert err <= bound, (vt, name, err, bound, scale)

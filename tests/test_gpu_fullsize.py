@@ -161,43 +161,59 @@ def test_two_rank_training_step():
     assert "MULTI_GPU_WORKER_OK rank 0" in r.stdout and "MULTI_GPU_WORKER_OK rank 1" in r.stdout
 
 
-# ---- the same N-rank code paths on ONE GPU: both ranks on cuda:0, collectives over gloo (RCCL refuses two ranks on one device) ----
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_two_ranks_rehearsal_on_one_gpu(scaling):
-    """bench.py --gpus 2 with NRH_BENCH_SHARE_GPU=1: the self-spawn through torch.distributed.run, the barriers and the
-    max-over-ranks time, the row-sharded strong-scaling render with its all-gather, and (weak) the training leg's eager fused steps
-    around the flat gradient all-reduce - executed with two ranks.  Timing is meaningless here (one GPU, host-staged collectives);
-    the line's structure and the rays accounted for are checked."""
+# ---- the same N-rank code paths on ONE GPU: all ranks on cuda:0, collectives over gloo (RCCL refuses two ranks on one device) ----
+# world 8 is the node the driver's scaling run uses: weak = 8 views, strong = one 800x800 frame in slabs of 80 000
+# rays (and 640 001 rays: slabs that differ by one, one padding row in the gather), training = configs[2]'s 1 024 rays split 8 x 128
+@pytest.mark.parametrize("world,scaling,extra", [(2, "weak", 0), (2, "strong", 0), (8, "weak", 0), (8, "strong", 0), (8, "strong", 1)])
+def test_bench_rehearsal_on_one_gpu(world, scaling, extra):
+    """bench.py --gpus N with NRH_BENCH_SHARE_GPU=1: the self-spawn through torch.distributed.run, the barriers and the
+    max-over-ranks time, the slab-sharded strong-scaling render with its ONE all_gather_into_tensor (every rank holds only its
+    slab of rays), and (weak) the training leg's fused steps around the flat gradient all-reduce with the reference's split
+    global batch - executed with N ranks.  Timing is meaningless here (one GPU, host-staged collectives); the line's structure,
+    the rays accounted for and the per-rank host times are checked."""
     env_extra = {"NRH_BENCH_SHARE_GPU": "1"}
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-rays", "0", "--no-secondary", "--scaling", scaling]
+    if extra:
+        env_extra["NRH_BENCH_EXTRA_RAYS"] = str(extra)
+    cmd = [sys.executable, "bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--cpu-rays", "0", "--no-secondary", "--scaling", scaling]
     if scaling == "strong":
         cmd.append("--no-train")
+    elif world == 8:
+        cmd += ["--train-batch-global", "1024"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1", **env_extra)
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = lines[0]
-    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0 and line.get("rehearsal") is True
+    assert line["n_gpus"] == world and line["scaling"] == scaling and line["value"] > 0 and line.get("rehearsal") is True
     # the line says what the process group was: backend, world size as the collective library sees it, one entry per rank
-    assert line["comm"]["backend"] == "gloo" and line["comm"]["world_size"] == 2 and line["comm"]["all_reduce_of_ones"] == 2.0
-    assert len(line["comm"]["devices"]) == 2 and line["comm"]["devices"][1].startswith("rank 1:")
-    rays = 640000 * (2 if scaling == "weak" else 1)
+    assert line["comm"]["backend"] == "gloo" and line["comm"]["world_size"] == world and line["comm"]["all_reduce_of_ones"] == float(world)
+    assert len(line["comm"]["devices"]) == world and line["comm"]["devices"][world - 1].startswith(f"rank {world - 1}:")
+    # per-rank host (enqueue) time per step beside the step's wall time: the scaling risk SURVEY 8e names, visible from the first run
+    host = line["comm"]["host_enqueue_ms_per_step_by_rank"]
+    assert len(host) == world and all(0.0 < h < line["comm"]["step_ms"] for h in host), (host, line["comm"]["step_ms"])
+    frame = 640000 + extra
+    rays = frame * (world if scaling == "weak" else 1)
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - rays) < 1e-3 * rays
+    if scaling == "strong":
+        assert line["config"]["rays_per_step_per_gpu"] == (frame + world - 1) // world          # rank 0's slab: the largest
+    assert line["roofline"]["library"]["embedded"] == line["roofline"]["library"]["tree"]
     if scaling == "weak":
         train = [json.loads(l) for l in r.stderr.splitlines() if l.startswith('{"train"')]
         assert len(train) == 1 and "error" not in train[0]["train"], train
         t = train[0]["train"]
-        assert t["value"] > 0 and t["batch_rays_per_gpu"] == 1024 and t["loss_last"] < t["loss_first"]
+        assert t["value"] > 0 and t["batch_rays_per_gpu"] == (1024 if world == 2 else 128) and t["loss_last"] < t["loss_first"]
+        assert t["dw_half"] is False and "error" not in t["handoff16"] and t["handoff16"]["dw_half"] is True
 
 
-def test_two_rank_training_step_rehearsal_on_one_gpu():
-    """tests/multi_gpu_worker.py with two ranks on one GPU (gloo): the flat all-reduce against the mean of the two ranks' local
-    gradients, and the two-graph GraphedTrainStep (graph | eager all-reduce | graph) keeping both ranks' parameters identical."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_training_step_rehearsal_on_one_gpu(world):
+    """tests/multi_gpu_worker.py with N ranks on one GPU (gloo): the flat all-reduce against the mean of the ranks' local
+    gradients, and the two-graph GraphedTrainStep (graph | eager all-reduce | graph) keeping all ranks' parameters identical."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1",
                NRH_WORKER_SHARE_GPU="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29519", os.path.join("tests", "multi_gpu_worker.py")], cwd=ROOT, env=env, capture_output=True,
-                       text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29519 + world), os.path.join("tests", "multi_gpu_worker.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "MULTI_GPU_WORKER_OK rank 0" in r.stdout and "MULTI_GPU_WORKER_OK rank 1" in r.stdout
+    assert all(f"MULTI_GPU_WORKER_OK rank {k}" in r.stdout for k in range(world))

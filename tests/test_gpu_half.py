@@ -13,7 +13,8 @@ import nrhints_amd as na
 from nrhints_amd import _lib, dw, ops
 
 pytestmark = pytest.mark.gpu
-COUP16 = os.environ.get("NRH_COUP16", "0") != "0"      # experiment switch of the library (csrc/nrh_api.hip coup16_mode): off by default
+# build-time experiment variant of the library (make variant DEFS=-DNRH_COUP16=1, csrc/nrh_api.hip coup16_mode): the default build has it off
+COUP16 = "NRH_COUP16=1" in _lib.load().nrh_build_info().decode()
 T = torch.from_numpy
 NPTS = 32768          # the 8-wave kernels; 16 384 points = the 4-wave builds of the same source (csrc/nrh_small.hip) on 256 CUs
 
@@ -84,7 +85,7 @@ def test_backward_half_arrays_scale_and_invariance(net):
             assert torch.equal(dw.from_half_tiled(r["zbar16"][l]), (rm(ref["zbar"][l]) * S).half()), ("zbar", l)
         assert torch.equal(r["zbar"][0], ref["zbar"][0]) and torch.equal(r["pbar"], ref["pbar"]) and torch.equal(r["coup"], ref["coup"])
     else:
-        # the experiment NRH_COUP16=1: coup - the sweeps' private hand-off - is fp16 as well (S x the value, half-tiled, in the same
+        # the experiment build -DNRH_COUP16=1: coup - the sweeps' private hand-off - is fp16 as well (S x the value, half-tiled, in the same
         # buffer); the value sweep sees it rounded to 11 bits, so zbar agrees with the float32 hand-off's to that rounding only
         coup16 = r["coup"].view(-1).view(torch.float16)[: 8 * NPTS * 256].view(8, NPTS, 256)
         for l in range(8):

@@ -343,7 +343,7 @@ def test_fused_register_view_step_equals_autograd(scene_states):
 def test_fused_step_equals_autograd_path(scene_states, half):
     """Same batch, same jitter through the autograd Functions (forward + train_loss_dict + backward) and through the fused
     sequence: same kernels for the sweeps and the weight gradients, so the results agree to fp32 round-off of the few
-    elementwise expressions that moved from torch into the composite / loss kernels.  ``half``: the fused step with its default
+    elementwise expressions that moved from torch into the composite / loss kernels.  ``half``: the fused step with the OPTIONAL
     16-bit hand-offs of the SDF net's weight-gradient operands (renderer.dw_half; the autograd path keeps float32 arrays and the
     bf16x3 products): the operands' 11-bit rounding shows as up to 1.5e-4 of a tensor's scale - the price measured against the
     reference in tests/test_gpu_train1024.py and profiles/r05/dw16_emulation.log."""

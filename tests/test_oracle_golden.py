@@ -343,6 +343,39 @@ def test_one_hint_and_hint_gradient_training_step_vs_reference(scene_states, vt)
             assert err <= bound, (vt, name, err, bound, scale)
 
 
+HG_COUNTS = {
+    "c4848g": dict(n_samples=48, n_importance_samples=48, up_sample_steps=4, n_shadow_samples=32, n_shadow_importance_samples=32),
+    "c8000g": dict(n_samples=80, n_importance_samples=0, up_sample_steps=4, n_shadow_samples=48, n_shadow_importance_samples=0),
+    "c6464g": dict(n_samples=64, n_importance_samples=64, up_sample_steps=4, n_shadow_samples=64, n_shadow_importance_samples=32),
+}
+
+
+@pytest.mark.parametrize("vt", sorted(HG_COUNTS))
+def test_shadow_hint_gradient_with_sample_counts_vs_reference(scene_states, vt):
+    """renderer.shadow_hint_gradient at shadow-ray counts off the defaults (tests/golden/make_golden_counts_hintgrad.py; :379,
+    :411-432: the differentiable visibility is the transmittance in front of the LAST EXISTING shadow sample): loss, rgb,
+    visibilities and the recorded gradients of one training step."""
+    g = load_npz("render_counts_hintgrad_b.npz")
+    rays = [T(g["t." + k]) for k in ("o", "d", "pl", "near", "far")]
+    st = {k: T(np.asarray(v)).clone().requires_grad_(True) for k, v in scene_states["b"].items()}
+    out = orc.render_forward(orc.params_from_state(st), *rays, background_rgb=torch.ones(1, 3), is_training=True,
+                             global_step=int(g["t.global_step"]), t_rand_primary=T(g[f"{vt}.t_rand_primary"]),
+                             t_rand_shadow=T(g[f"{vt}.t_rand_shadow"]), mode="as_written", differentiable=True,
+                             shadow_hint_gradient=True, **HG_COUNTS[vt])
+    np.testing.assert_allclose(out["rgb"].detach().numpy(), g[f"{vt}.t.rgb"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["visibilities"].detach().numpy(), g[f"{vt}.t.visibilities"], rtol=0, atol=2e-4)
+    loss, _, _ = orc.train_loss(out, T(g["t.rgb_gt"]))
+    np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)
+    loss.backward()
+    keys = [k for k in g if k.startswith(f"{vt}.grad.")]
+    assert len(keys) == 11
+    for k in keys:
+        name = k[len(vt) + 6:]
+        bound, scale = grad_bound(g[k], g[k.replace(".grad.", ".grad64.")])
+        err = float(np.abs(st[name].grad.numpy() - g[k.replace(".grad.", ".grad64.")]).max())
+        assert err <= bound, (vt, name, err, bound, scale)
+
+
 def test_outside_nerf_vs_reference(scene_states):
     """renderer.use_outside_nerf (models/neus_hint_model.py:434-473, :516-519, :630-633, :677-724; fields/nerf_density_field.py):
     the NeRF on its own, the evaluation render (160 weights per ray: 128 blended + 32 beyond the sphere) and one training step's

@@ -1,5 +1,8 @@
-"""The N > 1 path on CPU: world_size-2 gloo processes shard rays, render their slab with a deterministic stand-in
-renderer (the HIP library needs a GPU) and all-gather the pixels; the result must equal the single-process render."""
+"""The N > 1 path on CPU: world_size-2 and world_size-8 gloo processes shard rays, render their slab with a deterministic
+stand-in renderer (the HIP library needs a GPU) and gather the pixels with ONE all_gather_into_tensor on a preallocated flat
+buffer (nrhints_amd/parallel.py); the result must equal the single-process render - for frame sizes that divide evenly over
+the ranks (the gathered buffer IS the frame), that do not (one padding row on the shorter slabs), and that are smaller than the
+world (empty slabs).  ``render_slab``: every rank brings only its own slab."""
 import os
 import socket
 
@@ -10,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import nrhints_amd as na
-from nrhints_amd.parallel import render_sharded, slab_bounds, views_of_rank
+from nrhints_amd.parallel import render_sharded, render_slab, slab_bounds, views_of_rank
 from nrhints_amd.synthetic import make_rays
 
 
@@ -35,9 +38,19 @@ def _worker(rank, world, port, n, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = render_sharded(_fake_render, _bundle(n), fields=("rgb", "depth"))
+        stats = {}
+        res = render_sharded(_fake_render, _bundle(n), fields=("rgb", "depth"), stats=stats)
+        assert res["rgb"].shape == (n, 3) and res["depth"].shape == (n, 1) and stats["host_s"] > 0.0
         np.save(os.path.join(out_dir, f"rgb_{rank}.npy"), res["rgb"].numpy())
         np.save(os.path.join(out_dir, f"depth_{rank}.npy"), res["depth"].numpy())
+        # the same frame with every rank bringing ONLY its slab (no rank holds the other ranks' rays) - and the second frame
+        # reuses the first one's gather buffers
+        lo, hi = slab_bounds(n, rank, world)
+        res2 = render_slab(_fake_render, _bundle(n)[lo:hi], n, fields=("rgb", "depth"))
+        assert torch.equal(res2["rgb"], torch.from_numpy(np.load(os.path.join(out_dir, f"rgb_{rank}.npy"))))
+        if hi - lo != n:
+            with pytest.raises(ValueError):
+                render_slab(_fake_render, _bundle(n), n, fields=("rgb",))
     finally:
         dist.destroy_process_group()
 
@@ -52,14 +65,14 @@ def test_slab_bounds_cover_everything():
     assert views_of_rank(10, 1, 4) == [1, 5, 9] and views_of_rank(10, 0, 2, skip=2) == [0, 4, 8]
 
 
-@pytest.mark.parametrize("n", [1001, 64])
-def test_two_rank_sharded_render_matches_single_process(tmp_path, n):
+@pytest.mark.parametrize("world,n", [(2, 1001), (2, 64), (8, 4096), (8, 4099), (8, 5)])
+def test_sharded_render_matches_single_process(tmp_path, world, n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
     ref = _fake_render(_bundle(n))
-    for rank in range(2):
+    for rank in range(world):
         # torch's CPU sigmoid takes different SIMD/remainder paths for different slab lengths: allow 1 ulp
         np.testing.assert_allclose(np.load(tmp_path / f"rgb_{rank}.npy"), ref.rgb.numpy(), rtol=0, atol=2e-7)
         np.testing.assert_allclose(np.load(tmp_path / f"depth_{rank}.npy"), ref.depth.numpy(), rtol=0, atol=1e-6)
