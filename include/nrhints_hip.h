@@ -121,7 +121,7 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
  * consumer of the weight-gradient operands - a caller that ran its own GEMMs over them as if they were row-major would get wrong
  * gradients silently.  (nrhints_amd/dw.py: from_tiled is the de-tiling used by the tests.)  ROW-MAJOR are only: feat_rows
  * [npts,256], save_ge [npts][128], gebar [npts][64], pbar [npts,3], and every array of the reflectance network's training entries.
- * npts = nrays * n_per_ray must be a multiple of 16 and < 2^24 (32-bit element offsets inside a layer).
+ * npts = nrays * n_per_ray must be a multiple of 16 and < 2^22 = 4 194 304 (32-bit byte offsets inside a layer; checked, NRH_E_INVALID).
  *
  * nrh_sdf_train_forward: as nrh_sdf_eval mode 2 (sdf [npts], grad [npts,3]) with the feature ROW-MAJOR feat_rows
  *   [npts,256], plus  save_h [8][npts][256] (softplus outputs; layer 3 already holds the skip concatenation),

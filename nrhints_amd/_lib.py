@@ -68,6 +68,28 @@ def adjoint_scale(n_rays: int) -> float:
     return float(2.0 ** max(0, round(math.log2(max(1, int(n_rays)) / 8.0))))
 
 
+def adjoint_scale_from_seeds(seeds, n_rays: int) -> float:
+    """``adj_scale`` for the generic autograd Functions (SdfValueFeatGradHip, ColorNetHip, OutsideNetHip), whose caller's loss need
+    not be normalised by the ray count (sum-reduced or custom losses, register_view variants): the power of two that brings the
+    LARGEST incoming adjoint to [8, 16) - what adjoint_range_kernel computes on the device for the 16-bit hand-offs - so the f16x3
+    chains can neither underflow (1 / rays losses at large batches) nor overflow fp16's 65 504 (sum-reduced ones) whatever the
+    loss.  One host read of the seeds' maximum per backward; under hipGraph capture (no host read possible) and for empty or
+    non-finite seeds it falls back to the 1 / rays convention of ``adjoint_scale``.  Ignored by precision f32."""
+    import math
+
+    import torch
+    if torch.cuda.is_current_stream_capturing():
+        return adjoint_scale(n_rays)
+    mx = 0.0
+    for t in seeds:
+        if t is not None and t.numel():
+            mx = max(mx, float(t.detach().abs().max()))
+    if not (0.0 < mx < 3.0e38):          # zero, inf or NaN seeds: nothing to scale (NaN propagates into the gradients, loudly)
+        return adjoint_scale(n_rays)
+    e = 4 - math.frexp(mx)[1]            # mx = f 2^k, f in [0.5, 1)  ->  mx 2^(4 - k) in [8, 16)
+    return float(2.0 ** max(-60, min(60, e)))
+
+
 class HipExtensionMissing(RuntimeError):
     pass
 

@@ -133,7 +133,8 @@ class ColorNetHip(torch.autograd.Function):
         P = _lib.ptr
         cwt = packed["col_wt"]
         _lib.check(lib.nrh_color_train_backward(packed["precision"], int(hints), P(cwt, cwt.dtype), P(zbar4), P(save_h), n, P(zbar),
-                                                P(fbar), P(mbar), _lib.adjoint_scale(n), _lib.stream_handle()), "nrh_color_train_backward")
+                                                P(fbar), P(mbar), _lib.adjoint_scale_from_seeds((zbar4,), n), _lib.stream_handle()),
+                   "nrh_color_train_backward")
         nm = 105 if hints else 60
         grads_in = (fbar, mbar[:, 0:3], mbar[:, 3:6], mbar[:, 6:nm].reshape(ctx.rows, Pn // ctx.rows, nm - 6).sum(1), None)
         if not any(ctx.needs_input_grad[5:]):

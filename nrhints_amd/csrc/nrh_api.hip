@@ -566,6 +566,8 @@ static int sdf_train_forward_impl(int precision, const float* sdf_w, const float
     return fail(NRH_E_INVALID, "nrh_sdf_train_forward: null pointer%s", "");
   if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: bad n_per_ray/stride%s", "");
   if ((nrays * n_per_ray) % 16 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: the number of points must be a multiple of 16%s", "");
+  // (32-bit lane offsets inside a layer of the saved arrays, csrc/nrh_mlp.h arr_ptr: npts * 1 KiB must stay below 4 GiB)
+  if (nrays * n_per_ray >= (1LL << 22)) return fail(NRH_E_INVALID, "nrh_sdf_train_forward: at most 4 194 303 points per call%s", "");
   if (nrays == 0) return NRH_OK;
   int rc = ensure_attrs();
   if (rc) return rc;
@@ -640,6 +642,7 @@ static int sdf_train_backward_impl(int precision, const float* sdf_w, const floa
     return fail(NRH_E_INVALID, "nrh_sdf_train_backward: null pointer%s", "");
   if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: bad n_per_ray/stride%s", "");
   if ((nrays * n_per_ray) % 16 != 0) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: the number of points must be a multiple of 16%s", "");
+  if (nrays * n_per_ray >= (1LL << 22)) return fail(NRH_E_INVALID, "nrh_sdf_train_backward: at most 4 194 303 points per call%s", "");
   if (nrays == 0) return NRH_OK;
   int rc = ensure_attrs();
   if (rc) return rc;
@@ -658,8 +661,8 @@ static int sdf_train_backward_impl(int precision, const float* sdf_w, const floa
                   "(nrh_train_half_supported) and 16-byte aligned arrays%s", "");
     nrh::AdjRangeArgs ra;
     ra.sbar = sbar; ra.gbar = gbar; ra.fbar = fbar; ra.dyn = dyn; ra.npts = a.npts;
-    const long long want = (a.npts * 64 / 8 + 255) / 256;
-    hipLaunchKernelGGL(nrh::adjoint_range_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want))), dim3(256), 0, st, ra);
+    const long long want = (a.npts * 64 / 8 + 255) / 256;          // (every row of fbar is read: 1 024 blocks keep HBM busy)
+    hipLaunchKernelGGL(nrh::adjoint_range_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want))), dim3(256), 0, st, ra);
     rc = check_launch("adjoint_range_kernel");
     if (rc) return rc;
     a.abar16 = abar16; a.zbar16 = zbar16; a.dyn = dyn;

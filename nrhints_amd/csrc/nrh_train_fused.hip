@@ -261,25 +261,32 @@ struct AdjRangeArgs {
 };
 __global__ __launch_bounds__(256) void adjoint_range_kernel(const AdjRangeArgs a) {
   const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
-  float m = 0.0f;
-  for (long long i = tid; i < a.npts; i += nth) m = fmaxf(m, fabsf(a.sbar[i]));
-  for (long long i = tid; i < a.npts * 3; i += nth) m = fmaxf(m, fabsf(a.gbar[i]));
-  const long long nf = (a.npts + 7) / 8 * 64;          // float4 words of the sampled rows
+  // |x| as its bit pattern: non-negative floats order like their bits, and a NaN or inf seed (bits >= 0x7f800000) wins the maximum
+  // instead of being dropped by fmaxf - it then fails the range test below (S = 1) and propagates through the chain into the
+  // gradients, which is the loud outcome.  EVERY row of fbar is scanned (134 MB at 1 024 rays, ~30 us): an outlier
+  // in an unsampled row would have over-estimated S against fp16's 65 504.
+  unsigned int mb = 0u;
+  auto take = [&](float x) { const unsigned int b = __float_as_uint(x) & 0x7fffffffu; mb = b > mb ? b : mb; };
+  for (long long i = tid; i < a.npts; i += nth) take(a.sbar[i]);
+  for (long long i = tid; i < a.npts * 3; i += nth) take(a.gbar[i]);
+  const long long nf = a.npts * 64;                     // float4 words of fbar [npts, 256]
   for (long long i = tid; i < nf; i += nth) {
-    const long long row = (i >> 6) * 8;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a.fbar + row * 256 + (i & 63) * 4);
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.fbar + i * 4);
+    take(v[0]); take(v[1]); take(v[2]); take(v[3]);
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o); mb = t > mb ? t : mb; }
+  const float m = __uint_as_float(mb);
   __shared__ float wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   unsigned int* const w = reinterpret_cast<unsigned int*>(a.dyn);
   if (threadIdx.x == 0) {
-    // one pair of atomics per block (per wave they serialised to 50 us on 2 048 waves); non-negative floats order like their bit
-    // patterns; NaN seeds (bits above +inf) are caught below
-    atomicMax(w + 2, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+    // one pair of atomics per block (per wave they serialised to 50 us on 2 048 waves); bit patterns again (NaN / inf on top)
+    unsigned int bm = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned int b = __float_as_uint(wm[k]); bm = b > bm ? b : bm; }
+    atomicMax(w + 2, bm);
     __threadfence();
     if (atomicAdd(w + 3, 1u) == gridDim.x - 1) {
       const float mx = __uint_as_float(atomicMax(w + 2, 0u));

@@ -164,7 +164,7 @@ class OutsideNetHip(torch.autograd.Function):
             wt = pack_outside(params, precision, transposed=True)
             walpha = params[20].detach().float().reshape(-1).contiguous()
             _lib.check(lib.nrh_outside_backward(precision, P(wt, wt.dtype), P(walpha), P(dbar), P(cbar), P(sh), P(shv), npts, P(zbar), P(fbar),
-                                                P(zvbar), P(xbar), P(vbar), _lib.adjoint_scale(npts // max(1, ppr)), _lib.stream_handle()),
+                                                P(zvbar), P(xbar), P(vbar), _lib.adjoint_scale_from_seeds((dbar, cbar), npts // max(1, ppr)), _lib.stream_handle()),
                        "nrh_outside_backward")
             g = [torch.empty_like(p, dtype=torch.float32) for p in params]      # weight, bias pairs in parameter order
             J = dw.Job

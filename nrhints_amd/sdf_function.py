@@ -102,10 +102,10 @@ class SdfValueFeatGradHip(torch.autograd.Function):
 
         sb, fb, gb = full(sbar, 1), full(fbar, 256), full(gbar, 3)
         ro, rd, tt, npr = ctx.rays
-        # (m // 128 rays: the loss of a training step is normalised by the ray count, 128 sample points per ray)
+        # the adjoint scale follows the incoming adjoints (whatever the caller's loss normalisation; _lib.adjoint_scale_from_seeds)
         from . import _lib as _l
         r = ops.sdf_train_backward(packed["sdf_w"], packed["sdf_wt_feat"], packed["sdf_head"], ro, rd, tt, npr, saves,
-                                   sb.reshape(-1), fb, gb, adj_scale=_l.adjoint_scale(m // 128))
+                                   sb.reshape(-1), fb, gb, adj_scale=_l.adjoint_scale_from_seeds((sb, fb, gb), m // 128))
         zbar, abar, h, t = r["zbar"], r["abar"], saves["h"], saves["t"]
         p_bar = None
         if ctx.needs_input_grad[0]:       # only pose / light refinement asks for the points' adjoint

@@ -35,12 +35,36 @@ class SmiPoller:
 
     def __init__(self):
         self.freq = self.power = None
-        for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
-            if os.path.exists(os.path.join(h, "freq1_input")) and self.freq is None:
+        want = None
+        try:       # the card torch runs on (a box shows all eight cards of the node in sysfs; only one is visible to HIP)
+            pr = torch.cuda.get_device_properties(0)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001
+            pass
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+            slot = ""
+            try:
+                for line in open(os.path.join(dev, "uevent")):
+                    if line.startswith("PCI_SLOT_NAME="):
+                        slot = line.strip().split("=", 1)[1]
+            except Exception:  # noqa: BLE001
+                pass
+            for h in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                cards.append((slot, h))
+        self.card = None
+        for slot, h in cards:
+            if want is not None and slot.lower() != want.lower():
+                continue
+            if os.path.exists(os.path.join(h, "freq1_input")):
                 self.freq = os.path.join(h, "freq1_input")
             for name in ("power1_average", "power1_input"):
                 if os.path.exists(os.path.join(h, name)) and self.power is None:
                     self.power = os.path.join(h, name)
+            if self.freq or self.power:
+                self.card = slot
+                break
+        print("visible device", want, "-> hwmon of", self.card, "(of", len(cards), "cards in sysfs)", flush=True)
         self.samples, self._stop, self._t = [], False, None
 
     def _read(self, path, scale):
