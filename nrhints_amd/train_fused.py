@@ -112,7 +112,7 @@ class _Buffers:
 
 def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_rgb: Optional[torch.Tensor], global_step: int,
                         igr_weight: Optional[float] = None, t_rand_primary=None, t_rand_shadow=None, is_training: bool = True,
-                        ray_grads: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                        ray_grads: Optional[Dict[str, torch.Tensor]] = None, forward_out: Optional[dict] = None) -> torch.Tensor:
     """Forward + loss + backward of one batch.  Returns the loss vector [8] on the device (``LOSS_KEYS`` = entries 0..4) and sets
     ``.grad`` of every renderer parameter (overwriting, like zero_grad + backward) - unless the renderer's parameters are frozen
     (``requires_grad_(False)``, as in register_view), in which case the weight gradients, the weight-norm adjoint and the variance
@@ -123,7 +123,12 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
     Ray gradients: if any of the bundle's origins / directions / pl_positions requires grad, their adjoints are computed
     (nrh_ray_adjoint) and - ``ray_grads`` None - pushed into the autograd graph that produced the bundle (the ray generator's
     backward), accumulating ``.grad`` on its parameters like ``loss.backward()``; with a dict ``ray_grads`` they are returned in it
-    (keys origins / directions / pl_positions; persistent buffers) and nothing is propagated."""
+    (keys origins / directions / pl_positions; persistent buffers) and nothing is propagated.
+    ``forward_out`` (tests / diagnostics): a dict that receives THIS step's forward products - mid_z, dists [n,128], visibilities
+    [n,1], cue [n,128,4], weights, inside, and the SDF network's outputs at the samples (sdf [P,1], normals [n,128,3], feat
+    [P,256]) - i.e. the sample placement and linearisation point of the gradients this call leaves in ``.grad``.  (A separate
+    _render_train call is NOT guaranteed to place the same samples: this step folds weight-norm with nrh_weight_norm_fold, other
+    paths with torch ops, and a last-bit difference in a weight moves importance samples where the pdf sits at its floor.)"""
     why = supported(renderer, ray_bundle)
     if why is not None:
         raise ValueError(f"fused training step not applicable: {why}")
@@ -198,6 +203,9 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         half = (pk["precision"] == 1 and bool(getattr(renderer, "dw_half", False)) and bool(lib.nrh_train_half_supported(1, Pn)))
         res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half)
         pre, sv = res["pre"], res["pre"]["saves"]
+        if forward_out is not None:
+            forward_out.update({k: res[k] for k in ("mid_z", "dists", "visibilities", "cue", "weights", "inside", "normals", "depth")})
+            forward_out.update(sdf=pre["sdf"], feat=pre["feat"], vis_groups=res.get("vis_groups"))
         # ---- reflectance forward ----
         pts3 = B.pts.view(n, 128, 3)                       # p = o + d * t with separate roundings, as the SDF kernels form it
         torch.mul(d[:, None, :], res["mid_z"][..., None], out=pts3)

@@ -32,20 +32,18 @@ def main():
     model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
     model = model.cuda()
     rays_c = tuple(cu(g[k]) for k in ("o", "d", "pl", "near", "far"))
-    z, vis, cue, net, (mid, dist) = hip_placement(model, rays_c, gs, cu(g[p + "t_rand_primary"]), cu(g[p + "t_rand_shadow"]))
     rb = na.RayBundle(origins=rays_c[0], directions=rays_c[1], pl_positions=rays_c[2], nears=rays_c[3], fars=rays_c[4])
+    fwd = {}
     train_fused.train_step_backward(model, rb, cu(g["rgb_gt"]), torch.ones(1, 3).cuda(), gs, t_rand_primary=cu(g[p + "t_rand_primary"]),
-                                    t_rand_shadow=cu(g[p + "t_rand_shadow"]))
+                                    t_rand_shadow=cu(g[p + "t_rand_shadow"]), forward_out=fwd)
+    z, vis, cue, net, (mid, dist) = hip_placement(fwd)          # the step's OWN forward (a separate call may place samples differently)
     B = next(iter(model._fused_buffers.values()))
     n = 1024
     rgb_hip = B.rgb.cpu().double().numpy()
     col_hip = B.color.cpu().double().numpy().reshape(n, 128, 3)
-    # the HIP forward's own weights: a second _render_train (deterministic kernels)
-    o, d, pl, near, far = rays_c
+    w_hip = fwd["weights"].cpu().double().numpy()
     cos_anneal = min(1.0, gs / 50000)
-    res = model._render_train(o, d, pl, near.reshape(-1), far.reshape(-1), cos_anneal, cu(g[p + "t_rand_primary"]).reshape(-1),
-                              cu(g[p + "t_rand_shadow"]), 0)
-    w_hip = res["weights"].cpu().double().numpy()
+    res = dict(inside=fwd["inside"])
     params = orc.params_from_state({k: T(np.asarray(v)).double() for k, v in st.items()}, torch.float64)
     r64 = [T(np.asarray(g[k])).double() for k in ("o", "d", "pl", "near", "far")]
     for label, netov in (("same placement only", None), ("same placement + same sdf / grad / feat", net)):
@@ -63,6 +61,12 @@ def main():
         print(f"== {label}: max |rgb| diff {drgb.max():.3e} (median ray {np.median(drgb):.2e}); max |w| diff {dw.max():.3e}; "
               f"max |colour| diff {dc.max():.3e}; max |colour| diff weighted by w {np.max(dc * w):.3e}")
         worst = np.argsort(-drgb)[:4]
+        if netov is not None and len(sys.argv) > 3:        # dump the worst rays' per-sample arrays for offline analysis
+            rr = worst
+            np.savez(sys.argv[3], rays=rr, sdf_hip=net["sdf"].numpy().reshape(n, 128)[rr], grad_hip=net["grad"].numpy().reshape(n, 128, 3)[rr],
+                     mid=mid.numpy()[rr], dist=dist.numpy()[rr], w_hip=w_hip[rr], w_orc=w[rr], alpha_orc=out["alpha"].numpy()[rr],
+                     sdf_orc=sdf[rr], d=r64[1].numpy()[rr], o=r64[0].numpy()[rr], inv_s=inv_s, cos_anneal=cos_anneal,
+                     inside_hip=res["inside"].cpu().numpy()[rr], z=z.numpy()[rr])
         sdf = out["sdf"].numpy()
         inv_s = float(orc.inv_s_of(params))
         for r in worst:

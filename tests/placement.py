@@ -69,16 +69,12 @@ def oracle_step_at_placement(state, rays, rgb_gt, global_step, z, vis, cue, t_ra
     return losses, pgrads, rgrads, torch.cat(rgbs).numpy()
 
 
-def hip_placement(model, rays_cuda, global_step, t_rand_primary, t_rand_shadow):
-    """The non-differentiable products of the HIP training forward for this batch: (z [N,128], vis [N,1], cue [N,4]) as float64
-    CPU tensors, plus the SDF network's outputs at those samples (dict sdf / grad / feat: the forward VALUES the HIP backward
-    linearises at) and the sections (mid, dists) as the kernels hold them.  ``rays_cuda``: (o, d, pl, near, far) float32 CUDA tensors; deterministic kernels: the same call inside the fused
-    step places the same samples."""
-    o, d, pl, near, far = (t.detach().float().contiguous() for t in rays_cuda)
-    cfg = model.config
-    cos_anneal = min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0
-    res = model._render_train(o, d, pl, near.reshape(-1), far.reshape(-1), cos_anneal, t_rand_primary.reshape(-1).contiguous(),
-                              t_rand_shadow.contiguous(), 0)
-    mid, dist = res["mid_z"].double().cpu(), res["dists"].double().cpu()
-    net = dict(sdf=res["pre"]["sdf"].double().cpu(), grad=res["normals"].reshape(-1, 3).double().cpu(), feat=res["pre"]["feat"].double().cpu())
-    return mid - 0.5 * dist, res["visibilities"].double().cpu().reshape(-1, 1), res["cue"][:, 0, :].double().cpu(), net, (mid, dist)
+def hip_placement(forward_out):
+    """The non-differentiable products of a fused training step's forward, from the dict ``train_fused.train_step_backward(...,
+    forward_out=...)`` filled: (z [N,128], vis [N,1], cue [N,4]) as float64 CPU tensors, plus the SDF network's outputs at those
+    samples (dict sdf / grad / feat: the forward VALUES the HIP backward linearises at) and the sections (mid, dists) as the kernels
+    hold them.  Taken from the step ITSELF: a separate forward call may place samples differently (see train_step_backward)."""
+    f = forward_out
+    mid, dist = f["mid_z"].double().cpu(), f["dists"].double().cpu()
+    net = dict(sdf=f["sdf"].double().cpu(), grad=f["normals"].reshape(-1, 3).double().cpu(), feat=f["feat"].double().cpu())
+    return mid - 0.5 * dist, f["visibilities"].double().cpu().reshape(-1, 1), f["cue"][:, 0, :].double().cpu(), net, (mid, dist)
