@@ -192,7 +192,12 @@ def pack_sdf(d: Dict[str, torch.Tensor], precision: int = 0) -> Tuple[torch.Tens
     precision 0: float32 [SDF_PACKED_FLOATS]; precision 1 (f16x3): float16 [2 * SDF_PACKED_FLOATS]."""
     ps = pack_stage if precision == 0 else pack_stage_h3
     w = [d[f"sdf_w{i}"] for i in range(8)]
-    w4 = w[4] / math.sqrt(2.0)           # cat([h, embed]) / sqrt(2) folded into the weights
+    # cat([h, embed]) / sqrt(2) folded into the weights.  A TRUE float32 division by float32(sqrt 2), element by element, as
+    # PackPlan and nrh_pack_gather do it: ``tensor / python_float`` is a multiplication by the reciprocal on the GPU (and a
+    # division on the CPU), which made this direct packer and the plan differ in the last bit of 42 % of W4's entries - enough to
+    # move importance samples where the pdf sits at its floor, so an evaluation render (this packer) and a training forward (the
+    # plan) of the same parameters placed their samples differently (round 6, profiles/pack_route_probe.py).
+    w4 = w[4] / torch.full_like(w[4], math.sqrt(2.0))
     fwd = [w[0], w[1], w[2], w[3], w4, w[5], w[6], w[7]]
     regular = [fwd[l] for l in range(1, 8)] + [d["feat_w"]] + [fwd[l].t() for l in range(7, 0, -1)]
     packed = torch.cat([ps(fwd[0], 256, 64), pack_stages(regular, 256, 256, precision), ps(fwd[0].t(), 64, 256)])

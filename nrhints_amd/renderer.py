@@ -213,7 +213,13 @@ class NeuSHintRenderer(nn.Module):
                 variance = self.deviation_network.variance.detach().to(device=device, dtype=torch.float32)
                 if dense is None:
                     state = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items()}
-                    d = self._pad_hint_columns(packing.dense_params(state))
+                    # ONE fold for every path on the GPU: nrh_weight_norm_fold, the kernel the training paths fold with.  The torch
+                    # expression v * (g / |v|) differs from it in last bits, and a last-bit change of a weight moves importance
+                    # samples by a whole bin where the pdf sits at its floor - with two folds an evaluation render and a training
+                    # forward of the SAME parameters placed 20 % of their samples differently (profiles/train_forward_determinism.py,
+                    # round 6).  (CPU tensors - the packing tests of the emulators - keep the torch expression.)
+                    fold = packing.dense_params_hip if torch.device(device).type == "cuda" else packing.dense_params
+                    d = self._pad_hint_columns(fold(state))
                     packing.check_default_shapes(d, hints)
                     sw, sb, sh = packing.pack_sdf(d, prec)
                     cw, cb = packing.pack_color(d, prec, hints)

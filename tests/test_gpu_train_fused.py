@@ -426,6 +426,16 @@ def test_pack_plans_on_gpu_bit_identical(scene_states):
             a, b = want[k], got[k].cpu()
             assert a.dtype == b.dtype and torch.equal(a.view(torch.int16 if a.dtype == torch.float16 else torch.int32),
                                                       b.view(torch.int16 if b.dtype == torch.float16 else torch.int32)), (prec, k)
+        # ... and the DIRECT packers run on GPU tensors (what an evaluation render packs with) give the same bits as the plan (what a
+        # training step packs with): round 6 found W4 / sqrt(2) a multiplication by the reciprocal there (torch's tensor / scalar on
+        # the GPU) - a last-bit difference that moved importance samples between the two routes
+        sw, sb, sh = pk.pack_sdf(d_gpu, prec)
+        cw, cb = pk.pack_color(d_gpu, prec, True)
+        for name, direct in (("sdf_w", sw), ("sdf_b", sb), ("sdf_head", sh), ("col_w", cw), ("col_b", cb),
+                             ("sdf_wt_feat", pk.pack_feat_transposed(d_gpu, prec))):
+            a, b = got[name], direct
+            assert a.dtype == b.dtype and torch.equal(a.view(torch.int16 if a.dtype == torch.float16 else torch.int32),
+                                                      b.view(torch.int16 if b.dtype == torch.float16 else torch.int32)), (prec, name, "direct packer")
     ws, wt = pk32.PackPlan32(d_cpu).pack(d_cpu)
     gs, gt = pk32.PackPlan32(d_gpu).pack(d_gpu)
     assert torch.equal(ws.view(torch.int16), gs.cpu().view(torch.int16))
@@ -590,3 +600,39 @@ def test_fused_step_off_default_branches(scene_states, vt, prec):
             assert torch.equal(pg.detach(), before[name]), name
     finally:
         step.release()
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_every_path_places_the_same_samples(scene_states, prec):
+    """The same parameters, rays and jitter place the SAME samples whichever path evaluates them - the fused step's forward
+    (train_step_backward forward_out), the autograd path's forward, a bare _render_train and the evaluation pack - bit for bit.
+    Round 6 found them different: the evaluation pack folded weight-norm with torch ops, the training paths with
+    nrh_weight_norm_fold; the two W differ in last bits, and a 1e-7 change of the SDF moves importance samples by a whole bin
+    where the pdf sits at its floor (20 % of the samples of a 1 024-ray batch).  One fold kernel for all of them now
+    (renderer.packed_params)."""
+    n = 512
+    rs = np.random.RandomState(11)
+    rb = _bundle(*make_rays(n, seed=21, spread=0.1))
+    gt, tp, ts = (cu(rs.rand(n, k).astype(np.float32)) for k in (3, 1, 64))
+    bg = torch.ones(1, 3).cuda()
+    f32 = lambda t: t.detach().float().contiguous()
+    # 1. a bare training forward on a fresh model (pack built by packed_params(dense=None), the evaluation pack's route)
+    a = _model(scene_states["b"], prec)
+    res = a._render_train(f32(rb.origins), f32(rb.directions), f32(rb.pl_positions), f32(rb.nears).reshape(-1), f32(rb.fars).reshape(-1),
+                          30000 / a.config.anneal_end, tp.reshape(-1).contiguous(), ts, 0)
+    # 2. the fused step on another fresh model
+    b = _model(scene_states["b"], prec)
+    fwd = {}
+    train_fused.train_step_backward(b, rb, gt, bg, 30000, t_rand_primary=tp, t_rand_shadow=ts, forward_out=fwd)
+    # 3. the autograd path on a third
+    c = _model(scene_states["b"], prec)
+    out = c(rb, is_training=True, background_rgb=bg, global_step=30000, _t_rand_primary=tp, _t_rand_shadow=ts)
+    for k in ("mid_z", "dists", "weights", "visibilities", "depth"):
+        assert torch.equal(res[k], fwd[k]), (k, float((res[k] - fwd[k]).abs().max()))
+    assert torch.equal(res["pre"]["sdf"], fwd["sdf"]) and torch.equal(res["normals"], fwd["normals"])
+    assert torch.equal(out.weights.detach(), fwd["weights"]) and torch.equal(out.visibilities.detach(), fwd["visibilities"])
+    assert torch.equal(out.analytic_normals.detach(), fwd["normals"])
+    # ... and after the fused step the same model's bare forward still places them there (the cached pack is the step's)
+    res2 = b._render_train(f32(rb.origins), f32(rb.directions), f32(rb.pl_positions), f32(rb.nears).reshape(-1), f32(rb.fars).reshape(-1),
+                           30000 / b.config.anneal_end, tp.reshape(-1).contiguous(), ts, 0)
+    assert torch.equal(res2["mid_z"], fwd["mid_z"]) and torch.equal(res2["weights"], fwd["weights"])
