@@ -20,7 +20,7 @@ reachable offline.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      dominant kernel (SDF value+feature+gradient at the 128 composite samples), timed live with HIP
-                events inside the timed region; algorithmic FLOPs per point are in DESIGN.md
+                events inside the timed region; algorithmic FLOPs per point are in DESIGN.md section 3
   cpu_baseline  the CPU oracle in "as written" mode (the reference's call pattern, eager fp32 PyTorch) on a bounded
                 sample of the same rays: 4096 rays in 512-ray chunks, 1 warm-up + 3 repeats, median (BASELINE.md §4;
                 rank 0, N = 1 only)
@@ -56,11 +56,11 @@ from nrhints_amd import _lib  # noqa: E402
 from nrhints_amd.synthetic import make_image_rays, make_rays, perturb_state, psnr  # noqa: E402
 
 H = W = 800
-# algorithmic multiply-accumulates per evaluated point (SURVEY.md §8d / DESIGN.md §4)
+# algorithmic multiply-accumulates per evaluated point (SURVEY.md §8d / DESIGN.md section 3)
 MAC_F_FULL, MAC_F_SDF, MAC_G, MAC_C = 524_544, 459_008, 459_008, 289_792
 FLOP_PER_RAY = 2 * (224 * MAC_F_SDF + 128 * (MAC_F_FULL + MAC_G) + 128 * (MAC_F_SDF + MAC_G) + 128 * MAC_C)
 FLOP_PER_POINT_CORE = 2 * (MAC_F_FULL + MAC_G)   # the dominant kernel: sdf + feature + gradient per point
-# one training ray-step: the evaluation path without the reflectance forward's share of the no-grad pass,
+# one training ray-step (CHANGELOG.md section 7a): the evaluation path without the reflectance forward's share of the no-grad pass,
 # plus training forward (F + C), tangent and value sweeps (2 G + F), reflectance adjoint (C) and the weight gradients
 FLOP_PER_RAY_STEP = 1.4186e9
 # MI355X_MICROARCH.md dense MFMA peaks: fp32-input 157.3 TFLOP/s; fp16 2 500 TFLOP/s.  The f16x3 mode spends three
@@ -446,7 +446,7 @@ def train_leg(dev, rank, world, dist, batch=1024, steps=30, warm=3, global_batch
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
             **({"repeats_ms": [round(b / steps * 1e3, 3) for b in block_s]} if nblocks > 1 else {}),
             "bound_note": "the step's big kernels (SDF training forward, dW, tangent / value sweeps, reflectance adjoint) move the saved "
-                          "activations through HBM at 4-5.5 TB/s (profiles/r05/pmc_train_summary.txt, DESIGN.md 'training step'); the MFMA "
+                          "activations through HBM at 4-5.5 TB/s (profiles/r05/pmc_train_summary.txt, DESIGN.md section 3); the MFMA "
                           "fraction below is the SURVEY 8d convention",
             "roofline": {"bound": "mfma", "algorithmic_gflop_per_ray_step": round(FLOP_PER_RAY_STEP / 1e9, 4),
                          "achieved": round(value * FLOP_PER_RAY_STEP / 1e12 / world, 2), "peak": peak, "unit": "TFLOP/s",

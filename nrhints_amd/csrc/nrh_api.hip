@@ -1505,7 +1505,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
   if (train) {
     // training: the same evaluation with the feature row-major and the arrays the backward sweeps need (16-point kernels: a wide
     // one-wave-per-SIMD form was built in round 4, measured slower - its row stores do not overlap a single wave's MFMA stream,
-    // DESIGN.md section 7c - and removed in round 5)
+    // CHANGELOG.md section 7c - and removed in round 5)
     rc = sdf_train_forward_impl(net->precision, net->sdf_w, net->sdf_b, net->sdf_head, origins, directions, o_tmid, 128, 128, n,
                                sdf_c, o_grad, train->feat_rows, train->save_h, train->save_s1, train->save_t, train->save_ge, train->save_h16, train->save_t16, stream);
   } else {

@@ -18,7 +18,7 @@
 //   * a product is three MFMAs, hi*hi + hi*lo + lo*hi (the 3-term split of the f16x3 kernels, in bf16 because adjoints have no
 //     a-priori range: bf16 keeps float32's exponent, so nothing is scaled and nothing can overflow); operands carry 16 mantissa
 //     bits, products are exact in the fp32 accumulator: |error| <= 2^-16 per term, measured 4e-6 of an entry's own magnitude
-//     against 2.5e-7 for an fp32 GEMM in another summation order (the parity bound is 1e-4);
+//     against 2.5e-7 for an fp32 GEMM in another summation order (CHANGELOG.md section 7a; the parity bound is 1e-4);
 //   * the kernel is bound by HBM latency x bytes in flight: with the rows loaded into registers one step ahead it ran at
 //     1.5-2.3 TB/s (hipcc drains vmcnt to 0 before the first use of any loaded register, and copies the destination registers of
 //     asm loads while they are in flight), hence the DMA: 64 KB per CU stay in flight across MFMAs, conversion and barriers;

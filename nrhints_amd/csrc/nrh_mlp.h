@@ -68,7 +68,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //                  hi_x*hi_w + 2^-11 (hi_x*lo_w + lo_x*hi_w) with three v_mfma_f32_16x16x32_f16 into two fp32
 //                  accumulators.  The dropped lo*lo term and the fp16 rounding of lo are both ~2^-22 relative, i.e.
 //                  fp32 round-off class (measured on the SDF net: same error against fp64 as the fp32 chain,
-//                  DESIGN.md §5), at 16/3 of the fp32 matrix rate.
+//                  CHANGELOG.md section 5), at 16/3 of the fp32 matrix rate.
 constexpr float LO_SCALE = 2048.0f;
 constexpr float LO_UNSCALE = 1.0f / 2048.0f;
 
@@ -274,7 +274,7 @@ __device__ __forceinline__ void run_stage(const float* __restrict__ wsrc, const 
 // sigma' and coup are private to these kernels; h, t, abar, zbar are operands of nrh_dw_gemm, which is told per operand
 // (NrhDwJob.tiled_a / tiled_b) and rotates a block's rows by the block index on their way into LDS (the lanes of its LDS-DMA
 // fetch permuted addresses), so that its conversion reads two adjacent channels of 16 points without a bank conflict.
-// What round 5 measured: written as one 64-bit sum per access, a tiled address needs its own register pair
+// What round 5 measured (CHANGELOG.md section 7g): written as one 64-bit sum per access, a tiled address needs its own register pair
 // per 16-channel block (the blocks lie 1 KiB apart, beyond the instruction's immediate offset, where row-major blocks are 64 bytes
 // apart), which the 8-wave kernels - already at 256 registers - paid in 40-90 spilled registers, and the gain was gone; split
 // into a wave-uniform and a 32-bit lane part (arr_ptr below) nothing spills in the sweeps and sigma' tiled is worth +3 %.

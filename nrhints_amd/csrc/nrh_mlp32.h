@@ -1,7 +1,7 @@
 // "Wide" per-point MLP machinery for gfx950, precision mode f16x3: one wavefront per SIMD, 512 registers, 32-point tiles.
 //
 // Same transposed register chain as nrh_mlp.h (H_out^T = W * H_in^T, activations never leave registers between layers),
-// re-shaped around what limited the 16-point / 2-waves-per-SIMD form:
+// re-shaped around what limited the 16-point / 2-waves-per-SIMD form (CHANGELOG.md section 4.1):
 //   * v_mfma_f32_32x32x16_f16: a wave owns 32 points, so every weight fragment read from LDS feeds twice the FLOPs
 //     (half the ds_read_b128 and half the LDS-DMA pieces per FLOP) and MFMAs are 32 cycles apart: room for VALU fillers.
 //   * 4 waves per workgroup, ONE per SIMD (amdgpu_waves_per_eu(1,1)): 256 arch VGPRs + 256 AGPRs per wave.  The B operands

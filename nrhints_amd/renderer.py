@@ -106,7 +106,7 @@ class NeuSHintRenderer(nn.Module):
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate), or - a
     #: REDUCED-precision evaluation mode, never the default - "f16": f16x3 in everything (packing, training, the reflectance net)
     #: except that an evaluation render runs the wide SDF kernels in their single-pass builds (one fp16 MFMA per K step: weights
-    #: and activations of the SDF network at 11 bits; PSNR against the reference 73-85 dB on the test scenes)
+    #: and activations of the SDF network at 11 bits; PSNR against the reference 73-85 dB on the test scenes, CHANGELOG.md section 7h)
     precision = "f16x3"
     wide_kernels = True   # f16x3: evaluate the SDF network with the wide kernels (csrc/nrh_sdf32.hip); False = the 16-point kernels
     shadow_jvp = False         # the shadow march's last SDF evaluation in forward mode (mode 3: derivative along the ray only, no

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Go / no-go for 16-bit operands of the weight-gradient kernel ("16-bit storage of the dW-only operands would
+"""Go / no-go for 16-bit operands of the weight-gradient kernel (CHANGELOG.md section 7c item 3: "16-bit storage of the dW-only operands would
 halve four units and is not float32-equivalent") - priced on the GPU before anything is built: the fused 1 024-ray step of
 tests/test_gpu_train1024.py with the operand arrays of nrh_dw_gemm ROUNDED IN PLACE (torch) right before the call, every tensor's
 gradient against the reference's float64 gradient in units of the test's bound (3 x the reference's float32 noise, floor 1e-4 of scale;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """precision "f16" (the one-term builds of the wide SDF kernels) against the reference's recorded renders (tests/golden/render_*.npz,
-96 rays each) and against the float64 oracle on a strided sample of the benchmark frame: PSNR, max error - the numbers DESIGN 7h quotes."""
+96 rays each) and against the float64 oracle on a strided sample of the benchmark frame: PSNR, max error - the numbers CHANGELOG.md section 7h quotes."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """16-bit hand-offs of the weight-gradient operands (include/nrhints_hip.h: nrh_sdf_train_forward_half / _backward_half,
-NrhDwJob.half_ops) at the level of the C entry points: the fp16 arrays ARE the float32 arrays rounded to nearest, the
+NrhDwJob.half_ops; CHANGELOG.md section 7i) at the level of the C entry points: the fp16 arrays ARE the float32 arrays rounded to nearest, the
 adjoint scale follows the seeds (exact invariance under a power-of-two change of their magnitude), and the weight gradients they
 give agree with the float32 hand-offs to the operands' rounding.  The step-level parity - every gradient against the reference's
 float64 step at 1 024 rays - is tests/test_gpu_train1024.py, which runs with the hand-offs on."""

@@ -538,7 +538,7 @@ def test_sample_count_configs():
 
 
 def test_reduced_precision_option():
-    """precision "f16" (DESIGN 7h): packed exactly like f16x3 (the one-term kernels read the same streams), accepted by the module,
+    """precision "f16" (CHANGELOG.md section 7h): packed exactly like f16x3 (the one-term kernels read the same streams), accepted by the module,
     the default stays f16x3, anything else is refused."""
     import nrhints_amd as na
     assert _lib.PRECISIONS["f16"] == _lib.PRECISIONS["f16x3"] == 1 and _lib.PRECISIONS["f32"] == 0
