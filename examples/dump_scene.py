@@ -22,10 +22,10 @@ MAGIC = 0x4e52483031
 
 def dump(path, model, rays, background=(1.0, 1.0, 1.0), cos_anneal=1.0):
     """model: NeuSHintRenderer; rays: (o, d, pl, near, far) numpy float32.  The weight-norm fold and the packing run on the
-    model's device (a GPU-resident model gives bit-identical buffers to the ones its own forward() uses; CPU and GPU
-    row norms differ in the last bit)."""
+    model's device with the fold the renderer itself uses there (packing.dense_params_device: a GPU-resident model gives
+    bit-identical buffers to the ones its own forward() uses; the CPU fold differs from the GPU kernel's in last bits)."""
     state = {k: v.detach().float() for k, v in model.state_dict().items()}
-    d = packing.dense_params(state)
+    d = packing.dense_params_device(state)
     prec = _lib.PRECISIONS[model.precision]
     hints = bool(model._hints)
     sw, sb, sh = packing.pack_sdf(d, prec)

@@ -142,7 +142,7 @@ int nrh_sdf_grad_split(const float* sdf_w, const float* sdf_b, const float* sdf_
  *   size, which leaves three more octaves of head-room below fp16's 65 504 than 2^round(log2(rays)) would (the largest seed,
  *   d alpha / d sdf <= inv_s / 4 per unit of colour adjoint, grows with the trained sharpness); 1 reproduces the unscaled chain.
  *   For losses that are NOT ~1 / rays (sum-reduced, custom weights) derive S from the seeds' range instead, as the _half entries
- *   do on the device (`dyn`). */
+ *   do on the device (`dyn`) and the Python binding does on request (nrhints_amd._lib.ADJOINT_SCALE_FROM_SEEDS). */
 int nrh_sdf_train_forward(int precision, const float* sdf_w, const float* sdf_b, const float* sdf_head, const float* ro,
                           const float* rd, const float* t, int t_stride, int n_per_ray, long long nrays, float* sdf,
                           float* grad, float* feat_rows, float* save_h, float* save_s1, float* save_t, float* save_ge,

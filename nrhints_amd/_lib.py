@@ -68,17 +68,23 @@ def adjoint_scale(n_rays: int) -> float:
     return float(2.0 ** max(0, round(math.log2(max(1, int(n_rays)) / 8.0))))
 
 
+#: How the generic autograd Functions (SdfValueFeatGradHip, ColorNetHip, OutsideNetHip) choose ``adj_scale``.  False (default): the
+#: 1 / rays convention of ``adjoint_scale`` - right for the reference's loss (pipelines/base_pipeline.py:57-62: normalised by the ray
+#: count), no host synchronisation, and an eager step equals its hipGraph replay bit for bit.  True: from the incoming adjoints
+#: themselves (one host read per backward) - for callers whose loss is NOT ~1 / rays (sum-reduced, custom weights): the f16x3 chains
+#: then can neither underflow nor overflow fp16's 65 504 whatever the normalisation.
+ADJOINT_SCALE_FROM_SEEDS = False
+
+
 def adjoint_scale_from_seeds(seeds, n_rays: int) -> float:
-    """``adj_scale`` for the generic autograd Functions (SdfValueFeatGradHip, ColorNetHip, OutsideNetHip), whose caller's loss need
-    not be normalised by the ray count (sum-reduced or custom losses, register_view variants): the power of two that brings the
-    LARGEST incoming adjoint to [8, 16) - what adjoint_range_kernel computes on the device for the 16-bit hand-offs - so the f16x3
-    chains can neither underflow (1 / rays losses at large batches) nor overflow fp16's 65 504 (sum-reduced ones) whatever the
-    loss.  One host read of the seeds' maximum per backward; under hipGraph capture (no host read possible) and for empty or
-    non-finite seeds it falls back to the 1 / rays convention of ``adjoint_scale``.  Ignored by precision f32."""
+    """``adj_scale`` for the generic autograd Functions.  With ``ADJOINT_SCALE_FROM_SEEDS``: the power of two that brings the LARGEST
+    incoming adjoint to [8, 16) - what adjoint_range_kernel computes on the device for the 16-bit hand-offs; under hipGraph capture
+    (no host read possible) and for empty or non-finite seeds, and by default, the 1 / rays convention of ``adjoint_scale``.
+    Ignored by precision f32."""
     import math
 
     import torch
-    if torch.cuda.is_current_stream_capturing():
+    if not ADJOINT_SCALE_FROM_SEEDS or torch.cuda.is_current_stream_capturing():
         return adjoint_scale(n_rays)
     mx = 0.0
     for t in seeds:

@@ -173,6 +173,14 @@ def dense_params_hip(params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]
     return out
 
 
+def dense_params_device(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The fold the PRODUCT uses for tensors where they live: nrh_weight_norm_fold for float32 GPU tensors (every path on the GPU
+    folds with this one kernel, so the same parameters give the same packed bits - and the same sample placement - in an evaluation
+    render, a training forward and a file written by examples/dump_scene.py), the torch expression on the CPU."""
+    on_gpu = all(t.is_cuda and t.dtype == torch.float32 for k, t in state.items() if k.endswith(("weight_g", "weight_v")))
+    return dense_params_hip(state) if on_gpu else dense_params(state)
+
+
 def check_default_shapes(d: Dict[str, torch.Tensor], hints: bool = True) -> None:
     """The kernels are compiled for the default nr-hints network shape."""
     want = {"sdf_w0": (256, 39), "sdf_w1": (256, 256), "sdf_w2": (256, 256), "sdf_w3": (217, 256),

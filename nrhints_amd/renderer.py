@@ -218,8 +218,7 @@ class NeuSHintRenderer(nn.Module):
                     # samples by a whole bin where the pdf sits at its floor - with two folds an evaluation render and a training
                     # forward of the SAME parameters placed 20 % of their samples differently (profiles/train_forward_determinism.py,
                     # round 6).  (CPU tensors - the packing tests of the emulators - keep the torch expression.)
-                    fold = packing.dense_params_hip if torch.device(device).type == "cuda" else packing.dense_params
-                    d = self._pad_hint_columns(fold(state))
+                    d = self._pad_hint_columns(packing.dense_params_device(state))
                     packing.check_default_shapes(d, hints)
                     sw, sb, sh = packing.pack_sdf(d, prec)
                     cw, cb = packing.pack_color(d, prec, hints)

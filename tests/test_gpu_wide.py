@@ -128,7 +128,7 @@ def test_fused_feature_head(wscene, scene_states):
     from nrhints_amd import packing as pkg, packing32
     tag, model, packed, _ = wscene
     dev = torch.device("cuda", torch.cuda.current_device())
-    d = pkg.dense_params({k: v.detach().float().to(dev) for k, v in model.state_dict().items()})
+    d = pkg.dense_params_device({k: v.detach().float().to(dev) for k, v in model.state_dict().items()})     # the renderer's own fold
     w32f, tab32f = packing32.pack_sdf32_fused(d)
     o, dd, pl, near, far = make_rays(64, seed=12, spread=0.1)
     t = torch.rand(64, 128, device="cuda") * 2 + 2
