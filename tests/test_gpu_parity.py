@@ -38,8 +38,12 @@ def scene(request, scene_states):
 
 def test_native_library_loaded():
     from nrhints_amd import _lib
-    lib = _lib.load()
-    assert lib.nrh_version() >= 111
+    lib = _lib.load()           # (raises StaleLibrary if the binary was built from other sources than the tree's)
+    assert lib.nrh_version() == 147
+    # the binary that runs IS the tree: the hash the Makefile embedded against the hash of the sources beside it
+    ident = _lib.library_identity()
+    assert ident["embedded"] == ident["tree"] != "unknown", ident
+    assert ident["embedded"] in ident["build_info"]
     assert lib.nrh_mlp_grid() > 0
     assert _lib.param_sizes()[:5] == [pk.SDF_PACKED_FLOATS, pk.SDF_BIAS_FLOATS, pk.SDF_HEAD_FLOATS,
                                       pk.COL_PACKED_FLOATS, pk.COL_BIAS_FLOATS]

@@ -546,3 +546,17 @@ def test_reduced_precision_option():
     assert na.NeuSHintRenderer(precision="f16").precision == "f16"
     with pytest.raises(ValueError):
         na.NeuSHintRenderer(precision="bf16")
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """The binding refuses a library whose embedded source hash differs from the tree's (nrhints_amd/build_id.py): simulated by
+    making the tree's hash differ - every source edit without a rebuild does exactly that."""
+    from nrhints_amd import build_id
+    assert _lib.library_identity()["embedded"] == build_id.source_hash()
+    monkeypatch.setattr(build_id, "source_hash", lambda: "0123456789abcdef")
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.StaleLibrary):
+        _lib.load()
+    monkeypatch.setenv("NRHINTS_HIP_LIB", _lib.LIB_PATH)      # an explicitly named library (make variant) is exempt, and reported
+    assert _lib.load() is not None
+    monkeypatch.setattr(_lib, "_lib", None)
