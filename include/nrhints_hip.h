@@ -395,6 +395,8 @@ typedef struct NrhTrainSaves {
                            `visibilities` output is only the value at the maximal-weight sample); NULL = kept in the workspace */
   void* save_h16;       /* optional, both or neither (nrh_sdf_train_forward_half below): 16-bit hand-offs of h ...             */
   void* save_t16;       /* ... and t to nrh_dw_gemm, fp16 [8][nrays*128][256] in the half-tiled layout                          */
+  float* pts;           /* optional [nrays*128,3]: p = o + d * mid_z, the reflectance net's point input (ABI 148: written by the alpha
+                           stage, which forms the point anyway - it replaced two elementwise launches of the caller); NULL = not wanted */
 } NrhTrainSaves;
 int nrh_render_forward_train(const NrhNet* net, const float* origins, const float* directions, const float* pl_positions,
                              const float* nears, const float* fars, long long nrays, float cos_anneal,
@@ -587,6 +589,10 @@ int nrh_shadow_alpha_backward(const float* sdf, const float* grad, const float* 
 /* d loss / d variance from the per-ray partials of nrh_alpha_train_backward (inv_s = clip(exp(10 variance), 1e-6, 1e6),
  * models/neus_hint_model.py:104-110): variance_bar[0] = 10 inv_s sum(invs_bar) inside the clip range, else 0. */
 int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const float* dyn_scalars, float* variance_bar, void* stream);
+/* The scalars of a training step in ONE launch (ABI 148): values[i] -> *dst[i] for i < n <= 4 (dst, values: HOST arrays; the
+ * addresses are device pointers - the cos-anneal ratio models/neus_hint_model.py:669-671, the two learning rates), and, with
+ * `variance` (device [1]) non-null, inv_s_out[0] = clip(exp(10 variance), 1e-6, 1e6) (SingleVarianceNetwork, :104-110, :337-338). */
+int nrh_step_scalars(float* const* dst, const float* values, int n, const float* variance, float* inv_s_out, void* stream);
 
 /* ---- the optimiser step (trainer/trainer.py:99-102, 281: torch.optim.Adam over two parameter groups) in one launch ------------
  * Arithmetic of torch.optim.Adam's default implementation (what the reference runs; bias corrections in double), state layout

@@ -30,7 +30,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_source_hash", "nrh_last_error_
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
             "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step", "nrh_fuse_feature_head",
             "nrh_train_arrays_tiled", "nrh_sdf_eval_wide_f16", "nrh_train_half_supported", "nrh_sdf_train_forward_half",
-            "nrh_sdf_train_backward_half", "nrh_color_train_forward_half", "nrh_color_train_backward_half")
+            "nrh_sdf_train_backward_half", "nrh_color_train_forward_half", "nrh_color_train_backward_half", "nrh_step_scalars")
 
 
 class NrhNet(Structure):
@@ -52,7 +52,7 @@ class NrhAdamTensor(Structure):
 class NrhTrainSaves(Structure):
     _fields_ = [("sdf", c_void_p), ("feat_rows", c_void_p), ("save_h", c_void_p), ("save_s1", c_void_p),
                 ("save_t", c_void_p), ("save_ge", c_void_p), ("raymisc", c_void_p), ("shadow_mid_z", c_void_p),
-                ("shadow_dists", c_void_p), ("vis_groups", c_void_p), ("save_h16", c_void_p), ("save_t16", c_void_p)]
+                ("shadow_dists", c_void_p), ("vis_groups", c_void_p), ("save_h16", c_void_p), ("save_t16", c_void_p), ("pts", c_void_p)]
 
 
 def adjoint_scale(n_rays: int) -> float:
@@ -221,6 +221,7 @@ def load():
     lib.nrh_loss_finish.argtypes = [P, c_longlong, c_float, P, c_float, P, P]
     lib.nrh_alpha_train_backward_fused.argtypes = [P, P, P, P, c_float, c_float, P, c_longlong, P, P, c_int, P, P, P, P, P, P, c_int, P]
     lib.nrh_variance_grad.argtypes = [P, c_longlong, c_float, P, P, P]
+    lib.nrh_step_scalars.argtypes = [POINTER(c_void_p), POINTER(c_float), c_int, P, P, P]
     lib.nrh_adam_step.argtypes = [P, c_int, P, c_int, c_int, POINTER(ctypes.c_double), POINTER(c_void_p), POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double), POINTER(ctypes.c_double), P]
     lib.nrh_fuse_feature_head.argtypes = [P, c_int, P, P, P, P, P]
@@ -232,6 +233,16 @@ def load():
         getattr(lib, name)  # AttributeError if the build is stale
     _lib = lib
     return lib
+
+
+def step_scalars(pairs=(), variance=None, inv_s_out=None) -> None:
+    """nrh_step_scalars: ``pairs`` = up to four (0-dim or 1-element float32 CUDA tensor, python float) written in ONE launch, plus
+    - with ``variance`` / ``inv_s_out`` (float32 CUDA tensors) - inv_s_out[0] = clip(exp(10 variance), 1e-6, 1e6)."""
+    pairs = list(pairs)
+    n = len(pairs)
+    dst = (c_void_p * 4)(*([t.data_ptr() for t, _ in pairs] + [None] * (4 - n)))
+    val = (c_float * 4)(*([float(v) for _, v in pairs] + [0.0] * (4 - n)))
+    check(load().nrh_step_scalars(dst, val, n, ptr(variance), ptr(inv_s_out), stream_handle()), "nrh_step_scalars")
 
 
 def check(rc: int, what: str) -> None:

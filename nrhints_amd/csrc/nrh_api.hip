@@ -427,7 +427,7 @@ int launch_core_alpha(nrh::CoreArgs& c, hipStream_t st, const NrhNet* net) {
 
 extern "C" {
 
-int nrh_version(void) { return 147; }
+int nrh_version(void) { return 148; }
 int nrh_train_arrays_tiled(void) { return nrh::arr_tiled(nrh::ARR_H) ? 1 : 0; }
 #ifndef NRH_SOURCE_HASH
 #define NRH_SOURCE_HASH "unknown"      // (a build outside csrc/Makefile: _lib.load() refuses it)
@@ -1252,6 +1252,18 @@ int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const
   return check_launch("variance_grad_kernel");
 }
 
+int nrh_step_scalars(float* const* dst, const float* values, int n, const float* variance, float* inv_s_out, void* stream) {
+  if (n < 0 || n > 4 || (n > 0 && (!dst || !values))) return fail(NRH_E_INVALID, "nrh_step_scalars: 0..4 (address, value) pairs%s", "");
+  if ((variance != nullptr) != (inv_s_out != nullptr)) return fail(NRH_E_INVALID, "nrh_step_scalars: variance and inv_s_out come together%s", "");
+  if (n == 0 && !variance) return NRH_OK;
+  nrh::StepScalarsArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < n; ++i) { a.dst[i] = dst[i]; a.val[i] = values[i]; }
+  a.n = n; a.variance = variance; a.inv_s_out = inv_s_out;
+  hipLaunchKernelGGL(nrh::step_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  return check_launch("step_scalars_kernel");
+}
+
 int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const float* znew_in,
                      const float* snew_in, float* znew_out, const float* lin16, const float* last_dist_ray,
                      float* tmid, float* dists, float inv_s, float last_dist, int nrays, int n, int do_merge,
@@ -1521,6 +1533,7 @@ static int render_forward_impl(const NrhNet* net, const float* origins, const fl
     c.nhat = o_nhat; c.depth = o_depth; c.wsum = ws_wsum; c.cue = ws_cue; c.cue_b = o_cue_b; c.srd = ws_srd;
     c.slast = ws_slast; c.zs = ws_zbuf; c.inv_s = net->inv_s; c.cos_anneal = cos_anneal;
     c.dyn = net->dyn_scalars; c.hit = nullptr; c.hit_n = nullptr; c.depth_in = nullptr; c.hit_in = nullptr;
+    c.pts = train ? train->pts : nullptr;
     if (net->depth_type == 2) {
       // DepthComputationType.SphereTracing: the shadow-stage arrays are free until the core kernel has run
       float* q = ws_grad_s;

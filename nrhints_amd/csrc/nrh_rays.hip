@@ -283,6 +283,7 @@ struct CoreArgs {
   float* cue_b;         // [N,128,4] broadcast copy (RenderOutput.specular_cue) or null
   float* hit;           // [N,3] hit point o + d * depth (unit entry nrh_alpha_composite only) or null
   float* hit_n;         // [N,3] unit hit normal normalize(sum_j n_j w_j) (unit entry only) or null
+  float* pts;           // [N*128,3] p = o + d * mid (the reflectance net's point input in a training step) or null
   const float* depth_in;  // [N] DepthComputationType.SphereTracing: depth and hit point come from the tracer (:527-528) ...
   const float* hit_in;    // [N,3] ... instead of the compositing weights; both null otherwise
   float* srd;           // [N,3] shadow ray direction
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(256) void core_alpha_kernel(const CoreArgs a) {
     al[e] = neus_alpha(a.sdf[P], gx, gy, gz, dx, dy, dz, a.dists[P], a.dyn ? a.dyn[0] : a.inv_s, a.dyn ? a.dyn[1] : a.cos_anneal);
     const float px = ox + dx * mid[e], py = oy + dy * mid[e], pz = oz + dz * mid[e];
     ins[e] = (sqrtf(px * px + py * py + pz * pz) < 1.0f) ? 1.0f : 0.0f;
+    if (a.pts && active) { a.pts[P * 3 + 0] = px; a.pts[P * 3 + 1] = py; a.pts[P * 3 + 2] = pz; }   // fl(o + fl(d t)), as the SDF kernels form it
     if (a.nreal && lane + 64 * e >= a.nreal) { al[e] = 0.0f; ins[e] = 0.0f; }   // padded sample: no weight, not counted
     if (a.bg_alpha) al[e] = al[e] * ins[e] + a.bg_alpha[ray * 160 + lane + 64 * e] * (1.0f - ins[e]);
     const float gn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize eps

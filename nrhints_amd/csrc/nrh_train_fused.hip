@@ -327,4 +327,24 @@ __global__ __launch_bounds__(256) void variance_grad_kernel(const VarGradArgs a)
   }
 }
 
+// The handful of scalars a training step needs on the device, in ONE launch instead of one torch fill / pointwise kernel each
+// (a 64-ray step is ~50 launches of 5-20 us: every removed launch is 0.5 % of it): up to four host floats written to four device
+// addresses (cos-anneal ratio, learning rates), and 1 / s = clip(exp(10 variance), 1e-6, 1e6) (models/neus_hint_model.py:104-110,
+// :337-338) from the variance parameter.  NaN passes through the clip as in torch.clip.
+struct StepScalarsArgs {
+  float* dst[4];
+  float val[4];
+  int n;
+  const float* variance;   // [1] or null
+  float* inv_s_out;        // [1]
+};
+__global__ __launch_bounds__(64) void step_scalars_kernel(const StepScalarsArgs a) {
+  const int t = threadIdx.x;
+  if (t < a.n && a.dst[t]) *a.dst[t] = a.val[t];
+  if (t == 0 && a.variance) {
+    const float s = expf(a.variance[0] * 10.0f);
+    *a.inv_s_out = (s < 1e-6f) ? 1e-6f : ((s > 1e6f) ? 1e6f : s);
+  }
+}
+
 }  // namespace nrh

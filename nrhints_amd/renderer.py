@@ -243,8 +243,12 @@ class NeuSHintRenderer(nn.Module):
                         bufs["sdf_w32f"], bufs["sdf_tab32f"] = packing32.pack_sdf32_fused(d)
                         if hints and self.wide_color:
                             bufs["col_w32"], bufs["col_tab32"] = packing32.pack_color32(d)
+                # 1 / s = clip(exp(10 variance), 1e-6, 1e6) by ONE kernel in both modes (nrh_step_scalars): the host float of the
+                # eager mode and the device scalar of the captured mode are the same bits, and a captured step spends one launch
+                # on it instead of four pointwise torch kernels
                 if self.dyn_scalars is not None:      # no host sync: the kernels read inv_s from the device
-                    self.dyn_scalars[0:1].copy_(torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(1))
+                    with torch.cuda.device(device):
+                        _lib.step_scalars(variance=variance.reshape(1).contiguous(), inv_s_out=self.dyn_scalars)
                     inv_s = float("nan")
                     # ... so the f16x3 range check of the branch below cannot raise here.  It still runs, without a sync: every
                     # `range_check_every`-th pack enqueues the same test and copies its verdict to pinned memory; a later pack
@@ -257,7 +261,13 @@ class NeuSHintRenderer(nn.Module):
                     # kernels' input scaling must stay below 65504 - true for any trained NeuS net by orders of magnitude; a
                     # checkpoint outside that range is refused instead of rendered wrong)
                     ok = self._range_ok(bufs, d) if prec == 1 else torch.ones((), device=device)
-                    inv_s, ok = torch.stack([torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(()), ok.reshape(())]).tolist()
+                    if torch.device(device).type == "cuda":
+                        s_dev = torch.empty(1, dtype=torch.float32, device=device)
+                        with torch.cuda.device(device):
+                            _lib.step_scalars(variance=variance.reshape(1).contiguous(), inv_s_out=s_dev)
+                    else:       # (CPU tensors: host-side packing tests only)
+                        s_dev = torch.exp(variance * 10.0).clip(1e-6, 1e6).reshape(1)
+                    inv_s, ok = torch.stack([s_dev.reshape(()), ok.reshape(()).to(torch.float32)]).tolist()
                     if not ok:
                         raise ValueError(self._RANGE_MSG)
             self._packed = dict(bufs, inv_s=inv_s, precision=prec, hints=hints)
@@ -581,12 +591,13 @@ class NeuSHintRenderer(nn.Module):
 
     # ---------------------------------------------------------------------------------------------
     def _render_train(self, o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, raymisc=None, want_shadow=False,
-                      extra_net=None, half_handoffs=False):
+                      extra_net=None, half_handoffs=False, pts=None):
         """One nrh_render_forward_train call over the whole batch: the no-grad stages (samplers, hit point, shadow march,
         cue) plus the training evaluation of the SDF network at the section mid-points, whose outputs and saved arrays
         feed the backward sweeps directly (no second evaluation).  ``half_handoffs`` (the fused step, f16x3, batches the 8-wave
         kernels run): layers 0..6 of h and a copy of layers 1..7 of t go to float16 arrays ``saves["h16"]`` / ``saves["t16"]`` in the
-        half-tiled layout nrh_dw_gemm reads with one fp16 MFMA pass (include/nrhints_hip.h, nrh_sdf_train_forward_half)."""
+        half-tiled layout nrh_dw_gemm reads with one fp16 MFMA pass (include/nrhints_hip.h, nrh_sdf_train_forward_half).
+        ``pts`` [n*128,3]: receives p = o + d * mid_z from the alpha stage (the reflectance net's point input)."""
         lib = _lib.load()
         device = o.device
         n = o.shape[0]
@@ -613,7 +624,7 @@ class NeuSHintRenderer(nn.Module):
             sv["t16"] = torch.empty(8, n * T, 256, dtype=torch.float16, device=device)
         saves = _lib.NrhTrainSaves(P(pre["sdf"]), P(pre["feat"]), P(sv["h"]), P(sv["s1"]), P(sv["t"]), P(sv["ge"]), P(raymisc),
                                    P(out.get("shadow_mid_z")), P(out.get("shadow_dists")), P(out.get("vis_groups")),
-                                   P(sv.get("h16"), torch.float16), P(sv.get("t16"), torch.float16))
+                                   P(sv.get("h16"), torch.float16), P(sv.get("t16"), torch.float16), P(pts))
         ws = self._workspace(device, n)
         rc = lib.nrh_render_forward_train(
             net, P(o), P(d), P(pl), P(near), P(far), n, cos_anneal, P(t_rand_p) if t_rand_p is not None else None,

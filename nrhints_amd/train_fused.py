@@ -201,15 +201,13 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         # ``dw_half`` (NeuSHintRenderer.dw_half; False = float32 hand-offs, the precision-matched form).  Not an environment switch:
         # it changes numerics (11-bit operands of the weight-gradient products).
         half = (pk["precision"] == 1 and bool(getattr(renderer, "dw_half", False)) and bool(lib.nrh_train_half_supported(1, Pn)))
-        res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half)
+        # (the alpha stage also leaves p = o + d * t - separate roundings, as the SDF kernels form it - in B.pts for the reflectance net)
+        res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half, pts=B.pts)
         pre, sv = res["pre"], res["pre"]["saves"]
         if forward_out is not None:
             forward_out.update({k: res[k] for k in ("mid_z", "dists", "visibilities", "cue", "weights", "inside", "normals", "depth")})
             forward_out.update(sdf=pre["sdf"], feat=pre["feat"], vis_groups=res.get("vis_groups"))
         # ---- reflectance forward ----
-        pts3 = B.pts.view(n, 128, 3)                       # p = o + d * t with separate roundings, as the SDF kernels form it
-        torch.mul(d[:, None, :], res["mid_z"][..., None], out=pts3)
-        pts3.add_(o[:, None, :])
         cw = pk["col_w"]
         # the normal the reflectance net reads: normalised (default) or the raw gradient (normal_type Analytic, :622-623)
         normal_in = (res["normals"] if analytic else res["nhat"]).view(Pn, 3)

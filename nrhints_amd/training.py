@@ -350,9 +350,11 @@ class GraphedTrainStep:
     def _set_host_scalars(self, global_step: int) -> None:
         cfg = self.renderer.config
         cos = min(1.0, global_step / cfg.anneal_end) if cfg.anneal_end > 0 else 1.0
-        self.renderer.dyn_scalars[1:2].fill_(cos)
-        self.lr_t.fill_(self.base_lr * lr_factor(global_step, *self.sched_args))
-        self.ray_lr_t.fill_(self.base_ray_lr * lr_factor(global_step, *self.sched_args))
+        # one launch for the three (nrh_step_scalars; three fill kernels before)
+        from . import _lib
+        with torch.cuda.device(self.lr_t.device):
+            _lib.step_scalars([(self.renderer.dyn_scalars[1:2], cos), (self.lr_t, self.base_lr * lr_factor(global_step, *self.sched_args)),
+                               (self.ray_lr_t, self.base_ray_lr * lr_factor(global_step, *self.sched_args))])
 
     def _sync_active(self) -> bool:
         return self.grad_sync is not None and self.grad_sync._active()

@@ -636,3 +636,32 @@ def test_every_path_places_the_same_samples(scene_states, prec):
     res2 = b._render_train(f32(rb.origins), f32(rb.directions), f32(rb.pl_positions), f32(rb.nears).reshape(-1), f32(rb.fars).reshape(-1),
                            30000 / b.config.anneal_end, tp.reshape(-1).contiguous(), ts, 0)
     assert torch.equal(res2["mid_z"], fwd["mid_z"]) and torch.equal(res2["weights"], fwd["weights"])
+
+
+def test_step_scalars_and_alpha_stage_points(scene_states):
+    """ABI 148's launch savers: nrh_step_scalars writes up to four host floats and 1 / s = clip(exp(10 variance), 1e-6, 1e6) in one
+    launch (torch's pointwise kernels before); the alpha stage leaves the reflectance net's point input p = o + d * mid_z with the
+    roundings of the torch expression it replaced (fl(fl(d t) + o), what the SDF kernels form)."""
+    a, b, c = torch.zeros(2, device="cuda"), torch.zeros((), device="cuda"), torch.zeros((), device="cuda")
+    _lib.step_scalars([(a[1:2], 0.37), (b, 5e-4), (c, -2.5)])
+    assert a.tolist() == [0.0, float(np.float32(0.37))] and float(b) == float(np.float32(5e-4)) and float(c) == -2.5
+    for v in (0.3, 0.7, -2.0, 2.0, float("nan")):
+        var, out = torch.tensor([v], device="cuda"), torch.zeros(2, device="cuda")
+        _lib.step_scalars(variance=var, inv_s_out=out)
+        want = torch.exp(var * 10.0).clip(1e-6, 1e6)
+        got = out[0:1]
+        assert (torch.isnan(got).item() and torch.isnan(want).item()) or abs(float(got) - float(want)) <= 1.2e-7 * abs(float(want)), (v, float(got), float(want))
+    assert float(out[1]) == 0.0
+    # the points
+    n = 96
+    rs = np.random.RandomState(5)
+    rb = _bundle(*make_rays(n, seed=13, spread=0.1))
+    tp, ts = (cu(rs.rand(n, k).astype(np.float32)) for k in (1, 64))
+    m = _model(scene_states["b"])
+    f32 = lambda t: t.detach().float().contiguous()
+    pts = torch.full((n * 128, 3), float("nan"), device="cuda")
+    res = m._render_train(f32(rb.origins), f32(rb.directions), f32(rb.pl_positions), f32(rb.nears).reshape(-1), f32(rb.fars).reshape(-1), 0.6,
+                          tp.reshape(-1).contiguous(), ts, 0, pts=pts)
+    want = (rb.directions[:, None, :] * res["mid_z"][..., None])
+    want = want + rb.origins[:, None, :]
+    assert torch.equal(pts.view(n, 128, 3), want)
