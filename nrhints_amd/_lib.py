@@ -30,7 +30,7 @@ EXPORTED = ("nrh_version", "nrh_build_info", "nrh_source_hash", "nrh_last_error_
             "nrh_dw_workspace_floats", "nrh_dw_gemm", "nrh_embedding_rows", "nrh_composite_loss", "nrh_loss_finish",
             "nrh_alpha_train_backward_fused", "nrh_variance_grad", "nrh_pack_gather", "nrh_sdf32_tables", "nrh_adam_step", "nrh_fuse_feature_head",
             "nrh_train_arrays_tiled", "nrh_sdf_eval_wide_f16", "nrh_train_half_supported", "nrh_sdf_train_forward_half",
-            "nrh_sdf_train_backward_half", "nrh_color_train_forward_half", "nrh_color_train_backward_half", "nrh_step_scalars")
+            "nrh_sdf_train_backward_half", "nrh_color_train_forward_half", "nrh_color_train_backward_half", "nrh_step_scalars", "nrh_sampler_fusion")
 
 
 class NrhNet(Structure):
@@ -228,6 +228,8 @@ def load():
     lib.nrh_pack_gather.argtypes = [P, P, P, c_longlong, c_int, P, P]
     lib.nrh_sdf32_tables.argtypes = [POINTER(c_void_p), POINTER(c_int), P, P, P, P, P]
     lib.nrh_kernel_timing_select.argtypes = [c_int]
+    lib.nrh_sampler_fusion.argtypes = [c_int]
+    lib.nrh_sampler_fusion.restype = c_int
     lib.nrh_kernel_timing_read.argtypes = [POINTER(ctypes.c_double), POINTER(c_longlong)]
     for name in EXPORTED:
         getattr(lib, name)  # AttributeError if the build is stale

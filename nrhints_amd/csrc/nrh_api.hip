@@ -239,8 +239,10 @@ int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
 #ifndef NRH_SPLIT_MAX_PTS
 #define NRH_SPLIT_MAX_PTS 16384     // the training sampler takes the split kernel for passes of at most this many points (0: never)
 #endif
+static int g_sampler_fusion = 1;      // nrh_sampler_fusion: tests / measurements only
 int sdf_split_impl(const float* w, const float* b, const float* head, const float* ro, const float* rd, const float* t, int t_stride,
-                   int n_per_ray, long long nrays, float* sdf, int sdf_stride, int tiles, hipStream_t st) {
+                   int n_per_ray, long long nrays, float* sdf, int sdf_stride, int tiles, hipStream_t st,
+                   const nrh::StepArgs* step = nullptr) {
   if (!w || !b || !head || !ro || !rd || !t || !sdf) return fail(NRH_E_INVALID, "nrh_sdf_eval_split: null pointer%s", "");
   if (n_per_ray <= 0 || nrays < 0 || t_stride < n_per_ray || sdf_stride < n_per_ray)
     return fail(NRH_E_INVALID, "nrh_sdf_eval_split: bad n_per_ray/stride%s", "");
@@ -257,6 +259,13 @@ int sdf_split_impl(const float* w, const float* b, const float* head, const floa
   nrh::SdfSplitArgs a;
   a.w = w; a.b = b; a.head = head; a.ro = ro; a.rd = rd; a.t = t; a.sdf = sdf; a.npts = npts; a.n_per_ray = n_per_ray;
   a.t_stride = t_stride; a.sdf_stride = sdf_stride;
+  a.fused_step = 0;
+  if (step) {       // the per-ray sampler step in the launch's tail: a tile must be exactly one ray's 16 new samples
+    if (n_per_ray != 16 || t_stride != 16 || sdf_stride != 16 || step->n_new != 16 || step->nrays != nrays)
+      return fail(NRH_E_INVALID, "sdf_split: a fused sampler step needs 16 samples per ray%s", "");
+    a.fused_step = 1;
+    a.step = *step;
+  }
   const unsigned grid = (unsigned)((npts + 16 * tiles - 1) / (16 * tiles));
   TimedLaunch tl;
   bool timed;
@@ -376,28 +385,37 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
     return sdf_eval_impl(net->precision, 0, net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, t, stride, per_ray, n, out, stride, nullptr,
                          nullptr, nullptr, st, wide);
   };
+  // ... and with 16 new samples per step (a 16-point tile of such a pass IS one ray's new samples) the per-ray step that follows a
+  // pass runs in the tail of the pass's own launch (nrh_sampler_fusion(0) switches it off: tests compare the two forms bit for bit)
+  auto fuse_step = [&](int n_new) { return g_sampler_fusion && latency && net->precision == 1 && n_new == 16 && n * 16 <= split_max; };
   int rc = sdf0(z, 128, plan.nc, s);
   if (rc) return rc;
-  // five launches of the per-ray step kernel: up-sample 0 | merge i + up-sample i + 1 (i = 0, 1, 2) | merge 3 + finalise, with the
-  // SDF pass of the 16 new samples between them (the last up-sample's samples are merged without their sdf, :328-329)
+  // the per-ray step kernel: up-sample 0 | merge i + up-sample i + 1 (i = 0 .. steps - 2), with the SDF pass of the new samples
+  // between them; the LAST step's samples are merged without their sdf (:328-329) and the sections finalised inside the launch
+  // that drew them (StepArgs.then_finalize: the reference's last two steps have no SDF pass between them)
   nrh::StepArgs a;
+  memset(&a, 0, sizeof(a));
   a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew; a.snew_in = snew; a.znew_out = znew; a.lin16 = plan.lin_new;
   a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.last_dist = last_dist;
   a.nrays = (int)n; a.n_new = plan.n_new;
   a.inv_s = 64.0f; a.n = plan.nc; a.do_merge = 0; a.merge_sdf = 0; a.do_upsample = 1; a.do_finalize = 0;
+  a.then_finalize = plan.steps == 1 ? 1 : 0;
   rc = sampler_step_impl(a, st);
   if (rc) return rc;
-  for (int i = 0; i < plan.steps; ++i) {
-    const bool last = (i == plan.steps - 1);
-    if (!last) {
-      rc = sdf0(znew, 16, plan.n_new, snew);
-      if (rc) return rc;
-    }
-    // merge the new samples of step i (with their sdf unless they are the last step's); then up-sample step i + 1 from the merged
-    // state (inv_s = 64 * 2^(i+1)), or finalise after the last merge.  The step-2 launch's up-sample (step 3) is merged by the
-    // next launch without an SDF pass in between.
-    a.n = plan.nc + plan.n_new * i; a.do_merge = 1; a.merge_sdf = last ? 0 : 1; a.do_upsample = last ? 0 : 1; a.do_finalize = last ? 1 : 0;
+  for (int i = 0; i + 1 < plan.steps; ++i) {
+    // sdf of the samples step i drew, then: merge them, up-sample step i + 1 from the merged state (inv_s = 64 * 2^(i+1)) - and, if
+    // that was the last up-sample, merge ITS samples (no sdf) and finalise.  For small training batches with 16 new samples per
+    // step the SDF pass and the step are ONE launch (sdf_split_kernel's fused tail: a tile of the pass is a ray's 16 samples)
+    a.n = plan.nc + plan.n_new * i; a.do_merge = 1; a.merge_sdf = 1; a.do_upsample = 1; a.do_finalize = 0;
     a.inv_s = 64.0f * (float)(1 << (i + 1));
+    a.then_finalize = (i + 2 == plan.steps) ? 1 : 0;
+    if (fuse_step(plan.n_new)) {
+      rc = sdf_split_impl(net->sdf_w, net->sdf_b, net->sdf_head, ro, rd, znew, 16, plan.n_new, n, snew, 16, 0, st, &a);
+      if (rc) return rc;
+      continue;
+    }
+    rc = sdf0(znew, 16, plan.n_new, snew);
+    if (rc) return rc;
     rc = sampler_step_impl(a, st);
     if (rc) return rc;
   }
@@ -1252,6 +1270,12 @@ int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const
   return check_launch("variance_grad_kernel");
 }
 
+int nrh_sampler_fusion(int on) {
+  const int was = g_sampler_fusion;
+  if (on == 0 || on == 1) g_sampler_fusion = on;
+  return was;
+}
+
 int nrh_step_scalars(float* const* dst, const float* values, int n, const float* variance, float* inv_s_out, void* stream) {
   if (n < 0 || n > 4 || (n > 0 && (!dst || !values))) return fail(NRH_E_INVALID, "nrh_step_scalars: 0..4 (address, value) pairs%s", "");
   if ((variance != nullptr) != (inv_s_out != nullptr)) return fail(NRH_E_INVALID, "nrh_step_scalars: variance and inv_s_out come together%s", "");
@@ -1277,6 +1301,7 @@ int nrh_sampler_step(const float* ro, const float* rd, float* z, float* s, const
     return fail(NRH_E_INVALID, "nrh_sampler_step: bad sample count%s", "");
   if (nrays <= 0) return nrays == 0 ? NRH_OK : fail(NRH_E_INVALID, "nrh_sampler_step: nrays < 0%s", "");
   nrh::StepArgs a;
+  memset(&a, 0, sizeof(a));
   a.ro = ro; a.rd = rd; a.z = z; a.s = s; a.znew_in = znew_in; a.snew_in = snew_in; a.znew_out = znew_out;
   a.lin16 = lin16; a.last_dist_ray = last_dist_ray; a.tmid = tmid; a.dists = dists; a.inv_s = inv_s;
   a.last_dist = last_dist; a.nrays = nrays; a.n = n; a.do_merge = do_merge; a.merge_sdf = merge_sdf;

@@ -17,6 +17,7 @@
 // sdf_kernel<0, 1>'s (tests/test_gpu_split.py), which is the kernel the oracle comparisons of tests/test_gpu_parity.py pin.
 #include <type_traits>
 #include "nrh_mlp.h"
+#include "nrh_step.h"
 
 namespace nrh {
 
@@ -32,6 +33,11 @@ struct SdfSplitArgs {
   int n_per_ray;
   int t_stride;
   int sdf_stride;
+  // the per-ray sampler step that consumes this pass (nrh_step.h), run in the launch's tail by the wave that summed the tile's
+  // head: only for passes of 16 samples per ray, where tile i is exactly ray i's new samples (models/neus_hint_model.py:325-331:
+  // the sdf of the new samples, then cat_z_vals + the next up_sample).  Saves a launch per sampler step of a small training batch.
+  int fused_step;
+  StepArgs step;
 };
 
 constexpr int SPLIT_ROW = 544;     // bytes of one point's 256 fp16 activations (+32: the ds_read_b128 lane groups of the B operand hit 16 distinct 16-byte slots)
@@ -276,7 +282,26 @@ __global__ __launch_bounds__(256, T == 1 ? 2 : 1) void sdf_split_kernel(const Sd
       float part = head_part;
       part += __shfl_xor(part, 16, 64);
       part += __shfl_xor(part, 32, 64);
-      if (valid[t] && q == 0) a.sdf[ray[t] * a.sdf_stride + jj[t]] = (part + tab[9 * 256 + 256]) / 3.0f;
+      const float sdfv = (part + tab[9 * 256 + 256]) / 3.0f;
+      if (valid[t] && q == 0) a.sdf[ray[t] * a.sdf_stride + jj[t]] = sdfv;
+      if (a.fused_step) {
+        // ---- fused sampler step: this wave = this tile = ray `r`; lanes 0..15 hold the sdf of its 16 new samples ----
+        const long long r = (long long)blockIdx.x * T + t;
+        if (r < a.step.nrays) {
+          // activation buffer 0 is free (layer 7 read it, every wave passed the layer's barrier): four 144-float rows per tile
+          float* const Zs = reinterpret_cast<float*>(smem) + t * 4 * 144;
+          const int n = a.step.n, j0 = lane, j1 = lane + 64;
+          RayState st;
+          st.z0 = (j0 < n) ? a.step.z[r * 128 + j0] : 0.0f;
+          st.z1 = (j1 < n) ? a.step.z[r * 128 + j1] : 0.0f;
+          st.s0 = (j0 < n) ? a.step.s[r * 128 + j0] : 0.0f;
+          st.s1 = (j1 < n) ? a.step.s[r * 128 + j1] : 0.0f;
+          st.n = n;
+          const float zn = (lane < 16) ? a.step.znew_in[r * 16 + lane] : 0.0f;
+          const float sn = (lane < 16) ? sdfv : 0.0f;       // (lane < 16: q == 0, j == lane)
+          sampler_step_phases<false>(a.step, r, true, Zs, Zs + 144, Zs + 288, Zs + 432, st, zn, sn);
+        }
+      }
     }
   }
 }

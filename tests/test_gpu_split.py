@@ -144,3 +144,34 @@ def test_split_gradient_kernel_bit_identical_to_the_16_point_kernel(sscene, shap
     np.testing.assert_allclose(g_sdf.cpu().numpy().reshape(-1), o_sdf.numpy()[:, 0], rtol=0, atol=5e-6)
     # unorm16 sigma' hand-off (7.6e-6 per layer) dominates; gradient magnitude ~1 (scene b up to ~3)
     np.testing.assert_allclose(g_grad.cpu().numpy(), o_grad.numpy(), rtol=0, atol=1e-4 if tag == "a" else 5e-4)
+
+
+@pytest.mark.parametrize("nrays", [64, 77, 128, 257, 1024])
+def test_fused_sampler_step_is_bit_identical(sscene, nrays):
+    """Small training batches run each per-ray sampler step in the TAIL of the SDF pass that feeds it (sdf_split_kernel: tile i of
+    a 16-samples-per-ray pass is ray i's new samples; nrh_step.h) - one launch instead of two, 8 fewer per step.  Same bits as the
+    two-launch form in every product of the training forward: sample positions, sections, weights, visibility, sdf, gradient - at
+    one tile per workgroup (64, 77 rays), two (128, 257: an odd tile count leaves a workgroup's second tile empty) and at the
+    largest batch that takes the split kernel (1 024 rays = 16 384 points per pass)."""
+    from nrhints_amd import _lib
+    tag, model, packed, p64 = sscene
+    lib = _lib.load()
+    rs = np.random.RandomState(nrays)
+    o, d, pl, near, far = make_rays(nrays, seed=90 + nrays, spread=0.1)
+    tp, ts = cu(rs.rand(nrays).astype(np.float32)), cu(rs.rand(nrays, 64).astype(np.float32))
+
+    def forward():
+        r = model._render_train(cu(o), cu(d), cu(pl), cu(near).reshape(-1), cu(far).reshape(-1), 0.6, tp, ts, 0)
+        torch.cuda.synchronize()
+        return {k: r[k].clone() for k in ("mid_z", "dists", "weights", "visibilities", "depth", "normals", "cue")} | {"sdf": r["pre"]["sdf"].clone()}
+
+    was = lib.nrh_sampler_fusion(1)
+    try:
+        fused = forward()
+        assert lib.nrh_sampler_fusion(0) == 1
+        plain = forward()
+    finally:
+        lib.nrh_sampler_fusion(was)
+    for k in fused:
+        assert torch.equal(fused[k], plain[k]), (k, float((fused[k] - plain[k]).abs().max()))
+    assert float(fused["weights"].sum()) > 0.1 * nrays          # (rays that hit something: the comparison is not vacuous)
