@@ -5,6 +5,7 @@
 #include "nrh_sdf_split.hip"
 #include "nrh_sdf_train_split.hip"
 #include "nrh_color.hip"
+#include "nrh_color_split.hip"
 #include "nrh_outside.hip"
 #include "nrh_rays.hip"
 #include "nrh_rays_train.hip"
@@ -223,6 +224,14 @@ bool small_batch(long long npts) {
 bool split_train(int precision, long long npts) {
   static const bool on = !(prof_env("NRH_SPLIT_TRAIN") && atoi(prof_env("NRH_SPLIT_TRAIN")) == 0);
   return on && precision == 1 && npts <= 16LL * 2 * device_cus();      // (at 4 tiles per CU the 4-wave builds are as fast: profiles/r04/tsplit_ab.log)
+}
+
+// ... and the reflectance net's training forward / adjoint sweep (csrc/nrh_color_split.hip) while single tiles fit the CUs twice:
+// above that the 8-wave kernels' shared weight stream wins again.  NRH_PROFILING=1 NRH_SPLIT_COLOR_MAX_PTS=n overrides (A/B runs).
+bool split_color(int precision, long long npts) {
+  static const long long forced = prof_env("NRH_SPLIT_COLOR_MAX_PTS") ? atoll(prof_env("NRH_SPLIT_COLOR_MAX_PTS")) : -1;
+  const long long limit = forced >= 0 ? forced : 16LL * 2 * device_cus();
+  return precision == 1 && npts % 16 == 0 && npts <= limit;
 }
 
 int sampler_step_impl(const nrh::StepArgs& a, hipStream_t st) {
@@ -820,6 +829,12 @@ static int color_train_forward_impl(int precision, int hints, const float* col_w
   a.ro = pts; a.rd = pts; a.tmid = pts;  // unused in the training instantiation
   a.save_h = save_h; a.save_misc = save_misc; a.misc_shift = misc_shift; a.save_h16 = save_h16;
   a.npts = nrays * 128;
+  if (!save_h16 && split_color(precision, a.npts)) {      // small batch: one tile per workgroup, channels over its four waves
+    const dim3 sg((unsigned)(a.npts / 16)), sb(256);
+    if (hints) hipLaunchKernelGGL((nrh::color_train_split_kernel<8>), sg, sb, nrh::SPLC_LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((nrh::color_train_split_kernel<4>), sg, sb, nrh::SPLC_LDS_BYTES, (hipStream_t)stream, a);
+    return check_launch("color_train_split_kernel");
+  }
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_color_train_forward");
   if (rc) return rc;
@@ -864,6 +879,12 @@ static int color_train_backward_impl(int precision, int hints, const float* col_
   a.save_h16 = save_h16; a.zbar16 = zbar16; a.half_gain = half_gain;
   a.npts = nrays * 128;
   a.adj_scale = precision == 1 ? adj_scale : 1.0f;
+  if (!save_h16 && !zbar16 && split_color(precision, a.npts)) {
+    const dim3 sg((unsigned)(a.npts / 16)), sb(256);
+    if (hints) hipLaunchKernelGGL((nrh::color_adjoint_split_kernel<8>), sg, sb, nrh::SPLCA_LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((nrh::color_adjoint_split_kernel<4>), sg, sb, nrh::SPLCA_LDS_BYTES, (hipStream_t)stream, a);
+    return check_launch("color_adjoint_split_kernel");
+  }
   int grid = 0;
   rc = mlp_launch_geometry(a.npts, a.ntile_groups, grid, "nrh_color_train_backward");
   if (rc) return rc;

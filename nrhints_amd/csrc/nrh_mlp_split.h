@@ -70,6 +70,19 @@ struct SplLdsB {
     bl = *reinterpret_cast<const u32x4*>(row + 64 * s + SPL_TERM);
   }
 };
+// accumulator start values of a chunk (run_stage's HAS_INIT: one layer's K split in two stages); default: zeros
+struct SplNoInit {
+  template <typename C>
+  __device__ __forceinline__ void operator()(C, f32x4&, f32x4&) const {}
+};
+template <int KB>
+struct SplRegBk {       // B operands from an Act<1, KB> in registers (KB / 2 K steps)
+  const Act<1, KB>* e;
+  __device__ __forceinline__ void operator()(int s, u32x4& bh, u32x4& bl) const {
+    bh = u32x4{e->h[s * 4 + 0], e->h[s * 4 + 1], e->h[s * 4 + 2], e->h[s * 4 + 3]};
+    bl = u32x4{e->l[s * 4 + 0], e->l[s * 4 + 1], e->l[s * 4 + 2], e->l[s * 4 + 3]};
+  }
+};
 struct SplRegB {
   const Act<1, 4>* e;
   __device__ __forceinline__ void operator()(int s, u32x4& bh, u32x4& bl) const {
@@ -82,9 +95,10 @@ struct SplRegB {
 // slot; on entry the wave's next RD elements are in flight, and so they are on exit (the tail of the K loops requests the first
 // sets of the next stage: NC_N chunks x KS_N K steps at `nxt`; nxt == nullptr: nothing follows for this wave).
 //   pre(IC<ci>) -> P   issues the epilogue's global loads;   epi(IC<ci>, acc0, acc1, P)   consumes the chunk's two blocks
-template <int KS, int NC, int BASE, int KS_N, int NC_N, int RD, typename BFn, typename Pre, typename Epi>
+//   init(IC<ci>, acc0, acc1)   optional: the chunk's accumulator start values (the first MFMA adds to them, as run_stage's HAS_INIT)
+template <int KS, int NC, int BASE, int KS_N, int NC_N, int RD, typename BFn, typename Pre, typename Epi, typename Init = SplNoInit>
 __device__ __forceinline__ void spl_stage(SplRing<RD>& ring, const char* cur, const char* nxt, int lane, const BFn& bsrc, Pre&& pre,
-                                          Epi&& epi) {
+                                          Epi&& epi, const Init& init = Init()) {
   constexpr int S = NC * KS, SN = NC_N * KS_N;
   u32x4 bh[3], bl[3];
   if (S > 0) bsrc(0, bh[0], bl[0]);
@@ -93,6 +107,7 @@ __device__ __forceinline__ void spl_stage(SplRing<RD>& ring, const char* cur, co
     constexpr int CI = decltype(CIC)::value;
     const auto pv = pre(CIC);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    init(CIC, acc0, acc1);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int i = CI * KS + s;

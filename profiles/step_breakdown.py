@@ -49,3 +49,8 @@ if DETAIL:
 for k, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     if t > 5000 or DETAIL:
         print(f"{t / 1e6:8.3f} ms {n:5d}  {k}")
+if len(sys.argv) > 2 and sys.argv[2] in ("sequence", "detail+sequence") or (len(sys.argv) > 3 and sys.argv[3] == "sequence"):
+    t0 = int(step[0]["Start_Timestamp"])
+    print("\nthe step's launches in order (us since its first kernel, duration us):")
+    for r in step:
+        print(f"  {(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {dur(r) / 1e3:8.1f}  {cat(r['Kernel_Name'])}")

@@ -175,3 +175,53 @@ def test_fused_sampler_step_is_bit_identical(sscene, nrays):
     for k in fused:
         assert torch.equal(fused[k], plain[k]), (k, float((fused[k] - plain[k]).abs().max()))
     assert float(fused["weights"].sum()) > 0.1 * nrays          # (rays that hit something: the comparison is not vacuous)
+
+
+@pytest.mark.parametrize("hints", [True, False])
+def test_split_reflectance_kernels_bit_identical_to_the_8_wave_kernels(scene_states, hints):
+    """csrc/nrh_color_split.hip: the reflectance net's training forward and adjoint sweep for small batches (one tile per workgroup,
+    a stage's channels over its four waves) return the 8-wave kernels' bits - colour, save_h, save_misc; zbar, fbar, mbar - for
+    the hinted model (105 -> 128 misc inputs) and the pl-naive one (60 -> 64).  64 rays = 8 192 points evaluated alone (split
+    kernels) against the head of a 256-ray call on the same inputs (8-wave kernels; points are independent)."""
+    from nrhints_amd import _lib, packing
+    from nrhints_amd.synthetic import naive_state
+    lib = _lib.load()
+    P_ = _lib.ptr
+    cfg = na.NeuSModelConfig() if hints else na.NeuSModelConfig(renderer=na.NeuSRendererConfig(shadow_hint=False, specular_hint=False))
+    st = scene_states["b"] if hints else naive_state(scene_states["b"])
+    model = na.NeuSHintRenderer(cfg, precision="f16x3")
+    model.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+    model = model.cuda()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = packing.dense_params_device({k: v.detach().float() for k, v in model.state_dict().items()})
+    pk = model.packed_params(dev, dense=d)
+    cw, cb, cwt = pk["col_w"], pk["col_b"], pk["col_wt"]
+    mw = 128 if hints else 64
+    g = torch.Generator().manual_seed(3 + int(hints))
+    n_big, n_small = 256, 64
+    Pb, Ps = n_big * 128, n_small * 128
+    feat = (torch.randn(Pb, 256, generator=g) * 0.3).cuda()
+    pts = (torch.rand(Pb, 3, generator=g) * 2 - 1).cuda()
+    nrm = torch.nn.functional.normalize(torch.randn(Pb, 3, generator=g), dim=-1).cuda()
+    raymisc = (torch.rand(n_big, packing.RAYMISC_STRIDE, generator=g) * 2 - 1).cuda()
+    zbar4 = (torch.randn(Pb, 3, generator=g) * 1e-3).cuda()
+    new = lambda *s: torch.full(s, float("nan"), dtype=torch.float32, device="cuda")
+
+    def run(n):
+        P = n * 128
+        color, save_h, save_misc = new(P, 3), new(4, P, 256), new(P, mw)
+        _lib.check(lib.nrh_color_train_forward(1, int(hints), P_(cw, cw.dtype), P_(cb), P_(feat[:P].contiguous()), P_(pts[:P].contiguous()),
+                                               P_(nrm[:P].contiguous()), P_(raymisc[:n].contiguous()), n, P_(color), P_(save_h), P_(save_misc),
+                                               _lib.stream_handle()), "nrh_color_train_forward")
+        zbar, fbar, mbar = new(4, P, 256), new(P, 256), new(P, mw)
+        _lib.check(lib.nrh_color_train_backward(1, int(hints), P_(cwt, cwt.dtype), P_(zbar4[:P].contiguous()), P_(save_h), n, P_(zbar), P_(fbar),
+                                                P_(mbar), 8.0, _lib.stream_handle()), "nrh_color_train_backward")
+        torch.cuda.synchronize()
+        return dict(color=color, save_h=save_h, save_misc=save_misc, zbar=zbar, fbar=fbar, mbar=mbar)
+
+    big, small = run(n_big), run(n_small)
+    for k, v in small.items():
+        assert torch.isfinite(v).all(), k
+        ref = big[k][:, :Ps] if v.dim() == 3 else big[k][:Ps]
+        assert torch.equal(v, ref), (k, float((v - ref).abs().max()))
+    assert float(small["color"].std()) > 1e-3 and float(small["zbar"].abs().max()) > 0       # not vacuous
