@@ -21,8 +21,11 @@ Analytic (the reflectance net reads the raw gradient, its adjoint goes straight 
 and the partial visibility hint (``n_shadow_importance_clip``: one row of per-ray inputs per group of samples).
 Fewer than 128 samples per ray (``n_importance_samples = 0``, sample counts off the defaults): the per-sample arrays keep 128
 slots, the padded ones have weight and adjoint exactly 0.
-Restrictions (the autograd path covers the rest): GPU float32 parameters, no hint gradients, no outside NeRF, at most
-``max_fused_train_rays`` rays per call.
+Round 6: ``shadow_hint_gradient`` / ``specular_hint_gradient`` (models/neus_hint_model.py:379, :589) - the SDF training forward and
+both sweeps a second time at the shadow ray's sections, the shadow alpha stage's kernel pair, and a small autograd island on
+per-RAY tensors for the hit normal, the cue and the two encodings (_hint_forward / _hint_backward below).
+Restrictions (the autograd path covers the rest): GPU float32 parameters, no outside NeRF, at most ``max_fused_train_rays`` rays
+per call; shadow_hint_gradient with ray gradients or with the partial visibility hint is refused on both paths.
 """
 from __future__ import annotations
 
@@ -47,8 +50,11 @@ COLOR_HALF_GAIN = 1024.0
 def supported(renderer, ray_bundle) -> Optional[str]:
     """None if the fused step applies, else the reason it does not."""
     rc = renderer.config.renderer
-    if (rc.shadow_hint_gradient and renderer.has_shadow_hint) or (rc.specular_hint_gradient and renderer.has_specular_hint):
-        return "hint gradients (differentiated by the autograd path)"
+    if rc.shadow_hint_gradient and renderer.has_shadow_hint:
+        if int(getattr(renderer, "_shadow_clip", -1)) > 0:
+            return "shadow_hint_gradient with the partial visibility hint (not implemented on either path)"
+        if any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
+            return "shadow_hint_gradient together with ray gradients (not implemented on either path)"
     if getattr(renderer, "has_outside_nerf", False):
         return "outside-NeRF background"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
@@ -80,6 +86,7 @@ class _Buffers:
         self.sdf_bar, self.grad_bar, self.rd_bar, self.invs_bar = new(P), new(P, 3), new(n, 3), new(n)
         self.emb = new(P, 64)
         self.save_h16 = self.czbar16 = None      # the reflectance net's 16-bit hand-offs (allocated when the step uses them)
+        self.g_shadow = self.emb_shadow = None   # shadow_hint_gradient: the SDF net's weight gradients through the visibility
         self.dyn = torch.zeros(4, dtype=torch.float32, device=dev)      # {S, 1 / S, work words} of the 16-bit hand-offs (ops.sdf_train_backward)
         self.o_bar, self.d_bar, self.pl_bar = new(n, 3), new(n, 3), new(n, 3)      # ray adjoints (pose / light refinement)
         # What .grad of the 46 parameter tensors points at: views into ONE flat float32 buffer, laid out in the order of
@@ -202,8 +209,14 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         # it changes numerics (11-bit operands of the weight-gradient products).
         half = (pk["precision"] == 1 and bool(getattr(renderer, "dw_half", False)) and bool(lib.nrh_train_half_supported(1, Pn)))
         # (the alpha stage also leaves p = o + d * t - separate roundings, as the SDF kernels form it - in B.pts for the reflectance net)
-        res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half, pts=B.pts)
+        rcfg = cfg.renderer
+        shadow_grad = bool(rcfg.shadow_hint_gradient and renderer.has_shadow_hint and not zero_hints)
+        specular_grad = bool(rcfg.specular_hint_gradient and renderer.has_specular_hint and not zero_hints)
+        res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half, pts=B.pts,
+                                     want_shadow=shadow_grad)
         pre, sv = res["pre"], res["pre"]["saves"]
+        hg = _hint_forward(renderer, lib, B, pk, res, o, d, pl, cos_anneal, shadow_grad, specular_grad, want_rays) \
+            if (shadow_grad or specular_grad) else None
         if forward_out is not None:
             forward_out.update({k: res[k] for k in ("mid_z", "dists", "visibilities", "cue", "weights", "inside", "normals", "depth")})
             forward_out.update(sdf=pre["sdf"], feat=pre["feat"], vis_groups=res.get("vis_groups"))
@@ -250,13 +263,23 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         mw = B.mbar.shape[1]
         # NormalizedAnalytic: the unit normal's adjoint goes through the normalisation inside the kernel; Analytic: the reflectance
         # net read the gradient itself, its adjoint is added to the gradient's below
-        nbar = None if analytic else ctypes.c_void_p(B.mbar.data_ptr() + 12)
+        nbar, nbar_stride = (None if analytic else ctypes.c_void_p(B.mbar.data_ptr() + 12)), mw
+        if hg is not None:
+            # hint gradients (:379, :589): the adjoints of enc(visibility) / enc(cue) - per-ray sums of their mbar columns - go back
+            # through the hints: the cue's into the hit normal (unit normals and weights of this ray's samples: added to what the alpha
+            # adjoint reads), the visibility's into the shadow ray's alpha stage and from there into the SDF net at the shadow points
+            _hint_backward(hg, B, n, mw, analytic)
+            if hg.get("nhat_bar") is not None and analytic:      # Analytic: the net's normal input is the raw gradient, but the hit
+                nbar, nbar_stride = P_(hg["nhat_bar"]), 3        # normal is built from UNIT normals (:584): their adjoint on its own
         _lib.check(lib.nrh_alpha_train_backward_fused(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), float(inv_s),
-                                                      float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, mw, P_(res["inside"]),
+                                                      float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, nbar_stride, P_(res["inside"]),
                                                       ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
                                                       P_(B.invs_bar), int(renderer._samples), stream), "nrh_alpha_train_backward_fused")
         if analytic:
             B.grad_bar.add_(B.mbar[:, 3:6])
+        shadow_r = None
+        if hg is not None and hg.get("vis_bar") is not None:
+            shadow_r = _shadow_backward(hg, lib, B, pk, n, float(inv_s), float(cos_anneal), dyn, int(renderer._shadow_total), stream)
         if want_params:
             _lib.check(lib.nrh_variance_grad(P_(B.invs_bar), n, float(inv_s), P_(dyn), P_(B.var_bar), stream), "nrh_variance_grad")
         # ---- SDF network: tangent + value sweeps ----
@@ -266,6 +289,9 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         if want_rays:
             _lib.check(lib.nrh_ray_adjoint(P_(o), P_(d), P_(pl), P_(res["mid_z"]), P_(r["pbar"]), P_(B.grad_bar), P_(sv["ge"]), P_(B.mbar), mw,
                                            P_(B.rd_bar), n, P_(B.o_bar), P_(B.d_bar), P_(B.pl_bar), stream), "nrh_ray_adjoint")
+            if hg is not None and hg.get("d_bar") is not None:       # the cue's own dependence on the view direction and the light (:590-615)
+                B.d_bar.add_(hg["d_bar"])
+                B.pl_bar.add_(hg["pl_bar"])
         if not want_params:
             # frozen renderer (register_view, pipelines/base_pipeline.py:71-91: only the ray generator's deltas step): the reference
             # computes and discards all 46 parameter gradients there; the results are the same without them
@@ -277,7 +303,20 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         jobs = dw.sdf_jobs(shapes, sv["h"], sv["t"], r["zbar"], r["abar"], r["gebar"], B.emb, B.sdf_bar, B.fbar, B.g, half=h16) + \
             dw.color_jobs(hints, B.czbar, B.zbar4, B.save_h, pre["feat"], B.save_misc, B.g,
                           half=dict(zbar16=B.czbar16, h16=B.save_h16, inv_scale=1.0 / (_lib.adjoint_scale(n) * COLOR_HALF_GAIN)) if half_c else None)
+        if shadow_r is not None:
+            # the SDF net's weight gradients through the visibility: the same job table over the shadow points' arrays, into a second
+            # set of outputs that is added below (a job's output is written, not accumulated)
+            if B.g_shadow is None:
+                B.g_shadow = {k: torch.empty_like(B.g[k]) for k in [f"dW{l}" for l in range(8)] + [f"db{l}" for l in range(8)] + ["ws", "bs", "Wf", "bf"]}
+                B.emb_shadow = torch.empty_like(B.emb)
+            _lib.check(lib.nrh_embedding_rows(P_(pl), P_(hg["srd"]), P_(res["shadow_mid_z"]), 128, 128, n, P_(B.emb_shadow), stream), "nrh_embedding_rows")
+            # (its own nrh_dw_gemm call: the two tables together exceed the kernel's 24 jobs)
+            dw.run(dw.sdf_jobs(shapes, hg["saves"]["h"], hg["saves"]["t"], shadow_r["zbar"], shadow_r["abar"], shadow_r["gebar"],
+                               B.emb_shadow, hg["sdf_bar"], hg["fbar0"], B.g_shadow), Pn)
         dw.run(jobs, Pn)
+        if shadow_r is not None:
+            keys = list(B.g_shadow)
+            torch._foreach_add_([B.g[k] for k in keys], [B.g_shadow[k] for k in keys])
         # ---- weight-norm adjoint -> .grad ----
         g = B.g
         w0bar = g["w0"]
@@ -297,6 +336,100 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         for pname, prm in named.items():
             prm.grad = B.pgrad[pname]
         return _finish_rays(B, ray_bundle, want_rays, ray_grads)
+
+
+def _hint_forward(renderer, lib, B, pk, res, o, d, pl, cos_anneal, shadow_grad: bool, specular_grad: bool, want_rays: bool) -> dict:
+    """renderer.shadow_hint_gradient / specular_hint_gradient on the fused step (models/neus_hint_model.py:379, :589: the hints stay
+    inside the graph).  The per-sample work is the HIP kernels' - the SDF training forward at the shadow ray's 128 sections with
+    its own saved arrays, the shadow ray's alpha stage (nrh_shadow_alpha_forward) - and what is left is per-RAY arithmetic on
+    [n, .] tensors (hit normal = normalised weighted sum of unit normals, the Cook-Torrance cue, the two encodings), which runs as
+    a small torch autograd island whose leaves are exactly the quantities the kernels exchange adjoints in: the visibility [n,1],
+    the unit normals [n,128,3] and the weights [n,128] (and, under pose / light refinement, the view direction and the light).
+    The encodings it produces overwrite the kernel's (constant-hint) columns of the per-ray table before the reflectance forward."""
+    from . import autograd_core, ops
+    import torch.nn.functional as F
+    P_ = _lib.ptr
+    n = o.shape[0]
+    hgi = renderer._hint_grad_inputs(o, d, res["depth"], res, shadow_grad, specular_grad)
+    hit = hgi["hit"]
+    out = dict(shadow=shadow_grad, specular=specular_grad)
+    with torch.enable_grad():
+        encs, leaves = [], []
+        if shadow_grad:
+            sd = hit - pl
+            srd = (sd / torch.linalg.norm(sd, ord=2, dim=-1, keepdim=True)).contiguous()
+            mid_s = res["shadow_mid_z"]
+            pts_s = (pl[:, None, :] + srd[:, None, :] * mid_s[..., None]).reshape(-1, 3).contiguous()
+            sdf_s, _, grad_s, sv_s = ops.sdf_train_forward(pk["sdf_w"], pk["sdf_b"], pk["sdf_head"], pts_s)
+            vis = torch.empty(n, 1, dtype=torch.float32, device=o.device)
+            _lib.check(lib.nrh_shadow_alpha_forward(P_(sdf_s), P_(grad_s), P_(srd), P_(res["shadow_dists"]), float(pk["inv_s"]), float(cos_anneal),
+                                                    P_(renderer.dyn_scalars), n, int(renderer._shadow_total), P_(vis), _lib.stream_handle()),
+                       "nrh_shadow_alpha_forward")
+            vis_leaf = vis.requires_grad_(True)
+            out.update(srd=srd, pts_s=pts_s, sdf_s=sdf_s, grad_s=grad_s, saves=sv_s, vis_leaf=vis_leaf, shadow_dists=res["shadow_dists"])
+            enc_v = autograd_core._enc(vis_leaf, 4)
+            B.raymisc[:, 54:63].copy_(enc_v.detach())
+            encs.append(enc_v)
+            leaves.append(vis_leaf)
+        if specular_grad:
+            nh_leaf = res["nhat"].detach().requires_grad_(True)
+            w_leaf = res["weights"].detach().requires_grad_(True)
+            d_leaf = d.detach().requires_grad_(bool(want_rays))
+            pl_leaf = pl.detach().requires_grad_(bool(want_rays))
+            hit_n = F.normalize((nh_leaf * w_leaf[..., None]).sum(1), dim=-1, p=2)                     # :586-587
+            cue = autograd_core._specular_cue(hit_n, pl_leaf, hit, d_leaf, hgi["roughness"])
+            enc_c = autograd_core._enc(cue, 4)
+            B.raymisc[:, 63:99].copy_(enc_c.detach())
+            encs.append(enc_c)
+            out.update(nh_leaf=nh_leaf, w_leaf=w_leaf, d_leaf=d_leaf if want_rays else None, pl_leaf=pl_leaf if want_rays else None)
+        out["encs"] = encs
+    return out
+
+
+def _hint_backward(hg: dict, B, n: int, mw: int, analytic: bool) -> None:
+    """The island's backward: per-ray sums of the mbar columns of enc(visibility) [60:69] and enc(cue) [69:105] -> d loss / d
+    visibility (hg["vis_bar"]), and the cue's adjoints added to the weights' (B.wbar) and the unit normals' (columns 3..5 of mbar,
+    or - Analytic normals - their own array hg["nhat_bar"])."""
+    mb = B.mbar.view(n, 128, mw)
+    gouts = []
+    if hg["shadow"]:
+        gouts.append(mb[:, :, 60:69].sum(1))
+    if hg["specular"]:
+        gouts.append(mb[:, :, 69:105].sum(1))
+    with torch.enable_grad():
+        torch.autograd.backward(hg["encs"], gouts)
+    hg["vis_bar"] = hg["vis_leaf"].grad.contiguous() if hg["shadow"] else None
+    hg["nhat_bar"] = None
+    if hg["specular"]:
+        B.wbar.add_(hg["w_leaf"].grad)
+        nb = hg["nh_leaf"].grad.reshape(-1, 3)
+        if analytic:
+            hg["nhat_bar"] = nb.contiguous()
+        else:
+            B.mbar[:, 3:6].add_(nb)
+        if hg.get("d_leaf") is not None:
+            hg["d_bar"], hg["pl_bar"] = hg["d_leaf"].grad, hg["pl_leaf"].grad
+
+
+def _shadow_backward(hg: dict, lib, B, pk, n: int, inv_s: float, cos_anneal: float, dyn, n_real: int, stream) -> dict:
+    """d loss / d visibility -> the shadow ray's alpha stage (nrh_shadow_alpha_backward) -> the SDF net's two sweeps at the shadow
+    points; the per-ray 1 / s partials join the primary ray's (B.invs_bar) ahead of nrh_variance_grad."""
+    from . import ops
+    P_ = _lib.ptr
+    dev = B.dev
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    Pn = n * 128
+    sdf_bar, grad_bar, rd_bar, invs_bar = new(Pn), new(Pn, 3), new(n, 3), new(n)
+    _lib.check(lib.nrh_shadow_alpha_backward(P_(hg["sdf_s"]), P_(hg["grad_s"]), P_(hg["srd"]), P_(hg["shadow_dists"]), inv_s, cos_anneal, P_(dyn), n,
+                                             n_real, P_(hg["vis_bar"]), P_(sdf_bar), P_(grad_bar), P_(rd_bar), P_(invs_bar), stream),
+               "nrh_shadow_alpha_backward")
+    B.invs_bar.add_(invs_bar)
+    fbar0 = torch.zeros(Pn, 256, dtype=torch.float32, device=dev)
+    sv = hg["saves"]
+    r = ops.sdf_train_backward(pk["sdf_w"], pk["sdf_wt_feat"], pk["sdf_head"], hg["pts_s"], sv["zeros3"], sv["zeros1"], 1, sv, sdf_bar, fbar0,
+                               grad_bar, adj_scale=_lib.adjoint_scale(n))
+    hg["sdf_bar"], hg["fbar0"] = sdf_bar, fbar0
+    return r
 
 
 def _finish_rays(B, ray_bundle, want_rays: bool, ray_grads) -> torch.Tensor:

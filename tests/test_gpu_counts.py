@@ -145,3 +145,13 @@ def test_shadow_hint_gradient_with_sample_counts_vs_reference(scene_states, vt, 
             bound = max(bound, 3e-7)
         err = float(np.abs(named[name].grad.detach().cpu().numpy().astype(np.float64) - want64).max())
         assert err <= bound, (vt, name, err, bound, scale)
+    # ... and the fused (autograd-free) step on the same batch: the same kernels, n_real handed to the shadow alpha stage there too
+    from nrhints_amd import train_fused
+    fused = _model(scene_states["b"], prec, dict(shadow_hint_gradient=True, **HG_COUNTS[vt])).train()
+    assert train_fused.supported(fused, _bundle(g, "t.")) is None
+    l8 = train_fused.train_step_backward(fused, _bundle(g, "t."), cu(g["t.rgb_gt"]), torch.ones(1, 3).cuda(), int(g["t.global_step"]),
+                                         t_rand_primary=cu(g[f"{vt}.t_rand_primary"]), t_rand_shadow=cu(g[f"{vt}.t_rand_shadow"]))
+    np.testing.assert_allclose(float(l8[0]), float(ld["loss"].detach()), rtol=5e-6)
+    for (name, pa), (_, pf) in zip(model.named_parameters(), fused.named_parameters()):
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pf.grad).abs().max()) < 3e-4 * scale + 5e-6, (vt, name)

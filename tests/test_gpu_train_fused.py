@@ -665,3 +665,98 @@ def test_step_scalars_and_alpha_stage_points(scene_states):
     want = (rb.directions[:, None, :] * res["mid_z"][..., None])
     want = want + rb.origins[:, None, :]
     assert torch.equal(pts.view(n, 128, 3), want)
+
+
+def test_adjoint_scale_from_seeds_for_sum_reduced_losses(scene_states):
+    """_lib.ADJOINT_SCALE_FROM_SEEDS: the generic autograd Functions take their f16x3 adjoint scale from the incoming
+    adjoints instead of the 1 / rays convention - for callers whose loss is not normalised by the ray count.  A loss multiplied by
+    2^20 (adjoints of ~1e3 per sample: with the static scale rays / 8 = 32 on top, the SDF chain's largest seeds - inv_s / 4 per
+    unit of colour adjoint - leave fp16's range) gives, with the option on, exactly 2^20 times the gradients of the plain loss
+    (power-of-two scalings are exact through the chain); the default convention stays what the eager / graph identity tests pin."""
+    from nrhints_amd.training import train_loss_dict
+    n = 256
+    rs = np.random.RandomState(4)
+    rb = _bundle(*make_rays(n, seed=14, spread=0.1))
+    gt, tp, ts = (cu(rs.rand(n, k).astype(np.float32)) for k in (3, 1, 64))
+    bg = torch.ones(1, 3).cuda()
+
+    def grads(scale, from_seeds):
+        m = _model(scene_states["b"])
+        old = _lib.ADJOINT_SCALE_FROM_SEEDS
+        _lib.ADJOINT_SCALE_FROM_SEEDS = from_seeds
+        try:
+            out = m(rb, is_training=True, background_rgb=bg, global_step=30000, _t_rand_primary=tp, _t_rand_shadow=ts)
+            (train_loss_dict(out, gt, m.config.igr_weight)["loss"] * scale).backward()
+        finally:
+            _lib.ADJOINT_SCALE_FROM_SEEDS = old
+        return {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+
+    base = grads(1.0, False)
+    big = grads(2.0 ** 20, True)
+    for k in base:
+        assert torch.isfinite(big[k]).all(), k
+        want = base[k] * 2.0 ** 20
+        scale = float(want.abs().max()) + 1e-30
+        assert float((big[k] - want).abs().max()) <= 2e-4 * scale, (k, float((big[k] - want).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("vt", ["shg", "spg", "bhg"])
+def test_fused_step_hint_gradients(scene_states, vt):
+    """renderer.shadow_hint_gradient / specular_hint_gradient / both (models/neus_hint_model.py:379, :589) on the FUSED step (round 6;
+    the autograd path had them since round 3): loss and the recorded gradient tensors against the reference's float64 run (the bounds
+    of test_hint_gradients_vs_reference), every parameter gradient against the autograd path's, and the captured hipGraph takes the
+    fused step and replays it to the eager numbers."""
+    from nrhints_amd.training import GraphedTrainStep, train_loss_dict
+    g = load_npz("render_branches_b.npz")
+    R = na.NeuSRendererConfig
+    cfg = na.NeuSModelConfig(renderer=R(shadow_hint_gradient=vt in ("shg", "bhg"), specular_hint_gradient=vt in ("spg", "bhg")))
+    tb = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    bg = torch.ones(1, 3).cuda()
+    gs = int(g["t.global_step"])
+    tp, ts, gt = cu(g[f"{vt}.t_rand_primary"]), cu(g[f"{vt}.t_rand_shadow"]), cu(g["t.rgb_gt"])
+    fused = _model(scene_states["b"], cfg=cfg)
+    assert train_fused.supported(fused, tb) is None
+    loss8 = train_fused.train_step_backward(fused, tb, gt, bg, gs, t_rand_primary=tp, t_rand_shadow=ts)
+    np.testing.assert_allclose(float(loss8[0]), float(g[f"{vt}.loss"]), rtol=2e-4)
+    named = dict(fused.named_parameters())
+    keys = [k for k in g if k.startswith(f"{vt}.grad.") and ".rays." not in k]
+    assert len(keys) == 11
+    for k in keys:
+        name = k[len(vt) + 6:]
+        want64 = g[k.replace(".grad.", ".grad64.")]
+        bound, scale = grad_bound(g[k], want64, factor=4.0, floor=5e-3)
+        err = float(np.abs(named[name].grad.detach().cpu().numpy().astype(np.float64) - want64).max())
+        assert err <= bound, (vt, name, err, bound, scale)
+    # the autograd path on the same batch
+    auto = _model(scene_states["b"], cfg=cfg)
+    out = auto(tb, is_training=True, background_rgb=bg, global_step=gs, _t_rand_primary=tp, _t_rand_shadow=ts)
+    la = train_loss_dict(out, gt, 0.1)
+    la["loss"].backward()
+    np.testing.assert_allclose(float(loss8[0]), float(la["loss"]), rtol=2e-5)
+    for (name, pa), (_, pf) in zip(auto.named_parameters(), fused.named_parameters()):
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pf.grad).abs().max()) < 3e-4 * scale + 5e-7, (vt, name, float((pa.grad - pf.grad).abs().max()) / scale)
+    # the hint gradients are really in: d loss / d variance differs from the hint-constant model's as the fixture says (shadow),
+    # the first SDF layer's by ~10 % (specular)
+    plain = _model(scene_states["b"])
+    train_fused.train_step_backward(plain, tb, gt, bg, gs, t_rand_primary=tp, t_rand_shadow=ts)
+    pn = dict(plain.named_parameters())
+    if vt == "shg":
+        a, b = named["deviation_network.variance"].grad, pn["deviation_network.variance"].grad
+        assert abs(float(a - b)) > 0.5 * abs(float(a))
+    else:
+        a, b = named["sdf_network.lin0.weight_v"].grad, pn["sdf_network.lin0.weight_v"].grad
+        assert float((a - b).abs().max()) > 1e-2 * float(b.abs().max())
+    # captured
+    eager = {k: v.grad.detach().clone() for k, v in fused.named_parameters()}
+    cap = _model(scene_states["b"], cfg=cfg)
+    step = GraphedTrainStep(cap, tb.origins.shape[0], bg, lr=0.0, warm_up_end=0, global_step=gs, jitter=(tp, ts), fused=True)
+    try:
+        assert step._use_fused
+        got = step(tb, gt, global_step=gs)
+        np.testing.assert_allclose(float(got["loss"]), float(loss8[0]), rtol=1e-6)
+        for k, v in cap.named_parameters():
+            scale = float(eager[k].abs().max()) + 1e-30
+            assert float((v.grad - eager[k]).abs().max()) <= 1e-6 * scale, (vt, k)
+    finally:
+        step.release()
