@@ -56,9 +56,10 @@ int nrh_mlp_grid(void);
  * total_ms / launches are HOST pointers.  Not thread-safe; leave it off outside benchmarks. */
 int nrh_kernel_timing_select(int kind);
 /* Tests / measurements only: the sampler of a small training batch (passes of at most 16 384 points, 16 new samples per step) runs
- * each per-ray step in the tail of the SDF pass that feeds it (one launch instead of two; csrc/nrh_sdf_split.hip).  on = 0 / 1
- * switches that fusion off / on for the process (default on; any other value only queries); returns the previous setting.  Both
- * forms give the same bits (tests/test_gpu_split.py). */
+ * each per-ray step in the tail of the SDF pass that feeds it (one launch instead of two; csrc/nrh_sdf_split.hip).  on = 0: never;
+ * 1 (default): while a pass is one tile per workgroup (up to one ray per CU: where it is faster); 2: wherever the kernel supports
+ * it (passes of at most 16 384 points); any other value only queries; returns the previous setting.  All forms give the same bits
+ * (tests/test_gpu_split.py). */
 int nrh_sampler_fusion(int on);
 int nrh_kernel_timing_read(double* total_ms, long long* launches);
 

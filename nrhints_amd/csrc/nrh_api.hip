@@ -396,7 +396,14 @@ int run_sampler(const NrhNet* net, const float* ro, const float* rd, float* z, f
   };
   // ... and with 16 new samples per step (a 16-point tile of such a pass IS one ray's new samples) the per-ray step that follows a
   // pass runs in the tail of the pass's own launch (nrh_sampler_fusion(0) switches it off: tests compare the two forms bit for bit)
-  auto fuse_step = [&](int n_new) { return g_sampler_fusion && latency && net->precision == 1 && n_new == 16 && n * 16 <= split_max; };
+  // Taken while a pass is ONE tile per workgroup (at most one ray per CU's worth of tiles: 256 rays on 256 CUs): there the tail costs
+  // less than the separate launch's floor (0.90 -> 0.87 ms at 64 rays); with two tiles per workgroup the step serialises behind
+  // the MLP of a workgroup that occupies its CU alone and the separate launch wins (6.19 against 6.31 ms at 1 024 rays,
+  // profiles/r06/fused_step_ab.log).  nrh_sampler_fusion(2) forces it wherever the kernel supports it (tests).
+  auto fuse_step = [&](int n_new) {
+    const bool fits = g_sampler_fusion == 2 ? (n * 16 <= split_max) : (n * 16 <= 16LL * device_cus());
+    return g_sampler_fusion && latency && net->precision == 1 && n_new == 16 && fits;
+  };
   int rc = sdf0(z, 128, plan.nc, s);
   if (rc) return rc;
   // the per-ray step kernel: up-sample 0 | merge i + up-sample i + 1 (i = 0 .. steps - 2), with the SDF pass of the new samples
@@ -1293,7 +1300,7 @@ int nrh_variance_grad(const float* invs_bar, long long nrays, float inv_s, const
 
 int nrh_sampler_fusion(int on) {
   const int was = g_sampler_fusion;
-  if (on == 0 || on == 1) g_sampler_fusion = on;
+  if (on == 0 || on == 1 || on == 2) g_sampler_fusion = on;
   return was;
 }
 

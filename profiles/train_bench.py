@@ -16,7 +16,13 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     torch.manual_seed(0)
     student = na.NeuSHintRenderer().cuda()
-    student.dw_half = "half" in sys.argv[4:]       # 4th argument "half": the fp16 dW hand-offs (NeuSHintRenderer.dw_half); default float32
+    student.dw_half = "half" in sys.argv[4:]
+    if "nofuse" in sys.argv[4:]:                   # A/B of the fused "SDF pass + sampler step" launch (nrh_sampler_fusion: measurements only)
+        from nrhints_amd import _lib as _l
+        _l.load().nrh_sampler_fusion(0)
+    if "forcefuse" in sys.argv[4:]:
+        from nrhints_amd import _lib as _l
+        _l.load().nrh_sampler_fusion(2)       # 4th argument "half": the fp16 dW hand-offs (NeuSHintRenderer.dw_half); default float32
     backend = sys.argv[3] if len(sys.argv) > 3 else "hip"          # hip | hip_nosync (no per-step loss read-back) | graph | manual | autograd (the last two: tests/torch_backends.py)
     teacher = na.NeuSHintRenderer()
     st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in student.state_dict().items()})

@@ -165,15 +165,18 @@ def test_fused_sampler_step_is_bit_identical(sscene, nrays):
         torch.cuda.synchronize()
         return {k: r[k].clone() for k in ("mid_z", "dists", "weights", "visibilities", "depth", "normals", "cue")} | {"sdf": r["pre"]["sdf"].clone()}
 
-    was = lib.nrh_sampler_fusion(1)
+    was = lib.nrh_sampler_fusion(2)          # 2: fused wherever the kernel supports it (the default policy stops at one ray per CU)
     try:
         fused = forward()
+        assert lib.nrh_sampler_fusion(1) == 2
+        default = forward()
         assert lib.nrh_sampler_fusion(0) == 1
         plain = forward()
     finally:
         lib.nrh_sampler_fusion(was)
     for k in fused:
         assert torch.equal(fused[k], plain[k]), (k, float((fused[k] - plain[k]).abs().max()))
+        assert torch.equal(default[k], plain[k]), k
     assert float(fused["weights"].sum()) > 0.1 * nrays          # (rays that hit something: the comparison is not vacuous)
 
 
