@@ -81,8 +81,11 @@ def build_scene(precision):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_b.items()})
     if os.environ.get("NRH_BENCH_NO_FUSE"):       # A/B of NrhNet.feat_fused (profiles/r02/fused_head_ab.log); not a product knob
         model.fuse_feature_head = False
-    if os.environ.get("NRH_BENCH_CHUNK"):          # A/B of the rays-per-launch chunk (profiles/r02/chunk_rays_ab.log)
+    if os.environ.get("NRH_BENCH_CHUNK"):          # A/B of the rays-per-launch chunk (profiles/r02/chunk_rays_ab.log, r06/chunk_ab.log)
         model.max_chunk_rays = int(os.environ["NRH_BENCH_CHUNK"])
+        model.whole_frame_rays = 0
+    if os.environ.get("NRH_BENCH_SHARE_GPU") == "1" or os.environ.get("NRH_BENCH_WHOLE_FRAME") == "0":
+        model.whole_frame_rays = 0            # N ranks rehearsing on ONE GPU must not each take a whole-frame workspace; A/B runs
     if os.environ.get("NRH_BENCH_SHADOW_JVP"):     # A/B of the forward-mode shadow evaluation (profiles/r02/shadow_jvp_ab.log: slower)
         model.shadow_jvp = True
     if os.environ.get("NRH_BENCH_NO_WIDE_COLOR"):  # A/B of the wide reflectance kernel (profiles/r02/wide_color_ab.log)
@@ -121,10 +124,14 @@ def _traffic_from_summary(txt, precision, wide):
     return None
 
 
-def pmc_traffic(precision, wide):
+def pmc_traffic(precision, wide, rays_per_launch=None):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc passes of this same command
     (profiles/pmc_run.sh) - IF that summary was taken with today's kernel sources (its ``source_hash`` line); a summary of other
-    kernels is reported as stale and its number is not quoted.  -> (bytes or None, path or None, kind)."""
+    kernels is reported as stale and its number is not quoted.  -> (bytes or None, path or None, kind).
+    ``rays_per_launch``: this run's average rays per launch of the kernel; the summary's counters are per launch of ITS run
+    (``rays_per_launch`` line; summaries older than round 6 were taken with 4 x 131 072 + 115 712 rays per frame = 128 000 on
+    average) and the kernel's traffic is proportional to its points (the sigma' scratch round trip per point dominates), so the
+    figure is scaled to this run's launch size."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{precision}_v*", "summary.txt")))
@@ -135,6 +142,9 @@ def pmc_traffic(precision, wide):
             continue
         m = re.search(r"source_hash\s+(\w+)", txt)
         rel = os.path.relpath(path, ROOT)
+        mr = re.search(r"rays_per_launch\s+([0-9.]+)", txt)
+        if rays_per_launch:
+            t = int(t * float(rays_per_launch) / (float(mr.group(1)) if mr else 128000.0))
         if m and m.group(1) == kernel_source_hash():
             return t, rel, "committed rocprofv3 --pmc summary of this command taken with the same kernel sources (source_hash matches); --pmc collects it live"
         return None, rel, ("stale: the newest committed counter summary was taken with other kernel sources (source_hash "
@@ -637,7 +647,7 @@ def main():
         avg_ms = k_ms / launches
         achieved = FLOP_PER_POINT_CORE * pts_per_launch / (avg_ms * 1e-3) / 1e12
         wide = bool(getattr(model, "wide_kernels", False)) and args.precision == "f16x3"
-        traffic, traffic_src, traffic_kind = pmc_traffic(args.precision, wide)
+        traffic, traffic_src, traffic_kind = pmc_traffic(args.precision, wide, pts_per_launch / 128.0)
         if args.pmc and world == 1 and not os.environ.get("NRH_BENCH_PMC_CHILD"):
             live, how = pmc_live(args.precision, wide)
             if live is not None:
@@ -652,7 +662,7 @@ def main():
             "config": {"workload": "800x800 eval render (640000 primary rays/step" + ("" if strong else "/GPU") + "), 64+64 samples/ray, "
                                    "shadow + specular hints, synthetic random-weight scene b (BASELINE configs[1])",
                        "rays_per_step_per_gpu": (hi - lo), "samples_per_ray": 128,
-                       "chunk_rays": int(model.max_chunk_rays),
+                       "chunk_rays": int(model._pick_chunk(dev, nrays // (world if strong else 1))),
                        "parallelism": (f"one view in {world} row blocks + RCCL all-gather of rgb" if strong else f"view-sharded x{world}"),
                        "algorithmic_gflop_per_ray": round(FLOP_PER_RAY / 1e9, 4),
                        "whole_path_tflops": round(value * FLOP_PER_RAY / 1e12, 2),

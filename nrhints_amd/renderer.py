@@ -102,6 +102,12 @@ class SingleVarianceNetwork(nn.Module):
 class NeuSHintRenderer(nn.Module):
     #: rays per C call; bounds the workspace (about 145 KB per ray + 268 MB of gradient scratch)
     max_chunk_rays = 131072    # rays per nrh_render_forward call: 18 GB of workspace (HBM is 288 GB); +1.3 % over 32 768 (profiles/r02/chunk_rays_ab.log)
+    #: a batch larger than max_chunk_rays goes through in ONE call when its workspace fits whole_frame_fraction of the device's memory
+    #: (an 800 x 800 frame: 640 000 rays, 93 GB of the 288 GB) and can be allocated: 5 x fewer launch boundaries (persistent-grid
+    #: drains) per frame, +0.8 % on the headline (profiles/r06/chunk_ab.log); bit-identical by the re-chunking property
+    #: (tests/test_gpu_fullsize.py).  0 = never (always max_chunk_rays).
+    whole_frame_rays = 655360
+    whole_frame_fraction = 0.4
     #: matrix arithmetic of the MLP kernels: "f32" (v_mfma_f32_16x16x4_f32, exact fp32) or "f16x3" (three
     #: v_mfma_f32_16x16x32_f16 per product on fp16 hi/lo splits: fp32-equivalent accuracy at 16/3 the matrix rate), or - a
     #: REDUCED-precision evaluation mode, never the default - "f16": f16x3 in everything (packing, training, the reflectance net)
@@ -352,6 +358,26 @@ class NeuSHintRenderer(nn.Module):
             # linspace evaluated on the CPU so the tables are bit-identical to the reference's CPU/GPU values
             self._consts[k] = (torch.linspace(0.0, 1.0, 64).to(device), torch.linspace(0.0, 1.0, 16).to(device))
         return self._consts[k]
+
+    def _pick_chunk(self, device, n: int) -> int:
+        """Rays per nrh_render_forward call for a batch of ``n``: max_chunk_rays, or the whole batch when it is at most
+        whole_frame_rays and its workspace is affordable (see whole_frame_rays); an allocation failure falls back."""
+        if self.dyn_scalars is not None:
+            return max(1, min(self.max_eval_rays_while_graphed, n))
+        base = max(1, min(self.max_chunk_rays, n))
+        if n <= base or not self.whole_frame_rays or n > self.whole_frame_rays or self.max_chunk_rays != type(self).max_chunk_rays:
+            return base            # (an explicitly set max_chunk_rays is a request to chunk: tests of the re-chunking property, A/B runs)
+        need = int(_lib.load().nrh_render_workspace_floats(n)) * 4
+        ws = self._ws.get(str(device))
+        if ws is not None and ws.numel() * 4 >= need:
+            return n
+        if need > self.whole_frame_fraction * torch.cuda.get_device_properties(device).total_memory:
+            return base
+        try:
+            self._workspace(device, n)
+            return n
+        except torch.cuda.OutOfMemoryError:
+            return base
 
     def _workspace(self, device, nrays):
         lib = _lib.load()
@@ -672,7 +698,7 @@ class NeuSHintRenderer(nn.Module):
             out.update(normal_map=new(n, 3), normalized_normal_map=new(n, 3))
         if want_mid:
             out.update(mid_z=new(n, T), dists=new(n, T))
-        chunk = max(1, min(self.max_chunk_rays if self.dyn_scalars is None else self.max_eval_rays_while_graphed, n))
+        chunk = self._pick_chunk(device, n)
         cue_scratch = None
         if want_ray_cue and not want_samples:
             out.update(cue_ray=new(n, 4))

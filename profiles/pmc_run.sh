@@ -17,4 +17,9 @@ run write WRITE_SIZE
 python $GRAFT_REPO_ROOT/profiles/pmc_summarize.py $OUT > $OUT/summary.txt 2>&1
 # which kernels these counters belong to (bench.py quotes the summary only while this matches its own hash of the kernel sources)
 ( cd $GRAFT_REPO_ROOT && python -c "import bench; print('source_hash', bench.kernel_source_hash())" ) >> $OUT/summary.txt 2>/dev/null
+# ... and how many rays a launch of the dominant kernel had in these runs (bench.py scales the per-launch traffic to its own launch size)
+( cd $GRAFT_REPO_ROOT && python -c "
+import nrhints_amd as na
+c = na.NeuSHintRenderer.whole_frame_rays
+print('rays_per_launch', 640000 if c >= 640000 else 128000)" ) >> $OUT/summary.txt 2>/dev/null
 cat $OUT/summary.txt

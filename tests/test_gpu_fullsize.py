@@ -40,6 +40,9 @@ def test_configs1_full_frame(scene_states):
     launch of both chunkings."""
     model = _model(scene_states["b"])
     assert type(model).max_chunk_rays == 131072 and model.max_chunk_rays == 131072
+    # the default takes the whole 640 000-ray frame in ONE call (renderer.whole_frame_rays: 93 GB of workspace); below it is compared
+    # bit for bit with 65 536-ray chunks and with the 131 072-ray chunks it replaces
+    assert model._pick_chunk(torch.device("cuda", torch.cuda.current_device()), 640000) == 640000
     rays = make_image_rays(800, 800, azimuth=0.6, elevation=0.5)
     n = rays[0].shape[0]
     assert n == 640000 and n % 131072 == 115712
@@ -79,6 +82,16 @@ def test_configs1_full_frame(scene_states):
     for k in ("rgb", "depth", "visibilities", "weights"):
         assert torch.equal(keep[k], getattr(c, k)), k                                                # chunk-size independent, bit for bit
     assert torch.equal(nrm, c.analytic_normals[::997])
+    del c
+    torch.cuda.empty_cache()
+    model.whole_frame_rays = 0                      # 4 x 131 072 + 115 712: the chunking of rounds 2-5
+    try:
+        with torch.no_grad():
+            c = model(rb, is_training=False, background_rgb=one)
+    finally:
+        model.whole_frame_rays = type(model).whole_frame_rays
+    for k in ("rgb", "depth", "visibilities", "weights"):
+        assert torch.equal(keep[k], getattr(c, k)), k
     del c
     torch.cuda.empty_cache()
     # oracle on a strided sample: stride 313 -> 2 045 rays, at least 369 in every 131 072-launch and 184 in every 65 536-launch
@@ -171,6 +184,9 @@ def test_bench_rehearsal_on_one_gpu(world, scaling, extra):
     slab of rays), and (weak) the training leg's fused steps around the flat gradient all-reduce with the reference's split
     global batch - executed with N ranks.  Timing is meaningless here (one GPU, host-staged collectives); the line's structure,
     the rays accounted for and the per-rank host times are checked."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()        # (this process may still cache a whole-frame workspace from the tests above: 8 ranks need the GPU's memory)
     env_extra = {"NRH_BENCH_SHARE_GPU": "1"}
     if extra:
         env_extra["NRH_BENCH_EXTRA_RAYS"] = str(extra)
@@ -210,6 +226,9 @@ def test_bench_rehearsal_on_one_gpu(world, scaling, extra):
 def test_training_step_rehearsal_on_one_gpu(world):
     """tests/multi_gpu_worker.py with N ranks on one GPU (gloo): the flat all-reduce against the mean of the ranks' local
     gradients, and the two-graph GraphedTrainStep (graph | eager all-reduce | graph) keeping all ranks' parameters identical."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1",
                NRH_WORKER_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
