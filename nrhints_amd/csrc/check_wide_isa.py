@@ -3,7 +3,8 @@
   1. no v_accvgpr_read / v_accvgpr_mov and no AGPR spills (AGPRs belong to the generated schedule);
   2. no scratch use, no packed-f32 VALU;
   3. a register written by an asm global_load (q words) is not read or written by anything before the next s_waitcnt vmcnt
-     that covers it - here: before the next `s_waitcnt vmcnt(` at all (conservative).
+     that covers it - here: before the next `s_waitcnt vmcnt(` at all (conservative);
+  4. a half-register write (v_fma_mixlo_f16 / v_fma_mixhi_f16) is not consumed by the very next instruction.
     python nrhints_amd/csrc/check_wide_isa.py file.s   (the Makefile runs it on every build of nrh_wide.o)
 """
 import re, sys
@@ -17,10 +18,10 @@ def regs_of(tok):
 def main():
     path = sys.argv[1]
     kern, bad, inflight = None, [], {}
-    nload = 0
+    nload, npartial, partial = 0, 0, None
     for ln, line in enumerate(open(path), 1):
         m = re.match(r"^(_ZN\d+nrh32t?(?:12sdf32_kernelILi\dE|14color32_kernelE)\w+):", line)       # nrh32: three-term builds, nrh32t: one-term
-        if m: kern, inflight = m.group(1), {}; continue
+        if m: kern, inflight, partial = m.group(1), {}, None; continue
         if kern is None: continue
         if line.startswith(".Lfunc_end"): kern = None; continue
         t = line.strip().replace(",", " ").split()
@@ -28,15 +29,22 @@ def main():
         op = t[0]
         if op.startswith(("v_accvgpr_read", "v_accvgpr_mov")): bad.append((ln, "AGPR read/mov", line.strip()))
         if op.startswith("scratch_") or (op.startswith("v_pk_") and "f32" in op): bad.append((ln, "scratch / packed f32", line.strip()))
-        if op.startswith("s_waitcnt") and "vmcnt" in line: inflight = {}; continue
+        if op.startswith("s_waitcnt") and "vmcnt" in line: inflight, partial = {}, None; continue
         used = set()
         for tok in t[1:]: used |= regs_of(tok)
+        # 4. half-register writes (v_fma_mixlo_f16 / v_fma_mixhi_f16 of the generated hi / lo split, inside asm statements hipcc's
+        #    hazard recognizer does not see): the next instruction must not touch that register (gfx940+ dst_sel forwarding: 1 wait state)
+        if partial is not None and partial in used: bad.append((ln, f"v{partial}: half-register write consumed by the next instruction", line.strip()))
+        partial = None
+        if op in ("v_fma_mixlo_f16", "v_fma_mixhi_f16"):
+            npartial += 1
+            partial = min(regs_of(t[1]))
         hit = used & set(inflight)
         if hit: bad.append((ln, f"touches in-flight load result v{sorted(hit)[0]} (loaded at line {inflight[sorted(hit)[0]]})", line.strip()))
         if op.startswith("global_load_dwordx4"):
             nload += 1
             for r in regs_of(t[1]): inflight[r] = ln
-    print(f"{path}: {nload} asm/global dwordx4 loads checked, {len(bad)} problem(s)")
+    print(f"{path}: {nload} asm/global dwordx4 loads, {npartial} half-register writes checked, {len(bad)} problem(s)")
     for b in bad[:20]: print("  line %d: %s: %s" % b)
     return 1 if bad else 0
 

@@ -26,6 +26,9 @@ MFMA = "v_mfma_f32_32x32x16_f16"
 
 
 TRANS_COST = float(os.environ.get("NRH32_TRANS_COST", "1"))
+# hi / lo split of the SDF kernels' activations through v_fma_mixlo_f16 / v_fma_mixhi_f16 (see split_ops); NRH32_MIX_SPLIT=0: the
+# spelled-out C++ form of rounds 2-5 (A/B builds)
+MIX_SPLIT = os.environ.get("NRH32_MIX_SPLIT", "1") != "0"
 # NRH32_ONE_TERM=1: the SINGLE-PASS variant of every schedule (precision "f16": one v_mfma per K step - A_hi * B_hi, weights and
 # activations at fp16's 11 bits, fp32 accumulation): the two cross-term MFMAs of a K step are left out (their slots keep the
 # epilogue work and the DMA pieces), the low fragments are not read from LDS, the accumulator of the scaled cross terms (cc) does not
@@ -54,7 +57,14 @@ class Op:
         self.slot = None
 
 
+# timing ablations for profiles/ubench (WRONG RESULTS): the epilogues without their transcendentals / without their AGPR writes
+ABL_TRANS = bool(os.environ.get("NRH32_ABL_TRANS"))
+ABL_APUT = bool(os.environ.get("NRH32_ABL_APUT"))
+
+
 def aput(idx, val):
+    if ABL_APUT:
+        return Op(f'asm volatile("" ::"v"({val}));', uses=(val,), kind="aput")
     return Op(f'asm volatile("v_accvgpr_write_b32 a{idx}, %0" ::"v"({val}) : "a{idx}");', uses=(val,), kind="aput")
 
 
@@ -81,6 +91,21 @@ def split_ops(i, v0, v1, out_hi, out_lo, pfx="", scaled=False):
     if ONE_TERM:
         # (round to nearest: the high half is all there is - nrh_mlp32.h cvt_rn2)
         return [Op(f"nrh32::h16x2 hi{n} = nrh32::cvt_rn2({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1)), aput(out_hi, f"hi{n}")]
+    if MIX_SPLIT and not scaled:
+        # The residual pair straight into one packed register: v_fma_mixlo_f16 / v_fma_mixhi_f16 evaluate fma(hi (fp16, read in
+        # place), -1, v) in float32 - exact - and round the result to fp16 (nearest even) into the low / high half of the
+        # destination: 2 instructions per pair where hipcc made 5 of the spelled-out form (v_cvt_f32_f16 x 2, v_sub_f32 x 2 -
+        # an fma by -1 is folded into a subtraction, so v_fma_mix_f32 was never selected - and v_cvt_pkrtz).  A partial-register
+        # write must not be read by the NEXT VALU instruction (gfx940+ dst_sel forwarding hazard; hipcc cannot see into the
+        # statement): the high half's AGPR write sits between the two, and the low half's consumer is another micro-operation,
+        # scheduled at least one slot (one MFMA) later; check_wide_isa.py verifies both distances in the ISA.
+        return [
+            Op(f"nrh32::h16x2 hi{n} = __builtin_amdgcn_cvt_pkrtz({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1)),
+            Op(f'nrh32::h16x2 lo{n}; asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\\n\\t{"s_nop 0" if ABL_APUT else f"v_accvgpr_write_b32 a{out_hi}, %1"}\\n\\t'
+               f'v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(lo{n}) : "v"(hi{n}), "v"({v0}), "v"({v1}) : "a{out_hi}");',
+               defs=(f"lo{n}",), uses=(f"hi{n}", v0, v1), cost=3),
+            aput(out_lo, f"lo{n}"),
+        ]
     ops = [Op(f"nrh32::h16x2 hi{n} = __builtin_amdgcn_cvt_pkrtz({v0}, {v1});", defs=(f"hi{n}",), uses=(v0, v1))] + mid + [
         Op(f"nrh32::h16x2 lo{n} = __builtin_amdgcn_cvt_pkrtz(R{n}a, R{n}b);", defs=(f"lo{n}",), uses=(f"R{n}a", f"R{n}b")),
         aput(out_hi, f"hi{n}"),
@@ -100,13 +125,13 @@ def epi_fwd(c, hp, cp, want_d, out_base=128, qstore="W32_QSTORE", jvp=False):
             ops += [
                 Op(f"float t{r} = {joined(cp, hp, r)};", defs=(f"t{r}",)),
                 Op(f"float m{r} = __builtin_amdgcn_fmed3f(t{r}, 64.0f, -3.0e38f);", defs=(f"m{r}",), uses=(f"t{r}",)),
-                Op(f"float e{r} = __builtin_amdgcn_exp2f(m{r});", defs=(f"e{r}",), uses=(f"m{r}",), kind="trans"),
+                Op(f"float e{r} = {'0.5f * ' if ABL_TRANS else '__builtin_amdgcn_exp2f'}(m{r});", defs=(f"e{r}",), uses=(f"m{r}",), kind="trans"),
                 Op(f"float p{r} = 1.0f + e{r};", defs=(f"p{r}",), uses=(f"e{r}",)),
-                Op(f"float g{r} = __builtin_amdgcn_logf(p{r});", defs=(f"g{r}",), uses=(f"p{r}",), kind="trans"),
+                Op(f"float g{r} = {'0.5f * ' if ABL_TRANS else '__builtin_amdgcn_logf'}(p{r});", defs=(f"g{r}",), uses=(f"p{r}",), kind="trans"),
                 Op(f"float {'s' if jvp else 'u'}{r} = __builtin_amdgcn_fmed3f(g{r}, t{r}, 3.0e38f);", defs=(f"{'s' if jvp else 'u'}{r}",), uses=(f"g{r}", f"t{r}")),
             ]
             if want_d or jvp:
-                ops.append(Op(f"float q{r} = __builtin_amdgcn_rcpf(p{r});", defs=(f"q{r}",), uses=(f"p{r}",), kind="trans"))
+                ops.append(Op(f"float q{r} = {'0.25f * ' if ABL_TRANS else '__builtin_amdgcn_rcpf'}(p{r});", defs=(f"q{r}",), uses=(f"p{r}",), kind="trans"))
             if jvp:
                 ops += [
                     Op(f"float x{r} = W32_SWAP(q{r});", defs=(f"x{r}",), uses=(f"q{r}",)),
@@ -132,7 +157,7 @@ def epi_rev(c, hp, cp, out_base=128):
             ext = f"({w} >> 16)" if r & 1 else f"({w} & 0xffffu)"
             ops += [
                 Op(f"float g{r} = {joined(cp, hp, r)};", defs=(f"g{r}",)),
-                Op(f"float f{r} = (float){ext};", defs=(f"f{r}",), cost=2),
+                Op(f"float f{r} = (float){ext};", defs=(f"f{r}",)),          # one instruction: v_cvt_f32_u32_sdwa src0_sel:WORD_n
                 Op(f"float n{r} = g{r} * (-1.0f / 65535.0f);", defs=(f"n{r}",), uses=(f"g{r}",)),
                 Op(f"float u{r} = __builtin_fmaf(n{r}, f{r}, g{r});", defs=(f"u{r}",), uses=(f"n{r}", f"f{r}", f"g{r}")),
             ]
@@ -194,6 +219,20 @@ def schedule(ops, nslots, per_slot, trans_cost=1.0):
     return slots, todo
 
 
+# Between two groups of micro-operations that no MFMA separates (slots behind a K loop, the finish blocks): one wait state, so that
+# the consumer of a half-register write (split_ops: v_fma_mixhi_f16) is never the very next VALU instruction
+PARTIAL_WRITE_GAP = 'asm volatile("s_nop 0");'
+
+
+def emit_tail(out, ops, ind="  "):
+    """Left-over operations in list order: dependent ones can be neighbours here, so every consumer of a half-register write gets
+    its wait state explicitly."""
+    for o in ops:
+        if o.kind == "aput":
+            out.append(ind + PARTIAL_WRITE_GAP)
+        emit_ops(out, [o], ind)
+
+
 def emit_ops(out, ops, ind="  "):
     pins = []
     for o in ops:
@@ -220,33 +259,51 @@ class Window:
         self.use_ds = use_ds    # False: micro-benchmarks without LDS traffic (fragments stay whatever they are)
 
     def frag(self, s, part):
-        return f"fa{(s % (self.pf + 1)) * 2 + part}"
+        return f"fa{((s + self.rot) % (self.pf + 1)) * 2 + part}"
 
-    def emit(self, out, slots_ops, ind="  ", dma=None, head=None):
+    @staticmethod
+    def decl(pf=2):
+        return "nrh32::u32x4 " + ", ".join(f"fa{i}" for i in range((pf + 1) * 2)) + ";"
+
+    def emit(self, out, slots_ops, ind="  ", dma=None, head=None, declare=True, preloaded=False, prefetch_next=False, rot=0):
         """dma: {slot: [piece, ...]} - W32_DMA(piece) calls (LDS-DMA of a later block) issued in that slot.
         head: list of op lists emitted between the first LDS reads and the first MFMA (VALU work in the LDS latency: a SIMD
-        does not overlap one wave's VALU with its MFMAs anyway, so what sits here is free up to that latency)."""
+        does not overlap one wave's VALU with its MFMAs anyway, so what sits here is free up to that latency).
+        Cross-window prefetch (gen_stage, XWIN): with prefetch_next the block barrier of the NEXT window (W32_SYNC_MID: this wave's
+        pieces of the next block have landed, every fragment read of this block has returned, then s_barrier) sits behind the MFMAs
+        of K step ks - 2, and the last K step issues the fragment reads of the next window's first pf steps (address W32_WADDR_NEXT)
+        into the buffers the rotation would give steps ks, ks + 1, ... - the next window is emitted with preloaded=True and
+        rot = (rot + ks) % (pf + 1): no barrier and no cold LDS reads at its top.  The fragment variables then live at stage scope
+        (declare=False)."""
         ks, pf = self.ks, self.pf
+        self.rot = rot
         dma = dma or {}
-        nbuf = (pf + 1) * 2
-        out.append(ind + "nrh32::u32x4 " + ", ".join(f"fa{i}" for i in range(nbuf)) + ";")
+        if declare:
+            out.append(ind + self.decl(pf))
         issued = []  # LDS reads in issue order: (s, part)
 
-        def ds(s, part):
-            off = (2 * s + part) * 1024
+        def ds(s, part, base=None, soff=None):
+            off = (2 * (s if soff is None else soff) + part) * 1024
             issued.append((s, part))
             if not self.use_ds:
                 return
             # "memory": compiler-visible LDS loads (the bias word) stay where they are written - one that hipcc sinks between
             # these reads would become one of the "N youngest" the K loop's lgkmcnt(N) waits deliberately leave in flight
-            clob = ' : "memory"' if self.bias else ""
-            out.append(ind + f'asm volatile("ds_read_b128 %0, %1 offset:{off}" : "=v"({self.frag(s, part)}) : "v"({self.wa}){clob});')
+            clob = ' : "memory"' if (self.bias or base is not None) else ""
+            out.append(ind + f'asm volatile("ds_read_b128 %0, %1 offset:{off}" : "=v"({self.frag(s, part)}) : "v"({base or self.wa}){clob});')
 
         def wait_for(s, part):
             idx = issued.index((s, part))
             return len(issued) - 1 - idx
 
         for s in range(min(pf, ks)):
+            if preloaded:
+                # issued by the previous window's last K step, in this order (a compiler-visible LDS load between them and this
+                # window's own reads - the bias word - is not counted: the waits then cover one read more than needed, never fewer)
+                issued.append((s, 0))
+                if not ONE_TERM:
+                    issued.append((s, 1))
+                continue
             ds(s, 0)
             if not ONE_TERM:
                 ds(s, 1)
@@ -269,6 +326,13 @@ class Window:
                 # the MFMAs of step s - 1, all issued by now)
                 if s + pf < ks and j < (1 if ONE_TERM else 2):
                     ds(s + pf, j)
+                elif prefetch_next and s == ks - 1:
+                    # the next window's K steps 0 .. pf - 1, as steps ks .. ks + pf - 1 of this one (pf = 2: one read ahead of each of
+                    # the first two MFMAs, the second step's pair ahead of the third)
+                    nxt = [(t, q) for t in range(pf) for q in ((0,) if ONE_TERM else (0, 1))]
+                    per = (len(nxt) + 2) // 3
+                    for t, q in (nxt[j * per:(j + 1) * per] if j < 2 else nxt[2 * per:]):
+                        ds(ks + t, q, base="wa_next", soff=t)
                 # j = 0: A_hi * B_hi -> hh;  j = MID: A_lo * B_hi (A_lo is scaled by 2^11) -> cc;  the other: A_hi * B_lo (B_lo is
                 # unscaled) -> hh.  MID = 1 keeps the two hh updates of a K step apart (no back-to-back dependent MFMAs).
                 lo_a = (j == MID)
@@ -297,9 +361,14 @@ class Window:
                     emit_ops(out, slots_ops[slot], ind)
                 out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
                 slot += 1
+            if prefetch_next and s == ks - 2:
+                out.append(ind + "W32_SYNC_MID();")
+                out.append(ind + "const uint32_t wa_next = W32_WADDR_NEXT();")
+                out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
         # slots beyond the K loop (short K loops: the epilogue is longer than the MFMA stream)
         while slots_ops is not None and slot < len(slots_ops):
             if slots_ops[slot]:
+                out.append(ind + PARTIAL_WRITE_GAP)
                 emit_ops(out, slots_ops[slot], ind)
                 out.append(ind + "__builtin_amdgcn_sched_barrier(0);")
             slot += 1
@@ -315,6 +384,11 @@ MID = int(os.environ.get("NRH32_MID", "1"))      # which of a K step's three MFM
 # VALU ops placed ahead of a window's first MFMA, in HEAD_SLOTS dependency levels of HEAD_OPS each (see Window.emit)
 HEAD_SLOTS = int(os.environ.get("NRH32_HEAD_SLOTS", "0"))
 HEAD_OPS = int(os.environ.get("NRH32_HEAD_OPS", "10"))
+# cross-window prefetch of the weight fragments inside a stage (Window.emit); NRH32_XWIN=0: every window opens with its barrier and
+# cold LDS reads (rounds 2-5)
+XWIN = os.environ.get("NRH32_XWIN", "1") != "0"
+# VALU micro-operations fewer in a slot that also issues an LDS-DMA piece (s_mov m0 + s_nop + global_load_lds)
+DMA_PENALTY = int(os.environ.get("NRH32_DMA_PENALTY", "2"))
 
 
 def acc_names(c):
@@ -362,6 +436,10 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
     # window's opening wait keeps that many more operations in flight instead of draining them with `s_waitcnt vmcnt(8)`.
     sync_k = bool(os.environ.get("NRH32_SYNCK"))
     prev_stores = 0
+    xwin = XWIN and not small
+    if xwin:
+        out.append("  " + Window.decl())
+    rot = 0
     for c in range(7):
         out.append(f"  nrh32::f32x16 hh{c}, cc{c};")
     for c in range(7):
@@ -375,7 +453,9 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         ph, pc = acc_names(prev)
         has_epi = (c > 0 or pend_in) and not os.environ.get("NRH32_NOEPI")
         ekind = kind if c > 0 else pend_kind
-        if not small or c % 4 == 0:
+        if xwin and c > 0:
+            out.append("    W32_FETCH_SETUP();")         # (the block barrier sat in the previous window: W32_SYNC_MID)
+        elif not small or c % 4 == 0:
             if sync_k and not small and c > 0 and prev_stores:
                 out.append(f"    W32_SYNC_K({8 + prev_stores});")
             elif sync_k and not small and c == 0 and pend_in:
@@ -427,7 +507,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
             dma = DMA_SLOTS16
         if epi is not None:
             w_nv = nv + 2 if (c == 0 and not small) else nv      # window 0: everything has to sit before K step 14 (slot 42)
-            budget = (lambda k: max(1, w_nv - 2) if k in dma else w_nv) if not small else w_nv
+            budget = (lambda k: max(1, w_nv - DMA_PENALTY) if k in dma else w_nv) if not small else w_nv
             nslots = max(3 * ks, (len(epi) + w_nv - 1) // w_nv + 8)
             if c == 0 and not small:
                 budget0 = budget
@@ -442,10 +522,14 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         else:
             slots, tail = None, []
         prev_stores = sum(1 for o in (epi or []) if o.kind == "vmem")
-        win.emit(out, slots, "    ", dma=dma, head=head)
+        if xwin:
+            win.emit(out, slots, "    ", dma=dma, head=head, declare=False, preloaded=(c > 0), prefetch_next=(c < 7), rot=rot)
+            rot = (rot + ks) % 3
+        else:
+            win.emit(out, slots, "    ", dma=dma, head=head)
         if tail:
             out.append("    // epilogue work that did not fit the MFMA shadows")
-            emit_ops(out, tail, "    ")
+            emit_tail(out, tail, "    ")
         if skip:
             out.append(f"    W32_SKIP({c}, {hh}, {cc});")
         if not small or c % 4 == 3:
@@ -479,6 +563,7 @@ def gen_finish(kind, want_d, out_base):
     slots, tail = schedule(epi, (len(epi) + 7) // 8 + 8, 8)
     for ops in slots:
         if ops:
+            out.append("  " + PARTIAL_WRITE_GAP)
             emit_ops(out, ops, "  ")
             out.append("  __builtin_amdgcn_sched_barrier(0);")
     assert not tail
@@ -531,8 +616,11 @@ def gen_t7():
             ops += [Op(f"float f{r} = (float){ext};", defs=(f"f{r}",)),
                     Op(f"float n{r} = a8[{r}] * (-1.0f / 65535.0f);", defs=(f"n{r}",)),
                     Op(f"float u{r} = __builtin_fmaf(n{r}, f{r}, a8[{r}]);", defs=(f"u{r}",))]
-        for i in range(8):
-            ops += split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", 8 * c + i, 64 + 8 * c + i)
+        sp = [split_ops(i, f"u{2 * i}", f"u{2 * i + 1}", 8 * c + i, 64 + 8 * c + i) for i in range(8)]
+        # the eight pairs stage by stage (all high halves, all residuals, all AGPR writes): no operation directly behind the one that
+        # produces its input (the residual pair is a half-register write, see split_ops)
+        for k in range(max(len(x) for x in sp)):
+            ops += [x[k] for x in sp if k < len(x)]
         for o in ops:
             out.append("    " + o.code)
         out.append("    __builtin_amdgcn_sched_barrier(0);")
@@ -553,6 +641,8 @@ def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen32")
     os.makedirs(outdir, exist_ok=True)
     nv = int(os.environ.get("NRH32_NV", "4"))
+    nv_rev = int(os.environ.get("NRH32_NV_REV", str(nv)))       # the reverse stages' budget (their epilogue is the shortest)
+    nv_d1 = int(os.environ.get("NRH32_NV_D1", str(nv + 1)))     # forward stages that also encode and store sigma'
     bm = True      # bias through one extra MFMA per window (see gen_stage); the older start-value form is gone from the kernel
     nohinit = bool(os.environ.get("NRH32_NOHINIT"))      # timing ablation (WRONG RESULTS): forward windows start from zero
     files = {
@@ -560,8 +650,8 @@ def main():
         "l0_d1.inc": gen_stage("fwd", True, 3, "vgpr", 10, False, in_base=0, out_base=0, pend_in=False, bias_mfma=bm),
         "fwd_d0_p0.inc": gen_stage("fwd", False, 16, "agpr", nv, nohinit, in_base=0, out_base=128, bias_mfma=bm),
         "fwd_d0_p1.inc": gen_stage("fwd", False, 16, "agpr", nv, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
-        "fwd_d1_p0.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, nohinit, in_base=0, out_base=128, bias_mfma=bm),
-        "fwd_d1_p1.inc": gen_stage("fwd", True, 16, "agpr", nv + 1, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
+        "fwd_d1_p0.inc": gen_stage("fwd", True, 16, "agpr", nv_d1, nohinit, in_base=0, out_base=128, bias_mfma=bm),
+        "fwd_d1_p1.inc": gen_stage("fwd", True, 16, "agpr", nv_d1, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
         "fwd_fin_d0.inc": gen_finish("fwd", False, 128),
         # forward-mode variant for rays that only need the derivative along the ray (shadow march): 16 points + 16 tangents per tile
         "l0_j.inc": gen_stage("fwd_jvp", False, 3, "vgpr", 12, False, in_base=0, out_base=0, pend_in=False, bias_mfma=bm),
@@ -569,8 +659,8 @@ def main():
         "fwd_j_p1.inc": gen_stage("fwd_jvp", False, 16, "agpr", nv + 2, nohinit, in_base=128, out_base=0, bias_mfma=bm, skip=bm),
         "fwd_fin_j.inc": gen_finish("fwd_jvp", False, 128),
         "fwd_fin_d1.inc": gen_finish("fwd", True, 128),
-        "rev_p0.inc": gen_stage("rev", True, 16, "agpr", nv, True, in_base=0, out_base=128),
-        "rev_p1.inc": gen_stage("rev", True, 16, "agpr", nv, True, in_base=128, out_base=0),
+        "rev_p0.inc": gen_stage("rev", True, 16, "agpr", nv_rev, True, in_base=0, out_base=128),
+        "rev_p1.inc": gen_stage("rev", True, 16, "agpr", nv_rev, True, in_base=128, out_base=0),
         "rev_fin.inc": gen_finish("rev", True, 128),
         "kloop16.inc": gen_kloop(16, "agpr", False),
         "kloop16z.inc": gen_kloop(16, "agpr", True),

@@ -80,6 +80,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W32_FETCH_SETUP() fetch_setup()
 #define W32_WADDR() (wlane + cur_off)
 #define W32_NEXT() (cur_off = (cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES)
+// cross-window prefetch inside a stage (gen_mlp32.py Window.emit): the next block's barrier behind K step 14 of this window, then
+// the first fragment reads of the next window from the slot W32_NEXT() is about to select
+#define W32_SYNC_MID() W32_SYNC()
+#define W32_WADDR_NEXT() (wlane + ((cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES))
 #define W32_BCONST bconst
   const u32x4 bconst = {hf ? 0u : 0x10003c00u, 0u, 0u, 0u};
   const char* const brow = tabs + (lane & 31) * 4;
@@ -187,6 +191,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #undef W32_FETCH_SETUP
 #undef W32_WADDR
 #undef W32_NEXT
+#undef W32_SYNC_MID
+#undef W32_WADDR_NEXT
 #undef W32_BCONST
 }
 

@@ -252,6 +252,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W32_FETCH_SETUP() fetch_setup()
 #define W32_WADDR() (wlane + cur_off)
 #define W32_NEXT() (cur_off = (cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES)
+// cross-window prefetch inside a stage (gen_mlp32.py Window.emit): the next block's barrier behind K step 14 of this window, then
+// the first fragment reads of the next window from the slot W32_NEXT() is about to select
+#define W32_SYNC_MID() W32_SYNC()
+#define W32_WADDR_NEXT() (wlane + ((cur_off == 2 * SLOT_BYTES) ? 0 : cur_off + SLOT_BYTES))
 
     NRH32_STAMP(0);   // setup: rays, embedding
     // The layers ping-pong between the two AGPR sets (a[0:127], a[128:255]): L0 writes set 0, L1 reads it and writes set 1,

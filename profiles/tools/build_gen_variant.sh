@@ -17,5 +17,5 @@ if [ -n "$DEFS" ]; then ( cd $W/csrc && /opt/rocm/bin/hipcc $FLAGS $DEFS -c -o a
 ( cd $W/csrc && /opt/rocm/bin/hipcc $FLAGS -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form $DEFS -save-temps=obj -c -o wide.o nrh_wide.hip )
 wait
 python3 $CS/check_wide_isa.py $W/csrc/nrh_wide-hip-amdgcn-amd-amdhsa-gfx950.s
-grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count):" $W/csrc/nrh_wide-hip-amdgcn-amd-amdhsa-gfx950.s | paste - - - | sed 's/  */ /g' | grep "Li4E"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/nrhints_amd/lib/variants/libnrh_$NAME.so $API $W/csrc/wide.o $ROOT/nrhints_amd/lib/obj/nrh_small.o   # (the 4-wave training kernels: main build's unit)
+grep -E "^\s+\.(name|vgpr_count|vgpr_spill_count):" $W/csrc/nrh_wide-hip-amdgcn-amd-amdhsa-gfx950.s | paste - - - | sed 's/  */ /g' | grep "sdf32_kernel" || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/nrhints_amd/lib/variants/libnrh_$NAME.so $API $W/csrc/wide.o $ROOT/nrhints_amd/lib/obj/nrh_wide1.o $ROOT/nrhints_amd/lib/obj/nrh_small.o   # (the 4-wave training kernels: main build's unit)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Test vectors for profiles/ubench/sdf32_bench.hip: packed streams + tables of synthetic scene b, rays, sample positions and
-the fp64 oracle's sdf / gradient / feature at the first NCHECK points.  Output: profiles/ubench/data/sdf32_case.bin
+the fp64 oracle's sdf / gradient / feature at the first NCHECK points.  Output: profiles/ubench/bin/sdf32_case.bin
 (little-endian: header of int64 counts, then the arrays).  Runs on CPU; the file travels to the GPU box with the snapshot."""
 import os, sys
 import numpy as np, torch
@@ -30,7 +30,7 @@ def main():
     pts32 = (o[:, None, :] + dd[:, None, :] * t[:, :, None]).reshape(-1, 3).astype(np.float32)
     p64 = orc.params_from_state(st, torch.float64)
     sdf, feat, grad = orc.sdf_forward_grad_analytic(p64, torch.from_numpy(pts32[:ncheck].astype(np.float64)))
-    out = os.path.join(ROOT, "profiles", "ubench", "data", sys.argv[4] if len(sys.argv) > 4 else "sdf32_case.bin")
+    out = os.path.join(ROOT, "profiles", "ubench", "bin", sys.argv[4] if len(sys.argv) > 4 else "sdf32_case.bin")
     with open(out, "wb") as f:
         hdr = np.array([nrays, nper, ncheck, streams.numel(), tables.numel()], dtype=np.int64)
         f.write(hdr.tobytes())
