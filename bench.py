@@ -67,6 +67,11 @@ FLOP_PER_RAY_STEP = 1.4186e9
 # fp16 MFMAs per algorithmic multiply-add, so its ceiling in ALGORITHMIC flops is 833 TFLOP/s; frac is quoted
 # against the fp16 peak all the same (the honest denominator for the instruction that is issued).
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
+# measured context of the f16x3 roofline fraction (reported beside it, never instead of it): v_mfma_f32_32x32x16_f16 with random
+# operands in a bare register loop on one MI355X under its 1.4 kW package limit (2 492 TFLOP/s with all-zero operands), and the
+# kernel's MFMA-FLOP per algorithmic FLOP from the PMC passes (profiles/r06/mfma_sustained.log, profiles/r06/pmc_f16x3_*/summary.txt)
+SUSTAINED_MFMA_TFLOPS = 1710.0
+MFMA_FLOP_PER_ALGORITHMIC_FLOP = 3.16
 # the CPU baseline is the reference's algorithm; what runs on the GPU box is its restatement (oracle, mode "as_written").
 # Their wall times on identical rays / threads, reference under no_grad as its evaluation loop calls it
 # (pipelines/base_pipeline.py:114-119): 7.47 s against 7.42 s per 512 rays on 8 cores (profiles/r05/cpu_baseline_crosscheck.log).
@@ -682,6 +687,16 @@ def main():
                          "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
                          "algorithmic_flop_per_point": FLOP_PER_POINT_CORE},
         }
+        if args.precision == "f16x3":
+            # Context for `frac` (which stays priced against the guide's 2 500 TFLOP/s): the same MFMA instruction in a bare register
+            # loop sustains SUSTAINED_MFMA_TFLOPS with random operands - the package power limit, not the issue rate (32.00 cycles per
+            # MFMA there), sets it (profiles/ubench/mfma_sustained.hip -> profiles/r06/mfma_sustained.log); the kernel issues
+            # MFMA_FLOP_PER_ALGORITHMIC_FLOP MFMA-FLOP per algorithmic FLOP (three-term split, bias MFMAs, K padding; PMC SQ_INSTS_MFMA)
+            line["roofline"]["power_limit_context"] = {
+                "sustained_mfma_tflops_random_operands": SUSTAINED_MFMA_TFLOPS, "source": "profiles/r06/mfma_sustained.log",
+                "mfma_flop_per_algorithmic_flop": MFMA_FLOP_PER_ALGORITHMIC_FLOP,
+                "issued_mfma_tflops": round(achieved * MFMA_FLOP_PER_ALGORITHMIC_FLOP, 1),
+                "frac_of_sustained": round(achieved * MFMA_FLOP_PER_ALGORITHMIC_FLOP / SUSTAINED_MFMA_TFLOPS, 3)}
         if world == 1 and args.cpu_rays > 0:
             line["cpu_baseline"] = cpu_baseline(state, rays_np, args.cpu_rays, rgb)
         else:
