@@ -17,7 +17,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "nrhints_hip.h")
 def source_files():
     """Hand-written sources only (the generated gen32*/ schedules are a function of gen_mlp32.py, the objects of these files)."""
     files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")))
-    files += [os.path.join(CSRC, n) for n in ("gen_mlp32.py", "check_wide_isa.py", "Makefile")]
+    files += [os.path.join(CSRC, n) for n in ("gen_mlp32.py", "check_wide_isa.py", "check_gen32.py", "Makefile")]
     return files + [HEADER]
 
 

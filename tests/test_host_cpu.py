@@ -438,6 +438,40 @@ def test_wide_kernel_isa_invariants(tmp_path):
     assert chk.returncode == 0, chk.stdout + chk.stderr
 
 
+@pytest.mark.parametrize("env", [{}, {"NRH32_ONE_TERM": "1"}, {"NRH32_XWIN": "0"}, {"NRH32_MIX_SPLIT": "0", "NRH32_NV": "3", "NRH32_DMA_PENALTY": "0"}])
+def test_generated_schedules_lds_counter_model(tmp_path, env):
+    """The generated wide-kernel windows wait for their weight fragments with computed ``s_waitcnt lgkmcnt(N)`` and, since round 6,
+    request the first fragments of window n + 1 from inside window n (gen_mlp32.py XWIN).  nrhints_amd/csrc/check_gen32.py replays every
+    generated file against the in-order LDS counter: an MFMA may only read a fragment register whose read has landed AND holds the
+    fragment that MFMA is due.  Every generator configuration the tree builds or A/B-tests is checked; two deliberately broken files
+    (a wait loosened by two, the cross-window reads dropped) must be reported."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "nrhints_amd", "csrc")
+    out = str(tmp_path / "gen")
+    r = subprocess.run([sys.executable, os.path.join(csrc, "gen_mlp32.py"), out], env={**os.environ, **env}, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    chk = subprocess.run([sys.executable, os.path.join(csrc, "check_gen32.py"), out], capture_output=True, text=True)
+    assert chk.returncode == 0 and " 0 problem(s)" in chk.stdout, chk.stdout[-2000:]
+    assert int(re.search(r"(\d+) MFMA fragment reads", chk.stdout).group(1)) > 1500
+    sys.path.insert(0, csrc)
+    try:
+        import check_gen32
+    finally:
+        sys.path.remove(csrc)
+    text = open(os.path.join(out, "rev_p0.inc")).read()
+    assert check_gen32.check_text(text)[1] == []
+    pat = r"lgkmcnt\(1\)" if env.get("NRH32_ONE_TERM") else r"lgkmcnt\(3\)"
+    at = [m.start() for m in re.finditer(pat, text)][10]
+    loose = text[:at] + "lgkmcnt(5)" + text[at + len("lgkmcnt(3)"):]
+    assert any("in flight" in p for p in check_gen32.check_text(loose)[1])
+    if env.get("NRH32_XWIN") != "0":
+        dropped = re.sub(r'asm volatile\("ds_read_b128 %0, %1 offset:\d+" : "=v"\(fa\d\) : "v"\(wa_next\) : "memory"\);\n', "", text, count=2)
+        assert any("expected" in p for p in check_gen32.check_text(dropped)[1])
+
+
 def test_uint8_image_products_match_reference_fixture():
     """``to_uint8_images`` on the reference's own float images reproduces the uint8 arrays recorded with them
     (trainer/trainer.py:343-352 applied by make_golden_evaldict.py inside the reference process)."""
