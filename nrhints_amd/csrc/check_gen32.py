@@ -13,6 +13,9 @@ LDS queue exactly as the hardware counts it:
     MFMA is due (window = definition of `wa`, K step and half from the MFMA's position in the window; reads through `wa_next` belong to
     the next window): a dropped or misdirected read is reported even where stale data would have been "ready".
 
+Also checked (check_dma): every block set up by W32_FETCH_SETUP() gets exactly its eight LDS-DMA pieces, all of them ahead of a block
+barrier placed inside the window.
+
 The walk is sequential over a file, so the cross-window prefetch (a window that opens without reads of its own finds its first
 fragments requested by the window before it, through `wa_next`) falls under the same two rules.
 
@@ -74,7 +77,31 @@ def check_text(text):
             if holds.get(reg) != want:
                 problems.append(f"line {ln}: MFMA {nth} of window {window} reads {reg} = fragment {holds.get(reg)}, expected {want}")
             nth += 1
+    problems += check_dma(text)
     return checked, problems
+
+
+def check_dma(text):
+    """Every W32_FETCH_SETUP() (one 32 KiB block of the weight stream) is followed by exactly the pieces 0..7 of W32_DMA before the next
+    one, and a block barrier inside a window (W32_SYNC_MID: `s_waitcnt vmcnt(8)` = "everything but this window's 8 pieces has landed")
+    comes after all 8."""
+    problems, pieces, start, mid = [], None, 0, False
+    def close(ln):
+        if pieces is not None and sorted(pieces) != list(range(8)):
+            problems.append(f"line {start}: block set up here issues LDS-DMA pieces {sorted(pieces)} before line {ln}, expected 0..7 once each")
+    for ln, line in enumerate(text.split("\n"), 1):
+        if "W32_FETCH_SETUP()" in line and "define" not in line:
+            close(ln)
+            pieces, start, mid = [], ln, False
+        elif pieces is not None and "W32_SYNC_MID()" in line and "define" not in line:
+            if len(pieces) != 8:
+                problems.append(f"line {ln}: block barrier behind {len(pieces)} of the window's 8 LDS-DMA pieces (its vmcnt(8) would let a piece of the NEXT block stay in flight)")
+        else:
+            for m in re.finditer(r"W32_DMA\((\d+)\)", line):
+                if pieces is not None:
+                    pieces.append(int(m.group(1)))
+    close(len(text.split("\n")))
+    return problems
 
 
 def check_dir(d):

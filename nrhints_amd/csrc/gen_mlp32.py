@@ -278,6 +278,8 @@ class Window:
         ks, pf = self.ks, self.pf
         self.rot = rot
         dma = dma or {}
+        assert all(k < 3 * ks for k in dma), "an LDS-DMA piece scheduled behind the window's last MFMA slot would never be issued"
+        assert not prefetch_next or all(k < 3 * (ks - 1) for k in dma), "LDS-DMA pieces behind the block barrier (W32_SYNC_MID)"
         if declare:
             out.append(ind + self.decl(pf))
         issued = []  # LDS reads in issue order: (s, part)
@@ -374,7 +376,15 @@ class Window:
             slot += 1
 
 
-DMA_SLOTS16 = {2 + 3 * k: [k] for k in range(8)}     # regular window: one piece of block n + 2 after the last MFMA of K steps 0..7
+# regular window: one piece of block n + 2 behind the FIRST MFMA of K steps 6..13 - late in the window, where the epilogue (scheduled as
+# early as its dependencies allow) has thinned out, and ahead of the block barrier behind K step 14.  Rounds 2-5 issued them behind the
+# last MFMA of K steps 0..7 (NRH32_DMA_J=2 NRH32_DMA_FIRST=0): 521.1 -> 523.6 k rays/s interleaved (profiles/r06/eval_dma_slots_ab.log);
+# knobs: NRH32_DMA_J = which of the K step's three slots, NRH32_DMA_FIRST = first K step, NRH32_DMA_STRIDE = every how many K steps
+DMA_SLOTS16 = {int(os.environ.get("NRH32_DMA_J", "0")) + 3 * (int(os.environ.get("NRH32_DMA_FIRST", "6")) + int(os.environ.get("NRH32_DMA_STRIDE", "1")) * k): [k]
+               for k in range(8)}
+assert max(DMA_SLOTS16) < 42, "the LDS-DMA pieces of a window have to be issued ahead of its block barrier (behind K step 14)"
+# a full block consumed in fewer K steps (the reflectance net's first stage, ks = 8): one piece behind the last MFMA of every K step
+DMA_SLOTS_SHORT = {2 + 3 * k: [k] for k in range(8)}
 
 
 # experiment: the reflectance net's activations with the UNSCALED residual as well - build with
@@ -436,7 +446,9 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
     # window's opening wait keeps that many more operations in flight instead of draining them with `s_waitcnt vmcnt(8)`.
     sync_k = bool(os.environ.get("NRH32_SYNCK"))
     prev_stores = 0
-    xwin = XWIN and not small
+    # (16-step windows only: the block barrier behind K step ks - 2 has to come after ALL of the window's LDS-DMA pieces - its
+    # `vmcnt(8)` counts them as the 8 youngest - and a shorter window issues one per K step up to its last)
+    xwin = XWIN and ks == 16
     if xwin:
         out.append("  " + Window.decl())
     rot = 0
@@ -504,7 +516,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         if small:
             dma = {2: [2 * (c % 4)], 5: [2 * (c % 4) + 1]}
         else:
-            dma = DMA_SLOTS16
+            dma = DMA_SLOTS16 if ks == 16 else DMA_SLOTS_SHORT
         if epi is not None:
             w_nv = nv + 2 if (c == 0 and not small) else nv      # window 0: everything has to sit before K step 14 (slot 42)
             budget = (lambda k: max(1, w_nv - DMA_PENALTY) if k in dma else w_nv) if not small else w_nv
