@@ -86,17 +86,18 @@ int main(int argc, char** argv) {
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h_sdf.data(), d_sdf, npts * 4, hipMemcpyDeviceToHost));
-    double esdf = 0, egrad = 0, efeat = 0, chk = 0;
+    double esdf = 0, egrad = 0, efeat = 0, chk = 0, gsum = 0, fsum = 0;     // checksums over ALL points: sdf, gradient, features
     long long nan = 0;
     for (long long i = 0; i < npts; ++i) { if (!(h_sdf[i] == h_sdf[i])) ++nan; else chk += h_sdf[i]; }
     for (long long i = 0; i < ncheck; ++i) esdf = fmax(esdf, fabs(h_sdf[i] - e_sdf[i]));
     if (mode >= 1) {
       CK(hipMemcpy(h_grad.data(), d_grad, npts * 12, hipMemcpyDeviceToHost));
       for (long long i = 0; i < ncheck * 3; ++i) egrad = fmax(egrad, fabs(h_grad[i] - e_grad[i]));
-      for (long long i = 0; i < npts * 3; ++i) if (!(h_grad[i] == h_grad[i])) ++nan;
+      for (long long i = 0; i < npts * 3; ++i) { if (!(h_grad[i] == h_grad[i])) ++nan; else gsum += h_grad[i]; }
     }
     if (mode == 2) {
       CK(hipMemcpy(h_feat.data(), d_feat, h_feat.size() * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < (size_t)(npts / 16) * 4096; ++i) fsum += h_feat[i];
       for (long long p = 0; p < ncheck; ++p)
         for (int ft = 0; ft < 256; ++ft) {
           const long long tile = p / 16;
@@ -138,8 +139,8 @@ int main(int argc, char** argv) {
     ms /= reps;
     const bool pass = nan == 0 && esdf < 5e-6 && egrad < 5e-4 && efeat < 5e-5;
     if (!pass) ++bad;
-    printf("mode %d: %8.3f ms  %7.1f TFLOP/s (algorithmic)  max|sdf-ref| %.3e  max|grad-ref| %.3e  max|feat-ref| %.3e  nan %lld  sum(sdf) %.6f  %s\n",
-           mode, ms, flop_pt[mode] * npts / ms / 1e9, esdf, egrad, efeat, nan, chk, pass ? "PASS" : "FAIL");
+    printf("mode %d: %8.3f ms  %7.1f TFLOP/s (algorithmic)  max|sdf-ref| %.3e  max|grad-ref| %.3e  max|feat-ref| %.3e  nan %lld  sum(sdf) %.6f  sum(grad) %.6f  sum(feat) %.4f  %s\n",
+           mode, ms, flop_pt[mode] * npts / ms / 1e9, esdf, egrad, efeat, nan, chk, gsum, fsum, pass ? "PASS" : "FAIL");
   }
   return bad ? 1 : 0;
 }
