@@ -85,14 +85,14 @@ def check_dma(text):
     """Every W32_FETCH_SETUP() (one 32 KiB block of the weight stream) is followed by exactly the pieces 0..7 of W32_DMA before the next
     one, and a block barrier inside a window (W32_SYNC_MID: `s_waitcnt vmcnt(8)` = "everything but this window's 8 pieces has landed")
     comes after all 8."""
-    problems, pieces, start, mid = [], None, 0, False
+    problems, pieces, start = [], None, 0
     def close(ln):
         if pieces is not None and sorted(pieces) != list(range(8)):
             problems.append(f"line {start}: block set up here issues LDS-DMA pieces {sorted(pieces)} before line {ln}, expected 0..7 once each")
     for ln, line in enumerate(text.split("\n"), 1):
         if "W32_FETCH_SETUP()" in line and "define" not in line:
             close(ln)
-            pieces, start, mid = [], ln, False
+            pieces, start = [], ln
         elif pieces is not None and "W32_SYNC_MID()" in line and "define" not in line:
             if len(pieces) != 8:
                 problems.append(f"line {ln}: block barrier behind {len(pieces)} of the window's 8 LDS-DMA pieces (its vmcnt(8) would let a piece of the NEXT block stay in flight)")

@@ -443,8 +443,9 @@ def test_generated_schedules_lds_counter_model(tmp_path, env):
     """The generated wide-kernel windows wait for their weight fragments with computed ``s_waitcnt lgkmcnt(N)`` and, since round 6,
     request the first fragments of window n + 1 from inside window n (gen_mlp32.py XWIN).  nrhints_amd/csrc/check_gen32.py replays every
     generated file against the in-order LDS counter: an MFMA may only read a fragment register whose read has landed AND holds the
-    fragment that MFMA is due.  Every generator configuration the tree builds or A/B-tests is checked; two deliberately broken files
-    (a wait loosened by two, the cross-window reads dropped) must be reported."""
+    fragment that MFMA is due.  Every generator configuration the tree builds or A/B-tests is checked; deliberately broken files (a wait
+    loosened by two, the cross-window reads dropped, a block short of an LDS-DMA piece, a window's barrier ahead of its pieces) must be
+    reported."""
     import re
     import subprocess
     import sys
@@ -467,7 +468,12 @@ def test_generated_schedules_lds_counter_model(tmp_path, env):
     at = [m.start() for m in re.finditer(pat, text)][10]
     loose = text[:at] + "lgkmcnt(5)" + text[at + len("lgkmcnt(3)"):]
     assert any("in flight" in p for p in check_gen32.check_text(loose)[1])
+    fewer = re.sub(r"W32_DMA\(3\);\n", "", text, count=1)            # a block that gets seven of its eight LDS-DMA pieces
+    assert any("LDS-DMA pieces" in p for p in check_gen32.check_text(fewer)[1])
     if env.get("NRH32_XWIN") != "0":
+        early = text.replace("W32_SYNC_MID();", "W32_SYNC_MID_();", 1)     # the barrier of a window moved ahead of its pieces
+        early = early.replace("W32_DMA(2);", "W32_SYNC_MID(); W32_DMA(2);", 1)
+        assert any("block barrier behind" in p for p in check_gen32.check_text(early)[1])
         dropped = re.sub(r'asm volatile\("ds_read_b128 %0, %1 offset:\d+" : "=v"\(fa\d\) : "v"\(wa_next\) : "memory"\);\n', "", text, count=2)
         assert any("expected" in p for p in check_gen32.check_text(dropped)[1])
 
