@@ -4,6 +4,7 @@
 //   mode 0  operands all zero            (the multipliers do not toggle)
 //   mode 1  random fp16 operands, fixed  (the same A / B every iteration: operand buses quiet, arrays busy)
 //   mode 2  random fp16 operands, 8 different A fragments rotating (closer to a K loop's operand traffic)
+//   mode 3  v_mfma_f32_32x32x16_bf16 (nrh_dw_gemm's instruction) on bf16 values, 8 A fragments rotating
 // Prints TFLOP/s over ~0.4 s per mode (long enough for the power controller to settle) and the cycle count per MFMA from s_memtime.
 //   hipcc --offload-arch=gfx950 -O3 profiles/ubench/mfma_sustained.hip -o profiles/ubench/bin/mfma_sustained
 #include <hip/hip_runtime.h>
@@ -13,9 +14,10 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NA>
+template <int NA, bool BF>
 __global__ __launch_bounds__(256) void mfma_loop(const f16x8* __restrict__ ops, float* __restrict__ out, int iters, unsigned long long* cyc) {
   const int lane = threadIdx.x & 63;
   f16x8 a[NA], b[2];
@@ -27,10 +29,17 @@ __global__ __launch_bounds__(256) void mfma_loop(const f16x8* __restrict__ ops, 
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k) % NA], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k + 1) % NA], b[1], c1, 0, 0, 0);
-      c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k + 2) % NA], b[0], c2, 0, 0, 0);
-      c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k + 3) % NA], b[1], c3, 0, 0, 0);
+      if constexpr (BF) {       // the same bits read as bf16: v_mfma_f32_32x32x16_bf16 (the weight-gradient kernel's instruction)
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(k) % NA]), __builtin_bit_cast(bf16x8, b[0]), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(k + 1) % NA]), __builtin_bit_cast(bf16x8, b[1]), c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(k + 2) % NA]), __builtin_bit_cast(bf16x8, b[0]), c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(k + 3) % NA]), __builtin_bit_cast(bf16x8, b[1]), c3, 0, 0, 0);
+      } else {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k) % NA], b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k + 1) % NA], b[1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k + 2) % NA], b[0], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(k + 3) % NA], b[1], c3, 0, 0, 0);
+      }
     }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
@@ -51,17 +60,23 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_ops, h.size() * 2)); CK(hipMalloc(&d_out, cus * 256 * 4)); CK(hipMalloc(&d_cyc, 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("device %s, %d CUs, one wave per SIMD, v_mfma_f32_32x32x16_f16 (32 768 FLOP each), register operands\n", prop.gcnArchName, cus);
-  const char* names[3] = {"zero operands", "random operands, one A fragment", "random operands, 8 A fragments rotating"};
+  const char* names[4] = {"zero operands", "random operands, one A fragment", "random operands, 8 A fragments rotating",
+                          "bf16: random bit patterns, 8 A fragments rotating"};
   for (int rep = 0; rep < 2; ++rep)
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 4; ++mode) {
     srand(1);
-    for (auto& x : h) x = mode == 0 ? (_Float16)0.f : (_Float16)(((rand() & 0xffff) / 32768.0f - 1.0f) * 0.5f);
+    for (auto& x : h) {
+      const float v = ((rand() & 0xffff) / 32768.0f - 1.0f) * 0.5f;
+      if (mode == 3) { const __bf16 bv = (__bf16)v; x = __builtin_bit_cast(_Float16, bv); }      // 16 bits of a bf16 value
+      else x = mode == 0 ? (_Float16)0.f : (_Float16)v;
+    }
     CK(hipMemcpy(d_ops, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     int iters = 20000;
     for (int pass = 0; pass < 2; ++pass) {     // pass 0 calibrates the iteration count, pass 1 is the measurement
       CK(hipEventRecord(e0, 0));
-      if (mode == 2) hipLaunchKernelGGL(mfma_loop<8>, dim3(cus), dim3(256), 0, 0, d_ops, d_out, iters, d_cyc);
-      else hipLaunchKernelGGL(mfma_loop<1>, dim3(cus), dim3(256), 0, 0, d_ops, d_out, iters, d_cyc);
+      if (mode == 3) hipLaunchKernelGGL((mfma_loop<8, true>), dim3(cus), dim3(256), 0, 0, d_ops, d_out, iters, d_cyc);
+      else if (mode == 2) hipLaunchKernelGGL((mfma_loop<8, false>), dim3(cus), dim3(256), 0, 0, d_ops, d_out, iters, d_cyc);
+      else hipLaunchKernelGGL((mfma_loop<1, false>), dim3(cus), dim3(256), 0, 0, d_ops, d_out, iters, d_cyc);
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       unsigned long long cyc; CK(hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost));
