@@ -128,8 +128,9 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
     n = getattr(cfg, "outside_nerf", None) or NeRFConfig()
     checks = [
         (s.d_in == 3 and s.d_out_feat == 256 and s.d_hidden == 256 and s.n_layers == 8 and list(s.skip_in) == [4]
-         and s.multi_res == 6 and s.weight_norm and not s.inside_outside and float(s.scale) == 3.0,
-         "sdf_network must be the default 8x256 / skip_in=[4] / multi_res=6 / scale=3 MLP"),
+         and s.multi_res == 6 and s.weight_norm and float(s.scale) == 3.0,
+         "sdf_network must be the default 8x256 / skip_in=[4] / multi_res=6 / scale=3 MLP (init_bias, geometric_init and "
+         "inside_outside only choose the initial weights and are free)"),
         (c.d_hidden == 256 and c.n_layers == 4 and c.multi_res == 4 and c.weight_norm and c.squeeze_out,
          "reflectance_network must be the default 4x256 / multi_res=4 / sigmoid MLP"),
         (not r.use_outside_nerf or (r.n_outside_samples == 32 and r.n_importance_samples == 64 and r.n_shadow_importance_clip == -1

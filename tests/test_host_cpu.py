@@ -53,6 +53,24 @@ def test_module_init_and_state_dict_match_reference_fixture():
     m.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()})  # reference checkpoints load as-is
 
 
+def test_init_only_config_variants_match_reference_fixture():
+    """``inside_outside`` and ``init_bias`` only choose initial weights (fields/sdf_field.py:60, :95-100): accepted, and the constructor
+    consumes the RNG like the reference's (fixture of the imported reference under torch.manual_seed(0): the output layers' tensors
+    and the sum of every other tensor; tests/golden/make_golden_init_variants.py)."""
+    ref = load_npz("init_variants.npz")
+    cfg = na.NeuSModelConfig(sdf_network=na.SDFNetConfig(inside_outside=True, init_bias=0.05))
+    assert na.unsupported_reason(cfg) is None
+    torch.manual_seed(0)
+    sd = na.NeuSHintRenderer(cfg).state_dict()
+    keys = [k[len("io.sum."):] for k in ref if k.startswith("io.sum.")]
+    assert sorted(keys) == sorted(sd.keys())
+    for k in keys:
+        assert float(sd[k].double().sum()) == float(ref["io.sum." + k]), k
+        if "io." + k in ref:
+            assert np.array_equal(sd[k].numpy(), ref["io." + k]), k
+    assert float(sd["sdf_network.out_sdf.bias"]) == pytest.approx(0.05 * 3.0) and float(sd["sdf_network.out_sdf.weight_v"].mean()) < 0
+
+
 def test_unsupported_configs_are_rejected():
     bad = [
         na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=64)),
