@@ -12,6 +12,11 @@ sit in the 32-cycle shadow of an MFMA of the NEXT chunk, B operands have to stay
     end of its slot and ``sched_barrier(0)`` closes the slot, so neither instruction selection nor the machine scheduler
     moves work across slots.
 
+Round 6 (see Window.emit, DMA_SLOTS16, split_ops): inside a stage the block barrier of window n + 1 sits behind K step 14 of window n
+and K step 15 already requests the next window's first weight fragments (no barrier, no cold LDS reads at a window's top); a window's
+eight LDS-DMA pieces go out behind the first MFMA of K steps 6..13; the hi / lo residual is one v_fma_mixlo_f16 / v_fma_mixhi_f16
+pair.  check_gen32.py replays every generated file against the LDS counter model; the Makefile runs it.
+
 AGPR map (per wave): a[0:63] in.hi, a[64:127] in.lo, a[128:191] out.hi, a[192:255] out.lo; K step s reads a[4s:4s+3] and
 a[64+4s:64+4s+3].  hipcc never touches AGPRs in these kernels (-mllvm -amdgpu-mfma-vgpr-form, no spills; the build checks the
 disassembly for foreign v_accvgpr instructions).
@@ -536,7 +541,7 @@ def gen_stage(kind, want_d, ks, b_src, nv, hh_zero, in_base=0, out_base=128, pen
         prev_stores = sum(1 for o in (epi or []) if o.kind == "vmem")
         if xwin:
             win.emit(out, slots, "    ", dma=dma, head=head, declare=False, preloaded=(c > 0), prefetch_next=(c < 7), rot=rot)
-            rot = (rot + ks) % 3
+            rot = (rot + ks) % (win.pf + 1)
         else:
             win.emit(out, slots, "    ", dma=dma, head=head)
         if tail:
