@@ -496,6 +496,22 @@ def test_generated_schedules_lds_counter_model(tmp_path, env):
         assert any("expected" in p for p in check_gen32.check_text(dropped)[1])
 
 
+def test_committed_counter_summary_belongs_to_the_committed_kernels():
+    """``roofline.traffic`` is quoted from the newest committed rocprofv3 --pmc summary only while its ``source_hash`` line equals the
+    hash of the evaluation-kernel sources in the tree (bench.kernel_source_hash): the evidence under profiles/ has to be evidence of
+    THESE kernels.  Editing a kernel source without re-running profiles/pmc_run.sh fails here, on the CPU."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.remove(root)
+    traffic, path, kind = bench.pmc_traffic("f16x3", True, 640000)
+    assert traffic is not None and "source_hash matches" in kind, (path, kind)
+    assert 5e11 < traffic < 1.2e12          # ~9 KB per point x 81.9 M points of a whole-frame launch
+
+
 def test_uint8_image_products_match_reference_fixture():
     """``to_uint8_images`` on the reference's own float images reproduces the uint8 arrays recorded with them
     (trainer/trainer.py:343-352 applied by make_golden_evaldict.py inside the reference process)."""
