@@ -4,7 +4,10 @@
   2. no scratch use, no packed-f32 VALU;
   3. a register written by an asm global_load (q words) is not read or written by anything before the next s_waitcnt vmcnt
      that covers it - here: before the next `s_waitcnt vmcnt(` at all (conservative);
-  4. a half-register write (v_fma_mixlo_f16 / v_fma_mixhi_f16) is not consumed by the very next instruction.
+  4. a half-register write (v_fma_mixlo_f16 / v_fma_mixhi_f16) is not consumed by the very next instruction;
+  5. no scalar-memory instruction (s_load / s_buffer_load / s_memtime) behind a kernel's first MFMA: SMEM results return out of order
+     with LDS reads and count in the same lgkmcnt, so one in flight inside a window would let a computed `lgkmcnt(N)` pass with a
+     weight fragment still on its way (the timing builds of profiles/ubench, which stamp with s_memtime, are exempt - and showed it).
     python nrhints_amd/csrc/check_wide_isa.py file.s   (the Makefile runs it on every build of nrh_wide.o)
 """
 import re, sys
@@ -18,15 +21,18 @@ def regs_of(tok):
 def main():
     path = sys.argv[1]
     kern, bad, inflight = None, [], {}
-    nload, npartial, partial = 0, 0, None
+    nload, npartial, partial, seen_mfma = 0, 0, None, False
     for ln, line in enumerate(open(path), 1):
         m = re.match(r"^(_ZN\d+nrh32t?(?:12sdf32_kernelILi\dE|14color32_kernelE)\w+):", line)       # nrh32: three-term builds, nrh32t: one-term
-        if m: kern, inflight, partial = m.group(1), {}, None; continue
+        if m: kern, inflight, partial, seen_mfma = m.group(1), {}, None, False; continue
         if kern is None: continue
         if line.startswith(".Lfunc_end"): kern = None; continue
         t = line.strip().replace(",", " ").split()
         if not t or t[0][0] in ";.": continue
         op = t[0]
+        if op.startswith("v_mfma"): seen_mfma = True
+        if seen_mfma and op.startswith(("s_load_", "s_buffer_load", "s_memtime", "s_memrealtime")):
+            bad.append((ln, "scalar memory instruction behind the first MFMA (shares lgkmcnt with the LDS reads, returns out of order)", line.strip()))
         if op.startswith(("v_accvgpr_read", "v_accvgpr_mov")): bad.append((ln, "AGPR read/mov", line.strip()))
         if op.startswith("scratch_") or (op.startswith("v_pk_") and "f32" in op): bad.append((ln, "scratch / packed f32", line.strip()))
         if op.startswith("s_waitcnt") and "vmcnt" in line: inflight, partial = {}, None; continue
