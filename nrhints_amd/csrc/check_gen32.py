@@ -32,7 +32,7 @@ import sys
 RE_DS = re.compile(r'asm volatile\("ds_read_b128 %0, %1 offset:(\d+)" : "=v"\((fa\d+)\) : "v"\((\w+)\)')
 RE_WAIT = re.compile(r's_waitcnt lgkmcnt\((\d+)\)')
 RE_MFMA = re.compile(r'v_mfma_f32_32x32x16_f16 %0, %1, [^"]*" : "[^"]*"\(\w+\) : "v"\((\w+)\)')
-MID = 1          # which of a K step's three MFMAs takes the low fragment (gen_mlp32.py MID)
+MID = int(os.environ.get("NRH32_MID", "1"))          # which of a K step's three MFMAs takes the low fragment (gen_mlp32.py MID)
 
 
 def check_text(text):

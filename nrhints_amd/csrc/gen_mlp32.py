@@ -22,6 +22,22 @@ a[64+4s:64+4s+3].  hipcc never touches AGPRs in these kernels (-mllvm -amdgpu-mf
 disassembly for foreign v_accvgpr instructions).
 
 Usage: gen_mlp32.py <outdir>   ->  <outdir>/*.inc, included by nrh_sdf32.hip.
+
+Environment knobs (build-time; the Makefile sets none but NRH32_ONE_TERM for gen32_1t; experiment libraries:
+profiles/tools/build_gen_variant.sh NAME "KNOB=.. KNOB=.."; what each was measured to do: profiles/README.md):
+  NRH32_ONE_TERM=1      the single-pass schedules of precision "f16" (no cross-term MFMAs, no low halves)
+  NRH32_XWIN=0          no cross-window prefetch: every window opens with its block barrier and cold fragment reads (rounds 2-5)
+  NRH32_MIX_SPLIT=0     the hi / lo residual spelled out in C++ instead of v_fma_mixlo_f16 / v_fma_mixhi_f16
+  NRH32_DMA_J / _FIRST / _STRIDE   where a 16-step window issues its eight LDS-DMA pieces: slot of the K step (default 0), first K step (6), stride (1)
+  NRH32_DMA_PENALTY     VALU micro-operations fewer in a slot that issues a piece (2)
+  NRH32_NV / _NV_D1 / _NV_REV      micro-operations per MFMA slot: forward (4), forward with sigma' encode (NV + 1), reverse (NV)
+  NRH32_PF              weight-fragment reads in flight ahead of the MFMAs, in K steps (2; 3 measured null)
+  NRH32_MID             which of a K step's three MFMAs takes A_lo (1: the two hh updates stay apart)
+  NRH32_TRANS_COST      price of a transcendental in the slot scheduler, in plain operations (1)
+  NRH32_HEAD_SLOTS / _HEAD_OPS     epilogue operations placed ahead of a window's first MFMA (0: measured negative)
+  NRH32_SYNCK=1         window-opening waits that keep the previous window's stores in flight (measured null)
+  NRH32_COL_UNSCALED=1  the reflectance net's activations with the unscaled residual (needs -DNRH32_COL_UNSCALED=1 as well)
+  NRH32_NOEPI / _NOQSTORE / _NOHINIT / _ABL_TRANS / _ABL_APUT     timing ablations for profiles/ubench: WRONG RESULTS by construction
 """
 import os
 import sys
@@ -31,6 +47,7 @@ MFMA = "v_mfma_f32_32x32x16_f16"
 
 
 TRANS_COST = float(os.environ.get("NRH32_TRANS_COST", "1"))
+PF = int(os.environ.get("NRH32_PF", "2"))        # K steps of weight fragments requested ahead of the MFMAs that consume them (Window.emit)
 # hi / lo split of the SDF kernels' activations through v_fma_mixlo_f16 / v_fma_mixhi_f16 (see split_ops); NRH32_MIX_SPLIT=0: the
 # spelled-out C++ form of rounds 2-5 (A/B builds)
 MIX_SPLIT = os.environ.get("NRH32_MIX_SPLIT", "1") != "0"
@@ -253,7 +270,7 @@ class Window:
     b_src 'agpr': B operands are a[4s..] / a[64+4s..];  'vgpr': u32x4 expressions (bh(s), bl(s)) given by name pattern.
     hh_init: name of an f32x16 holding the start values (compiler-visible LDS loads), or None for zero."""
 
-    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=2, wa="wa", cd=None, use_ds=True, in_base=0,
+    def __init__(self, ks, hh, cc, b_src="agpr", bvar=("ebh", "ebl"), hh_zero=False, pf=PF, wa="wa", cd=None, use_ds=True, in_base=0,
                  acc_all=False, bias=None, b_lo_scaled=False):
         self.b_lo_scaled = b_lo_scaled   # B_lo carries a factor 2^11 as well (reflectance net): A_hi B_lo goes to cc, not hh
         self.ks, self.hh, self.cc, self.b_src, self.bvar, self.hh_zero, self.pf, self.wa = ks, hh, cc, b_src, bvar, hh_zero, pf, wa
@@ -267,8 +284,8 @@ class Window:
         return f"fa{((s + self.rot) % (self.pf + 1)) * 2 + part}"
 
     @staticmethod
-    def decl(pf=2):
-        return "nrh32::u32x4 " + ", ".join(f"fa{i}" for i in range((pf + 1) * 2)) + ";"
+    def decl(pf=None):
+        return "nrh32::u32x4 " + ", ".join(f"fa{i}" for i in range(((PF if pf is None else pf) + 1) * 2)) + ";"
 
     def emit(self, out, slots_ops, ind="  ", dma=None, head=None, declare=True, preloaded=False, prefetch_next=False, rot=0):
         """dma: {slot: [piece, ...]} - W32_DMA(piece) calls (LDS-DMA of a later block) issued in that slot.

@@ -456,7 +456,8 @@ def test_wide_kernel_isa_invariants(tmp_path):
     assert chk.returncode == 0, chk.stdout + chk.stderr
 
 
-@pytest.mark.parametrize("env", [{}, {"NRH32_ONE_TERM": "1"}, {"NRH32_XWIN": "0"}, {"NRH32_MIX_SPLIT": "0", "NRH32_NV": "3", "NRH32_DMA_PENALTY": "0"}])
+@pytest.mark.parametrize("env", [{}, {"NRH32_ONE_TERM": "1"}, {"NRH32_XWIN": "0"}, {"NRH32_MIX_SPLIT": "0", "NRH32_NV": "3", "NRH32_DMA_PENALTY": "0"},
+                                 {"NRH32_PF": "3", "NRH32_DMA_J": "2", "NRH32_DMA_FIRST": "0"}])
 def test_generated_schedules_lds_counter_model(tmp_path, env):
     """The generated wide-kernel windows wait for their weight fragments with computed ``s_waitcnt lgkmcnt(N)`` and, since round 6,
     request the first fragments of window n + 1 from inside window n (gen_mlp32.py XWIN).  nrhints_amd/csrc/check_gen32.py replays every
@@ -482,9 +483,9 @@ def test_generated_schedules_lds_counter_model(tmp_path, env):
         sys.path.remove(csrc)
     text = open(os.path.join(out, "rev_p0.inc")).read()
     assert check_gen32.check_text(text)[1] == []
-    pat = r"lgkmcnt\(1\)" if env.get("NRH32_ONE_TERM") else r"lgkmcnt\(3\)"
+    pat = r"lgkmcnt\(1\)" if env.get("NRH32_ONE_TERM") else (r"lgkmcnt\(5\)" if env.get("NRH32_PF") == "3" else r"lgkmcnt\(3\)")
     at = [m.start() for m in re.finditer(pat, text)][10]
-    loose = text[:at] + "lgkmcnt(5)" + text[at + len("lgkmcnt(3)"):]
+    loose = text[:at] + "lgkmcnt(7)" + text[at + len("lgkmcnt(3)"):]
     assert any("in flight" in p for p in check_gen32.check_text(loose)[1])
     fewer = re.sub(r"W32_DMA\(3\);\n", "", text, count=1)            # a block that gets seven of its eight LDS-DMA pieces
     assert any("LDS-DMA pieces" in p for p in check_gen32.check_text(fewer)[1])
