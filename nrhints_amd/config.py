@@ -127,12 +127,17 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
     s, c, r = cfg.sdf_network, cfg.reflectance_network, cfg.renderer
     n = getattr(cfg, "outside_nerf", None) or NeRFConfig()
     checks = [
-        (s.d_in == 3 and s.d_out_feat == 256 and s.d_hidden == 256 and s.n_layers == 8 and list(s.skip_in) == [4]
-         and s.multi_res == 6 and s.weight_norm and float(s.scale) == 3.0,
-         "sdf_network must be the default 8x256 / skip_in=[4] / multi_res=6 / scale=3 MLP (init_bias, geometric_init and "
+        # depth, skip position, input scale and weight-norm are compiled in; WIDTHS and encoding resolutions are upper bounds - a
+        # narrower network runs zero-padded on the same kernels (packing.pad_to_compiled: exact, at the full network's cost)
+        (s.d_in == 3 and s.n_layers == 8 and list(s.skip_in) == [4] and s.weight_norm and float(s.scale) == 3.0,
+         "sdf_network must be an 8-layer / skip_in=[4] / scale=3 weight-normalised MLP (init_bias, geometric_init and "
          "inside_outside only choose the initial weights and are free)"),
-        (c.d_hidden == 256 and c.n_layers == 4 and c.multi_res == 4 and c.weight_norm and c.squeeze_out,
-         "reflectance_network must be the default 4x256 / multi_res=4 / sigmoid MLP"),
+        (1 <= s.multi_res <= 6 and 3 + 6 * s.multi_res < s.d_hidden <= 256 and s.d_hidden - (3 + 6 * s.multi_res) <= 217
+         and 1 <= s.d_out_feat <= 256,
+         "sdf_network: multi_res in 1..6, d_hidden <= 256 with d_hidden - (3 + 6 multi_res) in 1..217 (the skip layer's rows), "
+         "d_out_feat in 1..256 (narrower than the compiled 256 / 6 / 256 runs zero-padded; wider is not built)"),
+        (c.n_layers == 4 and c.weight_norm and c.squeeze_out and 1 <= c.d_hidden <= 256 and 1 <= c.multi_res <= 4,
+         "reflectance_network must be a 4-layer weight-normalised sigmoid MLP with d_hidden <= 256 and multi_res in 1..4"),
         (not r.use_outside_nerf or (r.n_outside_samples == 32 and r.n_importance_samples == 64 and r.n_shadow_importance_clip == -1
                                     and not r.shadow_hint_gradient and not r.specular_hint_gradient),
          "use_outside_nerf needs n_outside_samples = 32, the 128-sample layout, the hit-point shadow mode and no hint gradients"),

@@ -181,6 +181,82 @@ def dense_params_device(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tenso
     return dense_params_hip(state) if on_gpu else dense_params(state)
 
 
+def enc_columns(dim: int, n_freq: int, n_freq_compiled: int) -> torch.Tensor:
+    """Where the columns of a NeRF encoding with ``n_freq`` frequencies sit in the encoding with ``n_freq_compiled`` of them
+    (fields/encodings.py:165-174: [x | sin(x_d 2^k), d-major | sin(x_d 2^k + pi/2), d-major], frequencies 2^0 .. 2^(n-1): the
+    shorter encoding is a subset of the longer one's columns)."""
+    assert 0 <= n_freq <= n_freq_compiled
+    d, k = torch.arange(dim)[:, None], torch.arange(n_freq)[None, :]
+    sin = (dim + d * n_freq_compiled + k).reshape(-1)
+    return torch.cat([torch.arange(dim), sin, sin + dim * n_freq_compiled])
+
+
+_PLACE_IDX: Dict[tuple, tuple] = {}
+
+
+def _place(w: torch.Tensor, rows: int, cols: int, col_idx: torch.Tensor = None) -> torch.Tensor:
+    """``w`` [r, c] inside a zero [rows, cols] matrix: rows 0..r-1, columns ``col_idx`` (default 0..c-1).  Differentiable; the
+    identity (same tensor, no launch) when nothing moves.  The index tensors are cached per device (a captured training step
+    re-pads every replay: no host-to-device copy may sit inside the capture)."""
+    r, c = w.shape
+    if col_idx is None:
+        if (r, c) == (rows, cols):
+            return w
+        return torch.nn.functional.pad(w, (0, cols - c, 0, rows - r))
+    key = (r, tuple(col_idx.tolist()), str(w.device))
+    if key not in _PLACE_IDX:
+        _PLACE_IDX[key] = (torch.arange(r, device=w.device)[:, None], col_idx.to(w.device)[None, :])
+    return w.new_zeros(rows, cols).index_put(_PLACE_IDX[key], w)
+
+
+def pad_to_compiled(d: Dict[str, torch.Tensor], shadow_hint: bool, specular_hint: bool, mv: int) -> Dict[str, torch.Tensor]:
+    """Dense matrices of a network NARROWER than the compiled one (sdf d_hidden <= 256 with multi_res <= 6 and d_out_feat <= 256,
+    reflectance d_hidden <= 256 with multi_res <= 4, one hint instead of two; fields/sdf_field.py:11-36,
+    fields/reflectance_network.py:9-22) as the matrices of the compiled shape - 8 x 256 / 39-column embedding / 217-row skip
+    layer, 4 x 256 / 361 (316 without hints) input columns - with zeros everywhere else.  Exact, not an approximation: a padded
+    hidden channel computes softplus(0) or relu(0) and every weight that reads it is zero; a padded encoding column is computed
+    by the kernels and multiplied by zero; value, gradient and every adjoint of the real entries are those of the narrow network.
+    Differentiable (pad / index_put), so the autograd path's parameter gradients come out in the parameters' own shapes.
+    ``mv``: the reflectance net's multi_res.  Widths are read from the matrices."""
+    h = d["sdf_w1"].shape[0]
+    e = d["sdf_w0"].shape[1]
+    m = (e - 3) // 6
+    f = d["feat_w"].shape[0]
+    ch = d["col_w1"].shape[0]
+    assert e == 3 + 6 * m and m <= 6 and h <= 256 and f <= 256 and ch <= 256 and d["sdf_w3"].shape[0] == h - e <= 217 and mv <= 4
+    out = dict(d)
+    emap = enc_columns(3, m, 6)
+    out["sdf_w0"] = _place(d["sdf_w0"], 256, 39, emap)
+    for l in (1, 2, 5, 6, 7):
+        out[f"sdf_w{l}"] = _place(d[f"sdf_w{l}"], 256, 256)
+    out["sdf_w3"] = _place(d["sdf_w3"], 217, 256)
+    # layer 4 reads cat([h3 (h - e), embedding (e)]) (fields/sdf_field.py:113-114): the compiled layer's columns 0..216 | 217..255
+    out["sdf_w4"] = _place(d["sdf_w4"], 256, 256, torch.cat([torch.arange(h - e), 217 + emap]))
+    out["sdf_head_w"] = _place(d["sdf_head_w"], 1, 256)
+    out["feat_w"] = _place(d["feat_w"], 256, 256)
+    for l in range(8):
+        out[f"sdf_b{l}"] = _pad_vec(d[f"sdf_b{l}"], 217 if l == 3 else 256)
+    out["feat_b"] = _pad_vec(d["feat_b"], 256)
+    # reflectance input (fields/reflectance_network.py:77-86): pts 3 | enc(view) | normal 3 | enc(pl) | feature f | enc(vis) | enc(cue)
+    ev, hints = 3 + 6 * mv, shadow_hint or specular_hint
+    cols = [torch.arange(3), 3 + enc_columns(3, mv, 4), 30 + torch.arange(3), 33 + enc_columns(3, mv, 4), 60 + torch.arange(f)]
+    if shadow_hint:
+        cols.append(316 + enc_columns(1, mv, 4))
+    if specular_hint:
+        cols.append(325 + enc_columns(4, mv, 4))
+    cmap = torch.cat(cols)
+    assert d["col_w0"].shape[1] == cmap.numel() == 6 + 2 * ev + f + (1 + 2 * mv) * (int(shadow_hint) + 4 * int(specular_hint))
+    width = 361 if hints else 316
+    identity = cmap.numel() == width and bool((cmap == torch.arange(width)).all())
+    out["col_w0"] = _place(d["col_w0"], 256, width, None if identity else cmap)
+    for l in (1, 2, 3):
+        out[f"col_w{l}"] = _place(d[f"col_w{l}"], 256, 256)
+    out["col_w4"] = _place(d["col_w4"], 3, 256)
+    for l in range(4):
+        out[f"col_b{l}"] = _pad_vec(d[f"col_b{l}"], 256)
+    return out
+
+
 def check_default_shapes(d: Dict[str, torch.Tensor], hints: bool = True) -> None:
     """The kernels are compiled for the default nr-hints network shape."""
     want = {"sdf_w0": (256, 39), "sdf_w1": (256, 256), "sdf_w2": (256, 256), "sdf_w3": (217, 256),

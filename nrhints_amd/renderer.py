@@ -176,6 +176,9 @@ class NeuSHintRenderer(nn.Module):
         n_cue = len(config.renderer.specular_roughness) if self.has_specular_hint else 0
         self.color_network = ReflectanceNetwork(config.sdf_network.d_out_feat, 12 + int(self.has_shadow_hint) + n_cue, 3,
                                                 config.reflectance_network, n_cue, self.has_shadow_hint)
+        # widths / encoding resolutions BELOW the compiled ones run zero-padded on the compiled kernels (_to_compiled)
+        sc_, cc_ = config.sdf_network, config.reflectance_network
+        self._narrow = (sc_.d_hidden, sc_.multi_res, sc_.d_out_feat, cc_.d_hidden, cc_.multi_res) != (256, 6, 256, 256, 4)
         self.has_outside_nerf = bool(config.renderer.use_outside_nerf)
         if self.has_outside_nerf:      # constructed after the reflectance net, as the reference does (:260-266)
             from .outside import OutsideNeRF
@@ -207,6 +210,14 @@ class NeuSHintRenderer(nn.Module):
             w0 = torch.cat([w0[:, :316], w0.new_zeros(w0.shape[0], 9), w0[:, 316:]], dim=1)
         return dict(dense, col_w0=w0)
 
+    def _to_compiled(self, dense):
+        """The folded matrices in the shape the kernels are compiled for: a narrower network (``_narrow``: widths / encoding
+        resolutions below the defaults, config.unsupported_reason) zero-padded by packing.pad_to_compiled, a one-hint model of the
+        default widths by _pad_hint_columns; the default nr-hints / pl-naive shapes pass through untouched (same tensors)."""
+        if self._narrow:
+            return packing.pad_to_compiled(dense, self.has_shadow_hint, self.has_specular_hint, int(self.config.reflectance_network.multi_res))
+        return self._pad_hint_columns(dense)
+
     def packed_params(self, device, dense=None):
         """Fold weight-norm and pack for the kernels; cached until a parameter changes.  ``dense``: the already folded
         matrices of the CURRENT parameters (the training forward folds them once, with autograd history)."""
@@ -224,7 +235,7 @@ class NeuSHintRenderer(nn.Module):
                     # samples by a whole bin where the pdf sits at its floor - with two folds an evaluation render and a training
                     # forward of the SAME parameters placed 20 % of their samples differently (profiles/train_forward_determinism.py,
                     # round 6).  (CPU tensors - the packing tests of the emulators - keep the torch expression.)
-                    d = self._pad_hint_columns(packing.dense_params_device(state))
+                    d = self._to_compiled(packing.dense_params_device(state))
                     packing.check_default_shapes(d, hints)
                     sw, sb, sh = packing.pack_sdf(d, prec)
                     cw, cb = packing.pack_color(d, prec, hints)
@@ -457,7 +468,7 @@ class NeuSHintRenderer(nn.Module):
             # fold weight-norm once, with autograd history; the kernels' packed copies are cut from the same matrices
             named = dict(self.named_parameters())
             on_gpu_f32 = all(p.is_cuda and p.dtype == torch.float32 for p in named.values())
-            dense = self._pad_hint_columns(packing.dense_params_hip(named) if on_gpu_f32 else packing.dense_params(named))
+            dense = self._to_compiled(packing.dense_params_hip(named) if on_gpu_f32 else packing.dense_params(named))
             self.packed_params(device, dense=dense)
         fused_train = needs_grad and n <= self.max_fused_train_rays
         rcfg = cfg.renderer
@@ -547,7 +558,7 @@ class NeuSHintRenderer(nn.Module):
         dense = None
         if needs_grad:
             named = dict(self.named_parameters())
-            dense = self._pad_hint_columns(packing.dense_params_hip({k: v for k, v in named.items() if not k.startswith("outside_nerf.")}))
+            dense = self._to_compiled(packing.dense_params_hip({k: v for k, v in named.items() if not k.startswith("outside_nerf.")}))
             self.packed_params(device, dense=dense)
         pk = self.packed_params(device)
         if self.dyn_scalars is not None:

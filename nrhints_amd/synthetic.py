@@ -69,13 +69,13 @@ def make_image_rays(h: int, w: int, radius: float = 4.0, light_radius: float = 4
 
 
 def perturb_state(state: dict, seed: int = 42, sigma: float = 0.02, sigma_pe: float = 0.004,
-                  variance: float = 0.7) -> dict:
+                  variance: float = 0.7, pe_cols: int = 36) -> dict:
     """Scene "b": break the sphere symmetry of the geometric init, deterministically.
 
     Adds N(0, sigma) to every SDF-trunk ``weight_v`` entry (N(0, sigma_pe) on the columns that read the
     positional-encoding part of the embedding, which the init leaves at exactly zero), small noise to the
     trunk biases, and sets the NeuS sharpness parameter to ``variance`` (inv_s = exp(10*variance) ~ 1.1e3).
-    The reflectance net keeps its reference init.
+    The reflectance net keeps its reference init.  ``pe_cols``: sinusoid columns of the embedding, 6 x multi_res (36 by default).
     """
     rs = np.random.RandomState(seed)
     out = {}
@@ -88,7 +88,7 @@ def perturb_state(state: dict, seed: int = 42, sigma: float = 0.02, sigma_pe: fl
             if layer == 0:
                 scale[:, 3:] = sigma_pe
             if layer == 4:
-                scale[:, -36:] = sigma_pe
+                scale[:, -pe_cols:] = sigma_pe
             v = v + scale * noise
         elif key.startswith("sdf_network.lin") and key.endswith("bias"):
             v = v + np.float32(0.01) * rs.randn(*v.shape).astype(np.float32)

@@ -24,6 +24,7 @@ slots, the padded ones have weight and adjoint exactly 0.
 Round 6: ``shadow_hint_gradient`` / ``specular_hint_gradient`` (models/neus_hint_model.py:379, :589) - the SDF training forward and
 both sweeps a second time at the shadow ray's sections, the shadow alpha stage's kernel pair, and a small autograd island on
 per-RAY tensors for the hit normal, the cue and the two encodings (_hint_forward / _hint_backward below).
+Networks narrower than the compiled shape (renderer._narrow) run zero-padded; the adjoint of the padding cuts the gradients back.
 Restrictions (the autograd path covers the rest): GPU float32 parameters, no outside NeRF, at most ``max_fused_train_rays`` rays
 per call; shadow_hint_gradient with ray gradients or with the partial visibility hint is refused on both paths.
 """
@@ -72,7 +73,7 @@ def supported(renderer, ray_bundle) -> Optional[str]:
 class _Buffers:
     """Per-(device, rays) arrays of a step, allocated once and reused (a captured graph bakes their addresses in)."""
 
-    def __init__(self, dev, n: int, hints: bool, shapes: Dict[str, tuple], param_layout: Dict[str, tuple], clip: int = 1):
+    def __init__(self, dev, n: int, hints: bool, shapes: Dict[str, tuple], param_layout: Dict[str, tuple], clip: int = 1, narrow: bool = False):
         T, P = 128, n * 128
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.n, self.dev = n, dev
@@ -102,15 +103,18 @@ class _Buffers:
             v._nrh_flat = (self.flat, off)
             self.pgrad[name] = v
         g = {}
+        # a network narrower than the compiled shape (renderer._narrow): the kernels write bias sums of the COMPILED length, so they
+        # go to buffers of their own and reach .grad through the adjoint of the zero padding (train_step_backward)
+        bias = (lambda name, key: new(*shapes[key])) if narrow else (lambda name, key: self.pgrad[name].view(-1))
         for l in range(8):     # dense (folded) weight gradients are intermediates; the bias gradients are final
-            g[f"dW{l}"], g[f"db{l}"] = new(*shapes[f"sdf_w{l}"]), self.pgrad[f"sdf_network.lin{l}.bias"].view(-1)
-        g["ws"], g["bs"] = new(1, 256), self.pgrad["sdf_network.out_sdf.bias"].view(-1)
-        g["Wf"], g["bf"] = new(256, 256), self.pgrad["sdf_network.out_feat.bias"].view(-1)
+            g[f"dW{l}"], g[f"db{l}"] = new(*shapes[f"sdf_w{l}"]), bias(f"sdf_network.lin{l}.bias", f"sdf_b{l}")
+        g["ws"], g["bs"] = new(1, 256), bias("sdf_network.out_sdf.bias", "sdf_head_b")
+        g["Wf"], g["bf"] = new(256, 256), bias("sdf_network.out_feat.bias", "feat_b")
         for l in range(5):
-            g[f"w{l}"], g[f"b{l}"] = new(*shapes[f"col_w{l}"]), self.pgrad[f"color_network.lin{l}.bias"].view(-1)
+            g[f"w{l}"], g[f"b{l}"] = new(*shapes[f"col_w{l}"]), bias(f"color_network.lin{l}.bias", f"col_b{l}")
         # one-hint models: the weight-gradient kernel fills the full model's [256, 361] first layer; ``w0_real`` receives the
         # columns that exist in the parameter (``shapes["col_w0_real"]``)
-        self.w0_real = new(*shapes["col_w0_real"]) if tuple(shapes["col_w0_real"]) != tuple(shapes["col_w0"]) else None
+        self.w0_real = new(*shapes["col_w0_real"]) if (tuple(shapes["col_w0_real"]) != tuple(shapes["col_w0"]) and not narrow) else None
         self.g = g
         self.vbars = {"v:" + k: self.pgrad[k + ".weight_v"] for k in packing._FOLD_LAYERS}
         self.gbars = {"g:" + k: self.pgrad[k + ".weight_g"] for k in packing._FOLD_LAYERS}
@@ -178,7 +182,16 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         for (wk, bk), k, w in zip(packing._FOLD_KEYS, packing._FOLD_LAYERS, ws):
             dense[wk], dense[bk] = w, named[k + ".bias"].detach()
         w0_real_shape = tuple(dense["col_w0"].shape)
-        dense = renderer._pad_hint_columns(dense)            # one-hint models: zero columns for the hint that is not there
+        narrow, real, padded = bool(getattr(renderer, "_narrow", False)), None, None
+        if narrow and want_params:
+            # a network narrower than the compiled shape runs zero-padded (packing.pad_to_compiled); the padding is recorded as a
+            # tiny autograd graph on the folded matrices, and its adjoint below cuts the kernels' compiled-shape gradients back
+            with torch.enable_grad():
+                real = {k: v.detach().requires_grad_(True) for k, v in dense.items()}
+                padded = renderer._to_compiled(real)
+            dense = {k: v.detach() for k, v in padded.items()}
+        else:
+            dense = renderer._to_compiled(dense)             # one-hint models: zero columns for the hint that is not there
         pk = renderer.packed_params(dev, dense=dense)
         hints = bool(renderer._hints)
         clip = max(1, int(getattr(renderer, "_shadow_clip", -1)))
@@ -201,7 +214,7 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             for pname, prm in renderer.named_parameters():
                 layout[pname] = (off, tuple(prm.shape))
                 off += prm.numel()
-            B = cache[key] = _Buffers(dev, n, hints, shapes, layout, clip)
+            B = cache[key] = _Buffers(dev, n, hints, shapes, layout, clip, narrow)
         # ---- no-grad stages + SDF training forward (one C call) ----
         Pn = n * 128
         # 16-bit hand-offs of the SDF net's weight-gradient operands (f16x3, batches the 8-wave kernels run): the renderer's option
@@ -319,6 +332,25 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             torch._foreach_add_([B.g[k] for k in keys], [B.g_shadow[k] for k in keys])
         # ---- weight-norm adjoint -> .grad ----
         g = B.g
+        if narrow:
+            # the adjoint of the zero padding: compiled-shape gradients -> the folded matrices' own shapes (rows / columns of padded
+            # channels and encoding columns are dropped; their entries are whatever the padded channels' constants produced)
+            wk = [f"sdf_w{l}" for l in range(8)] + ["sdf_head_w", "feat_w"] + [f"col_w{l}" for l in range(5)]
+            bk = [f"sdf_b{l}" for l in range(8)] + ["sdf_head_b", "feat_b"] + [f"col_b{l}" for l in range(5)]
+            gw = [g[f"dW{l}"] for l in range(8)] + [g["ws"], g["Wf"]] + [g[f"w{l}"] for l in range(5)]
+            gb = [g[f"db{l}"] for l in range(8)] + [g["bs"], g["bf"]] + [g[f"b{l}"] for l in range(5)]
+            with torch.enable_grad():
+                cut = torch.autograd.grad([padded[k] for k in wk + bk], [real[k] for k in wk + bk],
+                                          [t.view(padded[k].shape) for t, k in zip(gw + gb, wk + bk)])
+            wbars = [t.contiguous() for t in cut[:len(wk)]]
+            for name, t in zip(packing._FOLD_LAYERS, cut[len(wk):]):
+                B.pgrad[name + ".bias"].copy_(t)
+            vbars = [B.vbars["v:" + k] for k in packing._FOLD_LAYERS]
+            gbars = [B.gbars["g:" + k] for k in packing._FOLD_LAYERS]
+            packing.WeightNormFoldHip._call("nrh_weight_norm_fold_backward", vs, gs, wbars, vbars, gbars)
+            for pname, prm in named.items():
+                prm.grad = B.pgrad[pname]
+            return _finish_rays(B, ray_bundle, want_rays, ray_grads)
         w0bar = g["w0"]
         if B.w0_real is not None:       # one-hint model: drop the gradient columns of the hint that does not exist (renderer._pad_hint_columns)
             if renderer.has_shadow_hint:

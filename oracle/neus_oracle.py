@@ -89,8 +89,9 @@ def softplus100(x: torch.Tensor) -> torch.Tensor:
 
 
 def sdf_forward(p: OracleParams, pts: torch.Tensor, want_feat: bool = True):
-    """SDF trunk + heads (fields/sdf_field.py:106-123).  Returns (sdf [P,1], feat [P,256] or None)."""
-    e = nerf_encode(pts * 3.0, 6)
+    """SDF trunk + heads (fields/sdf_field.py:106-123).  Returns (sdf [P,1], feat [P,256] or None).  The encoding's resolution
+    (multi_res, :46-50) is read off the first layer's width: 3 + 6 multi_res input columns."""
+    e = nerf_encode(pts * 3.0, (p.sdf_w[0].shape[1] - 3) // 6)
     h = e
     for l in range(8):
         if l == 4:
@@ -119,7 +120,9 @@ def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: boo
     """One forward that keeps sigma'(z_l) = sigmoid(100 z_l), then the reverse chain by hand.
     Mathematically identical to ``sdf_gradient_autograd``; this is the structure of the HIP kernel."""
     x3 = pts * 3.0
-    e = nerf_encode(x3, 6)
+    m = (p.sdf_w[0].shape[1] - 3) // 6          # multi_res (6 in every shipped configuration)
+    n3 = p.sdf_w[3].shape[0]                    # rows of the layer in front of the skip: d_hidden - (3 + 6 multi_res) (217)
+    e = nerf_encode(x3, m)
     h = e
     dact = []
     for l in range(8):
@@ -138,13 +141,13 @@ def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: boo
         g = (g * dact[l]) @ p.sdf_w[l]
         if l == 4:
             g = g / math.sqrt(2.0)
-            ge_skip = g[:, 217:]
-            g = g[:, :217]
-    ge = g + ge_skip  # gradient w.r.t. the 39-d embedding
-    freqs = 2.0 ** torch.linspace(0.0, 5.0, 6, dtype=pts.dtype)
-    s = (x3[..., None] * freqs)                       # [P,3,6]
-    gs = ge[:, 3:21].reshape(-1, 3, 6)
-    gc = ge[:, 21:39].reshape(-1, 3, 6)
+            ge_skip = g[:, n3:]
+            g = g[:, :n3]
+    ge = g + ge_skip  # gradient w.r.t. the (3 + 6 m)-d embedding (39-d)
+    freqs = 2.0 ** torch.linspace(0.0, m - 1.0, m, dtype=pts.dtype)
+    s = (x3[..., None] * freqs)                       # [P,3,m]
+    gs = ge[:, 3:3 + 3 * m].reshape(-1, 3, m)
+    gc = ge[:, 3 + 3 * m:3 + 6 * m].reshape(-1, 3, m)
     dx3 = ge[:, 0:3] + ((gs * torch.cos(s) + gc * torch.cos(s + math.pi / 2.0)) * freqs).sum(-1)
     return sdf, feat, dx3 * 3.0
 
@@ -152,11 +155,14 @@ def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: boo
 def color_forward(p: OracleParams, pts, normals, view, feat, pls, vis=None, cue=None) -> torch.Tensor:
     """Reflectance MLP, input order [pts, enc4(view), normals, enc4(pl), feat, enc4(vis), enc4(cue)]
     (fields/reflectance_network.py:68-96); vis / cue are absent for the pl-naive model, either one for a one-hint model (:83-86)."""
-    parts = [pts, nerf_encode(view, 4), normals, nerf_encode(pls, 4), feat]
+    # the reflectance net's multi_res (:41-52; 4 in every shipped configuration) from the first layer's width
+    extra = (1 if vis is not None else 0) + (cue.shape[-1] if cue is not None else 0)
+    mv = (p.col_w[0].shape[1] - 12 - feat.shape[-1] - extra) // (2 * (6 + extra))
+    parts = [pts, nerf_encode(view, mv), normals, nerf_encode(pls, mv), feat]
     if vis is not None:
-        parts.append(nerf_encode(vis, 4))
+        parts.append(nerf_encode(vis, mv))
     if cue is not None:
-        parts.append(nerf_encode(cue, 4))
+        parts.append(nerf_encode(cue, mv))
     x = torch.cat(parts, dim=-1)
     for l in range(5):
         x = F.linear(x, p.col_w[l], p.col_b[l])

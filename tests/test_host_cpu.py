@@ -73,7 +73,11 @@ def test_init_only_config_variants_match_reference_fixture():
 
 def test_unsupported_configs_are_rejected():
     bad = [
-        na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=64)),
+        na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=512)),           # wider than the compiled 256
+        na.NeuSModelConfig(sdf_network=na.SDFNetConfig(n_layers=6)),             # depth is compiled in
+        na.NeuSModelConfig(sdf_network=na.SDFNetConfig(multi_res=2)),            # skip layer 256 - 15 = 241 rows > 217
+        na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=32)),            # narrower than its own embedding (39)
+        na.NeuSModelConfig(reflectance_network=na.ReflectanceNetConfig(multi_res=6)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True, n_outside_samples=16)),
         na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True), outside_nerf=na.NeRFConfig(d_hidden=128)),
         # force_* without the hint: the reference itself fails (tests/golden/render_branches_b.npz records its RuntimeError)
@@ -88,6 +92,8 @@ def test_unsupported_configs_are_rejected():
         with pytest.raises(ValueError):
             na.NeuSHintRenderer(cfg)
     assert na.unsupported_reason(na.NeuSModelConfig()) is None
+    # narrower than the compiled widths / resolutions: accepted (zero-padded, packing.pad_to_compiled)
+    assert na.unsupported_reason(na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=64), reflectance_network=na.ReflectanceNetConfig(d_hidden=64, multi_res=1))) is None
     # the renderer's two free scalars are kernel constants (NrhNet.custom_consts), not shapes: any sane value is accepted ...
     rc = na.NeuSHintRenderer(na.NeuSModelConfig(renderer=na.NeuSRendererConfig(specular_roughness=[0.03, 0.08, 0.2, 0.5], shadow_ray_offset=3e-2)))
     assert rc._net_consts == ([0.03, 0.08, 0.2, 0.5], 3e-2) and na.NeuSHintRenderer()._net_consts is None
@@ -635,3 +641,51 @@ def test_stale_library_is_refused(tmp_path, monkeypatch):
     monkeypatch.setenv("NRHINTS_HIP_LIB", _lib.LIB_PATH)      # an explicitly named library (make variant) is exempt, and reported
     assert _lib.load() is not None
     monkeypatch.setattr(_lib, "_lib", None)
+
+
+@pytest.mark.parametrize("vt", ["n128", "n192", "n160s"])
+def test_narrow_networks_zero_padded_to_the_compiled_shape_are_exact(vt):
+    """packing.pad_to_compiled (VERDICT r5 missing #2: widths / encoding resolutions below the compiled ones): the padded matrices
+    have the compiled shapes, and the restatement evaluated on them - SDF value, feature vector, analytic gradient, reflectance
+    colour - equals the restatement on the narrow matrices to float64 round-off: padded channels only ever meet zero weights, padded
+    encoding columns zero columns.  Also: the default shapes pass through as the same tensors (no copy, no launch)."""
+    import oracle.neus_oracle as orc
+    from nrhints_amd import packing
+    from tests import shape_variants as sv
+    g = load_npz("render_shapes.npz")
+    st = {k: torch.from_numpy(v).double() for k, v in sv.state(vt, g).items()}
+    m = na.NeuSHintRenderer(sv.config(vt))
+    assert m._narrow
+    d = packing.dense_params(st)
+    dp = m._to_compiled(d)
+    packing.check_default_shapes(dp, hints=True)
+    s_, c_, _ = sv.VARIANTS[vt]
+    f, mv = s_.get("d_out_feat", 256), c_.get("multi_res", 4)
+
+    def params(dd):
+        return orc.OracleParams([dd[f"sdf_w{l}"] for l in range(8)], [dd[f"sdf_b{l}"] for l in range(8)], dd["sdf_head_w"], dd["sdf_head_b"],
+                                dd["feat_w"], dd["feat_b"], [dd[f"col_w{l}"] for l in range(5)], [dd[f"col_b{l}"] for l in range(5)], st["deviation_network.variance"])
+
+    rs = np.random.RandomState(3)
+    pts = torch.from_numpy(rs.uniform(-0.8, 0.8, (200, 3)))
+    sdf_n, feat_n, grad_n = orc.sdf_forward_grad_analytic(params(d), pts)
+    sdf_p, feat_p, grad_p = orc.sdf_forward_grad_analytic(params(dp), pts)
+    assert float((sdf_n - sdf_p).abs().max()) < 1e-13 and float((grad_n - grad_p).abs().max()) < 1e-12
+    assert feat_p.shape == (200, 256) and float((feat_n - feat_p[:, :f]).abs().max()) < 1e-13 and float(feat_p[:, f:].abs().sum()) == 0.0
+    unit = lambda a: torch.from_numpy(a / np.linalg.norm(a, axis=-1, keepdims=True))
+    view, pls, nrm = unit(rs.randn(200, 3)), torch.from_numpy(rs.randn(200, 3) * 3.0), unit(rs.randn(200, 3))
+    vis = torch.from_numpy(rs.uniform(0, 1, (200, 1)))
+    cue = torch.from_numpy(rs.uniform(0, 2, (200, 4))) if m.has_specular_hint else None
+    col_n = orc.color_forward(params(d), pts, nrm, view, feat_n, pls, vis, cue)
+    # the compiled layout always has both hints' columns: the absent hint is fed (its encoding's columns are zero in the matrix)
+    col_p = orc.color_forward(params(dp), pts, nrm, view, feat_p, pls, vis, cue if cue is not None else torch.from_numpy(rs.uniform(0, 2, (200, 4))))
+    assert float((col_n - col_p).abs().max()) < 1e-13
+    # differentiable: a gradient through the padded matrices arrives in the parameters' own shapes
+    w0 = d["col_w0"].clone().requires_grad_(True)
+    m._to_compiled(dict(d, col_w0=w0))["col_w0"].square().sum().backward()
+    assert w0.grad.shape == d["col_w0"].shape and torch.allclose(w0.grad, 2 * d["col_w0"])
+    # default shapes: untouched
+    full = na.NeuSHintRenderer()
+    dd = packing.dense_params({k: v for k, v in full.state_dict().items()})
+    assert not full._narrow and all(full._to_compiled(dd)[k] is dd[k] for k in dd)
+    assert mv <= 4

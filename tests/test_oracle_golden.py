@@ -466,3 +466,34 @@ def test_training_forward_at_three_anneal_ratios_vs_reference(scene_states, gs):
                              t_rand_primary=tp.double(), t_rand_shadow=ts.double(), mode="minimal")
     # (rgb_f64 is stored as float32: 6e-8)
     np.testing.assert_allclose(o64["rgb"].numpy(), g[p_ + "rgb_f64"][:n], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("vt", ["n128", "n192", "n160s"])
+def test_narrow_network_shapes_vs_reference(vt):
+    """Widths / encoding resolutions below the defaults (fields/sdf_field.py:11-36, fields/reflectance_network.py:9-22;
+    tests/golden/make_golden_shapes.py): the restatement reads the shapes off the matrices; evaluation render and one training
+    step's loss against the reference's record.  (The state comes from the package's constructor, which this also pins to the
+    reference's init RNG stream for these shapes.)"""
+    from tests import shape_variants as sv
+    g = load_npz("render_shapes.npz")
+    st = sv.state(vt, g)
+    kw = dict(shadow_hint=True, specular_hint=sv.VARIANTS[vt][2].get("specular_hint", True))
+    p = orc.params_from_state(st)
+    rays = [T(g[k]) for k in ("o", "d", "pl", "near", "far")]
+    out = orc.render_forward(p, *rays, background_rgb=torch.ones(1, 3), mode="as_written", **kw)
+    # float32 against float32: the two programs sum in different orders, and on these freshly initialised narrow scenes single rays
+    # carry a sampler event (measured: mean 9e-7 / 1.5e-6, one ray at 5e-5 / 1e-4 of 64); the float64 comparison below is the pin
+    e32 = np.abs(out["rgb"].numpy() - g[f"{vt}.rgb"])
+    assert e32.mean() < 5e-6 and e32.max() < 3e-4, (vt, e32.mean(), e32.max())
+    np.testing.assert_allclose(out["depth"].numpy(), g[f"{vt}.depth"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(out["visibilities"].numpy(), g[f"{vt}.visibilities"], rtol=0, atol=2e-3)
+    p64 = orc.params_from_state(st, dtype=torch.float64)
+    o64 = orc.render_forward(p64, *(t.double() for t in rays), background_rgb=torch.ones(1, 3, dtype=torch.float64), mode="minimal", **kw)
+    np.testing.assert_allclose(o64["rgb"].numpy(), g[f"{vt}.rgb_f64"], rtol=0, atol=1e-9)
+    trays = [T(g["t." + k]) for k in ("o", "d", "pl", "near", "far")]
+    tout = orc.render_forward(p, *trays, background_rgb=torch.ones(1, 3), is_training=True, global_step=int(g["t.global_step"]),
+                              t_rand_primary=T(g[f"{vt}.t_rand_primary"]), t_rand_shadow=T(g[f"{vt}.t_rand_shadow"]), mode="as_written", **kw)
+    et = np.abs(tout["rgb"].numpy() - g[f"{vt}.t.rgb"])
+    assert et.mean() < 5e-6 and et.max() < 3e-4, (vt, et.mean(), et.max())
+    loss, _, _ = orc.train_loss(tout, T(g["t.rgb_gt"]))
+    np.testing.assert_allclose(loss.item(), g[f"{vt}.loss"], rtol=1e-4)
