@@ -191,7 +191,10 @@ class OutsideNetHip(torch.autograd.Function):
 
 def outside_z(far: torch.Tensor, n_samples: int, t_rand=None) -> torch.Tensor:
     """Sample positions beyond the unit sphere, inverse-depth spaced (models/neus_hint_model.py:677-693): far [N,1] -> [N,32]."""
-    u = torch.linspace(1e-3, 1.0 - 1.0 / (N_OUTSIDE + 1.0), N_OUTSIDE).to(far)     # linspace on the host, as the reference's default device does
+    key = ("outside_u", str(far.device), far.dtype)
+    if key not in _MAPS:      # linspace on the host, as the reference's default device does; cached per device (a captured step may not copy from the host)
+        _MAPS[key] = torch.linspace(1e-3, 1.0 - 1.0 / (N_OUTSIDE + 1.0), N_OUTSIDE).to(far)
+    u = _MAPS[key]
     if t_rand is not None:      # stratified jitter in training
         mids = 0.5 * (u[1:] + u[:-1])
         upper, lower = torch.cat([mids, u[-1:]]), torch.cat([u[:1], mids])
@@ -259,11 +262,29 @@ class AlphaBlendHip(torch.autograd.Function):
         return sdf_bar, grad_bar, rd_bar, None, None, bg_bar, var_bar, None, None, None
 
 
+class _ExclusiveCumprod(torch.autograd.Function):
+    """T_k = prod_{i<k} x_i along the last dimension, the forward exactly as render_core writes it (cumprod of [1, x][:-1], :520-523).
+    Its own backward because torch.cumprod's tests the input for zeros on the host - a synchronisation a captured training step
+    cannot contain; here x = 1 - alpha + 1e-7 > 0, and the zero-free formula is the one torch takes then: rev-cumsum(g y) / x."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.cumprod(torch.cat([torch.ones_like(x[:, :1]), x], dim=-1), dim=-1)[:, :-1]
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        gy = g * y
+        return (gy.flip(-1).cumsum(-1).flip(-1) - gy) / x
+
+
 def composite(weights128, tail_t, inside, color128, bg_alpha, bg_col, background_rgb) -> Dict[str, torch.Tensor]:
     """What render_core does after the alpha stage when a background is present (:520-523, :630-637): the 32 samples beyond the
     sphere continue the transmittance product from ``tail_t``; a sample outside the unit sphere shows the background's colour."""
     a_tail = bg_alpha[:, 128:]
-    trans = torch.cumprod(torch.cat([torch.ones_like(a_tail[:, :1]), 1.0 - a_tail + 1e-7], dim=-1), dim=-1)[:, :-1]
+    trans = _ExclusiveCumprod.apply(1.0 - a_tail + 1e-7)
     w_tail = a_tail * tail_t * trans
     weights = torch.cat([weights128, w_tail], dim=-1)
     ins = inside[..., None]

@@ -25,8 +25,12 @@ Round 6: ``shadow_hint_gradient`` / ``specular_hint_gradient`` (models/neus_hint
 both sweeps a second time at the shadow ray's sections, the shadow alpha stage's kernel pair, and a small autograd island on
 per-RAY tensors for the hit normal, the cue and the two encodings (_hint_forward / _hint_backward below).
 Networks narrower than the compiled shape (renderer._narrow) run zero-padded; the adjoint of the padding cuts the gradients back.
-Restrictions (the autograd path covers the rest): GPU float32 parameters, no outside NeRF, at most ``max_fused_train_rays`` rays
-per call; shadow_hint_gradient with ray gradients or with the partial visibility hint is refused on both paths.
+Fourth session of round 6: ``use_outside_nerf`` (:434-473, :516-519, :630-637) - the background network stays behind its autograd
+Function (its kernels, csrc/nrh_outside.hip), the 160-sample composite and the loss are a torch island between the kernels
+(_outside_forward / _outside_loss / _outside_backward below).
+Restrictions (the autograd path covers the rest): GPU float32 parameters, no ray gradients together with the outside NeRF, at most
+``max_fused_train_rays`` rays per call; shadow_hint_gradient with ray gradients or with the partial visibility hint is refused on
+both paths.
 """
 from __future__ import annotations
 
@@ -57,7 +61,8 @@ def supported(renderer, ray_bundle) -> Optional[str]:
         if any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
             return "shadow_hint_gradient together with ray gradients (not implemented on either path)"
     if getattr(renderer, "has_outside_nerf", False):
-        return "outside-NeRF background"
+        if any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
+            return "outside-NeRF background together with ray gradients (the autograd path runs it)"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
         return "more rays than max_fused_train_rays"
     if ray_bundle.origins.shape[0] == 0:
@@ -123,7 +128,8 @@ class _Buffers:
 
 def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_rgb: Optional[torch.Tensor], global_step: int,
                         igr_weight: Optional[float] = None, t_rand_primary=None, t_rand_shadow=None, is_training: bool = True,
-                        ray_grads: Optional[Dict[str, torch.Tensor]] = None, forward_out: Optional[dict] = None) -> torch.Tensor:
+                        ray_grads: Optional[Dict[str, torch.Tensor]] = None, forward_out: Optional[dict] = None,
+                        t_rand_outside=None) -> torch.Tensor:
     """Forward + loss + backward of one batch.  Returns the loss vector [8] on the device (``LOSS_KEYS`` = entries 0..4) and sets
     ``.grad`` of every renderer parameter (overwriting, like zero_grad + backward) - unless the renderer's parameters are frozen
     (``requires_grad_(False)``, as in register_view), in which case the weight gradients, the weight-norm adjoint and the variance
@@ -139,7 +145,8 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
     [n,1], cue [n,128,4], weights, inside, and the SDF network's outputs at the samples (sdf [P,1], normals [n,128,3], feat
     [P,256]) - i.e. the sample placement and linearisation point of the gradients this call leaves in ``.grad``.  (A separate
     _render_train call is NOT guaranteed to place the same samples: this step folds weight-norm with nrh_weight_norm_fold, other
-    paths with torch ops, and a last-bit difference in a weight moves importance samples where the pdf sits at its floor.)"""
+    paths with torch ops, and a last-bit difference in a weight moves importance samples where the pdf sits at its floor.)
+    ``t_rand_outside`` [n,32]: the stratified jitter of the samples beyond the sphere (renderer.use_outside_nerf, :689); drawn when None."""
     why = supported(renderer, ray_bundle)
     if why is not None:
         raise ValueError(f"fused training step not applicable: {why}")
@@ -225,8 +232,9 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         rcfg = cfg.renderer
         shadow_grad = bool(rcfg.shadow_hint_gradient and renderer.has_shadow_hint and not zero_hints)
         specular_grad = bool(rcfg.specular_hint_gradient and renderer.has_specular_hint and not zero_hints)
+        og = _outside_forward(renderer, lib, pk, o, d, pl, near, far, t_p, t_rand_outside, is_training) if renderer.has_outside_nerf else None
         res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half, pts=B.pts,
-                                     want_shadow=shadow_grad)
+                                     want_shadow=shadow_grad, extra_net=None if og is None else og["extra"])
         pre, sv = res["pre"], res["pre"]["saves"]
         hg = _hint_forward(renderer, lib, B, pk, res, o, d, pl, cos_anneal, shadow_grad, specular_grad, want_rays) \
             if (shadow_grad or specular_grad) else None
@@ -258,11 +266,14 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         # ---- composite, loss, adjoint seeds ----
         bg = f32(background_rgb.to(dev)).reshape(-1) if background_rgb is not None else None
         gt = f32(rgb_gt)
-        _lib.check(lib.nrh_composite_loss(P_(B.color), P_(res["weights"]), P_(gt), P_(bg), P_(res["normals"].view(Pn, 3)), P_(res["inside"]),
-                                          n, P_(B.rgb), P_(B.zbar4), P_(B.wbar), P_(B.partial), stream), "nrh_composite_loss")
         dyn = renderer.dyn_scalars
         inv_s = pk["inv_s"]
-        _lib.check(lib.nrh_loss_finish(P_(B.partial), n, float(inv_s), P_(dyn), igr, P_(B.loss8), stream), "nrh_loss_finish")
+        if og is None:
+            _lib.check(lib.nrh_composite_loss(P_(B.color), P_(res["weights"]), P_(gt), P_(bg), P_(res["normals"].view(Pn, 3)), P_(res["inside"]),
+                                              n, P_(B.rgb), P_(B.zbar4), P_(B.wbar), P_(B.partial), stream), "nrh_composite_loss")
+            _lib.check(lib.nrh_loss_finish(P_(B.partial), n, float(inv_s), P_(dyn), igr, P_(B.loss8), stream), "nrh_loss_finish")
+        else:
+            _outside_loss(og, B, res, gt, None if bg is None else bg.view(1, 3), igr, n, float(inv_s), dyn)
         # ---- reflectance adjoint sweep ----
         cwt = pk["col_wt"]
         if half_c:
@@ -284,10 +295,13 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             _hint_backward(hg, B, n, mw, analytic)
             if hg.get("nhat_bar") is not None and analytic:      # Analytic: the net's normal input is the raw gradient, but the hit
                 nbar, nbar_stride = P_(hg["nhat_bar"]), 3        # normal is built from UNIT normals (:584): their adjoint on its own
-        _lib.check(lib.nrh_alpha_train_backward_fused(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), float(inv_s),
-                                                      float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, nbar_stride, P_(res["inside"]),
-                                                      ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
-                                                      P_(B.invs_bar), int(renderer._samples), stream), "nrh_alpha_train_backward_fused")
+        if og is None:
+            _lib.check(lib.nrh_alpha_train_backward_fused(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), float(inv_s),
+                                                          float(cos_anneal), P_(dyn), n, P_(B.wbar), nbar, nbar_stride, P_(res["inside"]),
+                                                          ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
+                                                          P_(B.invs_bar), int(renderer._samples), stream), "nrh_alpha_train_backward_fused")
+        else:
+            _outside_backward(renderer, og, lib, B, pre, res, d, float(inv_s), float(cos_anneal), dyn, n, analytic, stream)
         if analytic:
             B.grad_bar.add_(B.mbar[:, 3:6])
         shadow_r = None
@@ -368,6 +382,86 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         for pname, prm in named.items():
             prm.grad = B.pgrad[pname]
         return _finish_rays(B, ray_bundle, want_rays, ray_grads)
+
+
+def _outside_forward(renderer, lib, pk, o, d, pl, near, far, t_p, t_rand_outside, is_training: bool) -> dict:
+    """renderer.use_outside_nerf on the fused step, part 1 (models/neus_hint_model.py:677-724, :434-473): where the primary ray's
+    samples are (nrh_sample_primary), the 32 positions beyond the sphere, and the background network at the merged 160 positions
+    (outside.render_outside: csrc/nrh_outside.hip behind its autograd Function, whose graph - background parameters -> alpha,
+    colour - is kept for part 3).  -> the NrhNet extras of the render call (bg_alpha in, tail_t out) and the island's tensors."""
+    from . import outside
+    P_ = _lib.ptr
+    dev, n = o.device, o.shape[0]
+    rc = renderer.config.renderer
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    z, mid0, dists0 = new(n, 128), new(n, 128), new(n, 128)
+    lin64, lin16 = renderer._const(dev)
+    net0 = _lib.make_net(pk, renderer._hints, renderer._normal_type, renderer._depth_type, renderer.dyn_scalars, wide=renderer.wide_kernels,
+                         consts=renderer._net_consts)
+    ws = renderer._workspace(dev, n)
+    _lib.check(lib.nrh_sample_primary(net0, P_(o), P_(d), P_(near), P_(far), n, P_(t_p), P_(lin64), P_(lin16), P_(z), P_(mid0), P_(dists0),
+                                      P_(ws), ws.numel(), _lib.stream_handle()), "nrh_sample_primary")
+    t_o = None
+    if is_training:
+        t_o = torch.rand(n, outside.N_OUTSIDE, device=dev) if t_rand_outside is None else t_rand_outside.detach().to(dev, torch.float32)
+    renderer.outside_nerf.precision = renderer.precision
+    with torch.enable_grad():
+        z_out = outside.outside_z(far.reshape(-1, 1), rc.n_samples, t_o)
+        z_feed, _ = torch.sort(torch.cat([z, z_out], dim=-1), dim=-1)
+        bg_alpha, bg_col = outside.render_outside(renderer.outside_nerf, o, d, pl, z_feed, 2.0 / rc.n_samples)
+    bg_a, tail_t = bg_alpha.detach().contiguous(), new(n)
+    return dict(bg_alpha=bg_alpha, bg_col=bg_col, bg_a=bg_a, tail_t=tail_t, extra=dict(bg_alpha=bg_a, tail_t=tail_t, sampled_color=None))
+
+
+def _outside_loss(og: dict, B, res, gt, bgc, igr: float, n: int, inv_s: float, dyn) -> None:
+    """Part 2: composite over 128 + 32 samples and the loss (:520-523, :630-637; pipelines/base_pipeline.py:50-69) as a torch island on
+    per-sample arrays the kernels produced - leaves: blended weights, the transmittance behind sample 127, the reflectance net's
+    colours, the SDF gradients (eikonal term), and the background's alpha / colour as cut points.  Its backward seeds everything
+    downstream: B.wbar, B.zbar4 (through the sigmoid, as nrh_composite_loss writes it), the eikonal seed, d loss / d tail_t and the
+    background's own adjoints; B.loss8 gets the loss vector."""
+    from . import outside
+    with torch.enable_grad():
+        w_leaf = res["weights"].detach().requires_grad_(True)
+        t_leaf = og["tail_t"].detach().view(n, 1).requires_grad_(True)
+        c_leaf = B.color.detach().view(n, 128, 3).requires_grad_(True)
+        n_leaf = res["normals"].detach().requires_grad_(True)
+        ba, bc = og["bg_alpha"].detach().requires_grad_(True), og["bg_col"].detach().requires_grad_(True)
+        rgb = outside.composite(w_leaf, t_leaf, res["inside"], c_leaf, ba, bc, bgc)["rgb"]
+        rgb_loss = (rgb - gt).abs().sum() / (n + 1e-5)
+        mask = res["inside"]
+        eik = (mask * (torch.linalg.norm(n_leaf, ord=2, dim=-1) - 1.0) ** 2).sum() / (mask.sum() + 1e-5)
+        loss = rgb_loss + eik * igr
+        gw, gt_, gc, gn, gba, gbc = torch.autograd.grad(loss, [w_leaf, t_leaf, c_leaf, n_leaf, ba, bc])
+    B.wbar.copy_(gw)
+    c = B.color.view(n, 128, 3)
+    B.zbar4.view(n, 128, 3).copy_(gc * c * (1.0 - c))
+    B.rgb.copy_(rgb.detach())
+    og.update(tbar=gt_.reshape(n).contiguous(), gn=gn.reshape(-1, 3), gba=gba, gbc=gbc)
+    s_val = (1.0 / dyn[0]).reshape(()) if dyn is not None else torch.full((), 1.0 / inv_s, dtype=torch.float32, device=rgb.device)
+    psnr = 10.0 * torch.log10(1.0 / torch.mean((rgb.detach() - gt) ** 2))
+    B.loss8[:5].copy_(torch.stack([loss.detach(), rgb_loss.detach(), eik.detach(), s_val, psnr]))
+
+
+def _outside_backward(renderer, og: dict, lib, B, pre, res, d, inv_s: float, cos_anneal: float, dyn, n: int, analytic: bool, stream) -> None:
+    """Part 3: the alpha stage's adjoint with the blend (nrh_alpha_blend_backward: also d loss / d bg_alpha[:, :128]), the eikonal
+    seed, and the background network's backward - its parameter gradients accumulate into their views of the flat .grad buffer."""
+    P_ = _lib.ptr
+    Pn = n * 128
+    nb = None if analytic else B.mbar[:, 3:6].contiguous()
+    bg128 = torch.empty(n, 128, dtype=torch.float32, device=B.dev)
+    _lib.check(lib.nrh_alpha_blend_backward(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), P_(res["inside"]), P_(og["bg_a"]),
+                                            inv_s, cos_anneal, P_(dyn), n, P_(B.wbar), P_(nb), P_(og["tbar"]), P_(B.sdf_bar), P_(B.grad_bar),
+                                            P_(B.rd_bar), P_(B.invs_bar), P_(bg128), stream), "nrh_alpha_blend_backward")
+    B.grad_bar.add_(og["gn"])
+    if og["bg_alpha"].requires_grad:
+        gba = og["gba"].clone()
+        gba[:, :128] += bg128
+        for name, prm in renderer.outside_nerf.named_parameters():
+            v = B.pgrad["outside_nerf." + name]
+            v.zero_()
+            prm.grad = v          # AccumulateGrad adds in place: the gradient lands in the flat buffer's view
+        with torch.enable_grad():
+            torch.autograd.backward([og["bg_alpha"], og["bg_col"]], [gba, og["gbc"]])
 
 
 def _hint_forward(renderer, lib, B, pk, res, o, d, pl, cos_anneal, shadow_grad: bool, specular_grad: bool, want_rays: bool) -> dict:

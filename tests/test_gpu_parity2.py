@@ -997,3 +997,64 @@ def test_outside_nerf_background(scene_states, prec):
         err = float(np.abs(got - want64).max())
         assert err <= bound, (name, err, bound, scale)
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_fused_step_outside_nerf(scene_states, prec):
+    """renderer.use_outside_nerf on the autograd-free step (VERDICT r5 missing #3; train_fused._outside_forward / _outside_loss /
+    _outside_backward): same batch, same three jitter draws as the autograd path of test_outside_nerf_background (itself held to the
+    reference's float64 gradients) - loss and all 70 gradient tensors, the background network's 24 included, to float32 round-off;
+    the gradients are views of the flat buffer; and the step is captured and replayed by GraphedTrainStep."""
+    from nrhints_amd import train_fused
+    from nrhints_amd.training import GraphedTrainStep, train_loss_dict
+    g = load_npz("outside_b.npz")
+    cfg = na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True))
+    state = {k: T(np.asarray(v)) for k, v in scene_states["b"].items()}
+    state.update({"outside_nerf." + k[5:]: T(v) for k, v in g.items() if k.startswith("nerf.")})
+    bg = torch.ones(1, 3).cuda()
+
+    def build():
+        m = na.NeuSHintRenderer(cfg, precision=prec)
+        m.load_state_dict(state)
+        return m.cuda().train()
+
+    tb = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    gs, gt = int(g["t.global_step"]), cu(g["t.rgb_gt"])
+    tp, ts, to = cu(g["t.t_rand_primary"]), cu(g["t.t_rand_shadow"]), cu(g["t.t_rand_outside"])
+    ref = build()
+    o = ref(tb, is_training=True, background_rgb=bg, global_step=gs, _t_rand_primary=tp, _t_rand_shadow=ts, _t_rand_outside=to)
+    ld = train_loss_dict(o, gt, 0.1)
+    ld["loss"].backward()
+    fused = build()
+    assert train_fused.supported(fused, tb) is None
+    l8 = train_fused.train_step_backward(fused, tb, gt, bg, gs, t_rand_primary=tp, t_rand_shadow=ts, t_rand_outside=to)
+    for i, k in enumerate(("loss", "rgb_loss", "eikonal_loss", "s_val", "psnr")):
+        np.testing.assert_allclose(float(l8[i]), float(ld[k].detach()), rtol=2e-5, err_msg=k)
+    np.testing.assert_allclose(float(l8[0]), float(g["t.loss"]), rtol=2e-4)
+    n_out = 0
+    for (name, pa), (_, pf) in zip(ref.named_parameters(), fused.named_parameters()):
+        assert pf.grad is not None and pf.grad.shape == pa.shape and hasattr(pf.grad, "_nrh_flat"), name
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, (name, float((pa.grad - pf.grad).abs().max()), scale)
+        n_out += name.startswith("outside_nerf.")
+    assert n_out == 24
+    # a second call overwrites (zero_grad + backward semantics), it does not accumulate
+    l8b = train_fused.train_step_backward(fused, tb, gt, bg, gs, t_rand_primary=tp, t_rand_shadow=ts, t_rand_outside=to)
+    for (name, pa), (_, pf) in zip(ref.named_parameters(), fused.named_parameters()):
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, name
+    # ray gradients with the background: the autograd path's job
+    rb2 = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    rb2.origins.requires_grad_(True)
+    assert "outside" in train_fused.supported(fused, rb2)
+    # captured
+    cap = build()
+    n = tb.origins.shape[0]
+    step = GraphedTrainStep(cap, n, bg, lr=5e-4, warm_up_end=20, global_step=gs)
+    assert step._use_fused
+    before = {k: v.detach().clone() for k, v in cap.named_parameters()}
+    losses = [step(tb, gt, global_step=gs + i)["loss"] for i in range(4)]
+    assert all(np.isfinite(losses)) and abs(losses[0] - float(ld["loss"].detach())) < 0.05 * abs(float(ld["loss"].detach()))
+    moved = {k: float((p.detach() - before[k]).abs().max()) for k, p in cap.named_parameters()}
+    assert min(moved[k] for k in moved if k.startswith("outside_nerf.") and k.endswith("weight")) > 0.0 and moved["sdf_network.lin3.weight_v"] > 0.0
+    step.release()
