@@ -138,9 +138,10 @@ def unsupported_reason(cfg: NeuSModelConfig) -> Optional[str]:
          "d_out_feat in 1..256 (narrower than the compiled 256 / 6 / 256 runs zero-padded; wider is not built)"),
         (c.n_layers == 4 and c.weight_norm and c.squeeze_out and 1 <= c.d_hidden <= 256 and 1 <= c.multi_res <= 4,
          "reflectance_network must be a 4-layer weight-normalised sigmoid MLP with d_hidden <= 256 and multi_res in 1..4"),
-        (not r.use_outside_nerf or (r.n_outside_samples == 32 and r.n_importance_samples == 64 and r.n_shadow_importance_clip == -1
-                                    and not r.shadow_hint_gradient and not r.specular_hint_gradient),
-         "use_outside_nerf needs n_outside_samples = 32, the 128-sample layout, the hit-point shadow mode and no hint gradients"),
+        # (hint gradients together with the background run on the fused training step only, train_fused.py; forward() under autograd
+        # refuses that pair at call time)
+        (not r.use_outside_nerf or (r.n_outside_samples == 32 and r.n_importance_samples == 64 and r.n_shadow_importance_clip == -1),
+         "use_outside_nerf needs n_outside_samples = 32, the 128-sample layout and the hit-point shadow mode"),
         (not r.use_outside_nerf or (n.d_hidden == 256 and n.n_layers == 8 and n.multi_res == 10 and n.multi_res_view == 4
                                     and list(n.skips) == [4]),
          "outside_nerf must be the default 8x256 / multires 10 + 4 / skips=[4] network"),

@@ -594,6 +594,10 @@ class NeuSHintRenderer(nn.Module):
                                 specular_cue=res["cue"] if self.has_specular_hint else None)
         if n > self.max_fused_train_rays:
             raise ValueError("training with use_outside_nerf needs at most max_fused_train_rays rays per call")
+        rcfg = cfg.renderer
+        if not zero_hints and ((rcfg.shadow_hint_gradient and self.has_shadow_hint) or (rcfg.specular_hint_gradient and self.has_specular_hint)):
+            raise NotImplementedError("use_outside_nerf together with shadow_hint_gradient / specular_hint_gradient trains on the fused step "
+                                      "(training.train_step / GraphedTrainStep / train_fused.train_step_backward), not through forward() + backward()")
         res = self._render_train(o, d, pl, near, far, cos_anneal, t_rand_p, t_rand_s, zero_hints, extra_net=extra)
         mid_z, dists, inside = res["mid_z"], res["dists"], res["inside"]
         pts = (o_g.to(torch.float32)[:, None, :] + d_g.to(torch.float32)[:, None, :] * mid_z[..., None]).reshape(-1, 3)

@@ -301,7 +301,8 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
                                                           ctypes.c_void_p(B.loss8.data_ptr() + 20), P_(B.sdf_bar), P_(B.grad_bar), P_(B.rd_bar),
                                                           P_(B.invs_bar), int(renderer._samples), stream), "nrh_alpha_train_backward_fused")
         else:
-            _outside_backward(renderer, og, lib, B, pre, res, d, float(inv_s), float(cos_anneal), dyn, n, analytic, stream)
+            _outside_backward(renderer, og, lib, B, pre, res, d, float(inv_s), float(cos_anneal), dyn, n, analytic, stream,
+                              nhat_bar=hg.get("nhat_bar") if (hg is not None and analytic) else None)
         if analytic:
             B.grad_bar.add_(B.mbar[:, 3:6])
         shadow_r = None
@@ -442,12 +443,15 @@ def _outside_loss(og: dict, B, res, gt, bgc, igr: float, n: int, inv_s: float, d
     B.loss8[:5].copy_(torch.stack([loss.detach(), rgb_loss.detach(), eik.detach(), s_val, psnr]))
 
 
-def _outside_backward(renderer, og: dict, lib, B, pre, res, d, inv_s: float, cos_anneal: float, dyn, n: int, analytic: bool, stream) -> None:
+def _outside_backward(renderer, og: dict, lib, B, pre, res, d, inv_s: float, cos_anneal: float, dyn, n: int, analytic: bool, stream,
+                      nhat_bar=None) -> None:
     """Part 3: the alpha stage's adjoint with the blend (nrh_alpha_blend_backward: also d loss / d bg_alpha[:, :128]), the eikonal
     seed, and the background network's backward - its parameter gradients accumulate into their views of the flat .grad buffer."""
     P_ = _lib.ptr
     Pn = n * 128
-    nb = None if analytic else B.mbar[:, 3:6].contiguous()
+    # the unit normals' adjoint: the reflectance net's input columns (NormalizedAnalytic) or - Analytic normals with the specular
+    # hint's gradient - the hit normal's own array (``nhat_bar``, _hint_backward)
+    nb = nhat_bar if analytic else B.mbar[:, 3:6].contiguous()
     bg128 = torch.empty(n, 128, dtype=torch.float32, device=B.dev)
     _lib.check(lib.nrh_alpha_blend_backward(P_(pre["sdf"]), P_(res["normals"].view(Pn, 3)), P_(d), P_(res["dists"]), P_(res["inside"]), P_(og["bg_a"]),
                                             inv_s, cos_anneal, P_(dyn), n, P_(B.wbar), P_(nb), P_(og["tbar"]), P_(B.sdf_bar), P_(B.grad_bar),

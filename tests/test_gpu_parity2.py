@@ -1058,3 +1058,42 @@ def test_fused_step_outside_nerf(scene_states, prec):
     moved = {k: float((p.detach() - before[k]).abs().max()) for k, p in cap.named_parameters()}
     assert min(moved[k] for k in moved if k.startswith("outside_nerf.") and k.endswith("weight")) > 0.0 and moved["sdf_network.lin3.weight_v"] > 0.0
     step.release()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_fused_step_outside_nerf_with_hint_gradients(scene_states, prec):
+    """use_outside_nerf + shadow_hint_gradient + specular_hint_gradient (VERDICT r5 missing #4; models/neus_hint_model.py:379,
+    :516-519, :586-589): on the fused step the background island and the hint island meet in the weights' adjoint.  Against the
+    reference's recorded float64 step (tests/golden/make_golden_outside_hintgrad.py: the variance gradient is 5x what it is without
+    the hints, the SDF net's up to 9 % different - the bounds below would catch a dropped term); forward() + backward() refuses
+    the pair with a pointer to the fused step; training.train_step takes the fused step by itself."""
+    from nrhints_amd import train_fused
+    g, src = load_npz("outside_hintgrad_b.npz"), load_npz("outside_b.npz")
+    cfg = na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True, shadow_hint_gradient=True, specular_hint_gradient=True))
+    assert na.unsupported_reason(cfg) is None
+    state = {k: T(np.asarray(v)) for k, v in scene_states["b"].items()}
+    state.update({"outside_nerf." + k[5:]: T(v) for k, v in src.items() if k.startswith("nerf.")})
+    bg = torch.ones(1, 3).cuda()
+    model = na.NeuSHintRenderer(cfg, precision=prec)
+    model.load_state_dict(state)
+    model = model.cuda().train()
+    tb = _bundle(*(src["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    gs, gt = int(src["t.global_step"]), cu(src["t.rgb_gt"])
+    jit = dict(t_rand_primary=cu(g["t.t_rand_primary"]), t_rand_shadow=cu(g["t.t_rand_shadow"]), t_rand_outside=cu(g["t.t_rand_outside"]))
+    assert train_fused.supported(model, tb) is None
+    l8 = train_fused.train_step_backward(model, tb, gt, bg, gs, **jit)
+    np.testing.assert_allclose(float(l8[0]), float(g["t.loss64"]), rtol=3e-4)
+    named = dict(model.named_parameters())
+    keys = [k for k in g if k.startswith("t.grad.")]
+    assert len(keys) == 14
+    for k in keys:
+        name = k[len("t.grad."):]
+        want64 = g[k.replace("t.grad.", "t.grad64.")]
+        bound, scale = grad_bound(g[k], want64, factor=4.0, floor=1e-2 if np.size(want64) == 1 else 5e-3)      # as test_outside_nerf_background
+        err = float(np.abs(named[name].grad.detach().cpu().numpy().astype(np.float64) - want64).max())
+        assert err <= bound, (name, err, bound, scale)
+    # without the hint terms the variance gradient would be off by its own size: make sure the fixture discriminates
+    v_with, v_without = float(g["t.grad64.deviation_network.variance"]), float(src["t.grad64.deviation_network.variance"])
+    assert abs(float(named["deviation_network.variance"].grad) - v_with) < 0.1 * abs(v_with - v_without)
+    with pytest.raises(NotImplementedError):
+        model(tb, is_training=True, background_rgb=bg, global_step=gs)
