@@ -78,7 +78,7 @@ def params_from_state(state, dtype=torch.float32) -> OracleParams:
 # --------------------------------------------------------------------------------------
 def nerf_encode(x: torch.Tensor, n_freq: int) -> torch.Tensor:
     """[x, sin(x_d 2^k) (d-major, k-minor), sin(x_d 2^k + pi/2)]   (fields/encodings.py:155-176)."""
-    freqs = 2.0 ** torch.linspace(0.0, n_freq - 1, n_freq, dtype=x.dtype)
+    freqs = 2.0 ** torch.linspace(0.0, n_freq - 1, n_freq, dtype=x.dtype, device=x.device)
     s = (x[..., None] * freqs).reshape(*x.shape[:-1], -1)
     return torch.cat([x, torch.sin(torch.cat([s, s + math.pi / 2.0], dim=-1))], dim=-1)
 
@@ -144,7 +144,7 @@ def sdf_forward_grad_analytic(p: OracleParams, pts: torch.Tensor, want_feat: boo
             ge_skip = g[:, n3:]
             g = g[:, :n3]
     ge = g + ge_skip  # gradient w.r.t. the (3 + 6 m)-d embedding (39-d)
-    freqs = 2.0 ** torch.linspace(0.0, m - 1.0, m, dtype=pts.dtype)
+    freqs = 2.0 ** torch.linspace(0.0, m - 1.0, m, dtype=pts.dtype, device=pts.device)
     s = (x3[..., None] * freqs)                       # [P,3,m]
     gs = ge[:, 3:3 + 3 * m].reshape(-1, 3, m)
     gc = ge[:, 3 + 3 * m:3 + 6 * m].reshape(-1, 3, m)
@@ -185,7 +185,7 @@ def sample_pdf_det(bins: torch.Tensor, weights: torch.Tensor, n: int) -> torch.T
     w = weights + 1e-5
     pdf = w / w.sum(-1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], dim=-1)
-    u = torch.linspace(0.0, 1.0, n).to(bins.dtype).expand(bins.shape[0], n).contiguous()  # fp32 linspace as in :31
+    u = torch.linspace(0.0, 1.0, n).to(device=bins.device, dtype=bins.dtype).expand(bins.shape[0], n).contiguous()  # fp32 linspace as in :31
     ind = torch.searchsorted(cdf, u, right=True)
     lo = (ind - 1).clamp(min=0)
     hi = ind.clamp(max=cdf.shape[-1] - 1)
@@ -279,7 +279,7 @@ def visibility(p: OracleParams, pls, hit, cos_anneal=1.0, offset=1e-2, t_rand=No
     dvec = hit - pls
     L = torch.linalg.norm(dvec, dim=-1, keepdim=True)
     ds = dvec / L
-    z = torch.linspace(0.0, 1.0, n_samples).to(pls.dtype)[None, :] * L * (1.0 - offset)
+    z = torch.linspace(0.0, 1.0, n_samples).to(device=pls.device, dtype=pls.dtype)[None, :] * L * (1.0 - offset)
     if t_rand is not None:  # stratified jitter in training (:388-395)
         mids = 0.5 * (z[:, 1:] + z[:, :-1])
         upper = torch.cat([mids, z[:, -1:]], -1)
@@ -343,7 +343,7 @@ def nerf_forward(nerf: Dict[str, torch.Tensor], pts4, views, pls):
 def outside_z(far, n_outside: int = 32, n_samples: int = 64, t_rand=None):
     """Sample positions of the background beyond the unit sphere (models/neus_hint_model.py:677-693): inverse-depth spacing,
     stratified jitter in training, ``far / flip(u) + 1 / n_samples``.  far [N,1] -> [N, n_outside]."""
-    u = torch.linspace(1e-3, 1.0 - 1.0 / (n_outside + 1.0), n_outside).to(far.dtype)
+    u = torch.linspace(1e-3, 1.0 - 1.0 / (n_outside + 1.0), n_outside).to(device=far.device, dtype=far.dtype)
     if t_rand is not None:
         mids = 0.5 * (u[1:] + u[:-1])
         upper, lower = torch.cat([mids, u[-1:]]), torch.cat([u[:1], mids])
@@ -355,7 +355,7 @@ def render_outside(nerf, o, d, pl, z, sample_dist: float):
     """``render_outside`` (models/neus_hint_model.py:434-473) at the sorted positions z [N,n]: inverted-sphere parameterisation
     (p / |p|, 1 / |p|) with |p| clipped to >= 1, alpha = 1 - exp(-softplus(density) dist).  -> (alpha [N,n], colour [N,n,3])."""
     n, m = z.shape
-    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=z.dtype)], dim=-1)
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=z.dtype, device=z.device)], dim=-1)
     mid = z + dists * 0.5
     pts = o[:, None, :] + d[:, None, :] * mid[..., None]
     r = torch.linalg.norm(pts, ord=2, dim=-1, keepdim=True).clip(1.0, 1e10)
@@ -368,7 +368,7 @@ def render_outside(nerf, o, d, pl, z, sample_dist: float):
 def sphere_trace(p: OracleParams, o, d, iterations: int = 2000, threshold: float = 1e-4, far: float = 100.0):
     """``NeuSHintRenderer.sphere_trace`` (models/neus_hint_model.py:359-372): from the ray origins, advance each ray by the SDF
     at its point until |sdf| < threshold or the travelled depth exceeds ``far``; -> (points [N,3], depths [N,1])."""
-    pts, depths = o, torch.zeros(o.shape[0], 1, dtype=o.dtype)
+    pts, depths = o, torch.zeros(o.shape[0], 1, dtype=o.dtype, device=o.device)
     with torch.no_grad():
         for _ in range(iterations):
             sdf = sdf_forward(p, pts, want_feat=False)[0]
@@ -417,7 +417,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
     if is_training and anneal_end > 0:
         cos_anneal = min(1.0, global_step / anneal_end)       # :669-671
     sample_dist = 2.0 / n_samples                              # :673
-    z = near + (far - near) * torch.linspace(0.0, 1.0, n_samples).to(dt)[None, :]
+    z = near + (far - near) * torch.linspace(0.0, 1.0, n_samples).to(device=near.device, dtype=dt)[None, :]
     if is_training:
         z = z + (t_rand_primary - 0.5) * 2.0 / n_samples       # :681-683
     if z_override is not None:
@@ -434,7 +434,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
         z_feed, _ = torch.sort(torch.cat([z, z_out], dim=-1), dim=-1)
         bg_alpha, bg_col = render_outside(outside_nerf, o, d, pl, z_feed, sample_dist)
     # ---- render_core ----
-    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=dt)], dim=-1)
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((n, 1), sample_dist, dtype=dt, device=z.device)], dim=-1)
     mid = z + dists * 0.5
     if sections_override is not None:
         mid, dists = sections_override[0].to(dt), sections_override[1].to(dt)
@@ -468,12 +468,12 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
             hit = o + d * depth
         vis_samples = None
         if shadow_hint and warmup:
-            vis = torch.zeros(n, 1, dtype=dt)                  # :577-579 (shadow_map = zeros)
+            vis = torch.zeros(n, 1, dtype=dt, device=o.device)                  # :577-579 (shadow_map = zeros)
         elif shadow_hint and n_shadow_importance_clip > 0:
             # partial visibility hint (:553-575): one shadow ray per group of 128 / clip samples, aimed at z_vals[:, g * ratio]
             clip = n_shadow_importance_clip
             ratio = T // clip
-            zt = z[:, torch.arange(0, T, ratio)]
+            zt = z[:, torch.arange(0, T, ratio, device=z.device)]
             tgt = (o[:, None, :] + d[:, None, :] * zt[..., None]).reshape(-1, 3)
             pls_g = pl[:, None, :].repeat(1, clip, 1).reshape(-1, 3)
             if vis_groups_override is not None:
@@ -498,7 +498,7 @@ def render_forward(p: OracleParams, o, d, pl, near, far, background_rgb=None, is
         vis_s = vis[:, None, :].expand(n, T, 1).reshape(-1, 1) if vis_samples is None else vis_samples.reshape(-1, 1)
     if specular_hint:
         with torch.enable_grad() if (specular_hint_gradient and differentiable) else torch.no_grad():   # :589
-            cue = torch.zeros(n, 4, dtype=dt) if warmup else specular_cue(hit_n, pl, hit, d, specular_roughness)   # :590-615, :617-619
+            cue = torch.zeros(n, 4, dtype=dt, device=o.device) if warmup else specular_cue(hit_n, pl, hit, d, specular_roughness)   # :590-615, :617-619
             if cue_override is not None:
                 cue = cue_override.to(dt)
         cue_s = cue[:, None, :].expand(n, T, 4).reshape(-1, 4)
