@@ -1097,3 +1097,30 @@ def test_fused_step_outside_nerf_with_hint_gradients(scene_states, prec):
     assert abs(float(named["deviation_network.variance"].grad) - v_with) < 0.1 * abs(v_with - v_without)
     with pytest.raises(NotImplementedError):
         model(tb, is_training=True, background_rgb=bg, global_step=gs)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_outside_nerf_ray_gradients_autograd_path(scene_states, prec):
+    """Pose / light refinement with the background (forward() + backward(), the path train_fused.supported sends this pair to): the
+    gradients of origins, directions and light positions against the reference's recorded float64 step (outside_b.npz: t.grad64.rays.*;
+    the far bound of a ray is a function of its origin and direction in the reference's ray generator and positions the 32 samples
+    beyond the sphere, :689-693 - here it is a constant of the bundle, as the fixture's rays are leaves)."""
+    from nrhints_amd.training import train_loss_dict
+    g = load_npz("outside_b.npz")
+    cfg = na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True))
+    state = {k: T(np.asarray(v)) for k, v in scene_states["b"].items()}
+    state.update({"outside_nerf." + k[5:]: T(v) for k, v in g.items() if k.startswith("nerf.")})
+    model = na.NeuSHintRenderer(cfg, precision=prec)
+    model.load_state_dict(state)
+    model = model.cuda().train()
+    tb = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    for t_ in (tb.origins, tb.directions, tb.pl_positions):
+        t_.requires_grad_(True)
+    o = model(tb, is_training=True, background_rgb=torch.ones(1, 3).cuda(), global_step=int(g["t.global_step"]),
+              _t_rand_primary=cu(g["t.t_rand_primary"]), _t_rand_shadow=cu(g["t.t_rand_shadow"]), _t_rand_outside=cu(g["t.t_rand_outside"]))
+    train_loss_dict(o, cu(g["t.rgb_gt"]), 0.1)["loss"].backward()
+    for nm in ("origins", "directions", "pl_positions"):
+        want64 = g[f"t.grad64.rays.{nm}"]
+        bound, scale = grad_bound(g[f"t.grad.rays.{nm}"], want64, factor=4.0, floor=5e-3)
+        err = float(np.abs(getattr(tb, nm).grad.detach().cpu().numpy().astype(np.float64) - want64).max())
+        assert err <= bound, (nm, err, bound, scale)
