@@ -28,8 +28,7 @@ Networks narrower than the compiled shape (renderer._narrow) run zero-padded; th
 Fourth session of round 6: ``use_outside_nerf`` (:434-473, :516-519, :630-637) - the background network stays behind its autograd
 Function (its kernels, csrc/nrh_outside.hip), the 160-sample composite and the loss are a torch island between the kernels
 (_outside_forward / _outside_loss / _outside_backward below).
-Restrictions (the autograd path covers the rest): GPU float32 parameters, no ray gradients together with the outside NeRF, at most
-``max_fused_train_rays`` rays per call; shadow_hint_gradient with ray gradients or with the partial visibility hint is refused on
+Restrictions (the autograd path covers the rest): GPU float32 parameters, at most ``max_fused_train_rays`` rays per call; shadow_hint_gradient with ray gradients or with the partial visibility hint is refused on
 both paths.
 """
 from __future__ import annotations
@@ -60,9 +59,6 @@ def supported(renderer, ray_bundle) -> Optional[str]:
             return "shadow_hint_gradient with the partial visibility hint (not implemented on either path)"
         if any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
             return "shadow_hint_gradient together with ray gradients (not implemented on either path)"
-    if getattr(renderer, "has_outside_nerf", False):
-        if any(torch.is_tensor(t) and t.requires_grad for t in (ray_bundle.origins, ray_bundle.directions, ray_bundle.pl_positions)):
-            return "outside-NeRF background together with ray gradients (the autograd path runs it)"
     if ray_bundle.origins.shape[0] > renderer.max_fused_train_rays:
         return "more rays than max_fused_train_rays"
     if ray_bundle.origins.shape[0] == 0:
@@ -95,6 +91,7 @@ class _Buffers:
         self.g_shadow = self.emb_shadow = None   # shadow_hint_gradient: the SDF net's weight gradients through the visibility
         self.dyn = torch.zeros(4, dtype=torch.float32, device=dev)      # {S, 1 / S, work words} of the 16-bit hand-offs (ops.sdf_train_backward)
         self.o_bar, self.d_bar, self.pl_bar = new(n, 3), new(n, 3), new(n, 3)      # ray adjoints (pose / light refinement)
+        self.far_bar = None          # ... and d loss / d far [n,1] when the outside NeRF's far bound carries a graph (train_step_backward)
         # What .grad of the 46 parameter tensors points at: views into ONE flat float32 buffer, laid out in the order of
         # renderer.parameters() (``param_layout``: name -> (offset, shape)).  The kernels that produce parameter gradients write
         # straight into it - the weight-norm adjoint (weight_v / weight_g), the weight-gradient reduction's column sums (biases),
@@ -232,7 +229,9 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         rcfg = cfg.renderer
         shadow_grad = bool(rcfg.shadow_hint_gradient and renderer.has_shadow_hint and not zero_hints)
         specular_grad = bool(rcfg.specular_hint_gradient and renderer.has_specular_hint and not zero_hints)
-        og = _outside_forward(renderer, lib, pk, o, d, pl, near, far, t_p, t_rand_outside, is_training) if renderer.has_outside_nerf else None
+        og = _outside_forward(renderer, lib, pk, o, d, pl, near, far, t_p, t_rand_outside, is_training, want_rays,
+                              ray_bundle.fars if (want_rays and torch.is_tensor(ray_bundle.fars) and ray_bundle.fars.requires_grad) else None) \
+            if renderer.has_outside_nerf else None
         res = renderer._render_train(o, d, pl, near, far, cos_anneal, t_p, t_s, zero_hints, raymisc=B.raymisc, half_handoffs=half, pts=B.pts,
                                      want_shadow=shadow_grad, extra_net=None if og is None else og["extra"])
         pre, sv = res["pre"], res["pre"]["saves"]
@@ -320,6 +319,10 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
             if hg is not None and hg.get("d_bar") is not None:       # the cue's own dependence on the view direction and the light (:590-615)
                 B.d_bar.add_(hg["d_bar"])
                 B.pl_bar.add_(hg["pl_bar"])
+            if og is not None and og.get("leaves") is not None:      # the background network's dependence on the rays (_outside_backward)
+                lv = og["leaves"]
+                B.o_bar.add_(lv["o"].grad); B.d_bar.add_(lv["d"].grad); B.pl_bar.add_(lv["pl"].grad)
+                B.far_bar = lv["far"].grad if lv["far"] is not None else None
         if not want_params:
             # frozen renderer (register_view, pipelines/base_pipeline.py:71-91: only the ray generator's deltas step): the reference
             # computes and discards all 46 parameter gradients there; the results are the same without them
@@ -385,7 +388,7 @@ def train_step_backward(renderer, ray_bundle, rgb_gt: torch.Tensor, background_r
         return _finish_rays(B, ray_bundle, want_rays, ray_grads)
 
 
-def _outside_forward(renderer, lib, pk, o, d, pl, near, far, t_p, t_rand_outside, is_training: bool) -> dict:
+def _outside_forward(renderer, lib, pk, o, d, pl, near, far, t_p, t_rand_outside, is_training: bool, want_rays: bool = False, far_g=None) -> dict:
     """renderer.use_outside_nerf on the fused step, part 1 (models/neus_hint_model.py:677-724, :434-473): where the primary ray's
     samples are (nrh_sample_primary), the 32 positions beyond the sphere, and the background network at the merged 160 positions
     (outside.render_outside: csrc/nrh_outside.hip behind its autograd Function, whose graph - background parameters -> alpha,
@@ -406,12 +409,21 @@ def _outside_forward(renderer, lib, pk, o, d, pl, near, far, t_p, t_rand_outside
     if is_training:
         t_o = torch.rand(n, outside.N_OUTSIDE, device=dev) if t_rand_outside is None else t_rand_outside.detach().to(dev, torch.float32)
     renderer.outside_nerf.precision = renderer.precision
+    # pose / light refinement: the background sees the rays through its sample points (o + d mid), its view / light inputs and - the
+    # ray generator's far bound positions the 32 samples beyond the sphere, :689-693 - through ``far``; leaves of the island
+    leaves = None
+    if want_rays:
+        leaves = dict(o=o.detach().clone().requires_grad_(True), d=d.detach().clone().requires_grad_(True), pl=pl.detach().clone().requires_grad_(True),
+                      far=(far.detach().reshape(-1, 1).clone().requires_grad_(True) if far_g is not None else None))
     with torch.enable_grad():
-        z_out = outside.outside_z(far.reshape(-1, 1), rc.n_samples, t_o)
+        lo, ld_, lpl = (leaves["o"], leaves["d"], leaves["pl"]) if leaves else (o, d, pl)
+        lfar = leaves["far"] if (leaves and leaves["far"] is not None) else far.reshape(-1, 1)
+        z_out = outside.outside_z(lfar, rc.n_samples, t_o)
         z_feed, _ = torch.sort(torch.cat([z, z_out], dim=-1), dim=-1)
-        bg_alpha, bg_col = outside.render_outside(renderer.outside_nerf, o, d, pl, z_feed, 2.0 / rc.n_samples)
+        bg_alpha, bg_col = outside.render_outside(renderer.outside_nerf, lo, ld_, lpl, z_feed, 2.0 / rc.n_samples)
     bg_a, tail_t = bg_alpha.detach().contiguous(), new(n)
-    return dict(bg_alpha=bg_alpha, bg_col=bg_col, bg_a=bg_a, tail_t=tail_t, extra=dict(bg_alpha=bg_a, tail_t=tail_t, sampled_color=None))
+    return dict(bg_alpha=bg_alpha, bg_col=bg_col, bg_a=bg_a, tail_t=tail_t, leaves=leaves,
+                extra=dict(bg_alpha=bg_a, tail_t=tail_t, sampled_color=None))
 
 
 def _outside_loss(og: dict, B, res, gt, bgc, igr: float, n: int, inv_s: float, dyn) -> None:
@@ -457,13 +469,14 @@ def _outside_backward(renderer, og: dict, lib, B, pre, res, d, inv_s: float, cos
                                             inv_s, cos_anneal, P_(dyn), n, P_(B.wbar), P_(nb), P_(og["tbar"]), P_(B.sdf_bar), P_(B.grad_bar),
                                             P_(B.rd_bar), P_(B.invs_bar), P_(bg128), stream), "nrh_alpha_blend_backward")
     B.grad_bar.add_(og["gn"])
-    if og["bg_alpha"].requires_grad:
+    if og["bg_alpha"].requires_grad:          # background parameters and / or ray leaves upstream
         gba = og["gba"].clone()
         gba[:, :128] += bg128
         for name, prm in renderer.outside_nerf.named_parameters():
-            v = B.pgrad["outside_nerf." + name]
-            v.zero_()
-            prm.grad = v          # AccumulateGrad adds in place: the gradient lands in the flat buffer's view
+            if prm.requires_grad:
+                v = B.pgrad["outside_nerf." + name]
+                v.zero_()
+                prm.grad = v      # AccumulateGrad adds in place: the gradient lands in the flat buffer's view
         with torch.enable_grad():
             torch.autograd.backward([og["bg_alpha"], og["bg_col"]], [gba, og["gbc"]])
 
@@ -568,8 +581,13 @@ def _finish_rays(B, ray_bundle, want_rays: bool, ray_grads) -> torch.Tensor:
     if want_rays:
         pairs = [(t, g) for t, g in ((ray_bundle.origins, B.o_bar), (ray_bundle.directions, B.d_bar), (ray_bundle.pl_positions, B.pl_bar))
                  if torch.is_tensor(t) and t.requires_grad]
+        far_bar = getattr(B, "far_bar", None)       # outside NeRF: the far bound positions the samples beyond the sphere
+        if far_bar is not None and torch.is_tensor(ray_bundle.fars) and ray_bundle.fars.requires_grad:
+            pairs.append((ray_bundle.fars, far_bar))
         if ray_grads is not None:
             ray_grads.update(origins=B.o_bar, directions=B.d_bar, pl_positions=B.pl_bar)
+            if far_bar is not None:
+                ray_grads["fars"] = far_bar
         elif pairs:
             torch.autograd.backward([t for t, _ in pairs], [g.to(t.dtype).reshape(t.shape) for t, g in pairs])
     return B.loss8

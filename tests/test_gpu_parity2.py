@@ -1043,10 +1043,36 @@ def test_fused_step_outside_nerf(scene_states, prec):
     for (name, pa), (_, pf) in zip(ref.named_parameters(), fused.named_parameters()):
         scale = float(pa.grad.abs().max()) + 1e-30
         assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, name
-    # ray gradients with the background: the autograd path's job
+    # pose / light refinement with the background on the fused step: the background network's own dependence on the rays (sample
+    # points, view and light inputs) joins nrh_ray_adjoint's; against the reference's recorded float64 ray gradients
     rb2 = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
-    rb2.origins.requires_grad_(True)
-    assert "outside" in train_fused.supported(fused, rb2)
+    for t_ in (rb2.origins, rb2.directions, rb2.pl_positions):
+        t_.requires_grad_(True)
+    assert train_fused.supported(fused, rb2) is None
+    rg = {}
+    train_fused.train_step_backward(fused, rb2, gt, bg, gs, t_rand_primary=tp, t_rand_shadow=ts, t_rand_outside=to, ray_grads=rg)
+    for nm in ("origins", "directions", "pl_positions"):
+        want64 = g[f"t.grad64.rays.{nm}"]
+        bound, scale = grad_bound(g[f"t.grad.rays.{nm}"], want64, factor=4.0, floor=5e-3)
+        err = float(np.abs(rg[nm].detach().cpu().numpy().astype(np.float64) - want64).max())
+        assert err <= bound, (nm, err, bound, scale)
+    # ... and pushed into the graph behind the bundle when no dict is given (here: leaves), the far bound included
+    rb3 = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    for t_ in (rb3.origins, rb3.directions, rb3.pl_positions, rb3.fars):
+        t_.requires_grad_(True)
+    train_fused.train_step_backward(fused, rb3, gt, bg, gs, t_rand_primary=tp, t_rand_shadow=ts, t_rand_outside=to)
+    assert float((rb3.origins.grad - rg["origins"]).abs().max()) < 1e-6 * float(rg["origins"].abs().max()) + 1e-9
+    assert rb3.fars.grad is not None and rb3.fars.grad.shape == rb3.fars.shape and float(rb3.fars.grad.abs().max()) > 0.0
+    # d loss / d far: against the autograd path, where the far bound keeps its graph through outside_z (:689-693)
+    rb4 = _bundle(*(g["t." + k] for k in ("o", "d", "pl", "near", "far")))
+    for t_ in (rb4.origins, rb4.directions, rb4.pl_positions, rb4.fars):
+        t_.requires_grad_(True)
+    ref2 = build()
+    o4 = ref2(rb4, is_training=True, background_rgb=bg, global_step=gs, _t_rand_primary=tp, _t_rand_shadow=ts, _t_rand_outside=to)
+    train_loss_dict(o4, gt, 0.1)["loss"].backward()
+    for a_, b_ in ((rb3.fars.grad, rb4.fars.grad), (rb3.origins.grad, rb4.origins.grad), (rb3.directions.grad, rb4.directions.grad),
+                   (rb3.pl_positions.grad, rb4.pl_positions.grad)):
+        assert float((a_ - b_).abs().max()) < 2e-4 * float(b_.abs().max()) + 1e-8, (float((a_ - b_).abs().max()), float(b_.abs().max()))
     # captured
     cap = build()
     n = tb.origins.shape[0]
