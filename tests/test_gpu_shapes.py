@@ -143,3 +143,40 @@ def test_narrow_network_trains_under_a_captured_step():
             ev, ev_e = graphed(_bundle(g), background_rgb=bg).rgb, eager(_bundle(g), background_rgb=bg).rgb
         assert float((ev - ev_e).abs().max()) < 2e-6, i
     step.release()
+
+
+def test_narrow_network_with_outside_nerf_fused_equals_autograd():
+    """The two round-6 additions together: a narrow network (zero-padded) with the outside-NeRF background - fused step (padding
+    adjoint + background island) against forward() + backward() on the same batch and jitter, all 70 gradient tensors."""
+    from nrhints_amd import train_fused
+    from nrhints_amd.training import train_loss_dict
+    g = load_npz("render_shapes.npz")
+    s_, c_, _ = sv.VARIANTS["n128"]
+    cfg = na.NeuSModelConfig(sdf_network=na.SDFNetConfig(**s_), reflectance_network=na.ReflectanceNetConfig(**c_),
+                             renderer=na.NeuSRendererConfig(use_outside_nerf=True))
+    torch.manual_seed(3)
+    proto = na.NeuSHintRenderer(cfg, precision="f16x3")
+    sd = proto.state_dict()
+    sd.update({k: T(np.asarray(v)) for k, v in sv.state("n128", g).items()})
+    sd["outside_nerf.alpha_linear.bias"] = sd["outside_nerf.alpha_linear.bias"] + 1.5          # a visible background
+    bg, gt, gs = torch.ones(1, 3).cuda(), cu(g["t.rgb_gt"]), int(g["t.global_step"])
+    rs = np.random.RandomState(4)
+    tp, ts, to = (cu(rs.rand(32, k).astype(np.float32)) for k in (1, 64, 32))
+
+    def build():
+        m = na.NeuSHintRenderer(cfg, precision="f16x3")
+        m.load_state_dict(sd)
+        return m.cuda().train()
+
+    ref, fused = build(), build()
+    assert ref._narrow and ref.has_outside_nerf
+    out = ref(_bundle(g, "t."), is_training=True, background_rgb=bg, global_step=gs, _t_rand_primary=tp, _t_rand_shadow=ts, _t_rand_outside=to)
+    assert out.weights.shape == (32, 160) and float(out.weights[:, 128:].sum(-1).mean()) > 0.01
+    ld = train_loss_dict(out, gt, 0.1)
+    ld["loss"].backward()
+    l8 = train_fused.train_step_backward(fused, _bundle(g, "t."), gt, bg, gs, t_rand_primary=tp, t_rand_shadow=ts, t_rand_outside=to)
+    np.testing.assert_allclose(float(l8[0]), float(ld["loss"].detach()), rtol=2e-5)
+    for (name, pa), (_, pf) in zip(ref.named_parameters(), fused.named_parameters()):
+        assert pf.grad is not None and pf.grad.shape == pa.shape, name
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, (name, float((pa.grad - pf.grad).abs().max()), scale)
