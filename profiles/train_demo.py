@@ -3,7 +3,10 @@
 from a teacher scene (synthetic scene b: perturbed geometry, sharper variance) with the reference's loss / Adam / schedule,
 and PSNR is tracked on a held-out 128x128 view.  Prints one JSON line per evaluation and a final summary line.
 
-    python profiles/train_demo.py [steps=1500] [batch=1024] [late_eval_every=0] [seed=0]
+    python profiles/train_demo.py [steps=1500] [batch=1024] [late_eval_every=0] [seed=0] [student=default|narrow]
+
+student = narrow: the student is a NARROWER network than the kernels are compiled for (sdf 128 / multi_res 4 / feature 128,
+reflectance 128 / multi_res 2: zero-padded onto the compiled kernels, packing.pad_to_compiled) fitted to the same full-size teacher.
 
 late_eval_every > 0: from step steps - 500 on, the held-out view is also evaluated every that many steps, and the summary carries the
 MEAN of those PSNRs and of the last 200 training losses - single evaluations of this fit swing by 3-4 dB from one to the next (in
@@ -24,10 +27,14 @@ def main():
     late = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0            # another stream of training rays and jitter (same scene, same view)
     late_psnr, losses = [], []
+    narrow = len(sys.argv) > 5 and sys.argv[5] == "narrow"
     torch.manual_seed(0)
-    student = na.NeuSHintRenderer().cuda()
     teacher = na.NeuSHintRenderer()
-    st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in student.state_dict().items()})
+    st = perturb_state({k: v.detach().cpu().numpy().copy() for k, v in teacher.state_dict().items()})
+    torch.manual_seed(0)
+    student = na.NeuSHintRenderer(na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=128, multi_res=4, d_out_feat=128),
+                                                     reflectance_network=na.ReflectanceNetConfig(d_hidden=128, multi_res=2))
+                                  if narrow else None).cuda()
     teacher.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()})
     teacher = teacher.cuda().eval()
     bg = torch.ones(1, 3, device="cuda")
