@@ -689,3 +689,51 @@ def test_narrow_networks_zero_padded_to_the_compiled_shape_are_exact(vt):
     dd = packing.dense_params({k: v for k, v in full.state_dict().items()})
     assert not full._narrow and all(full._to_compiled(dd)[k] is dd[k] for k in dd)
     assert mv <= 4
+
+
+def test_zero_padding_is_exact_for_random_narrow_shapes():
+    """packing.pad_to_compiled over a sweep of admissible shapes (config.unsupported_reason's bounds, all four hint layouts): fresh
+    constructor states, float64, SDF value / feature / analytic gradient and reflectance colour of the restatement on the narrow and
+    on the padded matrices agree to round-off - including the extremes (widest skip layer 217 rows, one encoding frequency, a
+    one-channel feature vector, a reflectance net of width 1)."""
+    import oracle.neus_oracle as orc
+    from nrhints_amd import packing
+    rs = np.random.RandomState(11)
+    shapes = [(256, 6, 256, 256, 4), (244, 4, 1, 1, 1), (226, 1, 7, 33, 3), (64, 6, 64, 64, 1), (40, 6, 256, 256, 4), (10, 1, 3, 5, 2)]
+    shapes += [(int(m * 6 + 4 + rs.randint(0, 200)), int(m), int(rs.randint(1, 257)), int(rs.randint(1, 257)), int(rs.randint(1, 5)))
+               for m in rs.randint(1, 7, size=6)]
+    hint_layouts = [(True, True), (True, False), (False, True), (False, False)]
+    done = 0
+    for i, (h, m, f, ch, mv) in enumerate(shapes):
+        h = min(h, 256, 217 + 3 + 6 * m)
+        sh, sp = hint_layouts[i % 4]
+        cfg = na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=h, multi_res=m, d_out_feat=f),
+                                 reflectance_network=na.ReflectanceNetConfig(d_hidden=ch, multi_res=mv),
+                                 renderer=na.NeuSRendererConfig(shadow_hint=sh, specular_hint=sp))
+        assert na.unsupported_reason(cfg) is None, (h, m, f, ch, mv, na.unsupported_reason(cfg))
+        torch.manual_seed(100 + i)
+        model = na.NeuSHintRenderer(cfg)
+        st = {k: (v.double() + 0.01 * torch.randn_like(v.double())) for k, v in model.state_dict().items()}      # no exact zeros left by the geometric init
+        d = packing.dense_params(st)
+        dp = model._to_compiled(d)
+        packing.check_default_shapes(dp, hints=sh or sp)
+
+        def params(dd):
+            return orc.OracleParams([dd[f"sdf_w{l}"] for l in range(8)], [dd[f"sdf_b{l}"] for l in range(8)], dd["sdf_head_w"], dd["sdf_head_b"],
+                                    dd["feat_w"], dd["feat_b"], [dd[f"col_w{l}"] for l in range(5)], [dd[f"col_b{l}"] for l in range(5)],
+                                    st["deviation_network.variance"])
+
+        pts = torch.from_numpy(rs.uniform(-0.7, 0.7, (64, 3)))
+        sdf_n, feat_n, grad_n = orc.sdf_forward_grad_analytic(params(d), pts)
+        sdf_p, feat_p, grad_p = orc.sdf_forward_grad_analytic(params(dp), pts)
+        assert float((sdf_n - sdf_p).abs().max()) < 1e-12 and float((grad_n - grad_p).abs().max()) < 1e-10, (h, m, f)
+        assert float((feat_n - feat_p[:, :f]).abs().max()) < 1e-12 and float(feat_p[:, f:].abs().sum()) == 0.0
+        unit = lambda a: torch.from_numpy(a / np.linalg.norm(a, axis=-1, keepdims=True))
+        view, pls, nrm = unit(rs.randn(64, 3)), torch.from_numpy(rs.randn(64, 3) * 3.0), unit(rs.randn(64, 3))
+        vis, cue = torch.from_numpy(rs.uniform(0, 1, (64, 1))), torch.from_numpy(rs.uniform(0, 2, (64, 4)))
+        col_n = orc.color_forward(params(d), pts, nrm, view, feat_n, pls, vis if sh else None, cue if sp else None)
+        # the compiled layout: both hints' columns when the model has any hint (the absent one's are zero), none for pl-naive
+        col_p = orc.color_forward(params(dp), pts, nrm, view, feat_p, pls, vis if (sh or sp) else None, cue if (sh or sp) else None)
+        assert float((col_n - col_p).abs().max()) < 1e-12, (h, m, f, ch, mv, sh, sp)
+        done += 1
+    assert done == 12
