@@ -180,3 +180,54 @@ def test_narrow_network_with_outside_nerf_fused_equals_autograd():
         assert pf.grad is not None and pf.grad.shape == pa.shape, name
         scale = float(pa.grad.abs().max()) + 1e-30
         assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, (name, float((pa.grad - pf.grad).abs().max()), scale)
+
+
+@pytest.mark.parametrize("layout", ["naive", "specular_only"])
+def test_narrow_network_other_hint_layouts(layout):
+    """A narrow network without hints (pl-naive: the 316-column compiled input) and with the specular hint only (its 36 columns at
+    the compiled offsets, the visibility's zero): evaluation against the float64 restatement (tests/test_oracle_golden.py pins it for
+    narrow shapes and for these layouts), and fused step == forward() + backward()."""
+    import oracle.neus_oracle as orc
+    from nrhints_amd import train_fused
+    from nrhints_amd.synthetic import make_rays, perturb_state
+    from nrhints_amd.training import train_loss_dict
+    sh, sp = {"naive": (False, False), "specular_only": (False, True)}[layout]
+    cfg = na.NeuSModelConfig(sdf_network=na.SDFNetConfig(d_hidden=96, multi_res=3, d_out_feat=48),
+                             reflectance_network=na.ReflectanceNetConfig(d_hidden=80, multi_res=2),
+                             renderer=na.NeuSRendererConfig(shadow_hint=sh, specular_hint=sp))
+    torch.manual_seed(0)
+    st = perturb_state({k: v.detach().numpy().copy() for k, v in na.NeuSHintRenderer(cfg).state_dict().items()}, pe_cols=18)
+
+    def build():
+        m = na.NeuSHintRenderer(cfg, precision="f16x3")
+        m.load_state_dict({k: T(np.asarray(v)) for k, v in st.items()})
+        return m.cuda()
+
+    rays = make_rays(64, seed=37, spread=0.12)
+    rb = na.RayBundle(**{k: cu(v) for k, v in zip(("origins", "directions", "pl_positions", "nears", "fars"), rays)})
+    model = build().eval()
+    assert model._narrow
+    with torch.no_grad():
+        out = model(rb, background_rgb=torch.ones(1, 3).cuda())
+    p64 = orc.params_from_state(st, dtype=torch.float64)
+    want = orc.render_forward(p64, *(T(a).double() for a in rays), background_rgb=torch.ones(1, 3, dtype=torch.float64), mode="minimal",
+                              shadow_hint=sh, specular_hint=sp, hints=sh or sp)
+    err = np.abs(out.rgb.cpu().numpy() - want["rgb"].numpy())
+    assert err.mean() < 5e-6 and err.max() < 3e-4, (layout, err.mean(), err.max())
+    assert out.visibilities is None and (out.specular_cue is None) == (not sp)
+    # training: fused == autograd on the same batch and jitter
+    trays = make_rays(32, seed=31, spread=0.1)
+    tb = lambda: na.RayBundle(**{k: cu(v) for k, v in zip(("origins", "directions", "pl_positions", "nears", "fars"), trays)})
+    gt, bg = torch.full((32, 3), 0.5).cuda(), torch.ones(1, 3).cuda()
+    rs = np.random.RandomState(2)
+    tp, ts = cu(rs.rand(32, 1).astype(np.float32)), cu(rs.rand(32, 64).astype(np.float32))
+    ref, fused = build().train(), build().train()
+    o = ref(tb(), is_training=True, background_rgb=bg, global_step=20000, _t_rand_primary=tp, _t_rand_shadow=ts if sh else None)
+    ld = train_loss_dict(o, gt, 0.1)
+    ld["loss"].backward()
+    l8 = train_fused.train_step_backward(fused, tb(), gt, bg, 20000, t_rand_primary=tp, t_rand_shadow=ts if sh else None)
+    np.testing.assert_allclose(float(l8[0]), float(ld["loss"].detach()), rtol=5e-6)
+    for (name, pa), (_, pf) in zip(ref.named_parameters(), fused.named_parameters()):
+        assert pf.grad.shape == pa.shape
+        scale = float(pa.grad.abs().max()) + 1e-30
+        assert float((pa.grad - pf.grad).abs().max()) < 1e-4 * scale + 5e-6, (layout, name)
