@@ -1150,3 +1150,43 @@ def test_outside_nerf_ray_gradients_autograd_path(scene_states, prec):
         bound, scale = grad_bound(g[f"t.grad.rays.{nm}"], want64, factor=4.0, floor=5e-3)
         err = float(np.abs(getattr(tb, nm).grad.detach().cpu().numpy().astype(np.float64) - want64).max())
         assert err <= bound, (nm, err, bound, scale)
+
+
+def test_fused_register_view_step_with_outside_nerf(scene_states):
+    """The step register_view takes (pipelines/base_pipeline.py:80-91: evaluation-mode forward, L1 / (N + 1e-5), renderer frozen, only
+    the rays' gradients) on a model with the outside-NeRF background: fused against forward() + backward() on the same rays, the
+    far bound's gradient included; no parameter of the renderer or of the background network receives a gradient."""
+    from nrhints_amd import train_fused
+    g = load_npz("outside_b.npz")
+    cfg = na.NeuSModelConfig(renderer=na.NeuSRendererConfig(use_outside_nerf=True))
+    state = {k: T(np.asarray(v)) for k, v in scene_states["b"].items()}
+    state.update({"outside_nerf." + k[5:]: T(v) for k, v in g.items() if k.startswith("nerf.")})
+    model = na.NeuSHintRenderer(cfg)
+    model.load_state_dict(state)
+    model = model.cuda().eval()
+    bg = torch.ones(1, 3).cuda()
+    n = 64
+    gt = cu(np.random.RandomState(9).rand(n, 3).astype(np.float32))
+
+    def rays():
+        rb = _bundle(*(g[k] for k in ("o", "d", "pl", "near", "far")))
+        for t_ in (rb.origins, rb.directions, rb.pl_positions, rb.fars):
+            t_.requires_grad_(True)
+        return rb
+
+    rb = rays()
+    out = model(rb, background_rgb=bg, is_training=False)
+    loss = torch.nn.functional.l1_loss(out.rgb, gt, reduction="sum") / (n + 1e-5)
+    loss.backward()
+    want = dict(origins=rb.origins.grad.clone(), directions=rb.directions.grad.clone(), pl_positions=rb.pl_positions.grad.clone(), fars=rb.fars.grad.clone())
+    model.zero_grad(set_to_none=True)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    rb2, grads = rays(), {}
+    assert train_fused.supported(model, rb2) is None
+    loss8 = train_fused.train_step_backward(model, rb2, gt, bg, 0, igr_weight=0.0, is_training=False, ray_grads=grads)
+    np.testing.assert_allclose(float(loss8[0]), float(loss.detach()), rtol=1e-5)
+    for nm, w in want.items():
+        scale = float(w.abs().max()) + 1e-30
+        assert float((grads[nm].reshape(w.shape) - w).abs().max()) < 2e-4 * scale + 1e-7, (nm, float((grads[nm].reshape(w.shape) - w).abs().max()), scale)
+    assert all(p.grad is None for p in model.parameters())
